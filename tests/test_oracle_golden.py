@@ -1,0 +1,168 @@
+"""Pins the CPU oracle (oracle/fw_oracle.c) against every golden vector / known-answer test the
+reference holds for the hot path:
+  test/data/tests_expected.tsv, test/contingency.jl:5-24,55-83, test/statfuns.jl:24-71,
+  test/data/learning_expected/*.edgelist.
+CPU only."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import GOLDEN, load_norm, read_edgelist, read_tests_expected, rel
+
+EXP = read_tests_expected()
+
+
+@pytest.fixture(scope="module")
+def mats():
+    return dict(mi=load_norm("pres_abs", np.int64), mi_nz=load_norm("clr_nonzero_binned", np.int64),
+                fz=load_norm("clr_adapt", np.float64))
+
+
+# ---- test/tests.jl:41-74 ------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["mi", "mi_nz"])
+@pytest.mark.parametrize("sparse", [False, True])
+def test_discrete_tests_expected(mats, kind, sparse):
+    o = O.Oracle(kind, mats[kind], sparse=sparse, max_k=3)
+    for Y in range(1, 50):  # FlashWeave.test(1, collect(2:50), data, test_name)
+        s, p, df, pw = o.test(0, Y, (), hps=5, n_obs_min=0)
+        es, ep, edf, epw = EXP["exp_uni_" + kind][Y - 1]
+        assert (df, pw) == (edf, epw)
+        assert rel(s, es) < 1e-12 and rel(p, ep) < 1e-12
+    for key, Zs in (("condZ1", (6,)), ("condZ3", (6, 13, 17))):  # test(31, 21, (7,)/(7,14,18), ...)
+        s, p, df, pw = o.test(30, 20, Zs, hps=5)
+        es, ep, edf, epw = EXP["exp_%s_%s" % (key, kind)][0]
+        assert (df, pw) == (edf, epw)
+        assert rel(s, es) < 1e-12 and rel(p, ep) < 1e-12
+
+
+def test_fz_tests_expected(mats):
+    # inputs are the Float32-printed fixture clr_adapt.tsv -> tolerance is fixture precision; the
+    # conditional rows only match with len_z = 0 and carry pcor_rec's 5-digit rounding.
+    clr = mats["fz"]
+    o = O.Oracle("fz", cor_mat=O.cor(clr, "f64"), n_obs=clr.shape[0])
+    for Y in range(1, 50):
+        s, p, df, pw = o.test(0, Y, (), n_obs_min=0)
+        es, ep, edf, epw = EXP["exp_uni_fz"][Y - 1]
+        assert (df, pw) == (edf, epw)
+        assert rel(s, es) < 2e-5 and rel(p, ep) < 2e-5
+    for key, Zs in (("condZ1", (6,)), ("condZ3", (6, 13, 17))):
+        s, p, df, pw = o.test(30, 20, Zs)
+        es, ep, edf, epw = EXP["exp_%s_fz" % key][0]
+        assert (df, pw) == (edf, epw)
+        assert abs(s - es) < 1e-4 and rel(p, ep) < 1e-3
+
+
+# ---- test/contingency.jl ---------------------------------------------------------------------
+VEC = np.array([[0, 0, 0, 0, 1, 1, 1, 1, 0, 1, 0, 1],
+                [0, 0, 1, 1, 1, 1, 0, 0, 0, 1, 0, 1],
+                [0, 0, 1, 1, 1, 1, 0, 0, 0, 1, 0, 2],
+                [0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1]]).T
+
+
+def _strata_multiset(t):
+    return sorted(tuple(t[:2, :2, k].ravel()) for k in range(t.shape[2]) if t[:, :, k].sum() > 0)
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_contingency_known_answers(sparse):
+    o = O.Oracle("mi", VEC, sparse=sparse, max_k=2)
+    t12, _ = o.contingency_table(0, 1)
+    assert (t12[:2, :2, 0] == np.array([[4, 2], [2, 4]])).all()
+    t23, _ = o.contingency_table(1, 2)
+    assert (t23[:2, :3, 0] == np.array([[6, 0, 0], [0, 5, 1]])).all()
+    c12_3 = np.zeros((2, 2, 3), int)
+    c12_3[0, 0, 0], c12_3[1, 0, 0], c12_3[0, 1, 1], c12_3[1, 1, 1], c12_3[1, 1, 2] = 4, 2, 2, 3, 1
+    t, lz = o.contingency_table(0, 1, (2,), nslots=9)
+    assert lz == 3 and _strata_multiset(t) == _strata_multiset(c12_3)
+    c12_34 = np.zeros((2, 2, 6), int)
+    c12_34[0, 0, 0] = 2
+    c12_34[0, 1, 1], c12_34[1, 1, 1] = 2, 2
+    c12_34[0, 0, 2], c12_34[1, 0, 2] = 2, 2
+    c12_34[1, 1, 3] = 1
+    c12_34[1, 1, 4] = 1
+    t, lz = o.contingency_table(0, 1, (2, 3), nslots=9)
+    assert lz == 5 and _strata_multiset(t) == _strata_multiset(c12_34)
+
+
+def test_sparse_backend_all_zero_y_terminates():
+    # test/contingency.jl:71-83: must not hang when Y is all-zero under Nz
+    v = np.concatenate([np.ones(25, int), np.full(25, 2)])
+    A = np.stack([v, np.zeros(50, int), v], axis=1)
+    o = O.Oracle("mi_nz", A, sparse=True, max_k=1)
+    o.test(0, 1, (2,), hps=5)
+
+
+# ---- test/statfuns.jl ------------------------------------------------------------------------
+def test_statfuns_known_answers(mats):
+    assert rel(O.fz_pval(-0.16393307352649356, 351, 1), 0.0020593283914246987) < 1e-6
+    assert rel(O.fz_pval(-0.07643814205965811, 351, 3), 0.1548665431407692) < 1e-6
+    assert rel(abs(O.mutual_information([[4, 2], [2, 4]])), 0.05663301226513242) < 1e-12
+    c12_3 = np.zeros((2, 2, 3), int)
+    c12_3[0, 0, 0], c12_3[1, 0, 0], c12_3[0, 1, 1], c12_3[1, 1, 1], c12_3[1, 1, 2] = 4, 2, 2, 3, 1
+    assert abs(O.mutual_information(c12_3)) < 1e-15
+    assert rel(O.mi_pval(0.05663301226513242, 1, 351), 2.8770005665168745e-10) < 1e-6
+    # pcor_rec vs the non-recursive values, atol 1e-4 (test/statfuns.jl:24-37), Float64 cor_mat
+    clr = mats["fz"]
+    o = O.Oracle("fz", cor_mat=O.cor(clr, "f64"), n_obs=clr.shape[0])
+    assert abs(o.pcor_rec(0, 15, (40,)) - (-0.16393307352649356)) < 1e-4
+    assert abs(o.pcor_rec(30, 20, (6, 13, 17)) - (-0.07643814205965811)) < 1e-4
+
+
+def test_benjamini_hochberg_known_answer():
+    pv = [0.0, 1.0, 0.973774, 0.722245, 0.805758, 0.713164, 0.314595, 0.947966, 0.001, 0.0339692]
+    fdr = np.array([0.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.786488, 1.0, 0.005, 0.113231])
+    got = O.benjamini_hochberg(pv)
+    sig = got < 0.01
+    assert (sig == (fdr < 0.01)).all()
+    assert np.allclose(got[sig], fdr[sig], rtol=1e-6)
+
+
+def test_chisq_ccdf_against_scipy():
+    from scipy.stats import chi2
+    rng = np.random.default_rng(1)
+    for df in (1, 2, 3, 4, 5, 8, 13, 27, 54):
+        for g in np.concatenate([rng.uniform(0, 5, 20), rng.uniform(5, 400, 20), [0.0, 1e-8, 1500.0]]):
+            a, b = O.lib().fwo_chisq_ccdf(df, float(g)), chi2.sf(g, df)
+            assert rel(a, b) < 5e-13, (df, g, a, b)
+
+
+# ---- test/learning.jl:176-237 golden networks -------------------------------------------------
+@pytest.mark.parametrize("kind,max_k,wtol", [("mi", 0, 1e-14), ("mi", 3, 1e-14), ("mi_nz", 0, 1e-14),
+                                             ("mi_nz", 3, 1e-14), ("fz", 0, 1e-7), ("fz", 3, 2e-7)])
+def test_golden_networks(mats, kind, max_k, wtol):
+    exp = read_edgelist("%s/learning_expected/exp_%s_maxk%d.edgelist" % (GOLDEN, kind, max_k))
+    if kind == "fz":
+        o = O.Oracle("fz", cor_mat=O.cor(mats["fz"], "f32"), n_obs=mats["fz"].shape[0])
+    else:
+        o = O.Oracle(kind, mats[kind], sparse=True, max_k=max_k)
+    r = o.learn(max_k=max_k, feed_forward=True, round_size=1)  # deterministic single_il schedule
+    got = r["edges"]
+    assert set(got) == set(exp)
+    for e in exp:
+        assert abs(got[e] - exp[e]) <= wtol
+    assert r["n_level0_tests"] == 50 * 49 // 2
+
+
+def test_mi_maxk3_single_mode_within_reference_tolerance(mats):
+    # parallel="single" (no feed-forward) is granted approx_nbr_diff = 22 by test/learning.jl:210-212
+    exp = read_edgelist("%s/learning_expected/exp_mi_maxk3.edgelist" % GOLDEN)
+    o = O.Oracle("mi", mats["mi"], sparse=True, max_k=3)
+    got = o.learn(max_k=3, feed_forward=False)["edges"]
+    diff = set(got) ^ set(exp)
+    assert 2 * len(diff) <= 22
+
+
+def test_dense_equals_sparse_mi_nz_low_k(mats):
+    # property borrowed from test/learning.jl:369-383 (dense == sparse for mi_nz at max_k 0/1 with some
+    # binary variables); the oracle dense path omits the row views of hiton.jl:41-50, which the
+    # nz-adjusted sub-table makes redundant for k <= 1
+    A = mats["mi_nz"].copy()
+    A[:, -6:] = (A[:, -6:] == 0).astype(A.dtype)
+    for mk in (0, 1):
+        od = O.Oracle("mi_nz", A, sparse=False, max_k=mk)
+        os_ = O.Oracle("mi_nz", A, sparse=True, max_k=mk)
+        a = od.learn(max_k=mk, feed_forward=True, round_size=1)["edges"]
+        b = os_.learn(max_k=mk, feed_forward=True, round_size=1)["edges"]
+        assert set(a) == set(b)
+        for e in a:
+            assert abs(a[e] - b[e]) < 1e-12
