@@ -1,0 +1,170 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X-native FlashWeave CI-test engine.
+
+Metric (BASELINE.json): CI tests/sec + time-to-network on synthetic 10k OTUs x 2k samples, FlashWeave-S
+(Fisher-z), max_k = 3 ("cfg3", fwsynth-v1).  One STEP = one full pass of the hot path over
+that input with the normalised matrix already resident in HBM: level-0 Pearson matrix (MFMA) + all-pairs tests +
+BH, then the conditional HITON-PC stage (level-synchronous test_subsets batches) up to the edge list on the host.
+CI tests counted = p(p-1)/2 level-0 tests + the reference-equivalent number of conditional tests (the count the
+sequential reference order would execute; identical to the CPU oracle's by construction).
+
+    python bench.py --gpus N --steps K --warmup W
+N > 1: launched by torch.distributed.run, one rank per GPU; targets of every feed-forward round are dealt
+round-robin over ranks and the per-round neighbour sets are all-gathered over RCCL.  Total work is fixed -> "strong".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def make_input(cfg, args):
+    from flashweave_jl_amd import preprocess as pre
+    from flashweave_jl_amd import synth
+    c = dict(synth.CONFIGS[cfg])
+    if args.p:
+        c["p"] = args.p
+    if args.n:
+        c["n"] = args.n
+    counts = synth.generate(c["p"], c["n"], c["seed"], mode=c["mode"])
+    data, _, _ = pre.normalize(counts, c["test_name"], prec=32)
+    return c, synth.checksum(counts), data
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--p", type=int, default=0, help="override #OTUs (debug)")
+    ap.add_argument("--n", type=int, default=0, help="override #samples (debug)")
+    ap.add_argument("--feed-forward", type=int, default=0)
+    ap.add_argument("--round-size", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    import flashweave_jl_amd as fw
+    from flashweave_jl_amd.dist import make_allgather
+
+    cfg, csum, data = make_input(args.config, args)
+    n, p = data.shape
+    eng = fw.Engine(cfg["test_name"], n, p, max_k=cfg["max_k"], device=local_rank)
+    eng.set_data(data)  # host -> HBM once, outside the timed region
+    cb = make_allgather(dist, dev) if world > 1 else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        if cfg["test_name"] == "fz":
+            eng.cor()
+        eng.pw_univar_neighbors()
+        return eng.lgl(feed_forward=bool(args.feed_forward), round_size=args.round_size, rank=rank,
+                       world_size=world, allgather=cb)
+
+    for _ in range(args.warmup):
+        step()
+    eng.reset_counters()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        net = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    cn = eng.counters()
+    # per-rank counters -> whole job
+    cond_ref = cn["cond_tests_ref"]
+    cond_eval = cn["cond_tests_evaluated"]
+    if world > 1:
+        tt = torch.tensor([cond_ref, cond_eval], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        cond_ref, cond_eval = int(tt[0].item()), int(tt[1].item())
+    steps = max(args.steps, 1)
+    level0_per_step = p * (p - 1) // 2
+    tests_per_step = level0_per_step + cond_ref // steps
+    value = tests_per_step * steps / dt
+
+    out = None
+    if rank == 0:
+        launches = max(cn["kernel_launches"], 1)
+        sub_launch_s = cn["t_dev_subsets_s"]
+        # dominant kernel: test_subsets batch (per launch averages over the timed region, this rank)
+        n_sub_launches = max(cn["kernel_launches"] - steps * (3 if cfg["test_name"] == "fz" else 1), 1)
+        achieved = (cn["alg_bytes_subsets"] / max(sub_launch_s, 1e-12)) / 1e9
+        roofline = {"bound": "hbm", "kernel": "fz_subsets_kernel" if cfg["test_name"] == "fz" else "mi_subsets_kernel",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None,
+                    "alg_bytes_per_launch": cn["alg_bytes_subsets"] / n_sub_launches,
+                    "avg_launch_us": 1e6 * sub_launch_s / n_sub_launches, "launches": n_sub_launches,
+                    "evaluated_tests_per_s_in_kernel": cn["cond_tests_evaluated"] / max(sub_launch_s, 1e-12)}
+        cpu = None
+        if not args.no_cpu_baseline:
+            from oracle import oracle as O
+            cm = eng.cor_mat() if cfg["test_name"] == "fz" else None
+            t1 = time.perf_counter()
+            if cfg["test_name"] == "fz":
+                orc = O.Oracle("fz", cor_mat=cm, n_obs=n)
+            else:
+                orc = O.Oracle(cfg["test_name"], data, sparse=True, max_k=cfg["max_k"])
+            stride = max(1, p // 512)
+            r = orc.learn(max_k=cfg["max_k"], feed_forward=False, target_stride=stride, max_seconds=args.cpu_seconds)
+            t_cpu = time.perf_counter() - t1
+            cpu_tests = r["n_level0_tests"] + r["n_cond_tests"]
+            cpu_secs = r["t_level0"] + r["t_cond"]
+            cpu = {"value": cpu_tests / cpu_secs, "unit": "tests/s", "cores": 1, "kind": "port",
+                   "sample": "oracle/fw_oracle.c (C restatement; the Julia reference cannot run here): full level-0 "
+                             "(%d pair tests, %.2fs) + conditional stage of every %d-th target of the schedule "
+                             "(%d targets, %d tests, %.2fs), feed_forward=0" %
+                             (r["n_level0_tests"], r["t_level0"], stride, r["n_targets"], r["n_cond_tests"], r["t_cond"]),
+                   "level0_tests_per_s": r["n_level0_tests"] / max(r["t_level0"], 1e-9),
+                   "cond_tests_per_s": r["n_cond_tests"] / max(r["t_cond"], 1e-9), "wall_s": t_cpu}
+        out = {"metric": "ci_tests_per_sec", "value": value, "unit": "tests/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f64" if cfg["test_name"] == "fz" else "i32", "data": "synthetic",
+               "config": {"workload": "%s: fwsynth-v1 %d OTUs x %d samples, %s, max_k=%d, alpha=0.01" %
+                                      (args.config, p, n, cfg["test_name"], cfg["max_k"]),
+                          "counts_sha256": csum, "feed_forward": args.feed_forward, "round_size": args.round_size,
+                          "parallelism": "targets round-robin over %d GPU(s)" % world},
+               "time_to_network_s": dt / steps, "edges": len(net["edges"]),
+               "tests_per_step": {"level0": level0_per_step, "conditional_ref_equivalent": cond_ref // steps,
+                                  "conditional_evaluated": cond_eval // steps},
+               "stage_seconds_rank0": {"level0": cn["t_level0_s"] / steps, "conditional": cn["t_cond_s"] / steps,
+                                       "subsets_kernels_device": sub_launch_s / steps},
+               "kernel_launches_per_step": launches / steps,
+               "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,518 @@
+// Context lifecycle, data hand-over, level-0 host logic (Benjamini-Hochberg + neighbour lists) and the
+// extern "C" entry points of include/flashweave_amd.h.  Device work lives in fw_fz.hip / fw_mi.hip,
+// the HITON-PC host driver in fw_hiton.cpp.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <numeric>
+
+#include "fw_internal.h"
+
+static thread_local std::string g_create_err;
+
+int fw_fail(const fw_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_create_err = buf;
+    return code;
+}
+
+int fw_dev_reserve(fw_ctx *ctx, FwDevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return FW_OK;
+    if (b.ptr) FW_HIP(ctx, hipFree(b.ptr));
+    b.ptr = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 2 + 256;
+    hipError_t e = hipMalloc(&b.ptr, want);
+    if (e != hipSuccess) return fw_fail(ctx, FW_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    b.cap = want;
+    return FW_OK;
+}
+
+int fw_pin_reserve(fw_ctx *ctx, FwPinned &b, size_t bytes)
+{
+    if (bytes <= b.cap) return FW_OK;
+    if (b.ptr) FW_HIP(ctx, hipHostFree(b.ptr));
+    b.ptr = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 2 + 256;
+    hipError_t e = hipHostMalloc(&b.ptr, want, hipHostMallocDefault);
+    if (e != hipSuccess) return fw_fail(ctx, FW_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    b.cap = want;
+    return FW_OK;
+}
+
+static double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+extern "C" {
+
+int fw_abi_version(void) { return FW_ABI_VERSION; }
+
+void fw_params_default(fw_params *P, int32_t kind, int32_t n, int32_t p)
+{
+    if (!P) return;
+    memset(P, 0, sizeof(*P));
+    P->kind = kind;
+    P->n = n;
+    P->p = p;
+    P->device = 0;
+    P->max_k = 3;
+    P->hps = 5;
+    P->fdr = 1;
+    P->n_obs_min = -1;
+    P->max_tests = 10000000;
+    P->alpha = 0.01;
+}
+
+const char *fw_last_error(const fw_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int fw_ctx_create(const fw_params *P, fw_ctx **out)
+{
+    if (out) *out = nullptr;
+    if (!P || !out) return fw_fail(nullptr, FW_ERR_ARG, "fw_ctx_create: NULL argument");
+    if (P->kind != FW_MI && P->kind != FW_MI_NZ && P->kind != FW_FZ)
+        return fw_fail(nullptr, FW_ERR_ARG, "fw_ctx_create: unknown test kind %d", P->kind);
+    if (P->n <= 0 || P->p <= 1) return fw_fail(nullptr, FW_ERR_ARG, "fw_ctx_create: need n > 0 and p > 1 (n=%d, p=%d)", P->n, P->p);
+    if (P->max_k < 0 || P->max_k > FW_MAX_K)
+        return fw_fail(nullptr, FW_ERR_LIMIT, "fw_ctx_create: max_k=%d outside [0, %d]", P->max_k, FW_MAX_K);
+    if (!(P->alpha > 0.0 && P->alpha < 1.0)) return fw_fail(nullptr, FW_ERR_ARG, "fw_ctx_create: alpha must be in (0,1)");
+    if (P->hps < 0) return fw_fail(nullptr, FW_ERR_ARG, "fw_ctx_create: hps must be >= 0");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fw_fail(nullptr, FW_ERR_DEVICE, "fw_ctx_create: no HIP device available (%s); this engine has no CPU fallback",
+                       e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (P->device < 0 || P->device >= ndev)
+        return fw_fail(nullptr, FW_ERR_DEVICE, "fw_ctx_create: device %d out of range (have %d)", P->device, ndev);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, P->device)) != hipSuccess)
+        return fw_fail(nullptr, FW_ERR_DEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fw_fail(nullptr, FW_ERR_DEVICE, "fw_ctx_create: device %d is %s; kernels are built for gfx950 only", P->device,
+                       prop.gcnArchName);
+    if ((e = hipSetDevice(P->device)) != hipSuccess) return fw_fail(nullptr, FW_ERR_DEVICE, "hipSetDevice: %s", hipGetErrorString(e));
+    fw_ctx *c = new (std::nothrow) fw_ctx();
+    if (!c) return fw_fail(nullptr, FW_ERR_NOMEM, "out of host memory");
+    c->P = *P;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+        delete c;
+        return fw_fail(nullptr, FW_ERR_DEVICE, "stream/event creation failed: %s", hipGetErrorString(e));
+    }
+    // continuous: the automatic n_obs_min is known immediately (learning.jl:59-61); discrete needs levels
+    c->n_obs_min_eff = P->n_obs_min >= 0 ? P->n_obs_min : (P->kind == FW_FZ ? 20 : -1);
+    *out = c;
+    return FW_OK;
+}
+
+static void free_dev(FwDevBuf &b)
+{
+    if (b.ptr) (void)hipFree(b.ptr);
+    b.ptr = nullptr;
+    b.cap = 0;
+}
+static void free_pin(FwPinned &b)
+{
+    if (b.ptr) (void)hipHostFree(b.ptr);
+    b.ptr = nullptr;
+    b.cap = 0;
+}
+
+int fw_ctx_destroy(fw_ctx *c)
+{
+    if (!c) return FW_OK;
+    (void)hipSetDevice(c->P.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *ptrs[] = {c->d_data, c->d_xc, c->d_sd, c->d_cor, c->d_nzbits, c->d_hibits, c->d_levels, c->d_maxvals, c->d_firstnz};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    free_dev(c->d_jobs);
+    free_dev(c->d_acc);
+    free_dev(c->d_out);
+    free_dev(c->d_tmp0);
+    free_dev(c->d_tmp1);
+    free_dev(c->d_tmp2);
+    free_pin(c->h_jobs);
+    free_pin(c->h_acc);
+    free_pin(c->h_out);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return FW_OK;
+}
+
+#define CHECK_CTX(c)                                          \
+    do {                                                      \
+        if (!(c)) return fw_fail(nullptr, FW_ERR_ARG, "NULL context"); \
+        (void)hipSetDevice((c)->P.device);                    \
+    } while (0)
+
+int fw_set_data_dense_f32(fw_ctx *c, const float *data)
+{
+    CHECK_CTX(c);
+    if (c->P.kind != FW_FZ) return fw_fail(c, FW_ERR_ARG, "fw_set_data_dense_f32: context is not FW_FZ");
+    if (!data) return fw_fail(c, FW_ERR_ARG, "fw_set_data_dense_f32: NULL data");
+    const size_t bytes = sizeof(float) * (size_t)c->P.n * c->P.p;
+    if (!c->d_data) FW_HIP(c, hipMalloc(&c->d_data, bytes));
+    FW_HIP(c, hipMemcpy(c->d_data, data, bytes, hipMemcpyHostToDevice));
+    c->have_data = true;
+    c->have_cor = false;
+    c->have_level0 = false;
+    c->have_network = false;
+    return FW_OK;
+}
+
+int fw_set_cor_mat(fw_ctx *c, const float *cor)
+{
+    CHECK_CTX(c);
+    if (c->P.kind != FW_FZ) return fw_fail(c, FW_ERR_ARG, "fw_set_cor_mat: context is not FW_FZ");
+    if (!cor) return fw_fail(c, FW_ERR_ARG, "fw_set_cor_mat: NULL matrix");
+    const size_t bytes = sizeof(float) * (size_t)c->P.p * c->P.p;
+    if (!c->d_cor) FW_HIP(c, hipMalloc(&c->d_cor, bytes));
+    FW_HIP(c, hipMemcpy(c->d_cor, cor, bytes, hipMemcpyHostToDevice));
+    c->have_cor = true;
+    c->have_level0 = false;
+    c->have_network = false;
+    return FW_OK;
+}
+
+int fw_compute_cor_mat(fw_ctx *c)
+{
+    CHECK_CTX(c);
+    if (c->P.kind != FW_FZ) return fw_fail(c, FW_ERR_ARG, "fw_compute_cor_mat: context is not FW_FZ");
+    return fwi_fz_compute_cor(c);
+}
+
+int fw_get_cor_mat(const fw_ctx *c, float *out)
+{
+    CHECK_CTX(c);
+    if (!c->have_cor) return fw_fail(c, FW_ERR_STATE, "fw_get_cor_mat: no correlation matrix resident");
+    if (!out) return fw_fail(c, FW_ERR_ARG, "fw_get_cor_mat: NULL output");
+    FW_HIP(c, hipMemcpy(out, c->d_cor, sizeof(float) * (size_t)c->P.p * c->P.p, hipMemcpyDeviceToHost));
+    return FW_OK;
+}
+
+// learning.jl:51-64 automatic n_obs_min for discrete tests (needs maximum(levels))
+static void resolve_n_obs_min_discrete(fw_ctx *c)
+{
+    if (c->P.n_obs_min >= 0) {
+        c->n_obs_min_eff = c->P.n_obs_min;
+        return;
+    }
+    int64_t max_level = 0;
+    for (int32_t l : c->levels) max_level = std::max<int64_t>(max_level, l);
+    int64_t n_strata = 1;
+    for (int j = 0; j < c->P.max_k; ++j) {
+        n_strata *= max_level;
+        if (n_strata > 8) break;
+    }
+    n_strata = std::min<int64_t>(n_strata, 8);
+    c->n_obs_min_eff = (int64_t)c->P.hps * 2 * 2 * n_strata;
+}
+
+int fw_set_data_csc_i32(fw_ctx *c, const int64_t *colptr, const int32_t *rowval, const int32_t *nzval)
+{
+    CHECK_CTX(c);
+    if (c->P.kind == FW_FZ) return fw_fail(c, FW_ERR_ARG, "fw_set_data_csc_i32: context is FW_FZ");
+    if (!colptr || (colptr[c->P.p] > 0 && (!rowval || !nzval))) return fw_fail(c, FW_ERR_ARG, "fw_set_data_csc_i32: NULL array");
+    int rc = fwi_mi_upload(c, colptr, rowval, nzval);
+    if (rc) return rc;
+    resolve_n_obs_min_discrete(c);
+    c->have_data = true;
+    c->have_level0 = false;
+    c->have_network = false;
+    return FW_OK;
+}
+
+int fw_set_data_dense_i32(fw_ctx *c, const int32_t *data)
+{
+    CHECK_CTX(c);
+    if (c->P.kind == FW_FZ) return fw_fail(c, FW_ERR_ARG, "fw_set_data_dense_i32: context is FW_FZ");
+    if (!data) return fw_fail(c, FW_ERR_ARG, "fw_set_data_dense_i32: NULL data");
+    const int n = c->P.n, p = c->P.p;
+    std::vector<int64_t> colptr(p + 1, 0);
+    std::vector<int32_t> rowval, nzval;
+    for (int v = 0; v < p; ++v) {
+        for (int i = 0; i < n; ++i) {
+            int32_t x = data[(size_t)v * n + i];
+            if (x != 0) {
+                rowval.push_back(i);
+                nzval.push_back(x);
+            }
+        }
+        colptr[v + 1] = (int64_t)rowval.size();
+    }
+    return fw_set_data_csc_i32(c, colptr.data(), rowval.data(), nzval.data());
+}
+
+int fw_get_levels(const fw_ctx *c, int32_t *levels, int32_t *max_vals)
+{
+    CHECK_CTX(c);
+    if (c->levels.empty()) return fw_fail(c, FW_ERR_STATE, "fw_get_levels: no discrete data uploaded");
+    if (levels) memcpy(levels, c->levels.data(), sizeof(int32_t) * c->levels.size());
+    if (max_vals) memcpy(max_vals, c->max_vals.data(), sizeof(int32_t) * c->max_vals.size());
+    return FW_OK;
+}
+
+int64_t fw_effective_n_obs_min(const fw_ctx *c) { return c ? c->n_obs_min_eff : -1; }
+
+// ---- level 0 --------------------------------------------------------------------------------------
+// BH (statfuns.jl:326-350) on the p < alpha subset + neighbour lists (tests.jl:372-388).
+int fw_level0(fw_ctx *c, int64_t *nnz_out)
+{
+    CHECK_CTX(c);
+    const double t0 = now_s();
+    const int p = c->P.p;
+    if (c->P.kind == FW_FZ) {
+        if (!c->have_cor) {
+            int rc = fwi_fz_compute_cor(c);
+            if (rc) return rc;
+        }
+    } else if (!c->have_data) {
+        return fw_fail(c, FW_ERR_STATE, "fw_level0: no data uploaded");
+    }
+    if (c->n_obs_min_eff > c->P.n)  // learning.jl:66-73
+        return fw_fail(c, FW_ERR_NOBS,
+                       "Dataset has an insufficient number of observations, need at least %lld ('n_obs_min') for reliable tests",
+                       (long long)c->n_obs_min_eff);
+    std::vector<int32_t> pi, pj;
+    std::vector<double> stat, pval;
+    int64_t m = 0;
+    int rc = (c->P.kind == FW_FZ) ? fwi_fz_level0(c, pi, pj, stat, pval, &m) : fwi_mi_level0(c, pi, pj, stat, pval, &m);
+    if (rc) return rc;
+    const size_t k = pi.size();
+    std::vector<uint32_t> ord(k);
+    std::iota(ord.begin(), ord.end(), 0u);
+    auto pairkey = [&](uint32_t t) { return (int64_t)pi[t] * p + pj[t]; };
+    if (c->P.fdr && k > 0) {
+        // stable ascending sort by p (ties: condensed pair order, i.e. the enumerate order of statfuns.jl:331)
+        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
+            if (pval[a] != pval[b]) return pval[a] < pval[b];
+            return pairkey(a) < pairkey(b);
+        });
+        std::vector<double> adj(k);
+        const double md = (double)m;
+        adj[k - 1] = std::min(pval[ord[k - 1]] * md / (double)k, 1.0);
+        for (size_t i = k - 1; i-- > 0;) {
+            const double next_adj = adj[i + 1];
+            const double new_adj = pval[ord[i]] * md / (double)(i + 1);
+            adj[i] = std::min(next_adj, new_adj);
+        }
+        for (size_t i = 0; i < k; ++i) pval[ord[i]] = adj[i];
+    }
+    // neighbour lists: adj p < alpha, partners ascending
+    std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return pairkey(a) < pairkey(b); });
+    c->nb_off.assign((size_t)p + 1, 0);
+    for (size_t t = 0; t < k; ++t)
+        if (pval[t] < c->P.alpha) {
+            c->nb_off[pi[t] + 1]++;
+            c->nb_off[pj[t] + 1]++;
+        }
+    for (int v = 0; v < p; ++v) c->nb_off[v + 1] += c->nb_off[v];
+    const int64_t tot = c->nb_off[p];
+    c->nb_idx.assign((size_t)tot, 0);
+    c->nb_stat.assign((size_t)tot, 0.0);
+    c->nb_p.assign((size_t)tot, 0.0);
+    std::vector<int64_t> fill(c->nb_off.begin(), c->nb_off.end() - 1);
+    for (size_t q = 0; q < k; ++q) {
+        const uint32_t t = ord[q];
+        if (!(pval[t] < c->P.alpha)) continue;
+        const int X = pi[t], Y = pj[t];
+        int64_t a = fill[X]++, b = fill[Y]++;
+        c->nb_idx[a] = Y;
+        c->nb_stat[a] = stat[t];
+        c->nb_p[a] = pval[t];
+        c->nb_idx[b] = X;
+        c->nb_stat[b] = stat[t];
+        c->nb_p[b] = pval[t];
+    }
+    c->have_level0 = true;
+    c->have_network = false;
+    c->cnt.level0_tests += (int64_t)p * (p - 1) / 2;
+    c->cnt.t_level0_s += now_s() - t0;
+    if (nnz_out) *nnz_out = tot;
+    return FW_OK;
+}
+
+int fw_level0_get(const fw_ctx *c, int64_t *off, int32_t *idx, double *stat, double *adj_p)
+{
+    CHECK_CTX(c);
+    if (!c->have_level0) return fw_fail(c, FW_ERR_STATE, "fw_level0_get: fw_level0 has not run");
+    if (off) memcpy(off, c->nb_off.data(), sizeof(int64_t) * c->nb_off.size());
+    const size_t tot = c->nb_idx.size();
+    if (idx && tot) memcpy(idx, c->nb_idx.data(), sizeof(int32_t) * tot);
+    if (stat && tot) memcpy(stat, c->nb_stat.data(), sizeof(double) * tot);
+    if (adj_p && tot) memcpy(adj_p, c->nb_p.data(), sizeof(double) * tot);
+    return FW_OK;
+}
+
+// ---- per-pair batches --------------------------------------------------------------------------------
+static int check_var(const fw_ctx *c, int32_t v) { return v >= 0 && v < c->P.p; }
+
+int fw_test_batch(fw_ctx *c, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff, const int32_t *zflat,
+                  fw_test_result *out)
+{
+    CHECK_CTX(c);
+    if (m < 0 || (m > 0 && (!X || !Y || !zoff || !out))) return fw_fail(c, FW_ERR_ARG, "fw_test_batch: NULL argument");
+    if (m == 0) return FW_OK;
+    for (int64_t t = 0; t < m; ++t) {
+        const int64_t k = zoff[t + 1] - zoff[t];
+        if (k < 0 || k > FW_MAX_K) return fw_fail(c, FW_ERR_LIMIT, "fw_test_batch: test %lld has %lld conditioning variables (max %d)", (long long)t, (long long)k, FW_MAX_K);
+        if (!check_var(c, X[t]) || !check_var(c, Y[t])) return fw_fail(c, FW_ERR_ARG, "fw_test_batch: variable index out of range in test %lld", (long long)t);
+        for (int64_t q = zoff[t]; q < zoff[t + 1]; ++q)
+            if (!check_var(c, zflat[q])) return fw_fail(c, FW_ERR_ARG, "fw_test_batch: conditioning variable out of range in test %lld", (long long)t);
+    }
+    if (c->P.kind == FW_FZ) {
+        if (!c->have_cor) return fw_fail(c, FW_ERR_STATE, "fw_test_batch: no correlation matrix (fw_compute_cor_mat / fw_set_cor_mat)");
+        return fwi_fz_test_batch(c, m, X, Y, zoff, zflat, out);
+    }
+    if (!c->have_data) return fw_fail(c, FW_ERR_STATE, "fw_test_batch: no data uploaded");
+    return fwi_mi_test_batch(c, m, X, Y, zoff, zflat, out);
+}
+
+}  // extern "C"
+
+int fwi_subsets_dispatch(fw_ctx *c, int64_t m, const FwJob *jobs, const int32_t *acc, int64_t acc_total, FwJobOut *out)
+{
+    if (c->P.kind == FW_FZ) {
+        if (c->P.n < c->n_obs_min_eff) {
+            // tests.jl:254-262: every test lacks power -> the first one is returned (0, 1, 0, false)
+            for (int64_t i = 0; i < m; ++i) {
+                FwJobOut o{};
+                o.stat = 0.0;
+                o.pval = 1.0;
+                o.num_tests = 1;
+                o.evaluated = 0;
+                o.status = FW_SUBSETS_STOPPED;
+                int s = std::min<int>(c->P.max_k, jobs[i].acc_len);
+                o.n_zs = s;
+                for (int q = 0; q < s; ++q) o.zs[q] = acc[jobs[i].acc_off + q];
+                out[i] = o;
+            }
+            return FW_OK;
+        }
+        return fwi_fz_subsets(c, m, jobs, acc, acc_total, out);
+    }
+    return fwi_mi_subsets(c, m, jobs, acc, acc_total, out);
+}
+
+static double binom_d(int n, int k)
+{
+    if (k < 0 || k > n) return 0.0;
+    double r = 1.0;
+    for (int i = 1; i <= k; ++i) r = r * (double)(n - k + i) / (double)i;
+    return std::floor(r + 0.5);
+}
+
+double fwi_alg_bytes(const fw_ctx *c, int a, int64_t evaluated)
+{
+    double bytes = 0.0, left = (double)evaluated;
+    for (int s = c->P.max_k; s >= 1 && left > 0; --s) {
+        const double cnt = std::min(left, binom_d(a, s));
+        double per;
+        if (c->P.kind == FW_FZ)
+            per = 4.0 * (double)((s + 2) * (s + 1) / 2) + 32.0;
+        else
+            per = (double)(s + 2) * (double)c->P.n * (c->P.kind == FW_MI ? 1.0 : 2.0) / 8.0 + 32.0;
+        bytes += cnt * per;
+        left -= cnt;
+    }
+    return bytes;
+}
+
+extern "C" {
+
+int fw_test_subsets_batch(fw_ctx *c, int64_t m, const int32_t *T, const int32_t *cand, const int64_t *accoff,
+                          const int32_t *accflat, fw_subsets_result *out)
+{
+    CHECK_CTX(c);
+    if (m < 0 || (m > 0 && (!T || !cand || !accoff || !out))) return fw_fail(c, FW_ERR_ARG, "fw_test_subsets_batch: NULL argument");
+    if (m == 0) return FW_OK;
+    if (c->P.kind == FW_FZ ? !c->have_cor : !c->have_data)
+        return fw_fail(c, FW_ERR_STATE, "fw_test_subsets_batch: no %s resident", c->P.kind == FW_FZ ? "correlation matrix" : "data");
+    if (c->P.max_k < 1) return fw_fail(c, FW_ERR_ARG, "fw_test_subsets_batch: max_k must be >= 1");
+    std::vector<FwJob> jobs;
+    std::vector<int64_t> map;
+    jobs.reserve((size_t)m);
+    for (int64_t i = 0; i < m; ++i) {
+        const int64_t len = accoff[i + 1] - accoff[i];
+        if (len < 0 || len > INT32_MAX) return fw_fail(c, FW_ERR_ARG, "fw_test_subsets_batch: bad accoff at job %lld", (long long)i);
+        if (!check_var(c, T[i]) || !check_var(c, cand[i])) return fw_fail(c, FW_ERR_ARG, "fw_test_subsets_batch: variable out of range in job %lld", (long long)i);
+        for (int64_t q = accoff[i]; q < accoff[i + 1]; ++q)
+            if (!check_var(c, accflat[q])) return fw_fail(c, FW_ERR_ARG, "fw_test_subsets_batch: accepted variable out of range in job %lld", (long long)i);
+        if (len == 0) {  // tests.jl:285 sentinel
+            fw_subsets_result r{};
+            r.stat = NAN;
+            r.pval = NAN;
+            r.df = -1;
+            r.suff_power = 1;
+            r.status = FW_SUBSETS_EMPTY;
+            r.n_zs = 0;
+            r.num_tests = -1;
+            r.frac = NAN;
+            out[i] = r;
+            continue;
+        }
+        FwJob j{};
+        j.X = T[i];
+        j.Y = cand[i];
+        j.acc_off = accoff[i];
+        j.acc_len = (int32_t)len;
+        jobs.push_back(j);
+        map.push_back(i);
+    }
+    std::vector<FwJobOut> jo(jobs.size());
+    int rc = fwi_subsets_dispatch(c, (int64_t)jobs.size(), jobs.data(), accflat, accoff[m], jo.data());
+    if (rc) return rc;
+    for (size_t q = 0; q < jobs.size(); ++q) {
+        const FwJobOut &o = jo[q];
+        fw_subsets_result r{};
+        r.stat = o.stat;
+        r.pval = o.pval;
+        r.df = o.df;
+        r.suff_power = o.suff_power;
+        r.status = o.status;
+        r.n_zs = o.n_zs;
+        for (int z = 0; z < FW_MAX_K; ++z) r.zs[z] = z < o.n_zs ? o.zs[z] : 0;
+        r.num_tests = o.num_tests;
+        double total = 0.0;  // tests.jl:313,327-332
+        for (int s = c->P.max_k; s >= 1; --s) total += binom_d(jobs[q].acc_len, s);
+        r.frac = total > 0 ? (double)o.num_tests / total : NAN;
+        out[map[q]] = r;
+        c->cnt.cond_tests_ref += o.num_tests;
+        c->cnt.cond_tests_evaluated += o.evaluated;
+        c->cnt.alg_bytes_subsets += fwi_alg_bytes(c, jobs[q].acc_len, o.evaluated);
+        c->cnt.subsets_calls += 1;
+    }
+    return FW_OK;
+}
+
+int fw_get_counters(const fw_ctx *c, fw_counters *out)
+{
+    CHECK_CTX(c);
+    if (!out) return fw_fail(c, FW_ERR_ARG, "fw_get_counters: NULL output");
+    *out = c->cnt;
+    return FW_OK;
+}
+
+int fw_reset_counters(fw_ctx *c)
+{
+    CHECK_CTX(c);
+    c->cnt = fw_counters{};
+    return FW_OK;
+}
+
+}  // extern "C"

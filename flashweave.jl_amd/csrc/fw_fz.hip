@@ -1,0 +1,718 @@
+// FlashWeave-S (Fisher-z) device path for gfx950: level-0 Pearson matrix on fp32 MFMA, level-0 pair tests,
+// and the per-(T, candidate) test_subsets batch (recursive partial correlation evaluated as a DP).
+//
+// Reference semantics (file:line into /root/reference/src):
+//   cor(data_dense) -> Float32          learning.jl:42-45 (Statistics.cor: centre, X'X, cov2cor! + clamp)
+//   univariate FzTest                    tests.jl:108-160 (branch :149-153), fz_pval statfuns.jl:3-17
+//   conditional FzTestCond               tests.jl:250-265, pcor_rec statfuns.jl:23-75 (len_z = 0 at tests.jl:256)
+//   test_subsets                         tests.jl:281-346
+// Compiled with -ffp-contract=off: the reference never fuses a*b+c and the partial-correlation value must be
+// reproducible to the bit (only +,-,*,/,sqrt,rint are involved).
+#include "fw_internal.h"
+
+#include <algorithm>
+#include <cmath>
+
+// ------------------------------------------------------------------------------------------------
+// 1. centring + column norms
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fz_center_kernel(const float *__restrict__ data, float *__restrict__ xc,
+                                                        float *__restrict__ sd, int n, int p, int n_pad)
+{
+    const int v = blockIdx.x;
+    float *dst = xc + (size_t)v * n_pad;
+    __shared__ double s_red[4];
+    if (v >= p) {
+        for (int i = threadIdx.x; i < n_pad; i += 256) dst[i] = 0.0f;
+        if (threadIdx.x == 0) sd[v] = 0.0f;
+        return;
+    }
+    const float *src = data + (size_t)v * n;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)src[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const double tot = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    const float mean = (float)(tot / (double)n);
+    __syncthreads();
+    double ss = 0.0;
+    for (int i = threadIdx.x; i < n_pad; i += 256) {
+        float d = 0.0f;
+        if (i < n) {
+            d = src[i] - mean;
+            ss += (double)d * (double)d;
+        }
+        dst[i] = d;
+    }
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) sd[v] = sqrtf((float)(s_red[0] + s_red[1] + s_red[2] + s_red[3]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2. C = Xc' Xc on v_mfma_f32_32x32x2_f32 (exact fp32), upper-triangular 128x128 tiles, fused cov2cor epilogue
+//    Xc is stored [variable][n_pad] (k contiguous), so both operands are k-contiguous ("TN" GEMM).
+//    LDS tile layout s[128][BK + 4]: 16-byte aligned rows for ds_write_b128 / ds_read_b128, and the row stride
+//    of 36 floats keeps the 16-lane b128 read groups conflict free.
+//    k is permuted inside a tile: lanes 0-31 take k in [0,16), lanes 32-63 k in [16,32) -- both operands use the
+//    same permutation, so the dot product is unchanged while each lane reads 4 consecutive k as one b128.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define GEMM_BM 128
+#define GEMM_BK 32
+#define GEMM_LD (GEMM_BK + 4)
+
+__device__ __forceinline__ void tri_decode(int b, int T, int &bi, int &bj)
+{
+    // rows of the upper triangle have T, T-1, ... tiles; small T (<= ~1000) -> a loop is fine but use closed form
+    // bi = floor(((2T+1) - sqrt((2T+1)^2 - 8b)) / 2)
+    double t = 2.0 * T + 1.0;
+    int r = (int)floor((t - sqrt(t * t - 8.0 * (double)b)) * 0.5);
+    // fix-up for rounding
+    while (r > 0 && (long long)r * T - (long long)r * (r - 1) / 2 > b) --r;
+    while ((long long)(r + 1) * T - (long long)(r + 1) * r / 2 <= b) ++r;
+    bi = r;
+    bj = r + (b - (int)((long long)r * T - (long long)r * (r - 1) / 2));
+}
+
+__global__ __launch_bounds__(256) void fz_cor_gemm_kernel(const float *__restrict__ xc, const float *__restrict__ sd,
+                                                          float *__restrict__ cor, int p, int n_pad, int T)
+{
+    __shared__ __attribute__((aligned(16))) float sA[GEMM_BM * GEMM_LD];
+    __shared__ __attribute__((aligned(16))) float sB[GEMM_BM * GEMM_LD];
+    int bi, bj;
+    tri_decode(blockIdx.x, T, bi, bj);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lm = lane & 31, lh = lane >> 5;
+
+    const float *gA = xc + (size_t)bi * GEMM_BM * n_pad;
+    const float *gB = xc + (size_t)bj * GEMM_BM * n_pad;
+    // global->LDS staging: 128 columns x 32 k = 1024 float4, 4 per thread; 8 consecutive lanes cover one 128-B row
+    const int ld_col = tid >> 3;  // 0..31 (+32 per step)
+    const int ld_k4 = tid & 7;    // float4 index within the 32-k row
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    float4 ra[4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int col = ld_col + 32 * s;
+            ra[s] = *reinterpret_cast<const float4 *>(gA + (size_t)col * n_pad + k0 + ld_k4 * 4);
+            rb[s] = *reinterpret_cast<const float4 *>(gB + (size_t)col * n_pad + k0 + ld_k4 * 4);
+        }
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int col = ld_col + 32 * s;
+            *reinterpret_cast<float4 *>(&sA[col * GEMM_LD + ld_k4 * 4]) = ra[s];
+            *reinterpret_cast<float4 *>(&sB[col * GEMM_LD + ld_k4 * 4]) = rb[s];
+        }
+    };
+
+    gload(0);
+    for (int k0 = 0; k0 < n_pad; k0 += GEMM_BK) {
+        __syncthreads();  // previous tile fully consumed
+        sstore();
+        __syncthreads();
+        if (k0 + GEMM_BK < n_pad) gload(k0 + GEMM_BK);  // prefetch next tile into registers
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 a0 = *reinterpret_cast<const float4 *>(&sA[(wm * 64 + lm) * GEMM_LD + lh * 16 + q * 4]);
+            float4 a1 = *reinterpret_cast<const float4 *>(&sA[(wm * 64 + 32 + lm) * GEMM_LD + lh * 16 + q * 4]);
+            float4 b0 = *reinterpret_cast<const float4 *>(&sB[(wn * 64 + lm) * GEMM_LD + lh * 16 + q * 4]);
+            float4 b1 = *reinterpret_cast<const float4 *>(&sB[(wn * 64 + 32 + lm) * GEMM_LD + lh * 16 + q * 4]);
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv0[e], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv1[e], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv0[e], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv1[e], acc[1][1], 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: cov2cor! (C[i,j] / (xsd[i] * xsd[j]), clampcor, unit diagonal), write (i,j) and the mirror (j,i)
+    const bool vec_ok = (p & 3) == 0;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int j = bj * GEMM_BM + wn * 64 + tn * 32 + lm;
+            const float sdj = (j < p) ? sd[j] : 0.0f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float vals[4];
+                const int i0 = bi * GEMM_BM + wm * 64 + tm * 32 + 8 * g + 4 * lh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = i0 + e;
+                    float c = acc[tm][tn][4 * g + e];
+                    const float sdi = (i < p) ? sd[i] : 0.0f;
+                    float r = c / (sdi * sdj);
+                    r = r > 1.0f ? 1.0f : (r < -1.0f ? -1.0f : r);  // NaN stays NaN
+                    if (i == j) r = 1.0f;
+                    vals[e] = r;
+                    if (i < p && j < p) cor[(size_t)i * p + j] = r;
+                }
+                if (bi != bj && j < p) {
+                    if (vec_ok && i0 + 3 < p) {
+                        *reinterpret_cast<float4 *>(&cor[(size_t)j * p + i0]) = make_float4(vals[0], vals[1], vals[2], vals[3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (i0 + e < p) cor[(size_t)j * p + i0 + e] = vals[e];
+                    }
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3. shared device math
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double fz_pval_dev(double r, double zscale /* sqrt(n-3)/2, 0 if n <= 3 */)
+{
+    // statfuns.jl:3-17; ccdf(Normal(), x) = erfc(x / sqrt2) / 2 (StatsFuns.normccdf)
+    double z = (zscale > 0.0) ? zscale * log((1.0 + r) / (1.0 - r)) : 0.0;
+    double cc = erfc(fabs(z) * 0.7071067811865476) / 2.0;
+    return cc * 2.0;
+}
+
+__device__ __forceinline__ float round5_f32(float x)
+{
+    float y = rintf(x * 100000.0f) / 100000.0f;
+    return isfinite(y) ? y : x;
+}
+__device__ __forceinline__ double round5_f64(double x)
+{
+    double y = rint(x * 100000.0) / 100000.0;
+    return isfinite(y) ? y : x;
+}
+
+// Partial correlation rho(X, Y | z[0..K-1]) with the reference's peel order (last element first) and its mixed
+// Float32/Float64 arithmetic, evaluated bottom-up: U = [X, Y, z_K, ..., z_1]; level j conditions
+// every remaining pair (a before b in U) on z_j.  (The recursion of statfuns.jl:44-53 touches exactly these
+// pairs in exactly these argument orders; level-1 values are symmetric.)
+template <int K>
+__device__ __forceinline__ double fz_pcor_dp(const float *__restrict__ cor, int p, int X, int Y, const int *z)
+{
+    constexpr int M = K + 2;
+    int U[M];
+    U[0] = X;
+    U[1] = Y;
+#pragma unroll
+    for (int j = 0; j < K; ++j) U[2 + j] = z[K - 1 - j];
+    double R[M][M];
+    bool is32[M][M];
+    float C0[M][M];
+#pragma unroll
+    for (int a = 0; a < M; ++a)
+#pragma unroll
+        for (int b = a + 1; b < M; ++b) C0[a][b] = cor[(size_t)U[a] * p + U[b]];
+    // level 1 (statfuns.jl:32-41), ContType = Float32
+    {
+        constexpr int last = M - 1;
+#pragma unroll
+        for (int a = 0; a < last; ++a)
+#pragma unroll
+            for (int b = a + 1; b < last; ++b) {
+                const float xy = C0[a][b], xz = C0[a][last], yz = C0[b][last];
+                const float prod = xz * yz;
+                float e = xy - prod;
+                e = round5_f32(e);
+                const float s1 = 1.0f - xz * xz, s2 = 1.0f - yz * yz;
+                const float d = sqrtf(s1) * sqrtf(s2);
+                double v;
+                bool f32;
+                if (d == 0.0f) {
+                    v = 0.0;
+                    f32 = false;
+                } else {
+                    v = (double)(e / d);
+                    f32 = true;
+                }
+                if (v < -1.0) {
+                    v = -1.0;
+                    f32 = false;
+                } else if (v >= 1.0) {
+                    v = 1.0;
+                    f32 = false;
+                }
+                R[a][b] = v;
+                is32[a][b] = f32;
+            }
+    }
+#pragma unroll
+    for (int j = 2; j <= K; ++j) {
+        const int last = M - j;
+#pragma unroll
+        for (int a = 0; a < M; ++a)
+#pragma unroll
+            for (int b = a + 1; b < M; ++b) {
+                if (b < last) {
+                    const double va = R[a][b], vb = R[a][last], vc = R[b][last];
+                    double ev, d1;
+                    if (j == 2) {
+                        const bool a32 = is32[a][b], b32 = is32[a][last], c32 = is32[b][last];
+                        double prod;
+                        bool p32;
+                        if (b32 && c32) {
+                            prod = (double)((float)vb * (float)vc);
+                            p32 = true;
+                        } else {
+                            prod = vb * vc;
+                            p32 = false;
+                        }
+                        if (a32 && p32)
+                            ev = (double)round5_f32((float)va - (float)prod);
+                        else
+                            ev = round5_f64(va - prod);
+                        if (b32) {
+                            const float bb = (float)vb * (float)vb;
+                            d1 = (double)sqrtf(1.0f - bb);
+                        } else {
+                            d1 = sqrt(1.0 - vb * vb);
+                        }
+                    } else {
+                        ev = round5_f64(va - vb * vc);
+                        d1 = sqrt(1.0 - vb * vb);
+                    }
+                    const double d2 = sqrt(1.0 - vc * vc);
+                    const double denom = d1 * d2;
+                    double v = (denom == 0.0) ? 0.0 : ev / denom;
+                    if (v < -1.0)
+                        v = -1.0;
+                    else if (v >= 1.0)
+                        v = 1.0;
+                    R[a][b] = v;
+                    is32[a][b] = false;
+                }
+            }
+    }
+    return R[0][1];
+}
+
+__device__ __forceinline__ double fz_pcor_any(const float *__restrict__ cor, int p, int X, int Y, const int *z, int k)
+{
+    switch (k) {
+        case 1: return fz_pcor_dp<1>(cor, p, X, Y, z);
+        case 2: return fz_pcor_dp<2>(cor, p, X, Y, z);
+        case 3: return fz_pcor_dp<3>(cor, p, X, Y, z);
+        case 4: return fz_pcor_dp<4>(cor, p, X, Y, z);
+        case 5: return fz_pcor_dp<5>(cor, p, X, Y, z);
+        default: return (double)cor[(size_t)X * p + Y];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 4. level 0: all pairs i < j of the resident matrix (tests.jl:149-159 + the NaN/m rule of :397-398,522-526)
+// ------------------------------------------------------------------------------------------------
+struct FzL0Counters {
+    unsigned long long n_sig;  // pairs with p < alpha (raw)
+    unsigned long long n_nan;  // pairs with NaN p (excluded from m)
+};
+
+__global__ __launch_bounds__(256) void fz_level0_kernel(const float *__restrict__ cor, int p, double alpha, double zscale,
+                                                        FzL0Counters *cnt, unsigned long long cap, int32_t *out_i,
+                                                        int32_t *out_j, float *out_r, double *out_p)
+{
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if ((int)(blockIdx.x * 256 + 255) <= i) return;  // whole block below/on the diagonal
+    bool sig = false, isn = false;
+    float r = 0.0f;
+    double pv = 1.0;
+    if (j > i && j < p) {
+        r = cor[(size_t)i * p + j];
+        pv = fz_pval_dev((double)r, zscale);
+        isn = isnan(pv);
+        sig = pv < alpha;
+    }
+    const unsigned long long ms = __ballot(sig), mn = __ballot(isn);
+    const int lane = threadIdx.x & 63;
+    if (ms) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&cnt->n_sig, (unsigned long long)__popcll(ms));
+        base = __shfl(base, 0);
+        if (sig) {
+            const unsigned long long slot = base + __popcll(ms & ((1ull << lane) - 1ull));
+            if (slot < cap) {
+                out_i[slot] = i;
+                out_j[slot] = j;
+                out_r[slot] = r;
+                out_p[slot] = pv;
+            }
+        }
+    }
+    if (mn && lane == 0) atomicAdd(&cnt->n_nan, (unsigned long long)__popcll(mn));
+}
+
+// ------------------------------------------------------------------------------------------------
+// 5. batch of single tests (tests.jl:108-160 / 250-265), one lane per test
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fz_test_batch_kernel(const float *__restrict__ cor, int p, long long m,
+                                                            const int32_t *__restrict__ X, const int32_t *__restrict__ Y,
+                                                            const long long *__restrict__ zoff,
+                                                            const int32_t *__restrict__ zflat, double zscale,
+                                                            fw_test_result *__restrict__ out)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= m) return;
+    const int k = (int)(zoff[t + 1] - zoff[t]);
+    int z[FW_MAX_K];
+    for (int q = 0; q < FW_MAX_K; ++q) z[q] = (q < k) ? zflat[zoff[t] + q] : 0;
+    const double r = fz_pcor_any(cor, p, X[t], Y[t], z, k);
+    fw_test_result o;
+    o.stat = r;
+    o.pval = fz_pval_dev(r, zscale);
+    o.df = 0;
+    o.suff_power = 1;
+    out[t] = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 6. test_subsets: one 256-lane workgroup per (T, candidate, accepted) job.  Subsets are enumerated in the
+//    reference order (sizes max_k..1, lexicographic over positions); lane l of a chunk evaluates rank base + l;
+//    the first non-significant rank (or the max_tests stop) ends the job, otherwise the (p, rank) maximum with
+//    "later wins ties" is carried across chunks (tests.jl:311-345).
+// ------------------------------------------------------------------------------------------------
+#define FW_ACC_LDS 2048
+
+__device__ __forceinline__ unsigned long long binom_u64(long long m, int t)
+{
+    if (m < t) return 0ull;
+    const unsigned long long SAT = 1ull << 62;
+    const double est = (t == 0) ? 1.0
+                                : (t == 1) ? (double)m
+                                           : (t == 2) ? 0.5 * m * (m - 1)
+                                                      : (t == 3) ? (double)m * (m - 1) * (m - 2) / 6.0
+                                                                 : (t == 4) ? (double)m * (m - 1) * (m - 2) * (m - 3) / 24.0
+                                                                            : (double)m * (m - 1) * (m - 2) * (m - 3) * (m - 4) / 120.0;
+    if (est > 4.0e18) return SAT;
+    const unsigned long long u = (unsigned long long)m;
+    switch (t) {
+        case 0: return 1ull;
+        case 1: return u;
+        case 2: return u * (u - 1) / 2ull;
+        case 3: return (u * (u - 1) / 2ull) * (u - 2) / 3ull;
+        case 4: return ((u * (u - 1) / 2ull) * (u - 2) / 3ull) * (u - 3) / 4ull;
+        default: return (((u * (u - 1) / 2ull) * (u - 2) / 3ull) * (u - 3) / 4ull) * (u - 4) / 5ull;
+    }
+}
+
+// lexicographic unranking of `rem` among the s-subsets of positions [0, a)
+__device__ __forceinline__ void unrank_comb(unsigned long long rem, int a, int s, int *pos)
+{
+    int prev = -1;
+    for (int d = 0; d < s; ++d) {
+        const int t = s - d;
+        const unsigned long long tot = binom_u64(a - 1 - prev, t);
+        int lo = prev + 1, hi = a - t;
+        while (lo < hi) {  // largest c with tot - C(a - c, t) <= rem
+            const int mid = (lo + hi + 1) >> 1;
+            const unsigned long long g = tot - binom_u64(a - mid, t);
+            if (g <= rem)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        rem -= tot - binom_u64(a - lo, t);
+        pos[d] = lo;
+        prev = lo;
+    }
+}
+
+__global__ __launch_bounds__(256) void fz_subsets_kernel(const float *__restrict__ cor, int p,
+                                                         const FwJob *__restrict__ jobs,
+                                                         const int32_t *__restrict__ accflat, FwJobOut *__restrict__ out,
+                                                         int max_k, double alpha, double zscale, long long max_tests)
+{
+    __shared__ int s_acc[FW_ACC_LDS];
+    __shared__ unsigned long long s_stop[4];
+    __shared__ double s_bp[4];
+    __shared__ unsigned long long s_br[4];
+    __shared__ double s_best_p, s_best_stat;
+    __shared__ int s_best_zs[FW_MAX_K], s_best_n;
+
+    const FwJob job = jobs[blockIdx.x];
+    const int a = job.acc_len;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t *gacc = accflat + job.acc_off;
+    const bool in_lds = a <= FW_ACC_LDS;
+    if (in_lds)
+        for (int i = tid; i < a; i += 256) s_acc[i] = gacc[i];
+    if (tid == 0) {
+        s_best_p = -1.0;
+        s_best_stat = 0.0;
+        s_best_n = 0;
+    }
+    // subset counts per size, in enumeration order s = max_k .. 1
+    unsigned long long cnt[FW_MAX_K + 1], N = 0;
+#pragma unroll
+    for (int s = FW_MAX_K; s >= 1; --s) {
+        cnt[s] = (s <= max_k) ? binom_u64(a, s) : 0ull;
+        N += cnt[s];
+        if (N > (1ull << 62)) N = 1ull << 62;
+    }
+    const unsigned long long Ncap = (max_tests > 0 && (unsigned long long)max_tests < N) ? (unsigned long long)max_tests : N;
+    __syncthreads();
+
+    const unsigned long long NONE = ~0ull;
+    unsigned long long evaluated = 0;
+    for (unsigned long long base = 0; base < Ncap; base += 256) {
+        const unsigned long long r = base + tid;
+        const bool valid = r < Ncap;
+        double stat = 0.0, pv = 0.0;
+        int zs[FW_MAX_K];
+        int s_sz = 0;
+        if (valid) {
+            unsigned long long rem = r;
+            int s = max_k;
+            while (s > 1 && rem >= cnt[s]) {
+                rem -= cnt[s];
+                --s;
+            }
+            s_sz = s;
+            int pos[FW_MAX_K];
+            unrank_comb(rem, a, s, pos);
+#pragma unroll
+            for (int q = 0; q < FW_MAX_K; ++q) zs[q] = (q < s) ? (in_lds ? s_acc[pos[q]] : gacc[pos[q]]) : 0;
+            stat = fz_pcor_any(cor, p, job.X, job.Y, zs, s);
+            pv = fz_pval_dev(stat, zscale);
+        }
+        const bool stop = valid && (!(pv < alpha) || (max_tests > 0 && r + 1 >= (unsigned long long)max_tests));
+        // first stopping rank in the workgroup
+        const unsigned long long bm = __ballot(stop);
+        if (lane == 0) s_stop[wave] = bm ? (base + wave * 64 + (unsigned long long)__builtin_ctzll(bm)) : NONE;
+        // chunk-local maximum of (p, rank), later rank wins ties
+        double bp = valid ? pv : -1.0;
+        unsigned long long br = valid ? r : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double op = __shfl_xor(bp, o);
+            const unsigned long long orr = __shfl_xor(br, o);
+            if (op > bp || (op == bp && orr > br)) {
+                bp = op;
+                br = orr;
+            }
+        }
+        if (lane == 0) {
+            s_bp[wave] = bp;
+            s_br[wave] = br;
+        }
+        __syncthreads();
+        unsigned long long first = s_stop[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) first = s_stop[w] < first ? s_stop[w] : first;
+        const unsigned long long nvalid = (Ncap - base) < 256ull ? (Ncap - base) : 256ull;
+        evaluated += nvalid;
+        if (first != NONE) {
+            if (r == first) {
+                FwJobOut o;
+                o.stat = stat;
+                o.pval = pv;
+                o.num_tests = (long long)(first + 1);
+                o.evaluated = (long long)evaluated;
+                o.df = 0;
+                o.suff_power = 1;
+                o.status = FW_SUBSETS_STOPPED;
+                o.n_zs = s_sz;
+#pragma unroll
+                for (int q = 0; q < FW_MAX_K; ++q) o.zs[q] = zs[q];
+                o.pad[0] = o.pad[1] = o.pad[2] = 0;
+                out[blockIdx.x] = o;
+            }
+            return;
+        }
+        double cbp = s_bp[0];
+        unsigned long long cbr = s_br[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (s_bp[w] > cbp || (s_bp[w] == cbp && s_br[w] > cbr)) {
+                cbp = s_bp[w];
+                cbr = s_br[w];
+            }
+        // tests.jl:338: replace when pval >= running best (ranks only grow, so ties go to the newer chunk)
+        if (valid && r == cbr && cbp >= s_best_p) {
+            s_best_p = pv;
+            s_best_stat = stat;
+            s_best_n = s_sz;
+#pragma unroll
+            for (int q = 0; q < FW_MAX_K; ++q) s_best_zs[q] = zs[q];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        FwJobOut o;
+        o.stat = s_best_stat;
+        o.pval = s_best_p < 0.0 ? 0.0 : s_best_p;
+        o.num_tests = (long long)Ncap;
+        o.evaluated = (long long)evaluated;
+        o.df = 0;
+        o.suff_power = 1;
+        o.status = FW_SUBSETS_ALL_SIG;
+        o.n_zs = s_best_n;
+#pragma unroll
+        for (int q = 0; q < FW_MAX_K; ++q) o.zs[q] = s_best_zs[q];
+        o.pad[0] = o.pad[1] = o.pad[2] = 0;
+        out[blockIdx.x] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+static double fz_zscale(const fw_ctx *ctx)
+{
+    const long long sf = (long long)ctx->P.n - 3;  // len_z = 0 always (tests.jl:156,256)
+    return sf > 0 ? std::sqrt((double)sf) / 2.0 : 0.0;
+}
+
+int fwi_fz_compute_cor(fw_ctx *ctx)
+{
+    if (!ctx->have_data) return fw_fail(ctx, FW_ERR_STATE, "fw_compute_cor_mat: no data uploaded (fw_set_data_dense_f32)");
+    const int n = ctx->P.n, p = ctx->P.p;
+    ctx->n_pad = (n + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+    ctx->p_pad = (p + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
+    if (!ctx->d_xc) FW_HIP(ctx, hipMalloc(&ctx->d_xc, sizeof(float) * (size_t)ctx->n_pad * ctx->p_pad));
+    if (!ctx->d_sd) FW_HIP(ctx, hipMalloc(&ctx->d_sd, sizeof(float) * (size_t)ctx->p_pad));
+    if (!ctx->d_cor) FW_HIP(ctx, hipMalloc(&ctx->d_cor, sizeof(float) * (size_t)p * p));
+    hipLaunchKernelGGL(fz_center_kernel, dim3(ctx->p_pad), dim3(256), 0, ctx->stream, ctx->d_data, ctx->d_xc, ctx->d_sd, n,
+                       p, ctx->n_pad);
+    const int T = ctx->p_pad / GEMM_BM;
+    const int nblk = T * (T + 1) / 2;
+    hipLaunchKernelGGL(fz_cor_gemm_kernel, dim3(nblk), dim3(256), 0, ctx->stream, ctx->d_xc, ctx->d_sd, ctx->d_cor, p,
+                       ctx->n_pad, T);
+    FW_HIP(ctx, hipGetLastError());
+    FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->cnt.kernel_launches += 2;
+    ctx->have_cor = true;
+    return FW_OK;
+}
+
+int fwi_fz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &pj, std::vector<double> &stat,
+                  std::vector<double> &pval, int64_t *m_reliable)
+{
+    const int p = ctx->P.p;
+    const long long npairs = (long long)p * (p - 1) / 2;
+    if (ctx->P.n < ctx->n_obs_min_eff) {  // tests.jl:11 -> every test lacks power -> all NaN
+        pi.clear();
+        pj.clear();
+        stat.clear();
+        pval.clear();
+        *m_reliable = 0;
+        return FW_OK;
+    }
+    unsigned long long cap = (unsigned long long)std::min<long long>(npairs, 4ll << 20);
+    if (cap == 0) cap = 1;
+    FzL0Counters h{};
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int rc;
+        if ((rc = fw_dev_reserve(ctx, ctx->d_tmp0, sizeof(FzL0Counters)))) return rc;
+        if ((rc = fw_dev_reserve(ctx, ctx->d_tmp1, cap * (2 * sizeof(int32_t) + sizeof(float))))) return rc;
+        if ((rc = fw_dev_reserve(ctx, ctx->d_tmp2, cap * sizeof(double)))) return rc;
+        FW_HIP(ctx, hipMemsetAsync(ctx->d_tmp0.ptr, 0, sizeof(FzL0Counters), ctx->stream));
+        int32_t *oi = (int32_t *)ctx->d_tmp1.ptr;
+        int32_t *oj = oi + cap;
+        float *orr = (float *)(oj + cap);
+        double *op = (double *)ctx->d_tmp2.ptr;
+        dim3 grid((p + 255) / 256, p);
+        hipLaunchKernelGGL(fz_level0_kernel, grid, dim3(256), 0, ctx->stream, ctx->d_cor, p, ctx->P.alpha, fz_zscale(ctx),
+                           (FzL0Counters *)ctx->d_tmp0.ptr, cap, oi, oj, orr, op);
+        FW_HIP(ctx, hipGetLastError());
+        FW_HIP(ctx, hipMemcpyAsync(&h, ctx->d_tmp0.ptr, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->cnt.kernel_launches += 1;
+        if (h.n_sig <= cap) {
+            const size_t k = (size_t)h.n_sig;
+            pi.resize(k);
+            pj.resize(k);
+            stat.resize(k);
+            pval.resize(k);
+            std::vector<float> rr(k);
+            if (k) {
+                FW_HIP(ctx, hipMemcpy(pi.data(), oi, k * sizeof(int32_t), hipMemcpyDeviceToHost));
+                FW_HIP(ctx, hipMemcpy(pj.data(), oj, k * sizeof(int32_t), hipMemcpyDeviceToHost));
+                FW_HIP(ctx, hipMemcpy(rr.data(), orr, k * sizeof(float), hipMemcpyDeviceToHost));
+                FW_HIP(ctx, hipMemcpy(pval.data(), op, k * sizeof(double), hipMemcpyDeviceToHost));
+            }
+            for (size_t t = 0; t < k; ++t) stat[t] = (double)rr[t];
+            *m_reliable = npairs - (long long)h.n_nan;
+            return FW_OK;
+        }
+        cap = h.n_sig;
+    }
+    return fw_fail(ctx, FW_ERR_DEVICE, "fz level-0: compaction buffer overflow twice");
+}
+
+int fwi_fz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff,
+                      const int32_t *zflat, fw_test_result *out)
+{
+    if (m == 0) return FW_OK;
+    const int64_t nz = zoff[m];
+    int rc;
+    if ((rc = fw_dev_reserve(ctx, ctx->d_jobs, (size_t)m * 2 * sizeof(int32_t) + (size_t)(m + 1) * sizeof(int64_t)))) return rc;
+    if ((rc = fw_dev_reserve(ctx, ctx->d_acc, (size_t)(nz > 0 ? nz : 1) * sizeof(int32_t)))) return rc;
+    if ((rc = fw_dev_reserve(ctx, ctx->d_out, (size_t)m * sizeof(fw_test_result)))) return rc;
+    long long *dz = (long long *)ctx->d_jobs.ptr;
+    int32_t *dX = (int32_t *)(dz + m + 1);
+    int32_t *dY = dX + m;
+    FW_HIP(ctx, hipMemcpyAsync(dz, zoff, (size_t)(m + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    FW_HIP(ctx, hipMemcpyAsync(dX, X, (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    FW_HIP(ctx, hipMemcpyAsync(dY, Y, (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (nz > 0)
+        FW_HIP(ctx, hipMemcpyAsync(ctx->d_acc.ptr, zflat, (size_t)nz * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(fz_test_batch_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_cor,
+                       ctx->P.p, (long long)m, dX, dY, dz, (const int32_t *)ctx->d_acc.ptr, fz_zscale(ctx),
+                       (fw_test_result *)ctx->d_out.ptr);
+    FW_HIP(ctx, hipGetLastError());
+    FW_HIP(ctx, hipMemcpyAsync(out, ctx->d_out.ptr, (size_t)m * sizeof(fw_test_result), hipMemcpyDeviceToHost, ctx->stream));
+    FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->cnt.kernel_launches += 1;
+    const bool power = ctx->P.n >= ctx->n_obs_min_eff;  // tests.jl:254 / :111
+    if (!power)
+        for (int64_t t = 0; t < m; ++t) {
+            out[t].stat = 0.0;
+            out[t].pval = 1.0;
+            out[t].df = 0;
+            out[t].suff_power = 0;
+        }
+    return FW_OK;
+}
+
+int fwi_fz_subsets(fw_ctx *ctx, int64_t m, const FwJob *jobs_host, const int32_t *acc_host, int64_t acc_total,
+                   FwJobOut *out_host)
+{
+    if (m == 0) return FW_OK;
+    int rc;
+    if ((rc = fw_dev_reserve(ctx, ctx->d_jobs, (size_t)m * sizeof(FwJob)))) return rc;
+    if ((rc = fw_dev_reserve(ctx, ctx->d_acc, (size_t)(acc_total > 0 ? acc_total : 1) * sizeof(int32_t)))) return rc;
+    if ((rc = fw_dev_reserve(ctx, ctx->d_out, (size_t)m * sizeof(FwJobOut)))) return rc;
+    FW_HIP(ctx, hipMemcpyAsync(ctx->d_jobs.ptr, jobs_host, (size_t)m * sizeof(FwJob), hipMemcpyHostToDevice, ctx->stream));
+    FW_HIP(ctx, hipMemcpyAsync(ctx->d_acc.ptr, acc_host, (size_t)acc_total * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    FW_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(fz_subsets_kernel, dim3((unsigned)m), dim3(256), 0, ctx->stream, ctx->d_cor, ctx->P.p,
+                       (const FwJob *)ctx->d_jobs.ptr, (const int32_t *)ctx->d_acc.ptr, (FwJobOut *)ctx->d_out.ptr,
+                       ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests);
+    FW_HIP(ctx, hipGetLastError());
+    FW_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    FW_HIP(ctx, hipMemcpyAsync(out_host, ctx->d_out.ptr, (size_t)m * sizeof(FwJobOut), hipMemcpyDeviceToHost, ctx->stream));
+    FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0.0f;
+    FW_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->cnt.t_dev_subsets_s += 1e-3 * (double)ms;
+    ctx->cnt.kernel_launches += 1;
+    return FW_OK;
+}

@@ -1,0 +1,366 @@
+// Host driver: the caller side of the hot path, restated for hosts without Julia.
+//   LGL                      learning.jl:203-279 (target order :97-98)
+//   si_HITON_PC              hiton.jl:283-400 (interleaving/elimination via hiton_backend :109-149,
+//                            check_candidate! :80-107, update_sig_result! :53-78, update_PC_dict! :249-256)
+//   feed-forward whitelist   interleaved.jl:112-183 (as level-synchronous rounds)
+//   make_weights / make_symmetric_graph   misc.jl:137-159, 201-272
+// Every target is a small state machine; one step of the loop collects the pending (T, candidate, accepted)
+// job of every active target and runs them as ONE fw_test_subsets batch on the device.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <numeric>
+#include <unordered_map>
+
+#include "fw_internal.h"
+
+namespace {
+
+struct ODict {  // OrderedDict{Int,Tuple{Float64,Float64}}: insertion order, re-assignment keeps the slot
+    std::vector<int32_t> key;
+    std::vector<double> stat, pval;
+    int find(int32_t k) const
+    {
+        for (size_t i = 0; i < key.size(); ++i)
+            if (key[i] == k) return (int)i;
+        return -1;
+    }
+    void set(int32_t k, double s, double p)
+    {
+        int i = find(k);
+        if (i < 0) {
+            key.push_back(k);
+            stat.push_back(s);
+            pval.push_back(p);
+        } else {
+            stat[i] = s;
+            pval[i] = p;
+        }
+    }
+};
+
+struct Target {
+    int32_t T = 0;
+    int phase = 0;  // 0 = interleaving, 1 = elimination, 2 = finished
+    size_t pos = 0;
+    std::vector<int32_t> cands;   // current phase's candidate list
+    std::vector<int32_t> acc;     // accepted (conditioning pool)
+    ODict TPC, PC;
+    const int32_t *wl = nullptr;  // sorted whitelist (snapshot of the running graph)
+    int wl_n = 0;
+    bool in_wl(int32_t v) const { return wl_n > 0 && std::binary_search(wl, wl + wl_n, v); }
+};
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+// Advance a target until it needs a device test (returns true, job = (T, cands[pos], acc)) or finishes.
+static bool advance(const fw_ctx *c, Target &t)
+{
+    const int64_t o = c->nb_off[t.T];
+    const int deg = (int)(c->nb_off[t.T + 1] - o);
+    auto univar = [&](int32_t v, double &s, double &p) {
+        const int32_t *b = c->nb_idx.data() + o;
+        const int32_t *it = std::lower_bound(b, b + deg, v);
+        s = c->nb_stat[o + (it - b)];
+        p = c->nb_p[o + (it - b)];
+    };
+    for (;;) {
+        if (t.phase == 2) return false;
+        ODict &dict = t.phase == 0 ? t.TPC : t.PC;
+        while (t.pos < t.cands.size()) {
+            const int32_t cand = t.cands[t.pos];
+            if (t.in_wl(cand)) {  // hiton.jl:20-30
+                t.acc.push_back(cand);
+                dict.set(cand, NAN, NAN);
+                ++t.pos;
+                continue;
+            }
+            if (t.phase == 1)  // hiton.jl:134-136
+                t.acc.erase(std::remove(t.acc.begin(), t.acc.end(), cand), t.acc.end());
+            if (t.acc.empty()) {  // tests.jl:285 sentinel + hiton.jl:57-59
+                double s, p;
+                if (t.phase == 0) {
+                    univar(cand, s, p);
+                } else {
+                    const int i = t.TPC.find(cand);
+                    s = t.TPC.stat[i];
+                    p = t.TPC.pval[i];
+                }
+                t.acc.push_back(cand);
+                dict.set(cand, s, p);
+                ++t.pos;
+                continue;
+            }
+            return true;
+        }
+        if (t.phase == 0) {  // hiton.jl:242: elimination over keys(TPC) in insertion order
+            t.phase = 1;
+            t.cands = t.TPC.key;
+            t.acc = t.cands;
+            t.pos = 0;
+        } else {  // hiton.jl:249-256 update_PC_dict!
+            for (size_t i = 0; i < t.PC.key.size(); ++i) {
+                const int ti = t.TPC.find(t.PC.key[i]);
+                if (ti >= 0 && (t.TPC.pval[ti] > t.PC.pval[i] || std::isnan(t.PC.pval[i]))) {
+                    t.PC.stat[i] = t.TPC.stat[ti];
+                    t.PC.pval[i] = t.TPC.pval[ti];
+                }
+            }
+            t.phase = 2;
+        }
+    }
+}
+
+static double maxweight(double w1, double w2)
+{  // misc.jl:201-218
+    if (std::isnan(w1)) return w2;
+    if (std::isnan(w2)) return w1;
+    const double s1 = (w1 > 0) - (w1 < 0), s2 = (w2 > 0) - (w2 < 0);
+    if (s1 * s2 < 0) return w1;  // "arbitrarily choosing one": the lower-index endpoint's direction
+    return std::max(std::fabs(w1), std::fabs(w2)) * s1;
+}
+
+extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allgather_fn allgather, void *user,
+                                int64_t *n_edges_out)
+{
+    if (!c) return fw_fail(nullptr, FW_ERR_ARG, "NULL context");
+    (void)hipSetDevice(c->P.device);
+    fw_learn_opts opt{};
+    opt.feed_forward = 1;
+    opt.round_size = 1;
+    opt.world_size = 1;
+    if (opts_in) opt = *opts_in;
+    if (opt.world_size < 1) opt.world_size = 1;
+    if (opt.rank < 0 || opt.rank >= opt.world_size) return fw_fail(c, FW_ERR_ARG, "fw_learn_network: rank %d outside world of %d", opt.rank, opt.world_size);
+    if (opt.world_size > 1 && !allgather) return fw_fail(c, FW_ERR_ARG, "fw_learn_network: world_size > 1 needs an allgather callback");
+    if (!c->have_level0) {
+        int rc = fw_level0(c, nullptr);
+        if (rc) return rc;
+    }
+    const int p = c->P.p;
+    const bool discrete = c->P.kind != FW_FZ;
+    const double t0 = now_s();
+
+    // learning.jl:97-98: ascending univariate degree, stable
+    std::vector<int32_t> order(p);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        return (c->nb_off[a + 1] - c->nb_off[a]) < (c->nb_off[b + 1] - c->nb_off[b]);
+    });
+    int nt = p;
+    if (opt.max_targets > 0 && opt.max_targets < p) nt = opt.max_targets;
+
+    // per-target directed results (all ranks hold all of them after each round's exchange)
+    std::vector<std::vector<int32_t>> pc_key(p);
+    std::vector<std::vector<double>> pc_stat(p), pc_p(p);
+    std::vector<std::vector<int32_t>> adj(p);  // running graph, sorted
+
+    if (c->P.max_k == 0) {  // learning.jl:171-172
+        for (int v = 0; v < p; ++v) {
+            const int64_t o = c->nb_off[v];
+            const int deg = (int)(c->nb_off[v + 1] - o);
+            pc_key[v].assign(c->nb_idx.begin() + o, c->nb_idx.begin() + o + deg);
+            pc_stat[v].assign(c->nb_stat.begin() + o, c->nb_stat.begin() + o + deg);
+            pc_p[v].assign(c->nb_p.begin() + o, c->nb_p.begin() + o + deg);
+        }
+    } else {
+        const int R = (opt.round_size <= 0) ? nt : opt.round_size;
+        std::vector<FwJob> jobs;
+        std::vector<int32_t> accflat;
+        std::vector<FwJobOut> jout;
+        std::vector<int> jt;
+        for (int r0 = 0; r0 < nt; r0 += R) {
+            const int r1 = std::min(nt, r0 + R);
+            // this rank's targets of the round: dealt round-robin in schedule order
+            std::vector<Target> tg;
+            for (int i = r0; i < r1; ++i) {
+                if ((i - r0) % opt.world_size != opt.rank) continue;
+                Target t;
+                t.T = order[i];
+                if (discrete && c->levels[t.T] < 2) {  // hiton.jl:182-184
+                    t.phase = 2;
+                    tg.push_back(std::move(t));
+                    continue;
+                }
+                // hiton.jl:211-217: candidates with adj p < alpha, stable sort by p
+                const int64_t o = c->nb_off[t.T];
+                const int deg = (int)(c->nb_off[t.T + 1] - o);
+                std::vector<int32_t> idx;
+                for (int q = 0; q < deg; ++q)
+                    if (c->nb_p[o + q] < c->P.alpha) idx.push_back(q);
+                std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return c->nb_p[o + a] < c->nb_p[o + b]; });
+                for (int32_t q : idx) t.cands.push_back(c->nb_idx[o + q]);
+                if (t.cands.empty()) t.phase = 2;  // hiton.jl:336-338
+                if (opt.feed_forward && !adj[t.T].empty()) {
+                    t.wl = adj[t.T].data();  // adj is only modified between rounds
+                    t.wl_n = (int)adj[t.T].size();
+                }
+                tg.push_back(std::move(t));
+            }
+            // level-synchronous steps
+            std::vector<int> active(tg.size());
+            std::iota(active.begin(), active.end(), 0);
+            while (!active.empty()) {
+                jobs.clear();
+                accflat.clear();
+                jt.clear();
+                for (int ti : active) {
+                    Target &t = tg[ti];
+                    if (!advance(c, t)) continue;
+                    FwJob j{};
+                    j.X = t.T;
+                    j.Y = t.cands[t.pos];
+                    j.acc_off = (int64_t)accflat.size();
+                    j.acc_len = (int32_t)t.acc.size();
+                    accflat.insert(accflat.end(), t.acc.begin(), t.acc.end());
+                    jobs.push_back(j);
+                    jt.push_back(ti);
+                }
+                if (jobs.empty()) break;
+                jout.resize(jobs.size());
+                int rc = fwi_subsets_dispatch(c, (int64_t)jobs.size(), jobs.data(), accflat.data(), (int64_t)accflat.size(), jout.data());
+                if (rc) return rc;
+                for (size_t q = 0; q < jobs.size(); ++q) {
+                    Target &t = tg[jt[q]];
+                    const FwJobOut &o = jout[q];
+                    c->cnt.cond_tests_ref += o.num_tests;
+                    c->cnt.cond_tests_evaluated += o.evaluated;
+                    c->cnt.alg_bytes_subsets += fwi_alg_bytes(c, jobs[q].acc_len, o.evaluated);
+                    c->cnt.subsets_calls += 1;
+                    const int32_t cand = t.cands[t.pos];
+                    if (o.pval < c->P.alpha && o.suff_power) {  // issig, tests.jl:1-3; hiton.jl:61-63
+                        t.acc.push_back(cand);
+                        (t.phase == 0 ? t.TPC : t.PC).set(cand, o.stat, o.pval);
+                    }
+                    ++t.pos;
+                }
+                active.swap(jt);
+            }
+            // exchange this round's directed results (target, neighbour, stat, p)
+            std::vector<int32_t> lt, ln;
+            std::vector<double> ls, lp;
+            for (Target &t : tg)
+                for (size_t i = 0; i < t.PC.key.size(); ++i) {
+                    lt.push_back(t.T);
+                    ln.push_back(t.PC.key[i]);
+                    ls.push_back(t.PC.stat[i]);
+                    lp.push_back(t.PC.pval[i]);
+                }
+            int64_t ntot = (int64_t)lt.size();
+            const int32_t *at = lt.data(), *an = ln.data();
+            const double *as = ls.data(), *ap = lp.data();
+            if (opt.world_size > 1) {
+                int rc = allgather(user, (int64_t)lt.size(), lt.data(), ln.data(), ls.data(), lp.data(), &ntot, &at, &an, &as, &ap);
+                if (rc) return fw_fail(c, FW_ERR_ARG, "fw_learn_network: allgather callback failed (%d)", rc);
+            }
+            for (int64_t i = 0; i < ntot; ++i) {
+                const int32_t T = at[i], u = an[i];
+                pc_key[T].push_back(u);
+                pc_stat[T].push_back(as[i]);
+                pc_p[T].push_back(ap[i]);
+            }
+            for (int64_t i = 0; i < ntot; ++i) {  // interleaved.jl:136-140 add_edge! (idempotent)
+                const int32_t T = at[i], u = an[i];
+                auto ins = [&](std::vector<int32_t> &v, int32_t x) {
+                    auto it = std::lower_bound(v.begin(), v.end(), x);
+                    if (it == v.end() || *it != x) v.insert(it, x);
+                };
+                ins(adj[T], u);
+                ins(adj[u], T);
+            }
+        }
+    }
+    c->cnt.t_cond_s += now_s() - t0;
+
+    // misc.jl:137-159 make_weights ("cond_stat"): discrete tests take the sign of the univariate statistic
+    std::vector<std::vector<double>> w(p);
+    for (int T = 0; T < p; ++T) {
+        w[T] = pc_stat[T];
+        if (!discrete) continue;
+        const int64_t o = c->nb_off[T];
+        const int deg = (int)(c->nb_off[T + 1] - o);
+        const int32_t *b = c->nb_idx.data() + o;
+        for (size_t i = 0; i < pc_key[T].size(); ++i) {
+            const int32_t *it = std::lower_bound(b, b + deg, pc_key[T][i]);
+            const double us = (it != b + deg && *it == pc_key[T][i]) ? c->nb_stat[o + (it - b)] : NAN;
+            const double sg = std::isnan(us) ? NAN : (double)((us > 0) - (us < 0));
+            w[T][i] = sg * std::fabs(pc_stat[T][i]);
+        }
+    }
+    c->pc_off.assign((size_t)p + 1, 0);
+    for (int T = 0; T < p; ++T) c->pc_off[T + 1] = c->pc_off[T] + (int64_t)pc_key[T].size();
+    c->pc_idx.clear();
+    c->pc_w.clear();
+    c->pc_p.clear();
+    for (int T = 0; T < p; ++T) {
+        c->pc_idx.insert(c->pc_idx.end(), pc_key[T].begin(), pc_key[T].end());
+        c->pc_w.insert(c->pc_w.end(), w[T].begin(), w[T].end());
+        c->pc_p.insert(c->pc_p.end(), pc_p[T].begin(), pc_p[T].end());
+    }
+    // misc.jl:230-272 make_symmetric_graph (OR rule, maxweight merge, NaN edges dropped)
+    c->e_src.clear();
+    c->e_dst.clear();
+    c->e_w.clear();
+    auto find_in = [&](int T, int32_t u) -> int {
+        for (size_t i = 0; i < pc_key[T].size(); ++i)
+            if (pc_key[T][i] == u) return (int)i;
+        return -1;
+    };
+    for (int a = 0; a < p; ++a) {
+        for (size_t i = 0; i < pc_key[a].size(); ++i) {  // direction a -> b exists
+            const int32_t b = pc_key[a][i];
+            if (b <= a) continue;
+            const int ri = find_in(b, a);
+            const double ww = maxweight(w[a][i], ri >= 0 ? w[b][ri] : NAN);
+            if (std::isnan(ww)) continue;
+            c->e_src.push_back(a);
+            c->e_dst.push_back(b);
+            c->e_w.push_back(ww);
+        }
+        for (int32_t b : adj[a]) {  // only b -> a exists
+            if (b <= a || find_in(a, b) >= 0) continue;
+            const int ri = find_in(b, a);
+            if (ri < 0) continue;
+            const double ww = maxweight(w[b][ri], NAN);
+            if (std::isnan(ww)) continue;
+            c->e_src.push_back(a);
+            c->e_dst.push_back(b);
+            c->e_w.push_back(ww);
+        }
+    }
+    if (c->P.max_k == 0) {
+        // adj was not maintained: every neighbour list is symmetric at level 0, the first loop covers all edges
+    }
+    c->have_network = true;
+    if (n_edges_out) *n_edges_out = (int64_t)c->e_src.size();
+    return FW_OK;
+}
+
+extern "C" int fw_network_get(const fw_ctx *c, int32_t *src, int32_t *dst, double *weight)
+{
+    if (!c) return fw_fail(nullptr, FW_ERR_ARG, "NULL context");
+    if (!c->have_network) return fw_fail(c, FW_ERR_STATE, "fw_network_get: fw_learn_network has not run");
+    const size_t k = c->e_src.size();
+    if (k) {
+        if (src) memcpy(src, c->e_src.data(), sizeof(int32_t) * k);
+        if (dst) memcpy(dst, c->e_dst.data(), sizeof(int32_t) * k);
+        if (weight) memcpy(weight, c->e_w.data(), sizeof(double) * k);
+    }
+    return FW_OK;
+}
+
+extern "C" int fw_network_get_directed(const fw_ctx *c, int64_t *off, int32_t *idx, double *weight, double *pval)
+{
+    if (!c) return fw_fail(nullptr, FW_ERR_ARG, "NULL context");
+    if (!c->have_network) return fw_fail(c, FW_ERR_STATE, "fw_network_get_directed: fw_learn_network has not run");
+    if (off) memcpy(off, c->pc_off.data(), sizeof(int64_t) * c->pc_off.size());
+    const size_t k = c->pc_idx.size();
+    if (k) {
+        if (idx) memcpy(idx, c->pc_idx.data(), sizeof(int32_t) * k);
+        if (weight) memcpy(weight, c->pc_w.data(), sizeof(double) * k);
+        if (pval) memcpy(pval, c->pc_p.data(), sizeof(double) * k);
+    }
+    return FW_OK;
+}

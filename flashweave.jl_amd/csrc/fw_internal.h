@@ -1,0 +1,127 @@
+// Internal declarations shared by the translation units of libflashweave_amd.so.
+// Nothing here is part of the ABI (include/flashweave_amd.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/flashweave_amd.h"
+
+struct FwDevBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+};
+
+struct FwPinned {
+    void *ptr = nullptr;
+    size_t cap = 0;
+};
+
+// Job descriptor for the test_subsets kernels (device layout)
+struct FwJob {
+    int32_t X;        // T
+    int32_t Y;        // candidate
+    int64_t acc_off;  // offset into the flat accepted array
+    int32_t acc_len;  // |accepted|
+    int32_t pad;
+};
+
+// Device-side result of one job (mirrors fw_subsets_result without frac)
+struct FwJobOut {
+    double stat;
+    double pval;
+    int64_t num_tests;  // reference-equivalent count
+    int64_t evaluated;  // tests evaluated by the kernel (speculation included)
+    int32_t df;
+    int32_t suff_power;
+    int32_t status;
+    int32_t n_zs;
+    int32_t zs[FW_MAX_K];
+    int32_t pad[3];
+};
+
+struct fw_ctx {
+    fw_params P{};
+    int64_t n_obs_min_eff = 0;
+    mutable std::string err;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // ---- continuous (FW_FZ) ----
+    float *d_data = nullptr;  // n x p column-major, as uploaded
+    float *d_xc = nullptr;    // centred columns, [p_pad][n_pad], zero padded
+    float *d_sd = nullptr;    // sqrt(sum xc^2) per column, [p_pad]
+    float *d_cor = nullptr;   // p x p (symmetric)
+    int n_pad = 0, p_pad = 0;
+    bool have_data = false, have_cor = false;
+
+    // ---- discrete (FW_MI / FW_MI_NZ) ----
+    std::vector<int32_t> levels, max_vals;
+    int L = 0;                   // maximum(max_vals) + 1
+    int W = 0;                   // 64-bit words per packed column
+    uint64_t *d_nzbits = nullptr;  // [p][W] bit i of word w: sample 64w+i has value != 0
+    uint64_t *d_hibits = nullptr;  // [p][W] value == 2 (second non-zero level); NULL when L == 2
+    int32_t *d_levels = nullptr, *d_maxvals = nullptr;
+    int32_t *d_firstnz = nullptr;  // per column: index of the first non-zero sample (n if none)
+
+    // ---- level-0 result (host, CSR) ----
+    bool have_level0 = false;
+    std::vector<int64_t> nb_off;
+    std::vector<int32_t> nb_idx;
+    std::vector<double> nb_stat, nb_p;
+
+    // ---- network result ----
+    bool have_network = false;
+    std::vector<int32_t> e_src, e_dst;
+    std::vector<double> e_w;
+    std::vector<int64_t> pc_off;
+    std::vector<int32_t> pc_idx;
+    std::vector<double> pc_w, pc_p;
+
+    fw_counters cnt{};
+
+    // grow-only scratch
+    FwDevBuf d_jobs, d_acc, d_out, d_tmp0, d_tmp1, d_tmp2;
+    FwPinned h_jobs, h_acc, h_out;
+};
+
+int fw_fail(const fw_ctx *ctx, int code, const char *fmt, ...);
+int fw_dev_reserve(fw_ctx *ctx, FwDevBuf &b, size_t bytes);
+int fw_pin_reserve(fw_ctx *ctx, FwPinned &b, size_t bytes);
+
+#define FW_HIP(ctx, call)                                                                        \
+    do {                                                                                         \
+        hipError_t e__ = (call);                                                                 \
+        if (e__ != hipSuccess)                                                                   \
+            return fw_fail(ctx, FW_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                           __FILE__, __LINE__);                                                  \
+    } while (0)
+
+// ---- fz (fw_fz.hip) ----
+int fwi_fz_compute_cor(fw_ctx *ctx);
+int fwi_fz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &pj, std::vector<double> &stat,
+                  std::vector<double> &pval, int64_t *m_reliable);
+int fwi_fz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff,
+                      const int32_t *zflat, fw_test_result *out);
+int fwi_fz_subsets(fw_ctx *ctx, int64_t m, const FwJob *jobs_host, const int32_t *acc_host, int64_t acc_total,
+                   FwJobOut *out_host);
+
+// ---- discrete (fw_mi.hip) ----
+int fwi_mi_upload(fw_ctx *ctx, const int64_t *colptr, const int32_t *rowval, const int32_t *nzval);
+int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &pj, std::vector<double> &stat,
+                  std::vector<double> &pval, int64_t *m_reliable);
+int fwi_mi_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff,
+                      const int32_t *zflat, fw_test_result *out);
+int fwi_mi_subsets(fw_ctx *ctx, int64_t m, const FwJob *jobs_host, const int32_t *acc_host, int64_t acc_total,
+                   FwJobOut *out_host);
+
+// algorithmic bytes of the first `evaluated` tests of a job with |accepted| = a (enumeration order: sizes max_k..1)
+double fwi_alg_bytes(const fw_ctx *ctx, int a, int64_t evaluated);
+
+// ---- host driver (fw_hiton.cpp) ----
+int fwi_subsets_dispatch(fw_ctx *ctx, int64_t m, const FwJob *jobs_host, const int32_t *acc_host, int64_t acc_total,
+                         FwJobOut *out_host);

@@ -1,0 +1,261 @@
+"""ctypes binding of include/flashweave_amd.h and the Python mirror of the reference's operator interface."""
+import ctypes as C
+import os
+from collections import namedtuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+FW_MI, FW_MI_NZ, FW_FZ = 0, 1, 2
+FW_MAX_K = 5
+_KINDS = {"mi": FW_MI, "mi_nz": FW_MI_NZ, "fz": FW_FZ}
+
+TestResult = namedtuple("TestResult", "stat pval df suff_power")  # src/types.jl:140-145
+
+
+class FlashWeaveError(RuntimeError):
+    """Raised for every non-zero ABI status (the reference throws Julia exceptions, e.g. learning.jl:72)."""
+
+    def __init__(self, code, msg):
+        super().__init__("[fw %d] %s" % (code, msg))
+        self.code = code
+
+
+class _Params(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n", C.c_int32), ("p", C.c_int32), ("device", C.c_int32),
+                ("max_k", C.c_int32), ("hps", C.c_int32), ("fdr", C.c_int32), ("reserved0", C.c_int32),
+                ("n_obs_min", C.c_int64), ("max_tests", C.c_int64), ("alpha", C.c_double)]
+
+
+class _TestResult(C.Structure):
+    _fields_ = [("stat", C.c_double), ("pval", C.c_double), ("df", C.c_int32), ("suff_power", C.c_int32)]
+
+
+class _SubsetsResult(C.Structure):
+    _fields_ = [("stat", C.c_double), ("pval", C.c_double), ("df", C.c_int32), ("suff_power", C.c_int32),
+                ("status", C.c_int32), ("n_zs", C.c_int32), ("zs", C.c_int32 * FW_MAX_K), ("reserved0", C.c_int32),
+                ("num_tests", C.c_int64), ("frac", C.c_double)]
+
+
+class _Counters(C.Structure):
+    _fields_ = [("level0_tests", C.c_int64), ("cond_tests_ref", C.c_int64), ("cond_tests_evaluated", C.c_int64),
+                ("subsets_calls", C.c_int64), ("kernel_launches", C.c_int64), ("t_level0_s", C.c_double),
+                ("t_cond_s", C.c_double), ("t_dev_subsets_s", C.c_double), ("alg_bytes_subsets", C.c_double)]
+
+
+class _LearnOpts(C.Structure):
+    _fields_ = [("feed_forward", C.c_int32), ("round_size", C.c_int32), ("rank", C.c_int32),
+                ("world_size", C.c_int32), ("max_targets", C.c_int32), ("reserved0", C.c_int32)]
+
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                           C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32)),
+                           C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.POINTER(C.c_double)))
+
+_LIB = None
+
+
+def lib_path():
+    return os.path.join(_HERE, "libflashweave_amd.so")
+
+
+def load_library():
+    """dlopen the in-tree library.  torch (if importable) is imported first so that a single HIP runtime
+    (libamdhip64.so.7) ends up in the process."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = lib_path()
+    if not os.path.exists(so):
+        raise FlashWeaveError(-2, "libflashweave_amd.so is missing (run __graft_entry__.build()); there is no "
+                                  "CPU fallback for the HIP path")
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = C.CDLL(so)
+    vp = C.c_void_p
+    L.fw_abi_version.restype = C.c_int
+    L.fw_params_default.argtypes = [C.POINTER(_Params), C.c_int32, C.c_int32, C.c_int32]
+    L.fw_ctx_create.argtypes = [C.POINTER(_Params), C.POINTER(vp)]
+    L.fw_ctx_destroy.argtypes = [vp]
+    L.fw_last_error.restype = C.c_char_p
+    L.fw_last_error.argtypes = [vp]
+    L.fw_set_data_dense_f32.argtypes = [vp, vp]
+    L.fw_set_data_csc_i32.argtypes = [vp, vp, vp, vp]
+    L.fw_set_data_dense_i32.argtypes = [vp, vp]
+    L.fw_get_levels.argtypes = [vp, vp, vp]
+    L.fw_set_cor_mat.argtypes = [vp, vp]
+    L.fw_compute_cor_mat.argtypes = [vp]
+    L.fw_get_cor_mat.argtypes = [vp, vp]
+    L.fw_level0.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.fw_level0_get.argtypes = [vp, vp, vp, vp, vp]
+    L.fw_test_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
+    L.fw_test_subsets_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
+    L.fw_learn_network.argtypes = [vp, C.POINTER(_LearnOpts), vp, vp, C.POINTER(C.c_int64)]
+    L.fw_network_get.argtypes = [vp, vp, vp, vp]
+    L.fw_network_get_directed.argtypes = [vp, vp, vp, vp, vp]
+    L.fw_get_counters.argtypes = [vp, C.POINTER(_Counters)]
+    L.fw_reset_counters.argtypes = [vp]
+    L.fw_effective_n_obs_min.restype = C.c_int64
+    L.fw_effective_n_obs_min.argtypes = [vp]
+    _LIB = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Engine:
+    """One engine context on one GPU (replaces make_test_object, src/misc.jl:34-45).
+
+    test_name: "mi" | "mi_nz" | "fz" (src/types.jl:64-72).  Keyword defaults are learn_network's
+    (src/learning.jl:466-473)."""
+
+    def __init__(self, test_name, n, p, max_k=3, alpha=0.01, hps=5, n_obs_min=-1, max_tests=10_000_000, FDR=True,
+                 device=0):
+        self.L = load_library()
+        self.test_name = test_name
+        self.n, self.p = int(n), int(p)
+        P = _Params()
+        self.L.fw_params_default(C.byref(P), _KINDS[test_name], self.n, self.p)
+        P.device, P.max_k, P.alpha, P.hps = device, max_k, alpha, hps
+        P.n_obs_min, P.max_tests, P.fdr = n_obs_min, max_tests, int(FDR)
+        self.h = C.c_void_p()
+        rc = self.L.fw_ctx_create(C.byref(P), C.byref(self.h))
+        if rc != 0:
+            raise FlashWeaveError(rc, self.L.fw_last_error(None).decode())
+        self.max_k = max_k
+        self._cb = None
+
+    # -- plumbing ------------------------------------------------------------------------------------
+    def _ck(self, rc):
+        if rc != 0:
+            raise FlashWeaveError(rc, self.L.fw_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.fw_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- data ----------------------------------------------------------------------------------------
+    def set_data(self, data):
+        """fz: dense Float32 n x p; mi / mi_nz: integer n x p (dense ndarray) or a (colptr, rowval, nzval) CSC triple
+        with 0-based rows."""
+        if self.test_name == "fz":
+            d = np.asfortranarray(np.asarray(data, dtype=np.float32))
+            assert d.shape == (self.n, self.p)
+            self._ck(self.L.fw_set_data_dense_f32(self.h, _ptr(d)))
+        elif isinstance(data, tuple):
+            colptr, rowval, nzval = (np.ascontiguousarray(data[0], dtype=np.int64),
+                                     np.ascontiguousarray(data[1], dtype=np.int32),
+                                     np.ascontiguousarray(data[2], dtype=np.int32))
+            self._ck(self.L.fw_set_data_csc_i32(self.h, _ptr(colptr), _ptr(rowval), _ptr(nzval)))
+        else:
+            d = np.asfortranarray(np.asarray(data, dtype=np.int32))
+            assert d.shape == (self.n, self.p)
+            self._ck(self.L.fw_set_data_dense_i32(self.h, _ptr(d)))
+
+    def set_cor_mat(self, cor_mat):
+        cm = np.asfortranarray(np.asarray(cor_mat, dtype=np.float32))
+        assert cm.shape == (self.p, self.p)
+        self._ck(self.L.fw_set_cor_mat(self.h, _ptr(cm)))
+
+    def cor(self):
+        """cor(data_dense) -> Float32 p x p, on the MFMA units (src/learning.jl:44)."""
+        self._ck(self.L.fw_compute_cor_mat(self.h))
+        return self.cor_mat()
+
+    def cor_mat(self):
+        out = np.zeros((self.p, self.p), dtype=np.float32, order="F")
+        self._ck(self.L.fw_get_cor_mat(self.h, _ptr(out)))
+        return out
+
+    def levels(self):
+        lv, mv = np.zeros(self.p, np.int32), np.zeros(self.p, np.int32)
+        self._ck(self.L.fw_get_levels(self.h, _ptr(lv), _ptr(mv)))
+        return lv, mv
+
+    @property
+    def n_obs_min(self):
+        return int(self.L.fw_effective_n_obs_min(self.h))
+
+    # -- level 0 -------------------------------------------------------------------------------------
+    def pw_univar_neighbors(self):
+        """pw_univar_neighbors (src/tests.jl:436-532) -> CSR dict(off, idx, stat, pval)."""
+        nnz = C.c_int64(0)
+        self._ck(self.L.fw_level0(self.h, C.byref(nnz)))
+        off = np.zeros(self.p + 1, np.int64)
+        k = max(nnz.value, 1)
+        idx, stat, pv = np.zeros(k, np.int32), np.zeros(k, np.float64), np.zeros(k, np.float64)
+        self._ck(self.L.fw_level0_get(self.h, _ptr(off), _ptr(idx), _ptr(stat), _ptr(pv)))
+        return dict(off=off, idx=idx[:nnz.value], stat=stat[:nnz.value], pval=pv[:nnz.value])
+
+    # -- single tests --------------------------------------------------------------------------------
+    def test_batch(self, X, Y, Zs_list):
+        """Batch of test(X, Y, Zs, ...) (src/tests.jl:28,108,184,250)."""
+        m = len(X)
+        Xa, Ya = np.asarray(X, np.int32), np.asarray(Y, np.int32)
+        zoff = np.zeros(m + 1, np.int64)
+        for i, z in enumerate(Zs_list):
+            zoff[i + 1] = zoff[i] + len(z)
+        zflat = np.array([v for z in Zs_list for v in z] or [0], dtype=np.int32)
+        out = (_TestResult * m)()
+        self._ck(self.L.fw_test_batch(self.h, m, _ptr(Xa), _ptr(Ya), _ptr(zoff), _ptr(zflat), out))
+        return [TestResult(o.stat, o.pval, o.df, bool(o.suff_power)) for o in out]
+
+    def test(self, X, Y, Zs=()):
+        return self.test_batch([X], [Y], [tuple(Zs)])[0]
+
+    def test_subsets_batch(self, T, cand, accepted_list):
+        """Batch of test_subsets(T, candidate, accepted, ...) (src/tests.jl:281-346)."""
+        m = len(T)
+        Ta, Ca = np.asarray(T, np.int32), np.asarray(cand, np.int32)
+        off = np.zeros(m + 1, np.int64)
+        for i, a in enumerate(accepted_list):
+            off[i + 1] = off[i] + len(a)
+        flat = np.array([v for a in accepted_list for v in a] or [0], dtype=np.int32)
+        out = (_SubsetsResult * m)()
+        self._ck(self.L.fw_test_subsets_batch(self.h, m, _ptr(Ta), _ptr(Ca), _ptr(off), _ptr(flat), out))
+        return [dict(status=o.status, stat=o.stat, pval=o.pval, df=o.df, suff_power=bool(o.suff_power),
+                     Zs=tuple(o.zs[:o.n_zs]), num_tests=o.num_tests, frac=o.frac) for o in out]
+
+    def test_subsets(self, T, cand, accepted):
+        return self.test_subsets_batch([T], [cand], [list(accepted)])[0]
+
+    # -- LGL -----------------------------------------------------------------------------------------
+    def lgl(self, feed_forward=True, round_size=1, rank=0, world_size=1, max_targets=0, allgather=None):
+        """LGL minus normalisation (src/learning.jl:203-279).  Returns dict(edges={(i,j): w}, directed=CSR)."""
+        opts = _LearnOpts(int(feed_forward), int(round_size), int(rank), int(world_size), int(max_targets), 0)
+        ne = C.c_int64(0)
+        cb = None
+        if allgather is not None:
+            cb = ALLGATHER_FN(allgather)
+            self._cb = cb
+        self._ck(self.L.fw_learn_network(self.h, C.byref(opts), C.cast(cb, C.c_void_p) if cb else None, None, C.byref(ne)))
+        k = max(ne.value, 1)
+        src, dst, w = np.zeros(k, np.int32), np.zeros(k, np.int32), np.zeros(k, np.float64)
+        self._ck(self.L.fw_network_get(self.h, _ptr(src), _ptr(dst), _ptr(w)))
+        off = np.zeros(self.p + 1, np.int64)
+        self._ck(self.L.fw_network_get_directed(self.h, _ptr(off), None, None, None))
+        kk = max(int(off[-1]), 1)
+        idx, pw, pp = np.zeros(kk, np.int32), np.zeros(kk, np.float64), np.zeros(kk, np.float64)
+        self._ck(self.L.fw_network_get_directed(self.h, _ptr(off), _ptr(idx), _ptr(pw), _ptr(pp)))
+        edges = {(int(a), int(b)): float(x) for a, b, x in zip(src[:ne.value], dst[:ne.value], w[:ne.value])}
+        return dict(edges=edges, pc_off=off, pc_idx=idx[:off[-1]], pc_weight=pw[:off[-1]], pc_pval=pp[:off[-1]])
+
+    def counters(self):
+        cn = _Counters()
+        self._ck(self.L.fw_get_counters(self.h, C.byref(cn)))
+        return {f: getattr(cn, f) for f, _ in _Counters._fields_}
+
+    def reset_counters(self):
+        self._ck(self.L.fw_reset_counters(self.h))

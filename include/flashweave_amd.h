@@ -1,0 +1,201 @@
+/*
+ * flashweave_amd.h -- C ABI of the MI355X-native conditional-independence engine for FlashWeave.
+ *
+ * This is the drop-in boundary for ONE path of the reference (FlashWeave.jl, /root/reference): the
+ * per-pair CI test batch + the level-0 all-pairs stage (src/tests.jl, src/contingency.jl, src/statfuns.jl).
+ * The reference has no FFI for it; the seam is Julia multiple dispatch on `test_obj::AbstractTest`
+ * (src/types.jl:57-59).  Each entry point below names the reference call edge it replaces, and
+ * INTEGRATION.md shows the `ccall` methods a maintainer would add for a `GpuTest <: AbstractTest`.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all buffers are caller-owned host memory unless stated otherwise;
+ *     the context owns every device allocation.
+ *   - variable indices are 0-based on this ABI (the Julia shim subtracts 1).
+ *   - data is n samples (rows) x p variables (columns), column-major, exactly as Julia holds it.
+ *   - every function returns FW_OK (0) or a negative error code; fw_last_error() gives the message.
+ *     Invalid input never aborts the process (reference: error()/@assert, e.g. src/learning.jl:72).
+ *   - a context is used by one host thread at a time; calls are blocking; one context per GPU.
+ *   - there is NO CPU fallback: if no gfx950 device is usable, fw_ctx_create fails with FW_ERR_DEVICE.
+ */
+#ifndef FLASHWEAVE_AMD_H
+#define FLASHWEAVE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FW_ABI_VERSION 1
+
+/* test kinds: src/types.jl:61-72 (test_name "mi" / "mi_nz" / "fz") */
+#define FW_MI 0
+#define FW_MI_NZ 1
+#define FW_FZ 2
+
+#define FW_OK 0
+#define FW_ERR_ARG (-1)     /* invalid argument */
+#define FW_ERR_DEVICE (-2)  /* no usable gfx950 device / HIP runtime error */
+#define FW_ERR_STATE (-3)   /* call order violated (e.g. level-0 before data upload) */
+#define FW_ERR_NOBS (-4)    /* n_obs_min exceeds the number of samples (src/learning.jl:66-73) */
+#define FW_ERR_LIMIT (-5)   /* a documented capacity limit was exceeded (max_k, table size) */
+#define FW_ERR_NOMEM (-6)
+
+#define FW_MAX_K 5 /* largest conditioning-set size the kernels support */
+
+typedef struct fw_ctx fw_ctx;
+
+/* Engine parameters; defaults follow learn_network / LGL (src/learning.jl:203-214,466-473). */
+typedef struct fw_params {
+    int32_t kind;      /* FW_MI / FW_MI_NZ / FW_FZ */
+    int32_t n;         /* samples (rows) */
+    int32_t p;         /* variables (columns) */
+    int32_t device;    /* HIP device ordinal */
+    int32_t max_k;     /* default 3; 0 = univariate network only */
+    int32_t hps;       /* default 5 (heuristic power size, src/tests.jl:5-6) */
+    int32_t fdr;       /* default 1: Benjamini-Hochberg on level-0 p-values (src/tests.jl:521-529) */
+    int32_t reserved0;
+    int64_t n_obs_min; /* default -1 = automatic (src/learning.jl:51-64, fires for every test kind) */
+    int64_t max_tests; /* default 10_000_000 per (T, candidate) pair (src/learning.jl:205) */
+    double alpha;      /* default 0.01 */
+} fw_params;
+
+/* One TestResult (src/types.jl:140-145) */
+typedef struct fw_test_result {
+    double stat;
+    double pval;
+    int32_t df;
+    int32_t suff_power; /* 0 / 1 */
+} fw_test_result;
+
+/* Return of test_subsets (src/tests.jl:281-346): (TestResult, Zs, num_tests, fraction) */
+#define FW_SUBSETS_EMPTY 0    /* Z_total was empty: sentinel (NaN, NaN, -1, true), (-1,), -1, NaN (src/tests.jl:285) */
+#define FW_SUBSETS_STOPPED 1  /* returned at the first non-significant test or at max_tests (:326-336) */
+#define FW_SUBSETS_ALL_SIG 2  /* every subset significant: the max-p result (:338-345) */
+typedef struct fw_subsets_result {
+    double stat;
+    double pval;
+    int32_t df;
+    int32_t suff_power;
+    int32_t status;          /* FW_SUBSETS_* */
+    int32_t n_zs;            /* length of zs */
+    int32_t zs[FW_MAX_K];    /* conditioning set of the returned result (variable ids) */
+    int32_t reserved0;
+    int64_t num_tests;       /* tests executed in the reference's sequential order (-1 for EMPTY) */
+    double frac;             /* num_tests / total number of subsets */
+} fw_subsets_result;
+
+/* Counters the metric needs (the reference has none) */
+typedef struct fw_counters {
+    int64_t level0_tests;        /* p(p-1)/2 pair tests issued */
+    int64_t cond_tests_ref;      /* sum of num_tests over all test_subsets calls (reference-equivalent) */
+    int64_t cond_tests_evaluated;/* tests actually evaluated on the device (includes speculation) */
+    int64_t subsets_calls;       /* number of (T, candidate) jobs */
+    int64_t kernel_launches;
+    double t_level0_s;           /* wall seconds inside fw_level0 */
+    double t_cond_s;             /* wall seconds inside the conditional stage of fw_learn_network */
+    double t_dev_subsets_s;      /* HIP-event seconds of the test_subsets kernels (sum) */
+    double alg_bytes_subsets;    /* algorithmic bytes of the evaluated conditional tests:
+                                    fz: 4*C(k+2,2)+32 per test of order k; discrete: (k+2)*n*b/8+32, b = 1 (mi) / 2 (mi_nz) */
+} fw_counters;
+
+/* ---- lifecycle -------------------------------------------------------------------------------- */
+
+/* Fills *params with the reference defaults for `kind`. */
+void fw_params_default(fw_params *params, int32_t kind, int32_t n, int32_t p);
+
+/* replaces: make_test_object (src/misc.jl:34-45) + the per-worker data hand-over (src/interleaved.jl:90-93).
+ * On failure *out is NULL and fw_last_error(NULL) describes the problem. */
+int fw_ctx_create(const fw_params *params, fw_ctx **out);
+int fw_ctx_destroy(fw_ctx *ctx);
+const char *fw_last_error(const fw_ctx *ctx); /* ctx may be NULL: last creation error of this thread */
+int fw_abi_version(void);
+
+/* ---- data ------------------------------------------------------------------------------------- */
+
+/* FW_FZ: the normalised dense matrix (Matrix{Float32}, n x p column-major) the reference hands to
+ * cor() in prepare_lgl (src/learning.jl:42-45). */
+int fw_set_data_dense_f32(fw_ctx *ctx, const float *data);
+
+/* FW_MI / FW_MI_NZ: SparseMatrixCSC{Int32,Int64} as produced by normalize_data (make_sparse = true).
+ * colptr has p+1 entries; rowval is 0-based and sorted within each column; values are 1..3.
+ * Also computes levels / max_vals (src/misc.jl:64-97). */
+int fw_set_data_csc_i32(fw_ctx *ctx, const int64_t *colptr, const int32_t *rowval, const int32_t *nzval);
+
+/* FW_MI / FW_MI_NZ, dense input (Matrix{Int32}, n x p column-major, values 0..3); converted on the host to
+ * the same packed device layout, i.e. evaluated with the SPARSE-path semantics (levels_z rules). */
+int fw_set_data_dense_i32(fw_ctx *ctx, const int32_t *data);
+
+int fw_get_levels(const fw_ctx *ctx, int32_t *levels, int32_t *max_vals); /* p entries each */
+
+/* FW_FZ: supply a precomputed Pearson matrix (p x p, Float32) instead of computing it on the device --
+ * mirrors `cor_mat` being an argument of pw_univar_neighbors / si_HITON_PC (src/tests.jl:441, src/hiton.jl:284). */
+int fw_set_cor_mat(fw_ctx *ctx, const float *cor_mat);
+/* replaces: cor(data_dense) -> Matrix{Float32} (src/learning.jl:44).  MFMA kernel; result stays resident. */
+int fw_compute_cor_mat(fw_ctx *ctx);
+int fw_get_cor_mat(const fw_ctx *ctx, float *cor_mat_out); /* p*p floats */
+
+/* ---- level 0 ---------------------------------------------------------------------------------- */
+
+/* replaces: pw_univar_neighbors (src/tests.jl:436-532) incl. the power/NaN rules and
+ * benjamini_hochberg! (src/statfuns.jl:326-350).  Runs all p(p-1)/2 univariate tests on the device and
+ * keeps the neighbour lists in the context.  *nnz_out = total number of (directed) neighbour entries. */
+int fw_level0(fw_ctx *ctx, int64_t *nnz_out);
+/* Neighbour lists as CSR: off[p+1]; idx/stat/adj_p have nnz entries, partners ascending per variable;
+ * adj_p is the BH-adjusted p-value when fdr = 1 (src/tests.jl:372-388). */
+int fw_level0_get(const fw_ctx *ctx, int64_t *off, int32_t *idx, double *stat, double *adj_p);
+
+/* ---- the per-pair test batch ------------------------------------------------------------------- */
+
+/* replaces: test(X, Y, Zs, data, test_obj, ...) (src/tests.jl:28,108 for empty Zs; :184,:250 otherwise).
+ * Test i is (X[i], Y[i] | zflat[zoff[i] .. zoff[i+1])), Z order preserved.  zoff has m+1 entries. */
+int fw_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff,
+                  const int32_t *zflat, fw_test_result *out);
+
+/* replaces: test_subsets(T, candidate, accepted, data, test_obj, max_k, alpha; hps, n_obs_min, max_tests)
+ * (src/tests.jl:281-346) for m independent (T, candidate, accepted) jobs -- the call edge hiton.jl:100.
+ * Job i conditions on accflat[accoff[i] .. accoff[i+1]) (acceptance order preserved, duplicates allowed).
+ * Enumeration order, early exit and the `>=` max-p rule are the reference's; num_tests is the count the
+ * sequential reference would have executed. */
+int fw_test_subsets_batch(fw_ctx *ctx, int64_t m, const int32_t *T, const int32_t *cand, const int64_t *accoff,
+                          const int32_t *accflat, fw_subsets_result *out);
+
+/* ---- host driver: the caller side, for hosts without Julia ----------------- */
+
+typedef struct fw_learn_opts {
+    int32_t feed_forward;  /* default 1 (src/learning.jl:469) */
+    int32_t round_size;    /* targets per feed-forward round; 1 = the reference's deterministic single_il schedule;
+                              0 = one round (no whitelist can form: identical to feed_forward = 0 / parallel="single") */
+    int32_t rank;          /* this process' rank in a target-sharded run (0 for single GPU) */
+    int32_t world_size;    /* number of ranks; targets of a round are dealt round-robin in schedule order */
+    int32_t max_targets;   /* > 0: stop after this many targets of the schedule (sampling; 0 = all) */
+    int32_t reserved0;
+} fw_learn_opts;
+
+/* Exchange callback for target-sharded runs: called once per feed-forward round with this rank's newly found
+ * directed neighbour entries (target, neighbour, weight-stat, p); must return the concatenation over all ranks
+ * (rank order) through *out_* buffers allocated by the callee and valid until the next call.  NULL for
+ * world_size = 1.  (RCCL all_gather in bench.py; gloo in the CPU tests.) */
+typedef int (*fw_allgather_fn)(void *user, int64_t n_local, const int32_t *tgt, const int32_t *nbr, const double *stat,
+                               const double *pval, int64_t *n_total, const int32_t **tgt_all, const int32_t **nbr_all,
+                               const double **stat_all, const double **pval_all);
+
+/* replaces: LGL minus normalisation (src/learning.jl:203-279): level 0 (if not yet run), target ordering,
+ * HITON-PC per target (src/hiton.jl:283-400) in level-synchronous batches over fw_test_subsets_batch,
+ * feed-forward rounds (src/interleaved.jl:112-183), make_weights + make_symmetric_graph (src/misc.jl:137-272).
+ * *n_edges_out = number of undirected edges; fetch them with fw_network_get. */
+int fw_learn_network(fw_ctx *ctx, const fw_learn_opts *opts, fw_allgather_fn allgather, void *user,
+                     int64_t *n_edges_out);
+int fw_network_get(const fw_ctx *ctx, int32_t *src, int32_t *dst, double *weight); /* src < dst */
+/* directed per-target results (state_results of every HitonState): CSR over targets */
+int fw_network_get_directed(const fw_ctx *ctx, int64_t *off, int32_t *idx, double *weight, double *pval);
+
+int fw_get_counters(const fw_ctx *ctx, fw_counters *out);
+int fw_reset_counters(fw_ctx *ctx);
+/* effective n_obs_min after the automatic rule */
+int64_t fw_effective_n_obs_min(const fw_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLASHWEAVE_AMD_H */

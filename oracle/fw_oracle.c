@@ -1246,6 +1246,8 @@ typedef struct {
     int feed_forward;
     int round_size;  /* whitelist snapshot refresh interval in targets; 1 = reference single_il */
     int max_targets; /* > 0: stop after this many targets of the schedule (baseline sampling) */
+    int target_stride; /* > 1 (only with feed_forward = 0): process every stride-th target of the schedule */
+    double max_seconds; /* > 0: stop the conditional stage after this many seconds (baseline sampling) */
 } fwo_params;
 
 typedef struct {
@@ -1472,8 +1474,12 @@ fwo_network *fwo_learn(fwo_ctx *c, const fwo_params *P_in, const fwo_nbrs *nb_in
     int rs = P.round_size > 0 ? P.round_size : 1;
     int nt = (P.max_targets > 0 && P.max_targets < p) ? P.max_targets : p;
     double t1 = now_s();
-    for (int ti = 0; ti < nt; ++ti) {
+    int stride = (P.target_stride > 1 && !P.feed_forward) ? P.target_stride : 1;
+    int n_done = 0;
+    for (int ti = 0; ti < nt; ti += stride) {
         int T = order[ti].idx;
+        if (P.max_seconds > 0 && now_s() - t1 > P.max_seconds) break;
+        ++n_done;
         if (ti % rs == 0)
             for (int v = 0; v < p; ++v) snap[v] = adj[v].n;
         const uint8_t *wlp = NULL;
@@ -1498,7 +1504,7 @@ fwo_network *fwo_learn(fwo_ctx *c, const fwo_params *P_in, const fwo_nbrs *nb_in
         }
     }
     g->t_cond = now_s() - t1;
-    g->n_targets_done = nt;
+    g->n_targets_done = n_done;
 
     /* misc.jl:137-159 make_weights ("cond_stat") -> per-direction weight, stored in PCs[].stat */
     for (int T = 0; T < p; ++T) {

@@ -1,0 +1,90 @@
+"""Worker for the world_size-2 tests (launched by tests/test_dist_cpu.py and tests/test_gpu_dist.py)."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run_callback_only(rank, world):
+    import torch
+    import torch.distributed as dist
+    from flashweave_jl_amd.dist import make_allgather
+    from flashweave_jl_amd.engine import ALLGATHER_FN
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cb = ALLGATHER_FN(make_allgather(dist, torch.device("cpu")))
+    ok = True
+    for rnd in range(3):
+        n = [3, 0, 5][(rank + rnd) % 3]  # ragged, including an empty contribution
+        t = np.arange(n, dtype=np.int32) + 100 * rank + 10 * rnd
+        u = np.arange(n, dtype=np.int32) + 7
+        s = np.linspace(-1, 1, n) if n else np.zeros(0)
+        s = s.astype(np.float64)
+        if n:
+            s[0] = np.nan
+        p = np.full(n, 1e-300 * (rank + 1))
+        n_total = C.c_int64(0)
+        pt, pn = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+        ps, pp = C.POINTER(C.c_double)(), C.POINTER(C.c_double)()
+        rc = cb(None, n, t.ctypes.data_as(C.POINTER(C.c_int32)), u.ctypes.data_as(C.POINTER(C.c_int32)),
+                s.ctypes.data_as(C.POINTER(C.c_double)), p.ctypes.data_as(C.POINTER(C.c_double)), C.byref(n_total),
+                C.byref(pt), C.byref(pn), C.byref(ps), C.byref(pp))
+        ok &= rc == 0
+        exp_t = []
+        for r in range(world):
+            nr = [3, 0, 5][(r + rnd) % 3]
+            exp_t += list(np.arange(nr) + 100 * r + 10 * rnd)
+        got_t = [pt[i] for i in range(n_total.value)]
+        ok &= got_t == exp_t
+        got_p = [pp[i] for i in range(n_total.value)]
+        ok &= all(v in (1e-300, 2e-300) for v in got_p)
+        ok &= sum(1 for i in range(n_total.value) if np.isnan(ps[i])) == sum(1 for r in range(world) if [3, 0, 5][(r + rnd) % 3])
+    dist.barrier()
+    dist.destroy_process_group()
+    return ok
+
+
+def run_sharded_gpu(rank, world, out_path):
+    """Two ranks on the same GPU (device 0), gloo transport: the sharded run must equal the single-rank run."""
+    import torch
+    import torch.distributed as dist
+    import flashweave_jl_amd as fw
+    from flashweave_jl_amd import preprocess as pre
+    from flashweave_jl_amd import synth
+    from flashweave_jl_amd.dist import make_allgather
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {}
+    for kind, mode in (("fz", "S"), ("mi", "F")):
+        counts = synth.generate(300, 250, 17, mode=mode)
+        data, _, _ = pre.normalize(counts, kind)
+        n, p = data.shape
+        eng = fw.Engine(kind, n, p, max_k=3)
+        eng.set_data(data)
+        cb = make_allgather(dist, torch.device("cpu"))
+        for ff, R in ((0, 0), (1, 32)):
+            sh = eng.lgl(feed_forward=bool(ff), round_size=R, rank=rank, world_size=world, allgather=cb)
+            res["%s_ff%d" % (kind, ff)] = sorted([a, b, w] for (a, b), w in sh["edges"].items())
+            if rank == 0:
+                single = fw.Engine(kind, n, p, max_k=3)
+                single.set_data(data)
+                one = single.lgl(feed_forward=bool(ff), round_size=R)
+                res["%s_ff%d_single" % (kind, ff)] = sorted([a, b, w] for (a, b), w in one["edges"].items())
+                single.close()
+        eng.close()
+    json.dump(res, open(out_path + ".%d" % rank, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+    return True
+
+
+if __name__ == "__main__":
+    mode, rank, world = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    if mode == "callback":
+        ok = run_callback_only(rank, world)
+    else:
+        ok = run_sharded_gpu(rank, world, sys.argv[4])
+    sys.exit(0 if ok else 1)

@@ -1,0 +1,58 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports every symbol that
+include/flashweave_amd.h declares; without a GPU the product fails loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import flashweave_jl_amd as fw
+from tests.util import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(fw.lib_path()):
+        fw.build_library()
+    return fw.load_library()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "flashweave_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(fw_[a-z0-9_]+)\s*\(", hdr))
+    names -= {"fw_allgather_fn"}
+    assert len(names) >= 20
+    raw = ctypes.CDLL(fw.lib_path())
+    missing = [n for n in sorted(names) if not hasattr(raw, n)]
+    assert not missing, missing
+
+
+def test_abi_version_and_defaults(lib):
+    from flashweave_jl_amd.engine import _Params
+    assert lib.fw_abi_version() == 1
+    P = _Params()
+    lib.fw_params_default(ctypes.byref(P), fw.FW_FZ, 100, 10)
+    # learn_network defaults, reference src/learning.jl:466-473
+    assert (P.max_k, P.hps, P.fdr, P.n_obs_min, P.max_tests, P.alpha) == (3, 5, 1, -1, 10_000_000, 0.01)
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(fw.FlashWeaveError) as ei:
+        fw.Engine("fz", 100, 10)
+    assert ei.value.code == -2 and "no CPU fallback" in str(ei.value)
+
+
+def test_argument_validation(lib):
+    from flashweave_jl_amd.engine import _Params
+    P = _Params()
+    h = ctypes.c_void_p()
+    lib.fw_params_default(ctypes.byref(P), 7, 100, 10)
+    assert lib.fw_ctx_create(ctypes.byref(P), ctypes.byref(h)) == -1  # unknown kind
+    lib.fw_params_default(ctypes.byref(P), fw.FW_FZ, 100, 10)
+    P.max_k = 9
+    assert lib.fw_ctx_create(ctypes.byref(P), ctypes.byref(h)) == -5  # FW_ERR_LIMIT
+    assert b"max_k" in lib.fw_last_error(None)

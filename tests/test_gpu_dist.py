@@ -1,0 +1,23 @@
+"""Target-sharded run with 2 ranks (both on GPU 0, gloo transport) equals the single-rank run: results do not
+depend on the number of ranks."""
+import json
+import os
+import tempfile
+
+import pytest
+
+from tests.test_dist_cpu import _launch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sharded_equals_single():
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "res")
+        assert _launch("sharded", (out,)) == [0, 0]
+        r0 = json.load(open(out + ".0"))
+        r1 = json.load(open(out + ".1"))
+        for k in ("fz_ff0", "fz_ff1", "mi_ff0", "mi_ff1"):
+            assert r0[k] == r1[k]                 # every rank ends with the full network
+            assert r0[k] == r0[k + "_single"]     # and it equals the single-rank network, weights included
+            assert len(r0[k]) > 0

@@ -1,0 +1,234 @@
+"""GPU parity tests of the FlashWeave-S (Fisher-z) HIP path against the CPU oracle, through the C ABI.
+
+Tolerances (stated per the north star):
+  * Pearson matrix (fp32 MFMA accumulation vs Float64 accumulation rounded to Float32): |diff| <= 5e-6.
+  * partial correlations / edge weights, given the SAME Float32 matrix: bit-exact (only + - * / sqrt rint).
+  * p-values: relative 1e-12 (device log/erfc vs libm).
+"""
+import numpy as np
+import pytest
+
+import flashweave_jl_amd as fw
+from flashweave_jl_amd import preprocess as pre
+from flashweave_jl_amd import synth
+from oracle import oracle as O
+from tests.util import GOLDEN, read_edgelist, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _synth_fz(p, n, seed):
+    counts = synth.generate(p, n, seed, mode="S")
+    data, _, _ = pre.normalize(counts, "fz", prec=32)
+    return np.asfortranarray(data)
+
+
+@pytest.fixture(scope="module")
+def small():
+    data = _synth_fz(400, 300, 11)
+    n, p = data.shape
+    eng = fw.Engine("fz", n, p, max_k=3)
+    eng.set_data(data)
+    cm = eng.cor()
+    orc = O.Oracle("fz", cor_mat=cm, n_obs=n)
+    return dict(data=data, n=n, p=p, eng=eng, cm=cm, orc=orc)
+
+
+def test_cor_matrix_tolerance_and_structure(small):
+    cm, data = small["cm"], small["data"]
+    ref = O.cor(data.astype(np.float64), "f32")
+    assert np.abs(cm - ref).max() <= 5e-6
+    assert (cm == cm.T).all()                      # mirrored writes: exactly symmetric
+    assert (np.diag(cm) == 1.0).all()
+    assert np.abs(cm).max() <= 1.0
+
+
+def test_cor_matrix_ragged_shapes():
+    # n not a multiple of the k-tile (32), p not a multiple of the 128 tile nor of 4
+    rng = np.random.default_rng(5)
+    for n, p in ((37, 5), (100, 131), (333, 257)):
+        data = np.asfortranarray(rng.standard_normal((n, p)).astype(np.float32))
+        data[:, 0] = 1.5  # zero-variance column -> NaN row/col except the unit diagonal (Statistics.cor)
+        eng = fw.Engine("fz", n, p)
+        eng.set_data(data)
+        cm = eng.cor()
+        ref = O.cor(data.astype(np.float64), "f32")
+        assert np.isnan(cm[0, 1:]).all() and np.isnan(cm[1:, 0]).all() and cm[0, 0] == 1.0
+        assert np.abs(cm[1:, 1:] - ref[1:, 1:]).max() <= 5e-6
+        eng.close()
+
+
+def test_single_tests_bit_exact(small):
+    eng, orc, p = small["eng"], small["orc"], small["p"]
+    rng = np.random.default_rng(3)
+    X, Y, Zs = [], [], []
+    for _ in range(3000):
+        k = int(rng.integers(0, 6))
+        v = rng.choice(p, size=k + 2, replace=False)
+        X.append(int(v[0])); Y.append(int(v[1])); Zs.append(tuple(int(t) for t in v[2:]))
+    # duplicated conditioning variables (feed-forward whitelist) and Z == X
+    X += [1, 2, 3]; Y += [5, 6, 7]; Zs += [(9, 9), (11, 12, 11), (3, 8)]
+    got = eng.test_batch(X, Y, Zs)
+    for x, y, z, g in zip(X, Y, Zs, got):
+        s, pv, df, pw = orc.test(x, y, z, n_obs_min=20)
+        assert (g.stat == s) or (np.isnan(g.stat) and np.isnan(s)), (x, y, z, g.stat, s)
+        assert rel(g.pval, pv) < 1e-12 or (np.isnan(g.pval) and np.isnan(pv))
+        assert g.df == 0 and g.suff_power == pw
+
+
+def _check_subsets(eng, orc, T, C, A, max_k, alpha=0.01, max_tests=10_000_000):
+    got = eng.test_subsets_batch(T, C, A)
+    for t, c, a, g in zip(T, C, A, got):
+        e = orc.test_subsets(t, c, a, max_k=max_k, alpha=alpha, n_obs_min=20, max_tests=max_tests)
+        assert g["status"] == e["status"], (t, c, a, g, e)
+        assert g["num_tests"] == e["num_tests"], (t, c, a, g, e)
+        if e["status"] == 0:
+            assert np.isnan(g["stat"]) and np.isnan(g["pval"]) and g["df"] == -1
+            continue
+        assert g["Zs"] == e["Zs"], (t, c, a, g, e)
+        assert g["stat"] == e["stat"], (g, e)
+        assert rel(g["pval"], e["pval"]) < 1e-12
+        assert rel(g["frac"], e["frac"]) < 1e-12
+
+
+def test_test_subsets_matches_reference_order(small):
+    eng, orc, p = small["eng"], small["orc"], small["p"]
+    rng = np.random.default_rng(4)
+    T, C, A = [], [], []
+    for _ in range(400):
+        a = int(rng.integers(0, 30))
+        v = rng.choice(p, size=a + 2, replace=False)
+        T.append(int(v[0])); C.append(int(v[1])); A.append([int(t) for t in v[2:]])
+    # jobs built from the strongest neighbours: long all-significant runs -> exercises the max-p rule
+    cm = small["cm"]
+    for t in range(20):
+        order = np.argsort(-np.abs(cm[t]))
+        nb = [int(v) for v in order if v != t][:14]
+        T.append(t); C.append(nb[0]); A.append(nb[1:])
+    A[3] = A[3] + A[3][:1]  # duplicate in the accepted list
+    _check_subsets(eng, orc, T, C, A, max_k=3)
+
+
+def test_test_subsets_max_tests_and_large_pool(small):
+    data, n, p, cm = small["data"], small["n"], small["p"], small["cm"]
+    eng = fw.Engine("fz", n, p, max_k=3, max_tests=37)
+    eng.set_cor_mat(cm)
+    orc = small["orc"]
+    T, C, A = [], [], []
+    for t in range(30):
+        order = np.argsort(-np.abs(cm[t]))
+        nb = [int(v) for v in order if v != t][:12]
+        T.append(t); C.append(nb[0]); A.append(nb[1:])
+    _check_subsets(eng, orc, T, C, A, max_k=3, max_tests=37)
+    eng.close()
+    # accepted pool larger than the LDS staging limit (2048): global-memory path; cap the work with max_tests
+    rng = np.random.default_rng(8)
+    eng = fw.Engine("fz", n, p, max_k=2, max_tests=3000, alpha=0.9999)
+    eng.set_cor_mat(cm)
+    big = [int(v) for v in rng.integers(2, p, size=2100)]
+    _check_subsets(eng, orc, [0], [1], [big], max_k=2, alpha=0.9999, max_tests=3000)
+    eng.close()
+
+
+@pytest.mark.parametrize("max_k", [1, 2, 4, 5])
+def test_test_subsets_other_max_k(small, max_k):
+    n, p, cm, orc = small["n"], small["p"], small["cm"], small["orc"]
+    eng = fw.Engine("fz", n, p, max_k=max_k)
+    eng.set_cor_mat(cm)
+    T, C, A = [], [], []
+    for t in range(25):
+        order = np.argsort(-np.abs(cm[t]))
+        nb = [int(v) for v in order if v != t][:9]
+        T.append(t); C.append(nb[0]); A.append(nb[1:])
+    _check_subsets(eng, orc, T, C, A, max_k=max_k)
+    eng.close()
+
+
+def test_level0_neighbours(small):
+    eng, orc, p = small["eng"], small["orc"], small["p"]
+    got = eng.pw_univar_neighbors()
+    exp = orc.level0(alpha=0.01, n_obs_min=20)
+    assert (got["off"] == exp["off"]).all()
+    assert (got["idx"] == exp["idx"]).all()
+    assert (got["stat"] == exp["stat"]).all()
+    assert np.allclose(got["pval"], exp["pval"], rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("ff,R", [(False, 0), (True, 1), (True, 16)])
+def test_network_matches_oracle(small, ff, R):
+    n, p, cm, orc = small["n"], small["p"], small["cm"], small["orc"]
+    eng = fw.Engine("fz", n, p, max_k=3)
+    eng.set_cor_mat(cm)
+    got = eng.lgl(feed_forward=ff, round_size=R)
+    exp = orc.learn(max_k=3, feed_forward=ff, round_size=max(R, 1) if ff else 1)
+    assert set(got["edges"]) == set(exp["edges"])
+    for e, w in exp["edges"].items():
+        assert got["edges"][e] == w            # weights are partial correlations: bit-exact
+    cn = eng.counters()
+    assert cn["cond_tests_ref"] == exp["n_cond_tests"]      # same sequential test count as the reference order
+    assert cn["level0_tests"] == p * (p - 1) // 2
+    assert cn["cond_tests_evaluated"] >= cn["cond_tests_ref"]
+    eng.close()
+
+
+@pytest.mark.parametrize("max_k,wtol", [(0, 1e-7), (3, 2e-7)])
+def test_golden_networks_fz(max_k, wtol):
+    # reference test/learning.jl:176-237 (exp_fz_maxk{0,3}.edgelist, generated with single_il + prec=64)
+    raw = np.loadtxt(GOLDEN + "/HMP_SRA_gut_small.tsv", delimiter="\t", skiprows=1, usecols=range(1, 51))
+    data, _, _ = pre.normalize(raw, "fz", prec=64)
+    cm = O.cor(data, "f32")  # prec=64 path: cor in Float64, stored as Float32 (learning.jl:44)
+    exp = read_edgelist("%s/learning_expected/exp_fz_maxk%d.edgelist" % (GOLDEN, max_k))
+    eng = fw.Engine("fz", data.shape[0], data.shape[1], max_k=max_k)
+    eng.set_cor_mat(cm)
+    got = eng.lgl(feed_forward=True, round_size=1)["edges"]
+    assert set(got) == set(exp)
+    for e in exp:
+        assert abs(got[e] - exp[e]) <= wtol
+    # and with the matrix computed on the device from the Float32 data (prec=32 path): same edge set here
+    eng2 = fw.Engine("fz", data.shape[0], data.shape[1], max_k=max_k)
+    eng2.set_data(data.astype(np.float32))
+    eng2.cor()
+    got2 = eng2.lgl(feed_forward=True, round_size=1)["edges"]
+    assert set(got2) == set(exp)
+    for e in exp:
+        assert abs(got2[e] - exp[e]) <= 5e-5  # 5-digit rounding inside pcor_rec amplifies fp32 differences
+    eng.close(); eng2.close()
+
+
+def test_full_size_properties():
+    # BASELINE size class (p in the thousands): size-independent properties instead of an oracle run
+    data = _synth_fz(3000, 600, 21)
+    n, p = data.shape
+    eng = fw.Engine("fz", n, p, max_k=3)
+    eng.set_data(data)
+    cm = eng.cor()
+    assert (cm == cm.T).all() and (np.diag(cm) == 1).all() and np.nanmax(np.abs(cm)) <= 1.0
+    r1 = eng.lgl(feed_forward=False)
+    c1 = eng.counters()
+    # idempotence: a second run on the same context gives the identical network and test count
+    eng.reset_counters()
+    r2 = eng.lgl(feed_forward=False)
+    c2 = eng.counters()
+    assert r1["edges"] == r2["edges"] and c1["cond_tests_ref"] == c2["cond_tests_ref"]
+    # every edge is a level-0 neighbour pair (HITON-PC only prunes), weights are correlations in [-1, 1]
+    nb = eng.pw_univar_neighbors()
+    pairs = set()
+    for v in range(p):
+        for u in nb["idx"][nb["off"][v]:nb["off"][v + 1]]:
+            pairs.add((min(v, int(u)), max(v, int(u))))
+    assert set(r1["edges"]) <= pairs
+    assert all(abs(w) <= 1.0 for w in r1["edges"].values())
+    # spot-check 200 random directed results against the oracle given the device matrix
+    orc = O.Oracle("fz", cor_mat=cm, n_obs=n)
+    exp = orc.learn(max_k=3, feed_forward=False, max_targets=1500)
+    # the first 1500 targets of the schedule have identical directed results
+    off, idx, w = r1["pc_off"], r1["pc_idx"], r1["pc_weight"]
+    eoff, eidx, ew = exp["pc_off"], exp["pc_idx"], exp["pc_weight"]
+    checked = 0
+    for T in range(p):
+        if eoff[T + 1] > eoff[T]:
+            assert list(idx[off[T]:off[T + 1]]) == list(eidx[eoff[T]:eoff[T + 1]])
+            assert list(w[off[T]:off[T + 1]]) == list(ew[eoff[T]:eoff[T + 1]])
+            checked += 1
+    assert checked > 0
+    eng.close()
