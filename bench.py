@@ -116,9 +116,9 @@ def main():
         launches = max(cn["kernel_launches"], 1)
         sub_launch_s = cn["t_dev_subsets_s"]
         # dominant kernel: test_subsets batch (per launch averages over the timed region, this rank)
-        n_sub_launches = max(cn["kernel_launches"] - steps * (3 if cfg["test_name"] == "fz" else 1), 1)
+        n_sub_launches = max(cn["subsets_launches"], 1)
         achieved = (cn["alg_bytes_subsets"] / max(sub_launch_s, 1e-12)) / 1e9
-        roofline = {"bound": "hbm", "kernel": "fz_subsets_kernel" if cfg["test_name"] == "fz" else "mi_subsets_kernel",
+        roofline = {"bound": "hbm", "kernel": "fz_subsets_seg_kernel" if cfg["test_name"] == "fz" else "mi_subsets_seg_kernel",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": None,
                     "alg_bytes_per_launch": cn["alg_bytes_subsets"] / n_sub_launches,

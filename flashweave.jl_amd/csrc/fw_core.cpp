@@ -385,28 +385,187 @@ int fw_test_batch(fw_ctx *c, int64_t m, const int32_t *X, const int32_t *Y, cons
 
 }  // extern "C"
 
+// ---- progressive, segment-parallel evaluation of test_subsets jobs -------------------------------------
+// A job's subsets are ranked in the reference's enumeration order.  Ranks are evaluated in windows that grow
+// geometrically (256, 1k, 4k, ... ranks); each window is cut into segments, one workgroup per segment, and the
+// per-segment outputs are merged IN RANK ORDER on the host: the first stopping rank ends the job exactly where the
+// sequential reference would have stopped (tests.jl:326-336); otherwise the (p, rank) maximum with "later wins
+// ties" is carried forward (tests.jl:338-341).  Speculation is bounded by the window growth factor.
+static uint64_t binom_sat(int64_t m, int t)
+{
+    if (t < 0 || m < t) return 0;
+    const uint64_t SAT = 1ull << 62;
+    long double r = 1.0L;
+    for (int i = 1; i <= t; ++i) r = r * (long double)(m - t + i) / (long double)i;
+    if (r > 4.0e18L) return SAT;
+    uint64_t v = 1;
+    for (int i = 1; i <= t; ++i) v = v * (uint64_t)(m - t + i) / (uint64_t)i;  // exact: product of i consecutive ints / i!
+    return v;
+}
+
+// lexicographic unranking (same order as the device code): rank -> subset size and positions
+static void unrank_host(uint64_t r, int a, int max_k, int *s_out, int *pos)
+{
+    int s = max_k;
+    while (s > 1) {
+        const uint64_t cnt = binom_sat(a, s);
+        if (r < cnt) break;
+        r -= cnt;
+        --s;
+    }
+    *s_out = s;
+    int prev = -1;
+    for (int d = 0; d < s; ++d) {
+        const int t = s - d;
+        int c = prev + 1;
+        for (;;) {
+            const uint64_t with_c = binom_sat(a - 1 - c, t - 1);
+            if (r < with_c) break;
+            r -= with_c;
+            ++c;
+        }
+        pos[d] = c;
+        prev = c;
+    }
+}
+
 int fwi_subsets_dispatch(fw_ctx *c, int64_t m, const FwJob *jobs, const int32_t *acc, int64_t acc_total, FwJobOut *out)
 {
-    if (c->P.kind == FW_FZ) {
-        if (c->P.n < c->n_obs_min_eff) {
-            // tests.jl:254-262: every test lacks power -> the first one is returned (0, 1, 0, false)
-            for (int64_t i = 0; i < m; ++i) {
-                FwJobOut o{};
-                o.stat = 0.0;
-                o.pval = 1.0;
-                o.num_tests = 1;
-                o.evaluated = 0;
-                o.status = FW_SUBSETS_STOPPED;
-                int s = std::min<int>(c->P.max_k, jobs[i].acc_len);
-                o.n_zs = s;
-                for (int q = 0; q < s; ++q) o.zs[q] = acc[jobs[i].acc_off + q];
-                out[i] = o;
-            }
-            return FW_OK;
+    if (m == 0) return FW_OK;
+    const bool fz = c->P.kind == FW_FZ;
+    if (fz && c->P.n < c->n_obs_min_eff) {
+        // tests.jl:254-262: every test lacks power -> the first one is returned (0, 1, 0, false)
+        for (int64_t i = 0; i < m; ++i) {
+            FwJobOut o{};
+            o.stat = 0.0;
+            o.pval = 1.0;
+            o.num_tests = 1;
+            o.evaluated = 0;
+            o.status = FW_SUBSETS_STOPPED;
+            int s = std::min<int>(c->P.max_k, jobs[i].acc_len);
+            o.n_zs = s;
+            for (int q = 0; q < s; ++q) o.zs[q] = acc[jobs[i].acc_off + q];
+            out[i] = o;
         }
-        return fwi_fz_subsets(c, m, jobs, acc, acc_total, out);
+        return FW_OK;
     }
-    return fwi_mi_subsets(c, m, jobs, acc, acc_total, out);
+    struct JState {
+        uint64_t N, next, width;
+        double best_p, best_stat;
+        uint64_t best_rank;
+        int32_t best_df;
+        bool done;
+    };
+    std::vector<JState> st((size_t)m);
+    const uint64_t mt = c->P.max_tests > 0 ? (uint64_t)c->P.max_tests : 0;
+    for (int64_t i = 0; i < m; ++i) {
+        uint64_t N = 0;
+        for (int s = c->P.max_k; s >= 1; --s) {
+            N += binom_sat(jobs[i].acc_len, s);
+            if (N > (1ull << 62)) N = 1ull << 62;
+        }
+        if (mt && mt < N) N = mt;
+        st[i] = JState{N, 0, 256, -1.0, 0.0, 0, 0, false};
+        out[i] = FwJobOut{};
+    }
+    int rc;
+    if ((rc = fw_dev_reserve(c, c->d_acc, (size_t)std::max<int64_t>(acc_total, 1) * sizeof(int32_t)))) return rc;
+    FW_HIP(c, hipMemcpyAsync(c->d_acc.ptr, acc, (size_t)acc_total * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+
+    std::vector<FwSeg> segs;
+    std::vector<int64_t> seg_job;
+    std::vector<FwSegOut> so;
+    std::vector<int64_t> live((size_t)m);
+    for (int64_t i = 0; i < m; ++i) live[i] = i;
+    while (!live.empty()) {
+        // window of every live job, then a segment length that yields a few thousand workgroups
+        uint64_t total = 0;
+        for (int64_t j : live) total += std::min(st[j].width, st[j].N - st[j].next);
+        uint64_t seglen = (total / 4096 + 255) / 256 * 256;
+        seglen = std::max<uint64_t>(256, std::min<uint64_t>(seglen, 8192));
+        segs.clear();
+        seg_job.clear();
+        for (int64_t j : live) {
+            const uint64_t lo = st[j].next, hi = lo + std::min(st[j].width, st[j].N - lo);
+            for (uint64_t sgs = lo; sgs < hi; sgs += seglen) {
+                FwSeg sg{};
+                sg.X = jobs[j].X;
+                sg.Y = jobs[j].Y;
+                sg.acc_off = jobs[j].acc_off;
+                sg.acc_len = jobs[j].acc_len;
+                sg.start = sgs;
+                sg.end = std::min(hi, sgs + seglen);
+                segs.push_back(sg);
+                seg_job.push_back(j);
+            }
+        }
+        const size_t ns = segs.size();
+        if ((rc = fw_dev_reserve(c, c->d_segs, ns * sizeof(FwSeg)))) return rc;
+        if ((rc = fw_dev_reserve(c, c->d_segout, ns * sizeof(FwSegOut)))) return rc;
+        FW_HIP(c, hipMemcpyAsync(c->d_segs.ptr, segs.data(), ns * sizeof(FwSeg), hipMemcpyHostToDevice, c->stream));
+        rc = fz ? fwi_fz_segments(c, (int64_t)ns, (const FwSeg *)c->d_segs.ptr, (const int32_t *)c->d_acc.ptr, (FwSegOut *)c->d_segout.ptr)
+                : fwi_mi_segments(c, (int64_t)ns, (const FwSeg *)c->d_segs.ptr, (const int32_t *)c->d_acc.ptr, (FwSegOut *)c->d_segout.ptr);
+        if (rc) return rc;
+        so.resize(ns);
+        FW_HIP(c, hipMemcpyAsync(so.data(), c->d_segout.ptr, ns * sizeof(FwSegOut), hipMemcpyDeviceToHost, c->stream));
+        FW_HIP(c, hipStreamSynchronize(c->stream));
+        float ms = 0.0f;
+        FW_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->cnt.t_dev_subsets_s += 1e-3 * (double)ms;
+        c->cnt.kernel_launches += 1;
+        c->cnt.subsets_launches += 1;
+        // in-order merge
+        for (size_t q = 0; q < ns; ++q) {
+            const int64_t j = seg_job[q];
+            JState &s = st[j];
+            FwJobOut &o = out[j];
+            o.evaluated += (int64_t)so[q].evaluated;
+            if (s.done) continue;  // a later (speculative) segment of a job that already stopped
+            if (so[q].stop_rank != FW_RANK_NONE) {
+                s.done = true;
+                o.stat = so[q].stop_stat;
+                o.pval = so[q].stop_pval;
+                o.df = so[q].stop_df;
+                o.suff_power = so[q].stop_power;
+                o.status = FW_SUBSETS_STOPPED;
+                o.num_tests = (int64_t)(so[q].stop_rank + 1);
+                s.best_rank = so[q].stop_rank;
+            } else if (so[q].best_pval >= s.best_p) {
+                s.best_p = so[q].best_pval;
+                s.best_stat = so[q].best_stat;
+                s.best_rank = so[q].best_rank;
+                s.best_df = so[q].best_df;
+            }
+        }
+        std::vector<int64_t> nxt;
+        for (int64_t j : live) {
+            JState &s = st[j];
+            if (s.done) continue;
+            s.next += std::min(s.width, s.N - s.next);
+            s.width *= 4;
+            if (s.next >= s.N) {
+                s.done = true;
+                FwJobOut &o = out[j];
+                o.stat = s.best_stat;
+                o.pval = s.best_p < 0.0 ? 0.0 : s.best_p;
+                o.df = s.best_df;
+                o.suff_power = 1;
+                o.status = FW_SUBSETS_ALL_SIG;
+                o.num_tests = (int64_t)s.N;
+            } else {
+                nxt.push_back(j);
+            }
+        }
+        live.swap(nxt);
+    }
+    // conditioning set of the returned result from its rank
+    for (int64_t i = 0; i < m; ++i) {
+        int s = 0, pos[FW_MAX_K] = {0, 0, 0, 0, 0};
+        unrank_host(st[i].best_rank, jobs[i].acc_len, c->P.max_k, &s, pos);
+        out[i].n_zs = s;
+        for (int q = 0; q < FW_MAX_K; ++q) out[i].zs[q] = q < s ? acc[jobs[i].acc_off + pos[q]] : 0;
+    }
+    return FW_OK;
 }
 
 static double binom_d(int n, int k)

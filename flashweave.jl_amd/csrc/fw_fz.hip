@@ -434,49 +434,43 @@ __device__ __forceinline__ void unrank_comb(unsigned long long rem, int a, int s
     }
 }
 
-__global__ __launch_bounds__(256) void fz_subsets_kernel(const float *__restrict__ cor, int p,
-                                                         const FwJob *__restrict__ jobs,
-                                                         const int32_t *__restrict__ accflat, FwJobOut *__restrict__ out,
-                                                         int max_k, double alpha, double zscale, long long max_tests)
+__global__ __launch_bounds__(256) void fz_subsets_seg_kernel(const float *__restrict__ cor, int p,
+                                                             const FwSeg *__restrict__ segs,
+                                                             const int32_t *__restrict__ accflat,
+                                                             FwSegOut *__restrict__ out, int max_k, double alpha,
+                                                             double zscale, long long max_tests)
 {
     __shared__ int s_acc[FW_ACC_LDS];
     __shared__ unsigned long long s_stop[4];
     __shared__ double s_bp[4];
     __shared__ unsigned long long s_br[4];
     __shared__ double s_best_p, s_best_stat;
-    __shared__ int s_best_zs[FW_MAX_K], s_best_n;
+    __shared__ unsigned long long s_best_rank;
 
-    const FwJob job = jobs[blockIdx.x];
-    const int a = job.acc_len;
+    const FwSeg seg = segs[blockIdx.x];
+    const int a = seg.acc_len;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int32_t *gacc = accflat + job.acc_off;
+    const int32_t *gacc = accflat + seg.acc_off;
     const bool in_lds = a <= FW_ACC_LDS;
     if (in_lds)
         for (int i = tid; i < a; i += 256) s_acc[i] = gacc[i];
     if (tid == 0) {
         s_best_p = -1.0;
         s_best_stat = 0.0;
-        s_best_n = 0;
+        s_best_rank = 0;
     }
     // subset counts per size, in enumeration order s = max_k .. 1
-    unsigned long long cnt[FW_MAX_K + 1], N = 0;
+    unsigned long long cnt[FW_MAX_K + 1];
 #pragma unroll
-    for (int s = FW_MAX_K; s >= 1; --s) {
-        cnt[s] = (s <= max_k) ? binom_u64(a, s) : 0ull;
-        N += cnt[s];
-        if (N > (1ull << 62)) N = 1ull << 62;
-    }
-    const unsigned long long Ncap = (max_tests > 0 && (unsigned long long)max_tests < N) ? (unsigned long long)max_tests : N;
+    for (int s = FW_MAX_K; s >= 1; --s) cnt[s] = (s <= max_k) ? binom_u64(a, s) : 0ull;
     __syncthreads();
 
-    const unsigned long long NONE = ~0ull;
+    const unsigned long long NONE = FW_RANK_NONE;
     unsigned long long evaluated = 0;
-    for (unsigned long long base = 0; base < Ncap; base += 256) {
+    for (unsigned long long base = seg.start; base < seg.end; base += 256) {
         const unsigned long long r = base + tid;
-        const bool valid = r < Ncap;
+        const bool valid = r < seg.end;
         double stat = 0.0, pv = 0.0;
-        int zs[FW_MAX_K];
-        int s_sz = 0;
         if (valid) {
             unsigned long long rem = r;
             int s = max_k;
@@ -484,19 +478,16 @@ __global__ __launch_bounds__(256) void fz_subsets_kernel(const float *__restrict
                 rem -= cnt[s];
                 --s;
             }
-            s_sz = s;
-            int pos[FW_MAX_K];
+            int pos[FW_MAX_K], zs[FW_MAX_K];
             unrank_comb(rem, a, s, pos);
 #pragma unroll
             for (int q = 0; q < FW_MAX_K; ++q) zs[q] = (q < s) ? (in_lds ? s_acc[pos[q]] : gacc[pos[q]]) : 0;
-            stat = fz_pcor_any(cor, p, job.X, job.Y, zs, s);
+            stat = fz_pcor_any(cor, p, seg.X, seg.Y, zs, s);
             pv = fz_pval_dev(stat, zscale);
         }
         const bool stop = valid && (!(pv < alpha) || (max_tests > 0 && r + 1 >= (unsigned long long)max_tests));
-        // first stopping rank in the workgroup
         const unsigned long long bm = __ballot(stop);
         if (lane == 0) s_stop[wave] = bm ? (base + wave * 64 + (unsigned long long)__builtin_ctzll(bm)) : NONE;
-        // chunk-local maximum of (p, rank), later rank wins ties
         double bp = valid ? pv : -1.0;
         unsigned long long br = valid ? r : 0ull;
 #pragma unroll
@@ -516,22 +507,22 @@ __global__ __launch_bounds__(256) void fz_subsets_kernel(const float *__restrict
         unsigned long long first = s_stop[0];
 #pragma unroll
         for (int w = 1; w < 4; ++w) first = s_stop[w] < first ? s_stop[w] : first;
-        const unsigned long long nvalid = (Ncap - base) < 256ull ? (Ncap - base) : 256ull;
+        const unsigned long long nvalid = (seg.end - base) < 256ull ? (seg.end - base) : 256ull;
         evaluated += nvalid;
         if (first != NONE) {
             if (r == first) {
-                FwJobOut o;
-                o.stat = stat;
-                o.pval = pv;
-                o.num_tests = (long long)(first + 1);
-                o.evaluated = (long long)evaluated;
-                o.df = 0;
-                o.suff_power = 1;
-                o.status = FW_SUBSETS_STOPPED;
-                o.n_zs = s_sz;
-#pragma unroll
-                for (int q = 0; q < FW_MAX_K; ++q) o.zs[q] = zs[q];
-                o.pad[0] = o.pad[1] = o.pad[2] = 0;
+                FwSegOut o;
+                o.stop_rank = first;
+                o.stop_stat = stat;
+                o.stop_pval = pv;
+                o.best_rank = 0;
+                o.best_stat = 0.0;
+                o.best_pval = -1.0;
+                o.stop_df = 0;
+                o.stop_power = 1;
+                o.best_df = 0;
+                o.pad = 0;
+                o.evaluated = evaluated;
                 out[blockIdx.x] = o;
             }
             return;
@@ -548,25 +539,23 @@ __global__ __launch_bounds__(256) void fz_subsets_kernel(const float *__restrict
         if (valid && r == cbr && cbp >= s_best_p) {
             s_best_p = pv;
             s_best_stat = stat;
-            s_best_n = s_sz;
-#pragma unroll
-            for (int q = 0; q < FW_MAX_K; ++q) s_best_zs[q] = zs[q];
+            s_best_rank = r;
         }
         __syncthreads();
     }
     if (tid == 0) {
-        FwJobOut o;
-        o.stat = s_best_stat;
-        o.pval = s_best_p < 0.0 ? 0.0 : s_best_p;
-        o.num_tests = (long long)Ncap;
-        o.evaluated = (long long)evaluated;
-        o.df = 0;
-        o.suff_power = 1;
-        o.status = FW_SUBSETS_ALL_SIG;
-        o.n_zs = s_best_n;
-#pragma unroll
-        for (int q = 0; q < FW_MAX_K; ++q) o.zs[q] = s_best_zs[q];
-        o.pad[0] = o.pad[1] = o.pad[2] = 0;
+        FwSegOut o;
+        o.stop_rank = NONE;
+        o.stop_stat = 0.0;
+        o.stop_pval = 0.0;
+        o.best_rank = s_best_rank;
+        o.best_stat = s_best_stat;
+        o.best_pval = s_best_p;
+        o.stop_df = 0;
+        o.stop_power = 1;
+        o.best_df = 0;
+        o.pad = 0;
+        o.evaluated = evaluated;
         out[blockIdx.x] = o;
     }
 }
@@ -692,27 +681,13 @@ int fwi_fz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y
     return FW_OK;
 }
 
-int fwi_fz_subsets(fw_ctx *ctx, int64_t m, const FwJob *jobs_host, const int32_t *acc_host, int64_t acc_total,
-                   FwJobOut *out_host)
+int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out)
 {
-    if (m == 0) return FW_OK;
-    int rc;
-    if ((rc = fw_dev_reserve(ctx, ctx->d_jobs, (size_t)m * sizeof(FwJob)))) return rc;
-    if ((rc = fw_dev_reserve(ctx, ctx->d_acc, (size_t)(acc_total > 0 ? acc_total : 1) * sizeof(int32_t)))) return rc;
-    if ((rc = fw_dev_reserve(ctx, ctx->d_out, (size_t)m * sizeof(FwJobOut)))) return rc;
-    FW_HIP(ctx, hipMemcpyAsync(ctx->d_jobs.ptr, jobs_host, (size_t)m * sizeof(FwJob), hipMemcpyHostToDevice, ctx->stream));
-    FW_HIP(ctx, hipMemcpyAsync(ctx->d_acc.ptr, acc_host, (size_t)acc_total * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (nseg == 0) return FW_OK;
     FW_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(fz_subsets_kernel, dim3((unsigned)m), dim3(256), 0, ctx->stream, ctx->d_cor, ctx->P.p,
-                       (const FwJob *)ctx->d_jobs.ptr, (const int32_t *)ctx->d_acc.ptr, (FwJobOut *)ctx->d_out.ptr,
-                       ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests);
+    hipLaunchKernelGGL(fz_subsets_seg_kernel, dim3((unsigned)nseg), dim3(256), 0, ctx->stream, ctx->d_cor, ctx->P.p, d_segs,
+                       d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests);
     FW_HIP(ctx, hipGetLastError());
     FW_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-    FW_HIP(ctx, hipMemcpyAsync(out_host, ctx->d_out.ptr, (size_t)m * sizeof(FwJobOut), hipMemcpyDeviceToHost, ctx->stream));
-    FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    float ms = 0.0f;
-    FW_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    ctx->cnt.t_dev_subsets_s += 1e-3 * (double)ms;
-    ctx->cnt.kernel_launches += 1;
     return FW_OK;
 }

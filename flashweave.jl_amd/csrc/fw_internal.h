@@ -44,6 +44,34 @@ struct FwJobOut {
     int32_t pad[3];
 };
 
+// One segment of a job: ranks [start, end) of the job's subset enumeration (device layout)
+struct FwSeg {
+    int32_t X;
+    int32_t Y;
+    int64_t acc_off;
+    int32_t acc_len;
+    int32_t pad;
+    uint64_t start;
+    uint64_t end;
+};
+
+#define FW_RANK_NONE (~0ull)
+
+// Device-side result of one segment.  The conditioning sets are recovered on the host from the ranks.
+struct FwSegOut {
+    uint64_t stop_rank;  // first rank in the segment that ends the job (non-significant or max_tests), else FW_RANK_NONE
+    double stop_stat;
+    double stop_pval;
+    uint64_t best_rank;  // last rank attaining the maximum p in the segment (valid when there was no stop)
+    double best_stat;
+    double best_pval;
+    int32_t stop_df;
+    int32_t stop_power;
+    int32_t best_df;
+    int32_t pad;
+    uint64_t evaluated;
+};
+
 struct fw_ctx {
     fw_params P{};
     int64_t n_obs_min_eff = 0;
@@ -85,7 +113,7 @@ struct fw_ctx {
     fw_counters cnt{};
 
     // grow-only scratch
-    FwDevBuf d_jobs, d_acc, d_out, d_tmp0, d_tmp1, d_tmp2;
+    FwDevBuf d_jobs, d_acc, d_out, d_tmp0, d_tmp1, d_tmp2, d_segs, d_segout;
     FwPinned h_jobs, h_acc, h_out;
 };
 
@@ -107,8 +135,7 @@ int fwi_fz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
                   std::vector<double> &pval, int64_t *m_reliable);
 int fwi_fz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff,
                       const int32_t *zflat, fw_test_result *out);
-int fwi_fz_subsets(fw_ctx *ctx, int64_t m, const FwJob *jobs_host, const int32_t *acc_host, int64_t acc_total,
-                   FwJobOut *out_host);
+int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out);
 
 // ---- discrete (fw_mi.hip) ----
 int fwi_mi_upload(fw_ctx *ctx, const int64_t *colptr, const int32_t *rowval, const int32_t *nzval);
@@ -116,8 +143,7 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
                   std::vector<double> &pval, int64_t *m_reliable);
 int fwi_mi_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff,
                       const int32_t *zflat, fw_test_result *out);
-int fwi_mi_subsets(fw_ctx *ctx, int64_t m, const FwJob *jobs_host, const int32_t *acc_host, int64_t acc_total,
-                   FwJobOut *out_host);
+int fwi_mi_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out);
 
 // algorithmic bytes of the first `evaluated` tests of a job with |accepted| = a (enumeration order: sizes max_k..1)
 double fwi_alg_bytes(const fw_ctx *ctx, int a, int64_t evaluated);

@@ -92,6 +92,7 @@ typedef struct fw_counters {
     int64_t cond_tests_evaluated;/* tests actually evaluated on the device (includes speculation) */
     int64_t subsets_calls;       /* number of (T, candidate) jobs */
     int64_t kernel_launches;
+    int64_t subsets_launches;    /* launches of the test_subsets segment kernel */
     double t_level0_s;           /* wall seconds inside fw_level0 */
     double t_cond_s;             /* wall seconds inside the conditional stage of fw_learn_network */
     double t_dev_subsets_s;      /* HIP-event seconds of the test_subsets kernels (sum) */
