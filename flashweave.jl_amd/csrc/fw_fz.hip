@@ -434,6 +434,91 @@ __device__ __forceinline__ void unrank_comb(unsigned long long rem, int a, int s
     }
 }
 
+// ---- tagged scalar forms of the pcor_rec levels (same arithmetic as fz_pcor_dp, used by the run-based kernel) ----
+struct TV {
+    double v;
+    bool f32;
+};
+
+// statfuns.jl:32-41 with ContType = Float32
+__device__ __forceinline__ TV pc_l1(float xy, float xz, float yz)
+{
+    const float prod = xz * yz;
+    float e = xy - prod;
+    e = round5_f32(e);
+    const float s1 = 1.0f - xz * xz, s2 = 1.0f - yz * yz;
+    const float d = sqrtf(s1) * sqrtf(s2);
+    TV r;
+    if (d == 0.0f) {
+        r.v = 0.0;
+        r.f32 = false;
+    } else {
+        r.v = (double)(e / d);
+        r.f32 = true;
+    }
+    if (r.v < -1.0) {
+        r.v = -1.0;
+        r.f32 = false;
+    } else if (r.v >= 1.0) {
+        r.v = 1.0;
+        r.f32 = false;
+    }
+    return r;
+}
+
+// statfuns.jl:44-62, children from level 1 (Float32 unless they were replaced by a Float64 literal)
+__device__ __forceinline__ double pc_l2(TV a, TV b, TV c)
+{
+    double prod, ev, d1;
+    bool p32;
+    if (b.f32 && c.f32) {
+        prod = (double)((float)b.v * (float)c.v);
+        p32 = true;
+    } else {
+        prod = b.v * c.v;
+        p32 = false;
+    }
+    if (a.f32 && p32)
+        ev = (double)round5_f32((float)a.v - (float)prod);
+    else
+        ev = round5_f64(a.v - prod);
+    if (b.f32) {
+        const float bb = (float)b.v * (float)b.v;
+        d1 = (double)sqrtf(1.0f - bb);
+    } else {
+        d1 = sqrt(1.0 - b.v * b.v);
+    }
+    const double d2 = sqrt(1.0 - c.v * c.v);
+    const double denom = d1 * d2;
+    double v = (denom == 0.0) ? 0.0 : ev / denom;
+    if (v < -1.0)
+        v = -1.0;
+    else if (v >= 1.0)
+        v = 1.0;
+    return v;
+}
+
+// statfuns.jl:44-62, all-Float64 children (level >= 3)
+__device__ __forceinline__ double pc_l3(double a, double b, double c)
+{
+    const double ev = round5_f64(a - b * c);
+    const double denom = sqrt(1.0 - b * b) * sqrt(1.0 - c * c);
+    double v = (denom == 0.0) ? 0.0 : ev / denom;
+    if (v < -1.0)
+        v = -1.0;
+    else if (v >= 1.0)
+        v = 1.0;
+    return v;
+}
+
+// Run-based segment kernel.  A segment [start, end) is processed in chunks of 256 * R ranks; lane l evaluates the R
+// consecutive ranks [cbase + l*R, cbase + (l+1)*R): it unranks once, then steps the combination lexicographically and
+// reuses every partial correlation that does not involve the position that changed (for max_k = 3 that is 4 of the
+// 10 formula evaluations and 6 of the 10 matrix entries).  Rank order is preserved: a lane stops at its first
+// stopping rank, the workgroup takes the minimum over lanes.
+#define FW_RUN_MAX 8
+
+template <bool HIGHK>  // HIGHK: conditioning sets of size 4-5 possible (generic DP fallback compiled in)
 __global__ __launch_bounds__(256) void fz_subsets_seg_kernel(const float *__restrict__ cor, int p,
                                                              const FwSeg *__restrict__ segs,
                                                              const int32_t *__restrict__ accflat,
@@ -459,37 +544,134 @@ __global__ __launch_bounds__(256) void fz_subsets_seg_kernel(const float *__rest
         s_best_stat = 0.0;
         s_best_rank = 0;
     }
-    // subset counts per size, in enumeration order s = max_k .. 1
     unsigned long long cnt[FW_MAX_K + 1];
 #pragma unroll
     for (int s = FW_MAX_K; s >= 1; --s) cnt[s] = (s <= max_k) ? binom_u64(a, s) : 0ull;
     __syncthreads();
+#define ACCV(i) (in_lds ? s_acc[(i)] : gacc[(i)])
+#define CORV(u, v) cor[(size_t)(u) * p + (v)]
 
+    const int X = seg.X, Y = seg.Y;
+    const float cXY = CORV(X, Y);
     const unsigned long long NONE = FW_RANK_NONE;
+    const unsigned long long len = seg.end - seg.start;
+    const int R = (int)((len + 255) / 256 < FW_RUN_MAX ? (len + 255) / 256 : FW_RUN_MAX);
     unsigned long long evaluated = 0;
-    for (unsigned long long base = seg.start; base < seg.end; base += 256) {
-        const unsigned long long r = base + tid;
-        const bool valid = r < seg.end;
-        double stat = 0.0, pv = 0.0;
-        if (valid) {
-            unsigned long long rem = r;
+
+    for (unsigned long long cbase = seg.start; cbase < seg.end; cbase += 256ull * R) {
+        const unsigned long long r0 = cbase + (unsigned long long)tid * R;
+        unsigned long long r1 = r0 + R;
+        if (r1 > seg.end) r1 = seg.end;
+        const bool any = r0 < seg.end;
+        // lane-local results
+        unsigned long long my_stop = NONE, my_br = 0;
+        double stop_stat = 0.0, stop_p = 0.0, my_bp = -1.0, my_bstat = 0.0;
+        if (any) {
+            // unrank the first rank of the run
+            unsigned long long rem = r0;
             int s = max_k;
             while (s > 1 && rem >= cnt[s]) {
                 rem -= cnt[s];
                 --s;
             }
-            int pos[FW_MAX_K], zs[FW_MAX_K];
-            unrank_comb(rem, a, s, pos);
+            int pos[FW_MAX_K];
 #pragma unroll
-            for (int q = 0; q < FW_MAX_K; ++q) zs[q] = (q < s) ? (in_lds ? s_acc[pos[q]] : gacc[pos[q]]) : 0;
-            stat = fz_pcor_any(cor, p, seg.X, seg.Y, zs, s);
-            pv = fz_pval_dev(stat, zscale);
+            for (int q = 0; q < FW_MAX_K; ++q) pos[q] = 0;
+            unrank_comb(rem, a, s, pos);
+            int chg = 0;  // lowest position index that changed since the previous test of this lane (0 = everything)
+            // cached state for s <= 3
+            int z1 = 0, z2 = 0;
+            float cXz1 = 0.f, cYz1 = 0.f, cXz2 = 0.f, cYz2 = 0.f, cz2z1 = 0.f;
+            TV A1{0.0, false}, B1{0.0, false}, C1{0.0, false};
+            double A2 = 0.0;
+            for (unsigned long long r = r0; r < r1; ++r) {
+                double stat;
+                if (s == 3) {
+                    if (chg <= 0) {
+                        z1 = ACCV(pos[0]);
+                        cXz1 = CORV(X, z1);
+                        cYz1 = CORV(Y, z1);
+                        A1 = pc_l1(cXY, cXz1, cYz1);
+                    }
+                    if (chg <= 1) {
+                        z2 = ACCV(pos[1]);
+                        cXz2 = CORV(X, z2);
+                        cYz2 = CORV(Y, z2);
+                        cz2z1 = CORV(z2, z1);
+                        B1 = pc_l1(cXz2, cXz1, cz2z1);
+                        C1 = pc_l1(cYz2, cYz1, cz2z1);
+                        A2 = pc_l2(A1, B1, C1);
+                    }
+                    const int z3 = ACCV(pos[2]);
+                    const float cXz3 = CORV(X, z3), cYz3 = CORV(Y, z3), cz3z1 = CORV(z3, z1), cz3z2 = CORV(z3, z2);
+                    const TV D1 = pc_l1(cXz3, cXz1, cz3z1);
+                    const TV E1 = pc_l1(cYz3, cYz1, cz3z1);
+                    const TV F1 = pc_l1(cz3z2, cz3z1, cz2z1);
+                    const double D2 = pc_l2(D1, B1, F1);
+                    const double E2 = pc_l2(E1, C1, F1);
+                    stat = pc_l3(A2, D2, E2);
+                } else if (s == 2) {
+                    if (chg <= 0) {
+                        z1 = ACCV(pos[0]);
+                        cXz1 = CORV(X, z1);
+                        cYz1 = CORV(Y, z1);
+                        A1 = pc_l1(cXY, cXz1, cYz1);
+                    }
+                    z2 = ACCV(pos[1]);
+                    cXz2 = CORV(X, z2);
+                    cYz2 = CORV(Y, z2);
+                    cz2z1 = CORV(z2, z1);
+                    B1 = pc_l1(cXz2, cXz1, cz2z1);
+                    C1 = pc_l1(cYz2, cYz1, cz2z1);
+                    stat = pc_l2(A1, B1, C1);
+                } else if (s == 1) {
+                    z1 = ACCV(pos[0]);
+                    stat = pc_l1(cXY, CORV(X, z1), CORV(Y, z1)).v;
+                } else if (HIGHK) {
+                    int zs[FW_MAX_K];
+#pragma unroll
+                    for (int q = 0; q < FW_MAX_K; ++q) zs[q] = (q < s) ? ACCV(pos[q]) : 0;
+                    stat = fz_pcor_any(cor, p, X, Y, zs, s);
+                } else {
+                    stat = 0.0;
+                }
+                const double pv = fz_pval_dev(stat, zscale);
+                if (!(pv < alpha) || (max_tests > 0 && r + 1 >= (unsigned long long)max_tests)) {
+                    my_stop = r;
+                    stop_stat = stat;
+                    stop_p = pv;
+                    break;
+                }
+                if (pv >= my_bp) {  // tests.jl:338, sequential within the run
+                    my_bp = pv;
+                    my_br = r;
+                    my_bstat = stat;
+                }
+                // next combination in lexicographic order (sizes descend when one is exhausted)
+                int i = s - 1;
+                while (i >= 0 && pos[i] == a - s + i) --i;
+                if (i < 0) {
+                    --s;
+#pragma unroll
+                    for (int q = 0; q < FW_MAX_K; ++q) pos[q] = q;
+                    chg = 0;
+                    if (s < 1) break;  // end of the enumeration (r1 never exceeds it)
+                } else {
+                    ++pos[i];
+                    for (int j = i + 1; j < s; ++j) pos[j] = pos[j - 1] + 1;
+                    chg = i;
+                }
+            }
         }
-        const bool stop = valid && (!(pv < alpha) || (max_tests > 0 && r + 1 >= (unsigned long long)max_tests));
-        const unsigned long long bm = __ballot(stop);
-        if (lane == 0) s_stop[wave] = bm ? (base + wave * 64 + (unsigned long long)__builtin_ctzll(bm)) : NONE;
-        double bp = valid ? pv : -1.0;
-        unsigned long long br = valid ? r : 0ull;
+        // first stopping rank in the workgroup
+        unsigned long long ws = my_stop;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long t = __shfl_xor(ws, o);
+            ws = t < ws ? t : ws;
+        }
+        double bp = my_bp;
+        unsigned long long br = my_br;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const double op = __shfl_xor(bp, o);
@@ -500,6 +682,7 @@ __global__ __launch_bounds__(256) void fz_subsets_seg_kernel(const float *__rest
             }
         }
         if (lane == 0) {
+            s_stop[wave] = ws;
             s_bp[wave] = bp;
             s_br[wave] = br;
         }
@@ -507,14 +690,14 @@ __global__ __launch_bounds__(256) void fz_subsets_seg_kernel(const float *__rest
         unsigned long long first = s_stop[0];
 #pragma unroll
         for (int w = 1; w < 4; ++w) first = s_stop[w] < first ? s_stop[w] : first;
-        const unsigned long long nvalid = (seg.end - base) < 256ull ? (seg.end - base) : 256ull;
-        evaluated += nvalid;
+        const unsigned long long cend = (cbase + 256ull * R) < seg.end ? (cbase + 256ull * R) : seg.end;
+        evaluated += cend - cbase;
         if (first != NONE) {
-            if (r == first) {
+            if (my_stop == first) {
                 FwSegOut o;
                 o.stop_rank = first;
-                o.stop_stat = stat;
-                o.stop_pval = pv;
+                o.stop_stat = stop_stat;
+                o.stop_pval = stop_p;
                 o.best_rank = 0;
                 o.best_stat = 0.0;
                 o.best_pval = -1.0;
@@ -535,14 +718,15 @@ __global__ __launch_bounds__(256) void fz_subsets_seg_kernel(const float *__rest
                 cbp = s_bp[w];
                 cbr = s_br[w];
             }
-        // tests.jl:338: replace when pval >= running best (ranks only grow, so ties go to the newer chunk)
-        if (valid && r == cbr && cbp >= s_best_p) {
-            s_best_p = pv;
-            s_best_stat = stat;
-            s_best_rank = r;
+        if (my_bp >= 0.0 && my_br == cbr && my_bp == cbp && cbp >= s_best_p) {
+            s_best_p = my_bp;
+            s_best_stat = my_bstat;
+            s_best_rank = my_br;
         }
         __syncthreads();
     }
+#undef ACCV
+#undef CORV
     if (tid == 0) {
         FwSegOut o;
         o.stop_rank = NONE;
@@ -685,8 +869,12 @@ int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_
 {
     if (nseg == 0) return FW_OK;
     FW_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(fz_subsets_seg_kernel, dim3((unsigned)nseg), dim3(256), 0, ctx->stream, ctx->d_cor, ctx->P.p, d_segs,
-                       d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests);
+    if (ctx->P.max_k > 3)
+        hipLaunchKernelGGL(fz_subsets_seg_kernel<true>, dim3((unsigned)nseg), dim3(256), 0, ctx->stream, ctx->d_cor, ctx->P.p,
+                           d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests);
+    else
+        hipLaunchKernelGGL(fz_subsets_seg_kernel<false>, dim3((unsigned)nseg), dim3(256), 0, ctx->stream, ctx->d_cor, ctx->P.p,
+                           d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests);
     FW_HIP(ctx, hipGetLastError());
     FW_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     return FW_OK;
