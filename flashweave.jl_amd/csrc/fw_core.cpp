@@ -465,7 +465,7 @@ int fwi_subsets_dispatch(fw_ctx *c, int64_t m, const FwJob *jobs, const int32_t 
             if (N > (1ull << 62)) N = 1ull << 62;
         }
         if (mt && mt < N) N = mt;
-        st[i] = JState{N, 0, 256, -1.0, 0.0, 0, 0, false};
+        st[i] = JState{N, 0, fz ? 256ull : 16ull, -1.0, 0.0, 0, 0, false};
         out[i] = FwJobOut{};
     }
     int rc;
@@ -481,8 +481,10 @@ int fwi_subsets_dispatch(fw_ctx *c, int64_t m, const FwJob *jobs, const int32_t 
         // window of every live job, then a segment length that yields a few thousand workgroups
         uint64_t total = 0;
         for (int64_t j : live) total += std::min(st[j].width, st[j].N - st[j].next);
-        uint64_t seglen = (total / 4096 + 255) / 256 * 256;
-        seglen = std::max<uint64_t>(256, std::min<uint64_t>(seglen, 8192));
+        // fz: one lane per test (256-rank granularity); discrete: one wavefront per test (4-rank granularity)
+        const uint64_t q = fz ? 256 : 4, smin = fz ? 256 : 8, smax = fz ? 8192 : 256;
+        uint64_t seglen = (total / 4096 + q - 1) / q * q;
+        seglen = std::max<uint64_t>(smin, std::min<uint64_t>(seglen, smax));
         segs.clear();
         seg_job.clear();
         for (int64_t j : live) {

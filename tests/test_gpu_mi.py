@@ -1,0 +1,213 @@
+"""GPU parity tests of the discrete (FlashWeave-F "mi" / FlashWeaveHE-F "mi_nz") HIP path against the CPU oracle,
+through the C ABI.  Integer outputs (df, suff_power, test counts, edge sets, conditioning sets) are compared
+bit-exact; MI statistics within 1e-12 relative (fp64 summation order / device log), p-values within 1e-10
+relative (device lgamma / exp in the incomplete gamma function)."""
+import numpy as np
+import pytest
+
+import flashweave_jl_amd as fw
+from flashweave_jl_amd import preprocess as pre
+from flashweave_jl_amd import synth
+from oracle import oracle as O
+from tests.util import GOLDEN, load_norm, read_edgelist, read_tests_expected, rel
+
+pytestmark = pytest.mark.gpu
+STOL, PTOL = 1e-12, 1e-10
+
+
+def _close(a, b, tol):
+    return (a == b) or (np.isnan(a) and np.isnan(b)) or rel(a, b) < tol
+
+
+def _synth(kind, p, n, seed):
+    if kind == "mi":
+        counts = synth.generate(p, n, seed, mode="F")
+        data, _, _ = pre.normalize(counts, "mi")
+    else:
+        counts, meta = synth.generate(p, n, seed, mode="F", habitats=4, n_meta=20)
+        data, rm, _ = pre.normalize(counts, "mi_nz")
+        meta = meta[rm]
+        keep = [j for j in range(meta.shape[1]) if len(np.unique(meta[:, j])) == 2]
+        data = np.concatenate([data, meta[:, keep]], axis=1)  # binary meta variables (max_val 1 -> not zero-adjusted)
+    return np.ascontiguousarray(data)
+
+
+@pytest.fixture(scope="module", params=["mi", "mi_nz"])
+def ctx(request):
+    kind = request.param
+    data = _synth(kind, 300, 400, 23)
+    n, p = data.shape
+    eng = fw.Engine(kind, n, p, max_k=3)
+    eng.set_data(data)
+    orc = O.Oracle(kind, data, sparse=True, max_k=3)
+    return dict(kind=kind, data=data, n=n, p=p, eng=eng, orc=orc)
+
+
+def test_levels(ctx):
+    lv, mv = ctx["eng"].levels()
+    elv, emv = ctx["orc"].levels()
+    assert (lv == elv).all() and (mv == emv).all()
+    assert ctx["eng"].n_obs_min == ctx["orc"].auto_n_obs_min(-1, 5, 3)
+
+
+def test_tests_expected_tsv():
+    # reference test/tests.jl:41-74 (integer inputs are the preprocessing fixtures)
+    exp = read_tests_expected()
+    for kind, fx in (("mi", "pres_abs"), ("mi_nz", "clr_nonzero_binned")):
+        data = load_norm(fx, np.int64)
+        eng = fw.Engine(kind, data.shape[0], data.shape[1], max_k=3, n_obs_min=0)
+        eng.set_data(data)
+        got = eng.test_batch([0] * 49, list(range(1, 50)), [()] * 49)
+        for g, e in zip(got, exp["exp_uni_" + kind]):
+            assert (g.df, g.suff_power) == (e[2], e[3])
+            assert _close(g.stat, e[0], 1e-11) and _close(g.pval, e[1], 1e-9)
+        for key, Zs in (("condZ1", (6,)), ("condZ3", (6, 13, 17))):
+            g = eng.test(30, 20, Zs)
+            e = exp["exp_%s_%s" % (key, kind)][0]
+            assert (g.df, g.suff_power) == (e[2], e[3])
+            assert _close(g.stat, e[0], 1e-11) and _close(g.pval, e[1], 1e-9)
+        eng.close()
+
+
+def test_single_tests(ctx):
+    eng, orc, p = ctx["eng"], ctx["orc"], ctx["p"]
+    rng = np.random.default_rng(3)
+    X, Y, Zs = [], [], []
+    for _ in range(4000):
+        k = int(rng.integers(0, 4))
+        v = rng.choice(p, size=k + 2, replace=False)
+        X.append(int(v[0])); Y.append(int(v[1])); Zs.append(tuple(int(t) for t in v[2:]))
+    X += [1, 2, 3]; Y += [5, 6, 7]; Zs += [(9, 9), (11, 12, 11), (3, 8)]  # duplicates, Z == X
+    got = eng.test_batch(X, Y, Zs)
+    nom = eng.n_obs_min
+    npow = 0
+    for x, y, z, g in zip(X, Y, Zs, got):
+        s, pv, df, pw = orc.test(x, y, z, hps=5, n_obs_min=nom)
+        assert (g.df, g.suff_power) == (df, pw), (x, y, z, g, (s, pv, df, pw))
+        assert _close(g.stat, s, STOL) and _close(g.pval, pv, PTOL), (x, y, z, g, (s, pv, df, pw))
+        npow += pw
+    assert npow > 100  # the comparison is not vacuous
+
+
+def _check_subsets(eng, orc, T, C, A, max_k, nom, alpha=0.01, max_tests=10_000_000):
+    got = eng.test_subsets_batch(T, C, A)
+    nstop = nall = 0
+    for t, c, a, g in zip(T, C, A, got):
+        e = orc.test_subsets(t, c, a, max_k=max_k, alpha=alpha, hps=5, n_obs_min=nom, max_tests=max_tests)
+        assert g["status"] == e["status"] and g["num_tests"] == e["num_tests"], (t, c, a, g, e)
+        if e["status"] == 0:
+            continue
+        assert g["Zs"] == e["Zs"] and g["df"] == e["df"] and g["suff_power"] == e["suff_power"], (t, c, a, g, e)
+        assert _close(g["stat"], e["stat"], STOL) and _close(g["pval"], e["pval"], PTOL), (g, e)
+        nstop += e["status"] == 1
+        nall += e["status"] == 2
+    return nstop, nall
+
+
+def test_test_subsets(ctx):
+    eng, orc, p = ctx["eng"], ctx["orc"], ctx["p"]
+    nb = orc.level0(alpha=0.01, hps=5, n_obs_min=eng.n_obs_min)
+    rng = np.random.default_rng(4)
+    T, C, A = [], [], []
+    for _ in range(150):  # random pools
+        a = int(rng.integers(0, 12))
+        v = rng.choice(p, size=a + 2, replace=False)
+        T.append(int(v[0])); C.append(int(v[1])); A.append([int(t) for t in v[2:]])
+    for t in range(p):  # pools of true neighbours: long significant runs
+        nbr = [int(u) for u in nb["idx"][nb["off"][t]:nb["off"][t + 1]]]
+        if len(nbr) >= 4:
+            T.append(t); C.append(nbr[0]); A.append(nbr[1:9])
+    nstop, nall = _check_subsets(eng, orc, T, C, A, 3, eng.n_obs_min)
+    assert nstop > 0
+
+
+def test_test_subsets_max_tests(ctx):
+    kind, data, n, p, orc = ctx["kind"], ctx["data"], ctx["n"], ctx["p"], ctx["orc"]
+    eng = fw.Engine(kind, n, p, max_k=3, max_tests=5, alpha=0.5)
+    eng.set_data(data)
+    T, C, A = list(range(20)), list(range(20, 40)), [list(range(40, 48))] * 20
+    _check_subsets(eng, orc, T, C, A, 3, eng.n_obs_min, alpha=0.5, max_tests=5)
+    eng.close()
+
+
+def test_level0(ctx):
+    eng, orc = ctx["eng"], ctx["orc"]
+    got = eng.pw_univar_neighbors()
+    exp = orc.level0(alpha=0.01, hps=5, n_obs_min=eng.n_obs_min)
+    assert (got["off"] == exp["off"]).all() and (got["idx"] == exp["idx"]).all()
+    assert np.allclose(got["stat"], exp["stat"], rtol=STOL, atol=0)
+    assert np.allclose(got["pval"], exp["pval"], rtol=PTOL, atol=0)
+    assert len(exp["idx"]) > 0
+
+
+@pytest.mark.parametrize("ff,R", [(False, 0), (True, 1), (True, 16)])
+def test_network_matches_oracle(ctx, ff, R):
+    kind, data, n, p, orc = ctx["kind"], ctx["data"], ctx["n"], ctx["p"], ctx["orc"]
+    eng = fw.Engine(kind, n, p, max_k=3)
+    eng.set_data(data)
+    got = eng.lgl(feed_forward=ff, round_size=R)
+    exp = orc.learn(max_k=3, feed_forward=ff, round_size=max(R, 1) if ff else 1)
+    assert set(got["edges"]) == set(exp["edges"])       # edge sets: bit-exact
+    for e, w in exp["edges"].items():
+        assert _close(got["edges"][e], w, STOL)
+    cn = eng.counters()
+    assert cn["cond_tests_ref"] == exp["n_cond_tests"]
+    assert cn["level0_tests"] == p * (p - 1) // 2
+    eng.close()
+
+
+@pytest.mark.parametrize("kind,fx,max_k", [("mi", "pres_abs", 0), ("mi", "pres_abs", 3),
+                                           ("mi_nz", "clr_nonzero_binned", 0), ("mi_nz", "clr_nonzero_binned", 3)])
+def test_golden_networks(kind, fx, max_k):
+    # reference test/learning.jl:176-237: exp_{mi,mi_nz}_maxk{0,3}.edgelist (single_il schedule, sparse data)
+    data = load_norm(fx, np.int64)
+    exp = read_edgelist("%s/learning_expected/exp_%s_maxk%d.edgelist" % (GOLDEN, kind, max_k))
+    eng = fw.Engine(kind, data.shape[0], data.shape[1], max_k=max_k)
+    eng.set_data(data)
+    got = eng.lgl(feed_forward=True, round_size=1)["edges"]
+    assert set(got) == set(exp)
+    for e in exp:
+        assert abs(got[e] - exp[e]) <= 1e-13
+    eng.close()
+
+
+def test_csc_input_equals_dense_input(ctx):
+    kind, data, n, p = ctx["kind"], ctx["data"], ctx["n"], ctx["p"]
+    colptr, rowval, nzval = O.dense_to_csc(data)
+    e1 = fw.Engine(kind, n, p, max_k=3)
+    e1.set_data((colptr, rowval, nzval))
+    a = e1.pw_univar_neighbors()
+    b = ctx["eng"].pw_univar_neighbors()
+    assert (a["off"] == b["off"]).all() and (a["idx"] == b["idx"]).all() and (a["pval"] == b["pval"]).all()
+    e1.close()
+
+
+def test_rejects_unsupported_values():
+    bad = np.zeros((50, 4), dtype=np.int32)
+    bad[:, 1] = 3
+    eng = fw.Engine("mi_nz", 50, 4)
+    with pytest.raises(fw.FlashWeaveError) as ei:
+        eng.set_data(bad)
+    assert ei.value.code == -5
+    eng.close()
+
+
+def test_full_size_properties():
+    # cfg2 size class (1k OTUs x 500 samples, FlashWeave-F): properties + a spot check against the oracle
+    data = _synth("mi", 1000, 500, 20260930)
+    n, p = data.shape
+    eng = fw.Engine("mi", n, p, max_k=3)
+    eng.set_data(data)
+    r1 = eng.lgl(feed_forward=False)
+    c1 = eng.counters()
+    eng.reset_counters()
+    r2 = eng.lgl(feed_forward=False)
+    assert r1["edges"] == r2["edges"] and c1["cond_tests_ref"] == eng.counters()["cond_tests_ref"]
+    nb = eng.pw_univar_neighbors()
+    pairs = {(min(v, int(u)), max(v, int(u))) for v in range(p) for u in nb["idx"][nb["off"][v]:nb["off"][v + 1]]}
+    assert set(r1["edges"]) <= pairs
+    orc = O.Oracle("mi", data, sparse=True, max_k=3)
+    exp = orc.learn(max_k=3, feed_forward=False)
+    assert set(r1["edges"]) == set(exp["edges"])
+    assert c1["cond_tests_ref"] == exp["n_cond_tests"]
+    eng.close()
