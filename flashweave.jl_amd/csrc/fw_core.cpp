@@ -429,144 +429,191 @@ static void unrank_host(uint64_t r, int a, int max_k, int *s_out, int *pos)
     }
 }
 
-int fwi_subsets_dispatch(fw_ctx *c, int64_t m, const FwJob *jobs, const int32_t *acc, int64_t acc_total, FwJobOut *out)
+static void no_power_result(const fw_ctx *c, const int32_t *acc, int a, FwJobOut &o)
 {
-    if (m == 0) return FW_OK;
+    // tests.jl:254-262: every test lacks power -> the first one is returned (0, 1, 0, false)
+    o = FwJobOut{};
+    o.stat = 0.0;
+    o.pval = 1.0;
+    o.num_tests = 1;
+    o.evaluated = 0;
+    o.status = FW_SUBSETS_STOPPED;
+    const int s = std::min<int>(c->P.max_k, a);
+    o.n_zs = s;
+    for (int q = 0; q < s; ++q) o.zs[q] = acc[q];
+}
+
+int fwi_pool_add(fw_ctx *c, FwPool &pool, int32_t X, int32_t Y, const int32_t *acc, int a, int64_t tag)
+{
+    FwPoolJob j;
+    j.X = X;
+    j.Y = Y;
+    j.tag = tag;
+    j.acc.assign(acc, acc + a);
+    uint64_t N = 0;
+    for (int s = c->P.max_k; s >= 1; --s) {
+        N += binom_sat(a, s);
+        if (N > (1ull << 62)) N = 1ull << 62;
+    }
+    const uint64_t mt = c->P.max_tests > 0 ? (uint64_t)c->P.max_tests : 0;
+    if (mt && mt < N) N = mt;
+    j.N = N;
+    j.next = 0;
+    j.width = c->P.kind == FW_FZ ? 256ull : 16ull;
+    j.best_p = -1.0;
+    j.best_stat = 0.0;
+    j.best_rank = 0;
+    j.best_df = 0;
+    j.done = false;
+    j.out = FwJobOut{};
+    pool.live.push_back(std::move(j));
+    return FW_OK;
+}
+
+static void finish_job(const fw_ctx *c, FwPoolJob &j)
+{
+    int s = 0, pos[FW_MAX_K] = {0, 0, 0, 0, 0};
+    unrank_host(j.best_rank, (int)j.acc.size(), c->P.max_k, &s, pos);  // conditioning set of the returned result
+    j.out.n_zs = s;
+    for (int q = 0; q < FW_MAX_K; ++q) j.out.zs[q] = q < s ? j.acc[pos[q]] : 0;
+    j.done = true;
+}
+
+// One window of every live job = one kernel launch.  Finished jobs are moved to `finished`.
+int fwi_pool_round(fw_ctx *c, FwPool &pool, std::vector<FwPoolJob> &finished)
+{
+    if (pool.live.empty()) return FW_OK;
     const bool fz = c->P.kind == FW_FZ;
     if (fz && c->P.n < c->n_obs_min_eff) {
-        // tests.jl:254-262: every test lacks power -> the first one is returned (0, 1, 0, false)
-        for (int64_t i = 0; i < m; ++i) {
-            FwJobOut o{};
-            o.stat = 0.0;
-            o.pval = 1.0;
-            o.num_tests = 1;
-            o.evaluated = 0;
-            o.status = FW_SUBSETS_STOPPED;
-            int s = std::min<int>(c->P.max_k, jobs[i].acc_len);
-            o.n_zs = s;
-            for (int q = 0; q < s; ++q) o.zs[q] = acc[jobs[i].acc_off + q];
-            out[i] = o;
+        for (FwPoolJob &j : pool.live) {
+            no_power_result(c, j.acc.data(), (int)j.acc.size(), j.out);
+            j.done = true;
+            finished.push_back(std::move(j));
         }
+        pool.live.clear();
         return FW_OK;
     }
-    struct JState {
-        uint64_t N, next, width;
-        double best_p, best_stat;
-        uint64_t best_rank;
-        int32_t best_df;
-        bool done;
-    };
-    std::vector<JState> st((size_t)m);
-    const uint64_t mt = c->P.max_tests > 0 ? (uint64_t)c->P.max_tests : 0;
-    for (int64_t i = 0; i < m; ++i) {
-        uint64_t N = 0;
-        for (int s = c->P.max_k; s >= 1; --s) {
-            N += binom_sat(jobs[i].acc_len, s);
-            if (N > (1ull << 62)) N = 1ull << 62;
-        }
-        if (mt && mt < N) N = mt;
-        st[i] = JState{N, 0, fz ? 256ull : 16ull, -1.0, 0.0, 0, 0, false};
-        out[i] = FwJobOut{};
+    const double tb0 = now_s();
+    // window of every live job, then a segment length that yields a few thousand workgroups
+    uint64_t total = 0, acc_total = 0;
+    for (const FwPoolJob &j : pool.live) {
+        total += std::min(j.width, j.N - j.next);
+        acc_total += j.acc.size();
     }
+    // fz: one lane per test (256-rank granularity); discrete: one wavefront per test (4-rank granularity)
+    const uint64_t q = fz ? 256 : 4, smin = fz ? 256 : 8, smax = fz ? 8192 : 256;
+    uint64_t seglen = (total / 4096 + q - 1) / q * q;
+    seglen = std::max<uint64_t>(smin, std::min<uint64_t>(seglen, smax));
+    size_t ns = 0;
+    for (const FwPoolJob &j : pool.live) ns += (size_t)((std::min(j.width, j.N - j.next) + seglen - 1) / seglen);
     int rc;
-    if ((rc = fw_dev_reserve(c, c->d_acc, (size_t)std::max<int64_t>(acc_total, 1) * sizeof(int32_t)))) return rc;
-    FW_HIP(c, hipMemcpyAsync(c->d_acc.ptr, acc, (size_t)acc_total * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    if ((rc = fw_pin_reserve(c, c->h_jobs, ns * sizeof(FwSeg)))) return rc;
+    if ((rc = fw_pin_reserve(c, c->h_acc, std::max<size_t>(acc_total, 1) * sizeof(int32_t)))) return rc;
+    if ((rc = fw_pin_reserve(c, c->h_out, ns * sizeof(FwSegOut)))) return rc;
+    if ((rc = fw_dev_reserve(c, c->d_acc, std::max<size_t>(acc_total, 1) * sizeof(int32_t)))) return rc;
+    if ((rc = fw_dev_reserve(c, c->d_segs, ns * sizeof(FwSeg)))) return rc;
+    if ((rc = fw_dev_reserve(c, c->d_segout, ns * sizeof(FwSegOut)))) return rc;
+    FwSeg *segs = (FwSeg *)c->h_jobs.ptr;
+    int32_t *hacc = (int32_t *)c->h_acc.ptr;
+    pool.seg_job.resize(ns);
+    size_t si = 0;
+    int64_t aoff = 0;
+    for (size_t ji = 0; ji < pool.live.size(); ++ji) {
+        const FwPoolJob &j = pool.live[ji];
+        memcpy(hacc + aoff, j.acc.data(), j.acc.size() * sizeof(int32_t));
+        const uint64_t lo = j.next, hi = lo + std::min(j.width, j.N - lo);
+        for (uint64_t sgs = lo; sgs < hi; sgs += seglen) {
+            FwSeg sg{};
+            sg.X = j.X;
+            sg.Y = j.Y;
+            sg.acc_off = aoff;
+            sg.acc_len = (int32_t)j.acc.size();
+            sg.start = sgs;
+            sg.end = std::min(hi, sgs + seglen);
+            segs[si] = sg;
+            pool.seg_job[si] = (int64_t)ji;
+            ++si;
+        }
+        aoff += (int64_t)j.acc.size();
+    }
+    const double tb1 = now_s();
+    c->cnt.t_host_build_s += tb1 - tb0;
+    FW_HIP(c, hipMemcpyAsync(c->d_acc.ptr, hacc, (size_t)acc_total * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    FW_HIP(c, hipMemcpyAsync(c->d_segs.ptr, segs, ns * sizeof(FwSeg), hipMemcpyHostToDevice, c->stream));
+    rc = fz ? fwi_fz_segments(c, (int64_t)ns, (const FwSeg *)c->d_segs.ptr, (const int32_t *)c->d_acc.ptr, (FwSegOut *)c->d_segout.ptr)
+            : fwi_mi_segments(c, (int64_t)ns, (const FwSeg *)c->d_segs.ptr, (const int32_t *)c->d_acc.ptr, (FwSegOut *)c->d_segout.ptr);
+    if (rc) return rc;
+    const FwSegOut *so = (const FwSegOut *)c->h_out.ptr;
+    FW_HIP(c, hipMemcpyAsync(c->h_out.ptr, c->d_segout.ptr, ns * sizeof(FwSegOut), hipMemcpyDeviceToHost, c->stream));
+    FW_HIP(c, hipStreamSynchronize(c->stream));
+    const double tb2 = now_s();
+    c->cnt.t_host_wait_s += tb2 - tb1;
+    float ms = 0.0f;
+    FW_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->cnt.t_dev_subsets_s += 1e-3 * (double)ms;
+    c->cnt.kernel_launches += 1;
+    c->cnt.subsets_launches += 1;
+    // in-order merge (segments of a job are contiguous and in rank order)
+    for (size_t s = 0; s < ns; ++s) {
+        FwPoolJob &j = pool.live[(size_t)pool.seg_job[s]];
+        j.out.evaluated += (int64_t)so[s].evaluated;
+        if (j.done) continue;  // a later (speculative) segment of a job that already stopped
+        if (so[s].stop_rank != FW_RANK_NONE) {
+            j.out.stat = so[s].stop_stat;
+            j.out.pval = so[s].stop_pval;
+            j.out.df = so[s].stop_df;
+            j.out.suff_power = so[s].stop_power;
+            j.out.status = FW_SUBSETS_STOPPED;
+            j.out.num_tests = (int64_t)(so[s].stop_rank + 1);
+            j.best_rank = so[s].stop_rank;
+            j.done = true;  // zs filled below
+        } else if (so[s].best_pval >= j.best_p) {
+            j.best_p = so[s].best_pval;
+            j.best_stat = so[s].best_stat;
+            j.best_rank = so[s].best_rank;
+            j.best_df = so[s].best_df;
+        }
+    }
+    size_t w = 0;
+    for (size_t ji = 0; ji < pool.live.size(); ++ji) {
+        FwPoolJob &j = pool.live[ji];
+        if (!j.done) {
+            j.next += std::min(j.width, j.N - j.next);
+            j.width *= 4;
+            if (j.next >= j.N) {
+                j.out.stat = j.best_stat;
+                j.out.pval = j.best_p < 0.0 ? 0.0 : j.best_p;
+                j.out.df = j.best_df;
+                j.out.suff_power = 1;
+                j.out.status = FW_SUBSETS_ALL_SIG;
+                j.out.num_tests = (int64_t)j.N;
+                j.done = true;
+            }
+        }
+        if (j.done) {
+            finish_job(c, j);
+            finished.push_back(std::move(j));
+        } else {
+            if (w != ji) pool.live[w] = std::move(j);
+            ++w;
+        }
+    }
+    pool.live.resize(w);
+    c->cnt.t_host_merge_s += now_s() - tb2;
+    return FW_OK;
+}
 
-    std::vector<FwSeg> segs;
-    std::vector<int64_t> seg_job;
-    std::vector<FwSegOut> so;
-    std::vector<int64_t> live((size_t)m);
-    for (int64_t i = 0; i < m; ++i) live[i] = i;
-    while (!live.empty()) {
-        // window of every live job, then a segment length that yields a few thousand workgroups
-        uint64_t total = 0;
-        for (int64_t j : live) total += std::min(st[j].width, st[j].N - st[j].next);
-        // fz: one lane per test (256-rank granularity); discrete: one wavefront per test (4-rank granularity)
-        const uint64_t q = fz ? 256 : 4, smin = fz ? 256 : 8, smax = fz ? 8192 : 256;
-        uint64_t seglen = (total / 4096 + q - 1) / q * q;
-        seglen = std::max<uint64_t>(smin, std::min<uint64_t>(seglen, smax));
-        segs.clear();
-        seg_job.clear();
-        for (int64_t j : live) {
-            const uint64_t lo = st[j].next, hi = lo + std::min(st[j].width, st[j].N - lo);
-            for (uint64_t sgs = lo; sgs < hi; sgs += seglen) {
-                FwSeg sg{};
-                sg.X = jobs[j].X;
-                sg.Y = jobs[j].Y;
-                sg.acc_off = jobs[j].acc_off;
-                sg.acc_len = jobs[j].acc_len;
-                sg.start = sgs;
-                sg.end = std::min(hi, sgs + seglen);
-                segs.push_back(sg);
-                seg_job.push_back(j);
-            }
-        }
-        const size_t ns = segs.size();
-        if ((rc = fw_dev_reserve(c, c->d_segs, ns * sizeof(FwSeg)))) return rc;
-        if ((rc = fw_dev_reserve(c, c->d_segout, ns * sizeof(FwSegOut)))) return rc;
-        FW_HIP(c, hipMemcpyAsync(c->d_segs.ptr, segs.data(), ns * sizeof(FwSeg), hipMemcpyHostToDevice, c->stream));
-        rc = fz ? fwi_fz_segments(c, (int64_t)ns, (const FwSeg *)c->d_segs.ptr, (const int32_t *)c->d_acc.ptr, (FwSegOut *)c->d_segout.ptr)
-                : fwi_mi_segments(c, (int64_t)ns, (const FwSeg *)c->d_segs.ptr, (const int32_t *)c->d_acc.ptr, (FwSegOut *)c->d_segout.ptr);
+int fwi_subsets_dispatch(fw_ctx *c, int64_t m, const FwJob *jobs, const int32_t *acc, int64_t acc_total, FwJobOut *out)
+{
+    (void)acc_total;
+    FwPool pool;
+    for (int64_t i = 0; i < m; ++i) fwi_pool_add(c, pool, jobs[i].X, jobs[i].Y, acc + jobs[i].acc_off, jobs[i].acc_len, i);
+    std::vector<FwPoolJob> fin;
+    while (!pool.live.empty()) {
+        int rc = fwi_pool_round(c, pool, fin);
         if (rc) return rc;
-        so.resize(ns);
-        FW_HIP(c, hipMemcpyAsync(so.data(), c->d_segout.ptr, ns * sizeof(FwSegOut), hipMemcpyDeviceToHost, c->stream));
-        FW_HIP(c, hipStreamSynchronize(c->stream));
-        float ms = 0.0f;
-        FW_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        c->cnt.t_dev_subsets_s += 1e-3 * (double)ms;
-        c->cnt.kernel_launches += 1;
-        c->cnt.subsets_launches += 1;
-        // in-order merge
-        for (size_t q = 0; q < ns; ++q) {
-            const int64_t j = seg_job[q];
-            JState &s = st[j];
-            FwJobOut &o = out[j];
-            o.evaluated += (int64_t)so[q].evaluated;
-            if (s.done) continue;  // a later (speculative) segment of a job that already stopped
-            if (so[q].stop_rank != FW_RANK_NONE) {
-                s.done = true;
-                o.stat = so[q].stop_stat;
-                o.pval = so[q].stop_pval;
-                o.df = so[q].stop_df;
-                o.suff_power = so[q].stop_power;
-                o.status = FW_SUBSETS_STOPPED;
-                o.num_tests = (int64_t)(so[q].stop_rank + 1);
-                s.best_rank = so[q].stop_rank;
-            } else if (so[q].best_pval >= s.best_p) {
-                s.best_p = so[q].best_pval;
-                s.best_stat = so[q].best_stat;
-                s.best_rank = so[q].best_rank;
-                s.best_df = so[q].best_df;
-            }
-        }
-        std::vector<int64_t> nxt;
-        for (int64_t j : live) {
-            JState &s = st[j];
-            if (s.done) continue;
-            s.next += std::min(s.width, s.N - s.next);
-            s.width *= 4;
-            if (s.next >= s.N) {
-                s.done = true;
-                FwJobOut &o = out[j];
-                o.stat = s.best_stat;
-                o.pval = s.best_p < 0.0 ? 0.0 : s.best_p;
-                o.df = s.best_df;
-                o.suff_power = 1;
-                o.status = FW_SUBSETS_ALL_SIG;
-                o.num_tests = (int64_t)s.N;
-            } else {
-                nxt.push_back(j);
-            }
-        }
-        live.swap(nxt);
     }
-    // conditioning set of the returned result from its rank
-    for (int64_t i = 0; i < m; ++i) {
-        int s = 0, pos[FW_MAX_K] = {0, 0, 0, 0, 0};
-        unrank_host(st[i].best_rank, jobs[i].acc_len, c->P.max_k, &s, pos);
-        out[i].n_zs = s;
-        for (int q = 0; q < FW_MAX_K; ++q) out[i].zs[q] = q < s ? acc[jobs[i].acc_off + pos[q]] : 0;
-    }
+    for (FwPoolJob &j : fin) out[j.tag] = j.out;
     return FW_OK;
 }
 

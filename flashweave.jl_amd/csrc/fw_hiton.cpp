@@ -167,10 +167,6 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
         }
     } else {
         const int R = (opt.round_size <= 0) ? nt : opt.round_size;
-        std::vector<FwJob> jobs;
-        std::vector<int32_t> accflat;
-        std::vector<FwJobOut> jout;
-        std::vector<int> jt;
         for (int r0 = 0; r0 < nt; r0 += R) {
             const int r1 = std::min(nt, r0 + R);
             // this rank's targets of the round: dealt round-robin in schedule order
@@ -199,35 +195,32 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                 }
                 tg.push_back(std::move(t));
             }
-            // level-synchronous steps
-            std::vector<int> active(tg.size());
-            std::iota(active.begin(), active.end(), 0);
-            while (!active.empty()) {
-                jobs.clear();
-                accflat.clear();
-                jt.clear();
-                for (int ti : active) {
+            // asynchronous job pool: a target posts its next (T, candidate, accepted) job as soon as its previous one
+            // has finished; every pool round evaluates one window of every in-flight job in ONE kernel launch.
+            FwPool pool;
+            std::vector<FwPoolJob> fin;
+            std::vector<int> need(tg.size());
+            std::iota(need.begin(), need.end(), 0);
+            for (;;) {
+                const double ta0 = now_s();
+                for (int ti : need) {
                     Target &t = tg[ti];
                     if (!advance(c, t)) continue;
-                    FwJob j{};
-                    j.X = t.T;
-                    j.Y = t.cands[t.pos];
-                    j.acc_off = (int64_t)accflat.size();
-                    j.acc_len = (int32_t)t.acc.size();
-                    accflat.insert(accflat.end(), t.acc.begin(), t.acc.end());
-                    jobs.push_back(j);
-                    jt.push_back(ti);
+                    fwi_pool_add(c, pool, t.T, t.cands[t.pos], t.acc.data(), (int)t.acc.size(), ti);
                 }
-                if (jobs.empty()) break;
-                jout.resize(jobs.size());
-                int rc = fwi_subsets_dispatch(c, (int64_t)jobs.size(), jobs.data(), accflat.data(), (int64_t)accflat.size(), jout.data());
+                need.clear();
+                c->cnt.t_host_advance_s += now_s() - ta0;
+                if (pool.live.empty()) break;
+                fin.clear();
+                int rc = fwi_pool_round(c, pool, fin);
                 if (rc) return rc;
-                for (size_t q = 0; q < jobs.size(); ++q) {
-                    Target &t = tg[jt[q]];
-                    const FwJobOut &o = jout[q];
+                const double ta1 = now_s();
+                for (FwPoolJob &j : fin) {
+                    Target &t = tg[(size_t)j.tag];
+                    const FwJobOut &o = j.out;
                     c->cnt.cond_tests_ref += o.num_tests;
                     c->cnt.cond_tests_evaluated += o.evaluated;
-                    c->cnt.alg_bytes_subsets += fwi_alg_bytes(c, jobs[q].acc_len, o.evaluated);
+                    c->cnt.alg_bytes_subsets += fwi_alg_bytes(c, (int)j.acc.size(), o.evaluated);
                     c->cnt.subsets_calls += 1;
                     const int32_t cand = t.cands[t.pos];
                     if (o.pval < c->P.alpha && o.suff_power) {  // issig, tests.jl:1-3; hiton.jl:61-63
@@ -235,8 +228,9 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                         (t.phase == 0 ? t.TPC : t.PC).set(cand, o.stat, o.pval);
                     }
                     ++t.pos;
+                    need.push_back((int)j.tag);
                 }
-                active.swap(jt);
+                c->cnt.t_host_advance_s += now_s() - ta1;
             }
             // exchange this round's directed results (target, neighbour, stat, p)
             std::vector<int32_t> lt, ln;

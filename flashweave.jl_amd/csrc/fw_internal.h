@@ -148,6 +148,25 @@ int fwi_mi_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_
 // algorithmic bytes of the first `evaluated` tests of a job with |accepted| = a (enumeration order: sizes max_k..1)
 double fwi_alg_bytes(const fw_ctx *ctx, int a, int64_t evaluated);
 
+// ---- asynchronous job pool (fw_core.cpp): every round evaluates one window of every live job in ONE launch ----
+struct FwPoolJob {
+    int32_t X = 0, Y = 0;
+    int64_t tag = 0;
+    std::vector<int32_t> acc;
+    uint64_t N = 0, next = 0, width = 0;
+    double best_p = -1.0, best_stat = 0.0;
+    uint64_t best_rank = 0;
+    int32_t best_df = 0;
+    bool done = false;
+    FwJobOut out{};
+};
+struct FwPool {
+    std::vector<FwPoolJob> live;
+    std::vector<int64_t> seg_job;
+};
+int fwi_pool_add(fw_ctx *ctx, FwPool &pool, int32_t X, int32_t Y, const int32_t *acc, int a, int64_t tag);
+int fwi_pool_round(fw_ctx *ctx, FwPool &pool, std::vector<FwPoolJob> &finished);
+
 // ---- host driver (fw_hiton.cpp) ----
 int fwi_subsets_dispatch(fw_ctx *ctx, int64_t m, const FwJob *jobs_host, const int32_t *acc_host, int64_t acc_total,
                          FwJobOut *out_host);

@@ -96,6 +96,10 @@ typedef struct fw_counters {
     double t_level0_s;           /* wall seconds inside fw_level0 */
     double t_cond_s;             /* wall seconds inside the conditional stage of fw_learn_network */
     double t_dev_subsets_s;      /* HIP-event seconds of the test_subsets kernels (sum) */
+    double t_host_advance_s;     /* host: HITON-PC state machines + job posting */
+    double t_host_build_s;       /* host: segment construction + staging */
+    double t_host_wait_s;        /* host: waiting for the device (copies + kernel + sync) */
+    double t_host_merge_s;       /* host: in-order merge of segment outputs */
     double alg_bytes_subsets;    /* algorithmic bytes of the evaluated conditional tests:
                                     fz: 4*C(k+2,2)+32 per test of order k; discrete: (k+2)*n*b/8+32, b = 1 (mi) / 2 (mi_nz) */
 } fw_counters;
