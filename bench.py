@@ -158,7 +158,7 @@ def main():
                "stage_seconds_rank0": {"level0": cn["t_level0_s"] / steps, "conditional": cn["t_cond_s"] / steps,
                                        "subsets_kernels_device": sub_launch_s / steps,
                                        "host_advance": cn["t_host_advance_s"] / steps, "host_build": cn["t_host_build_s"] / steps,
-                                       "host_wait_device": cn["t_host_wait_s"] / steps, "host_merge": cn["t_host_merge_s"] / steps,
+                                       "host_launch": cn["t_host_launch_s"] / steps, "host_wait_device": cn["t_host_wait_s"] / steps, "host_merge": cn["t_host_merge_s"] / steps,
                                        "subsets_calls": cn["subsets_calls"] / steps},
                "kernel_launches_per_step": launches / steps,
                "roofline": roofline, "cpu_baseline": cpu}

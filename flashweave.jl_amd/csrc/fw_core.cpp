@@ -111,6 +111,12 @@ int fw_ctx_create(const fw_params *P, fw_ctx **out)
         delete c;
         return fw_fail(nullptr, FW_ERR_DEVICE, "stream/event creation failed: %s", hipGetErrorString(e));
     }
+    for (FwPoolBuf &b : c->pb)
+        if ((e = hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking)) != hipSuccess ||
+            (e = hipEventCreate(&b.ev0)) != hipSuccess || (e = hipEventCreate(&b.ev1)) != hipSuccess) {
+            fw_ctx_destroy(c);
+            return fw_fail(nullptr, FW_ERR_DEVICE, "stream/event creation failed: %s", hipGetErrorString(e));
+        }
     // continuous: the automatic n_obs_min is known immediately (learning.jl:59-61); discrete needs levels
     c->n_obs_min_eff = P->n_obs_min >= 0 ? P->n_obs_min : (P->kind == FW_FZ ? 20 : -1);
     *out = c;
@@ -135,7 +141,7 @@ int fw_ctx_destroy(fw_ctx *c)
     if (!c) return FW_OK;
     (void)hipSetDevice(c->P.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->d_data, c->d_xc, c->d_sd, c->d_cor, c->d_nzbits, c->d_hibits, c->d_levels, c->d_maxvals, c->d_firstnz};
+    void *ptrs[] = {c->d_data, c->d_xc, c->d_sd, c->d_cor, c->d_thr, c->d_nzbits, c->d_hibits, c->d_levels, c->d_maxvals, c->d_firstnz};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     free_dev(c->d_jobs);
@@ -147,6 +153,16 @@ int fw_ctx_destroy(fw_ctx *c)
     free_pin(c->h_jobs);
     free_pin(c->h_acc);
     free_pin(c->h_out);
+    for (FwPoolBuf &b : c->pb) {
+        if (b.stream) (void)hipStreamSynchronize(b.stream);
+        free_pin(b.h_in);
+        free_pin(b.h_out);
+        free_dev(b.d_in);
+        free_dev(b.d_out);
+        if (b.ev0) (void)hipEventDestroy(b.ev0);
+        if (b.ev1) (void)hipEventDestroy(b.ev1);
+        if (b.stream) (void)hipStreamDestroy(b.stream);
+    }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -470,8 +486,11 @@ int fwi_pool_add(fw_ctx *c, FwPool &pool, int32_t X, int32_t Y, const int32_t *a
     return FW_OK;
 }
 
-static void finish_job(const fw_ctx *c, FwPoolJob &j)
+static void finish_job(const fw_ctx *c, FwPoolJob &j, bool want_zs)
 {
+    j.done = true;
+    j.out.n_zs = 0;
+    if (!want_zs) return;  // the HITON driver never looks at the conditioning set of the returned result
     int s = 0, pos[FW_MAX_K] = {0, 0, 0, 0, 0};
     unrank_host(j.best_rank, (int)j.acc.size(), c->P.max_k, &s, pos);  // conditioning set of the returned result
     j.out.n_zs = s;
@@ -479,21 +498,21 @@ static void finish_job(const fw_ctx *c, FwPoolJob &j)
     j.done = true;
 }
 
-// One window of every live job = one kernel launch.  Finished jobs are moved to `finished`.
-int fwi_pool_round(fw_ctx *c, FwPool &pool, std::vector<FwPoolJob> &finished)
+// One window of every live job = one kernel launch on the pool's own stream.  fwi_pool_launch only enqueues;
+// fwi_pool_collect waits for it and merges.  Two pools can therefore overlap: the host merges / re-posts one
+// while the GPU evaluates the other.
+int fwi_pool_launch(fw_ctx *c, FwPool &pool)
 {
+    pool.ns = 0;
+    pool.inflight = false;
     if (pool.live.empty()) return FW_OK;
     const bool fz = c->P.kind == FW_FZ;
-    if (fz && c->P.n < c->n_obs_min_eff) {
-        for (FwPoolJob &j : pool.live) {
-            no_power_result(c, j.acc.data(), (int)j.acc.size(), j.out);
-            j.done = true;
-            finished.push_back(std::move(j));
-        }
-        pool.live.clear();
+    if (fz && c->P.n < c->n_obs_min_eff) {  // no device work: fwi_pool_collect fills the results
+        pool.inflight = true;
         return FW_OK;
     }
     const double tb0 = now_s();
+    FwPoolBuf &pb = c->pb[pool.buf];
     // window of every live job, then a segment length that yields a few thousand workgroups
     uint64_t total = 0, acc_total = 0;
     for (const FwPoolJob &j : pool.live) {
@@ -506,15 +525,14 @@ int fwi_pool_round(fw_ctx *c, FwPool &pool, std::vector<FwPoolJob> &finished)
     seglen = std::max<uint64_t>(smin, std::min<uint64_t>(seglen, smax));
     size_t ns = 0;
     for (const FwPoolJob &j : pool.live) ns += (size_t)((std::min(j.width, j.N - j.next) + seglen - 1) / seglen);
+    const size_t in_bytes = ns * sizeof(FwSeg) + std::max<size_t>(acc_total, 1) * sizeof(int32_t);
     int rc;
-    if ((rc = fw_pin_reserve(c, c->h_jobs, ns * sizeof(FwSeg)))) return rc;
-    if ((rc = fw_pin_reserve(c, c->h_acc, std::max<size_t>(acc_total, 1) * sizeof(int32_t)))) return rc;
-    if ((rc = fw_pin_reserve(c, c->h_out, ns * sizeof(FwSegOut)))) return rc;
-    if ((rc = fw_dev_reserve(c, c->d_acc, std::max<size_t>(acc_total, 1) * sizeof(int32_t)))) return rc;
-    if ((rc = fw_dev_reserve(c, c->d_segs, ns * sizeof(FwSeg)))) return rc;
-    if ((rc = fw_dev_reserve(c, c->d_segout, ns * sizeof(FwSegOut)))) return rc;
-    FwSeg *segs = (FwSeg *)c->h_jobs.ptr;
-    int32_t *hacc = (int32_t *)c->h_acc.ptr;
+    if ((rc = fw_pin_reserve(c, pb.h_in, in_bytes))) return rc;
+    if ((rc = fw_pin_reserve(c, pb.h_out, ns * sizeof(FwSegOut)))) return rc;
+    if ((rc = fw_dev_reserve(c, pb.d_in, in_bytes))) return rc;
+    if ((rc = fw_dev_reserve(c, pb.d_out, ns * sizeof(FwSegOut)))) return rc;
+    FwSeg *segs = (FwSeg *)pb.h_in.ptr;
+    int32_t *hacc = (int32_t *)((char *)pb.h_in.ptr + ns * sizeof(FwSeg));
     pool.seg_job.resize(ns);
     size_t si = 0;
     int64_t aoff = 0;
@@ -538,21 +556,46 @@ int fwi_pool_round(fw_ctx *c, FwPool &pool, std::vector<FwPoolJob> &finished)
     }
     const double tb1 = now_s();
     c->cnt.t_host_build_s += tb1 - tb0;
-    FW_HIP(c, hipMemcpyAsync(c->d_acc.ptr, hacc, (size_t)acc_total * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    FW_HIP(c, hipMemcpyAsync(c->d_segs.ptr, segs, ns * sizeof(FwSeg), hipMemcpyHostToDevice, c->stream));
-    rc = fz ? fwi_fz_segments(c, (int64_t)ns, (const FwSeg *)c->d_segs.ptr, (const int32_t *)c->d_acc.ptr, (FwSegOut *)c->d_segout.ptr)
-            : fwi_mi_segments(c, (int64_t)ns, (const FwSeg *)c->d_segs.ptr, (const int32_t *)c->d_acc.ptr, (FwSegOut *)c->d_segout.ptr);
+    FW_HIP(c, hipMemcpyAsync(pb.d_in.ptr, pb.h_in.ptr, in_bytes, hipMemcpyHostToDevice, pb.stream));
+    const FwSeg *dsegs = (const FwSeg *)pb.d_in.ptr;
+    const int32_t *dacc = (const int32_t *)((const char *)pb.d_in.ptr + ns * sizeof(FwSeg));
+    rc = fz ? fwi_fz_segments(c, (int64_t)ns, dsegs, dacc, (FwSegOut *)pb.d_out.ptr, pb)
+            : fwi_mi_segments(c, (int64_t)ns, dsegs, dacc, (FwSegOut *)pb.d_out.ptr, pb);
     if (rc) return rc;
-    const FwSegOut *so = (const FwSegOut *)c->h_out.ptr;
-    FW_HIP(c, hipMemcpyAsync(c->h_out.ptr, c->d_segout.ptr, ns * sizeof(FwSegOut), hipMemcpyDeviceToHost, c->stream));
-    FW_HIP(c, hipStreamSynchronize(c->stream));
+    FW_HIP(c, hipMemcpyAsync(pb.h_out.ptr, pb.d_out.ptr, ns * sizeof(FwSegOut), hipMemcpyDeviceToHost, pb.stream));
+    pool.ns = ns;
+    pool.inflight = true;
+    pool.t_launch = now_s();
+    c->cnt.t_host_launch_s += pool.t_launch - tb1;
+    return FW_OK;
+}
+
+int fwi_pool_collect(fw_ctx *c, FwPool &pool, std::vector<FwPoolJob> &finished)
+{
+    if (!pool.inflight) return FW_OK;
+    pool.inflight = false;
+    const bool fz = c->P.kind == FW_FZ;
+    if (fz && c->P.n < c->n_obs_min_eff) {
+        for (FwPoolJob &j : pool.live) {
+            no_power_result(c, j.acc.data(), (int)j.acc.size(), j.out);
+            j.done = true;
+            finished.push_back(std::move(j));
+        }
+        pool.live.clear();
+        return FW_OK;
+    }
+    FwPoolBuf &pb = c->pb[pool.buf];
+    const double tb1 = now_s();
+    FW_HIP(c, hipStreamSynchronize(pb.stream));
     const double tb2 = now_s();
     c->cnt.t_host_wait_s += tb2 - tb1;
     float ms = 0.0f;
-    FW_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    FW_HIP(c, hipEventElapsedTime(&ms, pb.ev0, pb.ev1));
     c->cnt.t_dev_subsets_s += 1e-3 * (double)ms;
     c->cnt.kernel_launches += 1;
     c->cnt.subsets_launches += 1;
+    const size_t ns = pool.ns;
+    const FwSegOut *so = (const FwSegOut *)pb.h_out.ptr;
     // in-order merge (segments of a job are contiguous and in rank order)
     for (size_t s = 0; s < ns; ++s) {
         FwPoolJob &j = pool.live[(size_t)pool.seg_job[s]];
@@ -566,7 +609,7 @@ int fwi_pool_round(fw_ctx *c, FwPool &pool, std::vector<FwPoolJob> &finished)
             j.out.status = FW_SUBSETS_STOPPED;
             j.out.num_tests = (int64_t)(so[s].stop_rank + 1);
             j.best_rank = so[s].stop_rank;
-            j.done = true;  // zs filled below
+            j.done = true;
         } else if (so[s].best_pval >= j.best_p) {
             j.best_p = so[s].best_pval;
             j.best_stat = so[s].best_stat;
@@ -591,7 +634,7 @@ int fwi_pool_round(fw_ctx *c, FwPool &pool, std::vector<FwPoolJob> &finished)
             }
         }
         if (j.done) {
-            finish_job(c, j);
+            finish_job(c, j, pool.want_zs);
             finished.push_back(std::move(j));
         } else {
             if (w != ji) pool.live[w] = std::move(j);
@@ -603,10 +646,18 @@ int fwi_pool_round(fw_ctx *c, FwPool &pool, std::vector<FwPoolJob> &finished)
     return FW_OK;
 }
 
+int fwi_pool_round(fw_ctx *c, FwPool &pool, std::vector<FwPoolJob> &finished)
+{
+    int rc = fwi_pool_launch(c, pool);
+    if (rc) return rc;
+    return fwi_pool_collect(c, pool, finished);
+}
+
 int fwi_subsets_dispatch(fw_ctx *c, int64_t m, const FwJob *jobs, const int32_t *acc, int64_t acc_total, FwJobOut *out)
 {
     (void)acc_total;
     FwPool pool;
+    pool.want_zs = true;
     for (int64_t i = 0; i < m; ++i) fwi_pool_add(c, pool, jobs[i].X, jobs[i].Y, acc + jobs[i].acc_off, jobs[i].acc_len, i);
     std::vector<FwPoolJob> fin;
     while (!pool.live.empty()) {

@@ -517,19 +517,58 @@ __device__ __forceinline__ double pc_l3(double a, double b, double c)
 // 10 formula evaluations and 6 of the 10 matrix entries).  Rank order is preserved: a lane stops at its first
 // stopping rank, the workgroup takes the minimum over lanes.
 #define FW_RUN_MAX 8
+#define FZ_X_NONE 1.0e308    // "no candidate yet"
+#define FZ_X_SUB 26.0        // beyond this x = |z|/sqrt2, erfc(x)/2*2 leaves the normal range (ties become possible)
+#define FZ_X_SUBKEY 1.0e300  // common x-key of the underflow regime (ordered by exact p there)
+
+// (xa, pa, ra) strictly better than (xb, pb, rb)?  smaller x-key = larger p; equal keys: larger exact p, then later rank
+__device__ __forceinline__ bool fz_key_better(double xa, double pa, unsigned long long ra, double xb, double pb,
+                                              unsigned long long rb)
+{
+    if (xa != xb) return xa < xb;
+    if (xa == FZ_X_NONE) return false;
+    if (pa != pb) return pa > pb;
+    return ra > rb;
+}
+
+// |r| thresholds for `p < alpha`: bisection on the exact device p-value, then a +-1e-9 relative guard band.
+// thr = {lo_pos, hi_pos, lo_neg, hi_neg}: |r| > hi -> significant for sure, |r| < lo -> not significant for sure.
+__global__ void fz_thresholds_kernel(double alpha, double zscale, double *thr)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int sgn = 0; sgn < 2; ++sgn) {
+        double lo = 0.0, hi = 1.0;  // p(lo) >= alpha (not sig), p(hi) < alpha (sig) unless nothing is ever significant
+        const double sg = sgn ? -1.0 : 1.0;
+        if (!(fz_pval_dev(sg * 1.0, zscale) < alpha)) {
+            thr[2 * sgn] = 2.0;
+            thr[2 * sgn + 1] = 2.0;
+            continue;
+        }
+        for (int it = 0; it < 200; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (fz_pval_dev(sg * mid, zscale) < alpha)
+                hi = mid;
+            else
+                lo = mid;
+        }
+        thr[2 * sgn] = lo * (1.0 - 1e-9);
+        thr[2 * sgn + 1] = hi * (1.0 + 1e-9);
+    }
+}
 
 template <bool HIGHK>  // HIGHK: conditioning sets of size 4-5 possible (generic DP fallback compiled in)
 __global__ __launch_bounds__(256) void fz_subsets_seg_kernel(const float *__restrict__ cor, int p,
                                                              const FwSeg *__restrict__ segs,
                                                              const int32_t *__restrict__ accflat,
                                                              FwSegOut *__restrict__ out, int max_k, double alpha,
-                                                             double zscale, long long max_tests)
+                                                             double zscale, long long max_tests,
+                                                             const double *__restrict__ thr)
 {
     __shared__ int s_acc[FW_ACC_LDS];
     __shared__ unsigned long long s_stop[4];
-    __shared__ double s_bp[4];
+    __shared__ double s_bx[4], s_bps[4];
     __shared__ unsigned long long s_br[4];
-    __shared__ double s_best_p, s_best_stat;
+    __shared__ double s_best_x, s_best_ps, s_best_stat;
     __shared__ unsigned long long s_best_rank;
 
     const FwSeg seg = segs[blockIdx.x];
@@ -540,13 +579,16 @@ __global__ __launch_bounds__(256) void fz_subsets_seg_kernel(const float *__rest
     if (in_lds)
         for (int i = tid; i < a; i += 256) s_acc[i] = gacc[i];
     if (tid == 0) {
-        s_best_p = -1.0;
+        s_best_x = FZ_X_NONE;
+        s_best_ps = 0.0;
         s_best_stat = 0.0;
         s_best_rank = 0;
     }
     unsigned long long cnt[FW_MAX_K + 1];
 #pragma unroll
     for (int s = FW_MAX_K; s >= 1; --s) cnt[s] = (s <= max_k) ? binom_u64(a, s) : 0ull;
+    // significance thresholds on |r| (see fz_thresholds_kernel): outside [lo, hi] the verdict of p < alpha is certain
+    const double rlo_pos = thr[0], rhi_pos = thr[1], rlo_neg = thr[2], rhi_neg = thr[3];
     __syncthreads();
 #define ACCV(i) (in_lds ? s_acc[(i)] : gacc[(i)])
 #define CORV(u, v) cor[(size_t)(u) * p + (v)]
@@ -565,7 +607,10 @@ __global__ __launch_bounds__(256) void fz_subsets_seg_kernel(const float *__rest
         const bool any = r0 < seg.end;
         // lane-local results
         unsigned long long my_stop = NONE, my_br = 0;
-        double stop_stat = 0.0, stop_p = 0.0, my_bp = -1.0, my_bstat = 0.0;
+        double stop_stat = 0.0, stop_p = 0.0, my_bstat = 0.0;
+        // lane best: ordered by x = |z|/sqrt2 ascending (= p descending); in the underflow regime (x > FZ_X_SUB, where
+        // different x can give the same subnormal/zero p) by the exact p instead; later rank wins ties (tests.jl:338)
+        double my_bx = FZ_X_NONE, my_bps = 0.0, my_ba = 0.0;
         if (any) {
             // unrank the first rank of the run
             unsigned long long rem = r0;
@@ -635,17 +680,40 @@ __global__ __launch_bounds__(256) void fz_subsets_seg_kernel(const float *__rest
                 } else {
                     stat = 0.0;
                 }
-                const double pv = fz_pval_dev(stat, zscale);
-                if (!(pv < alpha) || (max_tests > 0 && r + 1 >= (unsigned long long)max_tests)) {
+                const double av = fabs(stat);
+                const bool negr = stat < 0.0;
+                bool sig;
+                if (av > (negr ? rhi_neg : rhi_pos))
+                    sig = true;
+                else if (av < (negr ? rlo_neg : rlo_pos))
+                    sig = false;
+                else
+                    sig = fz_pval_dev(stat, zscale) < alpha;  // inside the guard band (or NaN): exact
+                if (!sig || (max_tests > 0 && r + 1 >= (unsigned long long)max_tests)) {
                     my_stop = r;
                     stop_stat = stat;
-                    stop_p = pv;
+                    stop_p = fz_pval_dev(stat, zscale);
                     break;
                 }
-                if (pv >= my_bp) {  // tests.jl:338, sequential within the run
-                    my_bp = pv;
-                    my_br = r;
-                    my_bstat = stat;
+                // tests.jl:338 `pval >= lowest.pval`, sequential within the run, without evaluating p for every test:
+                // |r| can only matter if it is not clearly larger than the current best's
+                if (my_bx == FZ_X_NONE || my_bx > FZ_X_SUB || av <= my_ba * (1.0 + 1e-12)) {
+                    const double xz = fabs(zscale * log((1.0 + stat) / (1.0 - stat))) * 0.7071067811865476;
+                    bool take;
+                    double ps = 0.0;
+                    if (xz > FZ_X_SUB) {
+                        ps = fz_pval_dev(stat, zscale);  // exact (possibly subnormal / zero) p
+                        take = (my_bx == FZ_X_NONE) || (my_bx > FZ_X_SUB && ps >= my_bps);
+                    } else {
+                        take = (my_bx == FZ_X_NONE) || (my_bx > FZ_X_SUB) || (xz <= my_bx);
+                    }
+                    if (take) {
+                        my_bx = xz;
+                        my_bps = ps;
+                        my_ba = av;
+                        my_br = r;
+                        my_bstat = stat;
+                    }
                 }
                 // next combination in lexicographic order (sizes descend when one is exhausted)
                 int i = s - 1;
@@ -670,20 +738,24 @@ __global__ __launch_bounds__(256) void fz_subsets_seg_kernel(const float *__rest
             const unsigned long long t = __shfl_xor(ws, o);
             ws = t < ws ? t : ws;
         }
-        double bp = my_bp;
+        // key of the lane best: (xk, ps, rank); xk = x in the normal regime, FZ_X_SUBKEY in the underflow regime
+        double bx = (my_bx == FZ_X_NONE) ? FZ_X_NONE : (my_bx > FZ_X_SUB ? FZ_X_SUBKEY : my_bx);
+        double bps = my_bps;
         unsigned long long br = my_br;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            const double op = __shfl_xor(bp, o);
+            const double ox = __shfl_xor(bx, o), ops = __shfl_xor(bps, o);
             const unsigned long long orr = __shfl_xor(br, o);
-            if (op > bp || (op == bp && orr > br)) {
-                bp = op;
+            if (fz_key_better(ox, ops, orr, bx, bps, br)) {
+                bx = ox;
+                bps = ops;
                 br = orr;
             }
         }
         if (lane == 0) {
             s_stop[wave] = ws;
-            s_bp[wave] = bp;
+            s_bx[wave] = bx;
+            s_bps[wave] = bps;
             s_br[wave] = br;
         }
         __syncthreads();
@@ -710,16 +782,20 @@ __global__ __launch_bounds__(256) void fz_subsets_seg_kernel(const float *__rest
             }
             return;
         }
-        double cbp = s_bp[0];
+        double cbx = s_bx[0], cbps = s_bps[0];
         unsigned long long cbr = s_br[0];
 #pragma unroll
         for (int w = 1; w < 4; ++w)
-            if (s_bp[w] > cbp || (s_bp[w] == cbp && s_br[w] > cbr)) {
-                cbp = s_bp[w];
+            if (fz_key_better(s_bx[w], s_bps[w], s_br[w], cbx, cbps, cbr)) {
+                cbx = s_bx[w];
+                cbps = s_bps[w];
                 cbr = s_br[w];
             }
-        if (my_bp >= 0.0 && my_br == cbr && my_bp == cbp && cbp >= s_best_p) {
-            s_best_p = my_bp;
+        // chunks hold increasing ranks: the newer chunk wins ties against the running best of the segment
+        if (my_bx != FZ_X_NONE && my_br == cbr && cbx != FZ_X_NONE &&
+            (s_best_x == FZ_X_NONE || !fz_key_better(s_best_x, s_best_ps, 0ull, cbx, cbps, 1ull))) {
+            s_best_x = cbx;
+            s_best_ps = cbps;
             s_best_stat = my_bstat;
             s_best_rank = my_br;
         }
@@ -734,7 +810,7 @@ __global__ __launch_bounds__(256) void fz_subsets_seg_kernel(const float *__rest
         o.stop_pval = 0.0;
         o.best_rank = s_best_rank;
         o.best_stat = s_best_stat;
-        o.best_pval = s_best_p;
+        o.best_pval = (s_best_x == FZ_X_NONE) ? -1.0 : fz_pval_dev(s_best_stat, zscale);
         o.stop_df = 0;
         o.stop_power = 1;
         o.best_df = 0;
@@ -865,17 +941,23 @@ int fwi_fz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y
     return FW_OK;
 }
 
-int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out)
+int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb)
 {
     if (nseg == 0) return FW_OK;
-    FW_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    FW_HIP(ctx, hipEventRecord(pb.ev0, pb.stream));
+    if (!ctx->d_thr) {
+        FW_HIP(ctx, hipMalloc((void **)&ctx->d_thr, 4 * sizeof(double)));
+        hipLaunchKernelGGL(fz_thresholds_kernel, dim3(1), dim3(64), 0, pb.stream, ctx->P.alpha, fz_zscale(ctx), ctx->d_thr);
+        FW_HIP(ctx, hipGetLastError());
+        FW_HIP(ctx, hipStreamSynchronize(pb.stream));  // the other pool stream may use it next
+    }
     if (ctx->P.max_k > 3)
-        hipLaunchKernelGGL(fz_subsets_seg_kernel<true>, dim3((unsigned)nseg), dim3(256), 0, ctx->stream, ctx->d_cor, ctx->P.p,
-                           d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests);
+        hipLaunchKernelGGL(fz_subsets_seg_kernel<true>, dim3((unsigned)nseg), dim3(256), 0, pb.stream, ctx->d_cor, ctx->P.p,
+                           d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr);
     else
-        hipLaunchKernelGGL(fz_subsets_seg_kernel<false>, dim3((unsigned)nseg), dim3(256), 0, ctx->stream, ctx->d_cor, ctx->P.p,
-                           d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests);
+        hipLaunchKernelGGL(fz_subsets_seg_kernel<false>, dim3((unsigned)nseg), dim3(256), 0, pb.stream, ctx->d_cor, ctx->P.p,
+                           d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr);
     FW_HIP(ctx, hipGetLastError());
-    FW_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    FW_HIP(ctx, hipEventRecord(pb.ev1, pb.stream));
     return FW_OK;
 }

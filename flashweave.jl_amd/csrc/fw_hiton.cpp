@@ -195,8 +195,10 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                 }
                 tg.push_back(std::move(t));
             }
-            // asynchronous job pool: a target posts its next (T, candidate, accepted) job as soon as its previous one
+            // Asynchronous job pool: a target posts its next (T, candidate, accepted) job as soon as its previous one
             // has finished; every pool round evaluates one window of every in-flight job in ONE kernel launch.
+            // (A two-pool variant that overlaps host merging with device work was measured in round 1 and was slower:
+            // it doubles the number of launches in the latency-bound tail.)
             FwPool pool;
             std::vector<FwPoolJob> fin;
             std::vector<int> need(tg.size());

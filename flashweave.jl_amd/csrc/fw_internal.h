@@ -72,6 +72,14 @@ struct FwSegOut {
     uint64_t evaluated;
 };
 
+// per-pool staging: own stream + events so that two pools can be in flight (host merges one while the GPU runs the other)
+struct FwPoolBuf {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    FwPinned h_in, h_out;  // h_in = [FwSeg x ns | accepted ints]
+    FwDevBuf d_in, d_out;
+};
+
 struct fw_ctx {
     fw_params P{};
     int64_t n_obs_min_eff = 0;
@@ -84,6 +92,7 @@ struct fw_ctx {
     float *d_xc = nullptr;    // centred columns, [p_pad][n_pad], zero padded
     float *d_sd = nullptr;    // sqrt(sum xc^2) per column, [p_pad]
     float *d_cor = nullptr;   // p x p (symmetric)
+    double *d_thr = nullptr;  // |r| significance thresholds of the segment kernel (fz_thresholds_kernel)
     int n_pad = 0, p_pad = 0;
     bool have_data = false, have_cor = false;
 
@@ -115,6 +124,7 @@ struct fw_ctx {
     // grow-only scratch
     FwDevBuf d_jobs, d_acc, d_out, d_tmp0, d_tmp1, d_tmp2, d_segs, d_segout;
     FwPinned h_jobs, h_acc, h_out;
+    FwPoolBuf pb[2];
 };
 
 int fw_fail(const fw_ctx *ctx, int code, const char *fmt, ...);
@@ -135,7 +145,7 @@ int fwi_fz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
                   std::vector<double> &pval, int64_t *m_reliable);
 int fwi_fz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff,
                       const int32_t *zflat, fw_test_result *out);
-int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out);
+int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb);
 
 // ---- discrete (fw_mi.hip) ----
 int fwi_mi_upload(fw_ctx *ctx, const int64_t *colptr, const int32_t *rowval, const int32_t *nzval);
@@ -143,7 +153,7 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
                   std::vector<double> &pval, int64_t *m_reliable);
 int fwi_mi_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff,
                       const int32_t *zflat, fw_test_result *out);
-int fwi_mi_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out);
+int fwi_mi_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb);
 
 // algorithmic bytes of the first `evaluated` tests of a job with |accepted| = a (enumeration order: sizes max_k..1)
 double fwi_alg_bytes(const fw_ctx *ctx, int a, int64_t evaluated);
@@ -163,7 +173,14 @@ struct FwPoolJob {
 struct FwPool {
     std::vector<FwPoolJob> live;
     std::vector<int64_t> seg_job;
+    int buf = 0;            // which ctx->pb[] this pool stages through
+    bool want_zs = false;   // recover the conditioning set of each returned result from its rank (ABI path)
+    bool inflight = false;  // a window launch is pending (fwi_pool_launch without fwi_pool_collect)
+    size_t ns = 0;
+    double t_launch = 0.0;
 };
+int fwi_pool_launch(fw_ctx *ctx, FwPool &pool);                                    // asynchronous
+int fwi_pool_collect(fw_ctx *ctx, FwPool &pool, std::vector<FwPoolJob> &finished);  // waits + merges
 int fwi_pool_add(fw_ctx *ctx, FwPool &pool, int32_t X, int32_t Y, const int32_t *acc, int a, int64_t tag);
 int fwi_pool_round(fw_ctx *ctx, FwPool &pool, std::vector<FwPoolJob> &finished);
 

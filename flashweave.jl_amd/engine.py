@@ -41,7 +41,7 @@ class _Counters(C.Structure):
     _fields_ = [("level0_tests", C.c_int64), ("cond_tests_ref", C.c_int64), ("cond_tests_evaluated", C.c_int64),
                 ("subsets_calls", C.c_int64), ("kernel_launches", C.c_int64), ("subsets_launches", C.c_int64), ("t_level0_s", C.c_double),
                 ("t_cond_s", C.c_double), ("t_dev_subsets_s", C.c_double), ("t_host_advance_s", C.c_double),
-                ("t_host_build_s", C.c_double), ("t_host_wait_s", C.c_double), ("t_host_merge_s", C.c_double),
+                ("t_host_build_s", C.c_double), ("t_host_launch_s", C.c_double), ("t_host_wait_s", C.c_double), ("t_host_merge_s", C.c_double),
                 ("alg_bytes_subsets", C.c_double)]
 
 

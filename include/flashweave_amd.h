@@ -98,6 +98,7 @@ typedef struct fw_counters {
     double t_dev_subsets_s;      /* HIP-event seconds of the test_subsets kernels (sum) */
     double t_host_advance_s;     /* host: HITON-PC state machines + job posting */
     double t_host_build_s;       /* host: segment construction + staging */
+    double t_host_launch_s;      /* host: enqueueing copies + kernel */
     double t_host_wait_s;        /* host: waiting for the device (copies + kernel + sync) */
     double t_host_merge_s;       /* host: in-order merge of segment outputs */
     double alg_bytes_subsets;    /* algorithmic bytes of the evaluated conditional tests:

@@ -130,6 +130,34 @@ def test_test_subsets_max_tests_and_large_pool(small):
     eng.close()
 
 
+def test_test_subsets_pvalue_underflow_ties():
+    # X and Y share a private component: every rho(X, Y | S) ~ 0.999 -> p underflows to exactly 0 for every subset,
+    # so `pval >= lowest.pval` (tests.jl:338) makes the LAST enumerated subset win; near-zero but non-zero p-values
+    # (subnormal range) are mixed in through a second, slightly noisier pair.
+    rng = np.random.default_rng(12)
+    n, p = 400, 40
+    data = rng.standard_normal((n, p))
+    c = rng.standard_normal(n)
+    data[:, 0] = c + 0.02 * rng.standard_normal(n)
+    data[:, 1] = c + 0.02 * rng.standard_normal(n)
+    d = rng.standard_normal(n)
+    data[:, 2] = d + 0.21 * rng.standard_normal(n)
+    data[:, 3] = d + 0.21 * rng.standard_normal(n)
+    data = np.asfortranarray(data.astype(np.float32))
+    eng = fw.Engine("fz", n, p, max_k=3)
+    eng.set_data(data)
+    cm = eng.cor()
+    orc = O.Oracle("fz", cor_mat=cm, n_obs=n)
+    T = [0, 1, 2, 3, 0]
+    C = [1, 0, 3, 2, 1]
+    A = [list(range(4, 16)), list(range(10, 30)), list(range(4, 18)), list(range(20, 40)), [5, 6, 7, 5, 6]]
+    got = eng.test_subsets_batch(T, C, A)
+    pv = [g["pval"] for g in got]
+    assert pv[0] == 0.0 and pv[1] == 0.0          # underflow regime reached
+    _check_subsets(eng, orc, T, C, A, max_k=3)
+    eng.close()
+
+
 @pytest.mark.parametrize("max_k", [1, 2, 4, 5])
 def test_test_subsets_other_max_k(small, max_k):
     n, p, cm, orc = small["n"], small["p"], small["cm"], small["orc"]
