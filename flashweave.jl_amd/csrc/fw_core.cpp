@@ -310,44 +310,84 @@ int fw_level0(fw_ctx *c, int64_t *nnz_out)
     int rc = (c->P.kind == FW_FZ) ? fwi_fz_level0(c, pi, pj, stat, pval, &m) : fwi_mi_level0(c, pi, pj, stat, pval, &m);
     if (rc) return rc;
     const size_t k = pi.size();
-    std::vector<uint32_t> ord(k);
-    std::iota(ord.begin(), ord.end(), 0u);
-    auto pairkey = [&](uint32_t t) { return (int64_t)pi[t] * p + pj[t]; };
+    const double t_host0 = now_s();
     if (c->P.fdr && k > 0) {
-        // stable ascending sort by p (ties: condensed pair order, i.e. the enumerate order of statfuns.jl:331)
-        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
-            if (pval[a] != pval[b]) return pval[a] < pval[b];
-            return pairkey(a) < pairkey(b);
-        });
-        std::vector<double> adj(k);
+        // statfuns.jl:326-350.  Ascending sort by p: LSD radix sort on the IEEE bit pattern (p >= 0 -> order preserving).
+        // Ties need no stable order: the backward cumulative minimum gives every member of a tie group the same value.
+        std::vector<uint64_t> key(k), key2(k);
+        std::vector<uint32_t> val(k), val2(k);
+        for (size_t t = 0; t < k; ++t) {
+            uint64_t u;
+            memcpy(&u, &pval[t], 8);
+            key[t] = u;
+            val[t] = (uint32_t)t;
+        }
+        std::vector<uint32_t> hist(65536);
+        for (int pass = 0; pass < 4; ++pass) {
+            const int sh = 16 * pass;
+            std::fill(hist.begin(), hist.end(), 0u);
+            for (size_t t = 0; t < k; ++t) hist[(key[t] >> sh) & 0xFFFF]++;
+            uint32_t run = 0;
+            for (size_t d = 0; d < 65536; ++d) {
+                const uint32_t h = hist[d];
+                hist[d] = run;
+                run += h;
+            }
+            for (size_t t = 0; t < k; ++t) {
+                const uint32_t dst = hist[(key[t] >> sh) & 0xFFFF]++;
+                key2[dst] = key[t];
+                val2[dst] = val[t];
+            }
+            key.swap(key2);
+            val.swap(val2);
+        }
         const double md = (double)m;
-        adj[k - 1] = std::min(pval[ord[k - 1]] * md / (double)k, 1.0);
-        for (size_t i = k - 1; i-- > 0;) {
-            const double next_adj = adj[i + 1];
-            const double new_adj = pval[ord[i]] * md / (double)(i + 1);
-            adj[i] = std::min(next_adj, new_adj);
+        double next_adj = 0.0;
+        for (size_t i = k; i-- > 0;) {
+            double pv;
+            memcpy(&pv, &key[i], 8);
+            double adj = pv * md / (double)(i + 1);
+            if (i == k - 1)
+                adj = std::min(adj, 1.0);
+            else
+                adj = std::min(next_adj, adj);
+            next_adj = adj;
+            pval[val[i]] = adj;
         }
-        for (size_t i = 0; i < k; ++i) pval[ord[i]] = adj[i];
     }
-    // neighbour lists: adj p < alpha, partners ascending
-    std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return pairkey(a) < pairkey(b); });
-    c->nb_off.assign((size_t)p + 1, 0);
+    // neighbour lists (tests.jl:372-388): adj p < alpha, partners ascending.  Two stable counting sorts give the
+    // (X ascending, Y ascending) pair order of the reference's condensed arrays; appending in that order yields
+    // ascending partner lists for both endpoints.
+    std::vector<uint32_t> keep;
+    keep.reserve(k);
     for (size_t t = 0; t < k; ++t)
-        if (pval[t] < c->P.alpha) {
-            c->nb_off[pi[t] + 1]++;
-            c->nb_off[pj[t] + 1]++;
-        }
+        if (pval[t] < c->P.alpha) keep.push_back((uint32_t)t);
+    const size_t kk = keep.size();
+    std::vector<uint32_t> byj(kk), byij(kk);
+    {
+        std::vector<uint32_t> cnt((size_t)p + 1, 0);
+        for (uint32_t t : keep) cnt[pj[t] + 1]++;
+        for (int v = 0; v < p; ++v) cnt[v + 1] += cnt[v];
+        for (uint32_t t : keep) byj[cnt[pj[t]]++] = t;
+        std::fill(cnt.begin(), cnt.end(), 0u);
+        for (uint32_t t : byj) cnt[pi[t] + 1]++;
+        for (int v = 0; v < p; ++v) cnt[v + 1] += cnt[v];
+        for (uint32_t t : byj) byij[cnt[pi[t]]++] = t;
+    }
+    c->nb_off.assign((size_t)p + 1, 0);
+    for (uint32_t t : byij) {
+        c->nb_off[pi[t] + 1]++;
+        c->nb_off[pj[t] + 1]++;
+    }
     for (int v = 0; v < p; ++v) c->nb_off[v + 1] += c->nb_off[v];
     const int64_t tot = c->nb_off[p];
     c->nb_idx.assign((size_t)tot, 0);
     c->nb_stat.assign((size_t)tot, 0.0);
     c->nb_p.assign((size_t)tot, 0.0);
     std::vector<int64_t> fill(c->nb_off.begin(), c->nb_off.end() - 1);
-    for (size_t q = 0; q < k; ++q) {
-        const uint32_t t = ord[q];
-        if (!(pval[t] < c->P.alpha)) continue;
+    for (uint32_t t : byij) {
         const int X = pi[t], Y = pj[t];
-        int64_t a = fill[X]++, b = fill[Y]++;
+        const int64_t a = fill[X]++, b = fill[Y]++;
         c->nb_idx[a] = Y;
         c->nb_stat[a] = stat[t];
         c->nb_p[a] = pval[t];
@@ -355,6 +395,7 @@ int fw_level0(fw_ctx *c, int64_t *nnz_out)
         c->nb_stat[b] = stat[t];
         c->nb_p[b] = pval[t];
     }
+    c->cnt.t_level0_host_s += now_s() - t_host0;
     c->have_level0 = true;
     c->have_network = false;
     c->cnt.level0_tests += (int64_t)p * (p - 1) / 2;

@@ -39,7 +39,7 @@ class _SubsetsResult(C.Structure):
 
 class _Counters(C.Structure):
     _fields_ = [("level0_tests", C.c_int64), ("cond_tests_ref", C.c_int64), ("cond_tests_evaluated", C.c_int64),
-                ("subsets_calls", C.c_int64), ("kernel_launches", C.c_int64), ("subsets_launches", C.c_int64), ("t_level0_s", C.c_double),
+                ("subsets_calls", C.c_int64), ("kernel_launches", C.c_int64), ("subsets_launches", C.c_int64), ("t_level0_s", C.c_double), ("t_level0_host_s", C.c_double),
                 ("t_cond_s", C.c_double), ("t_dev_subsets_s", C.c_double), ("t_host_advance_s", C.c_double),
                 ("t_host_build_s", C.c_double), ("t_host_launch_s", C.c_double), ("t_host_wait_s", C.c_double), ("t_host_merge_s", C.c_double),
                 ("alg_bytes_subsets", C.c_double)]
@@ -176,6 +176,10 @@ class Engine:
         self._ck(self.L.fw_compute_cor_mat(self.h))
         return self.cor_mat()
 
+    def compute_cor(self):
+        """Device-only form of cor(): the matrix stays resident, nothing is copied back."""
+        self._ck(self.L.fw_compute_cor_mat(self.h))
+
     def cor_mat(self):
         out = np.zeros((self.p, self.p), dtype=np.float32, order="F")
         self._ck(self.L.fw_get_cor_mat(self.h, _ptr(out)))
@@ -191,6 +195,12 @@ class Engine:
         return int(self.L.fw_effective_n_obs_min(self.h))
 
     # -- level 0 -------------------------------------------------------------------------------------
+    def level0(self):
+        """Runs level 0 and keeps the neighbour lists in the context (no copy to Python); returns the entry count."""
+        nnz = C.c_int64(0)
+        self._ck(self.L.fw_level0(self.h, C.byref(nnz)))
+        return nnz.value
+
     def pw_univar_neighbors(self):
         """pw_univar_neighbors (src/tests.jl:436-532) -> CSR dict(off, idx, stat, pval)."""
         nnz = C.c_int64(0)

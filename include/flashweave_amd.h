@@ -94,6 +94,7 @@ typedef struct fw_counters {
     int64_t kernel_launches;
     int64_t subsets_launches;    /* launches of the test_subsets segment kernel */
     double t_level0_s;           /* wall seconds inside fw_level0 */
+    double t_level0_host_s;      /* of which: host-side BH + neighbour-list construction */
     double t_cond_s;             /* wall seconds inside the conditional stage of fw_learn_network */
     double t_dev_subsets_s;      /* HIP-event seconds of the test_subsets kernels (sum) */
     double t_host_advance_s;     /* host: HITON-PC state machines + job posting */
