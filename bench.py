@@ -34,8 +34,15 @@ def make_input(cfg, args):
         c["p"] = args.p
     if args.n:
         c["n"] = args.n
-    counts = synth.generate(c["p"], c["n"], c["seed"], mode=c["mode"])
-    data, _, _ = pre.normalize(counts, c["test_name"], prec=32)
+    if c.get("habitats"):  # HE configs: structural absences + 20 binary meta variables
+        counts, meta = synth.generate(c["p"], c["n"], c["seed"], mode=c["mode"], habitats=c["habitats"], n_meta=c["n_meta"])
+        data, rm, _ = pre.normalize(counts, c["test_name"], prec=32)
+        meta = meta[rm]
+        keep = [j for j in range(meta.shape[1]) if len(np.unique(meta[:, j])) == 2]
+        data = np.ascontiguousarray(np.concatenate([data, meta[:, keep]], axis=1))
+    else:
+        counts = synth.generate(c["p"], c["n"], c["seed"], mode=c["mode"])
+        data, _, _ = pre.normalize(counts, c["test_name"], prec=32)
     return c, synth.checksum(counts), data
 
 
@@ -118,9 +125,18 @@ def main():
         # dominant kernel: test_subsets batch (per launch averages over the timed region, this rank)
         n_sub_launches = max(cn["subsets_launches"], 1)
         achieved = (cn["alg_bytes_subsets"] / max(sub_launch_s, 1e-12)) / 1e9
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_cfg3_fz_pmc_summary.json")
+        if args.config == "cfg3" and not args.p and not args.n and os.path.exists(pmc_path):
+            # HBM-side bytes per launch of the same kernel on the same workload, from a separate rocprofv3 --pmc pass
+            # (PMC counters cannot be collected from inside this process); see profiles/README.md
+            traffic = json.load(open(pmc_path))["fz_subsets_seg_kernel"]["fetch_bytes_per_launch"]
+            traffic_src = "profiles/r01_cfg3_fz_pmc_summary.json (FETCH_SIZE, 4-byte gathers, width-uncorrected)"
         roofline = {"bound": "hbm", "kernel": "fz_subsets_seg_kernel" if cfg["test_name"] == "fz" else "mi_subsets_seg_kernel",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None,
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "note": "nominal HBM roofline with the algorithmic bytes of SURVEY 8d (fz: 4*C(k+2,2)+32 B per test); "
+                            "the correlation-matrix rows are L2-resident and the measured limiter is fp64 VALU issue",
                     "alg_bytes_per_launch": cn["alg_bytes_subsets"] / n_sub_launches,
                     "avg_launch_us": 1e6 * sub_launch_s / n_sub_launches, "launches": n_sub_launches,
                     "evaluated_tests_per_s_in_kernel": cn["cond_tests_evaluated"] / max(sub_launch_s, 1e-12)}

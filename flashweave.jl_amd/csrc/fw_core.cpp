@@ -546,6 +546,20 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
 {
     pool.ns = 0;
     pool.inflight = false;
+    if (pool.owner_epoch) {  // drop jobs whose owner's accepted set has changed since they were posted
+        size_t w = 0;
+        for (size_t ji = 0; ji < pool.live.size(); ++ji) {
+            FwPoolJob &j = pool.live[ji];
+            if (j.epoch != (*pool.owner_epoch)[(size_t)j.tag]) {
+                pool.dropped_evaluated += j.out.evaluated;
+                pool.dropped_alg_bytes += fwi_alg_bytes(c, (int)j.acc.size(), j.out.evaluated);
+                continue;
+            }
+            if (w != ji) pool.live[w] = std::move(j);
+            ++w;
+        }
+        pool.live.resize(w);
+    }
     if (pool.live.empty()) return FW_OK;
     const bool fz = c->P.kind == FW_FZ;
     if (fz && c->P.n < c->n_obs_min_eff) {  // no device work: fwi_pool_collect fills the results
@@ -556,16 +570,22 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
     FwPoolBuf &pb = c->pb[pool.buf];
     // window of every live job, then a segment length that yields a few thousand workgroups
     uint64_t total = 0, acc_total = 0;
-    for (const FwPoolJob &j : pool.live) {
+    size_t n_launch = 0;
+    for (FwPoolJob &j : pool.live) {
+        j.launched = !j.hold;
+        if (!j.launched) continue;
+        ++n_launch;
         total += std::min(j.width, j.N - j.next);
         acc_total += j.acc.size();
     }
+    if (n_launch == 0) return FW_OK;  // everything is on hold: nothing to do this round
     // fz: one lane per test (256-rank granularity); discrete: one wavefront per test (4-rank granularity)
     const uint64_t q = fz ? 256 : 4, smin = fz ? 256 : 8, smax = fz ? 8192 : 256;
     uint64_t seglen = (total / 4096 + q - 1) / q * q;
     seglen = std::max<uint64_t>(smin, std::min<uint64_t>(seglen, smax));
     size_t ns = 0;
-    for (const FwPoolJob &j : pool.live) ns += (size_t)((std::min(j.width, j.N - j.next) + seglen - 1) / seglen);
+    for (const FwPoolJob &j : pool.live)
+        if (j.launched) ns += (size_t)((std::min(j.width, j.N - j.next) + seglen - 1) / seglen);
     const size_t in_bytes = ns * sizeof(FwSeg) + std::max<size_t>(acc_total, 1) * sizeof(int32_t);
     int rc;
     if ((rc = fw_pin_reserve(c, pb.h_in, in_bytes))) return rc;
@@ -579,6 +599,7 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
     int64_t aoff = 0;
     for (size_t ji = 0; ji < pool.live.size(); ++ji) {
         const FwPoolJob &j = pool.live[ji];
+        if (!j.launched) continue;
         memcpy(hacc + aoff, j.acc.data(), j.acc.size() * sizeof(int32_t));
         const uint64_t lo = j.next, hi = lo + std::min(j.width, j.N - lo);
         for (uint64_t sgs = lo; sgs < hi; sgs += seglen) {
@@ -661,7 +682,7 @@ int fwi_pool_collect(fw_ctx *c, FwPool &pool, std::vector<FwPoolJob> &finished)
     size_t w = 0;
     for (size_t ji = 0; ji < pool.live.size(); ++ji) {
         FwPoolJob &j = pool.live[ji];
-        if (!j.done) {
+        if (!j.done && j.launched) {
             j.next += std::min(j.width, j.N - j.next);
             j.width *= 4;
             if (j.next >= j.N) {

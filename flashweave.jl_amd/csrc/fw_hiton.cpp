@@ -48,6 +48,9 @@ struct Target {
     ODict TPC, PC;
     const int32_t *wl = nullptr;  // sorted whitelist (snapshot of the running graph)
     int wl_n = 0;
+    // speculative posting (interleaving phase): candidates [pos, posted_end) have a job in the pool or a buffered result
+    size_t posted_end = 0;
+    std::vector<std::pair<int32_t, FwJobOut>> ready;  // finished but not yet committed (candidate index, result)
     bool in_wl(int32_t v) const { return wl_n > 0 && std::binary_search(wl, wl + wl_n, v); }
 };
 
@@ -100,6 +103,8 @@ static bool advance(const fw_ctx *c, Target &t)
             t.cands = t.TPC.key;
             t.acc = t.cands;
             t.pos = 0;
+            t.posted_end = 0;  // every interleaving candidate has been committed at this point
+            t.ready.clear();
         } else {  // hiton.jl:249-256 update_PC_dict!
             for (size_t i = 0; i < t.PC.key.size(); ++i) {
                 const int ti = t.TPC.find(t.PC.key[i]);
@@ -195,22 +200,73 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                 }
                 tg.push_back(std::move(t));
             }
-            // Asynchronous job pool: a target posts its next (T, candidate, accepted) job as soon as its previous one
-            // has finished; every pool round evaluates one window of every in-flight job in ONE kernel launch.
-            // (A two-pool variant that overlaps host merging with device work was measured in round 1 and was slower:
-            // it doubles the number of launches in the latency-bound tail.)
+            // Asynchronous job pool with speculative candidates.  A rejected candidate leaves the accepted set unchanged
+            // (hiton.jl:67-70), so during the interleaving phase the next FW_SPEC_DEPTH candidates of a target are posted
+            // together against the current accepted set; results are committed strictly in candidate order, and the
+            // first acceptance bumps the target's epoch, which cancels / voids everything posted after it.  The sequence
+            // of committed (T, candidate, accepted) jobs is therefore exactly the reference's; only the number of
+            // latency-bound rounds shrinks.  Every pool round = one window of every in-flight job = ONE kernel launch.
+            constexpr int FW_SPEC_DEPTH = 8;
+            constexpr long FW_SPEC_TARGETS = 512;
+            long n_unfinished = (long)tg.size();
             FwPool pool;
+            std::vector<int32_t> epoch(tg.size(), 0);
+            pool.owner_epoch = &epoch;
             std::vector<FwPoolJob> fin;
-            std::vector<int> need(tg.size());
-            std::iota(need.begin(), need.end(), 0);
+            std::vector<int> touched(tg.size());
+            std::iota(touched.begin(), touched.end(), 0);
+            std::vector<uint8_t> is_touched(tg.size(), 0);
             for (;;) {
                 const double ta0 = now_s();
-                for (int ti : need) {
+                for (int ti : touched) {
                     Target &t = tg[ti];
-                    if (!advance(c, t)) continue;
-                    fwi_pool_add(c, pool, t.T, t.cands[t.pos], t.acc.data(), (int)t.acc.size(), ti);
+                    is_touched[ti] = 0;
+                    // commit finished results in candidate order
+                    while (advance(c, t)) {
+                        int ri = -1;
+                        for (size_t q = 0; q < t.ready.size(); ++q)
+                            if ((size_t)t.ready[q].first == t.pos) {
+                                ri = (int)q;
+                                break;
+                            }
+                        if (ri < 0) break;
+                        const FwJobOut o = t.ready[ri].second;
+                        t.ready.erase(t.ready.begin() + ri);
+                        c->cnt.cond_tests_ref += o.num_tests;
+                        c->cnt.subsets_calls += 1;
+                        const int32_t cand = t.cands[t.pos];
+                        ++t.pos;
+                        if (o.pval < c->P.alpha && o.suff_power) {  // issig, tests.jl:1-3; hiton.jl:61-63
+                            t.acc.push_back(cand);
+                            (t.phase == 0 ? t.TPC : t.PC).set(cand, o.stat, o.pval);
+                            ++epoch[ti];  // accepted set changed: later speculative jobs / results are void
+                            t.ready.clear();
+                            t.posted_end = t.pos;
+                        }
+                    }
+                    if (t.phase == 2) {
+                        --n_unfinished;
+                        continue;
+                    }
+                    // post: the current candidate, plus speculative ones while interleaving.  Speculation is only used
+                    // once few targets are left (the latency-bound tail); with thousands of active targets the launches
+                    // are full anyway and the extra host bookkeeping would cost more than the saved rounds.
+                    if (t.posted_end < t.pos) t.posted_end = t.pos;
+                    const size_t depth = n_unfinished <= FW_SPEC_TARGETS ? (size_t)FW_SPEC_DEPTH : 1;
+                    const size_t limit = t.phase == 0 ? std::min(t.cands.size(), t.pos + depth) : t.pos + 1;
+                    while (t.posted_end < limit) {
+                        const size_t ci = t.posted_end;
+                        if (ci > t.pos && t.in_wl(t.cands[ci])) break;  // a whitelisted candidate will change the accepted set
+                        fwi_pool_add(c, pool, t.T, t.cands[ci], t.acc.data(), (int)t.acc.size(), ti);
+                        pool.live.back().aux = (int32_t)ci;
+                        pool.live.back().epoch = epoch[ti];
+                        ++t.posted_end;
+                    }
                 }
-                need.clear();
+                touched.clear();
+                // a speculative job (not the head candidate of its target) only ever runs its first window: most
+                // rejections happen within the first few tests, and a voided long job would be pure waste
+                for (FwPoolJob &j : pool.live) j.hold = (size_t)j.aux != tg[(size_t)j.tag].pos && j.next > 0;
                 c->cnt.t_host_advance_s += now_s() - ta0;
                 if (pool.live.empty()) break;
                 fin.clear();
@@ -218,22 +274,20 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                 if (rc) return rc;
                 const double ta1 = now_s();
                 for (FwPoolJob &j : fin) {
-                    Target &t = tg[(size_t)j.tag];
-                    const FwJobOut &o = j.out;
-                    c->cnt.cond_tests_ref += o.num_tests;
-                    c->cnt.cond_tests_evaluated += o.evaluated;
-                    c->cnt.alg_bytes_subsets += fwi_alg_bytes(c, (int)j.acc.size(), o.evaluated);
-                    c->cnt.subsets_calls += 1;
-                    const int32_t cand = t.cands[t.pos];
-                    if (o.pval < c->P.alpha && o.suff_power) {  // issig, tests.jl:1-3; hiton.jl:61-63
-                        t.acc.push_back(cand);
-                        (t.phase == 0 ? t.TPC : t.PC).set(cand, o.stat, o.pval);
+                    const int ti = (int)j.tag;
+                    c->cnt.cond_tests_evaluated += j.out.evaluated;
+                    c->cnt.alg_bytes_subsets += fwi_alg_bytes(c, (int)j.acc.size(), j.out.evaluated);
+                    if (j.epoch != epoch[ti]) continue;  // posted before an acceptance: void
+                    tg[ti].ready.emplace_back(j.aux, j.out);
+                    if (!is_touched[ti]) {
+                        is_touched[ti] = 1;
+                        touched.push_back(ti);
                     }
-                    ++t.pos;
-                    need.push_back((int)j.tag);
                 }
                 c->cnt.t_host_advance_s += now_s() - ta1;
             }
+            c->cnt.cond_tests_evaluated += pool.dropped_evaluated;
+            c->cnt.alg_bytes_subsets += pool.dropped_alg_bytes;
             // exchange this round's directed results (target, neighbour, stat, p)
             std::vector<int32_t> lt, ln;
             std::vector<double> ls, lp;

@@ -161,7 +161,11 @@ double fwi_alg_bytes(const fw_ctx *ctx, int a, int64_t evaluated);
 // ---- asynchronous job pool (fw_core.cpp): every round evaluates one window of every live job in ONE launch ----
 struct FwPoolJob {
     int32_t X = 0, Y = 0;
-    int64_t tag = 0;
+    int64_t tag = 0;     // caller's id (driver: target slot)
+    int32_t aux = 0;     // driver: candidate index
+    int32_t epoch = 0;   // driver: accepted-set epoch of the owner when the job was posted (stale jobs are dropped)
+    bool hold = false;     // driver: do not launch further windows for now (speculative job past its first window)
+    bool launched = false; // set by fwi_pool_launch for the jobs that are part of the pending window
     std::vector<int32_t> acc;
     uint64_t N = 0, next = 0, width = 0;
     double best_p = -1.0, best_stat = 0.0;
@@ -175,6 +179,9 @@ struct FwPool {
     std::vector<int64_t> seg_job;
     int buf = 0;            // which ctx->pb[] this pool stages through
     bool want_zs = false;   // recover the conditioning set of each returned result from its rank (ABI path)
+    const std::vector<int32_t> *owner_epoch = nullptr;  // if set: jobs whose epoch != (*owner_epoch)[tag] are cancelled
+    int64_t dropped_evaluated = 0;                      // tests already evaluated for jobs cancelled before they finished
+    double dropped_alg_bytes = 0.0;
     bool inflight = false;  // a window launch is pending (fwi_pool_launch without fwi_pool_collect)
     size_t ns = 0;
     double t_launch = 0.0;
