@@ -82,7 +82,7 @@ int fw_ctx_create(const fw_params *P, fw_ctx **out)
 {
     if (out) *out = nullptr;
     if (!P || !out) return fw_fail(nullptr, FW_ERR_ARG, "fw_ctx_create: NULL argument");
-    if (P->kind != FW_MI && P->kind != FW_MI_NZ && P->kind != FW_FZ)
+    if (P->kind != FW_MI && P->kind != FW_MI_NZ && P->kind != FW_FZ && P->kind != FW_FZ_NZ)
         return fw_fail(nullptr, FW_ERR_ARG, "fw_ctx_create: unknown test kind %d", P->kind);
     if (P->n <= 0 || P->p <= 1) return fw_fail(nullptr, FW_ERR_ARG, "fw_ctx_create: need n > 0 and p > 1 (n=%d, p=%d)", P->n, P->p);
     if (P->max_k < 0 || P->max_k > FW_MAX_K)
@@ -118,7 +118,7 @@ int fw_ctx_create(const fw_params *P, fw_ctx **out)
             return fw_fail(nullptr, FW_ERR_DEVICE, "stream/event creation failed: %s", hipGetErrorString(e));
         }
     // continuous: the automatic n_obs_min is known immediately (learning.jl:59-61); discrete needs levels
-    c->n_obs_min_eff = P->n_obs_min >= 0 ? P->n_obs_min : (P->kind == FW_FZ ? 20 : -1);
+    c->n_obs_min_eff = P->n_obs_min >= 0 ? P->n_obs_min : ((P->kind == FW_FZ || P->kind == FW_FZ_NZ) ? 20 : -1);
     *out = c;
     return FW_OK;
 }
@@ -150,6 +150,10 @@ int fw_ctx_destroy(fw_ctx *c)
     free_dev(c->d_tmp0);
     free_dev(c->d_tmp1);
     free_dev(c->d_tmp2);
+    free_dev(c->d_segs);
+    free_dev(c->d_segout);
+    free_dev(c->d_nzrecs);
+    free_dev(c->d_arena);
     free_pin(c->h_jobs);
     free_pin(c->h_acc);
     free_pin(c->h_out);
@@ -179,8 +183,16 @@ int fw_ctx_destroy(fw_ctx *c)
 int fw_set_data_dense_f32(fw_ctx *c, const float *data)
 {
     CHECK_CTX(c);
-    if (c->P.kind != FW_FZ) return fw_fail(c, FW_ERR_ARG, "fw_set_data_dense_f32: context is not FW_FZ");
+    if (c->P.kind != FW_FZ && c->P.kind != FW_FZ_NZ) return fw_fail(c, FW_ERR_ARG, "fw_set_data_dense_f32: context is not FW_FZ / FW_FZ_NZ");
     if (!data) return fw_fail(c, FW_ERR_ARG, "fw_set_data_dense_f32: NULL data");
+    if (c->P.kind == FW_FZ_NZ) {
+        int rc = fwi_fznz_upload(c, data);
+        if (rc) return rc;
+        c->have_data = true;
+        c->have_level0 = false;
+        c->have_network = false;
+        return FW_OK;
+    }
     const size_t bytes = sizeof(float) * (size_t)c->P.n * c->P.p;
     if (!c->d_data) FW_HIP(c, hipMalloc(&c->d_data, bytes));
     FW_HIP(c, hipMemcpy(c->d_data, data, bytes, hipMemcpyHostToDevice));
@@ -242,7 +254,7 @@ static void resolve_n_obs_min_discrete(fw_ctx *c)
 int fw_set_data_csc_i32(fw_ctx *c, const int64_t *colptr, const int32_t *rowval, const int32_t *nzval)
 {
     CHECK_CTX(c);
-    if (c->P.kind == FW_FZ) return fw_fail(c, FW_ERR_ARG, "fw_set_data_csc_i32: context is FW_FZ");
+    if (c->P.kind == FW_FZ || c->P.kind == FW_FZ_NZ) return fw_fail(c, FW_ERR_ARG, "fw_set_data_csc_i32: context is not discrete");
     if (!colptr || (colptr[c->P.p] > 0 && (!rowval || !nzval))) return fw_fail(c, FW_ERR_ARG, "fw_set_data_csc_i32: NULL array");
     int rc = fwi_mi_upload(c, colptr, rowval, nzval);
     if (rc) return rc;
@@ -256,7 +268,7 @@ int fw_set_data_csc_i32(fw_ctx *c, const int64_t *colptr, const int32_t *rowval,
 int fw_set_data_dense_i32(fw_ctx *c, const int32_t *data)
 {
     CHECK_CTX(c);
-    if (c->P.kind == FW_FZ) return fw_fail(c, FW_ERR_ARG, "fw_set_data_dense_i32: context is FW_FZ");
+    if (c->P.kind == FW_FZ || c->P.kind == FW_FZ_NZ) return fw_fail(c, FW_ERR_ARG, "fw_set_data_dense_i32: context is not discrete");
     if (!data) return fw_fail(c, FW_ERR_ARG, "fw_set_data_dense_i32: NULL data");
     const int n = c->P.n, p = c->P.p;
     std::vector<int64_t> colptr(p + 1, 0);
@@ -307,7 +319,9 @@ int fw_level0(fw_ctx *c, int64_t *nnz_out)
     std::vector<int32_t> pi, pj;
     std::vector<double> stat, pval;
     int64_t m = 0;
-    int rc = (c->P.kind == FW_FZ) ? fwi_fz_level0(c, pi, pj, stat, pval, &m) : fwi_mi_level0(c, pi, pj, stat, pval, &m);
+    int rc = (c->P.kind == FW_FZ)      ? fwi_fz_level0(c, pi, pj, stat, pval, &m)
+             : (c->P.kind == FW_FZ_NZ) ? fwi_fznz_level0(c, pi, pj, stat, pval, &m)
+                                       : fwi_mi_level0(c, pi, pj, stat, pval, &m);
     if (rc) return rc;
     const size_t k = pi.size();
     const double t_host0 = now_s();
@@ -437,6 +451,13 @@ int fw_test_batch(fw_ctx *c, int64_t m, const int32_t *X, const int32_t *Y, cons
         return fwi_fz_test_batch(c, m, X, Y, zoff, zflat, out);
     }
     if (!c->have_data) return fw_fail(c, FW_ERR_STATE, "fw_test_batch: no data uploaded");
+    if (c->P.kind == FW_FZ_NZ) {
+        if ((int64_t)c->P.n < c->n_obs_min_eff) {  // tests.jl:11 / :254 on the full row count
+            for (int64_t t = 0; t < m; ++t) out[t] = fw_test_result{0.0, 1.0, 0, 0};
+            return FW_OK;
+        }
+        return fwi_fznz_test_batch(c, m, X, Y, zoff, zflat, out);
+    }
     return fwi_mi_test_batch(c, m, X, Y, zoff, zflat, out);
 }
 
@@ -516,7 +537,7 @@ int fwi_pool_add(fw_ctx *c, FwPool &pool, int32_t X, int32_t Y, const int32_t *a
     if (mt && mt < N) N = mt;
     j.N = N;
     j.next = 0;
-    j.width = c->P.kind == FW_FZ ? 256ull : 16ull;
+    j.width = (c->P.kind == FW_FZ || c->P.kind == FW_FZ_NZ) ? 256ull : 16ull;
     j.best_p = -1.0;
     j.best_stat = 0.0;
     j.best_rank = 0;
@@ -531,7 +552,7 @@ static void finish_job(const fw_ctx *c, FwPoolJob &j, bool want_zs)
 {
     j.done = true;
     j.out.n_zs = 0;
-    if (!want_zs) return;  // the HITON driver never looks at the conditioning set of the returned result
+    if (!want_zs || j.no_zs) return;  // the HITON driver never looks at the conditioning set of the returned result
     int s = 0, pos[FW_MAX_K] = {0, 0, 0, 0, 0};
     unrank_host(j.best_rank, (int)j.acc.size(), c->P.max_k, &s, pos);  // conditioning set of the returned result
     j.out.n_zs = s;
@@ -561,8 +582,9 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
         pool.live.resize(w);
     }
     if (pool.live.empty()) return FW_OK;
-    const bool fz = c->P.kind == FW_FZ;
-    if (fz && c->P.n < c->n_obs_min_eff) {  // no device work: fwi_pool_collect fills the results
+    const bool fz = c->P.kind == FW_FZ || c->P.kind == FW_FZ_NZ;
+    const bool nzs = c->P.kind == FW_FZ_NZ;
+    if (c->P.kind == FW_FZ && c->P.n < c->n_obs_min_eff) {  // no device work: fwi_pool_collect fills the results
         pool.inflight = true;
         return FW_OK;
     }
@@ -595,6 +617,8 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
     FwSeg *segs = (FwSeg *)pb.h_in.ptr;
     int32_t *hacc = (int32_t *)((char *)pb.h_in.ptr + ns * sizeof(FwSeg));
     pool.seg_job.resize(ns);
+    pool.nzrecs.clear();
+    size_t arena_floats = 0;
     size_t si = 0;
     int64_t aoff = 0;
     for (size_t ji = 0; ji < pool.live.size(); ++ji) {
@@ -610,9 +634,21 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
             sg.acc_len = (int32_t)j.acc.size();
             sg.start = sgs;
             sg.end = std::min(hi, sgs + seglen);
+            sg.pad = (int32_t)pool.nzrecs.size();  // fz_nz: index of the job's record in this launch
             segs[si] = sg;
             pool.seg_job[si] = (int64_t)ji;
             ++si;
+        }
+        if (nzs) {
+            FwNzJob r{};
+            r.X = j.X;
+            r.Y = j.Y;
+            r.acc_off = aoff;
+            r.acc_len = (int32_t)j.acc.size();
+            r.m = r.acc_len + 2;
+            r.cor_off = (long long)arena_floats;
+            arena_floats += (size_t)r.m * r.m;
+            pool.nzrecs.push_back(r);
         }
         aoff += (int64_t)j.acc.size();
     }
@@ -621,8 +657,14 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
     FW_HIP(c, hipMemcpyAsync(pb.d_in.ptr, pb.h_in.ptr, in_bytes, hipMemcpyHostToDevice, pb.stream));
     const FwSeg *dsegs = (const FwSeg *)pb.d_in.ptr;
     const int32_t *dacc = (const int32_t *)((const char *)pb.d_in.ptr + ns * sizeof(FwSeg));
-    rc = fz ? fwi_fz_segments(c, (int64_t)ns, dsegs, dacc, (FwSegOut *)pb.d_out.ptr, pb)
-            : fwi_mi_segments(c, (int64_t)ns, dsegs, dacc, (FwSegOut *)pb.d_out.ptr, pb);
+    if (nzs) {
+        rc = fwi_fznz_submatrices(c, (int64_t)pool.nzrecs.size(), pool.nzrecs.data(), arena_floats, dacc, pb.stream);
+        if (rc) return rc;
+        rc = fwi_fznz_segments(c, (int64_t)ns, dsegs, dacc, (FwSegOut *)pb.d_out.ptr, pb);
+    } else {
+        rc = fz ? fwi_fz_segments(c, (int64_t)ns, dsegs, dacc, (FwSegOut *)pb.d_out.ptr, pb)
+                : fwi_mi_segments(c, (int64_t)ns, dsegs, dacc, (FwSegOut *)pb.d_out.ptr, pb);
+    }
     if (rc) return rc;
     FW_HIP(c, hipMemcpyAsync(pb.h_out.ptr, pb.d_out.ptr, ns * sizeof(FwSegOut), hipMemcpyDeviceToHost, pb.stream));
     pool.ns = ns;
@@ -636,8 +678,7 @@ int fwi_pool_collect(fw_ctx *c, FwPool &pool, std::vector<FwPoolJob> &finished)
 {
     if (!pool.inflight) return FW_OK;
     pool.inflight = false;
-    const bool fz = c->P.kind == FW_FZ;
-    if (fz && c->P.n < c->n_obs_min_eff) {
+    if (c->P.kind == FW_FZ && c->P.n < c->n_obs_min_eff) {
         for (FwPoolJob &j : pool.live) {
             no_power_result(c, j.acc.data(), (int)j.acc.size(), j.out);
             j.done = true;
@@ -672,6 +713,11 @@ int fwi_pool_collect(fw_ctx *c, FwPool &pool, std::vector<FwPoolJob> &finished)
             j.out.num_tests = (int64_t)(so[s].stop_rank + 1);
             j.best_rank = so[s].stop_rank;
             j.done = true;
+            if (so[s].stop_df == -2) {  // fz_nz: too few rows with T != 0 and candidate != 0 -> no test at all
+                j.out.df = 0;
+                j.out.num_tests = 0;
+                j.no_zs = true;
+            }
         } else if (so[s].best_pval >= j.best_p) {
             j.best_p = so[s].best_pval;
             j.best_stat = so[s].best_stat;
@@ -744,7 +790,7 @@ double fwi_alg_bytes(const fw_ctx *c, int a, int64_t evaluated)
     for (int s = c->P.max_k; s >= 1 && left > 0; --s) {
         const double cnt = std::min(left, binom_d(a, s));
         double per;
-        if (c->P.kind == FW_FZ)
+        if (c->P.kind == FW_FZ || c->P.kind == FW_FZ_NZ)  // gather variant (fz_nz: on the job-local matrix)
             per = 4.0 * (double)((s + 2) * (s + 1) / 2) + 32.0;
         else
             per = (double)(s + 2) * (double)c->P.n * (c->P.kind == FW_MI ? 1.0 : 2.0) / 8.0 + 32.0;

@@ -533,9 +533,8 @@ __device__ __forceinline__ bool fz_key_better(double xa, double pa, unsigned lon
 
 // |r| thresholds for `p < alpha`: bisection on the exact device p-value, then a +-1e-9 relative guard band.
 // thr = {lo_pos, hi_pos, lo_neg, hi_neg}: |r| > hi -> significant for sure, |r| < lo -> not significant for sure.
-__global__ void fz_thresholds_kernel(double alpha, double zscale, double *thr)
+__device__ void fz_thresholds_dev(double alpha, double zscale, double *thr)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     for (int sgn = 0; sgn < 2; ++sgn) {
         double lo = 0.0, hi = 1.0;  // p(lo) >= alpha (not sig), p(hi) < alpha (sig) unless nothing is ever significant
         const double sg = sgn ? -1.0 : 1.0;
@@ -556,13 +555,20 @@ __global__ void fz_thresholds_kernel(double alpha, double zscale, double *thr)
     }
 }
 
-template <bool HIGHK>  // HIGHK: conditioning sets of size 4-5 possible (generic DP fallback compiled in)
-__global__ __launch_bounds__(256) void fz_subsets_seg_kernel(const float *__restrict__ cor, int p,
+__global__ void fz_thresholds_kernel(double alpha, double zscale, double *thr)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    fz_thresholds_dev(alpha, zscale, thr);
+}
+
+template <bool HIGHK, bool LOCAL>  // HIGHK: subsets of size 4-5 possible; LOCAL: per-job matrices (fz_nz)
+__global__ __launch_bounds__(256) void fz_subsets_seg_kernel(const float *__restrict__ cor_g, int p_g,
                                                              const FwSeg *__restrict__ segs,
                                                              const int32_t *__restrict__ accflat,
                                                              FwSegOut *__restrict__ out, int max_k, double alpha,
-                                                             double zscale, long long max_tests,
-                                                             const double *__restrict__ thr)
+                                                             double zscale_g, long long max_tests,
+                                                             const double *__restrict__ thr_g,
+                                                             const FwNzJob *__restrict__ recs, long long n_obs_min)
 {
     __shared__ int s_acc[FW_ACC_LDS];
     __shared__ unsigned long long s_stop[4];
@@ -576,8 +582,37 @@ __global__ __launch_bounds__(256) void fz_subsets_seg_kernel(const float *__rest
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int32_t *gacc = accflat + seg.acc_off;
     const bool in_lds = a <= FW_ACC_LDS;
-    if (in_lds)
+    const float *cor = cor_g;
+    int p = p_g;
+    double zscale = zscale_g;
+    const double *thr = thr_g;
+    if (LOCAL) {
+        const FwNzJob *rec = recs + seg.pad;
+        cor = cor_g + rec->cor_off;
+        p = rec->m;
+        zscale = rec->zscale;
+        thr = rec->thr;
+        if ((long long)rec->nR < n_obs_min) {  // tests.jl:294-296: (0, 1, 0, false) with zero tests
+            if (tid == 0) {
+                FwSegOut o;
+                o.stop_rank = 0;
+                o.stop_stat = 0.0;
+                o.stop_pval = 1.0;
+                o.best_rank = 0;
+                o.best_stat = 0.0;
+                o.best_pval = -1.0;
+                o.stop_df = -2;  // marker: no test was executed
+                o.stop_power = 0;
+                o.best_df = 0;
+                o.pad = 0;
+                o.evaluated = 0;
+                out[blockIdx.x] = o;
+            }
+            return;
+        }
+    } else if (in_lds) {
         for (int i = tid; i < a; i += 256) s_acc[i] = gacc[i];
+    }
     if (tid == 0) {
         s_best_x = FZ_X_NONE;
         s_best_ps = 0.0;
@@ -590,10 +625,10 @@ __global__ __launch_bounds__(256) void fz_subsets_seg_kernel(const float *__rest
     // significance thresholds on |r| (see fz_thresholds_kernel): outside [lo, hi] the verdict of p < alpha is certain
     const double rlo_pos = thr[0], rhi_pos = thr[1], rlo_neg = thr[2], rhi_neg = thr[3];
     __syncthreads();
-#define ACCV(i) (in_lds ? s_acc[(i)] : gacc[(i)])
+#define ACCV(i) (LOCAL ? ((i) + 2) : (in_lds ? s_acc[(i)] : gacc[(i)]))
 #define CORV(u, v) cor[(size_t)(u) * p + (v)]
 
-    const int X = seg.X, Y = seg.Y;
+    const int X = LOCAL ? 0 : seg.X, Y = LOCAL ? 1 : seg.Y;
     const float cXY = CORV(X, Y);
     const unsigned long long NONE = FW_RANK_NONE;
     const unsigned long long len = seg.end - seg.start;
@@ -952,12 +987,341 @@ int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_
         FW_HIP(ctx, hipStreamSynchronize(pb.stream));  // the other pool stream may use it next
     }
     if (ctx->P.max_k > 3)
-        hipLaunchKernelGGL(fz_subsets_seg_kernel<true>, dim3((unsigned)nseg), dim3(256), 0, pb.stream, ctx->d_cor, ctx->P.p,
-                           d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr);
+        hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false>), dim3((unsigned)nseg), dim3(256), 0, pb.stream, ctx->d_cor,
+                           ctx->P.p, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx),
+                           (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll);
     else
-        hipLaunchKernelGGL(fz_subsets_seg_kernel<false>, dim3((unsigned)nseg), dim3(256), 0, pb.stream, ctx->d_cor, ctx->P.p,
-                           d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr);
+        hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false>), dim3((unsigned)nseg), dim3(256), 0, pb.stream, ctx->d_cor,
+                           ctx->P.p, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx),
+                           (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll);
     FW_HIP(ctx, hipGetLastError());
     FW_HIP(ctx, hipEventRecord(pb.ev1, pb.stream));
+    return FW_OK;
+}
+
+
+// ================================================================================================
+// HE-S ("fz_nz"): zero-ignoring Fisher-z tests.  Reference: tests.jl:108-160 (branch :120-125), statfuns.jl:91-123
+// (pair correlation over the rows where both are non-zero), tests.jl:293-308 + statfuns.jl:138-155 (cor_subset! per
+// (T, candidate) job), hiton.jl:41-50,85 (row views).  Data layout: dense Float32 [p][n] column-major exactly as
+// uploaded (zeros = absences) + one nz bit plane [p][W].  All sums run sequentially over the rows in Float64 in row
+// order -- the same operation sequence as the oracle -- so correlations are reproducible to the bit.
+// ================================================================================================
+
+// ---- level 0: one thread per pair (16 x 16 pair tiles), two passes over the samples ----
+__global__ __launch_bounds__(256) void fznz_level0_kernel(const float *__restrict__ data, const unsigned long long *__restrict__ nz,
+                                                          int n, int p, int W, double alpha, long long n_obs_min,
+                                                          FzL0Counters *cnt, unsigned long long cap, int32_t *out_i,
+                                                          int32_t *out_j, double *out_s, double *out_p)
+{
+    const int X = blockIdx.y * 16 + (threadIdx.x >> 4), Y = blockIdx.x * 16 + (threadIdx.x & 15);
+    if (blockIdx.x * 16 + 15 <= blockIdx.y * 16) return;  // tile entirely on/below the diagonal
+    const bool valid = X < Y && Y < p;
+    const float *cx = data + (size_t)(valid ? X : 0) * n, *cy = data + (size_t)(valid ? Y : 0) * n;
+    const unsigned long long *mx = nz + (size_t)(valid ? X : 0) * W, *my = nz + (size_t)(valid ? Y : 0) * W;
+    double sum_x = 0.0, sum_y = 0.0;
+    long long nn = 0;
+    for (int w = 0; w < W; ++w) {
+        unsigned long long m = valid ? (mx[w] & my[w]) : 0ull;
+        nn += __popcll(m);
+        while (m) {
+            const int row = w * 64 + __builtin_ctzll(m);
+            m &= m - 1;
+            sum_x += (double)cx[row];
+            sum_y += (double)cy[row];
+        }
+    }
+    double stat = 0.0, pval = 1.0;
+    bool reliable = false;
+    if (valid && (long long)n >= n_obs_min) {
+        double pc = 0.0;
+        if (nn > 0) {
+            const double mean_x = sum_x / (double)nn, mean_y = sum_y / (double)nn;
+            double cov = 0.0, vx = 0.0, vy = 0.0;
+            for (int w = 0; w < W; ++w) {
+                unsigned long long m = mx[w] & my[w];
+                while (m) {
+                    const int row = w * 64 + __builtin_ctzll(m);
+                    m &= m - 1;
+                    const double dx = (double)cx[row] - mean_x, dy = (double)cy[row] - mean_y;
+                    cov += dx * dy;
+                    vx += dx * dx;
+                    vy += dy * dy;
+                }
+            }
+            pc = cov / sqrt(vx * vy);
+            if (pc > 1.0)
+                pc = 1.0;
+            else if (pc < -1.0)
+                pc = -1.0;
+        }
+        if (nn < n_obs_min) pc = 0.0;  // tests.jl:123-125
+        const long long sf = nn - 3;
+        stat = pc;
+        pval = fz_pval_dev(pc, sf > 0 ? sqrt((double)sf) / 2.0 : 0.0);
+        reliable = nn >= n_obs_min;
+    }
+    const bool isn = valid && (!reliable || isnan(pval));  // NaN in the reference's condensed arrays (tests.jl:397-398)
+    const bool sig = valid && reliable && pval < alpha;
+    if (isn) atomicAdd(&cnt->n_nan, 1ull);
+    if (sig) {
+        const unsigned long long slot = atomicAdd(&cnt->n_sig, 1ull);
+        if (slot < cap) {
+            out_i[slot] = X;
+            out_j[slot] = Y;
+            out_s[slot] = stat;
+            out_p[slot] = pval;
+        }
+    }
+}
+
+// ---- per-job correlation sub-matrix (Statistics.cor of the row view restricted to {T, cand} + accepted) ----
+#define FZNZ_MAXM_LDS 2050
+__global__ __launch_bounds__(256) void fznz_submat_kernel(const float *__restrict__ data, const unsigned long long *__restrict__ nz,
+                                                          int n, int W, FwNzJob *__restrict__ recs,
+                                                          const int32_t *__restrict__ accflat, float *__restrict__ arena,
+                                                          double alpha)
+{
+    __shared__ double s_mean[FZNZ_MAXM_LDS], s_sd[FZNZ_MAXM_LDS], s_ss01[2];
+    __shared__ int s_var[FZNZ_MAXM_LDS];
+    FwNzJob *rec = recs + blockIdx.x;
+    const int m = rec->m, tid = threadIdx.x;
+    const unsigned long long *mx = nz + (size_t)rec->X * W, *my = nz + (size_t)rec->Y * W;
+    for (int t = tid; t < m; t += 256) s_var[t] = t == 0 ? rec->X : (t == 1 ? rec->Y : accflat[rec->acc_off + t - 2]);
+    long long nR = 0;
+    for (int w = 0; w < W; ++w) nR += __popcll(mx[w] & my[w]);
+    __syncthreads();
+    // column means and norms over R (sequential Float64 sums in row order)
+    for (int t = tid; t < m; t += 256) {
+        const float *col = data + (size_t)s_var[t] * n;
+        double sacc = 0.0;
+        for (int w = 0; w < W; ++w) {
+            unsigned long long mk = mx[w] & my[w];
+            while (mk) {
+                const int row = w * 64 + __builtin_ctzll(mk);
+                mk &= mk - 1;
+                sacc += (double)col[row];
+            }
+        }
+        const double mean = sacc / (double)nR;
+        double ss = 0.0;
+        for (int w = 0; w < W; ++w) {
+            unsigned long long mk = mx[w] & my[w];
+            while (mk) {
+                const int row = w * 64 + __builtin_ctzll(mk);
+                mk &= mk - 1;
+                const double d = (double)col[row] - mean;
+                ss += d * d;
+            }
+        }
+        s_mean[t] = mean;
+        s_sd[t] = sqrt(ss);
+        if (t < 2) s_ss01[t] = ss;
+    }
+    __syncthreads();
+    float *local = arena + rec->cor_off;
+    const long long npairs = (long long)m * (m - 1) / 2;
+    for (long long q = tid; q < npairs; q += 256) {
+        // pair index -> (a, b), a < b, row-major over the upper triangle
+        int a = (int)(((2.0 * m - 1.0) - sqrt((2.0 * m - 1.0) * (2.0 * m - 1.0) - 8.0 * (double)q)) * 0.5);
+        while (a > 0 && (long long)a * (2 * m - a - 1) / 2 > q) --a;
+        while ((long long)(a + 1) * (2 * m - a - 2) / 2 <= q) ++a;
+        const int b = a + 1 + (int)(q - (long long)a * (2 * m - a - 1) / 2);
+        const float *ca = data + (size_t)s_var[a] * n, *cb = data + (size_t)s_var[b] * n;
+        const double ma = s_mean[a], mb = s_mean[b];
+        double sacc = 0.0;
+        for (int w = 0; w < W; ++w) {
+            unsigned long long mk = mx[w] & my[w];
+            while (mk) {
+                const int row = w * 64 + __builtin_ctzll(mk);
+                mk &= mk - 1;
+                sacc += ((double)ca[row] - ma) * ((double)cb[row] - mb);
+            }
+        }
+        if (q == 0) {  // (a, b) = (0, 1): the pair statistic of statfuns.jl:114-120, unrounded
+            double pc = sacc / sqrt(s_ss01[0] * s_ss01[1]);
+            if (pc > 1.0)
+                pc = 1.0;
+            else if (pc < -1.0)
+                pc = -1.0;
+            rec->rxy = nR > 0 ? pc : 0.0;
+        }
+        double r = sacc / (s_sd[a] * s_sd[b]);
+        if (r > 1.0) r = 1.0;
+        if (r < -1.0) r = -1.0;
+        if (isnan(r)) r = 0.0;  // statfuns.jl:150
+        const float rf = (float)r;  // the scratch matrix of the reference is Float32 (learning.jl:127-129)
+        local[(size_t)a * m + b] = rf;
+        local[(size_t)b * m + a] = rf;
+    }
+    for (int t = tid; t < m; t += 256) local[(size_t)t * m + t] = 1.0f;
+    if (tid == 0) {
+        rec->nR = (int32_t)nR;
+        const long long sf = nR - 3;
+        rec->zscale = sf > 0 ? sqrt((double)sf) / 2.0 : 0.0;
+        fz_thresholds_dev(alpha, rec->zscale, rec->thr);
+    }
+}
+
+// ---- explicit single tests (fw_test_batch): one thread per test on the job's local matrix ----
+__global__ __launch_bounds__(64) void fznz_single_kernel(const FwNzJob *__restrict__ recs, const float *__restrict__ arena,
+                                                         long long m_tests, long long n_obs_min,
+                                                         fw_test_result *__restrict__ out)
+{
+    const long long t = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (t >= m_tests) return;
+    const FwNzJob rec = recs[t];
+    fw_test_result o;
+    if (rec.acc_len == 0) {  // univariate: tests.jl:120-125,155-159
+        const double ps = (long long)rec.nR < n_obs_min ? 0.0 : rec.rxy;
+        o.stat = ps;
+        o.pval = fz_pval_dev(ps, rec.zscale);
+        o.df = 0;
+        o.suff_power = (long long)rec.nR >= n_obs_min ? 1 : 0;
+    } else if ((long long)rec.nR < n_obs_min) {
+        o.stat = 0.0;
+        o.pval = 1.0;
+        o.df = 0;
+        o.suff_power = 0;
+    } else {
+        int z[FW_MAX_K];
+        for (int q = 0; q < FW_MAX_K; ++q) z[q] = 2 + q;
+        const double r = fz_pcor_any(arena + rec.cor_off, rec.m, 0, 1, z, rec.acc_len);
+        o.stat = r;
+        o.pval = fz_pval_dev(r, rec.zscale);
+        o.df = 0;
+        o.suff_power = 1;
+    }
+    out[t] = o;
+}
+
+int fwi_fznz_upload(fw_ctx *ctx, const float *data)
+{
+    const int n = ctx->P.n, p = ctx->P.p, W = (n + 63) / 64;
+    const size_t bytes = sizeof(float) * (size_t)n * p;
+    if (!ctx->d_data) FW_HIP(ctx, hipMalloc(&ctx->d_data, bytes));
+    FW_HIP(ctx, hipMemcpy(ctx->d_data, data, bytes, hipMemcpyHostToDevice));
+    std::vector<uint64_t> nzb((size_t)p * W, 0);
+    for (int v = 0; v < p; ++v)
+        for (int i = 0; i < n; ++i)
+            if (data[(size_t)v * n + i] != 0.0f) nzb[(size_t)v * W + (i >> 6)] |= 1ull << (i & 63);
+    if (ctx->d_nzbits) (void)hipFree(ctx->d_nzbits);
+    ctx->d_nzbits = nullptr;
+    FW_HIP(ctx, hipMalloc((void **)&ctx->d_nzbits, sizeof(uint64_t) * nzb.size()));
+    FW_HIP(ctx, hipMemcpy(ctx->d_nzbits, nzb.data(), sizeof(uint64_t) * nzb.size(), hipMemcpyHostToDevice));
+    ctx->W = W;
+    return FW_OK;
+}
+
+int fwi_fznz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &pj, std::vector<double> &stat,
+                    std::vector<double> &pval, int64_t *m_reliable)
+{
+    const int p = ctx->P.p;
+    const long long npairs = (long long)p * (p - 1) / 2;
+    unsigned long long cap = (unsigned long long)std::min<long long>(npairs, 4ll << 20);
+    if (cap == 0) cap = 1;
+    FzL0Counters h{};
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int rc;
+        if ((rc = fw_dev_reserve(ctx, ctx->d_tmp0, sizeof(FzL0Counters)))) return rc;
+        if ((rc = fw_dev_reserve(ctx, ctx->d_tmp1, cap * 2 * sizeof(int32_t)))) return rc;
+        if ((rc = fw_dev_reserve(ctx, ctx->d_tmp2, cap * 2 * sizeof(double)))) return rc;
+        FW_HIP(ctx, hipMemsetAsync(ctx->d_tmp0.ptr, 0, sizeof(FzL0Counters), ctx->stream));
+        int32_t *oi = (int32_t *)ctx->d_tmp1.ptr, *oj = oi + cap;
+        double *os = (double *)ctx->d_tmp2.ptr, *op = os + cap;
+        dim3 grid((p + 15) / 16, (p + 15) / 16);
+        hipLaunchKernelGGL(fznz_level0_kernel, grid, dim3(256), 0, ctx->stream, ctx->d_data,
+                           (const unsigned long long *)ctx->d_nzbits, ctx->P.n, p, ctx->W, ctx->P.alpha,
+                           (long long)ctx->n_obs_min_eff, (FzL0Counters *)ctx->d_tmp0.ptr, cap, oi, oj, os, op);
+        FW_HIP(ctx, hipGetLastError());
+        FW_HIP(ctx, hipMemcpyAsync(&h, ctx->d_tmp0.ptr, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->cnt.kernel_launches += 1;
+        if (h.n_sig <= cap) {
+            const size_t k = (size_t)h.n_sig;
+            pi.resize(k);
+            pj.resize(k);
+            stat.resize(k);
+            pval.resize(k);
+            if (k) {
+                FW_HIP(ctx, hipMemcpy(pi.data(), oi, k * sizeof(int32_t), hipMemcpyDeviceToHost));
+                FW_HIP(ctx, hipMemcpy(pj.data(), oj, k * sizeof(int32_t), hipMemcpyDeviceToHost));
+                FW_HIP(ctx, hipMemcpy(stat.data(), os, k * sizeof(double), hipMemcpyDeviceToHost));
+                FW_HIP(ctx, hipMemcpy(pval.data(), op, k * sizeof(double), hipMemcpyDeviceToHost));
+            }
+            *m_reliable = npairs - (long long)h.n_nan;
+            return FW_OK;
+        }
+        cap = h.n_sig;
+    }
+    return fw_fail(ctx, FW_ERR_DEVICE, "fz_nz level-0: compaction buffer overflow twice");
+}
+
+// recs_host: one record per job of this launch (X, Y, acc_off, acc_len, m, cor_off filled); d_acc: flat accepted ints
+int fwi_fznz_submatrices(fw_ctx *ctx, int64_t njobs, const FwNzJob *recs_host, size_t arena_floats, const int32_t *d_acc,
+                         hipStream_t stream)
+{
+    int rc;
+    if ((rc = fw_dev_reserve(ctx, ctx->d_nzrecs, (size_t)njobs * sizeof(FwNzJob)))) return rc;
+    if ((rc = fw_dev_reserve(ctx, ctx->d_arena, std::max<size_t>(arena_floats, 1) * sizeof(float)))) return rc;
+    FW_HIP(ctx, hipMemcpyAsync(ctx->d_nzrecs.ptr, recs_host, (size_t)njobs * sizeof(FwNzJob), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(fznz_submat_kernel, dim3((unsigned)njobs), dim3(256), 0, stream, ctx->d_data,
+                       (const unsigned long long *)ctx->d_nzbits, ctx->P.n, ctx->W, (FwNzJob *)ctx->d_nzrecs.ptr, d_acc,
+                       (float *)ctx->d_arena.ptr, ctx->P.alpha);
+    FW_HIP(ctx, hipGetLastError());
+    ctx->cnt.kernel_launches += 1;
+    return FW_OK;
+}
+
+int fwi_fznz_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb)
+{
+    if (nseg == 0) return FW_OK;
+    FW_HIP(ctx, hipEventRecord(pb.ev0, pb.stream));
+    if (ctx->P.max_k > 3)
+        hipLaunchKernelGGL((fz_subsets_seg_kernel<true, true>), dim3((unsigned)nseg), dim3(256), 0, pb.stream,
+                           (const float *)ctx->d_arena.ptr, 0, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, 0.0,
+                           (long long)ctx->P.max_tests, (const double *)nullptr, (const FwNzJob *)ctx->d_nzrecs.ptr,
+                           (long long)ctx->n_obs_min_eff);
+    else
+        hipLaunchKernelGGL((fz_subsets_seg_kernel<false, true>), dim3((unsigned)nseg), dim3(256), 0, pb.stream,
+                           (const float *)ctx->d_arena.ptr, 0, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, 0.0,
+                           (long long)ctx->P.max_tests, (const double *)nullptr, (const FwNzJob *)ctx->d_nzrecs.ptr,
+                           (long long)ctx->n_obs_min_eff);
+    FW_HIP(ctx, hipGetLastError());
+    FW_HIP(ctx, hipEventRecord(pb.ev1, pb.stream));
+    return FW_OK;
+}
+
+int fwi_fznz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff,
+                        const int32_t *zflat, fw_test_result *out)
+{
+    if (m == 0) return FW_OK;
+    std::vector<FwNzJob> recs((size_t)m);
+    size_t arena = 0;
+    for (int64_t t = 0; t < m; ++t) {
+        FwNzJob r{};
+        r.X = X[t];
+        r.Y = Y[t];
+        r.acc_off = zoff[t];
+        r.acc_len = (int32_t)(zoff[t + 1] - zoff[t]);
+        r.m = r.acc_len + 2;
+        r.cor_off = (long long)arena;
+        arena += (size_t)r.m * r.m;
+        recs[(size_t)t] = r;
+    }
+    const int64_t nz = zoff[m];
+    int rc;
+    if ((rc = fw_dev_reserve(ctx, ctx->d_acc, (size_t)std::max<int64_t>(nz, 1) * sizeof(int32_t)))) return rc;
+    if ((rc = fw_dev_reserve(ctx, ctx->d_out, (size_t)m * sizeof(fw_test_result)))) return rc;
+    if (nz > 0)
+        FW_HIP(ctx, hipMemcpyAsync(ctx->d_acc.ptr, zflat, (size_t)nz * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = fwi_fznz_submatrices(ctx, m, recs.data(), arena, (const int32_t *)ctx->d_acc.ptr, ctx->stream))) return rc;
+    hipLaunchKernelGGL(fznz_single_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, ctx->stream,
+                       (const FwNzJob *)ctx->d_nzrecs.ptr, (const float *)ctx->d_arena.ptr, (long long)m,
+                       (long long)ctx->n_obs_min_eff, (fw_test_result *)ctx->d_out.ptr);
+    FW_HIP(ctx, hipGetLastError());
+    FW_HIP(ctx, hipMemcpyAsync(out, ctx->d_out.ptr, (size_t)m * sizeof(fw_test_result), hipMemcpyDeviceToHost, ctx->stream));
+    FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->cnt.kernel_launches += 1;
     return FW_OK;
 }

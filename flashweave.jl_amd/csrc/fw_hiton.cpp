@@ -145,7 +145,7 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
         if (rc) return rc;
     }
     const int p = c->P.p;
-    const bool discrete = c->P.kind != FW_FZ;
+    const bool discrete = c->P.kind == FW_MI || c->P.kind == FW_MI_NZ;
     const double t0 = now_s();
 
     // learning.jl:97-98: ascending univariate degree, stable

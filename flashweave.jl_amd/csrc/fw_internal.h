@@ -57,6 +57,22 @@ struct FwSeg {
 
 #define FW_RANK_NONE (~0ull)
 
+// Per-job record of the HE-S (fz_nz) path: the correlation sub-matrix of a job is computed over the rows where both
+// T and the candidate are non-zero (statfuns.jl:138-155 cor_subset!), lives in a device arena and is indexed locally
+// (0 = T, 1 = candidate, 2 + i = accepted[i]).
+struct FwNzJob {
+    int32_t X, Y;
+    long long acc_off;  // into the flat accepted array of the launch
+    int32_t acc_len;
+    int32_t m;          // acc_len + 2
+    long long cor_off;  // offset (floats) of the m x m matrix in the arena
+    int32_t nR;         // rows with X != 0 and Y != 0            (device-computed)
+    int32_t pad;
+    double zscale;      // sqrt(nR - 3) / 2, 0 if nR <= 3          (device-computed)
+    double rxy;         // unrounded Float64 pair correlation of (X, Y) over R, statfuns.jl:114 (device-computed)
+    double thr[4];      // |r| significance thresholds for this nR (device-computed)
+};
+
 // Device-side result of one segment.  The conditioning sets are recovered on the host from the ranks.
 struct FwSegOut {
     uint64_t stop_rank;  // first rank in the segment that ends the job (non-significant or max_tests), else FW_RANK_NONE
@@ -122,7 +138,7 @@ struct fw_ctx {
     fw_counters cnt{};
 
     // grow-only scratch
-    FwDevBuf d_jobs, d_acc, d_out, d_tmp0, d_tmp1, d_tmp2, d_segs, d_segout;
+    FwDevBuf d_jobs, d_acc, d_out, d_tmp0, d_tmp1, d_tmp2, d_segs, d_segout, d_nzrecs, d_arena;
     FwPinned h_jobs, h_acc, h_out;
     FwPoolBuf pb[2];
 };
@@ -147,6 +163,16 @@ int fwi_fz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y
                       const int32_t *zflat, fw_test_result *out);
 int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb);
 
+// ---- HE-S / fz_nz (fw_fz.hip) ----
+int fwi_fznz_upload(fw_ctx *ctx, const float *data);
+int fwi_fznz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &pj, std::vector<double> &stat,
+                    std::vector<double> &pval, int64_t *m_reliable);
+int fwi_fznz_submatrices(fw_ctx *ctx, int64_t njobs, const FwNzJob *recs_host, size_t arena_floats, const int32_t *d_acc,
+                         hipStream_t stream);
+int fwi_fznz_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb);
+int fwi_fznz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff,
+                        const int32_t *zflat, fw_test_result *out);
+
 // ---- discrete (fw_mi.hip) ----
 int fwi_mi_upload(fw_ctx *ctx, const int64_t *colptr, const int32_t *rowval, const int32_t *nzval);
 int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &pj, std::vector<double> &stat,
@@ -166,6 +192,7 @@ struct FwPoolJob {
     int32_t epoch = 0;   // driver: accepted-set epoch of the owner when the job was posted (stale jobs are dropped)
     bool hold = false;     // driver: do not launch further windows for now (speculative job past its first window)
     bool launched = false; // set by fwi_pool_launch for the jobs that are part of the pending window
+    bool no_zs = false;    // the returned result has no conditioning set (fz_nz job without a test)
     std::vector<int32_t> acc;
     uint64_t N = 0, next = 0, width = 0;
     double best_p = -1.0, best_stat = 0.0;
@@ -177,6 +204,7 @@ struct FwPoolJob {
 struct FwPool {
     std::vector<FwPoolJob> live;
     std::vector<int64_t> seg_job;
+    std::vector<FwNzJob> nzrecs;  // fz_nz: job records of the pending launch
     int buf = 0;            // which ctx->pb[] this pool stages through
     bool want_zs = false;   // recover the conditioning set of each returned result from its rank (ABI path)
     const std::vector<int32_t> *owner_epoch = nullptr;  // if set: jobs whose epoch != (*owner_epoch)[tag] are cancelled

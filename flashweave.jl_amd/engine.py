@@ -6,9 +6,9 @@ from collections import namedtuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-FW_MI, FW_MI_NZ, FW_FZ = 0, 1, 2
+FW_MI, FW_MI_NZ, FW_FZ, FW_FZ_NZ = 0, 1, 2, 3
 FW_MAX_K = 5
-_KINDS = {"mi": FW_MI, "mi_nz": FW_MI_NZ, "fz": FW_FZ}
+_KINDS = {"mi": FW_MI, "mi_nz": FW_MI_NZ, "fz": FW_FZ, "fz_nz": FW_FZ_NZ}
 
 TestResult = namedtuple("TestResult", "stat pval df suff_power")  # src/types.jl:140-145
 
@@ -152,7 +152,7 @@ class Engine:
     def set_data(self, data):
         """fz: dense Float32 n x p; mi / mi_nz: integer n x p (dense ndarray) or a (colptr, rowval, nzval) CSC triple
         with 0-based rows."""
-        if self.test_name == "fz":
+        if self.test_name in ("fz", "fz_nz"):
             d = np.asfortranarray(np.asarray(data, dtype=np.float32))
             assert d.shape == (self.n, self.p)
             self._ck(self.L.fw_set_data_dense_f32(self.h, _ptr(d)))

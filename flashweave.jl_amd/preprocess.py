@@ -100,4 +100,7 @@ def normalize(counts, test_name, prec=32):
         cm = np.zeros_like(col_mask)
         cm[cols[km]] = True
         return d[:, km], row_mask, cm
-    raise ValueError("unsupported test_name %r (fz_nz is not built yet)" % (test_name,))
+    if test_name == "fz_nz":  # clr_nz (preprocessing.jl:335-342): zeros stay zeros (= absences)
+        out = clr_nz(data)
+        return out.astype(np.float32 if prec == 32 else np.float64), row_mask, col_mask
+    raise ValueError("unsupported test_name %r" % (test_name,))

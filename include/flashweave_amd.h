@@ -32,6 +32,7 @@ extern "C" {
 #define FW_MI 0
 #define FW_MI_NZ 1
 #define FW_FZ 2
+#define FW_FZ_NZ 3 /* "fz_nz": FlashWeaveHE-S, zero-ignoring Fisher-z tests */
 
 #define FW_OK 0
 #define FW_ERR_ARG (-1)     /* invalid argument */
@@ -47,7 +48,7 @@ typedef struct fw_ctx fw_ctx;
 
 /* Engine parameters; defaults follow learn_network / LGL (src/learning.jl:203-214,466-473). */
 typedef struct fw_params {
-    int32_t kind;      /* FW_MI / FW_MI_NZ / FW_FZ */
+    int32_t kind;      /* FW_MI / FW_MI_NZ / FW_FZ / FW_FZ_NZ */
     int32_t n;         /* samples (rows) */
     int32_t p;         /* variables (columns) */
     int32_t device;    /* HIP device ordinal */
@@ -121,7 +122,8 @@ int fw_abi_version(void);
 /* ---- data ------------------------------------------------------------------------------------- */
 
 /* FW_FZ: the normalised dense matrix (Matrix{Float32}, n x p column-major) the reference hands to
- * cor() in prepare_lgl (src/learning.jl:42-45). */
+ * cor() in prepare_lgl (src/learning.jl:42-45).  FW_FZ_NZ: the clr_nz matrix with zeros = absences (the reference
+ * holds it as SparseMatrixCSC{Float32}; the Julia shim densifies it once). */
 int fw_set_data_dense_f32(fw_ctx *ctx, const float *data);
 
 /* FW_MI / FW_MI_NZ: SparseMatrixCSC{Int32,Int64} as produced by normalize_data (make_sparse = true).

@@ -33,6 +33,8 @@
 #define FWO_MI 0
 #define FWO_MI_NZ 1
 #define FWO_FZ 2
+#define FWO_FZ_NZ 3
+#define FWO_IS_CONT(c) ((c)->kind >= FWO_FZ)
 
 typedef struct {
     double stat;
@@ -59,6 +61,9 @@ typedef struct fwo_ctx {
     const float *cor32; /* p x p, ContType = Float32 (learning.jl:44) */
     const double *cor64; /* p x p, ContType = Float64 (test convenience wrapper, tests.jl:272) */
     int n_obs;          /* size(data, 1) for fz tests */
+    /* fz_nz (HE-S): the normalised matrix itself (clr_nz, zeros = absences), n x p column-major */
+    const double *fdata; /* values widened to double (exact) */
+    int fdata_f32;       /* 1: the reference's element type is Float32 (prec = 32), 0: Float64 */
     /* scratch (one MiTestCond sized for max_k, hiton.jl:192) */
     int max_k;
     int64_t nstrata_cap; /* L^max_k (+1 slack) */
@@ -270,6 +275,20 @@ fwo_ctx *fwo_create_fz(int n_obs, int p, const float *cor32, const double *cor64
     c->p = p;
     c->cor32 = cor32;
     c->cor64 = cor64;
+    return c;
+}
+
+/* fz_nz: data = n x p column-major values (Float32 values widened exactly if is_f32) */
+fwo_ctx *fwo_create_fz_nz(int n, int p, const double *data, int is_f32)
+{
+    fwo_ctx *c = (fwo_ctx *)calloc(1, sizeof(fwo_ctx));
+    c->kind = FWO_FZ_NZ;
+    c->nz = 1;
+    c->n = n;
+    c->n_obs = n;
+    c->p = p;
+    c->fdata = data;
+    c->fdata_f32 = is_f32;
     return c;
 }
 
@@ -729,7 +748,7 @@ static inline int suff_power4(int64_t lx, int64_t ly, int64_t lz, int64_t n_obs,
 static int suff_power_data(const fwo_ctx *c, int X, int Y, int64_t n_rows, int64_t n_obs_min, int hps)
 {
     if (n_rows < n_obs_min) return 0;
-    if (c->kind != FWO_FZ) {
+    if (!FWO_IS_CONT(c)) {
         int64_t lx = c->levels[X], ly = c->levels[Y];
         int64_t ox = lx > 1 ? 2 : 1, oy = ly > 1 ? 2 : 1; /* statfuns.jl:307-311 called with levels */
         if (!suff_power3(lx - ox, ly - oy, n_rows, hps)) return 0;
@@ -938,11 +957,166 @@ static void fz_test_cond(const fwo_ctx *c, int X, int Y, const int *Zs, int k, i
     }
 }
 
+/* ---- HE-S ("fz_nz") ------------------------------------------------------------------------ */
+
+#define FD(c, i, v) ((c)->fdata[(int64_t)(v) * (c)->n + (i)])
+
+/* statfuns.jl:91-123 cor(X, Y, data::SparseMatrixCSC, nz = true): two passes over the rows where both X and Y are
+ * non-zero (misc.jl:275-364 iter_apply_sparse_rows! with x_nzadj = y_nzadj = true), Float64 accumulators. */
+static double fz_nz_pair_cor(const fwo_ctx *c, int X, int Y, int64_t *n_obs_out)
+{
+    double sum_x = 0.0, sum_y = 0.0;
+    int64_t nn = 0;
+    for (int i = 0; i < c->n; ++i) {
+        const double x = FD(c, i, X), y = FD(c, i, Y);
+        if (x != 0.0 && y != 0.0) {
+            sum_x += x;
+            sum_y += y;
+            ++nn;
+        }
+    }
+    *n_obs_out = nn;
+    if (nn == 0) return 0.0;
+    const double mean_x = sum_x / (double)nn, mean_y = sum_y / (double)nn;
+    double cov = 0.0, vx = 0.0, vy = 0.0;
+    for (int i = 0; i < c->n; ++i) {
+        const double x = FD(c, i, X), y = FD(c, i, Y);
+        if (x != 0.0 && y != 0.0) {
+            const double dx = x - mean_x, dy = y - mean_y;
+            cov += dx * dy;
+            vx += dx * dx;
+            vy += dy * dy;
+        }
+    }
+    double p = cov / sqrt(vx * vy);
+    if (p > 1.0)
+        p = 1.0;
+    else if (p < -1.0)
+        p = -1.0;
+    return p;
+}
+
+/* tests.jl:108-160 with a sparse matrix and an empty cor_mat (branch :120-125) */
+static void fz_nz_test_uni(const fwo_ctx *c, int X, int Y, int64_t n_obs_min, fwo_result *out)
+{
+    if (c->n < n_obs_min) { /* sufficient_power(X, Y, data, ...) on the full row count, tests.jl:11 */
+        set_result(out, 0.0, 1.0, 0, 0 >= n_obs_min);
+        return;
+    }
+    int64_t n_obs = 0;
+    double p_stat = fz_nz_pair_cor(c, X, Y, &n_obs);
+    if (n_obs < n_obs_min) p_stat = 0.0;
+    set_result(out, p_stat, fwo_fz_pval(p_stat, n_obs, 0), 0, n_obs >= n_obs_min);
+}
+
+/* statfuns.jl:138-155 cor_subset!: Statistics.cor of the rows R (both X and Y non-zero, hiton.jl:41-50,85) restricted
+ * to vars; NaN -> 0; stored in a Float32 matrix (learning.jl:127-129, cont_type = Float32).  local: m x m floats. */
+static int64_t fz_nz_cor_subset(const fwo_ctx *c, int X, int Y, const int *vars, int m, float *local)
+{
+    int *rows = (int *)malloc(sizeof(int) * (size_t)(c->n > 0 ? c->n : 1));
+    int64_t nR = 0;
+    for (int i = 0; i < c->n; ++i)
+        if (FD(c, i, X) != 0.0 && FD(c, i, Y) != 0.0) rows[nR++] = i;
+    if (local) {
+        const int64_t nr = nR > 0 ? nR : 1;
+        if (c->fdata_f32) { /* Statistics.cor in Float32: mean, centring, x'x and cov2cor! all in Float32 */
+            float *xc = (float *)malloc(sizeof(float) * (size_t)(nr * m));
+            float *sd = (float *)malloc(sizeof(float) * (size_t)m);
+            for (int a = 0; a < m; ++a) {
+                float s = 0.0f;
+                for (int64_t q = 0; q < nR; ++q) s += (float)FD(c, rows[q], vars[a]);
+                const float mean = s / (float)nR;
+                float ss = 0.0f;
+                for (int64_t q = 0; q < nR; ++q) {
+                    const float d = (float)FD(c, rows[q], vars[a]) - mean;
+                    xc[(int64_t)a * nr + q] = d;
+                    ss += d * d;
+                }
+                sd[a] = sqrtf(ss);
+            }
+            for (int a = 0; a < m; ++a)
+                for (int b = a + 1; b < m; ++b) {
+                    float s = 0.0f;
+                    for (int64_t q = 0; q < nR; ++q) s += xc[(int64_t)a * nr + q] * xc[(int64_t)b * nr + q];
+                    float r = s / (sd[a] * sd[b]);
+                    if (r > 1.0f) r = 1.0f;
+                    if (r < -1.0f) r = -1.0f;
+                    if (isnan(r)) r = 0.0f;
+                    local[(int64_t)b * m + a] = local[(int64_t)a * m + b] = r;
+                }
+            free(xc);
+            free(sd);
+        } else {
+            double *xc = (double *)malloc(sizeof(double) * (size_t)(nr * m));
+            double *sd = (double *)malloc(sizeof(double) * (size_t)m);
+            for (int a = 0; a < m; ++a) {
+                double s = 0.0;
+                for (int64_t q = 0; q < nR; ++q) s += FD(c, rows[q], vars[a]);
+                const double mean = s / (double)nR;
+                double ss = 0.0;
+                for (int64_t q = 0; q < nR; ++q) {
+                    const double d = FD(c, rows[q], vars[a]) - mean;
+                    xc[(int64_t)a * nr + q] = d;
+                    ss += d * d;
+                }
+                sd[a] = sqrt(ss);
+            }
+            for (int a = 0; a < m; ++a)
+                for (int b = a + 1; b < m; ++b) {
+                    double s = 0.0;
+                    for (int64_t q = 0; q < nR; ++q) s += xc[(int64_t)a * nr + q] * xc[(int64_t)b * nr + q];
+                    double r = s / (sd[a] * sd[b]);
+                    if (r > 1.0) r = 1.0;
+                    if (r < -1.0) r = -1.0;
+                    if (isnan(r)) r = 0.0;
+                    local[(int64_t)b * m + a] = local[(int64_t)a * m + b] = (float)r;
+                }
+            free(xc);
+            free(sd);
+        }
+        for (int a = 0; a < m; ++a) local[(int64_t)a * m + a] = 1.0f;
+    }
+    free(rows);
+    return nR;
+}
+
+/* conditional fz_nz test of one explicit subset (tests.jl:250-265 on the row view of hiton.jl:85) */
+static void fz_nz_test_cond(const fwo_ctx *c, int X, int Y, const int *Zs, int k, int64_t n_obs_min, fwo_result *out)
+{
+    int vars[2 + 16], loc[16];
+    vars[0] = X;
+    vars[1] = Y;
+    for (int j = 0; j < k; ++j) {
+        vars[2 + j] = Zs[j];
+        loc[j] = 2 + j;
+    }
+    const int m = k + 2;
+    float local[18 * 18];
+    const int64_t nR = fz_nz_cor_subset(c, X, Y, vars, m, local);
+    if (nR < n_obs_min) {
+        set_result(out, 0.0, 1.0, 0, 0);
+        return;
+    }
+    fwo_ctx tmp;
+    memset(&tmp, 0, sizeof(tmp));
+    tmp.kind = FWO_FZ;
+    tmp.p = m;
+    tmp.n = tmp.n_obs = (int)nR;
+    tmp.cor32 = local;
+    const double p_stat = pcor_rec(&tmp, 0, 1, loc, k).v;
+    set_result(out, p_stat, fwo_fz_pval(p_stat, nR, 0), 0, 1);
+}
+
 /* Public single-test entry: k = 0 univariate, k >= 1 conditional.
  * hps is used by discrete tests, n_obs_min by univariate discrete and all fz tests (Q2). */
 void fwo_test(fwo_ctx *c, int X, int Y, const int *Zs, int k, int hps, int64_t n_obs_min, fwo_result *out)
 {
-    if (c->kind == FWO_FZ) {
+    if (c->kind == FWO_FZ_NZ) {
+        if (k == 0)
+            fz_nz_test_uni(c, X, Y, n_obs_min, out);
+        else
+            fz_nz_test_cond(c, X, Y, Zs, k, n_obs_min, out);
+    } else if (c->kind == FWO_FZ) {
         if (k == 0)
             fz_test_uni(c, X, Y, n_obs_min, out);
         else
@@ -982,6 +1156,45 @@ int fwo_test_subsets(fwo_ctx *c, int X, int Y, const int *Z_total, int nZ, int m
         *num_tests_out = -1;
         *frac_out = NAN;
         return 0;
+    }
+    if (c->kind == FWO_FZ_NZ) {
+        /* tests.jl:293-308: rows with X != 0 and Y != 0 (hiton.jl:41-50,85); too few -> (0, 1, 0, false), 0 tests;
+         * else cor_subset! over {X, Y} + Z_total, then the ordinary enumeration on that Float32 matrix */
+        const int m = nZ + 2;
+        int *vars = (int *)malloc(sizeof(int) * (size_t)m);
+        int *locZ = (int *)malloc(sizeof(int) * (size_t)(nZ > 0 ? nZ : 1));
+        vars[0] = X;
+        vars[1] = Y;
+        for (int j = 0; j < nZ; ++j) {
+            vars[2 + j] = Z_total[j];
+            locZ[j] = 2 + j;
+        }
+        int64_t nR = fz_nz_cor_subset(c, X, Y, vars, m, NULL);
+        int status;
+        if (n_obs_min > nR) {
+            set_result(out, 0.0, 1.0, 0, 0);
+            *nZs_out = 0;
+            *num_tests_out = 0;
+            *frac_out = 0.0;
+            status = 1;
+        } else {
+            float *local = (float *)malloc(sizeof(float) * (size_t)m * (size_t)m);
+            fz_nz_cor_subset(c, X, Y, vars, m, local);
+            fwo_ctx tmp;
+            memset(&tmp, 0, sizeof(tmp));
+            tmp.kind = FWO_FZ;
+            tmp.p = m;
+            tmp.n = tmp.n_obs = (int)nR;
+            tmp.cor32 = local;
+            int zl[16];
+            status = fwo_test_subsets(&tmp, 0, 1, locZ, nZ, max_k, alpha, hps, n_obs_min, max_tests, out, zl, nZs_out,
+                                      num_tests_out, frac_out);
+            for (int j = 0; j < *nZs_out; ++j) Zs_out[j] = Z_total[zl[j] - 2];
+            free(local);
+        }
+        free(vars);
+        free(locZ);
+        return status;
     }
     fwo_result lowest;
     set_result(&lowest, 0.0, 0.0, 0, 1); /* :287 */
@@ -1108,7 +1321,7 @@ fwo_nbrs *fwo_level0(fwo_ctx *c, double alpha, int hps, int64_t n_obs_min, int F
     int64_t n_tests = 0, m = 0, pair = 0;
     for (int X = 0; X < p - 1; ++X) {
         /* tests.jl:80-92: all tests fail if levels[X] < 2 */
-        int x_fail = (c->kind != FWO_FZ) && c->levels[X] < 2;
+        int x_fail = !FWO_IS_CONT(c) && c->levels[X] < 2;
         for (int Y = X + 1; Y < p; ++Y, ++pair) {
             fwo_result r;
             if (x_fail)
@@ -1325,7 +1538,7 @@ static void si_hiton_pc(fwo_ctx *c, int T, const fwo_nbrs *nb, const fwo_params 
         for (int i = 0; i < deg; ++i) od_set(PC, nb->idx[o + i], nb->stat[o + i], nb->pval[o + i]);
         return;
     }
-    if (c->kind != FWO_FZ && c->levels[T] < 2) return; /* hiton.jl:182-184 */
+    if (!FWO_IS_CONT(c) && c->levels[T] < 2) return; /* hiton.jl:182-184 */
     odict univar;
     od_init(&univar);
     for (int i = 0; i < deg; ++i) od_set(&univar, nb->idx[o + i], nb->stat[o + i], nb->pval[o + i]);
@@ -1415,7 +1628,7 @@ static int cmp_deg(const void *a, const void *b)
 int64_t fwo_auto_n_obs_min(const fwo_ctx *c, int64_t n_obs_min, int hps, int max_k)
 {
     if (n_obs_min >= 0) return n_obs_min;
-    if (c->kind == FWO_FZ) return 20;
+    if (FWO_IS_CONT(c)) return 20;
     int64_t max_level = 0;
     for (int v = 0; v < c->p; ++v)
         if (c->levels[v] > max_level) max_level = c->levels[v];
@@ -1508,7 +1721,7 @@ fwo_network *fwo_learn(fwo_ctx *c, const fwo_params *P_in, const fwo_nbrs *nb_in
 
     /* misc.jl:137-159 make_weights ("cond_stat") -> per-direction weight, stored in PCs[].stat */
     for (int T = 0; T < p; ++T) {
-        if (c->kind == FWO_FZ) continue;
+        if (FWO_IS_CONT(c)) continue;
         const int o = nb->off[T], deg = nb->off[T + 1] - nb->off[T];
         for (int i = 0; i < PCs[T].n; ++i) {
             double us = NAN;

@@ -48,6 +48,8 @@ def lib():
         L.fwo_create_discrete_dense.argtypes = [C.c_int, C.c_int, vp, C.c_int, C.c_int]
         L.fwo_create_fz.restype = vp
         L.fwo_create_fz.argtypes = [C.c_int, C.c_int, vp, vp]
+        L.fwo_create_fz_nz.restype = vp
+        L.fwo_create_fz_nz.argtypes = [C.c_int, C.c_int, vp, C.c_int]
         L.fwo_destroy.argtypes = [vp]
         L.fwo_L.argtypes = [vp]
         L.fwo_get_levels.argtypes = [vp, vp, vp]
@@ -157,6 +159,13 @@ class Oracle:
                 cm = np.asfortranarray(cm.astype(np.float64))
                 self._keep.append(cm)
                 self.h = self.L.fwo_create_fz(self.n, self.p, None, _ptr(cm))
+        elif kind == "fz_nz":
+            arr = np.asarray(data)
+            self.n, self.p = arr.shape
+            is_f32 = 1 if arr.dtype == np.float32 else 0
+            d = np.asfortranarray(arr.astype(np.float64))
+            self._keep.append(d)
+            self.h = self.L.fwo_create_fz_nz(self.n, self.p, _ptr(d), is_f32)
         else:
             raise ValueError(kind)
 

@@ -1,0 +1,115 @@
+"""GPU parity tests of the HE-S ("fz_nz", zero-ignoring Fisher-z) HIP path against the CPU oracle, through the C ABI.
+The device sums run sequentially over the rows in Float64, like the oracle's: correlations, partial correlations and
+edge weights are compared bit-exact; p-values within 1e-12 relative (device log/erfc)."""
+import numpy as np
+import pytest
+
+import flashweave_jl_amd as fw
+from flashweave_jl_amd import preprocess as pre
+from flashweave_jl_amd import synth
+from oracle import oracle as O
+from tests.util import GOLDEN, read_edgelist, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _synth(p, n, seed):
+    counts = synth.generate(p, n, seed, mode="S", habitats=4)
+    data, _, _ = pre.normalize(counts, "fz_nz", prec=32)
+    return np.asfortranarray(data)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    data = _synth(250, 400, 31)
+    n, p = data.shape
+    eng = fw.Engine("fz_nz", n, p, max_k=3)
+    eng.set_data(data)
+    orc = O.Oracle("fz_nz", data=data.astype(np.float64))  # Float32 values, Float64 arithmetic (as on the device)
+    return dict(data=data, n=n, p=p, eng=eng, orc=orc)
+
+
+def _same(a, b):
+    return a == b or (np.isnan(a) and np.isnan(b))
+
+
+def test_single_tests(ctx):
+    eng, orc, p = ctx["eng"], ctx["orc"], ctx["p"]
+    rng = np.random.default_rng(2)
+    X, Y, Zs = [], [], []
+    for _ in range(1500):
+        k = int(rng.integers(0, 4))
+        v = rng.choice(p, size=k + 2, replace=False)
+        X.append(int(v[0])); Y.append(int(v[1])); Zs.append(tuple(int(t) for t in v[2:]))
+    got = eng.test_batch(X, Y, Zs)
+    npow = 0
+    for x, y, z, g in zip(X, Y, Zs, got):
+        s, pv, df, pw = orc.test(x, y, z, n_obs_min=20)
+        assert _same(g.stat, s) and g.suff_power == pw and g.df == 0, (x, y, z, g, (s, pv, pw))
+        assert _same(g.pval, pv) or rel(g.pval, pv) < 1e-12
+        npow += pw
+    assert npow > 100
+
+
+def test_level0(ctx):
+    got = ctx["eng"].pw_univar_neighbors()
+    exp = ctx["orc"].level0(alpha=0.01, n_obs_min=20)
+    assert (got["off"] == exp["off"]).all() and (got["idx"] == exp["idx"]).all()
+    assert (got["stat"] == exp["stat"]).all()
+    assert np.allclose(got["pval"], exp["pval"], rtol=1e-12, atol=0) and len(exp["idx"]) > 0
+
+
+def test_test_subsets(ctx):
+    eng, orc, p = ctx["eng"], ctx["orc"], ctx["p"]
+    nb = orc.level0(alpha=0.01, n_obs_min=20)
+    rng = np.random.default_rng(5)
+    T, C, A = [], [], []
+    for _ in range(150):
+        a = int(rng.integers(0, 14))
+        v = rng.choice(p, size=a + 2, replace=False)
+        T.append(int(v[0])); C.append(int(v[1])); A.append([int(t) for t in v[2:]])
+    for t in range(p):
+        nbr = [int(u) for u in nb["idx"][nb["off"][t]:nb["off"][t + 1]]]
+        if len(nbr) >= 4:
+            T.append(t); C.append(nbr[0]); A.append(nbr[1:12])
+    got = eng.test_subsets_batch(T, C, A)
+    kinds = set()
+    for t, c, a, g in zip(T, C, A, got):
+        e = orc.test_subsets(t, c, a, max_k=3, alpha=0.01, n_obs_min=20)
+        assert g["status"] == e["status"] and g["num_tests"] == e["num_tests"], (t, c, a, g, e)
+        if e["status"] == 0:
+            continue
+        assert g["Zs"] == e["Zs"] and _same(g["stat"], e["stat"]) and g["suff_power"] == e["suff_power"], (g, e)
+        assert _same(g["pval"], e["pval"]) or rel(g["pval"], e["pval"]) < 1e-12
+        kinds.add((e["status"], e["num_tests"] == 0))
+    assert (1, True) in kinds and (1, False) in kinds  # "too few common rows" and ordinary rejections both occur
+
+
+@pytest.mark.parametrize("ff,R", [(False, 0), (True, 1), (True, 16)])
+def test_network_matches_oracle(ctx, ff, R):
+    data, n, p, orc = ctx["data"], ctx["n"], ctx["p"], ctx["orc"]
+    eng = fw.Engine("fz_nz", n, p, max_k=3)
+    eng.set_data(data)
+    got = eng.lgl(feed_forward=ff, round_size=R)
+    exp = orc.learn(max_k=3, feed_forward=ff, round_size=max(R, 1) if ff else 1)
+    assert set(got["edges"]) == set(exp["edges"]) and len(exp["edges"]) > 0
+    for e, w in exp["edges"].items():
+        assert got["edges"][e] == w
+    assert eng.counters()["cond_tests_ref"] == exp["n_cond_tests"]
+    eng.close()
+
+
+@pytest.mark.parametrize("max_k", [0, 3])
+def test_golden_networks_fz_nz(max_k):
+    # reference test/learning.jl:176-237: exp_fz_nz_maxk{0,3}.edgelist (prec = 64).  The device takes the Float32 matrix
+    # (the reference's default prec = 32): weights agree to Float32-input precision.
+    raw = np.loadtxt(GOLDEN + "/HMP_SRA_gut_small.tsv", delimiter="\t", skiprows=1, usecols=range(1, 51))
+    data, _, _ = pre.normalize(raw, "fz_nz", prec=32)
+    exp = read_edgelist("%s/learning_expected/exp_fz_nz_maxk%d.edgelist" % (GOLDEN, max_k))
+    eng = fw.Engine("fz_nz", data.shape[0], data.shape[1], max_k=max_k)
+    eng.set_data(data)
+    got = eng.lgl(feed_forward=True, round_size=1)["edges"]
+    assert set(got) == set(exp)
+    for e in exp:
+        assert abs(got[e] - exp[e]) <= 2e-5
+    eng.close()

@@ -166,3 +166,40 @@ def test_dense_equals_sparse_mi_nz_low_k(mats):
         assert set(a) == set(b)
         for e in a:
             assert abs(a[e] - b[e]) < 1e-12
+
+
+# ---- HE-S ("fz_nz") ---------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def clr_nz64():
+    from flashweave_jl_amd import preprocess as pre
+    raw = np.loadtxt(GOLDEN + "/HMP_SRA_gut_small.tsv", delimiter="\t", skiprows=1, usecols=range(1, 51))
+    data, _, _ = pre.normalize(raw, "fz_nz", prec=64)
+    fx = load_norm("clr_nonzero", np.float64)  # printed as Float32
+    assert data.shape == fx.shape and np.abs(data - fx).max() < 1e-6
+    return data
+
+
+def test_fz_nz_tests_expected(clr_nz64):
+    o = O.Oracle("fz_nz", data=clr_nz64)
+    for Y in range(1, 50):  # sub_data = rows with X != 0; the test removes the rows with Y == 0 (tests.jl:127-131)
+        s, p, df, pw = o.test(0, Y, (), n_obs_min=0)
+        es, ep, edf, epw = EXP["exp_uni_fz_nz"][Y - 1]
+        assert (df, pw) == (edf, epw)
+        assert rel(s, es) < 1e-12 and rel(p, ep) < 1e-12
+    # conditional rows: the convenience wrapper uses a Float64 cor_mat of the row view (tests.jl:269-276)
+    sub = clr_nz64[(clr_nz64[:, 30] != 0) & (clr_nz64[:, 20] != 0)]
+    of = O.Oracle("fz", cor_mat=O.cor(sub, "f64"), n_obs=sub.shape[0])
+    for key, Zs in (("condZ1", (6,)), ("condZ3", (6, 13, 17))):
+        s, p, df, pw = of.test(30, 20, Zs)
+        es, ep, edf, epw = EXP["exp_%s_fz_nz" % key][0]
+        assert (df, pw) == (edf, epw) and abs(s - es) < 1e-4 and rel(p, ep) < 1e-3
+
+
+@pytest.mark.parametrize("max_k", [0, 3])
+def test_fz_nz_golden_networks(clr_nz64, max_k):
+    exp = read_edgelist("%s/learning_expected/exp_fz_nz_maxk%d.edgelist" % (GOLDEN, max_k))
+    o = O.Oracle("fz_nz", data=clr_nz64)
+    got = o.learn(max_k=max_k, feed_forward=True, round_size=1)["edges"]
+    assert set(got) == set(exp) and len(exp) in (9, 10)
+    for e in exp:
+        assert abs(got[e] - exp[e]) <= 1e-12
