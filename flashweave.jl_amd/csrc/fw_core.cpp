@@ -507,6 +507,21 @@ static void unrank_host(uint64_t r, int a, int max_k, int *s_out, int *pos)
     }
 }
 
+// geometric growth of the evaluation window of a job (speculation bound vs number of latency-bound rounds);
+// FW_WINDOW_GROWTH is a tuning knob for profiling runs
+static uint64_t fw_window_growth(size_t n_live)
+{
+    static const long forced = [] {
+        const char *e = getenv("FW_WINDOW_GROWTH");
+        long v = e ? atol(e) : 0;
+        return (v >= 2 && v <= 64) ? v : 0l;
+    }();
+    if (forced) return (uint64_t)forced;
+    // many jobs in flight: launches are full, keep speculation tight (x4); few jobs: the round latency dominates
+    // and a wider window (x16) saves rounds (measured on cfg3: 3236 -> 2024 launches for +9 % evaluated tests)
+    return n_live > 2048 ? 4 : 16;
+}
+
 static void no_power_result(const fw_ctx *c, const int32_t *acc, int a, FwJobOut &o)
 {
     // tests.jl:254-262: every test lacks power -> the first one is returned (0, 1, 0, false)
@@ -726,11 +741,12 @@ int fwi_pool_collect(fw_ctx *c, FwPool &pool, std::vector<FwPoolJob> &finished)
         }
     }
     size_t w = 0;
+    const uint64_t growth = fw_window_growth(pool.live.size());
     for (size_t ji = 0; ji < pool.live.size(); ++ji) {
         FwPoolJob &j = pool.live[ji];
         if (!j.done && j.launched) {
             j.next += std::min(j.width, j.N - j.next);
-            j.width *= 4;
+            j.width *= growth;
             if (j.next >= j.N) {
                 j.out.stat = j.best_stat;
                 j.out.pval = j.best_p < 0.0 ? 0.0 : j.best_p;
