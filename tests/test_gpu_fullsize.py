@@ -1,0 +1,70 @@
+"""BASELINE.json's metric configuration at FULL size (cfg3: fwsynth-v1 10 000 OTUs x 2 000 samples, FlashWeave-S,
+max_k = 3): the oracle cannot finish the whole job in seconds, so parity is checked through size-independent
+properties plus an exact comparison on the part of the schedule the oracle does finish quickly."""
+import numpy as np
+import pytest
+
+import flashweave_jl_amd as fw
+from flashweave_jl_amd import preprocess as pre
+from flashweave_jl_amd import synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cfg3_full_size():
+    c = synth.CONFIGS["cfg3"]
+    counts = synth.generate(c["p"], c["n"], c["seed"], mode=c["mode"])
+    assert synth.checksum(counts) == "5b7a8f4cf3a47d7a64a2f798ca9e52c3281be3b4854002e0388960b9a2794dbd"
+    data, _, _ = pre.normalize(counts, "fz", prec=32)
+    n, p = data.shape
+    eng = fw.Engine("fz", n, p, max_k=3)
+    eng.set_data(data)
+    cm = eng.cor()
+    # Pearson matrix: exactly symmetric, unit diagonal, bounded; agrees with a Float64 reference on a random sample
+    assert (cm == cm.T).all() and (np.diag(cm) == 1.0).all() and np.abs(cm).max() <= 1.0
+    rng = np.random.default_rng(0)
+    ii, jj = rng.integers(0, p, 2000), rng.integers(0, p, 2000)
+    d64 = data.astype(np.float64)
+    dc = d64 - d64.mean(axis=0)
+    ref = (dc[:, ii] * dc[:, jj]).sum(axis=0) / np.sqrt((dc[:, ii] ** 2).sum(axis=0) * (dc[:, jj] ** 2).sum(axis=0))
+    off = ii != jj
+    assert np.abs(cm[ii, jj][off] - ref[off]).max() <= 5e-6
+    # level 0 equals the oracle on the device's matrix (neighbour sets and statistics exact)
+    got0 = eng.pw_univar_neighbors()
+    orc = O.Oracle("fz", cor_mat=cm, n_obs=n)
+    exp0 = orc.level0(alpha=0.01, n_obs_min=20)
+    assert (got0["off"] == exp0["off"]).all() and (got0["idx"] == exp0["idx"]).all() and (got0["stat"] == exp0["stat"]).all()
+    # full network; idempotent; edges are a subset of the level-0 pairs; weights are correlations
+    r1 = eng.lgl(feed_forward=False)
+    c1 = eng.counters()
+    eng.reset_counters()
+    r2 = eng.lgl(feed_forward=False)
+    assert r1["edges"] == r2["edges"] and c1["cond_tests_ref"] == eng.counters()["cond_tests_ref"]
+    assert c1["cond_tests_evaluated"] >= c1["cond_tests_ref"] > 10**9
+    pairs = set()
+    for v in range(p):
+        for u in got0["idx"][got0["off"][v]:got0["off"][v + 1]]:
+            pairs.add((min(v, int(u)), max(v, int(u))))
+    assert set(r1["edges"]) <= pairs and all(abs(w) <= 1.0 for w in r1["edges"].values())
+    # exact comparison with the oracle on the first 6 000 targets of the schedule (ascending univariate degree)
+    exp = orc.learn(max_k=3, feed_forward=False, max_targets=6000)
+    off, idx, w = r1["pc_off"], r1["pc_idx"], r1["pc_weight"]
+    eoff, eidx, ew = exp["pc_off"], exp["pc_idx"], exp["pc_weight"]
+    deg = np.diff(got0["off"])
+    order = np.argsort(deg, kind="stable")[:6000]
+    nchk = ndiff = 0
+    for T in order:
+        a, b = list(idx[off[T]:off[T + 1]]), list(eidx[eoff[T]:eoff[T + 1]])
+        wa, wb = list(w[off[T]:off[T + 1]]), list(ew[eoff[T]:eoff[T + 1]])
+        assert sorted(a) == sorted(b)                      # neighbour SETS: always identical
+        if a != b or wa != wb:
+            # Level-0 p-values at the very bottom of the subnormal range (~1e-323) differ by one unit of the subnormal
+            # grid between device and host erfc (e.g. 0 vs 9.9e-324); two candidates with such p-values can then swap
+            # their order, which changes the conditioning order and the weights at the 1e-5 level.
+            ndiff += 1
+            da, db = dict(zip(a, wa)), dict(zip(b, wb))
+            assert all(abs(da[k] - db[k]) < 1e-4 for k in da)
+        nchk += len(b)
+    assert nchk > 1000 and ndiff <= 6                       # observed: 2 of 6 000 targets
+    eng.close()
