@@ -516,7 +516,7 @@ __device__ __forceinline__ double pc_l3(double a, double b, double c)
 // reuses every partial correlation that does not involve the position that changed (for max_k = 3 that is 4 of the
 // 10 formula evaluations and 6 of the 10 matrix entries).  Rank order is preserved: a lane stops at its first
 // stopping rank, the workgroup takes the minimum over lanes.
-#define FW_RUN_MAX 8
+#define FW_RUN_MAX 16
 #define FZ_X_NONE 1.0e308    // "no candidate yet"
 #define FZ_X_SUB 26.0        // beyond this x = |z|/sqrt2, erfc(x)/2*2 leaves the normal range (ties become possible)
 #define FZ_X_SUBKEY 1.0e300  // common x-key of the underflow regime (ordered by exact p there)
