@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--round-size", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for debugging)")
+    ap.add_argument("--single-device", action="store_true", help="debug: every rank uses GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -65,11 +67,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.single_device:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collective payloads live
 
     import flashweave_jl_amd as fw
     from flashweave_jl_amd.dist import make_allgather
@@ -78,7 +86,7 @@ def main():
     n, p = data.shape
     eng = fw.Engine(cfg["test_name"], n, p, max_k=cfg["max_k"], device=local_rank)
     eng.set_data(data)  # host -> HBM once, outside the timed region
-    cb = make_allgather(dist, dev) if world > 1 else None
+    cb = make_allgather(dist, cdev) if world > 1 else None
 
     def barrier():
         if world > 1:
@@ -102,7 +110,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     cn = eng.counters()
@@ -110,7 +118,7 @@ def main():
     cond_ref = cn["cond_tests_ref"]
     cond_eval = cn["cond_tests_evaluated"]
     if world > 1:
-        tt = torch.tensor([cond_ref, cond_eval], dtype=torch.float64, device=dev)
+        tt = torch.tensor([cond_ref, cond_eval], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         cond_ref, cond_eval = int(tt[0].item()), int(tt[1].item())
     steps = max(args.steps, 1)
