@@ -139,7 +139,7 @@ def main():
             # HBM-side bytes per launch of the same kernel on the same workload, from a separate rocprofv3 --pmc pass
             # (PMC counters cannot be collected from inside this process); see profiles/README.md
             traffic = json.load(open(pmc_path))["fz_subsets_seg_kernel"]["fetch_bytes_per_launch"]
-            traffic_src = "profiles/r01_cfg3_fz_pmc_summary.json (FETCH_SIZE, 4-byte gathers, width-uncorrected)"
+            traffic_src = "profiles/r01_cfg3_fz_pmc_summary.json (FETCH_SIZE + WRITE_SIZE per launch; 4-byte gathers, width-uncorrected)"
         roofline = {"bound": "hbm", "kernel": "fz_subsets_seg_kernel" if cfg["test_name"] == "fz" else "mi_subsets_seg_kernel",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": traffic_src,
