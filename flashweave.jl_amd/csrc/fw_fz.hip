@@ -190,14 +190,35 @@ __device__ __forceinline__ double fz_pval_dev(double r, double zscale /* sqrt(n-
     return cc * 2.0;
 }
 
+// round(x, digits = 5) = rint(x * 1e5) / 1e5 in the value's own type.  The division of the integer n = rint(x * 1e5)
+// by 1e5 is done as q0 = n * c, r = fma(-q0, 1e5, n), q = fma(r, c, q0) with c = RN(1e-5): this is the correctly
+// rounded quotient for every integer |n| <= 400000 in both Float32 and Float64 -- verified exhaustively on the host
+// (tests/test_oracle_golden.py::test_fast_division_by_1e5_is_exact) -- and costs 3 instructions instead of an IEEE
+// division sequence.  Larger |n| (|x| > 4, impossible for correlations) and NaN take the plain division.
 __device__ __forceinline__ float round5_f32(float x)
 {
-    float y = rintf(x * 100000.0f) / 100000.0f;
+    const float n = rintf(x * 100000.0f);
+    float y;
+    if (fabsf(n) <= 400000.0f) {
+        const float q0 = n * 1e-5f;
+        const float r = fmaf(-q0, 100000.0f, n);
+        y = fmaf(r, 1e-5f, q0);
+    } else {
+        y = n / 100000.0f;
+    }
     return isfinite(y) ? y : x;
 }
 __device__ __forceinline__ double round5_f64(double x)
 {
-    double y = rint(x * 100000.0) / 100000.0;
+    const double n = rint(x * 100000.0);
+    double y;
+    if (fabs(n) <= 400000.0) {
+        const double q0 = n * 1e-5;
+        const double r = fma(-q0, 100000.0, n);
+        y = fma(r, 1e-5, q0);
+    } else {
+        y = n / 100000.0;
+    }
     return isfinite(y) ? y : x;
 }
 
@@ -466,8 +487,9 @@ __device__ __forceinline__ TV pc_l1(float xy, float xz, float yz)
     return r;
 }
 
-// statfuns.jl:44-62, children from level 1 (Float32 unless they were replaced by a Float64 literal)
-__device__ __forceinline__ double pc_l2(TV a, TV b, TV c)
+// statfuns.jl:44-62, children from level 1 (Float32 unless they were replaced by a Float64 literal).
+// d2c = sqrt(1 - c^2) in Float64 (statfuns.jl:52, `^2.0`) is passed in so that callers can share it.
+__device__ __forceinline__ double pc_l2_d2(TV a, TV b, TV c, double d2c)
 {
     double prod, ev, d1;
     bool p32;
@@ -488,8 +510,7 @@ __device__ __forceinline__ double pc_l2(TV a, TV b, TV c)
     } else {
         d1 = sqrt(1.0 - b.v * b.v);
     }
-    const double d2 = sqrt(1.0 - c.v * c.v);
-    const double denom = d1 * d2;
+    const double denom = d1 * d2c;
     double v = (denom == 0.0) ? 0.0 : ev / denom;
     if (v < -1.0)
         v = -1.0;
@@ -497,6 +518,7 @@ __device__ __forceinline__ double pc_l2(TV a, TV b, TV c)
         v = 1.0;
     return v;
 }
+__device__ __forceinline__ double pc_l2(TV a, TV b, TV c) { return pc_l2_d2(a, b, c, sqrt(1.0 - c.v * c.v)); }
 
 // statfuns.jl:44-62, all-Float64 children (level >= 3)
 __device__ __forceinline__ double pc_l3(double a, double b, double c)
@@ -687,8 +709,9 @@ __global__ __launch_bounds__(256) void fz_subsets_seg_kernel(const float *__rest
                     const TV D1 = pc_l1(cXz3, cXz1, cz3z1);
                     const TV E1 = pc_l1(cYz3, cYz1, cz3z1);
                     const TV F1 = pc_l1(cz3z2, cz3z1, cz2z1);
-                    const double D2 = pc_l2(D1, B1, F1);
-                    const double E2 = pc_l2(E1, C1, F1);
+                    const double dF = sqrt(1.0 - F1.v * F1.v);  // shared by the two level-2 values below
+                    const double D2 = pc_l2_d2(D1, B1, F1, dF);
+                    const double E2 = pc_l2_d2(E1, C1, F1, dF);
                     stat = pc_l3(A2, D2, E2);
                 } else if (s == 2) {
                     if (chg <= 0) {

@@ -1880,3 +1880,22 @@ void fwo_cor(const double *data, int n, int p, float *out32, double *out64)
     free(xc);
     free(sd);
 }
+
+/* Numerical identity used by the device kernels (csrc/fw_fz.hip round5_*): for every integer |n| <= limit,
+ * q0 = n*c, r = fma(-q0, 1e5, n), q = fma(r, c, q0) with c = RN(1e-5) equals the correctly rounded n / 1e5,
+ * in Float32 and in Float64.  Returns the number of counter-examples (expected 0). */
+int64_t fwo_check_fast_div1e5(int64_t limit)
+{
+    int64_t bad = 0;
+    const float c32 = 1e-5f;
+    const double c64 = 1e-5;
+    for (int64_t n = -limit; n <= limit; ++n) {
+        const float fn = (float)n;
+        const float q0 = fn * c32, r = fmaf(-q0, 100000.0f, fn), q1 = fmaf(r, c32, q0);
+        if (q1 != fn / 100000.0f) ++bad;
+        const double dn = (double)n;
+        const double p0 = dn * c64, rr = fma(-p0, 100000.0, dn), p1 = fma(rr, c64, p0);
+        if (p1 != dn / 100000.0) ++bad;
+    }
+    return bad;
+}

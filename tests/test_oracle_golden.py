@@ -203,3 +203,13 @@ def test_fz_nz_golden_networks(clr_nz64, max_k):
     assert set(got) == set(exp) and len(exp) in (9, 10)
     for e in exp:
         assert abs(got[e] - exp[e]) <= 1e-12
+
+
+def test_fast_division_by_1e5_is_exact():
+    # the device evaluates round(x, digits=5) with an FMA-based division by 1e5 (csrc/fw_fz.hip round5_f32/_f64);
+    # exhaustive check of the identity over every integer the kernels can meet (|n| <= 400 000)
+    import ctypes
+    L = O.lib()
+    L.fwo_check_fast_div1e5.restype = ctypes.c_int64
+    L.fwo_check_fast_div1e5.argtypes = [ctypes.c_int64]
+    assert L.fwo_check_fast_div1e5(400000) == 0
