@@ -9,3 +9,4 @@ There is no CPU fallback: creating an Engine without a gfx950 device raises Flas
 """
 from .engine import (FW_FZ, FW_FZ_NZ, FW_MI, FW_MI_NZ, Engine, FlashWeaveError, TestResult, lib_path, load_library)  # noqa: F401
 from .build import build_library  # noqa: F401
+from .api import FWResult, learn_network  # noqa: F401,E402

@@ -1,0 +1,47 @@
+"""`learn_network`: the reference's user entry point (src/learning.jl:466-598) for the modes this engine covers, as a thin
+composition of the normalisation front-end, the device engine and the host driver.  Keyword names and defaults
+follow the reference; unsupported options raise instead of being silently ignored."""
+import numpy as np
+
+from . import io as fio
+from . import preprocess as pre
+from .engine import Engine
+
+
+class FWResult(dict):
+    """Edge list + bookkeeping (the reference's FWResult, src/types.jl:172-200, reduced to plain data)."""
+
+    def save(self, path):
+        fio.write_edgelist(path, self["edges"], self["variable_ids"], self["meta_variable_mask"])
+
+
+def learn_network(data, sensitive=True, heterogeneous=False, max_k=3, alpha=0.01, feed_forward=True, normalize=True,
+                  header=None, hps=5, FDR=True, n_obs_min=-1, max_tests=10_000_000, prec=32, round_size=1, device=0,
+                  **unsupported):
+    """data: samples x OTUs count matrix (or an already normalised matrix with normalize=False).
+    round_size: targets per feed-forward round; 1 = the reference's deterministic `single_il` schedule."""
+    if unsupported:
+        raise TypeError("learn_network: unsupported options %s (see DESIGN.md section 7)" % sorted(unsupported))
+    test_name = ("fz" if sensitive else "mi") + ("_nz" if heterogeneous else "")  # src/learning.jl:480-483
+    data = np.asarray(data)
+    if header is None:
+        header = ["X%d" % (i + 1) for i in range(data.shape[1])]
+    if normalize:
+        mat, row_mask, col_mask = pre.normalize(data, test_name, prec=prec)
+        header = [h for h, k in zip(header, col_mask) if k]
+    else:
+        mat = data
+    n, p = mat.shape
+    eng = Engine(test_name, n, p, max_k=max_k, alpha=alpha, hps=hps, n_obs_min=n_obs_min, max_tests=max_tests, FDR=FDR,
+                 device=device)
+    try:
+        eng.set_data(mat)
+        if test_name == "fz":
+            eng.compute_cor()
+        net = eng.lgl(feed_forward=feed_forward, round_size=round_size)
+        counters = eng.counters()
+    finally:
+        eng.close()
+    return FWResult(edges=net["edges"], variable_ids=header, meta_variable_mask=[False] * len(header),
+                    parameters=dict(sensitive=sensitive, heterogeneous=heterogeneous, max_k=max_k, alpha=alpha,
+                                    feed_forward=feed_forward, test_name=test_name), counters=counters)

@@ -520,6 +520,20 @@ __device__ __forceinline__ double pc_l2_d2(TV a, TV b, TV c, double d2c)
 }
 __device__ __forceinline__ double pc_l2(TV a, TV b, TV c) { return pc_l2_d2(a, b, c, sqrt(1.0 - c.v * c.v)); }
 
+// pc_l2_d2 specialised for the overwhelmingly common case that all three children are Float32 values (no Float64
+// literal 0 / +-1 among them): identical arithmetic, no per-flag branches.
+__device__ __forceinline__ double pc_l2_all32(float a, float b, float c, double d2c)
+{
+    const float prod = b * c;
+    const double ev = (double)round5_f32(a - prod);
+    const float bb = b * b;
+    const double d1 = (double)sqrtf(1.0f - bb);
+    const double denom = d1 * d2c;
+    double v = (denom == 0.0) ? 0.0 : ev / denom;
+    v = v < -1.0 ? -1.0 : (v >= 1.0 ? 1.0 : v);
+    return v;
+}
+
 // statfuns.jl:44-62, all-Float64 children (level >= 3)
 __device__ __forceinline__ double pc_l3(double a, double b, double c)
 {
@@ -584,7 +598,7 @@ __global__ void fz_thresholds_kernel(double alpha, double zscale, double *thr)
 }
 
 template <bool HIGHK, bool LOCAL>  // HIGHK: subsets of size 4-5 possible; LOCAL: per-job matrices (fz_nz)
-__global__ __launch_bounds__(256) void fz_subsets_seg_kernel(const float *__restrict__ cor_g, int p_g,
+__global__ __launch_bounds__(256, 3) void fz_subsets_seg_kernel(const float *__restrict__ cor_g, int p_g,
                                                              const FwSeg *__restrict__ segs,
                                                              const int32_t *__restrict__ accflat,
                                                              FwSegOut *__restrict__ out, int max_k, double alpha,
@@ -710,8 +724,14 @@ __global__ __launch_bounds__(256) void fz_subsets_seg_kernel(const float *__rest
                     const TV E1 = pc_l1(cYz3, cYz1, cz3z1);
                     const TV F1 = pc_l1(cz3z2, cz3z1, cz2z1);
                     const double dF = sqrt(1.0 - F1.v * F1.v);  // shared by the two level-2 values below
-                    const double D2 = pc_l2_d2(D1, B1, F1, dF);
-                    const double E2 = pc_l2_d2(E1, C1, F1, dF);
+                    double D2, E2;
+                    if (__all(D1.f32 && E1.f32 && F1.f32 && B1.f32 && C1.f32)) {  // wave-uniform fast path
+                        D2 = pc_l2_all32((float)D1.v, (float)B1.v, (float)F1.v, dF);
+                        E2 = pc_l2_all32((float)E1.v, (float)C1.v, (float)F1.v, dF);
+                    } else {
+                        D2 = pc_l2_d2(D1, B1, F1, dF);
+                        E2 = pc_l2_d2(E1, C1, F1, dF);
+                    }
                     stat = pc_l3(A2, D2, E2);
                 } else if (s == 2) {
                     if (chg <= 0) {

@@ -260,3 +260,20 @@ def test_full_size_properties():
             checked += 1
     assert checked > 0
     eng.close()
+
+
+def test_learn_network_api_reproduces_all_golden_networks(tmp_path):
+    # the reference's entry point on the bundled table (BASELINE config 1): all four modes x max_k in {0, 3}
+    from flashweave_jl_amd import io as fio
+    raw, header, _ = fio.read_table(GOLDEN + "/HMP_SRA_gut_small.tsv")
+    for sensitive, het, name, wtol in ((True, False, "fz", 5e-5), (True, True, "fz_nz", 2e-5),
+                                       (False, False, "mi", 1e-13), (False, True, "mi_nz", 1e-13)):
+        for max_k in (0, 3):
+            net = fw.learn_network(raw, sensitive=sensitive, heterogeneous=het, max_k=max_k)
+            exp = read_edgelist("%s/learning_expected/exp_%s_maxk%d.edgelist" % (GOLDEN, name, max_k))
+            assert set(net["edges"]) == set(exp), (name, max_k)
+            assert all(abs(net["edges"][e] - exp[e]) <= wtol for e in exp)
+    out = tmp_path / "net.edgelist"
+    net.save(str(out))
+    back, hdr, _ = fio.read_edgelist(str(out))
+    assert back == net["edges"] and len(hdr) == 50
