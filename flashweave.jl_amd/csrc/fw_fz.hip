@@ -80,8 +80,10 @@ __device__ __forceinline__ void tri_decode(int b, int T, int &bi, int &bj)
 __global__ __launch_bounds__(256) void fz_cor_gemm_kernel(const float *__restrict__ xc, const float *__restrict__ sd,
                                                           float *__restrict__ cor, int p, int n_pad, int T)
 {
-    __shared__ __attribute__((aligned(16))) float sA[GEMM_BM * GEMM_LD];
-    __shared__ __attribute__((aligned(16))) float sB[GEMM_BM * GEMM_LD];
+    // two LDS stages (73.7 KB): while a tile is being multiplied, the next one is already in registers and is written
+    // to the other stage right after the MFMA block -- one barrier per k-tile
+    __shared__ __attribute__((aligned(16))) float sA[2][GEMM_BM * GEMM_LD];
+    __shared__ __attribute__((aligned(16))) float sB[2][GEMM_BM * GEMM_LD];
     int bi, bj;
     tri_decode(blockIdx.x, T, bi, bj);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -102,47 +104,72 @@ __global__ __launch_bounds__(256) void fz_cor_gemm_kernel(const float *__restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    float4 ra[4], rb[4];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int col = ld_col + 32 * s;
-            ra[s] = *reinterpret_cast<const float4 *>(gA + (size_t)col * n_pad + k0 + ld_k4 * 4);
-            rb[s] = *reinterpret_cast<const float4 *>(gB + (size_t)col * n_pad + k0 + ld_k4 * 4);
-        }
-    };
-    auto sstore = [&]() {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int col = ld_col + 32 * s;
-            *reinterpret_cast<float4 *>(&sA[col * GEMM_LD + ld_k4 * 4]) = ra[s];
-            *reinterpret_cast<float4 *>(&sB[col * GEMM_LD + ld_k4 * 4]) = rb[s];
-        }
-    };
+    // Staging registers as eight named float4 values: indexing an array from inside a lambda made the compiler keep
+    // them in scratch memory (scratch_store/scratch_load around every prefetch, visible in the r01 ISA) and turned the
+    // prefetch into a synchronous load.
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    const float *pA = gA + (size_t)ld_col * n_pad + ld_k4 * 4, *pB = gB + (size_t)ld_col * n_pad + ld_k4 * 4;
+    const size_t cstep = (size_t)32 * n_pad;
+#define GEMM_GLOAD(k0)                                                     \
+    do {                                                                   \
+        ra0 = *reinterpret_cast<const float4 *>(pA + (k0));                \
+        ra1 = *reinterpret_cast<const float4 *>(pA + cstep + (k0));        \
+        ra2 = *reinterpret_cast<const float4 *>(pA + 2 * cstep + (k0));    \
+        ra3 = *reinterpret_cast<const float4 *>(pA + 3 * cstep + (k0));    \
+        rb0 = *reinterpret_cast<const float4 *>(pB + (k0));                \
+        rb1 = *reinterpret_cast<const float4 *>(pB + cstep + (k0));        \
+        rb2 = *reinterpret_cast<const float4 *>(pB + 2 * cstep + (k0));    \
+        rb3 = *reinterpret_cast<const float4 *>(pB + 3 * cstep + (k0));    \
+    } while (0)
+#define GEMM_SSTORE(st)                                                                              \
+    do {                                                                                             \
+        float *wa = &sA[st][ld_col * GEMM_LD + ld_k4 * 4], *wb = &sB[st][ld_col * GEMM_LD + ld_k4 * 4]; \
+        *reinterpret_cast<float4 *>(wa) = ra0;                                                       \
+        *reinterpret_cast<float4 *>(wa + 32 * GEMM_LD) = ra1;                                        \
+        *reinterpret_cast<float4 *>(wa + 64 * GEMM_LD) = ra2;                                        \
+        *reinterpret_cast<float4 *>(wa + 96 * GEMM_LD) = ra3;                                        \
+        *reinterpret_cast<float4 *>(wb) = rb0;                                                       \
+        *reinterpret_cast<float4 *>(wb + 32 * GEMM_LD) = rb1;                                        \
+        *reinterpret_cast<float4 *>(wb + 64 * GEMM_LD) = rb2;                                        \
+        *reinterpret_cast<float4 *>(wb + 96 * GEMM_LD) = rb3;                                        \
+    } while (0)
 
-    gload(0);
-    for (int k0 = 0; k0 < n_pad; k0 += GEMM_BK) {
-        __syncthreads();  // previous tile fully consumed
-        sstore();
-        __syncthreads();
-        if (k0 + GEMM_BK < n_pad) gload(k0 + GEMM_BK);  // prefetch next tile into registers
+    GEMM_GLOAD(0);
+    GEMM_SSTORE(0);
+    __syncthreads();
+    int st = 0;
+    for (int k0 = 0; k0 < n_pad; k0 += GEMM_BK, st ^= 1) {
+        const bool more = k0 + GEMM_BK < n_pad;
+        if (more) GEMM_GLOAD(k0 + GEMM_BK);  // next tile -> registers (latency hidden behind the MFMA block)
+        const float *cA = sA[st], *cB = sB[st];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 a0 = *reinterpret_cast<const float4 *>(&sA[(wm * 64 + lm) * GEMM_LD + lh * 16 + q * 4]);
-            float4 a1 = *reinterpret_cast<const float4 *>(&sA[(wm * 64 + 32 + lm) * GEMM_LD + lh * 16 + q * 4]);
-            float4 b0 = *reinterpret_cast<const float4 *>(&sB[(wn * 64 + lm) * GEMM_LD + lh * 16 + q * 4]);
-            float4 b1 = *reinterpret_cast<const float4 *>(&sB[(wn * 64 + 32 + lm) * GEMM_LD + lh * 16 + q * 4]);
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv0[e], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv1[e], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv0[e], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv1[e], acc[1][1], 0, 0, 0);
-            }
+            float4 a0 = *reinterpret_cast<const float4 *>(&cA[(wm * 64 + lm) * GEMM_LD + lh * 16 + q * 4]);
+            float4 a1 = *reinterpret_cast<const float4 *>(&cA[(wm * 64 + 32 + lm) * GEMM_LD + lh * 16 + q * 4]);
+            float4 b0 = *reinterpret_cast<const float4 *>(&cB[(wn * 64 + lm) * GEMM_LD + lh * 16 + q * 4]);
+            float4 b1 = *reinterpret_cast<const float4 *>(&cB[(wn * 64 + 32 + lm) * GEMM_LD + lh * 16 + q * 4]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b1.z, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b1.w, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc[1][1], 0, 0, 0);
         }
+        if (more) GEMM_SSTORE(st ^ 1);  // the other stage was last read before the previous barrier
+        __syncthreads();
     }
+#undef GEMM_GLOAD
+#undef GEMM_SSTORE
     // epilogue: cov2cor! (C[i,j] / (xsd[i] * xsd[j]), clampcor, unit diagonal), write (i,j) and the mirror (j,i)
     const bool vec_ok = (p & 3) == 0;
 #pragma unroll
