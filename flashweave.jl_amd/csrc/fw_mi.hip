@@ -613,7 +613,7 @@ __device__ __forceinline__ void mi_pair_epilogue(const MiDev &P, int X, int Y, i
                 pval = 1.0;  // any value >= alpha: never looked at again
         }
     }
-    if (unreliable) atomicAdd(&cnt->n_unreliable, 1ull);
+    // (unreliable pairs were already counted by the screening kernel)
     if (!unreliable && pval < alpha) {
         const unsigned long long slot = atomicAdd(&cnt->n_sig, 1ull);
         if (slot < cap) {
@@ -625,15 +625,106 @@ __device__ __forceinline__ void mi_pair_epilogue(const MiDev &P, int X, int Y, i
     }
 }
 
+// ---- level-0 screening (kernel 1) -----------------------------------------------------------------------
+// Integer logic (reliability, df) is exact; the G statistic is evaluated in Float32 only to decide whether the pair
+// can possibly reach the alpha quantile.  |G32 - G| <= 2 * sum_c c * (2e-7 |log| + 1e-7) <= n * 4e-6, so a margin of
+// 0.5 + 1e-4 n below 0.99 * quantile is safe by more than an order of magnitude.  Candidates go to kernel 2, which
+// evaluates the statistic and the p-value in Float64 (mi_pair_epilogue).  Everything is unrolled over the 3 x 3
+// table so that nothing lives in scratch memory.
+struct MiCand {
+    int32_t X, Y, A, B, C, D;
+};
+
+// returns 1 if the pair is unreliable (no power / too few observations), else 0
+__device__ __forceinline__ int mi_pair_screen(const MiDev &P, int X, int Y, int A, int B, int C, int D,
+                                              const int32_t *__restrict__ cnt_nz, const int32_t *__restrict__ cnt_hi,
+                                              const double *gthr, MiL0Counters *cnt, unsigned long long cap_c,
+                                              MiCand *__restrict__ cands)
+{
+    const int L = P.L;
+    const int nzX = cnt_nz[X], nzY = cnt_nz[Y], hiX = cnt_hi[X], hiY = cnt_hi[Y];
+    int t00, t01, t02, t10, t11, t12, t20, t21, t22;
+    t22 = D;
+    t21 = B - D;
+    t12 = C - D;
+    t11 = A - B - C + D;
+    t20 = hiX - B;
+    t10 = (nzX - hiX) - (A - B);
+    t02 = hiY - C;
+    t01 = (nzY - hiY) - (A - C);
+    t00 = P.n - nzX - nzY + A;
+    const int vx = P.levels[X], vy = P.levels[Y];
+    const int ox = vx > 1 ? 2 : 1, oy = vy > 1 ? 2 : 1;
+    bool reliable = vx >= 2 && (long long)P.n >= P.n_obs_min &&
+                    (((double)P.n / (double)((long long)(vx - ox) * (vy - oy))) > (double)P.hps);
+    const bool flagX = P.nzmode && P.maxv[X] > 1, flagY = P.nzmode && P.maxv[Y] > 1;
+    const int sx = flagX ? 1 : 0, sy = flagY ? 1 : 0;
+    const int lx = P.nzmode ? L - sx : vx, ly = P.nzmode ? L - sy : vy;
+    const int tt[3][3] = {{t00, t01, t02}, {t10, t11, t12}, {t20, t21, t22}};
+    int n_obs = 0;
+    int mi_[3] = {0, 0, 0}, mj_[3] = {0, 0, 0};  // indexed by sub-table row / column
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const bool insub = i >= sx && j >= sy && i < L && j < L;
+            n_obs += insub ? tt[i][j] : 0;
+            const bool inlev = insub && (i - sx) < lx && (j - sy) < ly;
+            const int v = inlev ? tt[i][j] : 0;
+            // sub-table indices i - sx, j - sy in {0, 1, 2}; sx, sy in {0, 1}
+            if (sx == 0) mi_[i] += v; else if (i >= 1) mi_[i - 1] += v;
+            if (sy == 0) mj_[j] += v; else if (j >= 1) mj_[j - 1] += v;
+        }
+    reliable = reliable && (long long)n_obs >= P.n_obs_min && (((double)n_obs / (double)(lx * ly)) > (double)P.hps);
+    if (!reliable) return 1;  // counted per workgroup by the caller (one atomic per pair serialised the whole kernel)
+    int alx = (mi_[0] > 0) + (mi_[1] > 0) + (mi_[2] > 0), aly = (mj_[0] > 0) + (mj_[1] > 0) + (mj_[2] > 0);
+    alx = alx < 1 ? 1 : alx;
+    aly = aly < 1 ? 1 : aly;
+    const int df = (alx - 1) * (aly - 1);
+    if (df == 0) return 0;  // p = 1
+    float g = 0.0f;
+    const float fn = (float)n_obs;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const bool inlev = i >= sx && j >= sy && i < L && j < L && (i - sx) < lx && (j - sy) < ly;
+            const int c = inlev ? tt[i][j] : 0;
+            const int mi = sx == 0 ? mi_[i] : (i >= 1 ? mi_[i - 1] : 0), mj = sy == 0 ? mj_[j] : (j >= 1 ? mj_[j - 1] : 0);
+            if (c != 0 && mi != 0 && mj != 0) g += (float)c * logf((fn * (float)c) / ((float)mi * (float)mj));
+        }
+    const double g32 = 2.0 * fabs((double)g);
+    if (g32 < 0.99 * gthr[df] - (0.5 + 1e-4 * (double)P.n)) return 0;  // cannot reach the alpha quantile
+    const unsigned long long slot = atomicAdd(&cnt->n_sig, 1ull);  // n_sig doubles as the candidate counter in kernel 1
+    if (slot < cap_c) {
+        MiCand cd;
+        cd.X = X;
+        cd.Y = Y;
+        cd.A = A;
+        cd.B = B;
+        cd.C = C;
+        cd.D = D;
+        cands[slot] = cd;
+    }
+    return 0;
+}
+
+// kernel 2: exact Float64 statistic + p-value for the screened candidates, one thread each
+__global__ __launch_bounds__(256) void mi_level0_exact_kernel(MiDev P, const MiCand *__restrict__ cands, unsigned long long ncand,
+                                                              const int32_t *__restrict__ cnt_nz, const int32_t *__restrict__ cnt_hi,
+                                                              double alpha, const double *gthr, MiL0Counters *cnt,
+                                                              unsigned long long cap, int32_t *out_i, int32_t *out_j,
+                                                              double *out_s, double *out_p);
+
 template <bool HAS_HI>
 __global__ __launch_bounds__(256) void mi_level0_kernel(MiDev P, int p, int T, const int32_t *__restrict__ cnt_nz,
-                                                        const int32_t *__restrict__ cnt_hi, double alpha, const double *gthr,
-                                                        MiL0Counters *cnt, unsigned long long cap, int32_t *out_i,
-                                                        int32_t *out_j, double *out_s, double *out_p)
+                                                        const int32_t *__restrict__ cnt_hi, const double *gthr,
+                                                        MiL0Counters *cnt, unsigned long long cap_c, MiCand *__restrict__ cands)
 {
     __shared__ unsigned long long sXn[L0_T][L0_WC + 1], sYn[L0_T][L0_WC + 1];
     __shared__ unsigned long long sXh[HAS_HI ? L0_T : 1][L0_WC + 1], sYh[HAS_HI ? L0_T : 1][L0_WC + 1];
     __shared__ double s_gthr[8];
+    __shared__ int s_cnt[256 * 16];
     // triangular tile decode
     int b = blockIdx.x, bi = 0;
     while (b >= T - bi) {
@@ -662,7 +753,7 @@ __global__ __launch_bounds__(256) void mi_level0_kernel(MiDev P, int p, int T, c
             }
         }
         __syncthreads();
-#pragma unroll
+#pragma unroll 1  // unrolling this loop made the compiler hoist all 8 x 16 LDS reads: 256 VGPRs + scratch (r01 ISA)
         for (int w = 0; w < L0_WC; ++w) {
             unsigned long long xn[4], yn[4], xh[4], yh[4];
 #pragma unroll
@@ -688,15 +779,42 @@ __global__ __launch_bounds__(256) void mi_level0_kernel(MiDev P, int p, int T, c
         }
     }
     __syncthreads();
+    // The 64 counters of a thread are parked in LDS row by row so that the screening code can run in a rolled loop
+    // with a dynamic index: inlining it 16 times with the counters live cost 256 VGPRs + scratch (r01 ISA).
+    int *mine = s_cnt + tid * 16;
+    int n_unrel = 0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 4; ++u) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const int X = bi * L0_T + ty * 4 + u, Y = bj * L0_T + tx * 4 + v;
-            if (X < Y && Y < p)
-                mi_pair_epilogue(P, X, Y, A[u][v], B[u][v], C[u][v], D[u][v], cnt_nz, cnt_hi, alpha, s_gthr, cnt, cap, out_i,
-                                 out_j, out_s, out_p);
+            mine[v * 4 + 0] = A[u][v];
+            mine[v * 4 + 1] = B[u][v];
+            mine[v * 4 + 2] = C[u][v];
+            mine[v * 4 + 3] = D[u][v];
         }
+        const int X = bi * L0_T + ty * 4 + u;
+#pragma unroll 1
+        for (int v = 0; v < 4; ++v) {
+            const int Y = bj * L0_T + tx * 4 + v;
+            if (X < Y && Y < p)
+                n_unrel += mi_pair_screen(P, X, Y, mine[v * 4 + 0], mine[v * 4 + 1], mine[v * 4 + 2], mine[v * 4 + 3], cnt_nz, cnt_hi,
+                                          s_gthr, cnt, cap_c, cands);
+        }
+    }
+    n_unrel = wave_sum_i(n_unrel);
+    if ((tid & 63) == 0 && n_unrel) atomicAdd(&cnt->n_unreliable, (unsigned long long)n_unrel);
+}
+
+__global__ __launch_bounds__(256) void mi_level0_exact_kernel(MiDev P, const MiCand *__restrict__ cands, unsigned long long ncand,
+                                                              const int32_t *__restrict__ cnt_nz, const int32_t *__restrict__ cnt_hi,
+                                                              double alpha, const double *gthr, MiL0Counters *cnt,
+                                                              unsigned long long cap, int32_t *out_i, int32_t *out_j,
+                                                              double *out_s, double *out_p)
+{
+    const unsigned long long t = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ncand) return;
+    const MiCand c = cands[t];
+    mi_pair_epilogue(P, c.X, c.Y, c.A, c.B, c.C, c.D, cnt_nz, cnt_hi, alpha, gthr, cnt, cap, out_i, out_j, out_s, out_p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -846,49 +964,67 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
         gthr[df] = 0.999 * lo;
     }
     int rc;
-    unsigned long long cap = (unsigned long long)std::min<long long>(npairs, 4ll << 20);
-    if (cap == 0) cap = 1;
-    MiL0Counters h{};
     const int T = (p + L0_T - 1) / L0_T;
     const int nblk = T * (T + 1) / 2;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        if ((rc = fw_dev_reserve(ctx, ctx->d_tmp0, sizeof(MiL0Counters) + 8 * sizeof(double)))) return rc;
-        if ((rc = fw_dev_reserve(ctx, ctx->d_tmp1, cap * 2 * sizeof(int32_t)))) return rc;
-        if ((rc = fw_dev_reserve(ctx, ctx->d_tmp2, cap * 2 * sizeof(double)))) return rc;
-        FW_HIP(ctx, hipMemsetAsync(ctx->d_tmp0.ptr, 0, sizeof(MiL0Counters), ctx->stream));
-        double *d_gthr = (double *)((char *)ctx->d_tmp0.ptr + sizeof(MiL0Counters));
+    const MiDev P = mi_dev(ctx);
+    // ---- kernel 1: popcounts + exact reliability/df + Float32 screen -> candidate records ----
+    unsigned long long cap_c = (unsigned long long)std::min<long long>(npairs, 8ll << 20);
+    if (cap_c == 0) cap_c = 1;
+    MiL0Counters h1{};
+    double *d_gthr = nullptr;
+    for (int attempt = 0;; ++attempt) {
+        if ((rc = fw_dev_reserve(ctx, ctx->d_tmp0, 2 * sizeof(MiL0Counters) + 8 * sizeof(double)))) return rc;
+        if ((rc = fw_dev_reserve(ctx, ctx->d_jobs, cap_c * sizeof(MiCand)))) return rc;
+        FW_HIP(ctx, hipMemsetAsync(ctx->d_tmp0.ptr, 0, 2 * sizeof(MiL0Counters), ctx->stream));
+        d_gthr = (double *)((char *)ctx->d_tmp0.ptr + 2 * sizeof(MiL0Counters));
         FW_HIP(ctx, hipMemcpyAsync(d_gthr, gthr, sizeof(gthr), hipMemcpyHostToDevice, ctx->stream));
-        int32_t *oi = (int32_t *)ctx->d_tmp1.ptr, *oj = oi + cap;
-        double *os = (double *)ctx->d_tmp2.ptr, *op = os + cap;
-        const MiDev P = mi_dev(ctx);
         if (ctx->d_hibits)
             hipLaunchKernelGGL(mi_level0_kernel<true>, dim3(nblk), dim3(256), 0, ctx->stream, P, p, T, ctx->d_firstnz,
-                               ctx->d_firstnz + p, ctx->P.alpha, d_gthr, (MiL0Counters *)ctx->d_tmp0.ptr, cap, oi, oj, os, op);
+                               ctx->d_firstnz + p, d_gthr, (MiL0Counters *)ctx->d_tmp0.ptr, cap_c, (MiCand *)ctx->d_jobs.ptr);
         else
             hipLaunchKernelGGL(mi_level0_kernel<false>, dim3(nblk), dim3(256), 0, ctx->stream, P, p, T, ctx->d_firstnz,
-                               ctx->d_firstnz + p, ctx->P.alpha, d_gthr, (MiL0Counters *)ctx->d_tmp0.ptr, cap, oi, oj, os, op);
+                               ctx->d_firstnz + p, d_gthr, (MiL0Counters *)ctx->d_tmp0.ptr, cap_c, (MiCand *)ctx->d_jobs.ptr);
         FW_HIP(ctx, hipGetLastError());
-        FW_HIP(ctx, hipMemcpyAsync(&h, ctx->d_tmp0.ptr, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        FW_HIP(ctx, hipMemcpyAsync(&h1, ctx->d_tmp0.ptr, sizeof(h1), hipMemcpyDeviceToHost, ctx->stream));
         FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->cnt.kernel_launches += 1;
-        if (h.n_sig <= cap) {
-            const size_t k = (size_t)h.n_sig;
-            pi.resize(k);
-            pj.resize(k);
-            stat.resize(k);
-            pval.resize(k);
-            if (k) {
-                FW_HIP(ctx, hipMemcpy(pi.data(), oi, k * sizeof(int32_t), hipMemcpyDeviceToHost));
-                FW_HIP(ctx, hipMemcpy(pj.data(), oj, k * sizeof(int32_t), hipMemcpyDeviceToHost));
-                FW_HIP(ctx, hipMemcpy(stat.data(), os, k * sizeof(double), hipMemcpyDeviceToHost));
-                FW_HIP(ctx, hipMemcpy(pval.data(), op, k * sizeof(double), hipMemcpyDeviceToHost));
-            }
-            *m_reliable = npairs - (long long)h.n_unreliable;
-            return FW_OK;
-        }
-        cap = h.n_sig;
+        if (h1.n_sig <= cap_c) break;
+        if (attempt == 1) return fw_fail(ctx, FW_ERR_DEVICE, "discrete level-0: candidate buffer overflow twice");
+        cap_c = h1.n_sig;
     }
-    return fw_fail(ctx, FW_ERR_DEVICE, "discrete level-0: compaction buffer overflow twice");
+    const unsigned long long ncand = h1.n_sig;
+    *m_reliable = npairs - (long long)h1.n_unreliable;
+    pi.clear();
+    pj.clear();
+    stat.clear();
+    pval.clear();
+    if (ncand == 0) return FW_OK;
+    // ---- kernel 2: exact Float64 statistic + p-value of the candidates ----
+    MiL0Counters *d_cnt2 = (MiL0Counters *)ctx->d_tmp0.ptr + 1;
+    if ((rc = fw_dev_reserve(ctx, ctx->d_tmp1, ncand * 2 * sizeof(int32_t)))) return rc;
+    if ((rc = fw_dev_reserve(ctx, ctx->d_tmp2, ncand * 2 * sizeof(double)))) return rc;
+    int32_t *oi = (int32_t *)ctx->d_tmp1.ptr, *oj = oi + ncand;
+    double *os = (double *)ctx->d_tmp2.ptr, *op = os + ncand;
+    hipLaunchKernelGGL(mi_level0_exact_kernel, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, ctx->stream, P,
+                       (const MiCand *)ctx->d_jobs.ptr, ncand, ctx->d_firstnz, ctx->d_firstnz + p, ctx->P.alpha, d_gthr, d_cnt2,
+                       ncand, oi, oj, os, op);
+    FW_HIP(ctx, hipGetLastError());
+    MiL0Counters h2{};
+    FW_HIP(ctx, hipMemcpyAsync(&h2, d_cnt2, sizeof(h2), hipMemcpyDeviceToHost, ctx->stream));
+    FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->cnt.kernel_launches += 1;
+    const size_t k = (size_t)h2.n_sig;
+    pi.resize(k);
+    pj.resize(k);
+    stat.resize(k);
+    pval.resize(k);
+    if (k) {
+        FW_HIP(ctx, hipMemcpy(pi.data(), oi, k * sizeof(int32_t), hipMemcpyDeviceToHost));
+        FW_HIP(ctx, hipMemcpy(pj.data(), oj, k * sizeof(int32_t), hipMemcpyDeviceToHost));
+        FW_HIP(ctx, hipMemcpy(stat.data(), os, k * sizeof(double), hipMemcpyDeviceToHost));
+        FW_HIP(ctx, hipMemcpy(pval.data(), op, k * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return FW_OK;
 }
 
 int fwi_mi_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff,
