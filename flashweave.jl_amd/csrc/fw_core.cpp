@@ -89,6 +89,8 @@ int fw_ctx_create(const fw_params *P, fw_ctx **out)
         return fw_fail(nullptr, FW_ERR_LIMIT, "fw_ctx_create: max_k=%d outside [0, %d]", P->max_k, FW_MAX_K);
     if (!(P->alpha > 0.0 && P->alpha < 1.0)) return fw_fail(nullptr, FW_ERR_ARG, "fw_ctx_create: alpha must be in (0,1)");
     if (P->hps < 0) return fw_fail(nullptr, FW_ERR_ARG, "fw_ctx_create: hps must be >= 0");
+    if (P->dense_rules && (P->kind == FW_FZ || P->kind == FW_FZ_NZ))
+        return fw_fail(nullptr, FW_ERR_ARG, "fw_ctx_create: dense_rules applies to the discrete tests only");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)

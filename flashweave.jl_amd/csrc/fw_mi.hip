@@ -27,6 +27,7 @@ struct MiDev {
     const int32_t *levels;
     const int32_t *maxv;
     int W, n, L, nzmode, hps;
+    int dense;  // dense-matrix table rules (contingency.jl:7-56): every row counted, levels_z = distinct Z keys over all rows
     long long n_obs_min;
 };
 
@@ -136,7 +137,7 @@ __device__ MiRes mi_test_wave(const MiDev &P, int X, int Y, const int *zs, int k
     for (int c = lane; c < MI_MAXCELL; c += 64) tab[c] = 0;
     const bool flagX = P.nzmode && P.maxv[X] > 1, flagY = P.nzmode && P.maxv[Y] > 1;
     const bool any_flag = flagX || flagY;
-    const bool special_k1 = (k == 1) && any_flag;  // contingency.jl:250-253
+    const bool special_k1 = (k == 1) && any_flag && !P.dense;  // contingency.jl:250-253 (sparse dispatch only)
     const int sx = flagX ? 1 : 0, sy = flagY ? 1 : 0;
     int lx, ly;
     if (P.nzmode) {  // tests.jl:200-203: levels of the nz-adjusted sub-table
@@ -192,7 +193,9 @@ __device__ MiRes mi_test_wave(const MiDev &P, int X, int Y, const int *zs, int k
                 anyz |= zv;
             }
         bool counted = row < P.n;
-        if (any_flag)
+        if (P.dense)
+            ;  // contingency.jl:42-56: the dense form visits every row; nz_adjust_cont_tab drops row/col 0 afterwards
+        else if (any_flag)
             counted = counted && (!flagX || xv != 0) && (!flagY || yv != 0);  // rows the merge does not skip
         else
             counted = counted && ((xv | yv | anyz) != 0);  // rows the merge visits; the rest is added below
@@ -204,7 +207,7 @@ __device__ MiRes mi_test_wave(const MiDev &P, int X, int Y, const int *zs, int k
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int n_counted = wave_sum_i(my_counted);
-    if (!any_flag) {
+    if (!any_flag && !P.dense) {
         // contingency.jl:462-476: never-visited (all-zero) rows go to cell (0, 0, stratum of the all-zero key)
         if (lane == 0) tab[0] += P.n - n_counted;
     }
@@ -259,11 +262,11 @@ __device__ MiRes mi_test_wave(const MiDev &P, int X, int Y, const int *zs, int k
     } else if (special_k1) {
         const int zm = wave_max_i(nonempty ? zmax : -1);
         levels_z = zm < 0 ? 1 : zm + 1;  // contingency.jl:168-176,186,229
-    } else if (any_flag) {
+    } else if (any_flag && !P.dense) {
         // distinct keys among counted rows, +1 if uncounted rows exist and the all-zero key was not among them
         levels_z = n_nonempty + ((P.n - n_counted > 0 && !key0_seen) ? 1 : 0);
     } else {
-        levels_z = n_nonempty;  // all rows are in the table
+        levels_z = n_nonempty;  // all rows are in the table (dense rule: level_map! misc.jl:162-184)
     }
     // power (tests.jl:58 / :210)
     bool power;
@@ -832,6 +835,7 @@ static MiDev mi_dev(const fw_ctx *ctx)
     P.L = ctx->L;
     P.nzmode = ctx->P.kind == FW_MI_NZ;
     P.hps = ctx->P.hps;
+    P.dense = ctx->P.dense_rules != 0;
     P.n_obs_min = ctx->n_obs_min_eff;
     return P;
 }

@@ -23,7 +23,7 @@ class FlashWeaveError(RuntimeError):
 
 class _Params(C.Structure):
     _fields_ = [("kind", C.c_int32), ("n", C.c_int32), ("p", C.c_int32), ("device", C.c_int32),
-                ("max_k", C.c_int32), ("hps", C.c_int32), ("fdr", C.c_int32), ("reserved0", C.c_int32),
+                ("max_k", C.c_int32), ("hps", C.c_int32), ("fdr", C.c_int32), ("dense_rules", C.c_int32),
                 ("n_obs_min", C.c_int64), ("max_tests", C.c_int64), ("alpha", C.c_double)]
 
 
@@ -117,7 +117,7 @@ class Engine:
     (src/learning.jl:466-473)."""
 
     def __init__(self, test_name, n, p, max_k=3, alpha=0.01, hps=5, n_obs_min=-1, max_tests=10_000_000, FDR=True,
-                 device=0):
+                 device=0, dense_rules=False):
         self.L = load_library()
         self.test_name = test_name
         self.n, self.p = int(n), int(p)
@@ -125,6 +125,7 @@ class Engine:
         self.L.fw_params_default(C.byref(P), _KINDS[test_name], self.n, self.p)
         P.device, P.max_k, P.alpha, P.hps = device, max_k, alpha, hps
         P.n_obs_min, P.max_tests, P.fdr = n_obs_min, max_tests, int(FDR)
+        P.dense_rules = int(bool(dense_rules))  # Matrix (dense) table methods instead of the SparseMatrixCSC ones
         self.h = C.c_void_p()
         rc = self.L.fw_ctx_create(C.byref(P), C.byref(self.h))
         if rc != 0:

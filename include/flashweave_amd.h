@@ -55,7 +55,13 @@ typedef struct fw_params {
     int32_t max_k;     /* default 3; 0 = univariate network only */
     int32_t hps;       /* default 5 (heuristic power size, src/tests.jl:5-6) */
     int32_t fdr;       /* default 1: Benjamini-Hochberg on level-0 p-values (src/tests.jl:521-529) */
-    int32_t reserved0;
+    int32_t dense_rules; /* FW_MI / FW_MI_NZ only.  0 (default): contingency tables follow the SparseMatrixCSC methods
+                          * (src/contingency.jl:80-480), what learn_network uses (make_sparse = true).  1: the dense
+                          * Matrix methods (src/contingency.jl:7-56 + level_map! src/misc.jl:162-184): every row is
+                          * visited and levels_z = number of distinct Z keys over all rows.  The cell counts
+                          * are the same; only levels_z (power verdict) can differ, and only for FW_MI_NZ.
+                          * fw_learn_network with FW_MI_NZ + dense_rules is refused: the reference then tests on a
+                          * per-target row view (src/hiton.jl:41-50) that no golden vector pins. */
     int64_t n_obs_min; /* default -1 = automatic (src/learning.jl:51-64, fires for every test kind) */
     int64_t max_tests; /* default 10_000_000 per (T, candidate) pair (src/learning.jl:205) */
     double alpha;      /* default 0.01 */

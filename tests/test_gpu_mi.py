@@ -211,3 +211,64 @@ def test_full_size_properties():
     assert set(r1["edges"]) == set(exp["edges"])
     assert c1["cond_tests_ref"] == exp["n_cond_tests"]
     eng.close()
+
+
+def test_dense_matrix_rules(ctx):
+    # contingency.jl:7-56 + level_map! (misc.jl:162-184): the Matrix methods the reference uses with make_sparse=false.
+    # Oracle(sparse=False) follows them and is pinned by tests_expected.tsv; levels_z differs from the sparse rules for
+    # mi_nz, so power verdicts can differ between the two engines below.
+    kind, data, n, p = ctx["kind"], ctx["data"], ctx["n"], ctx["p"]
+    eng = fw.Engine(kind, n, p, max_k=3, dense_rules=True)
+    eng.set_data(data)
+    orc = O.Oracle(kind, data, sparse=False, max_k=3)
+    rng = np.random.default_rng(11)
+    X, Y, Zs = [], [], []
+    for _ in range(4000):
+        k = int(rng.integers(0, 4))
+        v = rng.choice(p, size=k + 2, replace=False)
+        X.append(int(v[0])); Y.append(int(v[1])); Zs.append(tuple(int(t) for t in v[2:]))
+    got = eng.test_batch(X, Y, Zs)
+    sparse_got = ctx["eng"].test_batch(X, Y, Zs)
+    nom = eng.n_obs_min
+    npow = ndiff = 0
+    for x, y, z, g, gs in zip(X, Y, Zs, got, sparse_got):
+        s, pv, df, pw = orc.test(x, y, z, hps=5, n_obs_min=nom)
+        assert (g.df, g.suff_power) == (df, pw), (x, y, z, g, (s, pv, df, pw))
+        assert _close(g.stat, s, STOL) and _close(g.pval, pv, PTOL), (x, y, z, g, (s, pv, df, pw))
+        npow += pw
+        ndiff += (g.suff_power != gs.suff_power)
+    assert npow > 100
+    if kind == "mi":
+        assert ndiff == 0  # without zero adjustment the two rule sets coincide
+    # test_subsets on the full dense matrix (tests.jl:281-346 called without a row view)
+    nb = orc.level0(alpha=0.01, hps=5, n_obs_min=nom)
+    T, C, A = [], [], []
+    for t in range(p):
+        nbrs = [int(v) for v in nb["idx"][nb["off"][t]:nb["off"][t + 1]]]
+        if len(nbrs) >= 3:
+            for c in nbrs[:2]:
+                acc = [v for v in nbrs if v != c][:6]
+                T.append(t); C.append(c); A.append(acc)
+        if len(T) >= 300:
+            break
+    assert len(T) > 20
+    _check_subsets(eng, orc, T, C, A, 3, nom)
+    if kind == "mi_nz":
+        with pytest.raises(fw.FlashWeaveError):
+            eng.lgl()
+    eng.close()
+
+
+def test_tests_expected_tsv_dense_rules():
+    # the reference's expected TestResults were produced on dense matrices (test/tests.jl:41-74)
+    exp = read_tests_expected()
+    for kind, fx in (("mi", "pres_abs"), ("mi_nz", "clr_nonzero_binned")):
+        data = load_norm(fx, np.int64)
+        eng = fw.Engine(kind, data.shape[0], data.shape[1], max_k=3, n_obs_min=0, dense_rules=True)
+        eng.set_data(data)
+        for key, Zs in (("condZ1", (6,)), ("condZ3", (6, 13, 17))):
+            g = eng.test(30, 20, Zs)
+            e = exp["exp_%s_%s" % (key, kind)][0]
+            assert (g.df, g.suff_power) == (e[2], e[3])
+            assert _close(g.stat, e[0], 1e-11) and _close(g.pval, e[1], 1e-9)
+        eng.close()
