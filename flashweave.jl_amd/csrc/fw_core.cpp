@@ -115,10 +115,12 @@ int fw_ctx_create(const fw_params *P, fw_ctx **out)
     }
     for (FwPoolBuf &b : c->pb)
         if ((e = hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking)) != hipSuccess ||
-            (e = hipEventCreate(&b.ev0)) != hipSuccess || (e = hipEventCreate(&b.ev1)) != hipSuccess) {
+            (e = hipEventCreate(&b.ev0)) != hipSuccess || (e = hipEventCreate(&b.ev1)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&b.evd, hipEventDisableTiming)) != hipSuccess) {
             fw_ctx_destroy(c);
             return fw_fail(nullptr, FW_ERR_DEVICE, "stream/event creation failed: %s", hipGetErrorString(e));
         }
+    for (FwPoolBuf &b : c->pb) b.launch_stream = b.stream;
     // continuous: the automatic n_obs_min is known immediately (learning.jl:59-61); discrete needs levels
     c->n_obs_min_eff = P->n_obs_min >= 0 ? P->n_obs_min : ((P->kind == FW_FZ || P->kind == FW_FZ_NZ) ? 20 : -1);
     *out = c;
@@ -167,6 +169,7 @@ int fw_ctx_destroy(fw_ctx *c)
         free_dev(b.d_out);
         if (b.ev0) (void)hipEventDestroy(b.ev0);
         if (b.ev1) (void)hipEventDestroy(b.ev1);
+        if (b.evd) (void)hipEventDestroy(b.evd);
         if (b.stream) (void)hipStreamDestroy(b.stream);
     }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -210,7 +213,12 @@ int fw_set_cor_mat(fw_ctx *c, const float *cor)
     CHECK_CTX(c);
     if (c->P.kind != FW_FZ) return fw_fail(c, FW_ERR_ARG, "fw_set_cor_mat: context is not FW_FZ");
     if (!cor) return fw_fail(c, FW_ERR_ARG, "fw_set_cor_mat: NULL matrix");
-    const size_t bytes = sizeof(float) * (size_t)c->P.p * c->P.p;
+    const size_t cells = (size_t)c->P.p * c->P.p, bytes = sizeof(float) * cells;
+    // the device arithmetic relies on |entries| <= 1 (what cor() produces, cov2cor clamps); NaN is allowed and propagates
+    for (size_t t = 0; t < cells; ++t)
+        if (std::fabs(cor[t]) > 1.0f)
+            return fw_fail(c, FW_ERR_ARG, "fw_set_cor_mat: entry %zu = %g is outside [-1, 1]: not a correlation matrix", t,
+                           (double)cor[t]);
     if (!c->d_cor) FW_HIP(c, hipMalloc(&c->d_cor, bytes));
     FW_HIP(c, hipMemcpy(c->d_cor, cor, bytes, hipMemcpyHostToDevice));
     c->have_cor = true;
@@ -636,54 +644,62 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
     pool.seg_job.resize(ns);
     pool.nzrecs.clear();
     size_t arena_floats = 0;
-    size_t si = 0;
+    size_t si = 0, ns_tab = 0;
     int64_t aoff = 0;
-    for (size_t ji = 0; ji < pool.live.size(); ++ji) {
-        const FwPoolJob &j = pool.live[ji];
-        if (!j.launched) continue;
-        memcpy(hacc + aoff, j.acc.data(), j.acc.size() * sizeof(int32_t));
-        const uint64_t lo = j.next, hi = lo + std::min(j.width, j.N - lo);
-        for (uint64_t sgs = lo; sgs < hi; sgs += seglen) {
-            FwSeg sg{};
-            sg.X = j.X;
-            sg.Y = j.Y;
-            sg.acc_off = aoff;
-            sg.acc_len = (int32_t)j.acc.size();
-            sg.start = sgs;
-            sg.end = std::min(hi, sgs + seglen);
-            sg.pad = (int32_t)pool.nzrecs.size();  // fz_nz: index of the job's record in this launch
-            segs[si] = sg;
-            pool.seg_job[si] = (int64_t)ji;
-            ++si;
+    // fz / fz_nz with max_k <= 3: segments of jobs with at most FW_TAB_A accepted variables come first (table kernel)
+    static const bool no_tab = getenv("FW_NO_TAB") != nullptr;  // profiling knob: force the in-lane caching kernel
+    const bool split = fz && c->P.max_k <= 3 && !no_tab;
+    for (int pass = 0; pass < (split ? 2 : 1); ++pass) {
+        for (size_t ji = 0; ji < pool.live.size(); ++ji) {
+            const FwPoolJob &j = pool.live[ji];
+            if (!j.launched) continue;
+            if (split && (j.acc.size() <= FW_TAB_A) != (pass == 0)) continue;
+            memcpy(hacc + aoff, j.acc.data(), j.acc.size() * sizeof(int32_t));
+            const uint64_t lo = j.next, hi = lo + std::min(j.width, j.N - lo);
+            for (uint64_t sgs = lo; sgs < hi; sgs += seglen) {
+                FwSeg sg{};
+                sg.X = j.X;
+                sg.Y = j.Y;
+                sg.acc_off = aoff;
+                sg.acc_len = (int32_t)j.acc.size();
+                sg.start = sgs;
+                sg.end = std::min(hi, sgs + seglen);
+                sg.pad = (int32_t)pool.nzrecs.size();  // fz_nz: index of the job's record in this launch
+                segs[si] = sg;
+                pool.seg_job[si] = (int64_t)ji;
+                ++si;
+            }
+            if (nzs) {
+                FwNzJob r{};
+                r.X = j.X;
+                r.Y = j.Y;
+                r.acc_off = aoff;
+                r.acc_len = (int32_t)j.acc.size();
+                r.m = r.acc_len + 2;
+                r.cor_off = (long long)arena_floats;
+                arena_floats += (size_t)r.m * r.m;
+                pool.nzrecs.push_back(r);
+            }
+            aoff += (int64_t)j.acc.size();
         }
-        if (nzs) {
-            FwNzJob r{};
-            r.X = j.X;
-            r.Y = j.Y;
-            r.acc_off = aoff;
-            r.acc_len = (int32_t)j.acc.size();
-            r.m = r.acc_len + 2;
-            r.cor_off = (long long)arena_floats;
-            arena_floats += (size_t)r.m * r.m;
-            pool.nzrecs.push_back(r);
-        }
-        aoff += (int64_t)j.acc.size();
+        if (split && pass == 0) ns_tab = si;
     }
     const double tb1 = now_s();
     c->cnt.t_host_build_s += tb1 - tb0;
-    FW_HIP(c, hipMemcpyAsync(pb.d_in.ptr, pb.h_in.ptr, in_bytes, hipMemcpyHostToDevice, pb.stream));
+    FW_HIP(c, hipMemcpyAsync(pb.d_in.ptr, pb.h_in.ptr, in_bytes, hipMemcpyHostToDevice, pb.launch_stream));
     const FwSeg *dsegs = (const FwSeg *)pb.d_in.ptr;
     const int32_t *dacc = (const int32_t *)((const char *)pb.d_in.ptr + ns * sizeof(FwSeg));
     if (nzs) {
-        rc = fwi_fznz_submatrices(c, (int64_t)pool.nzrecs.size(), pool.nzrecs.data(), arena_floats, dacc, pb.stream);
+        rc = fwi_fznz_submatrices(c, (int64_t)pool.nzrecs.size(), pool.nzrecs.data(), arena_floats, dacc, pb.launch_stream);
         if (rc) return rc;
-        rc = fwi_fznz_segments(c, (int64_t)ns, dsegs, dacc, (FwSegOut *)pb.d_out.ptr, pb);
+        rc = fwi_fznz_segments(c, (int64_t)ns, (int64_t)ns_tab, dsegs, dacc, (FwSegOut *)pb.d_out.ptr, pb);
     } else {
-        rc = fz ? fwi_fz_segments(c, (int64_t)ns, dsegs, dacc, (FwSegOut *)pb.d_out.ptr, pb)
+        rc = fz ? fwi_fz_segments(c, (int64_t)ns, (int64_t)ns_tab, dsegs, dacc, (FwSegOut *)pb.d_out.ptr, pb)
                 : fwi_mi_segments(c, (int64_t)ns, dsegs, dacc, (FwSegOut *)pb.d_out.ptr, pb);
     }
     if (rc) return rc;
-    FW_HIP(c, hipMemcpyAsync(pb.h_out.ptr, pb.d_out.ptr, ns * sizeof(FwSegOut), hipMemcpyDeviceToHost, pb.stream));
+    FW_HIP(c, hipMemcpyAsync(pb.h_out.ptr, pb.d_out.ptr, ns * sizeof(FwSegOut), hipMemcpyDeviceToHost, pb.launch_stream));
+    FW_HIP(c, hipEventRecord(pb.evd, pb.launch_stream));
     pool.ns = ns;
     pool.inflight = true;
     pool.t_launch = now_s();
@@ -706,12 +722,27 @@ int fwi_pool_collect(fw_ctx *c, FwPool &pool, std::vector<FwPoolJob> &finished)
     }
     FwPoolBuf &pb = c->pb[pool.buf];
     const double tb1 = now_s();
-    FW_HIP(c, hipStreamSynchronize(pb.stream));
+    FW_HIP(c, hipEventSynchronize(pb.evd));
     const double tb2 = now_s();
     c->cnt.t_host_wait_s += tb2 - tb1;
     float ms = 0.0f;
     FW_HIP(c, hipEventElapsedTime(&ms, pb.ev0, pb.ev1));
     c->cnt.t_dev_subsets_s += 1e-3 * (double)ms;
+    {  // FW_TRACE_ROUNDS=<file>: one line per pool round (profiling aid; see profiles/README.md)
+        static FILE *tf = [] {
+            const char *e = getenv("FW_TRACE_ROUNDS");
+            return e ? fopen(e, "w") : (FILE *)nullptr;
+        }();
+        static double t_prev = 0.0;
+        if (tf) {
+            unsigned long long ev_sum = 0;
+            for (size_t q = 0; q < pool.ns; ++q) ev_sum += ((const FwSegOut *)pb.h_out.ptr)[q].evaluated;
+            fprintf(tf, "%zu %zu %.1f %.1f %.1f %llu\n", pool.live.size(), pool.ns, 1e3 * (double)ms, 1e6 * (tb2 - tb1),
+                    t_prev > 0.0 ? 1e6 * (tb2 - t_prev) : 0.0, ev_sum);
+            fflush(tf);
+        }
+        t_prev = tb2;
+    }
     c->cnt.kernel_launches += 1;
     c->cnt.subsets_launches += 1;
     const size_t ns = pool.ns;
@@ -761,6 +792,13 @@ int fwi_pool_collect(fw_ctx *c, FwPool &pool, std::vector<FwPoolJob> &finished)
         }
         if (j.done) {
             finish_job(c, j, pool.want_zs);
+            {  // FW_TRACE_JOBS=<file>: |accepted|, evaluated tests, reference-order tests, status per finished job
+                static FILE *jf = [] {
+                    const char *e = getenv("FW_TRACE_JOBS");
+                    return e ? fopen(e, "w") : (FILE *)nullptr;
+                }();
+                if (jf) fprintf(jf, "%zu %lld %lld %d\n", j.acc.size(), (long long)j.out.evaluated, (long long)j.out.num_tests, j.out.status);
+            }
             finished.push_back(std::move(j));
         } else {
             if (w != ji) pool.live[w] = std::move(j);

@@ -221,31 +221,23 @@ __device__ __forceinline__ double fz_pval_dev(double r, double zscale /* sqrt(n-
 // by 1e5 is done as q0 = n * c, r = fma(-q0, 1e5, n), q = fma(r, c, q0) with c = RN(1e-5): this is the correctly
 // rounded quotient for every integer |n| <= 400000 in both Float32 and Float64 -- verified exhaustively on the host
 // (tests/test_oracle_golden.py::test_fast_division_by_1e5_is_exact) -- and costs 3 instructions instead of an IEEE
-// division sequence.  Larger |n| (|x| > 4, impossible for correlations) and NaN take the plain division.
+// division sequence.  Every argument here is a - b * c with a, b, c in [-1, 1] (matrix entries are validated /
+// clamped to that range, every recursion level clamps its result), so |n| <= 200000; NaN propagates as in the
+// plain division.
 __device__ __forceinline__ float round5_f32(float x)
 {
     const float n = rintf(x * 100000.0f);
-    float y;
-    if (fabsf(n) <= 400000.0f) {
-        const float q0 = n * 1e-5f;
-        const float r = fmaf(-q0, 100000.0f, n);
-        y = fmaf(r, 1e-5f, q0);
-    } else {
-        y = n / 100000.0f;
-    }
+    const float q0 = n * 1e-5f;
+    const float r = fmaf(-q0, 100000.0f, n);
+    const float y = fmaf(r, 1e-5f, q0);
     return isfinite(y) ? y : x;
 }
 __device__ __forceinline__ double round5_f64(double x)
 {
     const double n = rint(x * 100000.0);
-    double y;
-    if (fabs(n) <= 400000.0) {
-        const double q0 = n * 1e-5;
-        const double r = fma(-q0, 100000.0, n);
-        y = fma(r, 1e-5, q0);
-    } else {
-        y = n / 100000.0;
-    }
+    const double q0 = n * 1e-5;
+    const double r = fma(-q0, 100000.0, n);
+    const double y = fma(r, 1e-5, q0);
     return isfinite(y) ? y : x;
 }
 
@@ -539,10 +531,8 @@ __device__ __forceinline__ double pc_l2_d2(TV a, TV b, TV c, double d2c)
     }
     const double denom = d1 * d2c;
     double v = (denom == 0.0) ? 0.0 : ev / denom;
-    if (v < -1.0)
-        v = -1.0;
-    else if (v >= 1.0)
-        v = 1.0;
+    v = v < -1.0 ? -1.0 : v;  // two selects, no branch (NaN stays NaN)
+    v = v >= 1.0 ? 1.0 : v;
     return v;
 }
 __device__ __forceinline__ double pc_l2(TV a, TV b, TV c) { return pc_l2_d2(a, b, c, sqrt(1.0 - c.v * c.v)); }
@@ -557,8 +547,39 @@ __device__ __forceinline__ double pc_l2_all32(float a, float b, float c, double 
     const double d1 = (double)sqrtf(1.0f - bb);
     const double denom = d1 * d2c;
     double v = (denom == 0.0) ? 0.0 : ev / denom;
-    v = v < -1.0 ? -1.0 : (v >= 1.0 ? 1.0 : v);
+    v = v < -1.0 ? -1.0 : v;
+    v = v >= 1.0 ? 1.0 : v;
     return v;
+}
+
+// the same with d1 = Float64(sqrt(1f0 - b^2)) taken from the LDS table (it only depends on the (z1, z2) entry)
+__device__ __forceinline__ double pc_l2_all32_d1(float a, float b, float c, double d1, double d2c)
+{
+    const float prod = b * c;
+    const double ev = (double)round5_f32(a - prod);
+    const double denom = d1 * d2c;
+    double v = (denom == 0.0) ? 0.0 : ev / denom;
+    v = v < -1.0 ? -1.0 : v;
+    v = v >= 1.0 ? 1.0 : v;
+    return v;
+}
+
+// pc_l1 with the two square roots sqrt(1 - xz^2), sqrt(1 - yz^2) taken from the LDS table
+__device__ __forceinline__ TV pc_l1_r(float xy, float xz, float yz, float rxz, float ryz)
+{
+    const float prod = xz * yz;
+    const float e = round5_f32(xy - prod);
+    const float d = rxz * ryz;
+    const bool nz = d != 0.0f;
+    const float q = e / (nz ? d : 1.0f);
+    TV r;
+    r.v = nz ? (double)q : 0.0;
+    r.f32 = nz;
+    const bool lo = r.v < -1.0, hi = r.v >= 1.0;
+    r.v = lo ? -1.0 : r.v;
+    r.v = hi ? 1.0 : r.v;
+    r.f32 = r.f32 && !lo && !hi;
+    return r;
 }
 
 // statfuns.jl:44-62, all-Float64 children (level >= 3)
@@ -567,10 +588,8 @@ __device__ __forceinline__ double pc_l3(double a, double b, double c)
     const double ev = round5_f64(a - b * c);
     const double denom = sqrt(1.0 - b * b) * sqrt(1.0 - c * c);
     double v = (denom == 0.0) ? 0.0 : ev / denom;
-    if (v < -1.0)
-        v = -1.0;
-    else if (v >= 1.0)
-        v = 1.0;
+    v = v < -1.0 ? -1.0 : v;
+    v = v >= 1.0 ? 1.0 : v;
     return v;
 }
 
@@ -580,6 +599,24 @@ __device__ __forceinline__ double pc_l3(double a, double b, double c)
 // 10 formula evaluations and 6 of the 10 matrix entries).  Rank order is preserved: a lane stops at its first
 // stopping rank, the workgroup takes the minimum over lanes.
 #define FW_RUN_MAX 16
+// Table path of the size-3 enumeration (accepted sets of up to FZ_TAB_A variables, max_k <= 3).  With
+// (z1, z2, z3) = accepted[(i, j, k)], i < j < k, the recursion of statfuns.jl:44-53 needs
+//   rho(X,Y|z1,z2)   = l2(A1(i), LX(i,j), LY(i,j))          -- depends on (i, j) only
+//   rho(X,z3|z1,z2)  = l2(LX(i,k), LX(i,j), F1(i,j,k))      -- LX(i,v) = rho(X,v|z1), LY(i,v) = rho(Y,v|z1)
+//   rho(Y,z3|z1,z2)  = l2(LY(i,k), LY(i,j), F1(i,j,k))      -- F1 = rho(z3,z2|z1)
+// so per chunk the workgroup first builds, for every z1-block i the chunk touches, one LDS entry per later position
+// v: {LX, LY, cor[v][z1], variable id + Float32 flags, rho(X,Y|z1,v)}.  A test then costs one matrix gather, one
+// level-1, two level-2 and one level-3 evaluation instead of 3 + 2 + 1 evaluations and 4 gathers, and -- more
+// importantly -- no lane ever recomputes a prefix while the other 63 wait (the divergence of the in-lane caching
+// path).  A chunk of 4096 ranks touches at most 1021 entries for every |accepted| <= 512 (profiles/tools/tab_bound.py).
+#define FZ_TAB_A FW_TAB_A
+#define FZ_TAB_CAP 1024
+#define FZ_TAB_ZMASK 0x1FFFFFFF
+// entries of blocks [i0, i): block t holds a - 1 - t entries
+__device__ __forceinline__ int fz_tab_off(int i, int i0, int a)
+{
+    return (i - i0) * (a - 1) - (i * (i - 1) - i0 * (i0 - 1)) / 2;
+}
 #define FZ_X_NONE 1.0e308    // "no candidate yet"
 #define FZ_X_SUB 26.0        // beyond this x = |z|/sqrt2, erfc(x)/2*2 leaves the normal range (ties become possible)
 #define FZ_X_SUBKEY 1.0e300  // common x-key of the underflow regime (ordered by exact p there)
@@ -624,7 +661,9 @@ __global__ void fz_thresholds_kernel(double alpha, double zscale, double *thr)
     fz_thresholds_dev(alpha, zscale, thr);
 }
 
-template <bool HIGHK, bool LOCAL>  // HIGHK: subsets of size 4-5 possible; LOCAL: per-job matrices (fz_nz)
+// HIGHK: subsets of size 4-5 possible; LOCAL: per-job matrices (fz_nz); TAB: size-3 subsets through the LDS table
+// (the host routes only segments of jobs with |accepted| <= FZ_TAB_A to a TAB launch; never together with HIGHK)
+template <bool HIGHK, bool LOCAL, bool TAB>
 __global__ __launch_bounds__(256, 3) void fz_subsets_seg_kernel(const float *__restrict__ cor_g, int p_g,
                                                              const FwSeg *__restrict__ segs,
                                                              const int32_t *__restrict__ accflat,
@@ -639,6 +678,10 @@ __global__ __launch_bounds__(256, 3) void fz_subsets_seg_kernel(const float *__r
     __shared__ unsigned long long s_br[4];
     __shared__ double s_best_x, s_best_ps, s_best_stat;
     __shared__ unsigned long long s_best_rank;
+    __shared__ float4 s_tab[TAB ? FZ_TAB_CAP : 1];    // {LX, LY, cor[v][z1], variable id | Float32 flags}
+    __shared__ float4 s_tab_r[TAB ? FZ_TAB_CAP : 1];  // {sqrt(1 - cor[v][z1]^2), sqrt(1 - LX^2), sqrt(1 - LY^2), -} in Float32
+    __shared__ double s_tab_a2[TAB ? FZ_TAB_CAP : 1]; // rho(X, Y | z1, v)
+    __shared__ int s_blk[2];
 
     const FwSeg seg = segs[blockIdx.x];
     const int a = seg.acc_len;
@@ -703,6 +746,49 @@ __global__ __launch_bounds__(256, 3) void fz_subsets_seg_kernel(const float *__r
         unsigned long long r1 = r0 + R;
         if (r1 > seg.end) r1 = seg.end;
         const bool any = r0 < seg.end;
+        // ---- table of the z1-blocks this chunk touches (see FZ_TAB_A) ----
+        bool tab_ok = false;
+        int tb_i0 = 0;
+        if (TAB) {
+            const unsigned long long c3 = (max_k >= 3) ? cnt[3] : 0ull;
+            if (cbase < c3) {  // workgroup-uniform; a <= FZ_TAB_A by the host's routing
+                unsigned long long last3 = cbase + 256ull * R;
+                last3 = last3 < seg.end ? last3 : seg.end;
+                last3 = (last3 < c3 ? last3 : c3) - 1ull;
+                if (tid == 0 || tid == 64) {
+                    int q[FW_MAX_K];
+                    unrank_comb(tid == 0 ? cbase : last3, a, 3, q);
+                    s_blk[tid == 0 ? 0 : 1] = q[0];
+                }
+                __syncthreads();
+                const int i0 = s_blk[0], i1 = s_blk[1];
+                const int E = fz_tab_off(i1 + 1, i0, a);  // <= 1021 for a <= 512 and chunks of 4096 ranks
+                if (E <= FZ_TAB_CAP) {
+                    tab_ok = true;
+                    tb_i0 = i0;
+                    for (int e = tid; e < E; e += 256) {
+                        int i = i0, rem = e;
+                        while (rem >= a - 1 - i) {
+                            rem -= a - 1 - i;
+                            ++i;
+                        }
+                        const int z1 = ACCV(i), zv = ACCV(i + 1 + rem);
+                        const float cXz1 = CORV(X, z1), cYz1 = CORV(Y, z1), cvz1 = CORV(zv, z1);
+                        const TV A1 = pc_l1(cXY, cXz1, cYz1);
+                        const TV LX = pc_l1(CORV(X, zv), cXz1, cvz1);
+                        const TV LY = pc_l1(CORV(Y, zv), cYz1, cvz1);
+                        s_tab_a2[e] = pc_l2(A1, LX, LY);
+                        // square roots the level-1 / level-2 formulas take of this entry's values (statfuns.jl:36,52);
+                        // for a Float64-literal LX / LY (0, +-1) the Float32 root is the exact one as well
+                        const float fx = (float)LX.v, fy = (float)LY.v;
+                        s_tab_r[e] = make_float4(sqrtf(1.0f - cvz1 * cvz1), sqrtf(1.0f - fx * fx), sqrtf(1.0f - fy * fy), 0.0f);
+                        s_tab[e] = make_float4((float)LX.v, (float)LY.v, cvz1,
+                                               __int_as_float(zv | (LX.f32 ? (1 << 30) : 0) | (LY.f32 ? (1 << 29) : 0)));
+                    }
+                }
+                __syncthreads();
+            }
+        }
         // lane-local results
         unsigned long long my_stop = NONE, my_br = 0;
         double stop_stat = 0.0, stop_p = 0.0, my_bstat = 0.0;
@@ -727,9 +813,32 @@ __global__ __launch_bounds__(256, 3) void fz_subsets_seg_kernel(const float *__r
             float cXz1 = 0.f, cYz1 = 0.f, cXz2 = 0.f, cYz2 = 0.f, cz2z1 = 0.f;
             TV A1{0.0, false}, B1{0.0, false}, C1{0.0, false};
             double A2 = 0.0;
+            int boff = 0;
             for (unsigned long long r = r0; r < r1; ++r) {
                 double stat;
-                if (s == 3) {
+                if (TAB && s == 3 && tab_ok) {
+                    const int pi = pos[0];
+                    if (chg <= 0) boff = fz_tab_off(pi, tb_i0, a) - pi - 1;
+                    const int ej = boff + pos[1], ek = boff + pos[2];
+                    const float4 tj = s_tab[ej], tk = s_tab[ek], rj = s_tab_r[ej];
+                    const float rk1 = s_tab_r[ek].x;
+                    const double A2j = s_tab_a2[ej];
+                    const int fj = __float_as_int(tj.w), fk = __float_as_int(tk.w);
+                    const float c32 = CORV(fk & FZ_TAB_ZMASK, fj & FZ_TAB_ZMASK);
+                    const TV F1 = pc_l1_r(c32, tk.z, tj.z, rk1, rj.x);
+                    const double dF = sqrt(1.0 - F1.v * F1.v);  // shared by the two level-2 values below
+                    double D2, E2;
+                    if (__all((((fj & fk) >> 29) & 3) == 3 && F1.f32)) {  // wave-uniform fast path: no Float64 literal
+                        D2 = pc_l2_all32_d1(tk.x, tj.x, (float)F1.v, (double)rj.y, dF);
+                        E2 = pc_l2_all32_d1(tk.y, tj.y, (float)F1.v, (double)rj.z, dF);
+                    } else {
+                        const TV D1{(double)tk.x, ((fk >> 30) & 1) != 0}, Bj{(double)tj.x, ((fj >> 30) & 1) != 0};
+                        const TV E1{(double)tk.y, ((fk >> 29) & 1) != 0}, Cj{(double)tj.y, ((fj >> 29) & 1) != 0};
+                        D2 = pc_l2_d2(D1, Bj, F1, dF);
+                        E2 = pc_l2_d2(E1, Cj, F1, dF);
+                    }
+                    stat = pc_l3(A2j, D2, E2);
+                } else if (!TAB && s == 3) {
                     if (chg <= 0) {
                         z1 = ACCV(pos[0]);
                         cXz1 = CORV(X, z1);
@@ -1046,26 +1155,35 @@ int fwi_fz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y
     return FW_OK;
 }
 
-int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb)
+int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out,
+                    FwPoolBuf &pb)
 {
     if (nseg == 0) return FW_OK;
-    FW_HIP(ctx, hipEventRecord(pb.ev0, pb.stream));
+    FW_HIP(ctx, hipEventRecord(pb.ev0, pb.launch_stream));
     if (!ctx->d_thr) {
         FW_HIP(ctx, hipMalloc((void **)&ctx->d_thr, 4 * sizeof(double)));
-        hipLaunchKernelGGL(fz_thresholds_kernel, dim3(1), dim3(64), 0, pb.stream, ctx->P.alpha, fz_zscale(ctx), ctx->d_thr);
+        hipLaunchKernelGGL(fz_thresholds_kernel, dim3(1), dim3(64), 0, pb.launch_stream, ctx->P.alpha, fz_zscale(ctx), ctx->d_thr);
         FW_HIP(ctx, hipGetLastError());
-        FW_HIP(ctx, hipStreamSynchronize(pb.stream));  // the other pool stream may use it next
+        FW_HIP(ctx, hipStreamSynchronize(pb.launch_stream));  // the other pool stream may use it next
     }
     if (ctx->P.max_k > 3)
-        hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false>), dim3((unsigned)nseg), dim3(256), 0, pb.stream, ctx->d_cor,
+        hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false, false>), dim3((unsigned)nseg), dim3(256), 0, pb.launch_stream, ctx->d_cor,
                            ctx->P.p, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx),
                            (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll);
-    else
-        hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false>), dim3((unsigned)nseg), dim3(256), 0, pb.stream, ctx->d_cor,
-                           ctx->P.p, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx),
-                           (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll);
+    else {
+        // segments [0, nseg_tab) belong to jobs with |accepted| <= FZ_TAB_A: table kernel; the rest: in-lane caching
+        if (nseg_tab > 0)
+            hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false, true>), dim3((unsigned)nseg_tab), dim3(256), 0, pb.launch_stream,
+                               ctx->d_cor, ctx->P.p, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx),
+                               (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll);
+        if (nseg > nseg_tab)
+            hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false, false>), dim3((unsigned)(nseg - nseg_tab)), dim3(256), 0,
+                               pb.launch_stream, ctx->d_cor, ctx->P.p, d_segs + nseg_tab, d_acc, d_out + nseg_tab, ctx->P.max_k,
+                               ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr,
+                               0ll);
+    }
     FW_HIP(ctx, hipGetLastError());
-    FW_HIP(ctx, hipEventRecord(pb.ev1, pb.stream));
+    FW_HIP(ctx, hipEventRecord(pb.ev1, pb.launch_stream));
     return FW_OK;
 }
 
@@ -1343,22 +1461,30 @@ int fwi_fznz_submatrices(fw_ctx *ctx, int64_t njobs, const FwNzJob *recs_host, s
     return FW_OK;
 }
 
-int fwi_fznz_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb)
+int fwi_fznz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out,
+                      FwPoolBuf &pb)
 {
     if (nseg == 0) return FW_OK;
-    FW_HIP(ctx, hipEventRecord(pb.ev0, pb.stream));
+    FW_HIP(ctx, hipEventRecord(pb.ev0, pb.launch_stream));
     if (ctx->P.max_k > 3)
-        hipLaunchKernelGGL((fz_subsets_seg_kernel<true, true>), dim3((unsigned)nseg), dim3(256), 0, pb.stream,
+        hipLaunchKernelGGL((fz_subsets_seg_kernel<true, true, false>), dim3((unsigned)nseg), dim3(256), 0, pb.launch_stream,
                            (const float *)ctx->d_arena.ptr, 0, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, 0.0,
                            (long long)ctx->P.max_tests, (const double *)nullptr, (const FwNzJob *)ctx->d_nzrecs.ptr,
                            (long long)ctx->n_obs_min_eff);
-    else
-        hipLaunchKernelGGL((fz_subsets_seg_kernel<false, true>), dim3((unsigned)nseg), dim3(256), 0, pb.stream,
-                           (const float *)ctx->d_arena.ptr, 0, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, 0.0,
-                           (long long)ctx->P.max_tests, (const double *)nullptr, (const FwNzJob *)ctx->d_nzrecs.ptr,
-                           (long long)ctx->n_obs_min_eff);
+    else {
+        if (nseg_tab > 0)
+            hipLaunchKernelGGL((fz_subsets_seg_kernel<false, true, true>), dim3((unsigned)nseg_tab), dim3(256), 0, pb.launch_stream,
+                               (const float *)ctx->d_arena.ptr, 0, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, 0.0,
+                               (long long)ctx->P.max_tests, (const double *)nullptr, (const FwNzJob *)ctx->d_nzrecs.ptr,
+                               (long long)ctx->n_obs_min_eff);
+        if (nseg > nseg_tab)
+            hipLaunchKernelGGL((fz_subsets_seg_kernel<false, true, false>), dim3((unsigned)(nseg - nseg_tab)), dim3(256), 0,
+                               pb.launch_stream, (const float *)ctx->d_arena.ptr, 0, d_segs + nseg_tab, d_acc, d_out + nseg_tab,
+                               ctx->P.max_k, ctx->P.alpha, 0.0, (long long)ctx->P.max_tests, (const double *)nullptr,
+                               (const FwNzJob *)ctx->d_nzrecs.ptr, (long long)ctx->n_obs_min_eff);
+    }
     FW_HIP(ctx, hipGetLastError());
-    FW_HIP(ctx, hipEventRecord(pb.ev1, pb.stream));
+    FW_HIP(ctx, hipEventRecord(pb.ev1, pb.launch_stream));
     return FW_OK;
 }
 

@@ -56,6 +56,7 @@ struct FwSeg {
 };
 
 #define FW_RANK_NONE (~0ull)
+#define FW_TAB_A 512  // fz / fz_nz: largest |accepted| served by the LDS-table kernel (csrc/fw_fz.hip, FZ_TAB_CAP)
 
 // Per-job record of the HE-S (fz_nz) path: the correlation sub-matrix of a job is computed over the rows where both
 // T and the candidate are non-zero (statfuns.jl:138-155 cor_subset!), lives in a device arena and is indexed locally
@@ -91,7 +92,9 @@ struct FwSegOut {
 // per-pool staging: own stream + events so that two pools can be in flight (host merges one while the GPU runs the other)
 struct FwPoolBuf {
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the segment kernel(s) of a launch
+    hipEvent_t evd = nullptr;                 // after the device-to-host copy of the launch's results
+    hipStream_t launch_stream = nullptr;      // stream the launches go to (= stream)
     FwPinned h_in, h_out;  // h_in = [FwSeg x ns | accepted ints]
     FwDevBuf d_in, d_out;
 };
@@ -161,7 +164,7 @@ int fwi_fz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
                   std::vector<double> &pval, int64_t *m_reliable);
 int fwi_fz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff,
                       const int32_t *zflat, fw_test_result *out);
-int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb);
+int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb);
 
 // ---- HE-S / fz_nz (fw_fz.hip) ----
 int fwi_fznz_upload(fw_ctx *ctx, const float *data);
@@ -169,7 +172,7 @@ int fwi_fznz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> 
                     std::vector<double> &pval, int64_t *m_reliable);
 int fwi_fznz_submatrices(fw_ctx *ctx, int64_t njobs, const FwNzJob *recs_host, size_t arena_floats, const int32_t *d_acc,
                          hipStream_t stream);
-int fwi_fznz_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb);
+int fwi_fznz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb);
 int fwi_fznz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff,
                         const int32_t *zflat, fw_test_result *out);
 

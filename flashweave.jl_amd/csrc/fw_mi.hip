@@ -1062,10 +1062,10 @@ int fwi_mi_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y
 int fwi_mi_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb)
 {
     if (nseg == 0) return FW_OK;
-    FW_HIP(ctx, hipEventRecord(pb.ev0, pb.stream));
-    hipLaunchKernelGGL(mi_subsets_seg_kernel, dim3((unsigned)nseg), dim3(256), 0, pb.stream, mi_dev(ctx), d_segs, d_acc, d_out,
+    FW_HIP(ctx, hipEventRecord(pb.ev0, pb.launch_stream));
+    hipLaunchKernelGGL(mi_subsets_seg_kernel, dim3((unsigned)nseg), dim3(256), 0, pb.launch_stream, mi_dev(ctx), d_segs, d_acc, d_out,
                        ctx->P.max_k, ctx->P.alpha, (long long)ctx->P.max_tests);
     FW_HIP(ctx, hipGetLastError());
-    FW_HIP(ctx, hipEventRecord(pb.ev1, pb.stream));
+    FW_HIP(ctx, hipEventRecord(pb.ev1, pb.launch_stream));
     return FW_OK;
 }
