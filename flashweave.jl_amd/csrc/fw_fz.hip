@@ -620,6 +620,7 @@ __device__ __forceinline__ int fz_tab_off(int i, int i0, int a)
 #define FZ_X_NONE 1.0e308    // "no candidate yet"
 #define FZ_X_SUB 26.0        // beyond this x = |z|/sqrt2, erfc(x)/2*2 leaves the normal range (ties become possible)
 #define FZ_X_SUBKEY 1.0e300  // common x-key of the underflow regime (ordered by exact p there)
+#define FZ_X_LAZY (-1.0)     // lane best taken by |r| alone; its x-key is computed at the end of the run
 
 // (xa, pa, ra) strictly better than (xb, pb, rb)?  smaller x-key = larger p; equal keys: larger exact p, then later rank
 __device__ __forceinline__ bool fz_key_better(double xa, double pa, unsigned long long ra, double xb, double pb,
@@ -730,6 +731,8 @@ __global__ __launch_bounds__(256, 3) void fz_subsets_seg_kernel(const float *__r
     for (int s = FW_MAX_K; s >= 1; --s) cnt[s] = (s <= max_k) ? binom_u64(a, s) : 0ull;
     // significance thresholds on |r| (see fz_thresholds_kernel): outside [lo, hi] the verdict of p < alpha is certain
     const double rlo_pos = thr[0], rhi_pos = thr[1], rlo_neg = thr[2], rhi_neg = thr[3];
+    // |r| below which x = |z|/sqrt2 < FZ_X_SUB for sure: x = zscale * log((1+r)/(1-r)) / sqrt2  <=>  r = tanh(x / (sqrt2 zscale))
+    const double rsub_lo = zscale > 0.0 ? tanh(FZ_X_SUB * 0.7071067811865476 / zscale) * (1.0 - 1e-9) : 2.0;
     __syncthreads();
 #define ACCV(i) (LOCAL ? ((i) + 2) : (in_lds ? s_acc[(i)] : gacc[(i)]))
 #define CORV(u, v) cor[(size_t)(u) * p + (v)]
@@ -909,9 +912,32 @@ __global__ __launch_bounds__(256, 3) void fz_subsets_seg_kernel(const float *__r
                     stop_p = fz_pval_dev(stat, zscale);
                     break;
                 }
-                // tests.jl:338 `pval >= lowest.pval`, sequential within the run, without evaluating p for every test:
-                // |r| can only matter if it is not clearly larger than the current best's
-                if (my_bx == FZ_X_NONE || my_bx > FZ_X_SUB || av <= my_ba * (1.0 + 1e-12)) {
+                // tests.jl:338 `pval >= lowest.pval`, sequential within the run, without evaluating p (or even z) for
+                // every test.  In the normal regime (|r| < rsub_lo, i.e. x < FZ_X_SUB) p is strictly decreasing in |r|
+                // once two values differ by more than rounding noise, so a clearly smaller |r| replaces the lane best
+                // "lazily" (x is computed once per run, below), a clearly larger one is skipped, and only near-ties and
+                // the underflow regime take the exact path.
+                bool exact = false, lazy_take = false;
+                if (av < rsub_lo) {
+                    if (my_bx == FZ_X_NONE || my_bx > FZ_X_SUB)
+                        lazy_take = true;  // nothing yet, or the best so far sits in the underflow regime (smaller p)
+                    else if (av < my_ba * (1.0 - 1e-12))
+                        lazy_take = true;
+                    else
+                        exact = av <= my_ba * (1.0 + 1e-12);
+                } else {
+                    exact = true;
+                }
+                if (lazy_take) {
+                    my_bx = FZ_X_LAZY;
+                    my_bps = 0.0;
+                    my_ba = av;
+                    my_br = r;
+                    my_bstat = stat;
+                }
+                if (exact) {
+                    if (my_bx == FZ_X_LAZY)
+                        my_bx = fabs(zscale * log((1.0 + my_bstat) / (1.0 - my_bstat))) * 0.7071067811865476;
                     const double xz = fabs(zscale * log((1.0 + stat) / (1.0 - stat))) * 0.7071067811865476;
                     bool take;
                     double ps = 0.0;
@@ -945,6 +971,8 @@ __global__ __launch_bounds__(256, 3) void fz_subsets_seg_kernel(const float *__r
                 }
             }
         }
+        if (my_bx == FZ_X_LAZY)  // resolve the lazily kept lane best: its x-key
+            my_bx = fabs(zscale * log((1.0 + my_bstat) / (1.0 - my_bstat))) * 0.7071067811865476;
         // first stopping rank in the workgroup
         unsigned long long ws = my_stop;
 #pragma unroll
