@@ -638,7 +638,11 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
     if ((rc = fw_pin_reserve(c, pb.h_in, in_bytes))) return rc;
     if ((rc = fw_pin_reserve(c, pb.h_out, ns * sizeof(FwSegOut)))) return rc;
     if ((rc = fw_dev_reserve(c, pb.d_in, in_bytes))) return rc;
-    if ((rc = fw_dev_reserve(c, pb.d_out, ns * sizeof(FwSegOut)))) return rc;
+    // results: one 64-byte record per workgroup, written straight into pinned host memory (posted PCIe writes) -- saves
+    // the device-to-host copy of every round; FW_ZC_OUT=0 stages them through device memory instead (profiling knob)
+    static const bool zc_out = !(getenv("FW_ZC_OUT") && atoi(getenv("FW_ZC_OUT")) == 0);
+    if (!zc_out && (rc = fw_dev_reserve(c, pb.d_out, ns * sizeof(FwSegOut)))) return rc;
+    FwSegOut *dout = zc_out ? (FwSegOut *)pb.h_out.ptr : (FwSegOut *)pb.d_out.ptr;
     FwSeg *segs = (FwSeg *)pb.h_in.ptr;
     int32_t *hacc = (int32_t *)((char *)pb.h_in.ptr + ns * sizeof(FwSeg));
     pool.seg_job.resize(ns);
@@ -686,19 +690,22 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
     }
     const double tb1 = now_s();
     c->cnt.t_host_build_s += tb1 - tb0;
-    FW_HIP(c, hipMemcpyAsync(pb.d_in.ptr, pb.h_in.ptr, in_bytes, hipMemcpyHostToDevice, pb.launch_stream));
-    const FwSeg *dsegs = (const FwSeg *)pb.d_in.ptr;
-    const int32_t *dacc = (const int32_t *)((const char *)pb.d_in.ptr + ns * sizeof(FwSeg));
+    static const bool zc_in = getenv("FW_ZC_IN") && atoi(getenv("FW_ZC_IN")) == 1;  // experiment: read inputs over PCIe
+    if (!zc_in) FW_HIP(c, hipMemcpyAsync(pb.d_in.ptr, pb.h_in.ptr, in_bytes, hipMemcpyHostToDevice, pb.launch_stream));
+    const char *in_base = zc_in ? (const char *)pb.h_in.ptr : (const char *)pb.d_in.ptr;
+    const FwSeg *dsegs = (const FwSeg *)in_base;
+    const int32_t *dacc = (const int32_t *)(in_base + ns * sizeof(FwSeg));
     if (nzs) {
         rc = fwi_fznz_submatrices(c, (int64_t)pool.nzrecs.size(), pool.nzrecs.data(), arena_floats, dacc, pb.launch_stream);
         if (rc) return rc;
-        rc = fwi_fznz_segments(c, (int64_t)ns, (int64_t)ns_tab, dsegs, dacc, (FwSegOut *)pb.d_out.ptr, pb);
+        rc = fwi_fznz_segments(c, (int64_t)ns, (int64_t)ns_tab, dsegs, dacc, dout, pb);
     } else {
-        rc = fz ? fwi_fz_segments(c, (int64_t)ns, (int64_t)ns_tab, dsegs, dacc, (FwSegOut *)pb.d_out.ptr, pb)
-                : fwi_mi_segments(c, (int64_t)ns, dsegs, dacc, (FwSegOut *)pb.d_out.ptr, pb);
+        rc = fz ? fwi_fz_segments(c, (int64_t)ns, (int64_t)ns_tab, dsegs, dacc, dout, pb)
+                : fwi_mi_segments(c, (int64_t)ns, dsegs, dacc, dout, pb);
     }
     if (rc) return rc;
-    FW_HIP(c, hipMemcpyAsync(pb.h_out.ptr, pb.d_out.ptr, ns * sizeof(FwSegOut), hipMemcpyDeviceToHost, pb.launch_stream));
+    if (!zc_out)
+        FW_HIP(c, hipMemcpyAsync(pb.h_out.ptr, pb.d_out.ptr, ns * sizeof(FwSegOut), hipMemcpyDeviceToHost, pb.launch_stream));
     FW_HIP(c, hipEventRecord(pb.evd, pb.launch_stream));
     pool.ns = ns;
     pool.inflight = true;
