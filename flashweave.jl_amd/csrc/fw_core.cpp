@@ -519,7 +519,7 @@ static void unrank_host(uint64_t r, int a, int max_k, int *s_out, int *pos)
 
 // geometric growth of the evaluation window of a job (speculation bound vs number of latency-bound rounds);
 // FW_WINDOW_GROWTH is a tuning knob for profiling runs
-static uint64_t fw_window_growth(size_t n_live)
+static uint64_t fw_window_growth(size_t n_live, uint64_t launched_ranks)
 {
     static const long forced = [] {
         const char *e = getenv("FW_WINDOW_GROWTH");
@@ -528,7 +528,14 @@ static uint64_t fw_window_growth(size_t n_live)
     }();
     if (forced) return (uint64_t)forced;
     // many jobs in flight: launches are full, keep speculation tight (x4); few jobs: the round latency dominates
-    // and a wider window (x16) saves rounds (measured on cfg3: 3236 -> 2024 launches for +9 % evaluated tests)
+    // and a wider window (x16) saves rounds (measured on cfg3: 3236 -> 2024 launches for +9 % evaluated tests);
+    // a launch that does not even fill the GPU (a few thousand workgroups of 256 ranks) costs the same whether its
+    // windows are 16 or 256 times larger: grow faster there, the extra speculative tests are free
+    static const uint64_t small = [] {
+        const char *e = getenv("FW_SMALL_LAUNCH");
+        return e ? (uint64_t)atoll(e) : (uint64_t)(1u << 22);  // cfg3 sweep: 0 -> 630 ms, 1M 613, 4M 569, 8M 588, 64M 582
+    }();
+    if (launched_ranks < small) return 256;
     return n_live > 2048 ? 4 : 16;
 }
 
@@ -625,6 +632,7 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
         total += std::min(j.width, j.N - j.next);
         acc_total += j.acc.size();
     }
+    pool.launched_ranks = total;
     if (n_launch == 0) return FW_OK;  // everything is on hold: nothing to do this round
     // fz: one lane per test (256-rank granularity); discrete: one wavefront per test (4-rank granularity)
     const uint64_t q = fz ? 256 : 4, smin = fz ? 256 : 8, smax = fz ? 8192 : 256;
@@ -781,7 +789,7 @@ int fwi_pool_collect(fw_ctx *c, FwPool &pool, std::vector<FwPoolJob> &finished)
         }
     }
     size_t w = 0;
-    const uint64_t growth = fw_window_growth(pool.live.size());
+    const uint64_t growth = fw_window_growth(pool.live.size(), pool.launched_ranks);
     for (size_t ji = 0; ji < pool.live.size(); ++ji) {
         FwPoolJob &j = pool.live[ji];
         if (!j.done && j.launched) {

@@ -212,6 +212,7 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
             // latency-bound rounds shrinks.  Every pool round = one window of every in-flight job = ONE kernel launch.
             constexpr int FW_SPEC_DEPTH = 8;
             constexpr long FW_SPEC_TARGETS = 512;
+
             long n_unfinished = (long)tg.size();
             FwPool pool;
             std::vector<int32_t> epoch(tg.size(), 0);

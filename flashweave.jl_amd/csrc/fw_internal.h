@@ -215,6 +215,7 @@ struct FwPool {
     double dropped_alg_bytes = 0.0;
     bool inflight = false;  // a window launch is pending (fwi_pool_launch without fwi_pool_collect)
     size_t ns = 0;
+    uint64_t launched_ranks = 0;  // ranks of the pending / last launch (window-growth policy)
     double t_launch = 0.0;
 };
 int fwi_pool_launch(fw_ctx *ctx, FwPool &pool);                                    // asynchronous
