@@ -167,6 +167,7 @@ int fw_ctx_destroy(fw_ctx *c)
         free_pin(b.h_out);
         free_dev(b.d_in);
         free_dev(b.d_out);
+        free_dev(b.d_acc);
         if (b.ev0) (void)hipEventDestroy(b.ev0);
         if (b.ev1) (void)hipEventDestroy(b.ev1);
         if (b.evd) (void)hipEventDestroy(b.evd);
@@ -641,11 +642,27 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
     size_t ns = 0;
     for (const FwPoolJob &j : pool.live)
         if (j.launched) ns += (size_t)((std::min(j.width, j.N - j.next) + seglen - 1) / seglen);
-    const size_t in_bytes = ns * sizeof(FwSeg) + std::max<size_t>(acc_total, 1) * sizeof(int32_t);
+    // Accepted lists live in a device arena for as long as their job does: a job uploads its list once, with its
+    // first window, not with every window (at cfg3 the lists of ~1500 live jobs are ~1 MB per round).  The arena is a
+    // bump allocator; when it is full every live job is re-staged from offset 0.
     int rc;
+    size_t new_ints = 0;
+    for (const FwPoolJob &j : pool.live)
+        if (j.launched && j.acc_dev_off < 0) new_ints += j.acc.size();
+    if (pool.arena_top + new_ints > pb.d_acc.cap / sizeof(int32_t) || pool.arena_top == 0) {
+        size_t live_ints = 0;
+        for (FwPoolJob &j : pool.live) {
+            j.acc_dev_off = -1;
+            live_ints += j.acc.size();
+        }
+        if ((rc = fw_dev_reserve(c, pb.d_acc, std::max<size_t>(4 * live_ints, (size_t)1 << 20) * sizeof(int32_t)))) return rc;
+        pool.arena_top = 0;
+        new_ints = acc_total;
+    }
+    const size_t in_bytes = ns * sizeof(FwSeg) + std::max<size_t>(new_ints, 1) * sizeof(int32_t);
     if ((rc = fw_pin_reserve(c, pb.h_in, in_bytes))) return rc;
     if ((rc = fw_pin_reserve(c, pb.h_out, ns * sizeof(FwSegOut)))) return rc;
-    if ((rc = fw_dev_reserve(c, pb.d_in, in_bytes))) return rc;
+    if ((rc = fw_dev_reserve(c, pb.d_in, ns * sizeof(FwSeg)))) return rc;
     // results: one 64-byte record per workgroup, written straight into pinned host memory (posted PCIe writes) -- saves
     // the device-to-host copy of every round; FW_ZC_OUT=0 stages them through device memory instead (profiling knob)
     static const bool zc_out = !(getenv("FW_ZC_OUT") && atoi(getenv("FW_ZC_OUT")) == 0);
@@ -657,16 +674,21 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
     pool.nzrecs.clear();
     size_t arena_floats = 0;
     size_t si = 0, ns_tab = 0;
-    int64_t aoff = 0;
+    size_t staged = 0;
     // fz / fz_nz with max_k <= 3: segments of jobs with at most FW_TAB_A accepted variables come first (table kernel)
     static const bool no_tab = getenv("FW_NO_TAB") != nullptr;  // profiling knob: force the in-lane caching kernel
     const bool split = fz && c->P.max_k <= 3 && !no_tab;
     for (int pass = 0; pass < (split ? 2 : 1); ++pass) {
         for (size_t ji = 0; ji < pool.live.size(); ++ji) {
-            const FwPoolJob &j = pool.live[ji];
+            FwPoolJob &j = pool.live[ji];
             if (!j.launched) continue;
             if (split && (j.acc.size() <= FW_TAB_A) != (pass == 0)) continue;
-            memcpy(hacc + aoff, j.acc.data(), j.acc.size() * sizeof(int32_t));
+            if (j.acc_dev_off < 0) {
+                memcpy(hacc + staged, j.acc.data(), j.acc.size() * sizeof(int32_t));
+                j.acc_dev_off = (int64_t)(pool.arena_top + staged);
+                staged += j.acc.size();
+            }
+            const int64_t aoff = j.acc_dev_off;
             const uint64_t lo = j.next, hi = lo + std::min(j.width, j.N - lo);
             for (uint64_t sgs = lo; sgs < hi; sgs += seglen) {
                 FwSeg sg{};
@@ -692,17 +714,18 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
                 arena_floats += (size_t)r.m * r.m;
                 pool.nzrecs.push_back(r);
             }
-            aoff += (int64_t)j.acc.size();
         }
         if (split && pass == 0) ns_tab = si;
     }
     const double tb1 = now_s();
     c->cnt.t_host_build_s += tb1 - tb0;
-    static const bool zc_in = getenv("FW_ZC_IN") && atoi(getenv("FW_ZC_IN")) == 1;  // experiment: read inputs over PCIe
-    if (!zc_in) FW_HIP(c, hipMemcpyAsync(pb.d_in.ptr, pb.h_in.ptr, in_bytes, hipMemcpyHostToDevice, pb.launch_stream));
-    const char *in_base = zc_in ? (const char *)pb.h_in.ptr : (const char *)pb.d_in.ptr;
-    const FwSeg *dsegs = (const FwSeg *)in_base;
-    const int32_t *dacc = (const int32_t *)(in_base + ns * sizeof(FwSeg));
+    FW_HIP(c, hipMemcpyAsync(pb.d_in.ptr, pb.h_in.ptr, ns * sizeof(FwSeg), hipMemcpyHostToDevice, pb.launch_stream));
+    if (staged)
+        FW_HIP(c, hipMemcpyAsync((int32_t *)pb.d_acc.ptr + pool.arena_top, hacc, staged * sizeof(int32_t), hipMemcpyHostToDevice,
+                                 pb.launch_stream));
+    pool.arena_top += staged;
+    const FwSeg *dsegs = (const FwSeg *)pb.d_in.ptr;
+    const int32_t *dacc = (const int32_t *)pb.d_acc.ptr;
     if (nzs) {
         rc = fwi_fznz_submatrices(c, (int64_t)pool.nzrecs.size(), pool.nzrecs.data(), arena_floats, dacc, pb.launch_stream);
         if (rc) return rc;

@@ -97,6 +97,7 @@ struct FwPoolBuf {
     hipStream_t launch_stream = nullptr;      // stream the launches go to (= stream)
     FwPinned h_in, h_out;  // h_in = [FwSeg x ns | accepted ints]
     FwDevBuf d_in, d_out;
+    FwDevBuf d_acc;  // arena of the live jobs' accepted lists (uploaded once per job, not once per round)
 };
 
 struct fw_ctx {
@@ -197,6 +198,7 @@ struct FwPoolJob {
     bool launched = false; // set by fwi_pool_launch for the jobs that are part of the pending window
     bool no_zs = false;    // the returned result has no conditioning set (fz_nz job without a test)
     std::vector<int32_t> acc;
+    int64_t acc_dev_off = -1;  // offset (ints) of this job's accepted list in the pool buffer's device arena, -1 = not uploaded
     uint64_t N = 0, next = 0, width = 0;
     double best_p = -1.0, best_stat = 0.0;
     uint64_t best_rank = 0;
@@ -216,6 +218,7 @@ struct FwPool {
     bool inflight = false;  // a window launch is pending (fwi_pool_launch without fwi_pool_collect)
     size_t ns = 0;
     uint64_t launched_ranks = 0;  // ranks of the pending / last launch (window-growth policy)
+    size_t arena_top = 0;         // ints used in pb.d_acc (accepted lists stay resident while their job lives)
     double t_launch = 0.0;
 };
 int fwi_pool_launch(fw_ctx *ctx, FwPool &pool);                                    // asynchronous
