@@ -209,6 +209,20 @@ __global__ __launch_bounds__(256) void fz_cor_gemm_kernel(const float *__restric
 // ------------------------------------------------------------------------------------------------
 // 3. shared device math
 // ------------------------------------------------------------------------------------------------
+// out of line for the segment kernel: inlined, the ~70 polynomial coefficients of log / erfc are hoisted into VGPRs
+// across the hot loop, which only reaches this code for tests inside the significance guard band
+__device__ __noinline__ double fz_pval_slow(double r, double zscale)
+{
+    double z = (zscale > 0.0) ? zscale * log((1.0 + r) / (1.0 - r)) : 0.0;
+    double cc = erfc(fabs(z) * 0.7071067811865476) / 2.0;
+    return cc * 2.0;
+}
+// x-key of the max-p tracking: |z| / sqrt2 (see FZ_X_SUB)
+__device__ __noinline__ double fz_xkey_slow(double r, double zscale)
+{
+    return fabs(zscale * log((1.0 + r) / (1.0 - r))) * 0.7071067811865476;
+}
+
 __device__ __forceinline__ double fz_pval_dev(double r, double zscale /* sqrt(n-3)/2, 0 if n <= 3 */)
 {
     // statfuns.jl:3-17; ccdf(Normal(), x) = erfc(x / sqrt2) / 2 (StatsFuns.normccdf)
@@ -665,7 +679,7 @@ __global__ void fz_thresholds_kernel(double alpha, double zscale, double *thr)
 // HIGHK: subsets of size 4-5 possible; LOCAL: per-job matrices (fz_nz); TAB: size-3 subsets through the LDS table
 // (the host routes only segments of jobs with |accepted| <= FZ_TAB_A to a TAB launch; never together with HIGHK)
 template <bool HIGHK, bool LOCAL, bool TAB>
-__global__ __launch_bounds__(256, 3) void fz_subsets_seg_kernel(const float *__restrict__ cor_g, int p_g,
+__global__ __launch_bounds__(256, 4) void fz_subsets_seg_kernel(const float *__restrict__ cor_g, int p_g,
                                                              const FwSeg *__restrict__ segs,
                                                              const int32_t *__restrict__ accflat,
                                                              FwSegOut *__restrict__ out, int max_k, double alpha,
@@ -673,14 +687,15 @@ __global__ __launch_bounds__(256, 3) void fz_subsets_seg_kernel(const float *__r
                                                              const double *__restrict__ thr_g,
                                                              const FwNzJob *__restrict__ recs, long long n_obs_min)
 {
-    __shared__ int s_acc[FW_ACC_LDS];
+    __shared__ int s_acc[TAB ? FZ_TAB_A : FW_ACC_LDS];  // TAB: |accepted| <= FZ_TAB_A by the host's routing
     __shared__ unsigned long long s_stop[4];
     __shared__ double s_bx[4], s_bps[4];
     __shared__ unsigned long long s_br[4];
     __shared__ double s_best_x, s_best_ps, s_best_stat;
     __shared__ unsigned long long s_best_rank;
     __shared__ float4 s_tab[TAB ? FZ_TAB_CAP : 1];    // {LX, LY, cor[v][z1], variable id | Float32 flags}
-    __shared__ float4 s_tab_r[TAB ? FZ_TAB_CAP : 1];  // {sqrt(1 - cor[v][z1]^2), sqrt(1 - LX^2), sqrt(1 - LY^2), -} in Float32
+    __shared__ float s_tab_r1[TAB ? FZ_TAB_CAP : 1];   // sqrt(1 - cor[v][z1]^2)                       (Float32 roots)
+    __shared__ float2 s_tab_r2[TAB ? FZ_TAB_CAP : 1];  // {sqrt(1 - LX^2), sqrt(1 - LY^2)}
     __shared__ double s_tab_a2[TAB ? FZ_TAB_CAP : 1]; // rho(X, Y | z1, v)
     __shared__ int s_blk[2];
 
@@ -688,7 +703,7 @@ __global__ __launch_bounds__(256, 3) void fz_subsets_seg_kernel(const float *__r
     const int a = seg.acc_len;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int32_t *gacc = accflat + seg.acc_off;
-    const bool in_lds = a <= FW_ACC_LDS;
+    const bool in_lds = a <= (TAB ? FZ_TAB_A : FW_ACC_LDS);
     const float *cor = cor_g;
     int p = p_g;
     double zscale = zscale_g;
@@ -784,7 +799,8 @@ __global__ __launch_bounds__(256, 3) void fz_subsets_seg_kernel(const float *__r
                         // square roots the level-1 / level-2 formulas take of this entry's values (statfuns.jl:36,52);
                         // for a Float64-literal LX / LY (0, +-1) the Float32 root is the exact one as well
                         const float fx = (float)LX.v, fy = (float)LY.v;
-                        s_tab_r[e] = make_float4(sqrtf(1.0f - cvz1 * cvz1), sqrtf(1.0f - fx * fx), sqrtf(1.0f - fy * fy), 0.0f);
+                        s_tab_r1[e] = sqrtf(1.0f - cvz1 * cvz1);
+                        s_tab_r2[e] = make_float2(sqrtf(1.0f - fx * fx), sqrtf(1.0f - fy * fy));
                         s_tab[e] = make_float4((float)LX.v, (float)LY.v, cvz1,
                                                __int_as_float(zv | (LX.f32 ? (1 << 30) : 0) | (LY.f32 ? (1 << 29) : 0)));
                     }
@@ -823,17 +839,18 @@ __global__ __launch_bounds__(256, 3) void fz_subsets_seg_kernel(const float *__r
                     const int pi = pos[0];
                     if (chg <= 0) boff = fz_tab_off(pi, tb_i0, a) - pi - 1;
                     const int ej = boff + pos[1], ek = boff + pos[2];
-                    const float4 tj = s_tab[ej], tk = s_tab[ek], rj = s_tab_r[ej];
-                    const float rk1 = s_tab_r[ek].x;
+                    const float4 tj = s_tab[ej], tk = s_tab[ek];
+                    const float rj1 = s_tab_r1[ej], rk1 = s_tab_r1[ek];
+                    const float2 rj2 = s_tab_r2[ej];
                     const double A2j = s_tab_a2[ej];
                     const int fj = __float_as_int(tj.w), fk = __float_as_int(tk.w);
                     const float c32 = CORV(fk & FZ_TAB_ZMASK, fj & FZ_TAB_ZMASK);
-                    const TV F1 = pc_l1_r(c32, tk.z, tj.z, rk1, rj.x);
+                    const TV F1 = pc_l1_r(c32, tk.z, tj.z, rk1, rj1);
                     const double dF = sqrt(1.0 - F1.v * F1.v);  // shared by the two level-2 values below
                     double D2, E2;
                     if (__all((((fj & fk) >> 29) & 3) == 3 && F1.f32)) {  // wave-uniform fast path: no Float64 literal
-                        D2 = pc_l2_all32_d1(tk.x, tj.x, (float)F1.v, (double)rj.y, dF);
-                        E2 = pc_l2_all32_d1(tk.y, tj.y, (float)F1.v, (double)rj.z, dF);
+                        D2 = pc_l2_all32_d1(tk.x, tj.x, (float)F1.v, (double)rj2.x, dF);
+                        E2 = pc_l2_all32_d1(tk.y, tj.y, (float)F1.v, (double)rj2.y, dF);
                     } else {
                         const TV D1{(double)tk.x, ((fk >> 30) & 1) != 0}, Bj{(double)tj.x, ((fj >> 30) & 1) != 0};
                         const TV E1{(double)tk.y, ((fk >> 29) & 1) != 0}, Cj{(double)tj.y, ((fj >> 29) & 1) != 0};
@@ -905,11 +922,11 @@ __global__ __launch_bounds__(256, 3) void fz_subsets_seg_kernel(const float *__r
                 else if (av < (negr ? rlo_neg : rlo_pos))
                     sig = false;
                 else
-                    sig = fz_pval_dev(stat, zscale) < alpha;  // inside the guard band (or NaN): exact
+                    sig = fz_pval_slow(stat, zscale) < alpha;  // inside the guard band (or NaN): exact
                 if (!sig || (max_tests > 0 && r + 1 >= (unsigned long long)max_tests)) {
                     my_stop = r;
                     stop_stat = stat;
-                    stop_p = fz_pval_dev(stat, zscale);
+                    stop_p = fz_pval_slow(stat, zscale);
                     break;
                 }
                 // tests.jl:338 `pval >= lowest.pval`, sequential within the run, without evaluating p (or even z) for
@@ -937,12 +954,12 @@ __global__ __launch_bounds__(256, 3) void fz_subsets_seg_kernel(const float *__r
                 }
                 if (exact) {
                     if (my_bx == FZ_X_LAZY)
-                        my_bx = fabs(zscale * log((1.0 + my_bstat) / (1.0 - my_bstat))) * 0.7071067811865476;
-                    const double xz = fabs(zscale * log((1.0 + stat) / (1.0 - stat))) * 0.7071067811865476;
+                        my_bx = fz_xkey_slow(my_bstat, zscale);
+                    const double xz = fz_xkey_slow(stat, zscale);
                     bool take;
                     double ps = 0.0;
                     if (xz > FZ_X_SUB) {
-                        ps = fz_pval_dev(stat, zscale);  // exact (possibly subnormal / zero) p
+                        ps = fz_pval_slow(stat, zscale);  // exact (possibly subnormal / zero) p
                         take = (my_bx == FZ_X_NONE) || (my_bx > FZ_X_SUB && ps >= my_bps);
                     } else {
                         take = (my_bx == FZ_X_NONE) || (my_bx > FZ_X_SUB) || (xz <= my_bx);
@@ -972,7 +989,7 @@ __global__ __launch_bounds__(256, 3) void fz_subsets_seg_kernel(const float *__r
             }
         }
         if (my_bx == FZ_X_LAZY)  // resolve the lazily kept lane best: its x-key
-            my_bx = fabs(zscale * log((1.0 + my_bstat) / (1.0 - my_bstat))) * 0.7071067811865476;
+            my_bx = fz_xkey_slow(my_bstat, zscale);
         // first stopping rank in the workgroup
         unsigned long long ws = my_stop;
 #pragma unroll
@@ -1052,7 +1069,7 @@ __global__ __launch_bounds__(256, 3) void fz_subsets_seg_kernel(const float *__r
         o.stop_pval = 0.0;
         o.best_rank = s_best_rank;
         o.best_stat = s_best_stat;
-        o.best_pval = (s_best_x == FZ_X_NONE) ? -1.0 : fz_pval_dev(s_best_stat, zscale);
+        o.best_pval = (s_best_x == FZ_X_NONE) ? -1.0 : fz_pval_slow(s_best_stat, zscale);
         o.stop_df = 0;
         o.stop_power = 1;
         o.best_df = 0;
