@@ -210,8 +210,8 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
             // first acceptance bumps the target's epoch, which cancels / voids everything posted after it.  The sequence
             // of committed (T, candidate, accepted) jobs is therefore exactly the reference's; only the number of
             // latency-bound rounds shrinks.  Every pool round = one window of every in-flight job = ONE kernel launch.
-            constexpr int FW_SPEC_DEPTH = 8;
-            constexpr long FW_SPEC_TARGETS = 512;
+            static const int FW_SPEC_DEPTH = [] { const char *e = getenv("FW_SPEC_DEPTH"); return e ? atoi(e) : 8; }();
+            static const long FW_SPEC_TARGETS = [] { const char *e = getenv("FW_SPEC_TARGETS"); return e ? atol(e) : 512l; }();
 
             long n_unfinished = (long)tg.size();
             FwPool pool;
