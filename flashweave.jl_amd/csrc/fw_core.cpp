@@ -158,6 +158,7 @@ int fw_ctx_destroy(fw_ctx *c)
     free_dev(c->d_segout);
     free_dev(c->d_nzrecs);
     free_dev(c->d_arena);
+    free_dev(c->d_bh);
     free_pin(c->h_jobs);
     free_pin(c->h_acc);
     free_pin(c->h_out);
@@ -330,10 +331,27 @@ int fw_level0(fw_ctx *c, int64_t *nnz_out)
     std::vector<int32_t> pi, pj;
     std::vector<double> stat, pval;
     int64_t m = 0;
-    int rc = (c->P.kind == FW_FZ)      ? fwi_fz_level0(c, pi, pj, stat, pval, &m)
-             : (c->P.kind == FW_FZ_NZ) ? fwi_fznz_level0(c, pi, pj, stat, pval, &m)
-                                       : fwi_mi_level0(c, pi, pj, stat, pval, &m);
+    // BH + neighbour lists run on the device (fw_bh.hip); FW_HOST_BH=1 keeps the host restatement below, which
+    // tests/test_gpu_*.py use to cross-check the two
+    const char *hb_env = getenv("FW_HOST_BH");
+    const bool host_bh = hb_env && atoi(hb_env) == 1;
+    FwL0Dev dev;
+    FwL0Dev *devp = host_bh ? nullptr : &dev;
+    int rc = (c->P.kind == FW_FZ)      ? fwi_fz_level0(c, pi, pj, stat, pval, &m, devp)
+             : (c->P.kind == FW_FZ_NZ) ? fwi_fznz_level0(c, pi, pj, stat, pval, &m, devp)
+                                       : fwi_mi_level0(c, pi, pj, stat, pval, &m, devp);
     if (rc) return rc;
+    if (!host_bh) {
+        const double t_bh0 = now_s();
+        if ((rc = fwi_bh_csr_device(c, dev, m))) return rc;
+        c->cnt.t_level0_host_s += now_s() - t_bh0;  // here: the device epilogue incl. its device-to-host copies
+        c->have_level0 = true;
+        c->have_network = false;
+        c->cnt.level0_tests += (int64_t)p * (p - 1) / 2;
+        c->cnt.t_level0_s += now_s() - t0;
+        if (nnz_out) *nnz_out = c->nb_off[p];
+        return FW_OK;
+    }
     const size_t k = pi.size();
     const double t_host0 = now_s();
     if (c->P.fdr && k > 0) {

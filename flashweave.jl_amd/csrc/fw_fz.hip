@@ -1111,8 +1111,9 @@ int fwi_fz_compute_cor(fw_ctx *ctx)
 }
 
 int fwi_fz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &pj, std::vector<double> &stat,
-                  std::vector<double> &pval, int64_t *m_reliable)
+                  std::vector<double> &pval, int64_t *m_reliable, FwL0Dev *dev)
 {
+    if (dev) *dev = FwL0Dev{};
     const int p = ctx->P.p;
     const long long npairs = (long long)p * (p - 1) / 2;
     if (ctx->P.n < ctx->n_obs_min_eff) {  // tests.jl:11 -> every test lacks power -> all NaN
@@ -1145,6 +1146,15 @@ int fwi_fz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
         ctx->cnt.kernel_launches += 1;
         if (h.n_sig <= cap) {
             const size_t k = (size_t)h.n_sig;
+            if (dev) {  // results stay on the device for fwi_bh_csr_device
+                dev->i = oi;
+                dev->j = oj;
+                dev->stat32 = orr;
+                dev->pval = op;
+                dev->k = k;
+                *m_reliable = npairs - (long long)h.n_nan;
+                return FW_OK;
+            }
             pi.resize(k);
             pj.resize(k);
             stat.resize(k);
@@ -1447,8 +1457,9 @@ int fwi_fznz_upload(fw_ctx *ctx, const float *data)
 }
 
 int fwi_fznz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &pj, std::vector<double> &stat,
-                    std::vector<double> &pval, int64_t *m_reliable)
+                    std::vector<double> &pval, int64_t *m_reliable, FwL0Dev *dev)
 {
+    if (dev) *dev = FwL0Dev{};
     const int p = ctx->P.p;
     const long long npairs = (long long)p * (p - 1) / 2;
     unsigned long long cap = (unsigned long long)std::min<long long>(npairs, 4ll << 20);
@@ -1472,6 +1483,15 @@ int fwi_fznz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> 
         ctx->cnt.kernel_launches += 1;
         if (h.n_sig <= cap) {
             const size_t k = (size_t)h.n_sig;
+            if (dev) {
+                dev->i = oi;
+                dev->j = oj;
+                dev->stat64 = os;
+                dev->pval = op;
+                dev->k = k;
+                *m_reliable = npairs - (long long)h.n_nan;
+                return FW_OK;
+            }
             pi.resize(k);
             pj.resize(k);
             stat.resize(k);

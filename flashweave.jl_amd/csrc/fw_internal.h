@@ -90,6 +90,15 @@ struct FwSegOut {
 };
 
 // per-pool staging: own stream + events so that two pools can be in flight (host merges one while the GPU runs the other)
+// significant level-0 pairs as the kernels leave them in device memory (i < j; statistic in Float64 or Float32)
+struct FwL0Dev {
+    const int32_t *i = nullptr, *j = nullptr;
+    const double *stat64 = nullptr;
+    const float *stat32 = nullptr;
+    const double *pval = nullptr;
+    size_t k = 0;
+};
+
 struct FwPoolBuf {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the segment kernel(s) of a launch
@@ -143,6 +152,7 @@ struct fw_ctx {
 
     // grow-only scratch
     FwDevBuf d_jobs, d_acc, d_out, d_tmp0, d_tmp1, d_tmp2, d_segs, d_segout, d_nzrecs, d_arena;
+    FwDevBuf d_bh;  // scratch of the device-side BH / neighbour-list epilogue (fw_bh.hip)
     FwPinned h_jobs, h_acc, h_out;
     FwPoolBuf pb[2];
 };
@@ -162,7 +172,7 @@ int fw_pin_reserve(fw_ctx *ctx, FwPinned &b, size_t bytes);
 // ---- fz (fw_fz.hip) ----
 int fwi_fz_compute_cor(fw_ctx *ctx);
 int fwi_fz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &pj, std::vector<double> &stat,
-                  std::vector<double> &pval, int64_t *m_reliable);
+                  std::vector<double> &pval, int64_t *m_reliable, FwL0Dev *dev);
 int fwi_fz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff,
                       const int32_t *zflat, fw_test_result *out);
 int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb);
@@ -170,7 +180,7 @@ int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *d_
 // ---- HE-S / fz_nz (fw_fz.hip) ----
 int fwi_fznz_upload(fw_ctx *ctx, const float *data);
 int fwi_fznz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &pj, std::vector<double> &stat,
-                    std::vector<double> &pval, int64_t *m_reliable);
+                    std::vector<double> &pval, int64_t *m_reliable, FwL0Dev *dev);
 int fwi_fznz_submatrices(fw_ctx *ctx, int64_t njobs, const FwNzJob *recs_host, size_t arena_floats, const int32_t *d_acc,
                          hipStream_t stream);
 int fwi_fznz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb);
@@ -180,7 +190,7 @@ int fwi_fznz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t 
 // ---- discrete (fw_mi.hip) ----
 int fwi_mi_upload(fw_ctx *ctx, const int64_t *colptr, const int32_t *rowval, const int32_t *nzval);
 int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &pj, std::vector<double> &stat,
-                  std::vector<double> &pval, int64_t *m_reliable);
+                  std::vector<double> &pval, int64_t *m_reliable, FwL0Dev *dev);
 int fwi_mi_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff,
                       const int32_t *zflat, fw_test_result *out);
 int fwi_mi_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb);
@@ -225,6 +235,9 @@ int fwi_pool_launch(fw_ctx *ctx, FwPool &pool);                                 
 int fwi_pool_collect(fw_ctx *ctx, FwPool &pool, std::vector<FwPoolJob> &finished);  // waits + merges
 int fwi_pool_add(fw_ctx *ctx, FwPool &pool, int32_t X, int32_t Y, const int32_t *acc, int a, int64_t tag);
 int fwi_pool_round(fw_ctx *ctx, FwPool &pool, std::vector<FwPoolJob> &finished);
+
+// device-side Benjamini-Hochberg + neighbour CSR (fw_bh.hip); fills ctx->nb_off / nb_idx / nb_stat / nb_p
+int fwi_bh_csr_device(fw_ctx *ctx, const FwL0Dev &in, int64_t m_reliable);
 
 // ---- host driver (fw_hiton.cpp) ----
 int fwi_subsets_dispatch(fw_ctx *ctx, int64_t m, const FwJob *jobs_host, const int32_t *acc_host, int64_t acc_total,

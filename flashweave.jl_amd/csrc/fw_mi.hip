@@ -946,8 +946,9 @@ static double host_igamc(double a, double x)
 }
 
 int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &pj, std::vector<double> &stat,
-                  std::vector<double> &pval, int64_t *m_reliable)
+                  std::vector<double> &pval, int64_t *m_reliable, FwL0Dev *dev)
 {
+    if (dev) *dev = FwL0Dev{};
     const int p = ctx->P.p;
     const long long npairs = (long long)p * (p - 1) / 2;
     // G thresholds per df (df <= 4 at level 0): 0.999 * the alpha quantile -> everything below has p > alpha
@@ -1018,6 +1019,14 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
     FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cnt.kernel_launches += 1;
     const size_t k = (size_t)h2.n_sig;
+    if (dev) {  // results stay on the device for fwi_bh_csr_device
+        dev->i = oi;
+        dev->j = oj;
+        dev->stat64 = os;
+        dev->pval = op;
+        dev->k = k;
+        return FW_OK;
+    }
     pi.resize(k);
     pj.resize(k);
     stat.resize(k);

@@ -277,3 +277,30 @@ def test_learn_network_api_reproduces_all_golden_networks(tmp_path):
     net.save(str(out))
     back, hdr, _ = fio.read_edgelist(str(out))
     assert back == net["edges"] and len(hdr) == 50
+
+
+@pytest.mark.parametrize("kind", ["fz", "fz_nz", "mi", "mi_nz"])
+@pytest.mark.parametrize("fdr", [True, False])
+def test_device_bh_equals_host_bh(kind, fdr, monkeypatch):
+    # benjamini_hochberg! + condensed_stats_to_dict on the device (fw_bh.hip) against the host restatement
+    # (FW_HOST_BH=1): offsets, partners, statistics and adjusted p-values must agree to the bit
+    from flashweave_jl_amd import preprocess as pre, synth
+    if kind in ("fz", "fz_nz"):
+        counts = synth.generate(700, 300, 5, mode="S")
+        data, _, _ = pre.normalize(counts, kind, prec=32)
+    else:
+        counts = synth.generate(700, 300, 5, mode="F")
+        data, _, _ = pre.normalize(counts, kind)
+    data = np.ascontiguousarray(data)
+    n, p = data.shape
+    res = []
+    for host in ("1", "0"):
+        monkeypatch.setenv("FW_HOST_BH", host)
+        eng = fw.Engine(kind, n, p, max_k=3, FDR=fdr)
+        eng.set_data(data)
+        res.append(eng.pw_univar_neighbors())
+        eng.close()
+    a, b = res
+    assert a["off"][-1] > 100
+    for key in ("off", "idx", "stat", "pval"):
+        assert np.array_equal(a[key], b[key]), key
