@@ -1306,14 +1306,26 @@ __global__ __launch_bounds__(256) void fznz_level0_kernel(const float *__restric
     }
     const bool isn = valid && (!reliable || isnan(pval));  // NaN in the reference's condensed arrays (tests.jl:397-398)
     const bool sig = valid && reliable && pval < alpha;
-    if (isn) atomicAdd(&cnt->n_nan, 1ull);
-    if (sig) {
-        const unsigned long long slot = atomicAdd(&cnt->n_sig, 1ull);
-        if (slot < cap) {
-            out_i[slot] = X;
-            out_j[slot] = Y;
-            out_s[slot] = stat;
-            out_p[slot] = pval;
+    // one atomic per wavefront for each counter (per-pair atomics on one address serialise the kernel)
+    const int lane = threadIdx.x & 63;
+    const unsigned long long mn = __ballot(isn), ms = __ballot(sig);
+    if (mn) {
+        const int leader = __ffsll((long long)mn) - 1;
+        if (lane == leader) atomicAdd(&cnt->n_nan, (unsigned long long)__popcll(mn));
+    }
+    if (ms) {
+        const int leader = __ffsll((long long)ms) - 1;
+        unsigned long long base = 0;
+        if (lane == leader) base = atomicAdd(&cnt->n_sig, (unsigned long long)__popcll(ms));
+        base = __shfl(base, leader);
+        if (sig) {
+            const unsigned long long slot = base + (unsigned long long)__popcll(ms & ((1ull << lane) - 1ull));
+            if (slot < cap) {
+                out_i[slot] = X;
+                out_j[slot] = Y;
+                out_s[slot] = stat;
+                out_p[slot] = pval;
+            }
         }
     }
 }

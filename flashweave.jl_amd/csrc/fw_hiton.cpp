@@ -25,17 +25,13 @@ struct ODict {  // OrderedDict{Int,Tuple{Float64,Float64}}: insertion order, re-
             if (key[i] == k) return (int)i;
         return -1;
     }
+    // Every key is assigned exactly once per phase (the candidate lists hold distinct variables: a neighbour list in
+    // the interleaving phase, keys(TPC) in the elimination phase), so assignment is an append -- no lookup.
     void set(int32_t k, double s, double p)
     {
-        int i = find(k);
-        if (i < 0) {
-            key.push_back(k);
-            stat.push_back(s);
-            pval.push_back(p);
-        } else {
-            stat[i] = s;
-            pval[i] = p;
-        }
+        key.push_back(k);
+        stat.push_back(s);
+        pval.push_back(p);
     }
 };
 
