@@ -99,6 +99,9 @@ int fwi_bh_csr_device(fw_ctx *ctx, const FwL0Dev &in, int64_t m)
 {
     const int p = ctx->P.p;
     const size_t k = in.k;
+    ctx->d_nb_off = nullptr;
+    ctx->d_nb_idx = nullptr;
+    ctx->d_nb_stat = ctx->d_nb_p = nullptr;
     ctx->nb_off.assign((size_t)p + 1, 0);
     ctx->nb_idx.clear();
     ctx->nb_stat.clear();
@@ -177,5 +180,9 @@ int fwi_bh_csr_device(fw_ctx *ctx, const FwL0Dev &in, int64_t m)
     FW_HIP(ctx, hipMemcpyAsync(ctx->nb_p.data(), pvo, (size_t)n2 * 8, hipMemcpyDeviceToHost, st));
     FW_HIP(ctx, hipStreamSynchronize(st));
     ctx->cnt.kernel_launches += 3;
+    ctx->d_nb_off = offs;  // stay valid until the next level-0 (the device HITON rounds read them)
+    ctx->d_nb_idx = idx;
+    ctx->d_nb_stat = sto;
+    ctx->d_nb_p = pvo;
     return FW_OK;
 }

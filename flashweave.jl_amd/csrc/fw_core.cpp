@@ -159,6 +159,8 @@ int fw_ctx_destroy(fw_ctx *c)
     free_dev(c->d_nzrecs);
     free_dev(c->d_arena);
     free_dev(c->d_bh);
+    free_dev(c->d_dh);
+    free_pin(c->h_dh);
     free_pin(c->h_jobs);
     free_pin(c->h_acc);
     free_pin(c->h_out);
@@ -352,6 +354,9 @@ int fw_level0(fw_ctx *c, int64_t *nnz_out)
         if (nnz_out) *nnz_out = c->nb_off[p];
         return FW_OK;
     }
+    c->d_nb_off = nullptr;
+    c->d_nb_idx = nullptr;
+    c->d_nb_stat = c->d_nb_p = nullptr;
     const size_t k = pi.size();
     const double t_host0 = now_s();
     if (c->P.fdr && k > 0) {

@@ -1,0 +1,629 @@
+// Device-resident HITON-PC rounds (FW_FZ).  The host driver of fw_hiton.cpp pays one host round trip per pool round
+// (collect -> merge -> advance -> build -> launch, ~140 us at cfg3, a third of the pass); here the per-target state
+// machines, the in-rank-order merge of the segment results and the construction of the next launch live in device
+// memory and run as three small kernels between two launches of the segment kernel:
+//     seg kernel -> dh_step_kernel (merge, commit, advance: one thread per target)
+//                -> dh_plan_kernel (segment length, per-target segment counts, exclusive scan: one workgroup)
+//                -> dh_fill_kernel (one thread per segment record) -> seg kernel -> ...
+// The host only enqueues batches of rounds and looks at a pinned "done" flag between batches.  Semantics are those
+// of the host driver (hiton.jl:109-149 interleaving / elimination, check_candidate! :80-107, update_PC_dict! :249-256,
+// tests.jl:326-345 merge rules) without its speculative candidate posting; windows follow the same growth policy.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "fw_internal.h"
+
+namespace {
+
+struct DhTgt {
+    int32_t T, phase, pos, nc;  // nc = candidates of the current phase
+    int32_t na, ntpc, npc, wl_n;
+    long long co;  // offset of this target's arrays (capacity cap each; accepted list: 2 * co, 2 * cap)
+    long long wl_off, nb_off;
+    int32_t nb_n, cap;
+    int32_t jactive, pad0;
+    unsigned long long jN, jnext, jwidth, jwin, jevaluated;
+    double jbest_p, jbest_stat;
+    unsigned long long c_ref, c_calls, c_eval;  // per-target totals (summed on the host: no same-address atomics)
+    double c_alg;
+};
+
+struct DhGlobal {
+    unsigned long long launched_ranks, next_ranks;
+    unsigned int n_live_prev, n_live_next;
+    unsigned int ns, seglen, done, rounds, rounds_nonempty, pad;
+    unsigned long long cond_tests_ref, subsets_calls, evaluated;
+    double alg_bytes;
+};
+
+struct DhArrays {
+    const int32_t *cand0;  // interleaving candidates (hiton.jl:211-217 order)
+    int32_t *tpc_key, *pc_key, *acc;
+    double *tpc_stat, *tpc_p, *pc_stat, *pc_p;
+    const int32_t *wl;        // sorted whitelists (feed-forward)
+    const long long *nb_off;  // level-0 neighbour lists (for the empty-pool case, hiton.jl:57-59)
+    const int32_t *nb_idx;
+    const double *nb_stat, *nb_p;
+};
+
+struct DhParams {
+    double alpha;
+    int max_k;
+    long long max_tests;
+    unsigned long long small_launch, w0_big;
+};
+
+__device__ __forceinline__ unsigned long long dh_binom(long long m, int t)
+{
+    if (m < t) return 0ull;
+    const unsigned long long SAT = 1ull << 62;
+    double est = 1.0;
+    for (int i = 1; i <= t; ++i) est = est * (double)(m - t + i) / (double)i;
+    if (est > 4.0e18) return SAT;
+    unsigned long long v = 1ull;
+    for (int i = 1; i <= t; ++i) v = v * (unsigned long long)(m - t + i) / (unsigned long long)i;  // exact: C(m-t+i, i)
+    return v;
+}
+
+__device__ __forceinline__ bool dh_in_wl(const DhTgt &x, const DhArrays &A, int32_t v)
+{
+    int lo = 0, hi = x.wl_n;
+    const int32_t *w = A.wl + x.wl_off;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (w[mid] < v)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo < x.wl_n && w[lo] == v;
+}
+
+// algorithmic bytes of the first `evaluated` ranks of a job over `a` accepted variables (fwi_alg_bytes, fz form)
+__device__ __forceinline__ double dh_alg_bytes(int a, unsigned long long evaluated, int max_k)
+{
+    double bytes = 0.0, left = (double)evaluated;
+    for (int s = max_k; s >= 1 && left > 0.0; --s) {
+        double b = 1.0;
+        for (int i = 1; i <= s; ++i) b = b * (double)(a - s + i) / (double)i;
+        if (a < s) b = 0.0;
+        const double cnt = left < b ? left : b;
+        bytes += cnt * (4.0 * (double)((s + 2) * (s + 1) / 2) + 32.0);
+        left -= cnt;
+    }
+    return bytes;
+}
+
+// Advance a target until it needs a device test (returns true; the job is (T, cands[pos], acc[0..na))) or finishes.
+// Executed by the whole wavefront of the target: every lane holds the same copy of x and takes the same branches;
+// the loops over the target's arrays (removing the candidate from the pool, the phase switch, update_PC_dict!) are
+// spread over the lanes -- a single lane walking 250 dependent global loads per candidate was 100 us per round.
+__device__ bool dh_advance(DhTgt &x, const DhArrays &A, int lane)
+{
+    int32_t *acc = A.acc + 2 * x.co;
+    for (;;) {
+        if (x.phase == 2) return false;
+        const int32_t *cands = x.phase == 0 ? A.cand0 + x.co : A.tpc_key + x.co;
+        int32_t *dkey = (x.phase == 0 ? A.tpc_key : A.pc_key) + x.co;
+        double *dstat = (x.phase == 0 ? A.tpc_stat : A.pc_stat) + x.co;
+        double *dp = (x.phase == 0 ? A.tpc_p : A.pc_p) + x.co;
+        int32_t &dn = x.phase == 0 ? x.ntpc : x.npc;
+        while (x.pos < x.nc) {
+            const int32_t cand = cands[x.pos];
+            if (x.wl_n > 0 && dh_in_wl(x, A, cand)) {  // hiton.jl:20-30
+                if (lane == 0) {
+                    acc[x.na] = cand;
+                    dkey[dn] = cand;
+                    dstat[dn] = NAN;
+                    dp[dn] = NAN;
+                }
+                ++x.na;
+                ++dn;
+                ++x.pos;
+                continue;
+            }
+            if (x.phase == 1) {  // hiton.jl:134-136: the candidate leaves the conditioning pool while it is tested
+                __threadfence();
+                int w = 0;  // stable in-place compaction, 64 entries at a time (writes never pass the read front)
+                for (int base = 0; base < x.na; base += 64) {
+                    const int q = base + lane;
+                    const int32_t v = q < x.na ? acc[q] : cand;
+                    const bool keep = q < x.na && v != cand;
+                    const unsigned long long m = __ballot(keep);
+                    if (keep) acc[w + __popcll(m & ((1ull << lane) - 1ull))] = v;
+                    w += __popcll(m);
+                }
+                x.na = w;
+                __threadfence();
+            }
+            if (x.na == 0) {  // tests.jl:285 sentinel + hiton.jl:57-59
+                double s = NAN, p = NAN;
+                if (x.phase == 0) {
+                    const int32_t *b = A.nb_idx + x.nb_off;
+                    int lo = 0, hi = x.nb_n;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (b[mid] < cand)
+                            lo = mid + 1;
+                        else
+                            hi = mid;
+                    }
+                    s = A.nb_stat[x.nb_off + lo];
+                    p = A.nb_p[x.nb_off + lo];
+                } else {
+                    for (int q = 0; q < x.ntpc; ++q)
+                        if (A.tpc_key[x.co + q] == cand) {
+                            s = A.tpc_stat[x.co + q];
+                            p = A.tpc_p[x.co + q];
+                            break;
+                        }
+                }
+                if (lane == 0) {
+                    acc[x.na] = cand;
+                    dkey[dn] = cand;
+                    dstat[dn] = s;
+                    dp[dn] = p;
+                }
+                ++x.na;
+                ++dn;
+                ++x.pos;
+                continue;
+            }
+            return true;
+        }
+        __threadfence();
+        if (x.phase == 0) {  // hiton.jl:242: elimination over keys(TPC) in insertion order
+            x.phase = 1;
+            x.nc = x.ntpc;
+            for (int q = lane; q < x.ntpc; q += 64) acc[q] = A.tpc_key[x.co + q];
+            x.na = x.ntpc;
+            x.pos = 0;
+        } else {  // hiton.jl:249-256 update_PC_dict!
+            for (int i = lane; i < x.npc; i += 64) {
+                const int32_t k = A.pc_key[x.co + i];
+                for (int q = 0; q < x.ntpc; ++q)
+                    if (A.tpc_key[x.co + q] == k) {
+                        const double tp = A.tpc_p[x.co + q], pp = A.pc_p[x.co + i];
+                        if (tp > pp || isnan(pp)) {
+                            A.pc_stat[x.co + i] = A.tpc_stat[x.co + q];
+                            A.pc_p[x.co + i] = tp;
+                        }
+                        break;
+                    }
+            }
+            x.phase = 2;
+        }
+        __threadfence();
+    }
+}
+
+// One wavefront per target: the lanes merge the job's segment records in parallel (first stop = minimum segment
+// index; otherwise the lexicographic maximum of (p, segment index), i.e. "later wins ties", tests.jl:338), lane 0 runs
+// the sequential part (commit, advance, next job).
+__global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, int ntg, const DhGlobal *__restrict__ g, DhArrays A,
+                                                      const FwSegOut *__restrict__ so, const long long *__restrict__ seg0,
+                                                      unsigned long long *__restrict__ win, DhParams P)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x * 4 + wave;
+    unsigned long long mywin = 0ull;
+    if (t < ntg) {
+        DhTgt x = tg[t];
+        const long long jseg0 = seg0[t];
+        const int jnseg = (int)(seg0[t + 1] - jseg0);
+        bool finished = false;
+        double r_stat = 0.0, r_p = 1.0;
+        int r_pow = 0;
+        unsigned long long r_nt = 0ull;
+        if (x.jactive) {
+            // ---- parallel part ----
+            unsigned long long ev = 0ull;
+            int my_stop = 0x7fffffff;  // smallest segment index of this lane that reports a stop
+            double st_stat = 0.0, st_p = 0.0;
+            int st_pow = 0;
+            unsigned long long st_rank = 0ull;
+            double bp = -2.0, bs = 0.0;  // lane best over its segments (increasing index, `>=`)
+            int bi = -1;
+            for (int sg = lane; sg < jnseg; sg += 64) {
+                const FwSegOut o = so[jseg0 + sg];
+                ev += o.evaluated;
+                if (o.stop_rank != FW_RANK_NONE) {
+                    if (my_stop == 0x7fffffff) {
+                        my_stop = sg;
+                        st_stat = o.stop_stat;
+                        st_p = o.stop_pval;
+                        st_pow = o.stop_power;
+                        st_rank = o.stop_rank;
+                    }
+                } else if (o.best_pval >= bp) {
+                    bp = o.best_pval;
+                    bs = o.best_stat;
+                    bi = sg;
+                }
+            }
+            int first = my_stop;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                ev += __shfl_xor(ev, o);
+                const int f2 = __shfl_xor(first, o);
+                first = f2 < first ? f2 : first;
+                const double p2 = __shfl_xor(bp, o), s2 = __shfl_xor(bs, o);
+                const int i2 = __shfl_xor(bi, o);
+                if (p2 > bp || (p2 == bp && i2 > bi)) {
+                    bp = p2;
+                    bs = s2;
+                    bi = i2;
+                }
+            }
+            bool done = false;
+            if (first != 0x7fffffff) {  // segments after the first stop were speculative
+                const int owner = first & 63;
+                r_stat = __shfl(st_stat, owner);
+                r_p = __shfl(st_p, owner);
+                r_pow = __shfl(st_pow, owner);
+                r_nt = __shfl(st_rank, owner) + 1ull;
+                done = true;
+            } else if (bi >= 0 && bp >= x.jbest_p) {
+                x.jbest_p = bp;
+                x.jbest_stat = bs;
+            }
+            x.jevaluated += ev;
+            // ---- sequential part (every lane computes the same values; only lane 0 writes) ----
+            if (!done) {
+                x.jnext += x.jwin;
+                const unsigned long long growth = g->launched_ranks < P.small_launch ? 256ull : (g->n_live_prev > 2048u ? 4ull : 16ull);
+                x.jwidth *= growth;
+                if (x.jnext >= x.jN) {
+                    r_stat = x.jbest_stat;
+                    r_p = x.jbest_p < 0.0 ? 0.0 : x.jbest_p;
+                    r_pow = 1;
+                    r_nt = x.jN;
+                    done = true;
+                }
+            }
+            if (done) {
+                x.jactive = 0;
+                finished = true;
+                x.c_ref += r_nt;
+                x.c_calls += 1ull;
+                x.c_eval += x.jevaluated;
+                x.c_alg += dh_alg_bytes(x.na, x.jevaluated, P.max_k);
+            }
+        }
+        if (finished) {  // commit: issig (tests.jl:1-3) -> hiton.jl:61-63
+            const int32_t *cands = x.phase == 0 ? A.cand0 + x.co : A.tpc_key + x.co;
+            const int32_t cand = cands[x.pos];
+            ++x.pos;
+            if (r_p < P.alpha && r_pow) {
+                if (lane == 0) {
+                    A.acc[2 * x.co + x.na] = cand;
+                    if (x.phase == 0) {
+                        A.tpc_key[x.co + x.ntpc] = cand;
+                        A.tpc_stat[x.co + x.ntpc] = r_stat;
+                        A.tpc_p[x.co + x.ntpc] = r_p;
+                    } else {
+                        A.pc_key[x.co + x.npc] = cand;
+                        A.pc_stat[x.co + x.npc] = r_stat;
+                        A.pc_p[x.co + x.npc] = r_p;
+                    }
+                }
+                ++x.na;
+                if (x.phase == 0)
+                    ++x.ntpc;
+                else
+                    ++x.npc;
+            }
+        }
+        if (!x.jactive && x.phase != 2 && dh_advance(x, A, lane)) {
+            unsigned long long N = 0ull;
+            for (int s = P.max_k; s >= 1; --s) {
+                N += dh_binom(x.na, s);
+                if (N > (1ull << 62)) N = 1ull << 62;
+            }
+            if (P.max_tests > 0 && (unsigned long long)P.max_tests < N) N = (unsigned long long)P.max_tests;
+            x.jN = N;
+            x.jnext = 0ull;
+            x.jwidth = x.na >= 64 ? P.w0_big : 256ull;
+            x.jbest_p = -1.0;
+            x.jbest_stat = 0.0;
+            x.jevaluated = 0ull;
+            x.jactive = 1;
+        }
+        if (x.jactive) {
+            const unsigned long long left = x.jN - x.jnext;
+            mywin = x.jwidth < left ? x.jwidth : left;
+        }
+        x.jwin = mywin;
+        if (lane == 0) {
+            tg[t] = x;
+            win[t] = mywin;  // 0 = no job in the coming launch
+        }
+    }
+}
+
+// one workgroup: totals of the coming launch, its segment length, per-target segment counts and their exclusive scan.
+// The segment length has no upper cap here, so the launch never holds more than seg_target + (live jobs) segments:
+// the fixed grid (seg_target + targets) always covers it.
+__global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__restrict__ g, const unsigned long long *__restrict__ win,
+                                                       long long *__restrict__ seg0, volatile unsigned int *__restrict__ hflags,
+                                                       unsigned int seg_target)
+{
+    __shared__ unsigned long long s_tot[16];
+    __shared__ unsigned int s_live[16], s_wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (ntg + 1023) / 1024;
+    const int b = tid * per, e = (b + per) < ntg ? (b + per) : ntg;
+    unsigned long long tot = 0ull;
+    unsigned int live = 0u;
+    for (int t = b; t < e; ++t) {
+        const unsigned long long w = win[t];
+        tot += w;
+        live += w != 0ull;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        tot += __shfl_xor(tot, o);
+        live += __shfl_xor(live, o);
+    }
+    if (lane == 0) {
+        s_tot[wave] = tot;
+        s_live[wave] = live;
+    }
+    __syncthreads();
+    unsigned long long total = 0ull;
+    unsigned int n_live = 0u;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        total += s_tot[w];
+        n_live += s_live[w];
+    }
+    unsigned long long seglen = (total / seg_target + 255ull) / 256ull * 256ull;
+    seglen = seglen < 256ull ? 256ull : seglen;
+    unsigned int local = 0u;
+    for (int t = b; t < e; ++t) local += (unsigned int)((win[t] + seglen - 1ull) / seglen);
+    unsigned int incl = local;  // inclusive scan inside the wavefront, then over the 16 wavefront totals
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    unsigned int wbase = 0u, ns = 0u;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) wbase += s_wsum[w];
+        ns += s_wsum[w];
+    }
+    unsigned int run = wbase + incl - local;
+    for (int t = b; t < e; ++t) {
+        seg0[t] = (long long)run;
+        run += (unsigned int)((win[t] + seglen - 1ull) / seglen);
+    }
+    if (tid == 0) {
+        seg0[ntg] = (long long)ns;
+        g->ns = ns;
+        g->seglen = (unsigned int)seglen;
+        g->launched_ranks = total;
+        g->n_live_prev = n_live;
+        if (n_live == 0u) g->done = 1u;
+        if (ns) g->rounds_nonempty += 1u;
+        hflags[1 + (g->rounds & 63u)] = ns;
+        hflags[0] = g->done;
+        g->rounds += 1u;
+    }
+}
+
+__global__ __launch_bounds__(256) void dh_fill_kernel(const DhTgt *__restrict__ tg, int ntg, const DhGlobal *__restrict__ g,
+                                                      const long long *__restrict__ seg0, const DhArrays A,
+                                                      FwSeg *__restrict__ segs)
+{
+    const unsigned int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= g->ns) return;
+    int lo = 0, hi = ntg;  // first t with seg0[t] > s; the job owning slot s is the one before it
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (seg0[mid] <= (long long)s)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    const DhTgt &x = tg[lo - 1];
+    const unsigned long long seglen = g->seglen;
+    const unsigned long long k = (unsigned long long)((long long)s - seg0[lo - 1]);
+    const int32_t *cands = x.phase == 0 ? A.cand0 + x.co : A.tpc_key + x.co;
+    FwSeg sg;
+    sg.X = x.T;
+    sg.Y = cands[x.pos];
+    sg.acc_off = 2 * x.co;
+    sg.acc_len = x.na;
+    sg.pad = 0;
+    sg.start = x.jnext + k * seglen;
+    const unsigned long long hi_r = x.jnext + x.jwin;
+    sg.end = sg.start + seglen < hi_r ? sg.start + seglen : hi_r;
+    segs[s] = sg;
+}
+
+}  // namespace
+
+// One round of targets on the device.  in: T ids, interleaving candidates and (sorted) whitelists per target;
+// out: PC (keys, statistics, p-values) per target in insertion order.
+int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<FwDhResult> &out)
+{
+    const int ntg = (int)in.size();
+    out.assign((size_t)ntg, FwDhResult{});
+    if (ntg == 0) return FW_OK;
+    hipStream_t st = c->pb[0].stream;
+    const int p = c->P.p;
+    // ---- host-side layout ----
+    std::vector<DhTgt> tg((size_t)ntg);
+    std::vector<int32_t> cand0, wl;
+    long long co = 0, wo = 0;
+    int max_cap = 0;
+    for (int t = 0; t < ntg; ++t) {
+        DhTgt x{};
+        x.T = in[t].T;
+        x.nc = (int32_t)in[t].cands.size();
+        x.cap = x.nc;
+        x.phase = x.nc == 0 ? 2 : 0;
+        x.co = co;
+        x.wl_off = wo;
+        x.wl_n = in[t].wl_n;
+        x.nb_off = c->nb_off[x.T];
+        x.nb_n = (int32_t)(c->nb_off[x.T + 1] - c->nb_off[x.T]);
+        cand0.insert(cand0.end(), in[t].cands.begin(), in[t].cands.end());
+        if (in[t].wl_n) wl.insert(wl.end(), in[t].wl, in[t].wl + in[t].wl_n);
+        co += x.nc;
+        wo += in[t].wl_n;
+        max_cap = std::max(max_cap, x.nc);
+        tg[t] = x;
+    }
+    const size_t tot = (size_t)co;
+    // ---- device buffers (one arena) ----
+    const bool nb_on_dev = c->d_nb_idx != nullptr;
+    const size_t nnz = (size_t)c->nb_off[p];
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const unsigned seg_target = 4096;
+    const unsigned max_ns = seg_target + (unsigned)ntg + 256u;
+    size_t need = pad(sizeof(DhTgt) * ntg) + pad(sizeof(DhGlobal)) + 2 * pad(sizeof(long long) * ((size_t)ntg + 1));
+    need += pad(4 * tot + 4) * 3 + pad(4 * 2 * tot + 4) + pad(8 * tot + 8) * 4 + pad(4 * wl.size() + 4);
+    need += pad(sizeof(FwSeg) * max_ns) + pad(sizeof(FwSegOut) * max_ns);
+    if (!nb_on_dev) need += pad(8 * ((size_t)p + 1)) + pad(4 * nnz + 4) + 2 * pad(8 * nnz + 8);
+    int rc;
+    if ((rc = fw_dev_reserve(c, c->d_dh, need))) return rc;
+    if ((rc = fw_pin_reserve(c, c->h_dh, 4096))) return rc;
+    unsigned int *hflags = (unsigned int *)c->h_dh.ptr;
+    memset(hflags, 0, 4096);
+    char *B = (char *)c->d_dh.ptr;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        char *q = B + off;
+        off += pad(bytes);
+        return q;
+    };
+    DhTgt *d_tg = (DhTgt *)carve(sizeof(DhTgt) * ntg);
+    DhGlobal *d_g = (DhGlobal *)carve(sizeof(DhGlobal));
+    long long *d_seg0 = (long long *)carve(sizeof(long long) * ((size_t)ntg + 1));
+    unsigned long long *d_win = (unsigned long long *)carve(sizeof(unsigned long long) * ((size_t)ntg + 1));
+    DhArrays A{};
+    int32_t *d_cand0 = (int32_t *)carve(4 * tot + 4);
+    A.cand0 = d_cand0;
+    A.tpc_key = (int32_t *)carve(4 * tot + 4);
+    A.pc_key = (int32_t *)carve(4 * tot + 4);
+    A.acc = (int32_t *)carve(4 * 2 * tot + 4);
+    A.tpc_stat = (double *)carve(8 * tot + 8);
+    A.tpc_p = (double *)carve(8 * tot + 8);
+    A.pc_stat = (double *)carve(8 * tot + 8);
+    A.pc_p = (double *)carve(8 * tot + 8);
+    int32_t *d_wl = (int32_t *)carve(4 * wl.size() + 4);
+    A.wl = d_wl;
+    FwSeg *d_segs = (FwSeg *)carve(sizeof(FwSeg) * max_ns);
+    FwSegOut *d_so = (FwSegOut *)carve(sizeof(FwSegOut) * max_ns);
+    FW_HIP(c, hipMemcpyAsync(d_tg, tg.data(), sizeof(DhTgt) * ntg, hipMemcpyHostToDevice, st));
+    FW_HIP(c, hipMemsetAsync(d_g, 0, sizeof(DhGlobal), st));
+    FW_HIP(c, hipMemsetAsync(d_seg0, 0, sizeof(long long) * ((size_t)ntg + 1), st));
+    if (tot) FW_HIP(c, hipMemcpyAsync(d_cand0, cand0.data(), 4 * tot, hipMemcpyHostToDevice, st));
+    if (!wl.empty()) FW_HIP(c, hipMemcpyAsync(d_wl, wl.data(), 4 * wl.size(), hipMemcpyHostToDevice, st));
+    if (nb_on_dev) {
+        A.nb_off = c->d_nb_off;
+        A.nb_idx = c->d_nb_idx;
+        A.nb_stat = c->d_nb_stat;
+        A.nb_p = c->d_nb_p;
+    } else {
+        long long *o = (long long *)carve(8 * ((size_t)p + 1));
+        int32_t *ix = (int32_t *)carve(4 * nnz + 4);
+        double *s1 = (double *)carve(8 * nnz + 8), *s2 = (double *)carve(8 * nnz + 8);
+        FW_HIP(c, hipMemcpyAsync(o, c->nb_off.data(), 8 * ((size_t)p + 1), hipMemcpyHostToDevice, st));
+        if (nnz) {
+            FW_HIP(c, hipMemcpyAsync(ix, c->nb_idx.data(), 4 * nnz, hipMemcpyHostToDevice, st));
+            FW_HIP(c, hipMemcpyAsync(s1, c->nb_stat.data(), 8 * nnz, hipMemcpyHostToDevice, st));
+            FW_HIP(c, hipMemcpyAsync(s2, c->nb_p.data(), 8 * nnz, hipMemcpyHostToDevice, st));
+        }
+        A.nb_off = o;
+        A.nb_idx = ix;
+        A.nb_stat = s1;
+        A.nb_p = s2;
+    }
+    DhParams P{};
+    P.alpha = c->P.alpha;
+    P.max_k = c->P.max_k;
+    P.max_tests = c->P.max_tests;
+    {
+        const char *e = getenv("FW_SMALL_LAUNCH");
+        P.small_launch = e ? (unsigned long long)atoll(e) : (1ull << 22);
+        const char *w = getenv("FW_W0_BIG");
+        P.w0_big = w ? (unsigned long long)atoll(w) : 16384ull;
+    }
+    const bool any_big = 2 * max_cap > FW_TAB_A;  // an accepted list can hold at most 2 * cap entries
+    const unsigned g_tg = (unsigned)((ntg + 3) / 4), g_fill = (max_ns + 255) / 256;  // step: one wavefront per target
+    const unsigned *d_ns = &d_g->ns;
+    // ---- rounds ----
+    constexpr int BATCH = 16;
+    hipEvent_t ev[2 * BATCH];
+    for (hipEvent_t &e : ev) FW_HIP(c, hipEventCreate(&e));
+    auto planfill = [&]() {
+        hipLaunchKernelGGL(dh_step_kernel, dim3(g_tg), dim3(256), 0, st, d_tg, ntg, (const DhGlobal *)d_g, A, (const FwSegOut *)d_so,
+                           (const long long *)d_seg0, d_win, P);
+        hipLaunchKernelGGL(dh_plan_kernel, dim3(1), dim3(1024), 0, st, ntg, d_g, (const unsigned long long *)d_win, d_seg0,
+                           (volatile unsigned int *)hflags, seg_target);
+        hipLaunchKernelGGL(dh_fill_kernel, dim3(g_fill), dim3(256), 0, st, (const DhTgt *)d_tg, ntg, (const DhGlobal *)d_g,
+                           (const long long *)d_seg0, A, d_segs);
+    };
+    planfill();  // nothing to merge yet: creates the first jobs and the first launch (plan #0)
+    int rc2 = FW_OK;
+    unsigned plan_base = 0;  // launch r of a batch executes plan #(plan_base + r)
+    for (;;) {
+        for (int r = 0; r < BATCH; ++r) {
+            (void)hipEventRecord(ev[2 * r], st);
+            if ((rc2 = fwi_fz_segments_dev(c, max_ns, d_segs, A.acc, d_so, d_ns, any_big, st))) break;
+            (void)hipEventRecord(ev[2 * r + 1], st);
+            planfill();
+        }
+        if (rc2) break;
+        FW_HIP(c, hipGetLastError());
+        FW_HIP(c, hipStreamSynchronize(st));
+        for (int r = 0; r < BATCH; ++r) {
+            if (hflags[1 + ((plan_base + (unsigned)r) & 63u)] == 0) continue;  // empty launch after the last round
+            float ms = 0.0f;
+            FW_HIP(c, hipEventElapsedTime(&ms, ev[2 * r], ev[2 * r + 1]));
+            c->cnt.t_dev_subsets_s += 1e-3 * (double)ms;
+            c->cnt.subsets_launches += 1;
+            c->cnt.kernel_launches += 4;
+        }
+        plan_base += BATCH;
+        if (hflags[0]) break;
+        if (plan_base > 4000000u) {  // every round finishes at least one window: this is a logic error, not a workload
+            rc2 = fw_fail(c, FW_ERR_DEVICE, "device HITON: no convergence after %u rounds", plan_base);
+            break;
+        }
+    }
+    for (hipEvent_t &e : ev) (void)hipEventDestroy(e);
+    if (rc2) return rc2;
+    // ---- results ----
+    DhGlobal hg{};
+    FW_HIP(c, hipMemcpy(&hg, d_g, sizeof(hg), hipMemcpyDeviceToHost));
+    FW_HIP(c, hipMemcpy(tg.data(), d_tg, sizeof(DhTgt) * ntg, hipMemcpyDeviceToHost));
+    std::vector<int32_t> pk(tot);
+    std::vector<double> ps(tot), pp(tot);
+    if (tot) {
+        FW_HIP(c, hipMemcpy(pk.data(), A.pc_key, 4 * tot, hipMemcpyDeviceToHost));
+        FW_HIP(c, hipMemcpy(ps.data(), A.pc_stat, 8 * tot, hipMemcpyDeviceToHost));
+        FW_HIP(c, hipMemcpy(pp.data(), A.pc_p, 8 * tot, hipMemcpyDeviceToHost));
+    }
+    for (int t = 0; t < ntg; ++t) {
+        const DhTgt &x = tg[t];
+        if (x.phase != 2) return fw_fail(c, FW_ERR_DEVICE, "device HITON: target %d did not finish (phase %d)", x.T, x.phase);
+        out[t].key.assign(pk.begin() + x.co, pk.begin() + x.co + x.npc);
+        out[t].stat.assign(ps.begin() + x.co, ps.begin() + x.co + x.npc);
+        out[t].pval.assign(pp.begin() + x.co, pp.begin() + x.co + x.npc);
+    }
+    for (const DhTgt &x : tg) {
+        c->cnt.cond_tests_ref += (int64_t)x.c_ref;
+        c->cnt.subsets_calls += (int64_t)x.c_calls;
+        c->cnt.cond_tests_evaluated += (int64_t)x.c_eval;
+        c->cnt.alg_bytes_subsets += x.c_alg;
+    }
+    (void)hg;
+    return FW_OK;
+}

@@ -685,8 +685,13 @@ __global__ __launch_bounds__(256, 4) void fz_subsets_seg_kernel(const float *__r
                                                              FwSegOut *__restrict__ out, int max_k, double alpha,
                                                              double zscale_g, long long max_tests,
                                                              const double *__restrict__ thr_g,
-                                                             const FwNzJob *__restrict__ recs, long long n_obs_min)
+                                                             const FwNzJob *__restrict__ recs, long long n_obs_min,
+                                                             const unsigned *__restrict__ ns_dev)
 {
+    // device-driven rounds (fw_devhiton.hip): fixed grid, the live segment count sits in device memory, and the
+    // table / in-lane variants each pick their own segments out of the unsorted list
+    if (ns_dev && blockIdx.x >= *ns_dev) return;
+    if (ns_dev && !HIGHK && ((segs[blockIdx.x].acc_len <= FZ_TAB_A) != TAB)) return;
     __shared__ int s_acc[TAB ? FZ_TAB_A : FW_ACC_LDS];  // TAB: |accepted| <= FZ_TAB_A by the host's routing
     __shared__ unsigned long long s_stop[4];
     __shared__ double s_bx[4], s_bps[4];
@@ -1210,32 +1215,64 @@ int fwi_fz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y
     return FW_OK;
 }
 
+static int fz_ensure_thresholds(fw_ctx *ctx, hipStream_t stream)
+{
+    if (!ctx->d_thr) {
+        FW_HIP(ctx, hipMalloc((void **)&ctx->d_thr, 4 * sizeof(double)));
+        hipLaunchKernelGGL(fz_thresholds_kernel, dim3(1), dim3(64), 0, stream, ctx->P.alpha, fz_zscale(ctx), ctx->d_thr);
+        FW_HIP(ctx, hipGetLastError());
+        FW_HIP(ctx, hipStreamSynchronize(stream));  // another stream may use it next
+    }
+    return FW_OK;
+}
+
+// Device-driven rounds (fw_devhiton.hip): a fixed grid over an unsorted segment list whose live length is *d_ns.
+int fwi_fz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, const unsigned *d_ns,
+                        bool any_big, hipStream_t stream)
+{
+    int rc = fz_ensure_thresholds(ctx, stream);
+    if (rc) return rc;
+    if (ctx->P.max_k > 3) {
+        hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false, false>), dim3(grid), dim3(256), 0, stream, ctx->d_cor, ctx->P.p, d_segs,
+                           d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr,
+                           (const FwNzJob *)nullptr, 0ll, d_ns);
+    } else {
+        hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false, true>), dim3(grid), dim3(256), 0, stream, ctx->d_cor, ctx->P.p, d_segs,
+                           d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr,
+                           (const FwNzJob *)nullptr, 0ll, d_ns);
+        if (any_big)  // some accepted set may exceed FZ_TAB_A
+            hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false, false>), dim3(grid), dim3(256), 0, stream, ctx->d_cor, ctx->P.p,
+                               d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests,
+                               ctx->d_thr, (const FwNzJob *)nullptr, 0ll, d_ns);
+    }
+    FW_HIP(ctx, hipGetLastError());
+    return FW_OK;
+}
+
 int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out,
                     FwPoolBuf &pb)
 {
     if (nseg == 0) return FW_OK;
     FW_HIP(ctx, hipEventRecord(pb.ev0, pb.launch_stream));
-    if (!ctx->d_thr) {
-        FW_HIP(ctx, hipMalloc((void **)&ctx->d_thr, 4 * sizeof(double)));
-        hipLaunchKernelGGL(fz_thresholds_kernel, dim3(1), dim3(64), 0, pb.launch_stream, ctx->P.alpha, fz_zscale(ctx), ctx->d_thr);
-        FW_HIP(ctx, hipGetLastError());
-        FW_HIP(ctx, hipStreamSynchronize(pb.launch_stream));  // the other pool stream may use it next
+    {
+        int rc = fz_ensure_thresholds(ctx, pb.launch_stream);
+        if (rc) return rc;
     }
     if (ctx->P.max_k > 3)
         hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false, false>), dim3((unsigned)nseg), dim3(256), 0, pb.launch_stream, ctx->d_cor,
                            ctx->P.p, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx),
-                           (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll);
+                           (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll, (const unsigned *)nullptr);
     else {
         // segments [0, nseg_tab) belong to jobs with |accepted| <= FZ_TAB_A: table kernel; the rest: in-lane caching
         if (nseg_tab > 0)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false, true>), dim3((unsigned)nseg_tab), dim3(256), 0, pb.launch_stream,
                                ctx->d_cor, ctx->P.p, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx),
-                               (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll);
+                               (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll, (const unsigned *)nullptr);
         if (nseg > nseg_tab)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false, false>), dim3((unsigned)(nseg - nseg_tab)), dim3(256), 0,
                                pb.launch_stream, ctx->d_cor, ctx->P.p, d_segs + nseg_tab, d_acc, d_out + nseg_tab, ctx->P.max_k,
                                ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr,
-                               0ll);
+                               0ll, (const unsigned *)nullptr);
     }
     FW_HIP(ctx, hipGetLastError());
     FW_HIP(ctx, hipEventRecord(pb.ev1, pb.launch_stream));
@@ -1547,18 +1584,18 @@ int fwi_fznz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *
         hipLaunchKernelGGL((fz_subsets_seg_kernel<true, true, false>), dim3((unsigned)nseg), dim3(256), 0, pb.launch_stream,
                            (const float *)ctx->d_arena.ptr, 0, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, 0.0,
                            (long long)ctx->P.max_tests, (const double *)nullptr, (const FwNzJob *)ctx->d_nzrecs.ptr,
-                           (long long)ctx->n_obs_min_eff);
+                           (long long)ctx->n_obs_min_eff, (const unsigned *)nullptr);
     else {
         if (nseg_tab > 0)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<false, true, true>), dim3((unsigned)nseg_tab), dim3(256), 0, pb.launch_stream,
                                (const float *)ctx->d_arena.ptr, 0, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, 0.0,
                                (long long)ctx->P.max_tests, (const double *)nullptr, (const FwNzJob *)ctx->d_nzrecs.ptr,
-                               (long long)ctx->n_obs_min_eff);
+                               (long long)ctx->n_obs_min_eff, (const unsigned *)nullptr);
         if (nseg > nseg_tab)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<false, true, false>), dim3((unsigned)(nseg - nseg_tab)), dim3(256), 0,
                                pb.launch_stream, (const float *)ctx->d_arena.ptr, 0, d_segs + nseg_tab, d_acc, d_out + nseg_tab,
                                ctx->P.max_k, ctx->P.alpha, 0.0, (long long)ctx->P.max_tests, (const double *)nullptr,
-                               (const FwNzJob *)ctx->d_nzrecs.ptr, (long long)ctx->n_obs_min_eff);
+                               (const FwNzJob *)ctx->d_nzrecs.ptr, (long long)ctx->n_obs_min_eff, (const unsigned *)nullptr);
     }
     FW_HIP(ctx, hipGetLastError());
     FW_HIP(ctx, hipEventRecord(pb.ev1, pb.launch_stream));

@@ -200,6 +200,34 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                 }
                 tg.push_back(std::move(t));
             }
+            // Device-resident rounds (fw_devhiton.hip) for FW_FZ: no host round trip per window.  FW_HOST_HITON=1 keeps the
+            // host pool below for every kind (it is also what rounds of fewer than 64 targets use: the reference's
+            // single_il schedule posts one target per round and would pay the device set-up each time).
+            bool ran_dev = false;
+            {
+                const char *hh = getenv("FW_HOST_HITON");
+                const bool host_only = hh && atoi(hh) == 1;
+                if (!host_only && c->P.kind == FW_FZ && c->P.n >= c->n_obs_min_eff && tg.size() >= 64) {
+                    std::vector<FwDhTarget> din(tg.size());
+                    for (size_t i = 0; i < tg.size(); ++i) {
+                        din[i].T = tg[i].T;
+                        if (tg[i].phase != 2) din[i].cands = tg[i].cands;
+                        din[i].wl = tg[i].wl;
+                        din[i].wl_n = tg[i].wl_n;
+                    }
+                    std::vector<FwDhResult> dres;
+                    int rc = fwi_devhiton_run(c, din, dres);
+                    if (rc) return rc;
+                    for (size_t i = 0; i < tg.size(); ++i) {
+                        tg[i].PC.key = std::move(dres[i].key);
+                        tg[i].PC.stat = std::move(dres[i].stat);
+                        tg[i].PC.pval = std::move(dres[i].pval);
+                        tg[i].phase = 2;
+                    }
+                    ran_dev = true;
+                }
+            }
+            if (!ran_dev) {
             // Asynchronous job pool with speculative candidates.  A rejected candidate leaves the accepted set unchanged
             // (hiton.jl:67-70), so during the interleaving phase the next FW_SPEC_DEPTH candidates of a target are posted
             // together against the current accepted set; results are committed strictly in candidate order, and the
@@ -289,6 +317,7 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
             }
             c->cnt.cond_tests_evaluated += pool.dropped_evaluated;
             c->cnt.alg_bytes_subsets += pool.dropped_alg_bytes;
+            }  // host pool
             // exchange this round's directed results (target, neighbour, stat, p)
             std::vector<int32_t> lt, ln;
             std::vector<double> ls, lp;

@@ -154,6 +154,12 @@ struct fw_ctx {
     // grow-only scratch
     FwDevBuf d_jobs, d_acc, d_out, d_tmp0, d_tmp1, d_tmp2, d_segs, d_segout, d_nzrecs, d_arena;
     FwDevBuf d_bh;  // scratch of the device-side BH / neighbour-list epilogue (fw_bh.hip)
+    // device copies of the level-0 neighbour CSR (inside d_bh, valid until the next fw_level0); null after a host-side BH
+    const long long *d_nb_off = nullptr;
+    const int32_t *d_nb_idx = nullptr;
+    const double *d_nb_stat = nullptr, *d_nb_p = nullptr;
+    FwDevBuf d_dh;  // arena of the device-resident HITON rounds (fw_devhiton.hip)
+    FwPinned h_dh;  // its pinned flag page
     FwPinned h_jobs, h_acc, h_out;
     FwPoolBuf pb[2];
 };
@@ -239,6 +245,21 @@ int fwi_pool_round(fw_ctx *ctx, FwPool &pool, std::vector<FwPoolJob> &finished);
 
 // device-side Benjamini-Hochberg + neighbour CSR (fw_bh.hip); fills ctx->nb_off / nb_idx / nb_stat / nb_p
 int fwi_bh_csr_device(fw_ctx *ctx, const FwL0Dev &in, int64_t m_reliable);
+
+// ---- device-resident HITON rounds (fw_devhiton.hip, FW_FZ) ----
+struct FwDhTarget {
+    int32_t T = 0;
+    std::vector<int32_t> cands;  // interleaving candidates in hiton.jl:211-217 order
+    const int32_t *wl = nullptr; // sorted whitelist (feed-forward), may be null
+    int wl_n = 0;
+};
+struct FwDhResult {
+    std::vector<int32_t> key;  // PC in insertion order
+    std::vector<double> stat, pval;
+};
+int fwi_devhiton_run(fw_ctx *ctx, const std::vector<FwDhTarget> &in, std::vector<FwDhResult> &out);
+int fwi_fz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, const unsigned *d_ns,
+                        bool any_big, hipStream_t stream);
 
 // ---- host driver (fw_hiton.cpp) ----
 int fwi_subsets_dispatch(fw_ctx *ctx, int64_t m, const FwJob *jobs_host, const int32_t *acc_host, int64_t acc_total,
