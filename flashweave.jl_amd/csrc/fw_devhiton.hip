@@ -96,7 +96,8 @@ __device__ __forceinline__ double dh_alg_bytes(int a, unsigned long long evaluat
 }
 
 // Advance a target until it needs a device test (returns true; the job is (T, cands[pos], acc[0..na))) or finishes.
-// Executed by the whole wavefront of the target: every lane holds the same copy of x and takes the same branches;
+// Executed by the whole wavefront of the target: every lane holds the same copy of x and takes the same branches
+// (stores of one lane are made visible to the others by workgroup-scope fences: one L1 per CU, no cache maintenance);
 // the loops over the target's arrays (removing the candidate from the pool, the phase switch, update_PC_dict!) are
 // spread over the lanes -- a single lane walking 250 dependent global loads per candidate was 100 us per round.
 __device__ bool dh_advance(DhTgt &x, const DhArrays &A, int lane)
@@ -124,7 +125,7 @@ __device__ bool dh_advance(DhTgt &x, const DhArrays &A, int lane)
                 continue;
             }
             if (x.phase == 1) {  // hiton.jl:134-136: the candidate leaves the conditioning pool while it is tested
-                __threadfence();
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 int w = 0;  // stable in-place compaction, 64 entries at a time (writes never pass the read front)
                 for (int base = 0; base < x.na; base += 64) {
                     const int q = base + lane;
@@ -135,7 +136,7 @@ __device__ bool dh_advance(DhTgt &x, const DhArrays &A, int lane)
                     w += __popcll(m);
                 }
                 x.na = w;
-                __threadfence();
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             }
             if (x.na == 0) {  // tests.jl:285 sentinel + hiton.jl:57-59
                 double s = NAN, p = NAN;
@@ -172,7 +173,7 @@ __device__ bool dh_advance(DhTgt &x, const DhArrays &A, int lane)
             }
             return true;
         }
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         if (x.phase == 0) {  // hiton.jl:242: elimination over keys(TPC) in insertion order
             x.phase = 1;
             x.nc = x.ntpc;
@@ -194,7 +195,7 @@ __device__ bool dh_advance(DhTgt &x, const DhArrays &A, int lane)
             }
             x.phase = 2;
         }
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
 }
 
@@ -345,6 +346,16 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
 // one workgroup: totals of the coming launch, its segment length, per-target segment counts and their exclusive scan.
 // The segment length has no upper cap here, so the launch never holds more than seg_target + (live jobs) segments:
 // the fixed grid (seg_target + targets) always covers it.
+// ceil(w / seglen) for w < 2^62: double quotient + exact fix-up (a 64-bit integer division costs ~100 instructions)
+__device__ __forceinline__ unsigned int dh_ceil_div(unsigned long long w, unsigned long long seglen, double inv)
+{
+    if (w == 0ull) return 0u;
+    unsigned long long q = (unsigned long long)((double)w * inv);
+    while (q * seglen < w) ++q;
+    while (q > 0ull && (q - 1ull) * seglen >= w) --q;
+    return (unsigned int)q;
+}
+
 __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__restrict__ g, const unsigned long long *__restrict__ win,
                                                        long long *__restrict__ seg0, volatile unsigned int *__restrict__ hflags,
                                                        unsigned int seg_target)
@@ -380,8 +391,9 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
     }
     unsigned long long seglen = (total / seg_target + 255ull) / 256ull * 256ull;
     seglen = seglen < 256ull ? 256ull : seglen;
+    const double inv = 1.0 / (double)seglen;
     unsigned int local = 0u;
-    for (int t = b; t < e; ++t) local += (unsigned int)((win[t] + seglen - 1ull) / seglen);
+    for (int t = b; t < e; ++t) local += dh_ceil_div(win[t], seglen, inv);
     unsigned int incl = local;  // inclusive scan inside the wavefront, then over the 16 wavefront totals
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -399,7 +411,7 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
     unsigned int run = wbase + incl - local;
     for (int t = b; t < e; ++t) {
         seg0[t] = (long long)run;
-        run += (unsigned int)((win[t] + seglen - 1ull) / seglen);
+        run += dh_ceil_div(win[t], seglen, inv);
     }
     if (tid == 0) {
         seg0[ntg] = (long long)ns;
@@ -485,7 +497,8 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     const size_t nnz = (size_t)c->nb_off[p];
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const unsigned seg_target = 4096;
-    const unsigned max_ns = seg_target + (unsigned)ntg + 256u;
+    const unsigned max_ns = seg_target + (unsigned)ntg + 256u;  // capacity of the segment list
+    const unsigned grid_seg = seg_target + 512u;                // striding workgroups of the segment kernel
     size_t need = pad(sizeof(DhTgt) * ntg) + pad(sizeof(DhGlobal)) + 2 * pad(sizeof(long long) * ((size_t)ntg + 1));
     need += pad(4 * tot + 4) * 3 + pad(4 * 2 * tot + 4) + pad(8 * tot + 8) * 4 + pad(4 * wl.size() + 4);
     need += pad(sizeof(FwSeg) * max_ns) + pad(sizeof(FwSegOut) * max_ns);
@@ -576,7 +589,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     for (;;) {
         for (int r = 0; r < BATCH; ++r) {
             (void)hipEventRecord(ev[2 * r], st);
-            if ((rc2 = fwi_fz_segments_dev(c, max_ns, d_segs, A.acc, d_so, d_ns, any_big, st))) break;
+            if ((rc2 = fwi_fz_segments_dev(c, grid_seg, d_segs, A.acc, d_so, d_ns, any_big, st))) break;
             (void)hipEventRecord(ev[2 * r + 1], st);
             planfill();
         }

@@ -679,19 +679,12 @@ __global__ void fz_thresholds_kernel(double alpha, double zscale, double *thr)
 // HIGHK: subsets of size 4-5 possible; LOCAL: per-job matrices (fz_nz); TAB: size-3 subsets through the LDS table
 // (the host routes only segments of jobs with |accepted| <= FZ_TAB_A to a TAB launch; never together with HIGHK)
 template <bool HIGHK, bool LOCAL, bool TAB>
-__global__ __launch_bounds__(256, 4) void fz_subsets_seg_kernel(const float *__restrict__ cor_g, int p_g,
-                                                             const FwSeg *__restrict__ segs,
-                                                             const int32_t *__restrict__ accflat,
-                                                             FwSegOut *__restrict__ out, int max_k, double alpha,
-                                                             double zscale_g, long long max_tests,
-                                                             const double *__restrict__ thr_g,
-                                                             const FwNzJob *__restrict__ recs, long long n_obs_min,
-                                                             const unsigned *__restrict__ ns_dev)
+__device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int p_g, const FwSeg *__restrict__ segs,
+                                            const int32_t *__restrict__ accflat, FwSegOut *__restrict__ out, int max_k,
+                                            double alpha, double zscale_g, long long max_tests,
+                                            const double *__restrict__ thr_g, const FwNzJob *__restrict__ recs,
+                                            long long n_obs_min, const unsigned sidx /* segment this workgroup evaluates */)
 {
-    // device-driven rounds (fw_devhiton.hip): fixed grid, the live segment count sits in device memory, and the
-    // table / in-lane variants each pick their own segments out of the unsorted list
-    if (ns_dev && blockIdx.x >= *ns_dev) return;
-    if (ns_dev && !HIGHK && ((segs[blockIdx.x].acc_len <= FZ_TAB_A) != TAB)) return;
     __shared__ int s_acc[TAB ? FZ_TAB_A : FW_ACC_LDS];  // TAB: |accepted| <= FZ_TAB_A by the host's routing
     __shared__ unsigned long long s_stop[4];
     __shared__ double s_bx[4], s_bps[4];
@@ -704,7 +697,7 @@ __global__ __launch_bounds__(256, 4) void fz_subsets_seg_kernel(const float *__r
     __shared__ double s_tab_a2[TAB ? FZ_TAB_CAP : 1]; // rho(X, Y | z1, v)
     __shared__ int s_blk[2];
 
-    const FwSeg seg = segs[blockIdx.x];
+    const FwSeg seg = segs[sidx];
     const int a = seg.acc_len;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int32_t *gacc = accflat + seg.acc_off;
@@ -733,7 +726,7 @@ __global__ __launch_bounds__(256, 4) void fz_subsets_seg_kernel(const float *__r
                 o.best_df = 0;
                 o.pad = 0;
                 o.evaluated = 0;
-                out[blockIdx.x] = o;
+                out[sidx] = o;
             }
             return;
         }
@@ -1042,7 +1035,7 @@ __global__ __launch_bounds__(256, 4) void fz_subsets_seg_kernel(const float *__r
                 o.best_df = 0;
                 o.pad = 0;
                 o.evaluated = evaluated;
-                out[blockIdx.x] = o;
+                out[sidx] = o;
             }
             return;
         }
@@ -1080,7 +1073,33 @@ __global__ __launch_bounds__(256, 4) void fz_subsets_seg_kernel(const float *__r
         o.best_df = 0;
         o.pad = 0;
         o.evaluated = evaluated;
-        out[blockIdx.x] = o;
+        out[sidx] = o;
+    }
+}
+
+// Host-driven rounds: one workgroup per segment (ns_dev == nullptr).  Device-driven rounds (fw_devhiton.hip): a fixed
+// grid strides over an unsorted segment list whose live length sits in device memory; the table / in-lane variants
+// each pick their own segments.
+template <bool HIGHK, bool LOCAL, bool TAB>
+__global__ __launch_bounds__(256, 4) void fz_subsets_seg_kernel(const float *__restrict__ cor_g, int p_g,
+                                                             const FwSeg *__restrict__ segs,
+                                                             const int32_t *__restrict__ accflat,
+                                                             FwSegOut *__restrict__ out, int max_k, double alpha,
+                                                             double zscale_g, long long max_tests,
+                                                             const double *__restrict__ thr_g,
+                                                             const FwNzJob *__restrict__ recs, long long n_obs_min,
+                                                             const unsigned *__restrict__ ns_dev)
+{
+    if (!ns_dev) {
+        fz_seg_body<HIGHK, LOCAL, TAB>(cor_g, p_g, segs, accflat, out, max_k, alpha, zscale_g, max_tests, thr_g, recs, n_obs_min,
+                                       blockIdx.x);
+        return;
+    }
+    const unsigned ns = *ns_dev;
+    for (unsigned s = blockIdx.x; s < ns; s += gridDim.x) {
+        if (!HIGHK && ((segs[s].acc_len <= FZ_TAB_A) != TAB)) continue;  // workgroup-uniform
+        fz_seg_body<HIGHK, LOCAL, TAB>(cor_g, p_g, segs, accflat, out, max_k, alpha, zscale_g, max_tests, thr_g, recs, n_obs_min, s);
+        __syncthreads();  // the LDS state of the body is reused by the next segment
     }
 }
 
@@ -1232,6 +1251,7 @@ int fwi_fz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const i
 {
     int rc = fz_ensure_thresholds(ctx, stream);
     if (rc) return rc;
+    const unsigned grid_big = grid < 512u ? grid : 512u;  // accepted sets beyond FZ_TAB_A are rare: few striding workgroups
     if (ctx->P.max_k > 3) {
         hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false, false>), dim3(grid), dim3(256), 0, stream, ctx->d_cor, ctx->P.p, d_segs,
                            d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr,
@@ -1241,7 +1261,7 @@ int fwi_fz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const i
                            d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr,
                            (const FwNzJob *)nullptr, 0ll, d_ns);
         if (any_big)  // some accepted set may exceed FZ_TAB_A
-            hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false, false>), dim3(grid), dim3(256), 0, stream, ctx->d_cor, ctx->P.p,
+            hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false, false>), dim3(grid_big), dim3(256), 0, stream, ctx->d_cor, ctx->P.p,
                                d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests,
                                ctx->d_thr, (const FwNzJob *)nullptr, 0ll, d_ns);
     }
