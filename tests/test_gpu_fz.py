@@ -304,3 +304,30 @@ def test_device_bh_equals_host_bh(kind, fdr, monkeypatch):
     assert a["off"][-1] > 100
     for key in ("off", "idx", "stat", "pval"):
         assert np.array_equal(a[key], b[key]), key
+
+
+@pytest.mark.parametrize("ff,R", [(False, 0), (True, 100), (True, 64)])
+def test_device_rounds_equal_host_driver_and_oracle(small, ff, R, monkeypatch):
+    # fw_devhiton.hip (rounds of >= 64 targets: state machines, merge and launch construction on the device) against
+    # the host driver (FW_HOST_HITON=1) and the oracle: same directed results, weights to the bit, same test count.
+    # R = 100 / 64 with feed_forward exercises the whitelist path (hiton.jl:20-30) on the device.
+    n, p, cm, orc = small["n"], small["p"], small["cm"], small["orc"]
+    res = {}
+    for host in ("1", "0"):
+        monkeypatch.setenv("FW_HOST_HITON", host)
+        eng = fw.Engine("fz", n, p, max_k=3)
+        eng.set_cor_mat(cm)
+        net = eng.lgl(feed_forward=ff, round_size=R)
+        res[host] = (net, eng.counters())
+        eng.close()
+    (nh, ch), (nd, cd) = res["1"], res["0"]
+    assert nh["edges"] == nd["edges"]
+    for key in ("pc_off", "pc_idx", "pc_weight", "pc_pval"):
+        assert np.array_equal(nh[key], nd[key], equal_nan=True), key
+    assert ch["cond_tests_ref"] == cd["cond_tests_ref"] and ch["subsets_calls"] == cd["subsets_calls"]
+    assert cd["subsets_launches"] > 0
+    exp = orc.learn(max_k=3, feed_forward=ff, round_size=max(R, 1) if ff else 1)
+    assert set(nd["edges"]) == set(exp["edges"])
+    for e, w in exp["edges"].items():
+        assert nd["edges"][e] == w
+    assert cd["cond_tests_ref"] == exp["n_cond_tests"]
