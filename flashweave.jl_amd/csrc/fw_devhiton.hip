@@ -35,6 +35,7 @@ struct DhGlobal {
     unsigned int ns, seglen, done, rounds, rounds_nonempty, pad;
     unsigned long long cond_tests_ref, subsets_calls, evaluated;
     double alg_bytes;
+    unsigned int ns_ring[64];  // segments of the last 64 planned launches (the host reads the record once per batch)
 };
 
 struct DhArrays {
@@ -356,9 +357,9 @@ __device__ __forceinline__ unsigned int dh_ceil_div(unsigned long long w, unsign
     return (unsigned int)q;
 }
 
+#define DH_PER 16  // targets per planning thread held in registers (more targets: extra passes over global memory)
 __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__restrict__ g, const unsigned long long *__restrict__ win,
-                                                       long long *__restrict__ seg0, volatile unsigned int *__restrict__ hflags,
-                                                       unsigned int seg_target)
+                                                       long long *__restrict__ seg0, unsigned int seg_target)
 {
     __shared__ unsigned long long s_tot[16];
     __shared__ unsigned int s_live[16], s_wsum[16];
@@ -367,7 +368,15 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
     const int b = tid * per, e = (b + per) < ntg ? (b + per) : ntg;
     unsigned long long tot = 0ull;
     unsigned int live = 0u;
-    for (int t = b; t < e; ++t) {
+    unsigned long long wr[DH_PER];  // this thread's windows (registers when per <= DH_PER)
+#pragma unroll
+    for (int q = 0; q < DH_PER; ++q) wr[q] = (b + q < e) ? win[b + q] : 0ull;
+#pragma unroll
+    for (int q = 0; q < DH_PER; ++q) {
+        tot += wr[q];
+        live += wr[q] != 0ull;
+    }
+    for (int t = b + DH_PER; t < e; ++t) {
         const unsigned long long w = win[t];
         tot += w;
         live += w != 0ull;
@@ -393,7 +402,13 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
     seglen = seglen < 256ull ? 256ull : seglen;
     const double inv = 1.0 / (double)seglen;
     unsigned int local = 0u;
-    for (int t = b; t < e; ++t) local += dh_ceil_div(win[t], seglen, inv);
+    unsigned int nr[DH_PER];
+#pragma unroll
+    for (int q = 0; q < DH_PER; ++q) {
+        nr[q] = dh_ceil_div(wr[q], seglen, inv);
+        local += nr[q];
+    }
+    for (int t = b + DH_PER; t < e; ++t) local += dh_ceil_div(win[t], seglen, inv);
     unsigned int incl = local;  // inclusive scan inside the wavefront, then over the 16 wavefront totals
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -409,7 +424,13 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
         ns += s_wsum[w];
     }
     unsigned int run = wbase + incl - local;
-    for (int t = b; t < e; ++t) {
+#pragma unroll
+    for (int q = 0; q < DH_PER; ++q)
+        if (b + q < e) {
+            seg0[b + q] = (long long)run;
+            run += nr[q];
+        }
+    for (int t = b + DH_PER; t < e; ++t) {
         seg0[t] = (long long)run;
         run += dh_ceil_div(win[t], seglen, inv);
     }
@@ -420,10 +441,9 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
         g->launched_ranks = total;
         g->n_live_prev = n_live;
         if (n_live == 0u) g->done = 1u;
-        if (ns) g->rounds_nonempty += 1u;
-        hflags[1 + (g->rounds & 63u)] = ns;
-        hflags[0] = g->done;
-        g->rounds += 1u;
+        const unsigned int r = g->rounds;
+        g->ns_ring[r & 63u] = ns;
+        g->rounds = r + 1u;
     }
 }
 
@@ -506,8 +526,8 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     int rc;
     if ((rc = fw_dev_reserve(c, c->d_dh, need))) return rc;
     if ((rc = fw_pin_reserve(c, c->h_dh, 4096))) return rc;
-    unsigned int *hflags = (unsigned int *)c->h_dh.ptr;
-    memset(hflags, 0, 4096);
+    DhGlobal *hg = (DhGlobal *)c->h_dh.ptr;  // pinned copy of the device record, refreshed once per batch
+    memset(hg, 0, sizeof(DhGlobal));
     char *B = (char *)c->d_dh.ptr;
     size_t off = 0;
     auto carve = [&](size_t bytes) {
@@ -572,50 +592,59 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     const unsigned g_tg = (unsigned)((ntg + 3) / 4), g_fill = (max_ns + 255) / 256;  // step: one wavefront per target
     const unsigned *d_ns = &d_g->ns;
     // ---- rounds ----
+    // Kernel timing: HIP events around every segment launch (fw_counters.t_dev_subsets_s).  FW_DH_TIME_EVERY=k brackets
+    // only every k-th launch and scales the sampled average (measured: 3 ms per pass at cfg3, and a biased estimate).
     constexpr int BATCH = 16;
+    static const int time_every = [] { const char *e = getenv("FW_DH_TIME_EVERY"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
     hipEvent_t ev[2 * BATCH];
     for (hipEvent_t &e : ev) FW_HIP(c, hipEventCreate(&e));
     auto planfill = [&]() {
         hipLaunchKernelGGL(dh_step_kernel, dim3(g_tg), dim3(256), 0, st, d_tg, ntg, (const DhGlobal *)d_g, A, (const FwSegOut *)d_so,
                            (const long long *)d_seg0, d_win, P);
         hipLaunchKernelGGL(dh_plan_kernel, dim3(1), dim3(1024), 0, st, ntg, d_g, (const unsigned long long *)d_win, d_seg0,
-                           (volatile unsigned int *)hflags, seg_target);
+                           seg_target);
         hipLaunchKernelGGL(dh_fill_kernel, dim3(g_fill), dim3(256), 0, st, (const DhTgt *)d_tg, ntg, (const DhGlobal *)d_g,
                            (const long long *)d_seg0, A, d_segs);
     };
     planfill();  // nothing to merge yet: creates the first jobs and the first launch (plan #0)
     int rc2 = FW_OK;
     unsigned plan_base = 0;  // launch r of a batch executes plan #(plan_base + r)
+    double timed_s = 0.0;
+    long timed_n = 0, launches_n = 0;
     for (;;) {
         for (int r = 0; r < BATCH; ++r) {
-            (void)hipEventRecord(ev[2 * r], st);
+            const bool timed = (r % time_every) == 0;
+            if (timed) (void)hipEventRecord(ev[2 * r], st);
             if ((rc2 = fwi_fz_segments_dev(c, grid_seg, d_segs, A.acc, d_so, d_ns, any_big, st))) break;
-            (void)hipEventRecord(ev[2 * r + 1], st);
+            if (timed) (void)hipEventRecord(ev[2 * r + 1], st);
             planfill();
         }
         if (rc2) break;
         FW_HIP(c, hipGetLastError());
+        FW_HIP(c, hipMemcpyAsync(hg, d_g, sizeof(DhGlobal), hipMemcpyDeviceToHost, st));
         FW_HIP(c, hipStreamSynchronize(st));
         for (int r = 0; r < BATCH; ++r) {
-            if (hflags[1 + ((plan_base + (unsigned)r) & 63u)] == 0) continue;  // empty launch after the last round
+            if (hg->ns_ring[(plan_base + (unsigned)r) & 63u] == 0) continue;  // empty launch after the last round
+            ++launches_n;
+            if ((r % time_every) != 0) continue;
             float ms = 0.0f;
             FW_HIP(c, hipEventElapsedTime(&ms, ev[2 * r], ev[2 * r + 1]));
-            c->cnt.t_dev_subsets_s += 1e-3 * (double)ms;
-            c->cnt.subsets_launches += 1;
-            c->cnt.kernel_launches += 4;
+            timed_s += 1e-3 * (double)ms;
+            ++timed_n;
         }
         plan_base += BATCH;
-        if (hflags[0]) break;
+        if (hg->done) break;
         if (plan_base > 4000000u) {  // every round finishes at least one window: this is a logic error, not a workload
             rc2 = fw_fail(c, FW_ERR_DEVICE, "device HITON: no convergence after %u rounds", plan_base);
             break;
         }
     }
+    if (timed_n > 0) c->cnt.t_dev_subsets_s += timed_s * (double)launches_n / (double)timed_n;
+    c->cnt.subsets_launches += launches_n;
+    c->cnt.kernel_launches += 4 * launches_n;
     for (hipEvent_t &e : ev) (void)hipEventDestroy(e);
     if (rc2) return rc2;
     // ---- results ----
-    DhGlobal hg{};
-    FW_HIP(c, hipMemcpy(&hg, d_g, sizeof(hg), hipMemcpyDeviceToHost));
     FW_HIP(c, hipMemcpy(tg.data(), d_tg, sizeof(DhTgt) * ntg, hipMemcpyDeviceToHost));
     std::vector<int32_t> pk(tot);
     std::vector<double> ps(tot), pp(tot);
@@ -637,6 +666,5 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         c->cnt.cond_tests_evaluated += (int64_t)x.c_eval;
         c->cnt.alg_bytes_subsets += x.c_alg;
     }
-    (void)hg;
     return FW_OK;
 }
