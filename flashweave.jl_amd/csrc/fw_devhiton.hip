@@ -1,4 +1,4 @@
-// Device-resident HITON-PC rounds (FW_FZ).  The host driver of fw_hiton.cpp pays one host round trip per pool round
+// Device-resident HITON-PC rounds (FW_FZ, FW_MI, FW_MI_NZ).  The host driver of fw_hiton.cpp pays one host round trip per pool round
 // (collect -> merge -> advance -> build -> launch, ~140 us at cfg3, a third of the pass); here the per-target state
 // machines, the in-rank-order merge of the segment results and the construction of the next launch live in device
 // memory and run as three small kernels between two launches of the segment kernel:
@@ -52,7 +52,9 @@ struct DhParams {
     double alpha;
     int max_k;
     long long max_tests;
-    unsigned long long small_launch, w0_big;
+    unsigned long long small_launch, w0_big, w0_small;  // window policy (fw_core.cpp: fwi_pool_add / fw_window_growth)
+    unsigned int seg_q, seg_min;                        // segment length granularity / minimum (fz 256 / 256, discrete 4 / 8)
+    double disc_bytes_per_col;                          // discrete kinds: n * b / 8 (algorithmic bytes per column), else 0
 };
 
 __device__ __forceinline__ unsigned long long dh_binom(long long m, int t)
@@ -82,7 +84,7 @@ __device__ __forceinline__ bool dh_in_wl(const DhTgt &x, const DhArrays &A, int3
 }
 
 // algorithmic bytes of the first `evaluated` ranks of a job over `a` accepted variables (fwi_alg_bytes, fz form)
-__device__ __forceinline__ double dh_alg_bytes(int a, unsigned long long evaluated, int max_k)
+__device__ __forceinline__ double dh_alg_bytes(int a, unsigned long long evaluated, int max_k, double disc_bytes_per_col)
 {
     double bytes = 0.0, left = (double)evaluated;
     for (int s = max_k; s >= 1 && left > 0.0; --s) {
@@ -90,7 +92,8 @@ __device__ __forceinline__ double dh_alg_bytes(int a, unsigned long long evaluat
         for (int i = 1; i <= s; ++i) b = b * (double)(a - s + i) / (double)i;
         if (a < s) b = 0.0;
         const double cnt = left < b ? left : b;
-        bytes += cnt * (4.0 * (double)((s + 2) * (s + 1) / 2) + 32.0);
+        bytes += cnt * (disc_bytes_per_col > 0.0 ? (double)(s + 2) * disc_bytes_per_col + 32.0
+                                                 : 4.0 * (double)((s + 2) * (s + 1) / 2) + 32.0);
         left -= cnt;
     }
     return bytes;
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
                 x.c_ref += r_nt;
                 x.c_calls += 1ull;
                 x.c_eval += x.jevaluated;
-                x.c_alg += dh_alg_bytes(x.na, x.jevaluated, P.max_k);
+                x.c_alg += dh_alg_bytes(x.na, x.jevaluated, P.max_k, P.disc_bytes_per_col);
             }
         }
         if (finished) {  // commit: issig (tests.jl:1-3) -> hiton.jl:61-63
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
             if (P.max_tests > 0 && (unsigned long long)P.max_tests < N) N = (unsigned long long)P.max_tests;
             x.jN = N;
             x.jnext = 0ull;
-            x.jwidth = x.na >= 64 ? P.w0_big : 256ull;
+            x.jwidth = x.na >= 64 ? P.w0_big : P.w0_small;
             x.jbest_p = -1.0;
             x.jbest_stat = 0.0;
             x.jevaluated = 0ull;
@@ -359,7 +362,8 @@ __device__ __forceinline__ unsigned int dh_ceil_div(unsigned long long w, unsign
 
 #define DH_PER 16  // targets per planning thread held in registers (more targets: extra passes over global memory)
 __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__restrict__ g, const unsigned long long *__restrict__ win,
-                                                       long long *__restrict__ seg0, unsigned int seg_target)
+                                                       long long *__restrict__ seg0, unsigned int seg_target, unsigned int seg_q,
+                                                       unsigned int seg_min)
 {
     __shared__ unsigned long long s_tot[16];
     __shared__ unsigned int s_live[16], s_wsum[16];
@@ -398,8 +402,8 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
         total += s_tot[w];
         n_live += s_live[w];
     }
-    unsigned long long seglen = (total / seg_target + 255ull) / 256ull * 256ull;
-    seglen = seglen < 256ull ? 256ull : seglen;
+    unsigned long long seglen = (total / seg_target + seg_q - 1ull) / seg_q * seg_q;
+    seglen = seglen < seg_min ? seg_min : seglen;
     const double inv = 1.0 / (double)seglen;
     unsigned int local = 0u;
     unsigned int nr[DH_PER];
@@ -588,6 +592,12 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         const char *w = getenv("FW_W0_BIG");
         P.w0_big = w ? (unsigned long long)atoll(w) : 16384ull;
     }
+    const bool fz = c->P.kind == FW_FZ;
+    P.w0_small = fz ? 256ull : 16ull;
+    if (!fz) P.w0_big = 16ull;
+    P.seg_q = fz ? 256u : 4u;
+    P.seg_min = fz ? 256u : 8u;
+    P.disc_bytes_per_col = fz ? 0.0 : (double)c->P.n * (c->P.kind == FW_MI ? 1.0 : 2.0) / 8.0;
     const bool any_big = 2 * max_cap > FW_TAB_A;  // an accepted list can hold at most 2 * cap entries
     const unsigned g_tg = (unsigned)((ntg + 3) / 4), g_fill = (max_ns + 255) / 256;  // step: one wavefront per target
     const unsigned *d_ns = &d_g->ns;
@@ -602,7 +612,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         hipLaunchKernelGGL(dh_step_kernel, dim3(g_tg), dim3(256), 0, st, d_tg, ntg, (const DhGlobal *)d_g, A, (const FwSegOut *)d_so,
                            (const long long *)d_seg0, d_win, P);
         hipLaunchKernelGGL(dh_plan_kernel, dim3(1), dim3(1024), 0, st, ntg, d_g, (const unsigned long long *)d_win, d_seg0,
-                           seg_target);
+                           seg_target, P.seg_q, P.seg_min);
         hipLaunchKernelGGL(dh_fill_kernel, dim3(g_fill), dim3(256), 0, st, (const DhTgt *)d_tg, ntg, (const DhGlobal *)d_g,
                            (const long long *)d_seg0, A, d_segs);
     };
@@ -615,7 +625,9 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         for (int r = 0; r < BATCH; ++r) {
             const bool timed = (r % time_every) == 0;
             if (timed) (void)hipEventRecord(ev[2 * r], st);
-            if ((rc2 = fwi_fz_segments_dev(c, grid_seg, d_segs, A.acc, d_so, d_ns, any_big, st))) break;
+            if ((rc2 = fz ? fwi_fz_segments_dev(c, grid_seg, d_segs, A.acc, d_so, d_ns, any_big, st)
+                          : fwi_mi_segments_dev(c, max_ns, d_segs, A.acc, d_so, d_ns, st)))
+                break;
             if (timed) (void)hipEventRecord(ev[2 * r + 1], st);
             planfill();
         }

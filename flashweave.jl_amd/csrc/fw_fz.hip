@@ -1090,14 +1090,10 @@ __global__ __launch_bounds__(256, 4) void fz_subsets_seg_kernel(const float *__r
                                                              const FwNzJob *__restrict__ recs, long long n_obs_min,
                                                              const unsigned *__restrict__ ns_dev)
 {
-    if (!ns_dev) {
-        fz_seg_body<HIGHK, LOCAL, TAB>(cor_g, p_g, segs, accflat, out, max_k, alpha, zscale_g, max_tests, thr_g, recs, n_obs_min,
-                                       blockIdx.x);
-        return;
-    }
-    const unsigned ns = *ns_dev;
+    // one instance of the body for both modes: host-driven = exactly one iteration, every segment of the launch is ours
+    const unsigned ns = ns_dev ? *ns_dev : gridDim.x;
     for (unsigned s = blockIdx.x; s < ns; s += gridDim.x) {
-        if (!HIGHK && ((segs[s].acc_len <= FZ_TAB_A) != TAB)) continue;  // workgroup-uniform
+        if (ns_dev && !HIGHK && ((segs[s].acc_len <= FZ_TAB_A) != TAB)) continue;  // workgroup-uniform
         fz_seg_body<HIGHK, LOCAL, TAB>(cor_g, p_g, segs, accflat, out, max_k, alpha, zscale_g, max_tests, thr_g, recs, n_obs_min, s);
         __syncthreads();  // the LDS state of the body is reused by the next segment
     }

@@ -200,14 +200,19 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                 }
                 tg.push_back(std::move(t));
             }
-            // Device-resident rounds (fw_devhiton.hip) for FW_FZ: no host round trip per window.  FW_HOST_HITON=1 keeps the
+            // Device-resident rounds (fw_devhiton.hip; every kind but fz_nz): no host round trip per window.  FW_HOST_HITON=1 keeps the
             // host pool below for every kind (it is also what rounds of fewer than 64 targets use: the reference's
             // single_il schedule posts one target per round and would pay the device set-up each time).
             bool ran_dev = false;
             {
                 const char *hh = getenv("FW_HOST_HITON");
                 const bool host_only = hh && atoi(hh) == 1;
-                if (!host_only && c->P.kind == FW_FZ && c->P.n >= c->n_obs_min_eff && tg.size() >= 64) {
+                const bool no_power = c->P.kind == FW_FZ && c->P.n < c->n_obs_min_eff;  // no device work at all
+                // discrete jobs are tiny (a few tests each): the device rounds only pay once thousands of targets keep the
+                // launches busy (cfg4: 191 -> 175 ms; cfg2 with 1000 targets: 30 -> 31 ms, so it stays on the host pool)
+                const char *mt = getenv("FW_DEV_MIN_TARGETS");  // test knob
+                const size_t min_targets = mt ? (size_t)atol(mt) : (c->P.kind == FW_FZ ? 64 : 4096);
+                if (!host_only && c->P.kind != FW_FZ_NZ && !no_power && tg.size() >= min_targets) {
                     std::vector<FwDhTarget> din(tg.size());
                     for (size_t i = 0; i < tg.size(); ++i) {
                         din[i].T = tg[i].T;

@@ -258,6 +258,8 @@ struct FwDhResult {
     std::vector<double> stat, pval;
 };
 int fwi_devhiton_run(fw_ctx *ctx, const std::vector<FwDhTarget> &in, std::vector<FwDhResult> &out);
+int fwi_mi_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, const unsigned *d_ns,
+                        hipStream_t stream);
 int fwi_fz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, const unsigned *d_ns,
                         bool any_big, hipStream_t stream);
 

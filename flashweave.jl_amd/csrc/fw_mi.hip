@@ -382,16 +382,15 @@ __device__ void mi_unrank(unsigned long long rem, int a, int s, int *pos)
 
 #define MI_RUN 4
 
-__global__ __launch_bounds__(256) void mi_subsets_seg_kernel(MiDev P, const FwSeg *__restrict__ segs,
-                                                             const int32_t *__restrict__ accflat,
-                                                             FwSegOut *__restrict__ out, int max_k, double alpha,
-                                                             long long max_tests)
+__device__ __forceinline__ void mi_seg_body(const MiDev &P, const FwSeg *__restrict__ segs, const int32_t *__restrict__ accflat,
+                                            FwSegOut *__restrict__ out, int max_k, double alpha, long long max_tests,
+                                            const unsigned sidx /* segment this workgroup evaluates */)
 {
     __shared__ int s_tab[4][MI_MAXCELL];
     __shared__ unsigned long long s_stop[4], s_br[4];
     __shared__ double s_sstat[4], s_sp[4], s_bp[4], s_bstat[4];
     __shared__ int s_sdf[4], s_spow[4], s_bdf[4];
-    const FwSeg seg = segs[blockIdx.x];
+    const FwSeg seg = segs[sidx];
     const int a = seg.acc_len;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int32_t *gacc = accflat + seg.acc_off;
@@ -490,7 +489,7 @@ __global__ __launch_bounds__(256) void mi_subsets_seg_kernel(MiDev P, const FwSe
                 o.best_df = 0;
                 o.pad = 0;
                 o.evaluated = evaluated;
-                out[blockIdx.x] = o;
+                out[sidx] = o;
             }
             return;
         }
@@ -517,8 +516,21 @@ __global__ __launch_bounds__(256) void mi_subsets_seg_kernel(MiDev P, const FwSe
         o.best_df = best_df;
         o.pad = 0;
         o.evaluated = evaluated;
-        out[blockIdx.x] = o;
+        out[sidx] = o;
     }
+}
+
+// Host-driven rounds: one workgroup per segment (ns_dev == nullptr); device-driven rounds (fw_devhiton.hip): a fixed
+// grid covers the device-built segment list whose live length is *ns_dev.
+__global__ __launch_bounds__(256) void mi_subsets_seg_kernel(MiDev P, const FwSeg *__restrict__ segs,
+                                                             const int32_t *__restrict__ accflat,
+                                                             FwSegOut *__restrict__ out, int max_k, double alpha,
+                                                             long long max_tests, const unsigned *__restrict__ ns_dev)
+{
+    // no grid-stride loop here: with the body inside a loop the compiler hoists its invariants and needs 254 VGPRs
+    // (occupancy 1 instead of 3); the device-driven grid covers the whole segment list and surplus workgroups leave
+    if (ns_dev && blockIdx.x >= *ns_dev) return;
+    mi_seg_body(P, segs, accflat, out, max_k, alpha, max_tests, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1090,6 +1102,16 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
     return FW_OK;
 }
 
+// Device-driven rounds (fw_devhiton.hip)
+int fwi_mi_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, const unsigned *d_ns,
+                        hipStream_t stream)
+{
+    hipLaunchKernelGGL(mi_subsets_seg_kernel, dim3(grid), dim3(256), 0, stream, mi_dev(ctx), d_segs, d_acc, d_out, ctx->P.max_k,
+                       ctx->P.alpha, (long long)ctx->P.max_tests, d_ns);
+    FW_HIP(ctx, hipGetLastError());
+    return FW_OK;
+}
+
 int fwi_mi_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff,
                       const int32_t *zflat, fw_test_result *out)
 {
@@ -1123,7 +1145,7 @@ int fwi_mi_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_
     if (nseg == 0) return FW_OK;
     FW_HIP(ctx, hipEventRecord(pb.ev0, pb.launch_stream));
     hipLaunchKernelGGL(mi_subsets_seg_kernel, dim3((unsigned)nseg), dim3(256), 0, pb.launch_stream, mi_dev(ctx), d_segs, d_acc, d_out,
-                       ctx->P.max_k, ctx->P.alpha, (long long)ctx->P.max_tests);
+                       ctx->P.max_k, ctx->P.alpha, (long long)ctx->P.max_tests, (const unsigned *)nullptr);
     FW_HIP(ctx, hipGetLastError());
     FW_HIP(ctx, hipEventRecord(pb.ev1, pb.launch_stream));
     return FW_OK;

@@ -272,3 +272,28 @@ def test_tests_expected_tsv_dense_rules():
             assert (g.df, g.suff_power) == (e[2], e[3])
             assert _close(g.stat, e[0], 1e-11) and _close(g.pval, e[1], 1e-9)
         eng.close()
+
+
+@pytest.mark.parametrize("ff,R", [(False, 0), (True, 100)])
+def test_device_rounds_equal_host_driver_and_oracle(ctx, ff, R, monkeypatch):
+    # fw_devhiton.hip for the discrete kinds: same directed results / weights / test counts as the host driver and
+    # the oracle (rounds of >= 64 targets run on the device; R = 100 with feed_forward exercises the whitelists)
+    kind, data, n, p, orc = ctx["kind"], ctx["data"], ctx["n"], ctx["p"], ctx["orc"]
+    res = {}
+    monkeypatch.setenv("FW_DEV_MIN_TARGETS", "64")  # the default threshold for discrete kinds is 4096 targets
+    for host in ("1", "0"):
+        monkeypatch.setenv("FW_HOST_HITON", host)
+        eng = fw.Engine(kind, n, p, max_k=3)
+        eng.set_data(data)
+        net = eng.lgl(feed_forward=ff, round_size=R)
+        res[host] = (net, eng.counters())
+        eng.close()
+    (nh, ch), (nd, cd) = res["1"], res["0"]
+    assert nh["edges"] == nd["edges"]
+    for key in ("pc_off", "pc_idx", "pc_weight", "pc_pval"):
+        assert np.array_equal(nh[key], nd[key], equal_nan=True), key
+    assert ch["cond_tests_ref"] == cd["cond_tests_ref"] and ch["subsets_calls"] == cd["subsets_calls"]
+    assert cd["kernel_launches"] != ch["kernel_launches"]  # the two drivers really are different code paths
+    exp = orc.learn(max_k=3, feed_forward=ff, round_size=max(R, 1) if ff else 1)
+    assert set(nd["edges"]) == set(exp["edges"])
+    assert cd["cond_tests_ref"] == exp["n_cond_tests"]
