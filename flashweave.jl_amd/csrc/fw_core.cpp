@@ -666,9 +666,10 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
     const uint64_t q = fz ? 256 : 4, smin = fz ? 256 : 8, smax = fz ? 8192 : 256;
     static const uint64_t seg_target = [] {
         const char *e = getenv("FW_SEG_TARGET");  // workgroups per launch the segment length aims for
-        return e && atoll(e) > 0 ? (uint64_t)atoll(e) : (uint64_t)4096;
+        return e && atoll(e) > 0 ? (uint64_t)atoll(e) : (uint64_t)0;
     }();
-    uint64_t seglen = (total / seg_target + q - 1) / q * q;
+    const uint64_t seg_tgt = seg_target ? seg_target : (fz ? 3072 : 4096);  // fz: runs of up to 32 ranks per lane
+    uint64_t seglen = (total / seg_tgt + q - 1) / q * q;
     seglen = std::max<uint64_t>(smin, std::min<uint64_t>(seglen, smax));
     size_t ns = 0;
     for (const FwPoolJob &j : pool.live)

@@ -32,7 +32,7 @@ struct DhTgt {
 struct DhGlobal {
     unsigned long long launched_ranks, next_ranks;
     unsigned int n_live_prev, n_live_next;
-    unsigned int ns, seglen, done, rounds, rounds_nonempty, pad;
+    unsigned int ns, seglen, done, rounds, rounds_nonempty, max_a;  // max_a: longest accepted list of any job so far
     unsigned long long cond_tests_ref, subsets_calls, evaluated;
     double alg_bytes;
     unsigned int ns_ring[64];  // segments of the last 64 planned launches (the host reads the record once per batch)
@@ -206,7 +206,7 @@ __device__ bool dh_advance(DhTgt &x, const DhArrays &A, int lane)
 // One wavefront per target: the lanes merge the job's segment records in parallel (first stop = minimum segment
 // index; otherwise the lexicographic maximum of (p, segment index), i.e. "later wins ties", tests.jl:338), lane 0 runs
 // the sequential part (commit, advance, next job).
-__global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, int ntg, const DhGlobal *__restrict__ g, DhArrays A,
+__global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, int ntg, DhGlobal *__restrict__ g, DhArrays A,
                                                       const FwSegOut *__restrict__ so, const long long *__restrict__ seg0,
                                                       unsigned long long *__restrict__ win, DhParams P)
 {
@@ -334,6 +334,7 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
             x.jbest_stat = 0.0;
             x.jevaluated = 0ull;
             x.jactive = 1;
+            if (lane == 0 && (unsigned int)x.na > g->max_a) atomicMax(&g->max_a, (unsigned int)x.na);  // rare: only on a new maximum
         }
         if (x.jactive) {
             const unsigned long long left = x.jN - x.jnext;
@@ -520,7 +521,8 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     const bool nb_on_dev = c->d_nb_idx != nullptr;
     const size_t nnz = (size_t)c->nb_off[p];
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const unsigned seg_target = 4096;
+    static const unsigned seg_target_env = [] { const char *e = getenv("FW_SEG_TARGET"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 0u; }();
+    const unsigned seg_target = seg_target_env ? seg_target_env : (c->P.kind == FW_FZ ? 3072u : 4096u);  // cfg3 sweep: 3072
     const unsigned max_ns = seg_target + (unsigned)ntg + 256u;  // capacity of the segment list
     const unsigned grid_seg = seg_target + 512u;                // striding workgroups of the segment kernel
     size_t need = pad(sizeof(DhTgt) * ntg) + pad(sizeof(DhGlobal)) + 2 * pad(sizeof(long long) * ((size_t)ntg + 1));
@@ -598,7 +600,11 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     P.seg_q = fz ? 256u : 4u;
     P.seg_min = fz ? 256u : 8u;
     P.disc_bytes_per_col = fz ? 0.0 : (double)c->P.n * (c->P.kind == FW_MI ? 1.0 : 2.0) / 8.0;
-    const bool any_big = 2 * max_cap > FW_TAB_A;  // an accepted list can hold at most 2 * cap entries
+    // The in-lane kernel (accepted lists beyond FW_TAB_A) is only launched when such a list can exist in the coming batch:
+    // without whitelists an accepted list grows by at most one entry per round, so max_a (longest list so far, read
+    // back once per batch) + BATCH bounds it; with whitelists a round can append several entries -> static bound.
+    const bool any_wl = !wl.empty();
+    const bool any_big_static = (any_wl ? 2 * max_cap : max_cap) > FW_TAB_A;
     const unsigned g_tg = (unsigned)((ntg + 3) / 4), g_fill = (max_ns + 255) / 256;  // step: one wavefront per target
     const unsigned *d_ns = &d_g->ns;
     // ---- rounds ----
@@ -609,7 +615,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     hipEvent_t ev[2 * BATCH];
     for (hipEvent_t &e : ev) FW_HIP(c, hipEventCreate(&e));
     auto planfill = [&]() {
-        hipLaunchKernelGGL(dh_step_kernel, dim3(g_tg), dim3(256), 0, st, d_tg, ntg, (const DhGlobal *)d_g, A, (const FwSegOut *)d_so,
+        hipLaunchKernelGGL(dh_step_kernel, dim3(g_tg), dim3(256), 0, st, d_tg, ntg, d_g, A, (const FwSegOut *)d_so,
                            (const long long *)d_seg0, d_win, P);
         hipLaunchKernelGGL(dh_plan_kernel, dim3(1), dim3(1024), 0, st, ntg, d_g, (const unsigned long long *)d_win, d_seg0,
                            seg_target, P.seg_q, P.seg_min);
@@ -624,6 +630,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     for (;;) {
         for (int r = 0; r < BATCH; ++r) {
             const bool timed = (r % time_every) == 0;
+            const bool any_big = any_big_static && (any_wl || hg->max_a + (unsigned)BATCH + 1u > (unsigned)FW_TAB_A);
             if (timed) (void)hipEventRecord(ev[2 * r], st);
             if ((rc2 = fz ? fwi_fz_segments_dev(c, grid_seg, d_segs, A.acc, d_so, d_ns, any_big, st)
                           : fwi_mi_segments_dev(c, max_ns, d_segs, A.acc, d_so, d_ns, st)))

@@ -612,7 +612,9 @@ __device__ __forceinline__ double pc_l3(double a, double b, double c)
 // reuses every partial correlation that does not involve the position that changed (for max_k = 3 that is 4 of the
 // 10 formula evaluations and 6 of the 10 matrix entries).  Rank order is preserved: a lane stops at its first
 // stopping rank, the workgroup takes the minimum over lanes.
-#define FW_RUN_MAX 16
+#ifndef FW_RUN_MAX
+#define FW_RUN_MAX 32  // chunk = 8192 ranks: fewer table builds / unrankings per test (16 -> 32: -9 % kernel time at cfg3)
+#endif
 // Table path of the size-3 enumeration (accepted sets of up to FZ_TAB_A variables, max_k <= 3).  With
 // (z1, z2, z3) = accepted[(i, j, k)], i < j < k, the recursion of statfuns.jl:44-53 needs
 //   rho(X,Y|z1,z2)   = l2(A1(i), LX(i,j), LY(i,j))          -- depends on (i, j) only
@@ -622,7 +624,8 @@ __device__ __forceinline__ double pc_l3(double a, double b, double c)
 // v: {LX, LY, cor[v][z1], variable id + Float32 flags, rho(X,Y|z1,v)}.  A test then costs one matrix gather, one
 // level-1, two level-2 and one level-3 evaluation instead of 3 + 2 + 1 evaluations and 4 gathers, and -- more
 // importantly -- no lane ever recomputes a prefix while the other 63 wait (the divergence of the in-lane caching
-// path).  A chunk of 4096 ranks touches at most 1021 entries for every |accepted| <= 512 (profiles/tools/tab_bound.py).
+// path).  A chunk of 256 * FW_RUN_MAX = 8192 ranks touches at most 1021 entries for every |accepted| <= 512
+// (profiles/tools/tab_bound.py 512 8192).
 #define FZ_TAB_A FW_TAB_A
 #define FZ_TAB_CAP 1024
 #define FZ_TAB_ZMASK 0x1FFFFFFF
@@ -778,7 +781,8 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 }
                 __syncthreads();
                 const int i0 = s_blk[0], i1 = s_blk[1];
-                const int E = fz_tab_off(i1 + 1, i0, a);  // <= 1021 for a <= 512 and chunks of 4096 ranks
+                const int E = fz_tab_off(i1 + 1, i0, a);  // <= 1021 for a <= 512 and chunks of 8192 ranks
+                if (E > FZ_TAB_CAP) __builtin_trap();      // would be a routing bug on the host side: fail loudly
                 if (E <= FZ_TAB_CAP) {
                     tab_ok = true;
                     tb_i0 = i0;

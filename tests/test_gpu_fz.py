@@ -331,3 +331,27 @@ def test_device_rounds_equal_host_driver_and_oracle(small, ff, R, monkeypatch):
     for e, w in exp["edges"].items():
         assert nd["edges"][e] == w
     assert cd["cond_tests_ref"] == exp["n_cond_tests"]
+
+
+def test_device_rounds_long_accepted_lists(monkeypatch):
+    # one shared factor: every variable stays associated with every other one given any 3 others, so accepted lists grow
+    # past FW_TAB_A = 512 and the device rounds have to switch on the in-lane kernel next to the table kernel
+    # (max_tests caps the job sizes).  Device rounds == host driver, bit for bit.
+    rng = np.random.default_rng(7)
+    n, p = 2000, 600  # n large enough that every partial correlation (~0.2) clears the threshold (~0.06) with margin
+    data = (rng.standard_normal((n, 1)) + 0.9 * rng.standard_normal((n, p))).astype(np.float32)
+    res = {}
+    for host in ("1", "0"):
+        monkeypatch.setenv("FW_HOST_HITON", host)
+        eng = fw.Engine("fz", n, p, max_k=3, max_tests=300)
+        eng.set_data(data)
+        eng.cor()
+        net = eng.lgl(feed_forward=False, round_size=0)
+        res[host] = (net, eng.counters())
+        eng.close()
+    (nh, ch), (nd, cd) = res["1"], res["0"]
+    assert np.diff(nd["pc_off"]).max() > 512          # some PC sets (hence accepted lists) exceed the table kernel's limit
+    assert nh["edges"] == nd["edges"]
+    for key in ("pc_off", "pc_idx", "pc_weight", "pc_pval"):
+        assert np.array_equal(nh[key], nd[key], equal_nan=True), key
+    assert ch["cond_tests_ref"] == cd["cond_tests_ref"]
