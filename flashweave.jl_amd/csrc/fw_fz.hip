@@ -975,6 +975,11 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                     }
                 }
                 // next combination in lexicographic order (sizes descend when one is exhausted)
+                if (s == 3 && pos[2] < a - 1) {  // by far the most frequent step, with static register indices (the
+                    ++pos[2];                     // generic code below indexes pos[] dynamically: ~60 instructions)
+                    chg = 2;
+                    continue;
+                }
                 int i = s - 1;
                 while (i >= 0 && pos[i] == a - s + i) --i;
                 if (i < 0) {
