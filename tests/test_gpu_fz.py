@@ -355,3 +355,24 @@ def test_device_rounds_long_accepted_lists(monkeypatch):
     for key in ("pc_off", "pc_idx", "pc_weight", "pc_pval"):
         assert np.array_equal(nh[key], nd[key], equal_nan=True), key
     assert ch["cond_tests_ref"] == cd["cond_tests_ref"]
+
+
+@pytest.mark.parametrize("max_k", [1, 2, 5])
+def test_device_rounds_other_max_k(small, max_k, monkeypatch):
+    # max_k = 5 runs the HIGHK variant of the segment kernel grid-strided under the device rounds; 1 and 2 the table
+    # kernel without any size-3 subsets
+    n, p, cm, orc = small["n"], small["p"], small["cm"], small["orc"]
+    res = {}
+    for host in ("1", "0"):
+        monkeypatch.setenv("FW_HOST_HITON", host)
+        eng = fw.Engine("fz", n, p, max_k=max_k)
+        eng.set_cor_mat(cm)
+        res[host] = (eng.lgl(feed_forward=False, round_size=0), eng.counters())
+        eng.close()
+    (nh, ch), (nd, cd) = res["1"], res["0"]
+    assert nh["edges"] == nd["edges"] and ch["cond_tests_ref"] == cd["cond_tests_ref"]
+    exp = orc.learn(max_k=max_k, feed_forward=False, round_size=1)
+    assert set(nd["edges"]) == set(exp["edges"])
+    for e, w in exp["edges"].items():
+        assert nd["edges"][e] == w
+    assert cd["cond_tests_ref"] == exp["n_cond_tests"]
