@@ -376,3 +376,16 @@ def test_device_rounds_other_max_k(small, max_k, monkeypatch):
     for e, w in exp["edges"].items():
         assert nd["edges"][e] == w
     assert cd["cond_tests_ref"] == exp["n_cond_tests"]
+
+
+def test_device_rounds_with_host_side_level0_lists(small, monkeypatch):
+    # FW_HOST_BH=1 leaves no device copy of the level-0 neighbour lists: the device rounds upload them themselves
+    n, p, cm = small["n"], small["p"], small["cm"]
+    nets = []
+    for host_bh in ("0", "1"):
+        monkeypatch.setenv("FW_HOST_BH", host_bh)
+        eng = fw.Engine("fz", n, p, max_k=3)
+        eng.set_cor_mat(cm)
+        nets.append(eng.lgl(feed_forward=False, round_size=0))
+        eng.close()
+    assert nets[0]["edges"] == nets[1]["edges"]
