@@ -55,6 +55,7 @@ struct DhParams {
     unsigned long long small_launch, w0_big, w0_small;  // window policy (fw_core.cpp: fwi_pool_add / fw_window_growth)
     unsigned int seg_q, seg_min;                        // segment length granularity / minimum (fz 256 / 256, discrete 4 / 8)
     double disc_bytes_per_col;                          // discrete kinds: n * b / 8 (algorithmic bytes per column), else 0
+    int elim_full;                                      // elimination-phase jobs start with the full enumeration as their window
 };
 
 __device__ __forceinline__ unsigned long long dh_binom(long long m, int t)
@@ -329,7 +330,10 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
             if (P.max_tests > 0 && (unsigned long long)P.max_tests < N) N = (unsigned long long)P.max_tests;
             x.jN = N;
             x.jnext = 0ull;
-            x.jwidth = x.na >= 64 ? P.w0_big : P.w0_small;
+            // Elimination phase: the candidate passed every test against (almost) this pool a moment ago, so nearly all
+            // of these jobs run to the end -- evaluate the whole enumeration in one window instead of two rounds
+            // (FW_ELIM_FULL=0 disables; cfg3: -20 % rounds for +2 % evaluated tests)
+            x.jwidth = (x.phase == 1 && P.elim_full) ? N : (x.na >= 64 ? P.w0_big : P.w0_small);
             x.jbest_p = -1.0;
             x.jbest_stat = 0.0;
             x.jevaluated = 0ull;
@@ -593,6 +597,10 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         P.small_launch = e ? (unsigned long long)atoll(e) : (1ull << 22);
         const char *w = getenv("FW_W0_BIG");
         P.w0_big = w ? (unsigned long long)atoll(w) : 16384ull;
+    }
+    {
+        const char *e = getenv("FW_ELIM_FULL");
+        P.elim_full = e ? atoi(e) : 1;
     }
     const bool fz = c->P.kind == FW_FZ;
     P.w0_small = fz ? 256ull : 16ull;

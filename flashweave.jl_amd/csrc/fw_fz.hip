@@ -692,6 +692,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     __shared__ unsigned long long s_stop[4];
     __shared__ double s_bx[4], s_bps[4];
     __shared__ unsigned long long s_br[4];
+    __shared__ unsigned int s_evc[4];  // tests really executed by each wavefront in the current chunk
     __shared__ double s_best_x, s_best_ps, s_best_stat;
     __shared__ unsigned long long s_best_rank;
     __shared__ float4 s_tab[TAB ? FZ_TAB_CAP : 1];    // {LX, LY, cor[v][z1], variable id | Float32 flags}
@@ -816,6 +817,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
         // lane best: ordered by x = |z|/sqrt2 ascending (= p descending); in the underflow regime (x > FZ_X_SUB, where
         // different x can give the same subnormal/zero p) by the exact p instead; later rank wins ties (tests.jl:338)
         double my_bx = FZ_X_NONE, my_bps = 0.0, my_ba = 0.0;
+        unsigned int my_done = 0;  // tests this lane executes in this chunk (it leaves its run at its first stop)
         if (any) {
             // unrank the first rank of the run
             unsigned long long rem = r0;
@@ -837,6 +839,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
             int boff = 0;
             for (unsigned long long r = r0; r < r1; ++r) {
                 double stat;
+                ++my_done;
                 if (TAB && s == 3 && tab_ok) {
                     const int pi = pos[0];
                     if (chg <= 0) boff = fz_tab_off(pi, tb_i0, a) - pi - 1;
@@ -1018,7 +1021,10 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 br = orr;
             }
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) my_done += __shfl_xor(my_done, o);
         if (lane == 0) {
+            s_evc[wave] = my_done;
             s_stop[wave] = ws;
             s_bx[wave] = bx;
             s_bps[wave] = bps;
@@ -1028,8 +1034,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
         unsigned long long first = s_stop[0];
 #pragma unroll
         for (int w = 1; w < 4; ++w) first = s_stop[w] < first ? s_stop[w] : first;
-        const unsigned long long cend = (cbase + 256ull * R) < seg.end ? (cbase + 256ull * R) : seg.end;
-        evaluated += cend - cbase;
+        evaluated += (unsigned long long)(s_evc[0] + s_evc[1] + s_evc[2] + s_evc[3]);  // executed tests, not chunk sizes
         if (first != NONE) {
             if (my_stop == first) {
                 FwSegOut o;

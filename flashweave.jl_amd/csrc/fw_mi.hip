@@ -390,6 +390,7 @@ __device__ __forceinline__ void mi_seg_body(const MiDev &P, const FwSeg *__restr
     __shared__ unsigned long long s_stop[4], s_br[4];
     __shared__ double s_sstat[4], s_sp[4], s_bp[4], s_bstat[4];
     __shared__ int s_sdf[4], s_spow[4], s_bdf[4];
+    __shared__ unsigned int s_evc[4];  // tests really executed by each wavefront in the current chunk
     const FwSeg seg = segs[sidx];
     const int a = seg.acc_len;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -411,6 +412,7 @@ __device__ __forceinline__ void mi_seg_body(const MiDev &P, const FwSeg *__restr
         unsigned long long my_stop = NONE, my_br = 0;
         double stop_stat = 0.0, stop_p = 0.0, my_bp = -1.0, my_bstat = 0.0;
         int stop_df = 0, stop_pow = 0, my_bdf = 0;
+        unsigned int my_done = 0;
         if (r0 < seg.end) {
             unsigned long long rem = r0;
             int s = max_k;
@@ -425,6 +427,7 @@ __device__ __forceinline__ void mi_seg_body(const MiDev &P, const FwSeg *__restr
 #pragma unroll
                 for (int q = 0; q < MI_MAX_K; ++q) zs[q] = (q < s) ? gacc[pos[q]] : 0;
                 const MiRes t = mi_test_wave(P, seg.X, seg.Y, zs, s, s_tab[wave]);
+                ++my_done;
                 const bool sig = (t.pval < alpha) && t.power;
                 if (!sig || (max_tests > 0 && r + 1 >= (unsigned long long)max_tests)) {
                     my_stop = r;
@@ -454,6 +457,7 @@ __device__ __forceinline__ void mi_seg_body(const MiDev &P, const FwSeg *__restr
             }
         }
         if (lane == 0) {
+            s_evc[wave] = my_done;
             s_stop[wave] = my_stop;
             s_sstat[wave] = stop_stat;
             s_sp[wave] = stop_p;
@@ -465,8 +469,7 @@ __device__ __forceinline__ void mi_seg_body(const MiDev &P, const FwSeg *__restr
             s_bdf[wave] = my_bdf;
         }
         __syncthreads();
-        const unsigned long long cend = (cbase + 4ull * R) < seg.end ? (cbase + 4ull * R) : seg.end;
-        evaluated += cend - cbase;
+        evaluated += (unsigned long long)(s_evc[0] + s_evc[1] + s_evc[2] + s_evc[3]);  // executed tests, not chunk sizes
         int fw = -1;
         unsigned long long first = NONE;
 #pragma unroll
