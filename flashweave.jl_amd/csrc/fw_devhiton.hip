@@ -365,7 +365,7 @@ __device__ __forceinline__ unsigned int dh_ceil_div(unsigned long long w, unsign
     return (unsigned int)q;
 }
 
-#define DH_PER 16  // targets per planning thread held in registers (more targets: extra passes over global memory)
+#define DH_PER 32  // targets per planning thread held in registers (more targets: extra passes over global memory)
 __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__restrict__ g, const unsigned long long *__restrict__ win,
                                                        long long *__restrict__ seg0, unsigned int seg_target, unsigned int seg_q,
                                                        unsigned int seg_min)
