@@ -128,6 +128,14 @@ struct MiRes {
     int df, power;
 };
 
+// word held by lane i (wave-uniform i) -> every lane
+__device__ __forceinline__ unsigned long long mi_rl64(unsigned long long v, int i)
+{
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, i);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), i);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 __device__ MiRes mi_test_wave(const MiDev &P, int X, int Y, const int *zs, int k, int *tab)
 {
     const int lane = threadIdx.x & 63;
@@ -175,18 +183,34 @@ __device__ MiRes mi_test_wave(const MiDev &P, int X, int Y, const int *zs, int k
         hz[j] = (j < k && P.hi) ? P.hi + (size_t)zs[j] * P.W : nullptr;
     }
     int my_counted = 0;
-    for (int w = 0; w < P.W; ++w) {
+    // Lane l first loads word w0 + l of every column (coalesced, all loads in flight at once); the words are then
+    // handed to the whole wavefront one at a time with v_readlane.  (One dependent round of ~10 global loads per
+    // word was ~1.5 us x 79 words = 120 us per test at cfg4: the kernel was bound by L2 latency, not by anything else.)
+    for (int w0 = 0; w0 < P.W; w0 += 64) {
+      const int wl = w0 + lane;
+      const bool wok = wl < P.W;
+      const unsigned long long rxn = wok ? cx[wl] : 0ull, ryn = wok ? cy[wl] : 0ull;
+      const unsigned long long rxh = (wok && hx) ? hx[wl] : 0ull, ryh = (wok && hy) ? hy[wl] : 0ull;
+      unsigned long long rzn[MI_MAX_K], rzh[MI_MAX_K];
+#pragma unroll
+      for (int j = 0; j < MI_MAX_K; ++j) {
+          rzn[j] = (j < k && wok) ? cz[j][wl] : 0ull;
+          rzh[j] = (j < k && wok && hz[j]) ? hz[j][wl] : 0ull;
+      }
+      const int nw = (P.W - w0) < 64 ? (P.W - w0) : 64;
+      for (int wi = 0; wi < nw; ++wi) {
+        const int w = w0 + wi;
         const int row = w * 64 + lane;
-        const unsigned long long xn = cx[w], yn = cy[w];
-        const unsigned long long xh = hx ? hx[w] : 0ull, yh = hy ? hy[w] : 0ull;
+        const unsigned long long xn = mi_rl64(rxn, wi), yn = mi_rl64(ryn, wi);
+        const unsigned long long xh = mi_rl64(rxh, wi), yh = mi_rl64(ryh, wi);
         const int xv = (int)((xn >> lane) & 1ull) + (int)((xh >> lane) & 1ull);
         const int yv = (int)((yn >> lane) & 1ull) + (int)((yh >> lane) & 1ull);
         int key = 0, mul = 1, anyz = 0;
 #pragma unroll
         for (int j = 0; j < MI_MAX_K; ++j)
             if (j < k) {
-                const unsigned long long zn = cz[j][w];
-                const unsigned long long zh = hz[j] ? hz[j][w] : 0ull;
+                const unsigned long long zn = mi_rl64(rzn[j], wi);
+                const unsigned long long zh = mi_rl64(rzh[j], wi);
                 const int zv = (int)((zn >> lane) & 1ull) + (int)((zh >> lane) & 1ull);
                 key += zv * mul;  // key = sum_j z_j * L^j (types.jl:32-39 cum_levels)
                 mul *= L;
@@ -203,6 +227,7 @@ __device__ MiRes mi_test_wave(const MiDev &P, int X, int Y, const int *zs, int k
             atomicAdd(&tab[xv + L * yv + L2 * key], 1);
             ++my_counted;
         }
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
