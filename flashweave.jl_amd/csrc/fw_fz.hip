@@ -378,23 +378,90 @@ struct FzL0Counters {
     unsigned long long n_nan;  // pairs with NaN p (excluded from m)
 };
 
-__global__ __launch_bounds__(256) void fz_level0_kernel(const float *__restrict__ cor, int p, double alpha, double zscale,
+// Kernel 1 (screen): p < alpha  <=>  |r| beyond the exact thresholds of fz_thresholds_kernel (lower edge of the
+// guard band); only those pairs (3 % at cfg3) go on to the Float64 log / erfc of kernel 2, densely packed, instead of
+// every wavefront paying for them.  NaN correlations are counted (they are excluded from m, tests.jl:397-398).
+#define FZ_L0_ROWS 8     // rows per workgroup
+#define FZ_L0_COLS 1024  // columns per workgroup (4 per thread, one float4 load)
+__global__ __launch_bounds__(256) void fz_level0_kernel(const float *__restrict__ cor, int p, const double *__restrict__ thr,
                                                         FzL0Counters *cnt, unsigned long long cap, int32_t *out_i,
-                                                        int32_t *out_j, float *out_r, double *out_p)
+                                                        int32_t *out_j, float *out_r)
 {
-    const int i = blockIdx.y;
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if ((int)(blockIdx.x * 256 + 255) <= i) return;  // whole block below/on the diagonal
-    bool sig = false, isn = false;
+    // 8 x 1024 pairs per workgroup (one row x 256 columns per workgroup was bound by workgroup dispatch: 400 000
+    // workgroups of almost no work at cfg3)
+    const int i0 = blockIdx.y * FZ_L0_ROWS;
+    const int jb = blockIdx.x * FZ_L0_COLS;
+    if (jb + FZ_L0_COLS - 1 <= i0) return;  // tile entirely on/below the diagonal
+    const int j0 = jb + threadIdx.x * 4;
+    const int lane = threadIdx.x & 63;
+    const float lo_pos = (float)thr[0], lo_neg = (float)thr[2];
+    // Float32 screen against thresholds lowered by 1e-6 relative (>> the rounding of the conversion): it can only let a
+    // few more pairs through to the exact kernel, never drop one
+    const float flo_pos = lo_pos * 0.999999f, flo_neg = lo_neg * 0.999999f;
+    unsigned int n_nan = 0;
+    for (int ii = 0; ii < FZ_L0_ROWS; ++ii) {
+        const int i = i0 + ii;
+        if (i >= p) break;
+        float rv[4] = {0.f, 0.f, 0.f, 0.f};
+        const float *row = cor + (size_t)i * p;
+        if (j0 + 3 < p && ((((size_t)i * p + j0) & 3) == 0)) {
+            const float4 q = *(const float4 *)(row + j0);
+            rv[0] = q.x;
+            rv[1] = q.y;
+            rv[2] = q.z;
+            rv[3] = q.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j0 + u < p) rv[u] = row[j0 + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u;
+            const bool in = j > i && j < p;
+            const float r = rv[u];
+            const bool isn = in && isnan(r);
+            const bool sig = in && !isn && fabsf(r) >= (r < 0.0f ? flo_neg : flo_pos);
+            n_nan += isn;
+            const unsigned long long ms = __ballot(sig);
+            if (ms) {
+                unsigned long long base = 0;
+                const int leader = __ffsll((long long)ms) - 1;
+                if (lane == leader) base = atomicAdd(&cnt->n_sig, (unsigned long long)__popcll(ms));
+                base = __shfl(base, leader);
+                if (sig) {
+                    const unsigned long long slot = base + __popcll(ms & ((1ull << lane) - 1ull));
+                    if (slot < cap) {
+                        out_i[slot] = i;
+                        out_j[slot] = j;
+                        out_r[slot] = r;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n_nan += __shfl_xor(n_nan, o);
+    if (lane == 0 && n_nan) atomicAdd(&cnt->n_nan, (unsigned long long)n_nan);
+}
+
+// Kernel 2 (exact): Fisher-z p-value of the screened pairs (tests.jl:149-159); keeps p < alpha.
+__global__ __launch_bounds__(256) void fz_level0_exact_kernel(const int32_t *__restrict__ ci, const int32_t *__restrict__ cj,
+                                                              const float *__restrict__ cr, unsigned long long ncand,
+                                                              double alpha, double zscale, FzL0Counters *cnt,
+                                                              unsigned long long cap, int32_t *out_i, int32_t *out_j,
+                                                              float *out_r, double *out_p)
+{
+    const unsigned long long t = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    bool sig = false;
     float r = 0.0f;
     double pv = 1.0;
-    if (j > i && j < p) {
-        r = cor[(size_t)i * p + j];
+    if (t < ncand) {
+        r = cr[t];
         pv = fz_pval_dev((double)r, zscale);
-        isn = isnan(pv);
         sig = pv < alpha;
     }
-    const unsigned long long ms = __ballot(sig), mn = __ballot(isn);
+    const unsigned long long ms = __ballot(sig);
     const int lane = threadIdx.x & 63;
     if (ms) {
         unsigned long long base = 0;
@@ -403,14 +470,13 @@ __global__ __launch_bounds__(256) void fz_level0_kernel(const float *__restrict_
         if (sig) {
             const unsigned long long slot = base + __popcll(ms & ((1ull << lane) - 1ull));
             if (slot < cap) {
-                out_i[slot] = i;
-                out_j[slot] = j;
+                out_i[slot] = ci[t];
+                out_j[slot] = cj[t];
                 out_r[slot] = r;
                 out_p[slot] = pv;
             }
         }
     }
-    if (mn && lane == 0) atomicAdd(&cnt->n_nan, (unsigned long long)__popcll(mn));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1134,6 +1200,8 @@ __global__ __launch_bounds__(256, 4) void fz_subsets_seg_kernel(const float *__r
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
+static int fz_ensure_thresholds(fw_ctx *ctx, hipStream_t stream);
+
 static double fz_zscale(const fw_ctx *ctx)
 {
     const long long sf = (long long)ctx->P.n - 3;  // len_z = 0 always (tests.jl:156,256)
@@ -1176,26 +1244,48 @@ int fwi_fz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
         *m_reliable = 0;
         return FW_OK;
     }
+    {
+        int rc0 = fz_ensure_thresholds(ctx, ctx->stream);
+        if (rc0) return rc0;
+    }
     unsigned long long cap = (unsigned long long)std::min<long long>(npairs, 4ll << 20);
     if (cap == 0) cap = 1;
     FzL0Counters h{};
     for (int attempt = 0; attempt < 2; ++attempt) {
         int rc;
-        if ((rc = fw_dev_reserve(ctx, ctx->d_tmp0, sizeof(FzL0Counters)))) return rc;
+        if ((rc = fw_dev_reserve(ctx, ctx->d_tmp0, 2 * sizeof(FzL0Counters)))) return rc;
         if ((rc = fw_dev_reserve(ctx, ctx->d_tmp1, cap * (2 * sizeof(int32_t) + sizeof(float))))) return rc;
         if ((rc = fw_dev_reserve(ctx, ctx->d_tmp2, cap * sizeof(double)))) return rc;
-        FW_HIP(ctx, hipMemsetAsync(ctx->d_tmp0.ptr, 0, sizeof(FzL0Counters), ctx->stream));
+        if ((rc = fw_dev_reserve(ctx, ctx->d_jobs, cap * (2 * sizeof(int32_t) + sizeof(float))))) return rc;
+        FW_HIP(ctx, hipMemsetAsync(ctx->d_tmp0.ptr, 0, 2 * sizeof(FzL0Counters), ctx->stream));
+        FzL0Counters *d_c1 = (FzL0Counters *)ctx->d_tmp0.ptr, *d_c2 = d_c1 + 1;
         int32_t *oi = (int32_t *)ctx->d_tmp1.ptr;
         int32_t *oj = oi + cap;
         float *orr = (float *)(oj + cap);
         double *op = (double *)ctx->d_tmp2.ptr;
-        dim3 grid((p + 255) / 256, p);
-        hipLaunchKernelGGL(fz_level0_kernel, grid, dim3(256), 0, ctx->stream, ctx->d_cor, p, ctx->P.alpha, fz_zscale(ctx),
-                           (FzL0Counters *)ctx->d_tmp0.ptr, cap, oi, oj, orr, op);
+        int32_t *ci = (int32_t *)ctx->d_jobs.ptr;
+        int32_t *cj = ci + cap;
+        float *cr = (float *)(cj + cap);
+        dim3 grid((p + FZ_L0_COLS - 1) / FZ_L0_COLS, (p + FZ_L0_ROWS - 1) / FZ_L0_ROWS);
+        hipLaunchKernelGGL(fz_level0_kernel, grid, dim3(256), 0, ctx->stream, ctx->d_cor, p, (const double *)ctx->d_thr, d_c1, cap, ci,
+                           cj, cr);
         FW_HIP(ctx, hipGetLastError());
-        FW_HIP(ctx, hipMemcpyAsync(&h, ctx->d_tmp0.ptr, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        FzL0Counters h1{};
+        FW_HIP(ctx, hipMemcpyAsync(&h1, d_c1, sizeof(h1), hipMemcpyDeviceToHost, ctx->stream));
         FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->cnt.kernel_launches += 1;
+        if (h1.n_sig > cap) {  // more screened pairs than the buffer holds: retry with the exact count
+            cap = h1.n_sig;
+            continue;
+        }
+        if (h1.n_sig)
+            hipLaunchKernelGGL(fz_level0_exact_kernel, dim3((unsigned)((h1.n_sig + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const int32_t *)ci, (const int32_t *)cj, (const float *)cr, h1.n_sig, ctx->P.alpha, fz_zscale(ctx),
+                               d_c2, cap, oi, oj, orr, op);
+        FW_HIP(ctx, hipGetLastError());
+        FW_HIP(ctx, hipMemcpyAsync(&h, d_c2, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        h.n_nan = h1.n_nan;
+        ctx->cnt.kernel_launches += 2;
         if (h.n_sig <= cap) {
             const size_t k = (size_t)h.n_sig;
             if (dev) {  // results stay on the device for fwi_bh_csr_device
