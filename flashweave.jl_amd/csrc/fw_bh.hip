@@ -75,7 +75,8 @@ __global__ void bh_rows_kernel(const unsigned long long *__restrict__ keys, cons
     pv[q] = padj[t];
 }
 
-__global__ void bh_offsets_kernel(const unsigned long long *__restrict__ keys, size_t n2, int p, long long *__restrict__ off)
+__global__ void bh_offsets_kernel(const unsigned long long *__restrict__ keys, size_t n2, int p, long long *__restrict__ off,
+                                  int *__restrict__ off32)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v > p) return;
@@ -89,6 +90,7 @@ __global__ void bh_offsets_kernel(const unsigned long long *__restrict__ keys, s
             hi = mid;
     }
     off[v] = (long long)lo;
+    off32[v] = (int)lo;
 }
 
 inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -102,6 +104,8 @@ int fwi_bh_csr_device(fw_ctx *ctx, const FwL0Dev &in, int64_t m)
     ctx->d_nb_off = nullptr;
     ctx->d_nb_idx = nullptr;
     ctx->d_nb_stat = ctx->d_nb_p = nullptr;
+    ctx->d_cand = nullptr;
+    ctx->nb_host_valid = true;  // (empty lists until proven otherwise)
     ctx->nb_off.assign((size_t)p + 1, 0);
     ctx->nb_idx.clear();
     ctx->nb_stat.clear();
@@ -110,14 +114,17 @@ int fwi_bh_csr_device(fw_ctx *ctx, const FwL0Dev &in, int64_t m)
     if (k > 0xFFFFFFF0ull) return fw_fail(ctx, FW_ERR_LIMIT, "level-0: %zu significant pairs exceed the 32-bit index range", k);
     hipStream_t st = ctx->stream;
     // temp storage sizes of the three library calls
-    size_t tb_sort1 = 0, tb_scan = 0, tb_sort2 = 0;
+    size_t tb_sort1 = 0, tb_scan = 0, tb_sort2 = 0, tb_seg = 0;
     FW_HIP(ctx, (hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb_sort1, (const double *)nullptr, (double *)nullptr,
                                                              (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)k, 0, 64, st)));
     FW_HIP(ctx, (hipcub::DeviceScan::InclusiveScan(nullptr, tb_scan, (const double *)nullptr, (double *)nullptr, MinOp(), (int)k, st)));
     FW_HIP(ctx, (hipcub::DeviceRadixSort::SortPairs(nullptr, tb_sort2, (const unsigned long long *)nullptr,
                                                    (unsigned long long *)nullptr, (const uint32_t *)nullptr,
                                                    (uint32_t *)nullptr, (int)(2 * k), 0, 64, st)));
-    const size_t tb = std::max(tb_sort1, std::max(tb_scan, tb_sort2));
+    FW_HIP(ctx, (hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tb_seg, (const double *)nullptr, (double *)nullptr,
+                                                            (const int32_t *)nullptr, (int32_t *)nullptr, (int)(2 * k), p,
+                                                            (const int *)nullptr, (const int *)nullptr, 0, 64, st)));
+    const size_t tb = std::max(std::max(tb_sort1, tb_seg), std::max(tb_scan, tb_sort2));
     // carve one scratch buffer
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -128,7 +135,8 @@ int fwi_bh_csr_device(fw_ctx *ctx, const FwL0Dev &in, int64_t m)
     const size_t o_tmp = take(tb), o_pdesc = take(k * 8), o_idesc = take(k * 4), o_iota = take(k * 4), o_adj = take(k * 8),
                  o_padj = take(k * 8), o_cnt = take(8), o_keys = take(2 * k * 8), o_pay = take(2 * k * 4),
                  o_keys2 = take(2 * k * 8), o_pay2 = take(2 * k * 4), o_idx = take(2 * k * 4), o_st = take(2 * k * 8),
-                 o_pv = take(2 * k * 8), o_off = take(((size_t)p + 1) * 8);
+                 o_pv = take(2 * k * 8), o_off = take(((size_t)p + 1) * 8), o_off32 = take(((size_t)p + 1) * 4),
+                 o_cand = take(2 * k * 4), o_psort = take(2 * k * 8);
     int rc;
     if ((rc = fw_dev_reserve(ctx, ctx->d_bh, off))) return rc;
     char *B = (char *)ctx->d_bh.ptr;
@@ -168,21 +176,45 @@ int fwi_bh_csr_device(fw_ctx *ctx, const FwL0Dev &in, int64_t m)
                                                    pay2, (int)n2, 0, 32 + bits, st)));
     hipLaunchKernelGGL(bh_rows_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, (const unsigned long long *)keys2,
                        (const uint32_t *)pay2, in.stat64, in.stat32, (const double *)padj, (size_t)n2, idx, sto, pvo);
+    int *off32 = (int *)(B + o_off32);
+    int32_t *cand = (int32_t *)(B + o_cand);
+    double *psort = (double *)(B + o_psort);
     hipLaunchKernelGGL(bh_offsets_kernel, dim3((unsigned)((p + 1 + 255) / 256)), dim3(256), 0, st,
-                       (const unsigned long long *)keys2, (size_t)n2, p, offs);
+                       (const unsigned long long *)keys2, (size_t)n2, p, offs, off32);
+    // candidate order of every variable (hiton.jl:211-217): its neighbours by ascending adjusted p, ties by ascending
+    // index = a STABLE sort of each row by p (radix sort is stable; rows are already in ascending partner order)
+    size_t t4 = tb;
+    FW_HIP(ctx, (hipcub::DeviceSegmentedRadixSort::SortPairs(B + o_tmp, t4, (const double *)pvo, psort, (const int32_t *)idx, cand,
+                                                            (int)n2, p, (const int *)off32, (const int *)off32 + 1, 0, 64, st)));
     FW_HIP(ctx, hipGetLastError());
-    ctx->nb_idx.resize((size_t)n2);
-    ctx->nb_stat.resize((size_t)n2);
-    ctx->nb_p.resize((size_t)n2);
+    // only the row offsets go to the host now; partners / statistics / p-values follow on demand (fwi_nb_host_ensure):
+    // the device-resident rounds never need them there (58 MB at cfg3)
     FW_HIP(ctx, hipMemcpyAsync(ctx->nb_off.data(), offs, ((size_t)p + 1) * 8, hipMemcpyDeviceToHost, st));
-    FW_HIP(ctx, hipMemcpyAsync(ctx->nb_idx.data(), idx, (size_t)n2 * 4, hipMemcpyDeviceToHost, st));
-    FW_HIP(ctx, hipMemcpyAsync(ctx->nb_stat.data(), sto, (size_t)n2 * 8, hipMemcpyDeviceToHost, st));
-    FW_HIP(ctx, hipMemcpyAsync(ctx->nb_p.data(), pvo, (size_t)n2 * 8, hipMemcpyDeviceToHost, st));
     FW_HIP(ctx, hipStreamSynchronize(st));
-    ctx->cnt.kernel_launches += 3;
+    ctx->cnt.kernel_launches += 4;
+    ctx->nb_host_valid = false;
+    ctx->d_cand = cand;
     ctx->d_nb_off = offs;  // stay valid until the next level-0 (the device HITON rounds read them)
     ctx->d_nb_idx = idx;
     ctx->d_nb_stat = sto;
     ctx->d_nb_p = pvo;
+    return FW_OK;
+}
+
+// Host copies of the neighbour lists (partners, statistics, adjusted p) on demand.
+int fwi_nb_host_ensure(fw_ctx *ctx)
+{
+    if (ctx->nb_host_valid) return FW_OK;
+    const size_t n2 = (size_t)ctx->nb_off[ctx->P.p];
+    ctx->nb_idx.resize(n2);
+    ctx->nb_stat.resize(n2);
+    ctx->nb_p.resize(n2);
+    if (n2) {
+        if (!ctx->d_nb_idx) return fw_fail(ctx, FW_ERR_STATE, "level-0 neighbour lists are neither on the host nor on the device");
+        FW_HIP(ctx, hipMemcpy(ctx->nb_idx.data(), ctx->d_nb_idx, n2 * 4, hipMemcpyDeviceToHost));
+        FW_HIP(ctx, hipMemcpy(ctx->nb_stat.data(), ctx->d_nb_stat, n2 * 8, hipMemcpyDeviceToHost));
+        FW_HIP(ctx, hipMemcpy(ctx->nb_p.data(), ctx->d_nb_p, n2 * 8, hipMemcpyDeviceToHost));
+    }
+    ctx->nb_host_valid = true;
     return FW_OK;
 }

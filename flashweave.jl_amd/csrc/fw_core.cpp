@@ -357,6 +357,8 @@ int fw_level0(fw_ctx *c, int64_t *nnz_out)
     c->d_nb_off = nullptr;
     c->d_nb_idx = nullptr;
     c->d_nb_stat = c->d_nb_p = nullptr;
+    c->d_cand = nullptr;
+    c->nb_host_valid = true;
     const size_t k = pi.size();
     const double t_host0 = now_s();
     if (c->P.fdr && k > 0) {
@@ -456,6 +458,7 @@ int fw_level0_get(const fw_ctx *c, int64_t *off, int32_t *idx, double *stat, dou
 {
     CHECK_CTX(c);
     if (!c->have_level0) return fw_fail(c, FW_ERR_STATE, "fw_level0_get: fw_level0 has not run");
+    if (int rc = fwi_nb_host_ensure(const_cast<fw_ctx *>(c))) return rc;  // lists may still live on the device only
     if (off) memcpy(off, c->nb_off.data(), sizeof(int64_t) * c->nb_off.size());
     const size_t tot = c->nb_idx.size();
     if (idx && tot) memcpy(idx, c->nb_idx.data(), sizeof(int32_t) * tot);

@@ -20,6 +20,7 @@ struct DhTgt {
     int32_t T, phase, pos, nc;  // nc = candidates of the current phase
     int32_t na, ntpc, npc, wl_n;
     long long co;  // offset of this target's arrays (capacity cap each; accepted list: 2 * co, 2 * cap)
+    long long cand_off;  // offset of its interleaving candidates in DhArrays::cand0
     long long wl_off, nb_off;
     int32_t nb_n, cap;
     int32_t jactive, pad0;
@@ -110,7 +111,7 @@ __device__ bool dh_advance(DhTgt &x, const DhArrays &A, int lane)
     int32_t *acc = A.acc + 2 * x.co;
     for (;;) {
         if (x.phase == 2) return false;
-        const int32_t *cands = x.phase == 0 ? A.cand0 + x.co : A.tpc_key + x.co;
+        const int32_t *cands = x.phase == 0 ? A.cand0 + x.cand_off : A.tpc_key + x.co;
         int32_t *dkey = (x.phase == 0 ? A.tpc_key : A.pc_key) + x.co;
         double *dstat = (x.phase == 0 ? A.tpc_stat : A.pc_stat) + x.co;
         double *dp = (x.phase == 0 ? A.tpc_p : A.pc_p) + x.co;
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
             }
         }
         if (finished) {  // commit: issig (tests.jl:1-3) -> hiton.jl:61-63
-            const int32_t *cands = x.phase == 0 ? A.cand0 + x.co : A.tpc_key + x.co;
+            const int32_t *cands = x.phase == 0 ? A.cand0 + x.cand_off : A.tpc_key + x.co;
             const int32_t cand = cands[x.pos];
             ++x.pos;
             if (r_p < P.alpha && r_pow) {
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(256) void dh_fill_kernel(const DhTgt *__restrict__ 
     const DhTgt &x = tg[lo - 1];
     const unsigned long long seglen = g->seglen;
     const unsigned long long k = (unsigned long long)((long long)s - seg0[lo - 1]);
-    const int32_t *cands = x.phase == 0 ? A.cand0 + x.co : A.tpc_key + x.co;
+    const int32_t *cands = x.phase == 0 ? A.cand0 + x.cand_off : A.tpc_key + x.co;
     FwSeg sg;
     sg.X = x.T;
     sg.Y = cands[x.pos];
@@ -498,6 +499,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     hipStream_t st = c->pb[0].stream;
     const int p = c->P.p;
     // ---- host-side layout ----
+    const bool use_devc = in[0].nc_dev >= 0 && c->d_cand != nullptr;  // candidate lists built on the device (fw_bh.hip)
     std::vector<DhTgt> tg((size_t)ntg);
     std::vector<int32_t> cand0, wl;
     long long co = 0, wo = 0;
@@ -505,15 +507,16 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     for (int t = 0; t < ntg; ++t) {
         DhTgt x{};
         x.T = in[t].T;
-        x.nc = (int32_t)in[t].cands.size();
+        x.nc = use_devc ? in[t].nc_dev : (int32_t)in[t].cands.size();
         x.cap = x.nc;
+        x.cand_off = use_devc ? c->nb_off[in[t].T] : co;
         x.phase = x.nc == 0 ? 2 : 0;
         x.co = co;
         x.wl_off = wo;
         x.wl_n = in[t].wl_n;
         x.nb_off = c->nb_off[x.T];
         x.nb_n = (int32_t)(c->nb_off[x.T + 1] - c->nb_off[x.T]);
-        cand0.insert(cand0.end(), in[t].cands.begin(), in[t].cands.end());
+        if (!use_devc) cand0.insert(cand0.end(), in[t].cands.begin(), in[t].cands.end());
         if (in[t].wl_n) wl.insert(wl.end(), in[t].wl, in[t].wl + in[t].wl_n);
         co += x.nc;
         wo += in[t].wl_n;
@@ -551,7 +554,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     unsigned long long *d_win = (unsigned long long *)carve(sizeof(unsigned long long) * ((size_t)ntg + 1));
     DhArrays A{};
     int32_t *d_cand0 = (int32_t *)carve(4 * tot + 4);
-    A.cand0 = d_cand0;
+    A.cand0 = use_devc ? c->d_cand : d_cand0;
     A.tpc_key = (int32_t *)carve(4 * tot + 4);
     A.pc_key = (int32_t *)carve(4 * tot + 4);
     A.acc = (int32_t *)carve(4 * 2 * tot + 4);
@@ -566,7 +569,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     FW_HIP(c, hipMemcpyAsync(d_tg, tg.data(), sizeof(DhTgt) * ntg, hipMemcpyHostToDevice, st));
     FW_HIP(c, hipMemsetAsync(d_g, 0, sizeof(DhGlobal), st));
     FW_HIP(c, hipMemsetAsync(d_seg0, 0, sizeof(long long) * ((size_t)ntg + 1), st));
-    if (tot) FW_HIP(c, hipMemcpyAsync(d_cand0, cand0.data(), 4 * tot, hipMemcpyHostToDevice, st));
+    if (tot && !use_devc) FW_HIP(c, hipMemcpyAsync(d_cand0, cand0.data(), 4 * tot, hipMemcpyHostToDevice, st));
     if (!wl.empty()) FW_HIP(c, hipMemcpyAsync(d_wl, wl.data(), 4 * wl.size(), hipMemcpyHostToDevice, st));
     if (nb_on_dev) {
         A.nb_off = c->d_nb_off;

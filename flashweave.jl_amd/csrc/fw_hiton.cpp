@@ -40,6 +40,7 @@ struct Target {
     int phase = 0;  // 0 = interleaving, 1 = elimination, 2 = finished
     size_t pos = 0;
     std::vector<int32_t> cands;   // current phase's candidate list
+    int32_t nc_dev = -1;          // device rounds: number of candidates in the device-built list (no host copy)
     std::vector<int32_t> acc;     // accepted (conditioning pool)
     ODict TPC, PC;
     const int32_t *wl = nullptr;  // sorted whitelist (snapshot of the running graph)
@@ -163,6 +164,7 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
     std::vector<std::vector<int32_t>> adj(p);  // running graph, sorted
 
     if (c->P.max_k == 0) {  // learning.jl:171-172
+        if (int rc = fwi_nb_host_ensure(c)) return rc;
         for (int v = 0; v < p; ++v) {
             const int64_t o = c->nb_off[v];
             const int deg = (int)(c->nb_off[v + 1] - o);
@@ -175,6 +177,22 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
         for (int r0 = 0; r0 < nt; r0 += R) {
             const int r1 = std::min(nt, r0 + R);
             // this rank's targets of the round: dealt round-robin in schedule order
+            size_t n_my = 0;
+            for (int i = r0; i < r1; ++i) n_my += ((i - r0) % opt.world_size == opt.rank);
+            // Device-resident rounds (fw_devhiton.hip; every kind but fz_nz): no host round trip per window.  FW_HOST_HITON=1
+            // keeps the host pool below for every kind (it is also what rounds of fewer than 64 targets use: the
+            // reference's single_il schedule posts one target per round and would pay the device set-up each time).
+            // Discrete jobs are tiny (a few tests each): the device rounds only pay once thousands of targets keep the
+            // launches busy (cfg4: 191 -> 175 ms; cfg2 with 1000 targets: 30 -> 31 ms, so it stays on the host pool).
+            const char *hh = getenv("FW_HOST_HITON");
+            const bool host_only = hh && atoi(hh) == 1;
+            const bool no_power = c->P.kind == FW_FZ && c->P.n < c->n_obs_min_eff;  // no device work at all
+            const char *mt = getenv("FW_DEV_MIN_TARGETS");  // test knob
+            const size_t min_targets = mt ? (size_t)atol(mt) : (c->P.kind == FW_FZ ? 64 : 4096);
+            const bool use_dev = !host_only && c->P.kind != FW_FZ_NZ && !no_power && n_my >= min_targets;
+            const bool dev_cands = use_dev && c->d_cand != nullptr;  // candidate order already built on the device (fw_bh.hip)
+            if (!dev_cands)
+                if (int rc = fwi_nb_host_ensure(c)) return rc;
             std::vector<Target> tg;
             for (int i = r0; i < r1; ++i) {
                 if ((i - r0) % opt.world_size != opt.rank) continue;
@@ -188,35 +206,35 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                 // hiton.jl:211-217: candidates with adj p < alpha, stable sort by p
                 const int64_t o = c->nb_off[t.T];
                 const int deg = (int)(c->nb_off[t.T + 1] - o);
-                std::vector<int32_t> idx;
-                for (int q = 0; q < deg; ++q)
-                    if (c->nb_p[o + q] < c->P.alpha) idx.push_back(q);
-                std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return c->nb_p[o + a] < c->nb_p[o + b]; });
-                for (int32_t q : idx) t.cands.push_back(c->nb_idx[o + q]);
-                if (t.cands.empty()) t.phase = 2;  // hiton.jl:336-338
+                if (dev_cands) {
+                    t.nc_dev = deg;  // every stored neighbour has adj p < alpha; the sorted list lives in c->d_cand
+                    if (deg == 0) t.phase = 2;
+                } else {
+                    std::vector<int32_t> idx;
+                    for (int q = 0; q < deg; ++q)
+                        if (c->nb_p[o + q] < c->P.alpha) idx.push_back(q);
+                    std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return c->nb_p[o + a] < c->nb_p[o + b]; });
+                    for (int32_t q : idx) t.cands.push_back(c->nb_idx[o + q]);
+                    if (t.cands.empty()) t.phase = 2;  // hiton.jl:336-338
+                }
                 if (opt.feed_forward && !adj[t.T].empty()) {
                     t.wl = adj[t.T].data();  // adj is only modified between rounds
                     t.wl_n = (int)adj[t.T].size();
                 }
                 tg.push_back(std::move(t));
             }
-            // Device-resident rounds (fw_devhiton.hip; every kind but fz_nz): no host round trip per window.  FW_HOST_HITON=1 keeps the
-            // host pool below for every kind (it is also what rounds of fewer than 64 targets use: the reference's
-            // single_il schedule posts one target per round and would pay the device set-up each time).
             bool ran_dev = false;
             {
-                const char *hh = getenv("FW_HOST_HITON");
-                const bool host_only = hh && atoi(hh) == 1;
-                const bool no_power = c->P.kind == FW_FZ && c->P.n < c->n_obs_min_eff;  // no device work at all
-                // discrete jobs are tiny (a few tests each): the device rounds only pay once thousands of targets keep the
-                // launches busy (cfg4: 191 -> 175 ms; cfg2 with 1000 targets: 30 -> 31 ms, so it stays on the host pool)
-                const char *mt = getenv("FW_DEV_MIN_TARGETS");  // test knob
-                const size_t min_targets = mt ? (size_t)atol(mt) : (c->P.kind == FW_FZ ? 64 : 4096);
-                if (!host_only && c->P.kind != FW_FZ_NZ && !no_power && tg.size() >= min_targets) {
+                if (use_dev) {
                     std::vector<FwDhTarget> din(tg.size());
                     for (size_t i = 0; i < tg.size(); ++i) {
                         din[i].T = tg[i].T;
-                        if (tg[i].phase != 2) din[i].cands = tg[i].cands;
+                        if (tg[i].phase != 2) {
+                            din[i].cands = tg[i].cands;
+                            din[i].nc_dev = tg[i].nc_dev;
+                        } else if (dev_cands) {
+                            din[i].nc_dev = 0;
+                        }
                         din[i].wl = tg[i].wl;
                         din[i].wl_n = tg[i].wl_n;
                     }
@@ -359,6 +377,8 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
     }
     c->cnt.t_cond_s += now_s() - t0;
 
+    if (discrete)
+        if (int rc = fwi_nb_host_ensure(c)) return rc;
     // misc.jl:137-159 make_weights ("cond_stat"): discrete tests take the sign of the univariate statistic
     std::vector<std::vector<double>> w(p);
     for (int T = 0; T < p; ++T) {

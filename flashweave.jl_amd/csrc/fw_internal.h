@@ -158,6 +158,8 @@ struct fw_ctx {
     const long long *d_nb_off = nullptr;
     const int32_t *d_nb_idx = nullptr;
     const double *d_nb_stat = nullptr, *d_nb_p = nullptr;
+    const int32_t *d_cand = nullptr;  // per variable: its neighbours in candidate order (ascending adjusted p, stable)
+    bool nb_host_valid = true;        // nb_idx / nb_stat / nb_p hold the current lists (nb_off always does)
     FwDevBuf d_dh;  // arena of the device-resident HITON rounds (fw_devhiton.hip)
     FwPinned h_dh;  // its pinned flag page
     FwPinned h_jobs, h_acc, h_out;
@@ -245,11 +247,13 @@ int fwi_pool_round(fw_ctx *ctx, FwPool &pool, std::vector<FwPoolJob> &finished);
 
 // device-side Benjamini-Hochberg + neighbour CSR (fw_bh.hip); fills ctx->nb_off / nb_idx / nb_stat / nb_p
 int fwi_bh_csr_device(fw_ctx *ctx, const FwL0Dev &in, int64_t m_reliable);
+int fwi_nb_host_ensure(fw_ctx *ctx);  // download partners / statistics / adjusted p if only the device holds them
 
 // ---- device-resident HITON rounds (fw_devhiton.hip, FW_FZ) ----
 struct FwDhTarget {
     int32_t T = 0;
-    std::vector<int32_t> cands;  // interleaving candidates in hiton.jl:211-217 order
+    std::vector<int32_t> cands;  // interleaving candidates in hiton.jl:211-217 order (unused when nc_dev >= 0)
+    int32_t nc_dev = -1;         // >= 0: take the first nc_dev entries of ctx->d_cand at nb_off[T] (device-built order)
     const int32_t *wl = nullptr; // sorted whitelist (feed-forward), may be null
     int wl_n = 0;
 };
