@@ -383,15 +383,23 @@ struct FzL0Counters {
 // every wavefront paying for them.  NaN correlations are counted (they are excluded from m, tests.jl:397-398).
 #define FZ_L0_ROWS 8     // rows per workgroup
 #define FZ_L0_COLS 1024  // columns per workgroup (4 per thread, one float4 load)
+#define FZ_L0_QCAP 2048  // per-workgroup queue of screened pairs (overflow: direct append)
 __global__ __launch_bounds__(256) void fz_level0_kernel(const float *__restrict__ cor, int p, const double *__restrict__ thr,
                                                         FzL0Counters *cnt, unsigned long long cap, int32_t *out_i,
                                                         int32_t *out_j, float *out_r)
 {
-    // 8 x 1024 pairs per workgroup (one row x 256 columns per workgroup was bound by workgroup dispatch: 400 000
-    // workgroups of almost no work at cfg3)
+    // 8 x 1024 pairs per workgroup (one row x 256 columns per workgroup was bound by workgroup dispatch), screened
+    // pairs queued in LDS and appended with ONE atomic per workgroup (one atomic per wavefront step on the single
+    // counter was 4.7 of the kernel's 5 ms: ~700 000 same-address atomics)
+    __shared__ int s_qi[FZ_L0_QCAP], s_qj[FZ_L0_QCAP];
+    __shared__ float s_qr[FZ_L0_QCAP];
+    __shared__ int s_qn;
+    __shared__ unsigned long long s_qbase;
     const int i0 = blockIdx.y * FZ_L0_ROWS;
     const int jb = blockIdx.x * FZ_L0_COLS;
     if (jb + FZ_L0_COLS - 1 <= i0) return;  // tile entirely on/below the diagonal
+    if (threadIdx.x == 0) s_qn = 0;
+    __syncthreads();
     const int j0 = jb + threadIdx.x * 4;
     const int lane = threadIdx.x & 63;
     const float lo_pos = (float)thr[0], lo_neg = (float)thr[2];
@@ -421,16 +429,15 @@ __global__ __launch_bounds__(256) void fz_level0_kernel(const float *__restrict_
             const bool in = j > i && j < p;
             const float r = rv[u];
             const bool isn = in && isnan(r);
-            const bool sig = in && !isn && fabsf(r) >= (r < 0.0f ? flo_neg : flo_pos);
             n_nan += isn;
-            const unsigned long long ms = __ballot(sig);
-            if (ms) {
-                unsigned long long base = 0;
-                const int leader = __ffsll((long long)ms) - 1;
-                if (lane == leader) base = atomicAdd(&cnt->n_sig, (unsigned long long)__popcll(ms));
-                base = __shfl(base, leader);
-                if (sig) {
-                    const unsigned long long slot = base + __popcll(ms & ((1ull << lane) - 1ull));
+            if (in && !isn && fabsf(r) >= (r < 0.0f ? flo_neg : flo_pos)) {
+                const int q = atomicAdd(&s_qn, 1);  // LDS
+                if (q < FZ_L0_QCAP) {
+                    s_qi[q] = i;
+                    s_qj[q] = j;
+                    s_qr[q] = r;
+                } else {
+                    const unsigned long long slot = atomicAdd(&cnt->n_sig, 1ull);
                     if (slot < cap) {
                         out_i[slot] = i;
                         out_j[slot] = j;
@@ -443,6 +450,18 @@ __global__ __launch_bounds__(256) void fz_level0_kernel(const float *__restrict_
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) n_nan += __shfl_xor(n_nan, o);
     if (lane == 0 && n_nan) atomicAdd(&cnt->n_nan, (unsigned long long)n_nan);
+    __syncthreads();
+    const int nq = s_qn < FZ_L0_QCAP ? s_qn : FZ_L0_QCAP;
+    if (threadIdx.x == 0 && nq > 0) s_qbase = atomicAdd(&cnt->n_sig, (unsigned long long)nq);
+    __syncthreads();
+    for (int q = threadIdx.x; q < nq; q += 256) {
+        const unsigned long long slot = s_qbase + (unsigned long long)q;
+        if (slot < cap) {
+            out_i[slot] = s_qi[q];
+            out_j[slot] = s_qj[q];
+            out_r[slot] = s_qr[q];
+        }
+    }
 }
 
 // Kernel 2 (exact): Fisher-z p-value of the screened pairs (tests.jl:149-159); keeps p < alpha.
