@@ -539,8 +539,8 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     int rc;
     if ((rc = fw_dev_reserve(c, c->d_dh, need))) return rc;
     if ((rc = fw_pin_reserve(c, c->h_dh, 4096))) return rc;
-    DhGlobal *hg = (DhGlobal *)c->h_dh.ptr;  // pinned copy of the device record, refreshed once per batch
-    memset(hg, 0, sizeof(DhGlobal));
+    DhGlobal *hg = (DhGlobal *)c->h_dh.ptr;  // two pinned copies of the device record (one per batch in flight)
+    memset(hg, 0, 2 * sizeof(DhGlobal));
     char *B = (char *)c->d_dh.ptr;
     size_t off = 0;
     auto carve = [&](size_t bytes) {
@@ -621,10 +621,16 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     // ---- rounds ----
     // Kernel timing: HIP events around every segment launch (fw_counters.t_dev_subsets_s).  FW_DH_TIME_EVERY=k brackets
     // only every k-th launch and scales the sampled average (measured: 3 ms per pass at cfg3, and a biased estimate).
+    // Two batches are kept in flight: the host enqueues batch b + 1 before it waits for the end of batch b, so the GPU
+    // never runs dry while the host looks at the round record (a stream synchronisation per batch left ~200 us of
+    // idle GPU per 16 rounds).  Rounds after the last one are no-ops (no live segment, nothing to merge).
     constexpr int BATCH = 16;
     static const int time_every = [] { const char *e = getenv("FW_DH_TIME_EVERY"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
-    hipEvent_t ev[2 * BATCH];
-    for (hipEvent_t &e : ev) FW_HIP(c, hipEventCreate(&e));
+    hipEvent_t ev[2][2 * BATCH], ev_end[2];
+    for (int q = 0; q < 2; ++q) {
+        for (hipEvent_t &e : ev[q]) FW_HIP(c, hipEventCreate(&e));
+        FW_HIP(c, hipEventCreateWithFlags(&ev_end[q], hipEventDisableTiming));
+    }
     auto planfill = [&]() {
         hipLaunchKernelGGL(dh_step_kernel, dim3(g_tg), dim3(256), 0, st, d_tg, ntg, d_g, A, (const FwSegOut *)d_so,
                            (const long long *)d_seg0, d_win, P);
@@ -635,44 +641,72 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     };
     planfill();  // nothing to merge yet: creates the first jobs and the first launch (plan #0)
     int rc2 = FW_OK;
-    unsigned plan_base = 0;  // launch r of a batch executes plan #(plan_base + r)
     double timed_s = 0.0;
     long timed_n = 0, launches_n = 0;
-    for (;;) {
+    unsigned max_a_seen = 0;  // longest accepted list reported so far (lags by up to two batches)
+    auto enqueue_batch = [&](unsigned b) -> int {
+        const int q = (int)(b & 1u);
         for (int r = 0; r < BATCH; ++r) {
             const bool timed = (r % time_every) == 0;
-            const bool any_big = any_big_static && (any_wl || hg->max_a + (unsigned)BATCH + 1u > (unsigned)FW_TAB_A);
-            if (timed) (void)hipEventRecord(ev[2 * r], st);
-            if ((rc2 = fz ? fwi_fz_segments_dev(c, grid_seg, d_segs, A.acc, d_so, d_ns, any_big, st)
-                          : fwi_mi_segments_dev(c, max_ns, d_segs, A.acc, d_so, d_ns, st)))
-                break;
-            if (timed) (void)hipEventRecord(ev[2 * r + 1], st);
+            // lists grow by at most one entry per round: 3 batches cover the lag of the record plus this batch
+            const bool any_big = any_big_static && (any_wl || max_a_seen + 3u * (unsigned)BATCH + 1u > (unsigned)FW_TAB_A);
+            if (timed) (void)hipEventRecord(ev[q][2 * r], st);
+            int rc = fz ? fwi_fz_segments_dev(c, grid_seg, d_segs, A.acc, d_so, d_ns, any_big, st)
+                        : fwi_mi_segments_dev(c, max_ns, d_segs, A.acc, d_so, d_ns, st);
+            if (rc) return rc;
+            if (timed) (void)hipEventRecord(ev[q][2 * r + 1], st);
             planfill();
         }
-        if (rc2) break;
         FW_HIP(c, hipGetLastError());
-        FW_HIP(c, hipMemcpyAsync(hg, d_g, sizeof(DhGlobal), hipMemcpyDeviceToHost, st));
-        FW_HIP(c, hipStreamSynchronize(st));
+        FW_HIP(c, hipMemcpyAsync(hg + q, d_g, sizeof(DhGlobal), hipMemcpyDeviceToHost, st));
+        FW_HIP(c, hipEventRecord(ev_end[q], st));
+        return FW_OK;
+    };
+    // returns 1 when the record of batch b says that every target has finished
+    auto retire_batch = [&](unsigned b, int *done) -> int {
+        const int q = (int)(b & 1u);
+        FW_HIP(c, hipEventSynchronize(ev_end[q]));
+        const DhGlobal &rec = hg[q];
         for (int r = 0; r < BATCH; ++r) {
-            if (hg->ns_ring[(plan_base + (unsigned)r) & 63u] == 0) continue;  // empty launch after the last round
+            if (rec.ns_ring[(b * (unsigned)BATCH + (unsigned)r) & 63u] == 0) continue;  // empty launch after the last round
             ++launches_n;
             if ((r % time_every) != 0) continue;
             float ms = 0.0f;
-            FW_HIP(c, hipEventElapsedTime(&ms, ev[2 * r], ev[2 * r + 1]));
+            FW_HIP(c, hipEventElapsedTime(&ms, ev[q][2 * r], ev[q][2 * r + 1]));
             timed_s += 1e-3 * (double)ms;
             ++timed_n;
         }
-        plan_base += BATCH;
-        if (hg->done) break;
-        if (plan_base > 4000000u) {  // every round finishes at least one window: this is a logic error, not a workload
-            rc2 = fw_fail(c, FW_ERR_DEVICE, "device HITON: no convergence after %u rounds", plan_base);
-            break;
+        max_a_seen = rec.max_a > max_a_seen ? rec.max_a : max_a_seen;
+        *done = rec.done != 0u;
+        return FW_OK;
+    };
+    {
+        unsigned b = 0;
+        int done = 0;
+        rc2 = enqueue_batch(0);
+        while (!rc2) {
+            if ((rc2 = enqueue_batch(b + 1))) break;   // keep the GPU fed ...
+            if ((rc2 = retire_batch(b, &done))) break;  // ... while the host reads the previous batch's record
+            ++b;
+            if (done) {
+                int d2 = 0;
+                rc2 = retire_batch(b, &d2);  // the batch still in flight holds only no-op rounds
+                break;
+            }
+            if (b > 250000u) {  // every round finishes at least one window: this is a logic error, not a workload
+                rc2 = fw_fail(c, FW_ERR_DEVICE, "device HITON: no convergence after %u rounds", b * (unsigned)BATCH);
+                break;
+            }
         }
+        if (rc2) (void)hipStreamSynchronize(st);
     }
     if (timed_n > 0) c->cnt.t_dev_subsets_s += timed_s * (double)launches_n / (double)timed_n;
     c->cnt.subsets_launches += launches_n;
     c->cnt.kernel_launches += 4 * launches_n;
-    for (hipEvent_t &e : ev) (void)hipEventDestroy(e);
+    for (int q = 0; q < 2; ++q) {
+        for (hipEvent_t &e : ev[q]) (void)hipEventDestroy(e);
+        (void)hipEventDestroy(ev_end[q]);
+    }
     if (rc2) return rc2;
     // ---- results ----
     FW_HIP(c, hipMemcpy(tg.data(), d_tg, sizeof(DhTgt) * ntg, hipMemcpyDeviceToHost));
