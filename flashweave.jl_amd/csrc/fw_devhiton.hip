@@ -57,6 +57,8 @@ struct DhParams {
     unsigned int seg_q, seg_min;                        // segment length granularity / minimum (fz 256 / 256, discrete 4 / 8)
     double disc_bytes_per_col;                          // discrete kinds: n * b / 8 (algorithmic bytes per column), else 0
     int elim_full;                                      // elimination-phase jobs start with the full enumeration as their window
+    unsigned long long growth_small, growth, growth_busy;  // window growth: launch below small_launch / default / many jobs
+    unsigned int busy_jobs;
 };
 
 __device__ __forceinline__ unsigned long long dh_binom(long long m, int t)
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
             // ---- sequential part (every lane computes the same values; only lane 0 writes) ----
             if (!done) {
                 x.jnext += x.jwin;
-                const unsigned long long growth = g->launched_ranks < P.small_launch ? 256ull : (g->n_live_prev > 2048u ? 4ull : 16ull);
+                const unsigned long long growth = g->launched_ranks < P.small_launch ? P.growth_small : (g->n_live_prev > P.busy_jobs ? P.growth_busy : P.growth);
                 x.jwidth *= growth;
                 if (x.jnext >= x.jN) {
                     r_stat = x.jbest_stat;
@@ -604,6 +606,13 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     {
         const char *e = getenv("FW_ELIM_FULL");
         P.elim_full = e ? atoi(e) : 1;
+    }
+    {
+        auto envu = [](const char *n, unsigned long long d) { const char *e = getenv(n); return e && atoll(e) > 0 ? (unsigned long long)atoll(e) : d; };
+        P.growth_small = envu("FW_DH_GROWTH_SMALL", 256ull);
+        P.growth = envu("FW_DH_GROWTH", 8ull);  // cfg3 sweep: 4 -> 322 ms, 8 -> 321.5, 16 -> 331, 32 -> 350 (the host pool uses 16: its rounds cost 3x more)
+        P.growth_busy = envu("FW_DH_GROWTH_BUSY", 4ull);
+        P.busy_jobs = (unsigned int)envu("FW_DH_BUSY_JOBS", 2048ull);
     }
     const bool fz = c->P.kind == FW_FZ;
     P.w0_small = fz ? 256ull : 16ull;
