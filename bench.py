@@ -46,7 +46,28 @@ def make_input(cfg, args):
     return c, synth.checksum(counts), data
 
 
+def cpu_worker(path, w, W, seconds):
+    """One process of the multi-core CPU leg: conditional stage of the schedule positions w, w + S, ... (S = max(W,
+    p // 512)) with the oracle, for `seconds`; prints one JSON line."""
+    from oracle import oracle as O
+    z = np.load(path, allow_pickle=False)
+    kind, n, max_k = str(z["kind"]), int(z["n"]), int(z["max_k"])
+    if kind == "fz":
+        orc = O.Oracle("fz", cor_mat=z["cm"], n_obs=n)
+        p = z["cm"].shape[0]
+    else:
+        orc = O.Oracle(kind, z["data"], sparse=True, max_k=max_k)
+        p = z["data"].shape[1]
+    stride = max(W, p // 512, 1)
+    r = orc.learn(max_k=max_k, feed_forward=False, target_stride=stride, target_offset=w, max_seconds=seconds)
+    print(json.dumps({"w": w, "n_cond_tests": r["n_cond_tests"], "t_cond": r["t_cond"], "n_targets": r["n_targets"],
+                      "t_level0": r["t_level0"]}))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -58,6 +79,8 @@ def main():
     ap.add_argument("--round-size", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-workers", type=int, default=-1,
+                    help="processes of the multi-core CPU leg (-1: min(32, hardware threads / 2); 0: skip it)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for debugging)")
     ap.add_argument("--single-device", action="store_true", help="debug: every rank uses GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
@@ -174,6 +197,38 @@ def main():
                              (r["n_level0_tests"], r["t_level0"], stride, r["n_targets"], r["n_cond_tests"], r["t_cond"]),
                    "level0_tests_per_s": r["n_level0_tests"] / max(r["t_level0"], 1e-9),
                    "cond_tests_per_s": r["n_cond_tests"] / max(r["t_cond"], 1e-9), "wall_s": t_cpu}
+            # the same oracle on many host cores: W processes, each takes its own targets of the schedule (the analogue of
+            # the reference's worker processes, interleaved.jl:90); level-0 stays single-threaded as in the reference
+            # (tests.jl:470-479), so only the conditional stage is reported for this leg
+            W = args.cpu_workers if args.cpu_workers >= 0 else min(32, max(1, (os.cpu_count() or 2) // 2))
+            if W > 1:
+                import subprocess
+                import tempfile
+                t2 = time.perf_counter()
+                with tempfile.TemporaryDirectory() as td:
+                    path = os.path.join(td, "in.npz")
+                    if cfg["test_name"] == "fz":
+                        np.savez(path, kind="fz", n=n, max_k=cfg["max_k"], cm=cm)
+                    else:
+                        np.savez(path, kind=cfg["test_name"], n=n, max_k=cfg["max_k"], data=data)
+                    budget = max(3.0, args.cpu_seconds * 0.6)
+                    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(w), str(W),
+                                               str(budget)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=ROOT)
+                             for w in range(W)]
+                    outs = []
+                    for pr in procs:
+                        o, _ = pr.communicate(timeout=600)
+                        lines = [ln for ln in o.decode().splitlines() if ln.startswith("{")]
+                        if pr.returncode == 0 and lines:
+                            outs.append(json.loads(lines[-1]))
+                if outs:
+                    tot = sum(o["n_cond_tests"] for o in outs)
+                    tmax = max(o["t_cond"] for o in outs)
+                    cpu["multicore"] = {"cores": len(outs), "cond_tests_per_s": tot / max(tmax, 1e-9),
+                                        "sample": "%d oracle processes, process w = schedule positions w, w + S, ... "
+                                                  "(%d targets, %d conditional tests, slowest process %.2fs)" %
+                                                  (len(outs), sum(o["n_targets"] for o in outs), tot, tmax),
+                                        "wall_s": time.perf_counter() - t2}
         out = {"metric": "ci_tests_per_sec", "value": value, "unit": "tests/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": "f64" if cfg["test_name"] == "fz" else "i32", "data": "synthetic",

@@ -1461,6 +1461,7 @@ typedef struct {
     int max_targets; /* > 0: stop after this many targets of the schedule (baseline sampling) */
     int target_stride; /* > 1 (only with feed_forward = 0): process every stride-th target of the schedule */
     double max_seconds; /* > 0: stop the conditional stage after this many seconds (baseline sampling) */
+    int target_offset;  /* first schedule position to process (with target_stride: worker w of W takes w, w + W, ...) */
 } fwo_params;
 
 typedef struct {
@@ -1689,7 +1690,8 @@ fwo_network *fwo_learn(fwo_ctx *c, const fwo_params *P_in, const fwo_nbrs *nb_in
     double t1 = now_s();
     int stride = (P.target_stride > 1 && !P.feed_forward) ? P.target_stride : 1;
     int n_done = 0;
-    for (int ti = 0; ti < nt; ti += stride) {
+    const int ti0 = (P.target_offset > 0 && !P.feed_forward) ? P.target_offset : 0;
+    for (int ti = ti0; ti < nt; ti += stride) {
         int T = order[ti].idx;
         if (P.max_seconds > 0 && now_s() - t1 > P.max_seconds) break;
         ++n_done;

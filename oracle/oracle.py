@@ -23,7 +23,7 @@ class Params(C.Structure):
     _fields_ = [("alpha", C.c_double), ("hps", C.c_int), ("n_obs_min", C.c_int64), ("max_k", C.c_int),
                 ("max_tests", C.c_int64), ("FDR", C.c_int), ("feed_forward", C.c_int),
                 ("round_size", C.c_int), ("max_targets", C.c_int), ("target_stride", C.c_int),
-                ("max_seconds", C.c_double)]
+                ("max_seconds", C.c_double), ("target_offset", C.c_int)]
 
 
 def build(force=False):
@@ -233,9 +233,9 @@ class Oracle:
         return dict(off=off, idx=idx[:tot], stat=stat[:tot], pval=pval[:tot], n_tests=int(nt))
 
     def learn(self, max_k=3, alpha=0.01, hps=5, n_obs_min=-1, max_tests=10_000_000, FDR=True, feed_forward=True,
-              round_size=1, max_targets=0, target_stride=1, max_seconds=0.0):
+              round_size=1, max_targets=0, target_stride=1, max_seconds=0.0, target_offset=0):
         P = Params(alpha, hps, n_obs_min, max_k, max_tests, int(FDR), int(feed_forward), round_size, max_targets,
-                   target_stride, max_seconds)
+                   target_stride, max_seconds, target_offset)
         g = self.L.fwo_learn(self.h, C.byref(P), None)
         ne = self.L.fwo_network_nedges(g)
         if ne < 0:
