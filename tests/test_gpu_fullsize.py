@@ -68,3 +68,27 @@ def test_cfg3_full_size():
         nchk += len(b)
     assert nchk > 1000 and ndiff <= 6                       # observed: 2 of 6 000 targets
     eng.close()
+
+
+def test_cfg3_full_size_device_rounds_equal_host_driver(monkeypatch):
+    # The two drivers of the conditional stage at the BASELINE size: device-resident rounds (default) and the host job
+    # pool (FW_HOST_HITON=1) must produce the same directed results bit for bit and the same reference-order test count
+    # (they evaluate different speculative windows, so only `cond_tests_evaluated` may differ).
+    c = synth.CONFIGS["cfg3"]
+    counts = synth.generate(c["p"], c["n"], c["seed"], mode=c["mode"])
+    data, _, _ = pre.normalize(counts, "fz", prec=32)
+    n, p = data.shape
+    res = {}
+    for host in ("1", "0"):
+        monkeypatch.setenv("FW_HOST_HITON", host)
+        eng = fw.Engine("fz", n, p, max_k=3)
+        eng.set_data(data)
+        eng.cor()
+        res[host] = (eng.lgl(feed_forward=False), eng.counters())
+        eng.close()
+    (nh, ch), (nd, cd) = res["1"], res["0"]
+    assert nh["edges"] == nd["edges"] and len(nd["edges"]) > 10000
+    for key in ("pc_off", "pc_idx", "pc_weight", "pc_pval"):
+        assert np.array_equal(nh[key], nd[key], equal_nan=True), key
+    assert ch["cond_tests_ref"] == cd["cond_tests_ref"] > 10**10
+    assert ch["subsets_calls"] == cd["subsets_calls"]
