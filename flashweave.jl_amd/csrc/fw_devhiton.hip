@@ -371,7 +371,7 @@ __device__ __forceinline__ unsigned int dh_ceil_div(unsigned long long w, unsign
 #define DH_PER 32  // targets per planning thread held in registers (more targets: extra passes over global memory)
 __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__restrict__ g, const unsigned long long *__restrict__ win,
                                                        long long *__restrict__ seg0, unsigned int seg_target, unsigned int seg_q,
-                                                       unsigned int seg_min)
+                                                       unsigned int seg_min, ulonglong2 *__restrict__ log, unsigned int log_cap)
 {
     __shared__ unsigned long long s_tot[16];
     __shared__ unsigned int s_live[16], s_wsum[16];
@@ -456,6 +456,7 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
         const unsigned int r = g->rounds;
         g->ns_ring[r & 63u] = ns;
         g->rounds = r + 1u;
+        if (log && r < log_cap) log[r] = make_ulonglong2(total, ((unsigned long long)n_live << 32) | ns);  // FW_DH_LOG
     }
 }
 
@@ -534,7 +535,10 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     const unsigned seg_target = seg_target_env ? seg_target_env : (c->P.kind == FW_FZ ? 3072u : 4096u);  // cfg3 sweep: 3072
     const unsigned max_ns = seg_target + (unsigned)ntg + 256u;  // capacity of the segment list
     const unsigned grid_seg = seg_target + 512u;                // striding workgroups of the segment kernel
-    size_t need = pad(sizeof(DhTgt) * ntg) + pad(sizeof(DhGlobal)) + 2 * pad(sizeof(long long) * ((size_t)ntg + 1));
+    // FW_DH_LOG=<file>: one line per planned launch (ranks, live jobs, segments) -- profiling aid, see profiles/README.md
+    static const char *log_path = getenv("FW_DH_LOG");
+    constexpr unsigned LOG_CAP = 1u << 16;
+    size_t need = (log_path ? pad(sizeof(ulonglong2) * LOG_CAP) : 0) + pad(sizeof(DhTgt) * ntg) + pad(sizeof(DhGlobal)) + 2 * pad(sizeof(long long) * ((size_t)ntg + 1));
     need += pad(4 * tot + 4) * 3 + pad(4 * 2 * tot + 4) + pad(8 * tot + 8) * 4 + pad(4 * wl.size() + 4);
     need += pad(sizeof(FwSeg) * max_ns) + pad(sizeof(FwSegOut) * max_ns);
     if (!nb_on_dev) need += pad(8 * ((size_t)p + 1)) + pad(4 * nnz + 4) + 2 * pad(8 * nnz + 8);
@@ -568,6 +572,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     A.wl = d_wl;
     FwSeg *d_segs = (FwSeg *)carve(sizeof(FwSeg) * max_ns);
     FwSegOut *d_so = (FwSegOut *)carve(sizeof(FwSegOut) * max_ns);
+    ulonglong2 *d_log = log_path ? (ulonglong2 *)carve(sizeof(ulonglong2) * LOG_CAP) : nullptr;
     FW_HIP(c, hipMemcpyAsync(d_tg, tg.data(), sizeof(DhTgt) * ntg, hipMemcpyHostToDevice, st));
     FW_HIP(c, hipMemsetAsync(d_g, 0, sizeof(DhGlobal), st));
     FW_HIP(c, hipMemsetAsync(d_seg0, 0, sizeof(long long) * ((size_t)ntg + 1), st));
@@ -644,7 +649,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         hipLaunchKernelGGL(dh_step_kernel, dim3(g_tg), dim3(256), 0, st, d_tg, ntg, d_g, A, (const FwSegOut *)d_so,
                            (const long long *)d_seg0, d_win, P);
         hipLaunchKernelGGL(dh_plan_kernel, dim3(1), dim3(1024), 0, st, ntg, d_g, (const unsigned long long *)d_win, d_seg0,
-                           seg_target, P.seg_q, P.seg_min);
+                           seg_target, P.seg_q, P.seg_min, d_log, LOG_CAP);
         hipLaunchKernelGGL(dh_fill_kernel, dim3(g_fill), dim3(256), 0, st, (const DhTgt *)d_tg, ntg, (const DhGlobal *)d_g,
                            (const long long *)d_seg0, A, d_segs);
     };
@@ -652,6 +657,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     int rc2 = FW_OK;
     double timed_s = 0.0;
     long timed_n = 0, launches_n = 0;
+    std::vector<float> log_ms;  // FW_DH_LOG: segment-kernel time of launch i (planned by plan #i)
     unsigned max_a_seen = 0;  // longest accepted list reported so far (lags by up to two batches)
     auto enqueue_batch = [&](unsigned b) -> int {
         const int q = (int)(b & 1u);
@@ -684,6 +690,11 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
             FW_HIP(c, hipEventElapsedTime(&ms, ev[q][2 * r], ev[q][2 * r + 1]));
             timed_s += 1e-3 * (double)ms;
             ++timed_n;
+            if (log_path) {
+                const size_t idx = (size_t)b * BATCH + (size_t)r;
+                if (log_ms.size() <= idx) log_ms.resize(idx + 1, 0.0f);
+                log_ms[idx] = ms;
+            }
         }
         max_a_seen = rec.max_a > max_a_seen ? rec.max_a : max_a_seen;
         *done = rec.done != 0u;
@@ -717,6 +728,19 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         (void)hipEventDestroy(ev_end[q]);
     }
     if (rc2) return rc2;
+    if (d_log) {
+        std::vector<ulonglong2> lg(LOG_CAP);
+        DhGlobal fin{};
+        FW_HIP(c, hipMemcpy(&fin, d_g, sizeof(DhGlobal), hipMemcpyDeviceToHost));
+        FW_HIP(c, hipMemcpy(lg.data(), d_log, sizeof(ulonglong2) * LOG_CAP, hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(log_path, "a")) {
+            fprintf(f, "# targets %d rounds %u\n", ntg, fin.rounds);
+            for (unsigned r = 0; r < fin.rounds && r < LOG_CAP; ++r)
+                fprintf(f, "%u %llu %llu %llu %.1f\n", r, lg[r].x, lg[r].y >> 32, lg[r].y & 0xffffffffull,
+                        r < log_ms.size() ? 1e3 * (double)log_ms[r] : 0.0);
+            fclose(f);
+        }
+    }
     // ---- results ----
     FW_HIP(c, hipMemcpy(tg.data(), d_tg, sizeof(DhTgt) * ntg, hipMemcpyDeviceToHost));
     std::vector<int32_t> pk(tot);

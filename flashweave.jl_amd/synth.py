@@ -40,7 +40,8 @@ def generate(p, n, seed, profile="confounded", mode="S", habitats=0, n_meta=0, f
         lam = np.exp(mu[None, :] + SIGMA * z + g @ a + d[:, None])
         if habitats:
             lam[~present[h], :] = 0.0
-        counts[:, b * BLOCK:b * BLOCK + w] = rng.poisson(lam).astype(np.int32)
+        # saturate instead of wrapping: a heavy-tailed draw can exceed the int32 count range (seen once in ~600 seeds)
+        counts[:, b * BLOCK:b * BLOCK + w] = np.minimum(rng.poisson(lam), 2**31 - 1).astype(np.int32)
     if n_meta:
         assert habitats == 4 and n_meta == 20
         meta = np.zeros((n, 20), dtype=np.int32)
