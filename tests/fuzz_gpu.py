@@ -17,7 +17,8 @@ from flashweave_jl_amd import preprocess as pre
 from flashweave_jl_amd import synth
 from oracle import oracle as O
 
-STOL = 1e-9  # discrete statistics: Float32 x ln x tables on both sides, sums in different association (tests/test_gpu_mi.py)
+STOL = 1e-12  # discrete statistics: summation order, device log (tests/test_gpu_mi.py)
+PTOL = 1e-10  # discrete p-values: device lgamma / exp in Q(a, x) (tests/test_gpu_mi.py)
 ENV_KEYS = ("FW_HOST_HITON", "FW_DEV_MIN_TARGETS", "FW_HOST_BH")
 
 
@@ -152,14 +153,109 @@ def run_case(seed):
                 os.environ[k] = v
 
 
+def _n_enum(a, max_k):
+    from math import comb
+    return sum(comb(a, s) for s in range(1, max_k + 1))
+
+
+def run_subsets_case(seed, jobs=48, budget=300_000):
+    """test_subsets batches (tests.jl:281-346) with random accepted lists: status, number of tests in reference order,
+    winning conditioning set, statistic (bit-exact for fz) and p-value against the oracle."""
+    r = np.random.default_rng(1_000_003 + seed)
+    c = dict(seed=seed, kind=str(r.choice(["fz", "fz", "fz", "mi", "mi_nz"])))
+    c["max_k"] = int(r.choice([1, 2, 3, 3, 3, 4, 5])) if c["kind"] == "fz" else int(r.choice([1, 2, 3, 3]))
+    c["alpha"] = float(r.choice([0.01, 0.01, 0.2, 0.9999]))
+    c["max_tests"] = int(r.choice([10_000_000, 10_000_000, int(r.integers(5, 60_000))]))
+    c["hps"] = int(r.choice([5, 5, 3]))
+    if c["kind"] == "fz":
+        p, n = int(r.integers(60, 900)), int(r.choice([40, 150, 400, 3000]))
+        nf = int(r.integers(1, 4))
+        load = r.standard_normal((nf, p)) * r.choice([0.2, 0.6, 1.5])
+        data = np.asfortranarray((r.standard_normal((n, nf)) @ load + r.standard_normal((n, p))).astype(np.float32))
+        lens = [0, 1, 2, 3, 4, 7, 17, 40, 63, 64, 65, 120, 300, 511, 512, 513, 700]
+    else:
+        c2 = dict(c, p=int(r.integers(40, 200)), n=int(r.integers(80, 420)), source="synth", dups=False)
+        data = make_data(c2)
+        lens = [0, 1, 2, 3, 4, 7, 12, 20, 33]
+    n, p = data.shape
+    c["p"], c["n"] = p, n
+    eng = orc = None
+    try:
+        kw = dict(max_k=c["max_k"], alpha=c["alpha"], hps=c["hps"], max_tests=c["max_tests"])
+        eng = fw.Engine(c["kind"], n, p, **kw)
+        eng.set_data(data)
+        if c["kind"] == "fz":
+            cm = eng.cor()
+            orc = O.Oracle("fz", cor_mat=cm, n_obs=n)
+        else:
+            orc = O.Oracle(c["kind"], data, sparse=True, max_k=c["max_k"])
+        nom = eng.n_obs_min
+        T, Cn, A = [], [], []
+        for _ in range(jobs):
+            ok = [a for a in lens if a + 2 <= p and min(_n_enum(a, c["max_k"]), c["max_tests"]) <= budget]
+            a = int(r.choice(ok))
+            if c["kind"] == "fz" and r.integers(0, 3) == 0:  # strongest neighbours: long all-significant runs
+                t = int(r.integers(0, p))
+                order = [int(v) for v in np.argsort(-np.abs(np.nan_to_num(cm[t]))) if v != t][:a + 1]
+                v = [t] + order
+            else:
+                v = [int(x) for x in r.choice(p, size=a + 2, replace=False)]
+            acc = v[2:]
+            # duplicate entry (feed-forward whitelist, SURVEY Q12).  fz only: two orderings of the same conditioning set
+            # tie exactly there (bit-exact arithmetic on both sides); the discrete sums run in a different order on the
+            # device, so which of the two tied orderings attains the maximum p is a rounding matter (tolerance class)
+            if c["kind"] == "fz" and len(acc) > 2 and r.integers(0, 6) == 0:
+                acc = acc + acc[:1]
+            T.append(v[0]); Cn.append(v[1]); A.append(acc)
+        got = eng.test_subsets_batch(T, Cn, A)
+        tol = 0.0 if c["kind"] == "fz" else STOL
+        for t, cd, a, g in zip(T, Cn, A, got):
+            e = orc.test_subsets(t, cd, a, max_k=c["max_k"], alpha=c["alpha"], hps=c["hps"], n_obs_min=nom,
+                                 max_tests=c["max_tests"])
+            where = "T %d cand %d |accepted| %d: hip %r oracle %r" % (t, cd, len(a), g, e)
+            if g["status"] != e["status"] or g["num_tests"] != e["num_tests"]:
+                return c, "status / num_tests: " + where
+            if e["status"] == 0:
+                continue
+            if g["df"] != e["df"] or g["suff_power"] != e["suff_power"]:
+                return c, "df / power: " + where
+            if g["Zs"] != e["Zs"]:
+                # discrete kinds, no test stopped the job (status 2 = maximum p over the enumeration): two subsets whose
+                # tables agree cell for cell (a conditioning variable that is constant on the rows in play) tie exactly
+                # in exact arithmetic; which of them attains the maximum is decided by the last bits of the sums
+                tie = tol > 0 and e["status"] == 2 and _close(g["stat"], e["stat"], tol) and _close(g["pval"], e["pval"], PTOL)
+                if not tie:
+                    return c, "conditioning set: " + where
+            if not _close(g["stat"], e["stat"], tol) or not _close(g["pval"], e["pval"], PTOL if tol else 1e-12):
+                return c, "statistic / p-value: " + where
+        c["jobs"] = jobs
+        return c, None
+    finally:
+        if eng is not None:
+            eng.close()
+        if orc is not None:
+            orc.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--subsets", action="store_true", help="test_subsets batches instead of whole networks")
     a = ap.parse_args()
     bad = 0
     tot_edges = tot_cond = 0
+    if a.subsets:
+        for s in range(a.first, a.first + a.cases):
+            c, msg = run_subsets_case(s)
+            if msg:
+                bad += 1
+                print("FAIL seed %d: %s\n     %s" % (s, msg, c), flush=True)
+            elif a.verbose:
+                print("ok   seed %d: %s" % (s, c), flush=True)
+        print("%d test_subsets cases, %d failures" % (a.cases, bad))
+        return 1 if bad else 0
     for s in range(a.first, a.first + a.cases):
         c, msg = run_case(s)
         tot_edges += c.get("edges", 0)

@@ -16,3 +16,9 @@ def test_random_cases_match_oracle(first):
         assert msg is None, (msg, case)
         kinds.add(case["kind"])
     assert kinds == {"fz", "fz_nz", "mi", "mi_nz"}
+
+
+def test_random_test_subsets_batches_match_oracle():
+    for seed in range(60):
+        case, msg = fuzz_gpu.run_subsets_case(seed)
+        assert msg is None, (msg, case)
