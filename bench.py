@@ -83,6 +83,8 @@ def main():
                     help="processes of the multi-core CPU leg (-1: min(32, hardware threads / 2); 0: skip it)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for debugging)")
     ap.add_argument("--single-device", action="store_true", help="debug: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--simulate-world", type=int, default=0,
+                    help="debug: time rank 0's share of an N-rank job on one GPU (no peers; the JSON line is not a result)")
     args = ap.parse_args()
 
     import torch
@@ -110,6 +112,13 @@ def main():
     eng = fw.Engine(cfg["test_name"], n, p, max_k=cfg["max_k"], device=local_rank)
     eng.set_data(data)  # host -> HBM once, outside the timed region
     cb = make_allgather(dist, cdev) if world > 1 else None
+    if args.simulate_world > 1 and world == 1:
+        import ctypes as C
+
+        def cb(user, n_local, tgt, nbr, stat, pval, n_total, tgt_all, nbr_all, stat_all, pval_all):  # echo: no peers
+            n_total[0] = n_local
+            tgt_all[0], nbr_all[0], stat_all[0], pval_all[0] = tgt, nbr, stat, pval
+            return 0
 
     def barrier():
         if world > 1:
@@ -121,7 +130,7 @@ def main():
             eng.compute_cor()  # matrix stays resident in HBM
         eng.level0()
         return eng.lgl(feed_forward=bool(args.feed_forward), round_size=args.round_size, rank=rank,
-                       world_size=world, allgather=cb)
+                       world_size=max(world, args.simulate_world) if world == 1 else world, allgather=cb)
 
     for _ in range(args.warmup):
         step()

@@ -2,12 +2,13 @@
 // (collect -> merge -> advance -> build -> launch, ~140 us at cfg3, a third of the pass); here the per-target state
 // machines, the in-rank-order merge of the segment results and the construction of the next launch live in device
 // memory and run as three small kernels between two launches of the segment kernel:
-//     seg kernel -> dh_step_kernel (merge, commit, advance: one thread per target)
+//     seg kernel -> dh_step_kernel (merge, commit, advance: one wavefront per target)
 //                -> dh_plan_kernel (segment length, per-target segment counts, exclusive scan: one workgroup)
 //                -> dh_fill_kernel (one thread per segment record) -> seg kernel -> ...
 // The host only enqueues batches of rounds and looks at a pinned "done" flag between batches.  Semantics are those
 // of the host driver (hiton.jl:109-149 interleaving / elimination, check_candidate! :80-107, update_PC_dict! :249-256,
-// tests.jl:326-345 merge rules) without its speculative candidate posting; windows follow the same growth policy.
+// tests.jl:326-345 merge rules); windows follow the same growth policy.  Speculation here is the elimination-phase
+// look-ahead described at dh_step_kernel (the host pool posts candidates of the interleaving phase ahead instead).
 #include <algorithm>
 #include <cstring>
 #include <vector>
@@ -23,7 +24,8 @@ struct DhTgt {
     long long cand_off;  // offset of its interleaving candidates in DhArrays::cand0
     long long wl_off, nb_off;
     int32_t nb_n, cap;
-    int32_t jactive, pad0;
+    int32_t jactive, nsp;  // nsp: look-ahead jobs of the elimination phase in the coming launch (see dh_step_kernel)
+    int32_t cur, pad0;     // accepted-list buffer in use (0 .. spec_depth)
     unsigned long long jN, jnext, jwidth, jwin, jevaluated;
     double jbest_p, jbest_stat;
     unsigned long long c_ref, c_calls, c_eval;  // per-target totals (summed on the host: no same-address atomics)
@@ -38,6 +40,9 @@ struct DhGlobal {
     double alg_bytes;
     unsigned int ns_ring[64];  // segments of the last 64 planned launches (the host reads the record once per batch)
 };
+
+// accepted-list buffer b of a target: (spec_depth + 1) buffers of 2 * cap entries each
+#define DH_ACC_OFF(x, b, d1) (2ll * (x).co * (long long)(d1) + 2ll * (long long)(b) * (long long)(x).cap)
 
 struct DhArrays {
     const int32_t *cand0;  // interleaving candidates (hiton.jl:211-217 order)
@@ -59,6 +64,8 @@ struct DhParams {
     int elim_full;                                      // elimination-phase jobs start with the full enumeration as their window
     unsigned long long growth_small, growth, growth_busy;  // window growth: launch below small_launch / default / many jobs
     unsigned int busy_jobs;
+    int spec_depth;  // elimination-phase look-ahead: candidates tested ahead of the current one per target (0 = off)
+    unsigned long long spec_below;  // ... only while the last launch held fewer ranks than this
 };
 
 __device__ __forceinline__ unsigned long long dh_binom(long long m, int t)
@@ -108,10 +115,10 @@ __device__ __forceinline__ double dh_alg_bytes(int a, unsigned long long evaluat
 // (stores of one lane are made visible to the others by workgroup-scope fences: one L1 per CU, no cache maintenance);
 // the loops over the target's arrays (removing the candidate from the pool, the phase switch, update_PC_dict!) are
 // spread over the lanes -- a single lane walking 250 dependent global loads per candidate was 100 us per round.
-__device__ bool dh_advance(DhTgt &x, const DhArrays &A, int lane)
+__device__ bool dh_advance(DhTgt &x, const DhArrays &A, int lane, int d1)
 {
-    int32_t *acc = A.acc + 2 * x.co;
     for (;;) {
+        int32_t *acc = A.acc + DH_ACC_OFF(x, x.cur, d1);
         if (x.phase == 2) return false;
         const int32_t *cands = x.phase == 0 ? A.cand0 + x.cand_off : A.tpc_key + x.co;
         int32_t *dkey = (x.phase == 0 ? A.tpc_key : A.pc_key) + x.co;
@@ -207,78 +214,159 @@ __device__ bool dh_advance(DhTgt &x, const DhArrays &A, int lane)
     }
 }
 
-// One wavefront per target: the lanes merge the job's segment records in parallel (first stop = minimum segment
-// index; otherwise the lexicographic maximum of (p, segment index), i.e. "later wins ties", tests.jl:338), lane 0 runs
-// the sequential part (commit, advance, next job).
+// ceil(w / seglen) for w < 2^62: double quotient + exact fix-up (a 64-bit integer division costs ~100 instructions)
+__device__ __forceinline__ unsigned int dh_ceil_div(unsigned long long w, unsigned long long seglen, double inv)
+{
+    if (w == 0ull) return 0u;
+    unsigned long long q = (unsigned long long)((double)w * inv);
+    while (q * seglen < w) ++q;
+    while (q > 0ull && (q - 1ull) * seglen >= w) --q;
+    return (unsigned int)q;
+}
+
+
+// In-rank-order merge of the nseg segment records of one job by the 64 lanes of a wavefront (tests.jl:326-345): the
+// first stop (smallest segment index) ends the job; otherwise the lexicographic maximum of (p, segment index), i.e.
+// "later wins ties" (tests.jl:338).  Every lane returns the same values.
+struct DhMerge {
+    bool stop;
+    double stat, p;  // of the stopping test (stop) or of the maximum-p test (!stop; p = -2 if no segment had one)
+    int pow;
+    unsigned long long nt;  // stop: tests up to and including the stopping one
+    unsigned long long ev;  // tests executed by the segments
+};
+
+__device__ __forceinline__ DhMerge dh_merge(const FwSegOut *__restrict__ so, long long base, int nseg, int lane)
+{
+    unsigned long long ev = 0ull;
+    int my_stop = 0x7fffffff;  // smallest segment index of this lane that reports a stop
+    double st_stat = 0.0, st_p = 0.0;
+    int st_pow = 0;
+    unsigned long long st_rank = 0ull;
+    double bp = -2.0, bs = 0.0;  // lane best over its segments (increasing index, `>=`)
+    int bi = -1;
+    for (int sg = lane; sg < nseg; sg += 64) {
+        const FwSegOut o = so[base + sg];
+        ev += o.evaluated;
+        if (o.stop_rank != FW_RANK_NONE) {
+            if (my_stop == 0x7fffffff) {
+                my_stop = sg;
+                st_stat = o.stop_stat;
+                st_p = o.stop_pval;
+                st_pow = o.stop_power;
+                st_rank = o.stop_rank;
+            }
+        } else if (o.best_pval >= bp) {
+            bp = o.best_pval;
+            bs = o.best_stat;
+            bi = sg;
+        }
+    }
+    int first = my_stop;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ev += __shfl_xor(ev, o);
+        const int f2 = __shfl_xor(first, o);
+        first = f2 < first ? f2 : first;
+        const double p2 = __shfl_xor(bp, o), s2 = __shfl_xor(bs, o);
+        const int i2 = __shfl_xor(bi, o);
+        if (p2 > bp || (p2 == bp && i2 > bi)) {
+            bp = p2;
+            bs = s2;
+            bi = i2;
+        }
+    }
+    DhMerge M;
+    M.ev = ev;
+    if (first != 0x7fffffff) {  // segments after the first stop were speculative
+        const int owner = first & 63;
+        M.stop = true;
+        M.stat = __shfl(st_stat, owner);
+        M.p = __shfl(st_p, owner);
+        M.pow = __shfl(st_pow, owner);
+        M.nt = __shfl(st_rank, owner) + 1ull;
+    } else {
+        M.stop = false;
+        M.stat = bs;
+        M.p = bi >= 0 ? bp : -2.0;
+        M.pow = 1;
+        M.nt = 0ull;
+    }
+    return M;
+}
+
+// issig (tests.jl:1-3) -> hiton.jl:61-63: the candidate at x.pos joins the accepted list (buffer x.cur) and TPC / PC,
+// or is dropped.  Every lane computes the same state; lane 0 writes.
+__device__ __forceinline__ bool dh_commit(DhTgt &x, const DhArrays &A, int lane, int d1, double r_stat, double r_p, int r_pow,
+                                          double alpha)
+{
+    const int32_t *cands = x.phase == 0 ? A.cand0 + x.cand_off : A.tpc_key + x.co;
+    const int32_t cand = cands[x.pos];
+    ++x.pos;
+    if (!(r_p < alpha && r_pow)) return false;
+    if (lane == 0) {
+        A.acc[DH_ACC_OFF(x, x.cur, d1) + x.na] = cand;
+        if (x.phase == 0) {
+            A.tpc_key[x.co + x.ntpc] = cand;
+            A.tpc_stat[x.co + x.ntpc] = r_stat;
+            A.tpc_p[x.co + x.ntpc] = r_p;
+        } else {
+            A.pc_key[x.co + x.npc] = cand;
+            A.pc_stat[x.co + x.npc] = r_stat;
+            A.pc_p[x.co + x.npc] = r_p;
+        }
+    }
+    ++x.na;
+    if (x.phase == 0)
+        ++x.ntpc;
+    else
+        ++x.npc;
+    return true;
+}
+
+// One wavefront per target: the lanes merge the job's segment records in parallel, then run the sequential part
+// (commit, advance, next job) in lock-step -- every lane holds the same copy of the state, lane 0 writes.
+//
+// Elimination-phase look-ahead (spec_depth > 0, FW_ELIM_FULL windows): the phase tests the members c_0, c_1, ... of TPC one
+// after the other, each against the pool without itself, and nearly always keeps them (cfg3: 96 %), so a target with
+// 170 members is a chain of 170 rounds of one job each.  With the job of c_0 (pool L_0) the launch therefore also
+// carries the jobs of c_1 .. c_d against the pools they will see IF every earlier member is kept:
+// L_{j+1} = (L_j + [c_j]) \ {c_{j+1}} (hiton.jl:134-149: a kept member re-enters the pool at its end), each in its own
+// accepted-list buffer.  The step kernel commits them in order; the first dropped member ends the chain (the later
+// look-ahead jobs saw a pool that still held it: their results are discarded and they run again).
 __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, int ntg, DhGlobal *__restrict__ g, DhArrays A,
                                                       const FwSegOut *__restrict__ so, const long long *__restrict__ seg0,
-                                                      unsigned long long *__restrict__ win, DhParams P)
+                                                      unsigned long long *__restrict__ win, unsigned int *__restrict__ sp,
+                                                      DhParams P)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = blockIdx.x * 4 + wave;
+    const int d1 = P.spec_depth + 1;
     unsigned long long mywin = 0ull;
     if (t < ntg) {
         DhTgt x = tg[t];
         const long long jseg0 = seg0[t];
-        const int jnseg = (int)(seg0[t + 1] - jseg0);
-        bool finished = false;
-        double r_stat = 0.0, r_p = 1.0;
-        int r_pow = 0;
-        unsigned long long r_nt = 0ull;
+        const int nsp_done = x.nsp;
+        const int jnseg = (int)(seg0[t + 1] - jseg0) / (1 + nsp_done);  // records per job (look-ahead jobs: same window)
+        x.nsp = 0;
+        bool finished = false, kept = false;
         if (x.jactive) {
-            // ---- parallel part ----
-            unsigned long long ev = 0ull;
-            int my_stop = 0x7fffffff;  // smallest segment index of this lane that reports a stop
-            double st_stat = 0.0, st_p = 0.0;
-            int st_pow = 0;
-            unsigned long long st_rank = 0ull;
-            double bp = -2.0, bs = 0.0;  // lane best over its segments (increasing index, `>=`)
-            int bi = -1;
-            for (int sg = lane; sg < jnseg; sg += 64) {
-                const FwSegOut o = so[jseg0 + sg];
-                ev += o.evaluated;
-                if (o.stop_rank != FW_RANK_NONE) {
-                    if (my_stop == 0x7fffffff) {
-                        my_stop = sg;
-                        st_stat = o.stop_stat;
-                        st_p = o.stop_pval;
-                        st_pow = o.stop_power;
-                        st_rank = o.stop_rank;
-                    }
-                } else if (o.best_pval >= bp) {
-                    bp = o.best_pval;
-                    bs = o.best_stat;
-                    bi = sg;
-                }
-            }
-            int first = my_stop;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                ev += __shfl_xor(ev, o);
-                const int f2 = __shfl_xor(first, o);
-                first = f2 < first ? f2 : first;
-                const double p2 = __shfl_xor(bp, o), s2 = __shfl_xor(bs, o);
-                const int i2 = __shfl_xor(bi, o);
-                if (p2 > bp || (p2 == bp && i2 > bi)) {
-                    bp = p2;
-                    bs = s2;
-                    bi = i2;
-                }
-            }
+            const DhMerge M = dh_merge(so, jseg0, jnseg, lane);
+            double r_stat = 0.0, r_p = 1.0;
+            int r_pow = 0;
+            unsigned long long r_nt = 0ull;
             bool done = false;
-            if (first != 0x7fffffff) {  // segments after the first stop were speculative
-                const int owner = first & 63;
-                r_stat = __shfl(st_stat, owner);
-                r_p = __shfl(st_p, owner);
-                r_pow = __shfl(st_pow, owner);
-                r_nt = __shfl(st_rank, owner) + 1ull;
+            if (M.stop) {
+                r_stat = M.stat;
+                r_p = M.p;
+                r_pow = M.pow;
+                r_nt = M.nt;
                 done = true;
-            } else if (bi >= 0 && bp >= x.jbest_p) {
-                x.jbest_p = bp;
-                x.jbest_stat = bs;
+            } else if (M.p != -2.0 && M.p >= x.jbest_p) {
+                x.jbest_p = M.p;
+                x.jbest_stat = M.stat;
             }
-            x.jevaluated += ev;
-            // ---- sequential part (every lane computes the same values; only lane 0 writes) ----
+            x.jevaluated += M.ev;
             if (!done) {
                 x.jnext += x.jwin;
                 const unsigned long long growth = g->launched_ranks < P.small_launch ? P.growth_small : (g->n_live_prev > P.busy_jobs ? P.growth_busy : P.growth);
@@ -298,33 +386,27 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
                 x.c_calls += 1ull;
                 x.c_eval += x.jevaluated;
                 x.c_alg += dh_alg_bytes(x.na, x.jevaluated, P.max_k, P.disc_bytes_per_col);
+                kept = dh_commit(x, A, lane, d1, r_stat, r_p, r_pow, P.alpha);
             }
         }
-        if (finished) {  // commit: issig (tests.jl:1-3) -> hiton.jl:61-63
-            const int32_t *cands = x.phase == 0 ? A.cand0 + x.cand_off : A.tpc_key + x.co;
-            const int32_t cand = cands[x.pos];
-            ++x.pos;
-            if (r_p < P.alpha && r_pow) {
-                if (lane == 0) {
-                    A.acc[2 * x.co + x.na] = cand;
-                    if (x.phase == 0) {
-                        A.tpc_key[x.co + x.ntpc] = cand;
-                        A.tpc_stat[x.co + x.ntpc] = r_stat;
-                        A.tpc_p[x.co + x.ntpc] = r_p;
-                    } else {
-                        A.pc_key[x.co + x.npc] = cand;
-                        A.pc_stat[x.co + x.npc] = r_stat;
-                        A.pc_p[x.co + x.npc] = r_p;
-                    }
-                }
-                ++x.na;
-                if (x.phase == 0)
-                    ++x.ntpc;
-                else
-                    ++x.npc;
+        if (nsp_done > 0) {  // look-ahead jobs of the elimination phase: whole enumerations, pools of n entries
+            const int n = x.na - (kept ? 1 : 0), cur0 = x.cur;
+            bool valid = finished && kept;
+            for (int j = 1; j <= nsp_done; ++j) {
+                const DhMerge M = dh_merge(so, jseg0 + (long long)j * jnseg, jnseg, lane);
+                x.c_eval += M.ev;
+                if (!valid) continue;  // an earlier member was dropped: this job saw the wrong pool
+                x.cur = (cur0 + j) % d1;
+                x.na = n;
+                const double r_stat = M.stop ? M.stat : (M.p != -2.0 ? M.stat : 0.0);
+                const double r_p = M.stop ? M.p : (M.p < 0.0 ? 0.0 : M.p);
+                x.c_ref += M.stop ? M.nt : x.jN;
+                x.c_calls += 1ull;
+                x.c_alg += dh_alg_bytes(n, M.ev, P.max_k, P.disc_bytes_per_col);
+                if (!dh_commit(x, A, lane, d1, r_stat, r_p, M.stop ? M.pow : 1, P.alpha)) valid = false;
             }
         }
-        if (!x.jactive && x.phase != 2 && dh_advance(x, A, lane)) {
+        if (!x.jactive && x.phase != 2 && dh_advance(x, A, lane, d1)) {
             unsigned long long N = 0ull;
             for (int s = P.max_k; s >= 1; --s) {
                 N += dh_binom(x.na, s);
@@ -342,6 +424,36 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
             x.jevaluated = 0ull;
             x.jactive = 1;
             if (lane == 0 && (unsigned int)x.na > g->max_a) atomicMax(&g->max_a, (unsigned int)x.na);  // rare: only on a new maximum
+            if (x.phase == 1 && P.elim_full && P.spec_depth > 0 && g->launched_ranks < P.spec_below) {
+                // pools of the next members (see above), each built from the previous one by the 64 lanes
+                const int32_t *cands = A.tpc_key + x.co;
+                const int n = x.na;
+                int q = 0, pbuf = x.cur;
+                int32_t pc = cands[x.pos];
+                while (q < P.spec_depth && x.pos + 1 + q < x.nc) {
+                    const int32_t cn = cands[x.pos + 1 + q];
+                    if (x.wl_n > 0 && dh_in_wl(x, A, cn)) break;  // whitelisted: kept without a test (hiton.jl:20-30)
+                    const int nb = (x.cur + 1 + q) % d1;
+                    const int32_t *src = A.acc + DH_ACC_OFF(x, pbuf, d1);
+                    int32_t *dst = A.acc + DH_ACC_OFF(x, nb, d1);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    int w = 0;
+                    for (int base = 0; base <= n; base += 64) {
+                        const int i = base + lane;
+                        const int32_t v = i < n ? src[i] : pc;
+                        const bool keep = i <= n && v != cn;
+                        const unsigned long long m = __ballot(keep);
+                        if (keep) dst[w + __popcll(m & ((1ull << lane) - 1ull))] = v;
+                        w += __popcll(m);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    if (w != n) break;  // duplicated entries (whitelists): leave this member to the sequential path
+                    pbuf = nb;
+                    pc = cn;
+                    ++q;
+                }
+                x.nsp = q;
+            }
         }
         if (x.jactive) {
             const unsigned long long left = x.jN - x.jnext;
@@ -351,6 +463,7 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
         if (lane == 0) {
             tg[t] = x;
             win[t] = mywin;  // 0 = no job in the coming launch
+            sp[t] = (unsigned int)x.nsp;
         }
     }
 }
@@ -358,19 +471,9 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
 // one workgroup: totals of the coming launch, its segment length, per-target segment counts and their exclusive scan.
 // The segment length has no upper cap here, so the launch never holds more than seg_target + (live jobs) segments:
 // the fixed grid (seg_target + targets) always covers it.
-// ceil(w / seglen) for w < 2^62: double quotient + exact fix-up (a 64-bit integer division costs ~100 instructions)
-__device__ __forceinline__ unsigned int dh_ceil_div(unsigned long long w, unsigned long long seglen, double inv)
-{
-    if (w == 0ull) return 0u;
-    unsigned long long q = (unsigned long long)((double)w * inv);
-    while (q * seglen < w) ++q;
-    while (q > 0ull && (q - 1ull) * seglen >= w) --q;
-    return (unsigned int)q;
-}
-
 #define DH_PER 32  // targets per planning thread held in registers (more targets: extra passes over global memory)
 __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__restrict__ g, const unsigned long long *__restrict__ win,
-                                                       long long *__restrict__ seg0, unsigned int seg_target, unsigned int seg_q,
+                                                       const unsigned int *__restrict__ sp, long long *__restrict__ seg0, unsigned int seg_target, unsigned int seg_q,
                                                        unsigned int seg_min, ulonglong2 *__restrict__ log, unsigned int log_cap)
 {
     __shared__ unsigned long long s_tot[16];
@@ -381,17 +484,22 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
     unsigned long long tot = 0ull;
     unsigned int live = 0u;
     unsigned long long wr[DH_PER];  // this thread's windows (registers when per <= DH_PER)
-#pragma unroll
-    for (int q = 0; q < DH_PER; ++q) wr[q] = (b + q < e) ? win[b + q] : 0ull;
+    unsigned int mr[DH_PER];        // jobs with that window: 1 + look-ahead jobs
 #pragma unroll
     for (int q = 0; q < DH_PER; ++q) {
-        tot += wr[q];
-        live += wr[q] != 0ull;
+        wr[q] = (b + q < e) ? win[b + q] : 0ull;
+        mr[q] = (b + q < e) ? 1u + sp[b + q] : 1u;
+    }
+#pragma unroll
+    for (int q = 0; q < DH_PER; ++q) {
+        tot += wr[q] * mr[q];
+        live += wr[q] != 0ull ? mr[q] : 0u;
     }
     for (int t = b + DH_PER; t < e; ++t) {
         const unsigned long long w = win[t];
-        tot += w;
-        live += w != 0ull;
+        const unsigned int m = 1u + sp[t];
+        tot += w * m;
+        live += w != 0ull ? m : 0u;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -417,10 +525,10 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
     unsigned int nr[DH_PER];
 #pragma unroll
     for (int q = 0; q < DH_PER; ++q) {
-        nr[q] = dh_ceil_div(wr[q], seglen, inv);
+        nr[q] = dh_ceil_div(wr[q], seglen, inv) * mr[q];
         local += nr[q];
     }
-    for (int t = b + DH_PER; t < e; ++t) local += dh_ceil_div(win[t], seglen, inv);
+    for (int t = b + DH_PER; t < e; ++t) local += dh_ceil_div(win[t], seglen, inv) * (1u + sp[t]);
     unsigned int incl = local;  // inclusive scan inside the wavefront, then over the 16 wavefront totals
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -444,7 +552,7 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
         }
     for (int t = b + DH_PER; t < e; ++t) {
         seg0[t] = (long long)run;
-        run += dh_ceil_div(win[t], seglen, inv);
+        run += dh_ceil_div(win[t], seglen, inv) * (1u + sp[t]);
     }
     if (tid == 0) {
         seg0[ntg] = (long long)ns;
@@ -462,7 +570,7 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
 
 __global__ __launch_bounds__(256) void dh_fill_kernel(const DhTgt *__restrict__ tg, int ntg, const DhGlobal *__restrict__ g,
                                                       const long long *__restrict__ seg0, const DhArrays A,
-                                                      FwSeg *__restrict__ segs)
+                                                      FwSeg *__restrict__ segs, int d1)
 {
     const unsigned int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= g->ns) return;
@@ -476,12 +584,18 @@ __global__ __launch_bounds__(256) void dh_fill_kernel(const DhTgt *__restrict__ 
     }
     const DhTgt &x = tg[lo - 1];
     const unsigned long long seglen = g->seglen;
-    const unsigned long long k = (unsigned long long)((long long)s - seg0[lo - 1]);
+    unsigned long long k = (unsigned long long)((long long)s - seg0[lo - 1]);
     const int32_t *cands = x.phase == 0 ? A.cand0 + x.cand_off : A.tpc_key + x.co;
+    unsigned int slot = 0;  // 0 = the target's job, j = its j-th look-ahead job (same window, own pool buffer)
+    if (x.nsp > 0) {
+        const unsigned int per = (unsigned int)(seg0[lo] - seg0[lo - 1]) / (1u + (unsigned int)x.nsp);
+        slot = (unsigned int)k / per;
+        k -= (unsigned long long)slot * per;
+    }
     FwSeg sg;
     sg.X = x.T;
-    sg.Y = cands[x.pos];
-    sg.acc_off = 2 * x.co;
+    sg.Y = cands[x.pos + (int)slot];
+    sg.acc_off = DH_ACC_OFF(x, (x.cur + (int)slot) % d1, d1);
     sg.acc_len = x.na;
     sg.pad = 0;
     sg.start = x.jnext + k * seglen;
@@ -533,13 +647,21 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
     static const unsigned seg_target_env = [] { const char *e = getenv("FW_SEG_TARGET"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 0u; }();
     const unsigned seg_target = seg_target_env ? seg_target_env : (c->P.kind == FW_FZ ? 3072u : 4096u);  // cfg3 sweep: 3072
-    const unsigned max_ns = seg_target + (unsigned)ntg + 256u;  // capacity of the segment list
+    // elimination-phase look-ahead (fz, FW_ELIM_FULL windows; see dh_step_kernel): FW_DH_SPEC = members tested ahead per
+    // target, FW_DH_SPEC_BELOW = only while the last launch held fewer ranks than this.  cfg3 sweep (ms per pass, one
+    // GPU / one rank of 8): off 326.7 / 112.0; depth 4 always 338 / 103; depth 4 below 4M 318.5 / 104.4, below 8M
+    // 317.3 / 104.6, below 12M 314.8 / 103.6, below 16M 341 -- a launch that already fills the GPU only pays for the
+    // jobs wasted behind every dropped member (3.7 % of the members at cfg3)
+    static const int spec_env = [] { const char *e = getenv("FW_DH_SPEC"); return e ? atoi(e) : 4; }();
+    const int spec_depth = c->P.kind == FW_FZ ? std::min(std::max(spec_env, 0), 15) : 0;
+    const int d1 = spec_depth + 1;
+    const unsigned max_ns = seg_target + (unsigned)ntg * (unsigned)d1 + 256u;  // capacity of the segment list
     const unsigned grid_seg = seg_target + 512u;                // striding workgroups of the segment kernel
     // FW_DH_LOG=<file>: one line per planned launch (ranks, live jobs, segments) -- profiling aid, see profiles/README.md
     static const char *log_path = getenv("FW_DH_LOG");
     constexpr unsigned LOG_CAP = 1u << 16;
-    size_t need = (log_path ? pad(sizeof(ulonglong2) * LOG_CAP) : 0) + pad(sizeof(DhTgt) * ntg) + pad(sizeof(DhGlobal)) + 2 * pad(sizeof(long long) * ((size_t)ntg + 1));
-    need += pad(4 * tot + 4) * 3 + pad(4 * 2 * tot + 4) + pad(8 * tot + 8) * 4 + pad(4 * wl.size() + 4);
+    size_t need = (log_path ? pad(sizeof(ulonglong2) * LOG_CAP) : 0) + pad(sizeof(unsigned int) * ((size_t)ntg + 1)) + pad(sizeof(DhTgt) * ntg) + pad(sizeof(DhGlobal)) + 2 * pad(sizeof(long long) * ((size_t)ntg + 1));
+    need += pad(4 * tot + 4) * 3 + pad(4 * 2 * tot * (size_t)d1 + 4) + pad(8 * tot + 8) * 4 + pad(4 * wl.size() + 4);
     need += pad(sizeof(FwSeg) * max_ns) + pad(sizeof(FwSegOut) * max_ns);
     if (!nb_on_dev) need += pad(8 * ((size_t)p + 1)) + pad(4 * nnz + 4) + 2 * pad(8 * nnz + 8);
     int rc;
@@ -558,12 +680,13 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     DhGlobal *d_g = (DhGlobal *)carve(sizeof(DhGlobal));
     long long *d_seg0 = (long long *)carve(sizeof(long long) * ((size_t)ntg + 1));
     unsigned long long *d_win = (unsigned long long *)carve(sizeof(unsigned long long) * ((size_t)ntg + 1));
+    unsigned int *d_sp = (unsigned int *)carve(sizeof(unsigned int) * ((size_t)ntg + 1));
     DhArrays A{};
     int32_t *d_cand0 = (int32_t *)carve(4 * tot + 4);
     A.cand0 = use_devc ? c->d_cand : d_cand0;
     A.tpc_key = (int32_t *)carve(4 * tot + 4);
     A.pc_key = (int32_t *)carve(4 * tot + 4);
-    A.acc = (int32_t *)carve(4 * 2 * tot + 4);
+    A.acc = (int32_t *)carve(4 * 2 * tot * (size_t)d1 + 4);
     A.tpc_stat = (double *)carve(8 * tot + 8);
     A.tpc_p = (double *)carve(8 * tot + 8);
     A.pc_stat = (double *)carve(8 * tot + 8);
@@ -618,6 +741,8 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         P.growth = envu("FW_DH_GROWTH", 8ull);  // cfg3 sweep: 4 -> 322 ms, 8 -> 321.5, 16 -> 331, 32 -> 350 (the host pool uses 16: its rounds cost 3x more)
         P.growth_busy = envu("FW_DH_GROWTH_BUSY", 4ull);
         P.busy_jobs = (unsigned int)envu("FW_DH_BUSY_JOBS", 2048ull);
+        P.spec_depth = spec_depth;
+        P.spec_below = envu("FW_DH_SPEC_BELOW", 12000000ull);
     }
     const bool fz = c->P.kind == FW_FZ;
     P.w0_small = fz ? 256ull : 16ull;
@@ -647,11 +772,12 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     }
     auto planfill = [&]() {
         hipLaunchKernelGGL(dh_step_kernel, dim3(g_tg), dim3(256), 0, st, d_tg, ntg, d_g, A, (const FwSegOut *)d_so,
-                           (const long long *)d_seg0, d_win, P);
-        hipLaunchKernelGGL(dh_plan_kernel, dim3(1), dim3(1024), 0, st, ntg, d_g, (const unsigned long long *)d_win, d_seg0,
+                           (const long long *)d_seg0, d_win, d_sp, P);
+        hipLaunchKernelGGL(dh_plan_kernel, dim3(1), dim3(1024), 0, st, ntg, d_g, (const unsigned long long *)d_win,
+                           (const unsigned int *)d_sp, d_seg0,
                            seg_target, P.seg_q, P.seg_min, d_log, LOG_CAP);
         hipLaunchKernelGGL(dh_fill_kernel, dim3(g_fill), dim3(256), 0, st, (const DhTgt *)d_tg, ntg, (const DhGlobal *)d_g,
-                           (const long long *)d_seg0, A, d_segs);
+                           (const long long *)d_seg0, A, d_segs, d1);
     };
     planfill();  // nothing to merge yet: creates the first jobs and the first launch (plan #0)
     int rc2 = FW_OK;
@@ -728,21 +854,26 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         (void)hipEventDestroy(ev_end[q]);
     }
     if (rc2) return rc2;
+    // ---- results ----
+    FW_HIP(c, hipMemcpy(tg.data(), d_tg, sizeof(DhTgt) * ntg, hipMemcpyDeviceToHost));
     if (d_log) {
         std::vector<ulonglong2> lg(LOG_CAP);
         DhGlobal fin{};
         FW_HIP(c, hipMemcpy(&fin, d_g, sizeof(DhGlobal), hipMemcpyDeviceToHost));
         FW_HIP(c, hipMemcpy(lg.data(), d_log, sizeof(ulonglong2) * LOG_CAP, hipMemcpyDeviceToHost));
+        long long n_tpc = 0, n_pc = 0;  // interleaving survivors / elimination survivors
+        for (const DhTgt &x : tg) {
+            n_tpc += x.ntpc;
+            n_pc += x.npc;
+        }
         if (FILE *f = fopen(log_path, "a")) {
-            fprintf(f, "# targets %d rounds %u\n", ntg, fin.rounds);
+            fprintf(f, "# targets %d rounds %u tpc %lld pc %lld\n", ntg, fin.rounds, n_tpc, n_pc);
             for (unsigned r = 0; r < fin.rounds && r < LOG_CAP; ++r)
                 fprintf(f, "%u %llu %llu %llu %.1f\n", r, lg[r].x, lg[r].y >> 32, lg[r].y & 0xffffffffull,
                         r < log_ms.size() ? 1e3 * (double)log_ms[r] : 0.0);
             fclose(f);
         }
     }
-    // ---- results ----
-    FW_HIP(c, hipMemcpy(tg.data(), d_tg, sizeof(DhTgt) * ntg, hipMemcpyDeviceToHost));
     std::vector<int32_t> pk(tot);
     std::vector<double> ps(tot), pp(tot);
     if (tot) {
