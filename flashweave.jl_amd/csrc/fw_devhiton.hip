@@ -66,6 +66,9 @@ struct DhParams {
     unsigned int busy_jobs;
     int spec_depth;  // elimination-phase look-ahead: candidates tested ahead of the current one per target (0 = off)
     unsigned long long spec_below;  // ... only while the last launch held fewer ranks than this
+    int spec0_depth;                // interleaving-phase look-ahead (first windows of the next candidates)
+    unsigned long long spec0_below;
+    unsigned int spec0_jobs;  // ... and fewer live jobs than this
 };
 
 __device__ __forceinline__ unsigned long long dh_binom(long long m, int t)
@@ -389,21 +392,44 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
                 kept = dh_commit(x, A, lane, d1, r_stat, r_p, r_pow, P.alpha);
             }
         }
-        if (nsp_done > 0) {  // look-ahead jobs of the elimination phase: whole enumerations, pools of n entries
+        if (nsp_done > 0) {
+            // look-ahead jobs, committed in candidate order while the assumption they were built on holds: elimination
+            // phase -- every earlier member kept (own pool buffers, whole enumerations); interleaving phase -- every
+            // earlier candidate dropped (same accepted list, first window only: a candidate that survives its first
+            // window becomes the target's job and ends the chain)
+            const bool ph1 = x.phase == 1;
             const int n = x.na - (kept ? 1 : 0), cur0 = x.cur;
-            bool valid = finished && kept;
+            const unsigned long long wsp = x.jwin;  // look-ahead jobs ride with the first window of the target's job
+            bool valid = finished && (ph1 ? kept : !kept);
             for (int j = 1; j <= nsp_done; ++j) {
                 const DhMerge M = dh_merge(so, jseg0 + (long long)j * jnseg, jnseg, lane);
-                x.c_eval += M.ev;
-                if (!valid) continue;  // an earlier member was dropped: this job saw the wrong pool
-                x.cur = (cur0 + j) % d1;
-                x.na = n;
+                if (!valid) {  // built on an assumption that failed: executed for nothing
+                    x.c_eval += M.ev;
+                    continue;
+                }
+                if (ph1) {
+                    x.cur = (cur0 + j) % d1;
+                    x.na = n;
+                }
+                if (!M.stop && wsp < x.jN) {  // interleaving: survived the first window -> continues as the target's job
+                    const unsigned long long growth = g->launched_ranks < P.small_launch ? P.growth_small : (g->n_live_prev > P.busy_jobs ? P.growth_busy : P.growth);
+                    x.jactive = 1;
+                    x.jnext = wsp;
+                    x.jwidth = wsp * growth;
+                    x.jbest_p = M.p != -2.0 ? M.p : -1.0;
+                    x.jbest_stat = M.p != -2.0 ? M.stat : 0.0;
+                    x.jevaluated = M.ev;
+                    valid = false;
+                    continue;
+                }
                 const double r_stat = M.stop ? M.stat : (M.p != -2.0 ? M.stat : 0.0);
                 const double r_p = M.stop ? M.p : (M.p < 0.0 ? 0.0 : M.p);
                 x.c_ref += M.stop ? M.nt : x.jN;
                 x.c_calls += 1ull;
+                x.c_eval += M.ev;
                 x.c_alg += dh_alg_bytes(n, M.ev, P.max_k, P.disc_bytes_per_col);
-                if (!dh_commit(x, A, lane, d1, r_stat, r_p, M.stop ? M.pow : 1, P.alpha)) valid = false;
+                const bool k = dh_commit(x, A, lane, d1, r_stat, r_p, M.stop ? M.pow : 1, P.alpha);
+                valid = ph1 ? k : !k;
             }
         }
         if (!x.jactive && x.phase != 2 && dh_advance(x, A, lane, d1)) {
@@ -424,6 +450,15 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
             x.jevaluated = 0ull;
             x.jactive = 1;
             if (lane == 0 && (unsigned int)x.na > g->max_a) atomicMax(&g->max_a, (unsigned int)x.na);  // rare: only on a new maximum
+            if (x.phase == 0 && P.spec0_depth > 0 && g->launched_ranks < P.spec0_below && g->n_live_prev < P.spec0_jobs) {
+                const int32_t *cands = A.cand0 + x.cand_off;
+                int q = 0;
+                while (q < P.spec0_depth && x.pos + 1 + q < x.nc) {
+                    if (x.wl_n > 0 && dh_in_wl(x, A, cands[x.pos + 1 + q])) break;  // whitelisted: joins without a test
+                    ++q;
+                }
+                x.nsp = q;
+            }
             if (x.phase == 1 && P.elim_full && P.spec_depth > 0 && g->launched_ranks < P.spec_below) {
                 // pools of the next members (see above), each built from the previous one by the 64 lanes
                 const int32_t *cands = A.tpc_key + x.co;
@@ -595,7 +630,7 @@ __global__ __launch_bounds__(256) void dh_fill_kernel(const DhTgt *__restrict__ 
     FwSeg sg;
     sg.X = x.T;
     sg.Y = cands[x.pos + (int)slot];
-    sg.acc_off = DH_ACC_OFF(x, (x.cur + (int)slot) % d1, d1);
+    sg.acc_off = DH_ACC_OFF(x, x.phase == 1 ? (x.cur + (int)slot) % d1 : x.cur, d1);
     sg.acc_len = x.na;
     sg.pad = 0;
     sg.start = x.jnext + k * seglen;
@@ -655,7 +690,13 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     static const int spec_env = [] { const char *e = getenv("FW_DH_SPEC"); return e ? atoi(e) : 4; }();
     const int spec_depth = c->P.kind == FW_FZ ? std::min(std::max(spec_env, 0), 15) : 0;
     const int d1 = spec_depth + 1;
-    const unsigned max_ns = seg_target + (unsigned)ntg * (unsigned)d1 + 256u;  // capacity of the segment list
+    // interleaving-phase look-ahead (first windows of the next candidates, same accepted list): FW_DH_SPEC0 candidates,
+    // only while the last launch held fewer than FW_DH_SPEC0_BELOW ranks and fewer than FW_DH_SPEC0_JOBS jobs -- it
+    // pays where the rounds are latency-bound, i.e. on a rank of a multi-GPU job (one rank of 8: 103.6 -> 95.2 ms,
+    // one of 2: 208 -> 204.7 ms) and in the tail of a single-GPU pass (315.8 -> 314.2 ms)
+    static const int spec0_env = [] { const char *e = getenv("FW_DH_SPEC0"); return e ? atoi(e) : 2; }();
+    const int spec0_depth = c->P.kind == FW_FZ ? std::min(std::max(spec0_env, 0), 15) : 0;
+    const unsigned max_ns = seg_target + (unsigned)ntg * (unsigned)(1 + std::max(spec_depth, spec0_depth)) + 256u;  // capacity of the segment list
     const unsigned grid_seg = seg_target + 512u;                // striding workgroups of the segment kernel
     // FW_DH_LOG=<file>: one line per planned launch (ranks, live jobs, segments) -- profiling aid, see profiles/README.md
     static const char *log_path = getenv("FW_DH_LOG");
@@ -743,6 +784,9 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         P.busy_jobs = (unsigned int)envu("FW_DH_BUSY_JOBS", 2048ull);
         P.spec_depth = spec_depth;
         P.spec_below = envu("FW_DH_SPEC_BELOW", 12000000ull);
+        P.spec0_depth = spec0_depth;
+        P.spec0_below = envu("FW_DH_SPEC0_BELOW", 12000000ull);
+        P.spec0_jobs = (unsigned int)envu("FW_DH_SPEC0_JOBS", 512ull);
     }
     const bool fz = c->P.kind == FW_FZ;
     P.w0_small = fz ? 256ull : 16ull;
