@@ -38,6 +38,7 @@ struct DhGlobal {
     unsigned int ns, seglen, done, rounds, rounds_nonempty, max_a;  // max_a: longest accepted list of any job so far
     unsigned long long cond_tests_ref, subsets_calls, evaluated;
     double alg_bytes;
+    unsigned int n_act, act_sel;  // unfinished targets: act[act_sel * ntg + 0 .. n_act) (dh_compact_kernel)
     unsigned int ns_ring[64];  // segments of the last 64 planned launches (the host reads the record once per batch)
 };
 
@@ -340,17 +341,18 @@ __device__ __forceinline__ bool dh_commit(DhTgt &x, const DhArrays &A, int lane,
 __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, int ntg, DhGlobal *__restrict__ g, DhArrays A,
                                                       const FwSegOut *__restrict__ so, const long long *__restrict__ seg0,
                                                       unsigned long long *__restrict__ win, unsigned int *__restrict__ sp,
-                                                      DhParams P)
+                                                      const int32_t *__restrict__ act, DhParams P)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int t = blockIdx.x * 4 + wave;
+    const int ci = blockIdx.x * 4 + wave;  // position in the list of unfinished targets (seg0 is indexed by it)
     const int d1 = P.spec_depth + 1;
     unsigned long long mywin = 0ull;
-    if (t < ntg) {
+    if (ci < (int)g->n_act) {
+        const int t = act[(size_t)g->act_sel * ntg + ci];
         DhTgt x = tg[t];
-        const long long jseg0 = seg0[t];
+        const long long jseg0 = seg0[ci];
         const int nsp_done = x.nsp;
-        const int jnseg = (int)(seg0[t + 1] - jseg0) / (1 + nsp_done);  // records per job (look-ahead jobs: same window)
+        const int jnseg = (int)(seg0[ci + 1] - jseg0) / (1 + nsp_done);  // records per job (look-ahead jobs: same window)
         x.nsp = 0;
         bool finished = false, kept = false;
         if (x.jactive) {
@@ -508,22 +510,26 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
 // the fixed grid (seg_target + targets) always covers it.
 #define DH_PER 32  // targets per planning thread held in registers (more targets: extra passes over global memory)
 __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__restrict__ g, const unsigned long long *__restrict__ win,
-                                                       const unsigned int *__restrict__ sp, long long *__restrict__ seg0, unsigned int seg_target, unsigned int seg_q,
+                                                       const unsigned int *__restrict__ sp, const int32_t *__restrict__ act_all,
+                                                       long long *__restrict__ seg0, unsigned int seg_target, unsigned int seg_q,
                                                        unsigned int seg_min, ulonglong2 *__restrict__ log, unsigned int log_cap)
 {
     __shared__ unsigned long long s_tot[16];
     __shared__ unsigned int s_live[16], s_wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = (ntg + 1023) / 1024;
-    const int b = tid * per, e = (b + per) < ntg ? (b + per) : ntg;
+    const int na = (int)g->n_act;  // unfinished targets; everything below is indexed by the position in that list
+    const int32_t *act = act_all + (size_t)g->act_sel * ntg;
+    const int per = (na + 1023) / 1024;
+    const int b = tid * per, e = (b + per) < na ? (b + per) : na;
     unsigned long long tot = 0ull;
     unsigned int live = 0u;
     unsigned long long wr[DH_PER];  // this thread's windows (registers when per <= DH_PER)
     unsigned int mr[DH_PER];        // jobs with that window: 1 + look-ahead jobs
 #pragma unroll
     for (int q = 0; q < DH_PER; ++q) {
-        wr[q] = (b + q < e) ? win[b + q] : 0ull;
-        mr[q] = (b + q < e) ? 1u + sp[b + q] : 1u;
+        const int tq = (b + q < e) ? act[b + q] : 0;
+        wr[q] = (b + q < e) ? win[tq] : 0ull;
+        mr[q] = (b + q < e) ? 1u + sp[tq] : 1u;
     }
 #pragma unroll
     for (int q = 0; q < DH_PER; ++q) {
@@ -531,8 +537,8 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
         live += wr[q] != 0ull ? mr[q] : 0u;
     }
     for (int t = b + DH_PER; t < e; ++t) {
-        const unsigned long long w = win[t];
-        const unsigned int m = 1u + sp[t];
+        const unsigned long long w = win[act[t]];
+        const unsigned int m = 1u + sp[act[t]];
         tot += w * m;
         live += w != 0ull ? m : 0u;
     }
@@ -563,7 +569,7 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
         nr[q] = dh_ceil_div(wr[q], seglen, inv) * mr[q];
         local += nr[q];
     }
-    for (int t = b + DH_PER; t < e; ++t) local += dh_ceil_div(win[t], seglen, inv) * (1u + sp[t]);
+    for (int t = b + DH_PER; t < e; ++t) local += dh_ceil_div(win[act[t]], seglen, inv) * (1u + sp[act[t]]);
     unsigned int incl = local;  // inclusive scan inside the wavefront, then over the 16 wavefront totals
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -587,10 +593,10 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
         }
     for (int t = b + DH_PER; t < e; ++t) {
         seg0[t] = (long long)run;
-        run += dh_ceil_div(win[t], seglen, inv) * (1u + sp[t]);
+        run += dh_ceil_div(win[act[t]], seglen, inv) * (1u + sp[act[t]]);
     }
     if (tid == 0) {
-        seg0[ntg] = (long long)ns;
+        seg0[na] = (long long)ns;
         g->ns = ns;
         g->seglen = (unsigned int)seglen;
         g->launched_ranks = total;
@@ -605,11 +611,11 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
 
 __global__ __launch_bounds__(256) void dh_fill_kernel(const DhTgt *__restrict__ tg, int ntg, const DhGlobal *__restrict__ g,
                                                       const long long *__restrict__ seg0, const DhArrays A,
-                                                      FwSeg *__restrict__ segs, int d1)
+                                                      FwSeg *__restrict__ segs, int d1, const int32_t *__restrict__ act)
 {
     const unsigned int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= g->ns) return;
-    int lo = 0, hi = ntg;  // first t with seg0[t] > s; the job owning slot s is the one before it
+    int lo = 0, hi = (int)g->n_act;  // first list position with seg0 > s; the job owning slot s is the one before it
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (seg0[mid] <= (long long)s)
@@ -617,7 +623,7 @@ __global__ __launch_bounds__(256) void dh_fill_kernel(const DhTgt *__restrict__ 
         else
             hi = mid;
     }
-    const DhTgt &x = tg[lo - 1];
+    const DhTgt &x = tg[act[(size_t)g->act_sel * ntg + lo - 1]];
     const unsigned long long seglen = g->seglen;
     unsigned long long k = (unsigned long long)((long long)s - seg0[lo - 1]);
     const int32_t *cands = x.phase == 0 ? A.cand0 + x.cand_off : A.tpc_key + x.co;
@@ -637,6 +643,52 @@ __global__ __launch_bounds__(256) void dh_fill_kernel(const DhTgt *__restrict__ 
     const unsigned long long hi_r = x.jnext + x.jwin;
     sg.end = sg.start + seglen < hi_r ? sg.start + seglen : hi_r;
     segs[s] = sg;
+}
+
+// One workgroup, once per batch of rounds (between dh_step_kernel and dh_plan_kernel): drops the finished targets from
+// the list the three kernels above walk.  Most targets finish early (cfg3: 10 000 targets, a few hundred alive for
+// most of the rounds; cfg4: 50 020 / a few thousand), so step, plan and fill shrink with the work that is left.
+// Order-preserving; writes the other half of the ping-pong list and flips act_sel.
+__global__ __launch_bounds__(1024) void dh_compact_kernel(const DhTgt *__restrict__ tg, int ntg, DhGlobal *__restrict__ g,
+                                                          int32_t *__restrict__ act_all)
+{
+    __shared__ unsigned int s_wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int na = (int)g->n_act;
+    const unsigned int sel = g->act_sel;
+    const int32_t *src = act_all + (size_t)sel * ntg;
+    int32_t *dst = act_all + (size_t)(sel ^ 1u) * ntg;
+    const int per = (na + 1023) / 1024;
+    const int b = tid * per, e = (b + per) < na ? (b + per) : na;
+    unsigned int local = 0u;
+    for (int i = b; i < e; ++i) {
+        const DhTgt &x = tg[src[i]];
+        local += (x.phase != 2 || x.jactive) ? 1u : 0u;
+    }
+    unsigned int incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    unsigned int wbase = 0u, total = 0u;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) wbase += s_wsum[w];
+        total += s_wsum[w];
+    }
+    unsigned int pos = wbase + incl - local;
+    for (int i = b; i < e; ++i) {
+        const int t = src[i];
+        const DhTgt &x = tg[t];
+        if (x.phase != 2 || x.jactive) dst[pos++] = t;
+    }
+    if (tid == 0) {
+        g->n_act = total;
+        g->act_sel = sel ^ 1u;
+    }
 }
 
 }  // namespace
@@ -701,7 +753,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     // FW_DH_LOG=<file>: one line per planned launch (ranks, live jobs, segments) -- profiling aid, see profiles/README.md
     static const char *log_path = getenv("FW_DH_LOG");
     constexpr unsigned LOG_CAP = 1u << 16;
-    size_t need = (log_path ? pad(sizeof(ulonglong2) * LOG_CAP) : 0) + pad(sizeof(unsigned int) * ((size_t)ntg + 1)) + pad(sizeof(DhTgt) * ntg) + pad(sizeof(DhGlobal)) + 2 * pad(sizeof(long long) * ((size_t)ntg + 1));
+    size_t need = (log_path ? pad(sizeof(ulonglong2) * LOG_CAP) : 0) + pad(sizeof(int32_t) * 2 * (size_t)ntg) + pad(sizeof(unsigned int) * ((size_t)ntg + 1)) + pad(sizeof(DhTgt) * ntg) + pad(sizeof(DhGlobal)) + 2 * pad(sizeof(long long) * ((size_t)ntg + 1));
     need += pad(4 * tot + 4) * 3 + pad(4 * 2 * tot * (size_t)d1 + 4) + pad(8 * tot + 8) * 4 + pad(4 * wl.size() + 4);
     need += pad(sizeof(FwSeg) * max_ns) + pad(sizeof(FwSegOut) * max_ns);
     if (!nb_on_dev) need += pad(8 * ((size_t)p + 1)) + pad(4 * nnz + 4) + 2 * pad(8 * nnz + 8);
@@ -722,6 +774,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     long long *d_seg0 = (long long *)carve(sizeof(long long) * ((size_t)ntg + 1));
     unsigned long long *d_win = (unsigned long long *)carve(sizeof(unsigned long long) * ((size_t)ntg + 1));
     unsigned int *d_sp = (unsigned int *)carve(sizeof(unsigned int) * ((size_t)ntg + 1));
+    int32_t *d_act = (int32_t *)carve(sizeof(int32_t) * 2 * (size_t)ntg);  // ping-pong list of the unfinished targets
     DhArrays A{};
     int32_t *d_cand0 = (int32_t *)carve(4 * tot + 4);
     A.cand0 = use_devc ? c->d_cand : d_cand0;
@@ -738,7 +791,13 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     FwSegOut *d_so = (FwSegOut *)carve(sizeof(FwSegOut) * max_ns);
     ulonglong2 *d_log = log_path ? (ulonglong2 *)carve(sizeof(ulonglong2) * LOG_CAP) : nullptr;
     FW_HIP(c, hipMemcpyAsync(d_tg, tg.data(), sizeof(DhTgt) * ntg, hipMemcpyHostToDevice, st));
-    FW_HIP(c, hipMemsetAsync(d_g, 0, sizeof(DhGlobal), st));
+    hg[0].n_act = (unsigned int)ntg;  // every target starts on the list (the pinned page is the staging copy: stream-ordered)
+    FW_HIP(c, hipMemcpyAsync(d_g, hg, sizeof(DhGlobal), hipMemcpyHostToDevice, st));
+    {
+        std::vector<int32_t> iota((size_t)ntg);
+        for (int t = 0; t < ntg; ++t) iota[t] = t;
+        FW_HIP(c, hipMemcpy(d_act, iota.data(), sizeof(int32_t) * (size_t)ntg, hipMemcpyHostToDevice));
+    }
     FW_HIP(c, hipMemsetAsync(d_seg0, 0, sizeof(long long) * ((size_t)ntg + 1), st));
     if (tot && !use_devc) FW_HIP(c, hipMemcpyAsync(d_cand0, cand0.data(), 4 * tot, hipMemcpyHostToDevice, st));
     if (!wl.empty()) FW_HIP(c, hipMemcpyAsync(d_wl, wl.data(), 4 * wl.size(), hipMemcpyHostToDevice, st));
@@ -799,7 +858,8 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     // back once per batch) + BATCH bounds it; with whitelists a round can append several entries -> static bound.
     const bool any_wl = !wl.empty();
     const bool any_big_static = (any_wl ? 2 * max_cap : max_cap) > FW_TAB_A;
-    const unsigned g_tg = (unsigned)((ntg + 3) / 4), g_fill = (max_ns + 255) / 256;  // step: one wavefront per target
+    const unsigned g_fill = (max_ns + 255) / 256;
+    unsigned n_act_bound = (unsigned)ntg;  // unfinished targets as of the last record read (only ever shrinks)
     const unsigned *d_ns = &d_g->ns;
     // ---- rounds ----
     // Kernel timing: HIP events around every segment launch (fw_counters.t_dev_subsets_s).  FW_DH_TIME_EVERY=k brackets
@@ -814,16 +874,18 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         for (hipEvent_t &e : ev[q]) FW_HIP(c, hipEventCreate(&e));
         FW_HIP(c, hipEventCreateWithFlags(&ev_end[q], hipEventDisableTiming));
     }
-    auto planfill = [&]() {
-        hipLaunchKernelGGL(dh_step_kernel, dim3(g_tg), dim3(256), 0, st, d_tg, ntg, d_g, A, (const FwSegOut *)d_so,
-                           (const long long *)d_seg0, d_win, d_sp, P);
+    auto planfill = [&](bool compact) {
+        hipLaunchKernelGGL(dh_step_kernel, dim3((n_act_bound + 3u) / 4u), dim3(256), 0, st, d_tg, ntg, d_g, A,
+                           (const FwSegOut *)d_so, (const long long *)d_seg0, d_win, d_sp, (const int32_t *)d_act, P);
+        if (compact)  // between step and plan: seg0 of the coming launch is built on the new list
+            hipLaunchKernelGGL(dh_compact_kernel, dim3(1), dim3(1024), 0, st, (const DhTgt *)d_tg, ntg, d_g, d_act);
         hipLaunchKernelGGL(dh_plan_kernel, dim3(1), dim3(1024), 0, st, ntg, d_g, (const unsigned long long *)d_win,
-                           (const unsigned int *)d_sp, d_seg0,
-                           seg_target, P.seg_q, P.seg_min, d_log, LOG_CAP);
+                           (const unsigned int *)d_sp, (const int32_t *)d_act, d_seg0, seg_target, P.seg_q, P.seg_min, d_log,
+                           LOG_CAP);
         hipLaunchKernelGGL(dh_fill_kernel, dim3(g_fill), dim3(256), 0, st, (const DhTgt *)d_tg, ntg, (const DhGlobal *)d_g,
-                           (const long long *)d_seg0, A, d_segs, d1);
+                           (const long long *)d_seg0, A, d_segs, d1, (const int32_t *)d_act);
     };
-    planfill();  // nothing to merge yet: creates the first jobs and the first launch (plan #0)
+    planfill(true);  // nothing to merge yet: creates the first jobs and the first launch (plan #0)
     int rc2 = FW_OK;
     double timed_s = 0.0;
     long timed_n = 0, launches_n = 0;
@@ -836,11 +898,13 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
             // lists grow by at most one entry per round: 3 batches cover the lag of the record plus this batch
             const bool any_big = any_big_static && (any_wl || max_a_seen + 3u * (unsigned)BATCH + 1u > (unsigned)FW_TAB_A);
             if (timed) (void)hipEventRecord(ev[q][2 * r], st);
+            // discrete segment kernel: one workgroup per record, no stride loop -> the grid follows the bound on the list
+            const unsigned grid_mi = std::min(max_ns, seg_target + n_act_bound * (unsigned)(1 + std::max(spec_depth, spec0_depth)) + 256u);
             int rc = fz ? fwi_fz_segments_dev(c, grid_seg, d_segs, A.acc, d_so, d_ns, any_big, st)
-                        : fwi_mi_segments_dev(c, max_ns, d_segs, A.acc, d_so, d_ns, st);
+                        : fwi_mi_segments_dev(c, grid_mi, d_segs, A.acc, d_so, d_ns, st);
             if (rc) return rc;
             if (timed) (void)hipEventRecord(ev[q][2 * r + 1], st);
-            planfill();
+            planfill(r == 0);
         }
         FW_HIP(c, hipGetLastError());
         FW_HIP(c, hipMemcpyAsync(hg + q, d_g, sizeof(DhGlobal), hipMemcpyDeviceToHost, st));
@@ -867,6 +931,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
             }
         }
         max_a_seen = rec.max_a > max_a_seen ? rec.max_a : max_a_seen;
+        n_act_bound = rec.n_act < n_act_bound ? rec.n_act : n_act_bound;
         *done = rec.done != 0u;
         return FW_OK;
     };

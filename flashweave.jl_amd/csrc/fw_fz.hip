@@ -1268,6 +1268,7 @@ int fwi_fz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
         if (rc0) return rc0;
     }
     unsigned long long cap = (unsigned long long)std::min<long long>(npairs, 4ll << 20);
+    if (cap < ctx->l0_cap_hint) cap = ctx->l0_cap_hint;  // a repeated call does not overflow (and re-run the kernel) again
     if (cap == 0) cap = 1;
     FzL0Counters h{};
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1292,6 +1293,7 @@ int fwi_fz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
         FzL0Counters h1{};
         FW_HIP(ctx, hipMemcpyAsync(&h1, d_c1, sizeof(h1), hipMemcpyDeviceToHost, ctx->stream));
         FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (h1.n_sig > ctx->l0_cap_hint) ctx->l0_cap_hint = h1.n_sig;
         if (h1.n_sig > cap) {  // more screened pairs than the buffer holds: retry with the exact count
             cap = h1.n_sig;
             continue;
@@ -1669,6 +1671,7 @@ int fwi_fznz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> 
     const int p = ctx->P.p;
     const long long npairs = (long long)p * (p - 1) / 2;
     unsigned long long cap = (unsigned long long)std::min<long long>(npairs, 4ll << 20);
+    if (cap < ctx->l0_cap_hint) cap = ctx->l0_cap_hint;
     if (cap == 0) cap = 1;
     FzL0Counters h{};
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1687,6 +1690,7 @@ int fwi_fznz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> 
         FW_HIP(ctx, hipMemcpyAsync(&h, ctx->d_tmp0.ptr, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->cnt.kernel_launches += 1;
+        if (h.n_sig > ctx->l0_cap_hint) ctx->l0_cap_hint = h.n_sig;
         if (h.n_sig <= cap) {
             const size_t k = (size_t)h.n_sig;
             if (dev) {

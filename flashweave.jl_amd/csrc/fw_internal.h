@@ -159,6 +159,7 @@ struct fw_ctx {
     const int32_t *d_nb_idx = nullptr;
     const double *d_nb_stat = nullptr, *d_nb_p = nullptr;
     const int32_t *d_cand = nullptr;  // per variable: its neighbours in candidate order (ascending adjusted p, stable)
+    unsigned long long l0_cap_hint = 0;  // most screened / significant level-0 pairs seen so far (sizes the next call's buffers)
     bool nb_host_valid = true;        // nb_idx / nb_stat / nb_p hold the current lists (nb_off always does)
     FwDevBuf d_dh;  // arena of the device-resident HITON rounds (fw_devhiton.hip)
     FwPinned h_dh;  // its pinned flag page

@@ -1063,6 +1063,7 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
     // ---- kernel 1: popcounts + exact reliability/df + Float32 screen -> candidate records ----
     static const int l0_dbg = getenv("FW_L0_DBG") ? atoi(getenv("FW_L0_DBG")) : 0;  // profiling only (invalid results)
     unsigned long long cap_c = (unsigned long long)std::min<long long>(npairs, 8ll << 20);
+    if (cap_c < ctx->l0_cap_hint) cap_c = ctx->l0_cap_hint;  // a repeated call does not overflow (and re-run the kernel) again
     if (cap_c == 0) cap_c = 1;
     MiL0Counters h1{};
     double *d_gthr = nullptr;
@@ -1082,6 +1083,7 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
         FW_HIP(ctx, hipMemcpyAsync(&h1, ctx->d_tmp0.ptr, sizeof(h1), hipMemcpyDeviceToHost, ctx->stream));
         FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->cnt.kernel_launches += 1;
+        if (h1.n_sig > ctx->l0_cap_hint) ctx->l0_cap_hint = h1.n_sig;
         if (h1.n_sig <= cap_c) break;
         if (attempt == 1) return fw_fail(ctx, FW_ERR_DEVICE, "discrete level-0: candidate buffer overflow twice");
         cap_c = h1.n_sig;
