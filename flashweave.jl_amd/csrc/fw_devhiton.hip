@@ -512,7 +512,8 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
 __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__restrict__ g, const unsigned long long *__restrict__ win,
                                                        const unsigned int *__restrict__ sp, const int32_t *__restrict__ act_all,
                                                        long long *__restrict__ seg0, unsigned int seg_target, unsigned int seg_q,
-                                                       unsigned int seg_min, ulonglong2 *__restrict__ log, unsigned int log_cap)
+                                                       unsigned int seg_min, ulonglong2 *__restrict__ log, unsigned int log_cap,
+                                                       unsigned long long seg_a, unsigned long long seg_b)
 {
     __shared__ unsigned long long s_tot[16];
     __shared__ unsigned int s_live[16], s_wsum[16];
@@ -559,7 +560,10 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
         total += s_tot[w];
         n_live += s_live[w];
     }
-    unsigned long long seglen = (total / seg_target + seg_q - 1ull) / seg_q * seg_q;
+    // small launches: fewer, longer segments (one / two residency waves of workgroups instead of three) -- every
+    // workgroup pays its set-up (accepted list, thresholds, LDS table) once, and a launch of a few M ranks is latency-bound
+    const unsigned int tgt = total < seg_a ? (seg_target + 2u) / 3u : (total < seg_b ? (2u * seg_target + 2u) / 3u : seg_target);
+    unsigned long long seglen = (total / tgt + seg_q - 1ull) / seg_q * seg_q;
     seglen = seglen < seg_min ? seg_min : seglen;
     const double inv = 1.0 / (double)seglen;
     unsigned int local = 0u;
@@ -748,6 +752,13 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     // one of 2: 208 -> 204.7 ms) and in the tail of a single-GPU pass (315.8 -> 314.2 ms)
     static const int spec0_env = [] { const char *e = getenv("FW_DH_SPEC0"); return e ? atoi(e) : 2; }();
     const int spec0_depth = c->P.kind == FW_FZ ? std::min(std::max(spec0_env, 0), 15) : 0;
+    // segments per launch by launch size (fz): below FW_SEG_A ranks a third of seg_target, below FW_SEG_B two thirds.
+    // cfg3, ms per pass on one GPU / one rank of 2 / of 8: fixed 3 072: 298.8 / 200.3 / 94.9; A, B = 4M, 8M: 295.8 /
+    // 194.4 / 82.3; 6M, 10M: 295.8 / 192.8 / 80.3; 8M, 12M: 295.1 / 193.7 / 79.8 (fixed 1 024: 81.1 for the rank of 8
+    // but 221 for the rank of 2; 512: 102)
+    static const unsigned long long seg_a_env = [] { const char *e = getenv("FW_SEG_A"); return e ? (unsigned long long)atoll(e) : 8000000ull; }();
+    static const unsigned long long seg_b_env = [] { const char *e = getenv("FW_SEG_B"); return e ? (unsigned long long)atoll(e) : 12000000ull; }();
+    const unsigned long long seg_a = c->P.kind == FW_FZ ? seg_a_env : 0ull, seg_b = c->P.kind == FW_FZ ? seg_b_env : 0ull;
     const unsigned max_ns = seg_target + (unsigned)ntg * (unsigned)(1 + std::max(spec_depth, spec0_depth)) + 256u;  // capacity of the segment list
     const unsigned grid_seg = seg_target + 512u;                // striding workgroups of the segment kernel
     // FW_DH_LOG=<file>: one line per planned launch (ranks, live jobs, segments) -- profiling aid, see profiles/README.md
@@ -881,7 +892,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
             hipLaunchKernelGGL(dh_compact_kernel, dim3(1), dim3(1024), 0, st, (const DhTgt *)d_tg, ntg, d_g, d_act);
         hipLaunchKernelGGL(dh_plan_kernel, dim3(1), dim3(1024), 0, st, ntg, d_g, (const unsigned long long *)d_win,
                            (const unsigned int *)d_sp, (const int32_t *)d_act, d_seg0, seg_target, P.seg_q, P.seg_min, d_log,
-                           LOG_CAP);
+                           LOG_CAP, seg_a, seg_b);
         hipLaunchKernelGGL(dh_fill_kernel, dim3(g_fill), dim3(256), 0, st, (const DhTgt *)d_tg, ntg, (const DhGlobal *)d_g,
                            (const long long *)d_seg0, A, d_segs, d1, (const int32_t *)d_act);
     };
