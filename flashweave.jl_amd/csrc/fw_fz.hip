@@ -9,6 +9,7 @@
 // Compiled with -ffp-contract=off: the reference never fuses a*b+c and the partial-correlation value must be
 // reproducible to the bit (only +,-,*,/,sqrt,rint are involved).
 #include "fw_internal.h"
+#include "fw_unrank.h"
 
 #include <algorithm>
 #include <cmath>
@@ -529,49 +530,9 @@ __global__ __launch_bounds__(256) void fz_test_batch_kernel(const float *__restr
 // ------------------------------------------------------------------------------------------------
 #define FW_ACC_LDS 2048
 
-__device__ __forceinline__ unsigned long long binom_u64(long long m, int t)
-{
-    if (m < t) return 0ull;
-    const unsigned long long SAT = 1ull << 62;
-    const double est = (t == 0) ? 1.0
-                                : (t == 1) ? (double)m
-                                           : (t == 2) ? 0.5 * m * (m - 1)
-                                                      : (t == 3) ? (double)m * (m - 1) * (m - 2) / 6.0
-                                                                 : (t == 4) ? (double)m * (m - 1) * (m - 2) * (m - 3) / 24.0
-                                                                            : (double)m * (m - 1) * (m - 2) * (m - 3) * (m - 4) / 120.0;
-    if (est > 4.0e18) return SAT;
-    const unsigned long long u = (unsigned long long)m;
-    switch (t) {
-        case 0: return 1ull;
-        case 1: return u;
-        case 2: return u * (u - 1) / 2ull;
-        case 3: return (u * (u - 1) / 2ull) * (u - 2) / 3ull;
-        case 4: return ((u * (u - 1) / 2ull) * (u - 2) / 3ull) * (u - 3) / 4ull;
-        default: return (((u * (u - 1) / 2ull) * (u - 2) / 3ull) * (u - 3) / 4ull) * (u - 4) / 5ull;
-    }
-}
-
-// lexicographic unranking of `rem` among the s-subsets of positions [0, a)
-__device__ __forceinline__ void unrank_comb(unsigned long long rem, int a, int s, int *pos)
-{
-    int prev = -1;
-    for (int d = 0; d < s; ++d) {
-        const int t = s - d;
-        const unsigned long long tot = binom_u64(a - 1 - prev, t);
-        int lo = prev + 1, hi = a - t;
-        while (lo < hi) {  // largest c with tot - C(a - c, t) <= rem
-            const int mid = (lo + hi + 1) >> 1;
-            const unsigned long long g = tot - binom_u64(a - mid, t);
-            if (g <= rem)
-                lo = mid;
-            else
-                hi = mid - 1;
-        }
-        rem -= tot - binom_u64(a - lo, t);
-        pos[d] = lo;
-        prev = lo;
-    }
-}
+// C(m, t) and the lexicographic unranking of subset ranks: fw_unrank.h (shared with the host-side exhaustive check)
+#define binom_u64 fw_binom_u64
+#define unrank_comb fw_unrank_comb
 
 // ---- tagged scalar forms of the pcor_rec levels (same arithmetic as fz_pcor_dp, used by the run-based kernel) ----
 struct TV {

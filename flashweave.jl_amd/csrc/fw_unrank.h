@@ -1,0 +1,92 @@
+// Lexicographic unranking of subset ranks (the enumeration order of tests.jl:281-346 over the POSITIONS of the accepted
+// vector).  Shared by the device kernels (fw_fz.hip) and a host-side exhaustive check (tests/native/unrank_check.cpp,
+// tests/test_abi_cpu.py): everything here is integer-exact, the floating-point root is only a starting guess.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define FW_HD __host__ __device__ __forceinline__
+#else
+#define FW_HD inline
+#endif
+
+// C(m, t) for t <= 5, saturating at 2^62
+FW_HD unsigned long long fw_binom_u64(long long m, int t)
+{
+    if (m < t) return 0ull;
+    const unsigned long long SAT = 1ull << 62;
+    const double est = (t == 0) ? 1.0
+                                : (t == 1) ? (double)m
+                                           : (t == 2) ? 0.5 * m * (m - 1)
+                                                      : (t == 3) ? (double)m * (m - 1) * (m - 2) / 6.0
+                                                                 : (t == 4) ? (double)m * (m - 1) * (m - 2) * (m - 3) / 24.0
+                                                                            : (double)m * (m - 1) * (m - 2) * (m - 3) * (m - 4) / 120.0;
+    if (est > 4.0e18) return SAT;
+    const unsigned long long u = (unsigned long long)m;
+    switch (t) {
+        case 0: return 1ull;
+        case 1: return u;
+        case 2: return u * (u - 1) / 2ull;
+        case 3: return (u * (u - 1) / 2ull) * (u - 2) / 3ull;
+        case 4: return ((u * (u - 1) / 2ull) * (u - 2) / 3ull) * (u - 3) / 4ull;
+        default: return (((u * (u - 1) / 2ull) * (u - 2) / 3ull) * (u - 3) / 4ull) * (u - 4) / 5ull;
+    }
+}
+
+// reference form: binary search per position (3 x log2(a) binomials; kept for the host-side check)
+FW_HD void fw_unrank_bsearch(unsigned long long rem, int a, int s, int *pos)
+{
+    int prev = -1;
+    for (int d = 0; d < s; ++d) {
+        const int t = s - d;
+        const unsigned long long tot = fw_binom_u64(a - 1 - prev, t);
+        int lo = prev + 1, hi = a - t;
+        while (lo < hi) {  // largest c with tot - C(a - c, t) <= rem
+            const int mid = (lo + hi + 1) >> 1;
+            const unsigned long long g = tot - fw_binom_u64(a - mid, t);
+            if (g <= rem)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        rem -= tot - fw_binom_u64(a - lo, t);
+        pos[d] = lo;
+        prev = lo;
+    }
+}
+
+// smallest m in [t, mmax] with C(m, t) >= R  (1 <= R <= C(mmax, t)): t-th root as the guess, exact fix-up
+FW_HD int fw_inv_binom(unsigned long long R, int t, int mmax)
+{
+    if (t == 1) return (int)R;
+    const double x = (double)R;
+    int m;
+    if (t == 2)
+        m = (int)((1.0 + sqrt(1.0 + 8.0 * x)) * 0.5);
+    else if (t == 3)
+        m = (int)cbrt(6.0 * x) + 1;
+    else if (t == 4)
+        m = (int)sqrt(sqrt(24.0 * x)) + 2;
+    else
+        m = (int)pow(120.0 * x, 0.2) + 2;
+    m = m < t ? t : (m > mmax ? mmax : m);
+    while (m > t && fw_binom_u64(m - 1, t) >= R) --m;
+    while (fw_binom_u64(m, t) < R) ++m;
+    return m;
+}
+
+// position d of the subset = a - (smallest m with C(m, t) >= number of subsets from this rank to the end of the
+// block that starts at the previous position): the same answer as fw_unrank_bsearch with ~3 binomials per position
+FW_HD void fw_unrank_comb(unsigned long long rem, int a, int s, int *pos)
+{
+    int prev = -1;
+    for (int d = 0; d < s; ++d) {
+        const int t = s - d, n = a - 1 - prev;
+        const unsigned long long tot = fw_binom_u64(n, t);
+        const int m = fw_inv_binom(tot - rem, t, n);
+        rem -= tot - fw_binom_u64(m, t);
+        pos[d] = a - m;
+        prev = a - m;
+    }
+}

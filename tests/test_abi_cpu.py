@@ -56,3 +56,16 @@ def test_argument_validation(lib):
     P.max_k = 9
     assert lib.fw_ctx_create(ctypes.byref(P), ctypes.byref(h)) == -5  # FW_ERR_LIMIT
     assert b"max_k" in lib.fw_last_error(None)
+
+
+def test_unranking_root_guess_equals_enumeration(tmp_path):
+    # csrc/fw_unrank.h (shared by the device kernels): inverse-binomial unranking with a floating-point root as the guess
+    # and an exact integer fix-up == binary-search unranking == plain lexicographic enumeration, exhaustively for
+    # |accepted| <= 32 and subset sizes 1..5, and on random ranks for lists of up to 5 000 entries
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "unrank_check")
+    subprocess.run(["g++", "-O2", "-o", exe, os.path.join(root, "tests", "native", "unrank_check.cpp")], check=True)
+    out = subprocess.run([exe, "32"], check=True, capture_output=True, text=True).stdout
+    assert out.startswith("ok "), out
