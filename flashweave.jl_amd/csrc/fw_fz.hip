@@ -741,6 +741,8 @@ __global__ void fz_thresholds_kernel(double alpha, double zscale, double *thr)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     fz_thresholds_dev(alpha, zscale, thr);
+    // thr[4]: |r| below which x = |z|/sqrt2 < FZ_X_SUB for sure (see fz_seg_body); once here instead of once per thread
+    thr[4] = zscale > 0.0 ? tanh(FZ_X_SUB * 0.7071067811865476 / zscale) * (1.0 - 1e-9) : 2.0;
 }
 
 // HIGHK: subsets of size 4-5 possible; LOCAL: per-job matrices (fz_nz); TAB: size-3 subsets through the LDS table
@@ -813,7 +815,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     // significance thresholds on |r| (see fz_thresholds_kernel): outside [lo, hi] the verdict of p < alpha is certain
     const double rlo_pos = thr[0], rhi_pos = thr[1], rlo_neg = thr[2], rhi_neg = thr[3];
     // |r| below which x = |z|/sqrt2 < FZ_X_SUB for sure: x = zscale * log((1+r)/(1-r)) / sqrt2  <=>  r = tanh(x / (sqrt2 zscale))
-    const double rsub_lo = zscale > 0.0 ? tanh(FZ_X_SUB * 0.7071067811865476 / zscale) * (1.0 - 1e-9) : 2.0;
+    const double rsub_lo = !LOCAL ? thr[4] : (zscale > 0.0 ? tanh(FZ_X_SUB * 0.7071067811865476 / zscale) * (1.0 - 1e-9) : 2.0);
     __syncthreads();
 #define ACCV(i) (LOCAL ? ((i) + 2) : (in_lds ? s_acc[(i)] : gacc[(i)]))
 #define CORV(u, v) cor[(size_t)(u) * p + (v)]
@@ -1337,7 +1339,7 @@ int fwi_fz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y
 static int fz_ensure_thresholds(fw_ctx *ctx, hipStream_t stream)
 {
     if (!ctx->d_thr) {
-        FW_HIP(ctx, hipMalloc((void **)&ctx->d_thr, 4 * sizeof(double)));
+        FW_HIP(ctx, hipMalloc((void **)&ctx->d_thr, 8 * sizeof(double)));
         hipLaunchKernelGGL(fz_thresholds_kernel, dim3(1), dim3(64), 0, stream, ctx->P.alpha, fz_zscale(ctx), ctx->d_thr);
         FW_HIP(ctx, hipGetLastError());
         FW_HIP(ctx, hipStreamSynchronize(stream));  // another stream may use it next
