@@ -60,16 +60,16 @@ FW_HD void fw_unrank_bsearch(unsigned long long rem, int a, int s, int *pos)
 FW_HD int fw_inv_binom(unsigned long long R, int t, int mmax)
 {
     if (t == 1) return (int)R;
-    const double x = (double)R;
+    const float x = (float)R;  // single precision is plenty for a guess (and keeps the kernels' register count down)
     int m;
     if (t == 2)
-        m = (int)((1.0 + sqrt(1.0 + 8.0 * x)) * 0.5);
+        m = (int)((1.0f + sqrtf(1.0f + 8.0f * x)) * 0.5f);
     else if (t == 3)
-        m = (int)cbrt(6.0 * x) + 1;
+        m = (int)cbrtf(6.0f * x) + 1;
     else if (t == 4)
-        m = (int)sqrt(sqrt(24.0 * x)) + 2;
+        m = (int)sqrtf(sqrtf(24.0f * x)) + 2;
     else
-        m = (int)pow(120.0 * x, 0.2) + 2;
+        m = (int)exp2f(0.2f * log2f(120.0f * x)) + 2;
     m = m < t ? t : (m > mmax ? mmax : m);
     while (m > t && fw_binom_u64(m - 1, t) >= R) --m;
     while (fw_binom_u64(m, t) < R) ++m;
