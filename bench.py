@@ -177,7 +177,8 @@ def main():
                     "traffic": traffic, "traffic_source": traffic_src,
                     "note": "nominal HBM roofline with the algorithmic bytes of SURVEY 8d (fz: 4*C(k+2,2)+32 B per test, discrete: "
                             "(k+2)*n*b/8+32 B); the gathered matrix entries are mostly L2-resident and the measured limiter of "
-                            "the fz kernel is VALU issue of the Float64 division / square-root sequences",
+                            "the fz kernel is VALU issue of the Float64 division / square-root sequences; avg_launch_us = HIP events "
+                            "on the launch stream (device rounds: one launch in four, rotating slot, scaled to all launches)",
                     "alg_bytes_per_launch": cn["alg_bytes_subsets"] / n_sub_launches,
                     "avg_launch_us": 1e6 * sub_launch_s / n_sub_launches, "launches": n_sub_launches,
                     "evaluated_tests_per_s_in_kernel": cn["cond_tests_evaluated"] / max(sub_launch_s, 1e-12)}

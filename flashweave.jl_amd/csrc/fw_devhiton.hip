@@ -873,13 +873,16 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     unsigned n_act_bound = (unsigned)ntg;  // unfinished targets as of the last record read (only ever shrinks)
     const unsigned *d_ns = &d_g->ns;
     // ---- rounds ----
-    // Kernel timing: HIP events around every segment launch (fw_counters.t_dev_subsets_s).  FW_DH_TIME_EVERY=k brackets
-    // only every k-th launch and scales the sampled average (measured: 3 ms per pass at cfg3, and a biased estimate).
+    // Kernel timing (fw_counters.t_dev_subsets_s): HIP events around one segment launch in FW_DH_TIME_EVERY (default 4),
+    // the sampled slot rotating from batch to batch so that every position of the 16-round batch is covered; the
+    // sampled average is scaled to all non-empty launches.  Every event pair costs ~12 us of idle GPU around the launch
+    // (rocprofv3 trace: 5.9 us before + 5.7 us after, back-to-back otherwise): cfg3, ms per pass / average launch us at
+    // k = 1: 275.3 / 224.2, k = 2: 272.2 / 224.5, k = 4: 270.4 / 224.5, k = 8: 270.2 / 224.8 -- same average, 2 % less time.
     // Two batches are kept in flight: the host enqueues batch b + 1 before it waits for the end of batch b, so the GPU
     // never runs dry while the host looks at the round record (a stream synchronisation per batch left ~200 us of
     // idle GPU per 16 rounds).  Rounds after the last one are no-ops (no live segment, nothing to merge).
     constexpr int BATCH = 16;
-    static const int time_every = [] { const char *e = getenv("FW_DH_TIME_EVERY"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
+    static const int time_every = [] { const char *e = getenv("FW_DH_TIME_EVERY"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
     hipEvent_t ev[2][2 * BATCH], ev_end[2];
     for (int q = 0; q < 2; ++q) {
         for (hipEvent_t &e : ev[q]) FW_HIP(c, hipEventCreate(&e));
@@ -905,7 +908,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     auto enqueue_batch = [&](unsigned b) -> int {
         const int q = (int)(b & 1u);
         for (int r = 0; r < BATCH; ++r) {
-            const bool timed = (r % time_every) == 0;
+            const bool timed = ((r + (int)(b % (unsigned)time_every)) % time_every) == 0;  // the sampled slot rotates from batch to batch
             // lists grow by at most one entry per round: 3 batches cover the lag of the record plus this batch
             const bool any_big = any_big_static && (any_wl || max_a_seen + 3u * (unsigned)BATCH + 1u > (unsigned)FW_TAB_A);
             if (timed) (void)hipEventRecord(ev[q][2 * r], st);
@@ -930,7 +933,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         for (int r = 0; r < BATCH; ++r) {
             if (rec.ns_ring[(b * (unsigned)BATCH + (unsigned)r) & 63u] == 0) continue;  // empty launch after the last round
             ++launches_n;
-            if ((r % time_every) != 0) continue;
+            if (((r + (int)(b % (unsigned)time_every)) % time_every) != 0) continue;
             float ms = 0.0f;
             FW_HIP(c, hipEventElapsedTime(&ms, ev[q][2 * r], ev[q][2 * r + 1]));
             timed_s += 1e-3 * (double)ms;
