@@ -232,6 +232,8 @@ __device__ __forceinline__ unsigned int dh_ceil_div(unsigned long long w, unsign
 // In-rank-order merge of the nseg segment records of one job by the 64 lanes of a wavefront (tests.jl:326-345): the
 // first stop (smallest segment index) ends the job; otherwise the lexicographic maximum of (p, segment index), i.e.
 // "later wins ties" (tests.jl:338).  Every lane returns the same values.
+#define DH_MAX_SPEC 8  // look-ahead jobs per target (register arrays in dh_step_kernel)
+
 struct DhMerge {
     bool stop;
     double stat, p;  // of the stopping test (stop) or of the maximum-p test (!stop; p = -2 if no segment had one)
@@ -462,33 +464,61 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
                 x.nsp = q;
             }
             if (x.phase == 1 && P.elim_full && P.spec_depth > 0 && g->launched_ranks < P.spec_below) {
-                // pools of the next members (see above), each built from the previous one by the 64 lanes
+                // pools of the next members (see above), all built in ONE pass over the current pool:
+                // L_j = (L_0 without c_1 .. c_j, in L_0's order) + [c_0, ..., c_{j-1}]
                 const int32_t *cands = A.tpc_key + x.co;
                 const int n = x.na;
-                int q = 0, pbuf = x.cur;
-                int32_t pc = cands[x.pos];
-                while (q < P.spec_depth && x.pos + 1 + q < x.nc) {
-                    const int32_t cn = cands[x.pos + 1 + q];
-                    if (x.wl_n > 0 && dh_in_wl(x, A, cn)) break;  // whitelisted: kept without a test (hiton.jl:20-30)
-                    const int nb = (x.cur + 1 + q) % d1;
-                    const int32_t *src = A.acc + DH_ACC_OFF(x, pbuf, d1);
-                    int32_t *dst = A.acc + DH_ACC_OFF(x, nb, d1);
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                    int w = 0;
-                    for (int base = 0; base <= n; base += 64) {
-                        const int i = base + lane;
-                        const int32_t v = i < n ? src[i] : pc;
-                        const bool keep = i <= n && v != cn;
-                        const unsigned long long m = __ballot(keep);
-                        if (keep) dst[w + __popcll(m & ((1ull << lane) - 1ull))] = v;
-                        w += __popcll(m);
+                const int32_t c0 = cands[x.pos];
+                int32_t cn[DH_MAX_SPEC];
+                int Q = 0;
+#pragma unroll
+                for (int j = 0; j < DH_MAX_SPEC; ++j) {
+                    cn[j] = -1;
+                    if (j == Q && j < P.spec_depth && x.pos + 1 + j < x.nc) {
+                        const int32_t c = cands[x.pos + 1 + j];
+                        if (!(x.wl_n > 0 && dh_in_wl(x, A, c))) {  // whitelisted: kept without a test (hiton.jl:20-30)
+                            cn[j] = c;
+                            Q = j + 1;
+                        }
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                    if (w != n) break;  // duplicated entries (whitelists): leave this member to the sequential path
-                    pbuf = nb;
-                    pc = cn;
-                    ++q;
                 }
+                const int32_t *src = A.acc + DH_ACC_OFF(x, x.cur, d1);
+                int w[DH_MAX_SPEC];
+#pragma unroll
+                for (int j = 0; j < DH_MAX_SPEC; ++j) w[j] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                for (int base = 0; base < n; base += 64) {
+                    const int i = base + lane;
+                    const int32_t v = i < n ? src[i] : -1;
+                    bool alive = i < n;
+#pragma unroll
+                    for (int j = 0; j < DH_MAX_SPEC; ++j) {
+                        if (j < Q) {  // wavefront-uniform
+                            alive = alive && v != cn[j];
+                            const unsigned long long m = __ballot(alive);
+                            int32_t *dst = A.acc + DH_ACC_OFF(x, (x.cur + 1 + j) % d1, d1);
+                            if (alive) dst[w[j] + __popcll(m & ((1ull << lane) - 1ull))] = v;
+                            w[j] += __popcll(m);
+                        }
+                    }
+                }
+                int q = 0;
+#pragma unroll
+                for (int j = 0; j < DH_MAX_SPEC; ++j) {
+                    // a pool that lost anything but exactly c_1 .. c_{j+1} (duplicated entries: whitelists) ends the chain
+                    if (j == q && j < Q && w[j] == n - (j + 1)) {
+                        int32_t *dst = A.acc + DH_ACC_OFF(x, (x.cur + 1 + j) % d1, d1);
+                        if (lane <= j) {
+                            int32_t tail = c0;
+#pragma unroll
+                            for (int u = 0; u < DH_MAX_SPEC; ++u)
+                                if (lane == u + 1) tail = cn[u];
+                            dst[w[j] + lane] = tail;
+                        }
+                        q = j + 1;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 x.nsp = q;
             }
         }
@@ -744,14 +774,14 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     // 317.3 / 104.6, below 12M 314.8 / 103.6, below 16M 341 -- a launch that already fills the GPU only pays for the
     // jobs wasted behind every dropped member (3.7 % of the members at cfg3)
     static const int spec_env = [] { const char *e = getenv("FW_DH_SPEC"); return e ? atoi(e) : 4; }();
-    const int spec_depth = c->P.kind == FW_FZ ? std::min(std::max(spec_env, 0), 15) : 0;
+    const int spec_depth = c->P.kind == FW_FZ ? std::min(std::max(spec_env, 0), DH_MAX_SPEC) : 0;
     const int d1 = spec_depth + 1;
     // interleaving-phase look-ahead (first windows of the next candidates, same accepted list): FW_DH_SPEC0 candidates,
     // only while the last launch held fewer than FW_DH_SPEC0_BELOW ranks and fewer than FW_DH_SPEC0_JOBS jobs -- it
     // pays where the rounds are latency-bound, i.e. on a rank of a multi-GPU job (one rank of 8: 103.6 -> 95.2 ms,
     // one of 2: 208 -> 204.7 ms) and in the tail of a single-GPU pass (315.8 -> 314.2 ms)
     static const int spec0_env = [] { const char *e = getenv("FW_DH_SPEC0"); return e ? atoi(e) : 2; }();
-    const int spec0_depth = c->P.kind == FW_FZ ? std::min(std::max(spec0_env, 0), 15) : 0;
+    const int spec0_depth = c->P.kind == FW_FZ ? std::min(std::max(spec0_env, 0), DH_MAX_SPEC) : 0;
     // segments per launch by launch size (fz): below FW_SEG_A ranks a third of seg_target, below FW_SEG_B two thirds.
     // cfg3, ms per pass on one GPU / one rank of 2 / of 8: fixed 3 072: 298.8 / 200.3 / 94.9; A, B = 4M, 8M: 295.8 /
     // 194.4 / 82.3; 6M, 10M: 295.8 / 192.8 / 80.3; 8M, 12M: 295.1 / 193.7 / 79.8 (fixed 1 024: 81.1 for the rank of 8
