@@ -130,7 +130,8 @@ def main():
             eng.compute_cor()  # matrix stays resident in HBM
         eng.level0()
         return eng.lgl(feed_forward=bool(args.feed_forward), round_size=args.round_size, rank=rank,
-                       world_size=max(world, args.simulate_world) if world == 1 else world, allgather=cb)
+                       world_size=max(world, args.simulate_world) if world == 1 else world, allgather=cb,
+                       edge_dict=False)  # the network stays in the arrays the C ABI fills (no Python dictionary of tuples)
 
     for _ in range(args.warmup):
         step()
@@ -246,7 +247,7 @@ def main():
                                       (args.config, p, n, cfg["test_name"], cfg["max_k"]),
                           "counts_sha256": csum, "feed_forward": args.feed_forward, "round_size": args.round_size,
                           "parallelism": "targets round-robin over %d GPU(s)" % world},
-               "time_to_network_s": dt / steps, "edges": len(net["edges"]),
+               "time_to_network_s": dt / steps, "edges": int(len(net["edge_src"])),
                "tests_per_step": {"level0": level0_per_step, "conditional_ref_equivalent": cond_ref // steps,
                                   "conditional_evaluated": cond_eval // steps},
                "stage_seconds_rank0": {"level0": cn["t_level0_s"] / steps, "level0_host": cn["t_level0_host_s"] / steps, "conditional": cn["t_cond_s"] / steps,

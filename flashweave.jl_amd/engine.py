@@ -245,8 +245,10 @@ class Engine:
         return self.test_subsets_batch([T], [cand], [list(accepted)])[0]
 
     # -- LGL -----------------------------------------------------------------------------------------
-    def lgl(self, feed_forward=True, round_size=1, rank=0, world_size=1, max_targets=0, allgather=None):
-        """LGL minus normalisation (src/learning.jl:203-279).  Returns dict(edges={(i,j): w}, directed=CSR)."""
+    def lgl(self, feed_forward=True, round_size=1, rank=0, world_size=1, max_targets=0, allgather=None, edge_dict=True):
+        """LGL minus normalisation (src/learning.jl:203-279).  Returns dict(edges={(i,j): w}, directed=CSR);
+        edge_dict=False leaves the edges as the three arrays fw_network_get fills (edge_src, edge_dst, edge_weight) and
+        skips the Python dictionary (48 000 tuples cost ~8 ms at cfg3)."""
         opts = _LearnOpts(int(feed_forward), int(round_size), int(rank), int(world_size), int(max_targets), 0)
         ne = C.c_int64(0)
         cb = None
@@ -262,8 +264,12 @@ class Engine:
         kk = max(int(off[-1]), 1)
         idx, pw, pp = np.zeros(kk, np.int32), np.zeros(kk, np.float64), np.zeros(kk, np.float64)
         self._ck(self.L.fw_network_get_directed(self.h, _ptr(off), _ptr(idx), _ptr(pw), _ptr(pp)))
-        edges = {(int(a), int(b)): float(x) for a, b, x in zip(src[:ne.value], dst[:ne.value], w[:ne.value])}
-        return dict(edges=edges, pc_off=off, pc_idx=idx[:off[-1]], pc_weight=pw[:off[-1]], pc_pval=pp[:off[-1]])
+        m = ne.value
+        out = dict(edge_src=src[:m], edge_dst=dst[:m], edge_weight=w[:m], pc_off=off, pc_idx=idx[:off[-1]],
+                   pc_weight=pw[:off[-1]], pc_pval=pp[:off[-1]])
+        if edge_dict:
+            out["edges"] = dict(zip(zip(src[:m].tolist(), dst[:m].tolist()), w[:m].tolist()))  # python ints / floats
+        return out
 
     def counters(self):
         cn = _Counters()
