@@ -185,7 +185,9 @@ def main():
                     "evaluated_tests_per_s_in_kernel": cn["cond_tests_evaluated"] / max(sub_launch_s, 1e-12)}
         cpu = None
         cpu_skipped = None
-        if not args.no_cpu_baseline and level0_per_step > 100_000_000:
+        if world > 1:
+            cpu_skipped = "the CPU baseline is timed at N = 1 only"
+        elif not args.no_cpu_baseline and level0_per_step > 100_000_000:
             # the oracle's level-0 is a full pass (not sampled): 4.7e8 pair tests at cfg4 would take ~10 minutes on one core
             cpu_skipped = "skipped: %d level-0 pair tests do not fit the bounded CPU sample" % level0_per_step
         elif not args.no_cpu_baseline:
