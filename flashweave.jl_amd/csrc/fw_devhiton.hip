@@ -5,10 +5,12 @@
 //     seg kernel -> dh_step_kernel (merge, commit, advance: one wavefront per target)
 //                -> dh_plan_kernel (segment length, per-target segment counts, exclusive scan: one workgroup)
 //                -> dh_fill_kernel (one thread per segment record) -> seg kernel -> ...
+// (plus dh_compact_kernel once per batch: the three kernels walk a list of the targets that still have work).
 // The host only enqueues batches of rounds and looks at a pinned "done" flag between batches.  Semantics are those
 // of the host driver (hiton.jl:109-149 interleaving / elimination, check_candidate! :80-107, update_PC_dict! :249-256,
-// tests.jl:326-345 merge rules); windows follow the same growth policy.  Speculation here is the elimination-phase
-// look-ahead described at dh_step_kernel (the host pool posts candidates of the interleaving phase ahead instead).
+// tests.jl:326-345 merge rules); windows follow the same growth policy.  Speculation here is the look-ahead described
+// at dh_step_kernel (elimination phase: next members against the pools they will see if every earlier one is kept;
+// interleaving phase: first windows of the next candidates), switched on only while launches are small.
 #include <algorithm>
 #include <cstring>
 #include <vector>
