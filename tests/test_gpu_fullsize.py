@@ -92,3 +92,45 @@ def test_cfg3_full_size_device_rounds_equal_host_driver(monkeypatch):
         assert np.array_equal(nh[key], nd[key], equal_nan=True), key
     assert ch["cond_tests_ref"] == cd["cond_tests_ref"] > 10**10
     assert ch["subsets_calls"] == cd["subsets_calls"]
+
+
+_HASH_SNIPPET = r"""
+import hashlib, sys
+sys.path.insert(0, %r)
+import bench
+import flashweave_jl_amd as fw
+class A: pass
+a = A(); a.p = 0; a.n = 0
+cfg, cs, data = bench.make_input("cfg3", a)
+n, p = data.shape
+e = fw.Engine("fz", n, p, max_k=3)
+e.set_data(data)
+hs = []
+for it in range(2):
+    e.compute_cor(); e.level0()
+    net = e.lgl(feed_forward=False, round_size=0, edge_dict=False)
+    hs.append(hashlib.sha256(b"".join(net[k].tobytes() for k in ("edge_src", "edge_dst", "edge_weight", "pc_off", "pc_idx",
+                                                                  "pc_weight", "pc_pval"))).hexdigest())
+assert hs[0] == hs[1]
+print("HASH", hs[0], len(net["edge_src"]), e.counters()["cond_tests_ref"])
+"""
+
+
+def test_cfg3_network_independent_of_schedule():
+    # the device rounds merge segment results in rank order, so the learned network (edges, weights, directed lists,
+    # p-values, reference-order test count) must not depend on how the work was cut: segment counts, look-ahead jobs on /
+    # off / deeper, every launch timed.  The knobs are read once per process -> one subprocess per setting; each also
+    # checks that two passes on one engine give identical bytes.
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    settings = [{}, {"FW_SEG_TARGET": "2048", "FW_SEG_A": "0", "FW_SEG_B": "0"}, {"FW_DH_SPEC": "0", "FW_DH_SPEC0": "0"},
+                {"FW_DH_SPEC": "8", "FW_DH_SPEC0": "4", "FW_DH_SPEC_BELOW": "100000000000", "FW_DH_SPEC0_BELOW": "100000000000",
+                 "FW_DH_SPEC0_JOBS": "100000", "FW_DH_TIME_EVERY": "1"}]
+    seen = set()
+    for s in settings:
+        out = subprocess.run([sys.executable, "-c", _HASH_SNIPPET % root], env=dict(os.environ, **s), cwd=root, check=True,
+                             capture_output=True, text=True).stdout
+        seen.add([ln for ln in out.splitlines() if ln.startswith("HASH")][-1])
+    assert len(seen) == 1, seen
