@@ -179,7 +179,16 @@ def main():
                     "note": "nominal HBM roofline with the algorithmic bytes of SURVEY 8d (fz: 4*C(k+2,2)+32 B per test, discrete: "
                             "(k+2)*n*b/8+32 B); the gathered matrix entries are mostly L2-resident and the measured limiter of "
                             "the fz kernel is VALU issue of the Float64 division / square-root sequences; avg_launch_us = HIP events "
-                            "on the launch stream (device rounds: one launch in four, rotating slot, scaled to all launches)",
+                            "on the launch stream (device rounds: one launch in four, rotating slot, scaled to all launches); with two "
+                            "concurrent chains the launches of the two streams overlap, see roofline.stage",
+                    # FlashWeave-S runs two chains of device rounds concurrently (FW_DH_CHAINS): launches of the two streams
+                    # overlap, so the per-launch duration above (what HIP events and rocprofv3 see) counts shared time twice.
+                    # The aggregate view: algorithmic bytes of the pass / wall time of the whole conditional stage (all chains,
+                    # step / plan / fill included) -- a lower bound on the bandwidth while the kernel is running.
+                    "stage": {"chains": int(os.environ.get("FW_DH_CHAINS", "2")) if cfg["test_name"] == "fz" else 1,
+                              "achieved": cn["alg_bytes_subsets"] / max(cn["t_cond_s"], 1e-12) / 1e9,
+                              "frac": cn["alg_bytes_subsets"] / max(cn["t_cond_s"], 1e-12) / 1e9 / HBM_PEAK_GBS,
+                              "conditional_stage_s": cn["t_cond_s"] / steps},
                     "alg_bytes_per_launch": cn["alg_bytes_subsets"] / n_sub_launches,
                     "avg_launch_us": 1e6 * sub_launch_s / n_sub_launches, "launches": n_sub_launches,
                     "evaluated_tests_per_s_in_kernel": cn["cond_tests_evaluated"] / max(sub_launch_s, 1e-12)}

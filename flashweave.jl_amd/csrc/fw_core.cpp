@@ -159,8 +159,11 @@ int fw_ctx_destroy(fw_ctx *c)
     free_dev(c->d_nzrecs);
     free_dev(c->d_arena);
     free_dev(c->d_bh);
-    free_dev(c->d_dh);
-    free_pin(c->h_dh);
+    for (int q = 0; q < FW_DH_MAX_CHAINS; ++q) {
+        free_dev(c->d_dh[q]);
+        free_pin(c->h_dh[q]);
+        if (c->dh_stream[q]) (void)hipStreamDestroy(c->dh_stream[q]);
+    }
     free_pin(c->h_jobs);
     free_pin(c->h_acc);
     free_pin(c->h_out);

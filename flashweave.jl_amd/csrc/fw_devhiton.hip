@@ -13,6 +13,7 @@
 // interleaving phase: first windows of the next candidates), switched on only while launches are small.
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "fw_internal.h"
@@ -731,12 +732,14 @@ __global__ __launch_bounds__(1024) void dh_compact_kernel(const DhTgt *__restric
 
 // One round of targets on the device.  in: T ids, interleaving candidates and (sorted) whitelists per target;
 // out: PC (keys, statistics, p-values) per target in insertion order.
-int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<FwDhResult> &out)
+int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<FwDhResult> &out, int chain)
 {
     const int ntg = (int)in.size();
     out.assign((size_t)ntg, FwDhResult{});
     if (ntg == 0) return FW_OK;
-    hipStream_t st = c->pb[0].stream;
+    // chain > 0: a second (third, ...) instance running concurrently from its own host thread on its own stream / arena
+    if (chain > 0 && !c->dh_stream[chain]) FW_HIP(c, hipStreamCreateWithFlags(&c->dh_stream[chain], hipStreamNonBlocking));
+    hipStream_t st = chain == 0 ? c->pb[0].stream : c->dh_stream[chain];
     const int p = c->P.p;
     // ---- host-side layout ----
     const bool use_devc = in[0].nc_dev >= 0 && c->d_cand != nullptr;  // candidate lists built on the device (fw_bh.hip)
@@ -801,11 +804,11 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     need += pad(sizeof(FwSeg) * max_ns) + pad(sizeof(FwSegOut) * max_ns);
     if (!nb_on_dev) need += pad(8 * ((size_t)p + 1)) + pad(4 * nnz + 4) + 2 * pad(8 * nnz + 8);
     int rc;
-    if ((rc = fw_dev_reserve(c, c->d_dh, need))) return rc;
-    if ((rc = fw_pin_reserve(c, c->h_dh, 4096))) return rc;
-    DhGlobal *hg = (DhGlobal *)c->h_dh.ptr;  // two pinned copies of the device record (one per batch in flight)
+    if ((rc = fw_dev_reserve(c, c->d_dh[chain], need))) return rc;
+    if ((rc = fw_pin_reserve(c, c->h_dh[chain], 4096))) return rc;
+    DhGlobal *hg = (DhGlobal *)c->h_dh[chain].ptr;  // two pinned copies of the device record (one per batch in flight)
     memset(hg, 0, 2 * sizeof(DhGlobal));
-    char *B = (char *)c->d_dh.ptr;
+    char *B = (char *)c->d_dh[chain].ptr;
     size_t off = 0;
     auto carve = [&](size_t bytes) {
         char *q = B + off;
@@ -1001,9 +1004,13 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         }
         if (rc2) (void)hipStreamSynchronize(st);
     }
-    if (timed_n > 0) c->cnt.t_dev_subsets_s += timed_s * (double)launches_n / (double)timed_n;
-    c->cnt.subsets_launches += launches_n;
-    c->cnt.kernel_launches += 4 * launches_n;
+    static std::mutex cnt_mu;  // concurrent chains share the context's counters
+    {
+        std::lock_guard<std::mutex> lk(cnt_mu);
+        if (timed_n > 0) c->cnt.t_dev_subsets_s += timed_s * (double)launches_n / (double)timed_n;
+        c->cnt.subsets_launches += launches_n;
+        c->cnt.kernel_launches += 4 * launches_n;
+    }
     for (int q = 0; q < 2; ++q) {
         for (hipEvent_t &e : ev[q]) (void)hipEventDestroy(e);
         (void)hipEventDestroy(ev_end[q]);
@@ -1043,6 +1050,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         out[t].stat.assign(ps.begin() + x.co, ps.begin() + x.co + x.npc);
         out[t].pval.assign(pp.begin() + x.co, pp.begin() + x.co + x.npc);
     }
+    std::lock_guard<std::mutex> lk(cnt_mu);
     for (const DhTgt &x : tg) {
         c->cnt.cond_tests_ref += (int64_t)x.c_ref;
         c->cnt.subsets_calls += (int64_t)x.c_calls;

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cmath>
 #include <numeric>
+#include <thread>
 #include <unordered_map>
 
 #include "fw_internal.h"
@@ -239,7 +240,38 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                         din[i].wl_n = tg[i].wl_n;
                     }
                     std::vector<FwDhResult> dres;
-                    int rc = fwi_devhiton_run(c, din, dres);
+                    // FW_DH_CHAINS = K (default 2, FlashWeave-S): the round's targets are dealt to K independent chains of device
+                    // rounds that run concurrently (own host thread, stream and arena each): while one chain is between
+                    // two launches (step / plan / fill, the thinning tail of its segment kernel) the other keeps the CUs
+                    // busy.  cfg3, ms per pass with 1 / 2 / 3 / 4 chains: 261.8 / 229.4 / 224.2 / 274.3 on one GPU,
+                    // 70.5 / 62.4 / 63.7 for one rank of eight; the per-launch duration of the segment kernel grows with
+                    // the overlap (224 -> 167 us for launches half the size), which is what HIP events and rocprofv3 see
+                    static const int dh_chains = [] { const char *e = getenv("FW_DH_CHAINS"); return std::min(std::max(e ? atoi(e) : 2, 1), FW_DH_MAX_CHAINS); }();
+                    static const size_t dh_chain_min = [] { const char *e = getenv("FW_DH_CHAIN_MIN"); return e && atol(e) > 0 ? (size_t)atol(e) : (size_t)256; }();
+                    const int K = (c->P.kind == FW_FZ && din.size() >= (size_t)dh_chains * dh_chain_min) ? dh_chains : 1;
+                    int rc = FW_OK;
+                    if (K == 1) {
+                        rc = fwi_devhiton_run(c, din, dres);
+                    } else {
+                        std::vector<std::vector<FwDhTarget>> part((size_t)K);
+                        std::vector<std::vector<FwDhResult>> pres((size_t)K);
+                        for (size_t i = 0; i < din.size(); ++i) part[i % (size_t)K].push_back(std::move(din[i]));
+                        std::vector<int> rcs((size_t)K, FW_OK);
+                        std::vector<std::thread> th;
+                        for (int q = 1; q < K; ++q)
+                            th.emplace_back([&, q] {
+                                (void)hipSetDevice(c->P.device);
+                                rcs[q] = fwi_devhiton_run(c, part[q], pres[q], q);
+                            });
+                        rcs[0] = fwi_devhiton_run(c, part[0], pres[0], 0);
+                        for (std::thread &t : th) t.join();
+                        for (int q = 0; q < K; ++q)
+                            if (rcs[q]) rc = rcs[q];
+                        if (!rc) {
+                            dres.resize(din.size());
+                            for (size_t i = 0; i < din.size(); ++i) dres[i] = std::move(pres[i % (size_t)K][i / (size_t)K]);
+                        }
+                    }
                     if (rc) return rc;
                     for (size_t i = 0; i < tg.size(); ++i) {
                         tg[i].PC.key = std::move(dres[i].key);

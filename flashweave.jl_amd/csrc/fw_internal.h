@@ -161,8 +161,10 @@ struct fw_ctx {
     const int32_t *d_cand = nullptr;  // per variable: its neighbours in candidate order (ascending adjusted p, stable)
     unsigned long long l0_cap_hint = 0;  // most screened / significant level-0 pairs seen so far (sizes the next call's buffers)
     bool nb_host_valid = true;        // nb_idx / nb_stat / nb_p hold the current lists (nb_off always does)
-    FwDevBuf d_dh;  // arena of the device-resident HITON rounds (fw_devhiton.hip)
-    FwPinned h_dh;  // its pinned flag page
+#define FW_DH_MAX_CHAINS 4
+    FwDevBuf d_dh[FW_DH_MAX_CHAINS];  // arenas of the device-resident HITON rounds (fw_devhiton.hip), one per concurrent chain
+    FwPinned h_dh[FW_DH_MAX_CHAINS];  // their pinned flag pages
+    hipStream_t dh_stream[FW_DH_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};  // streams of chains 1.. (chain 0: pb[0].stream)
     FwPinned h_jobs, h_acc, h_out;
     FwPoolBuf pb[2];
 };
@@ -262,7 +264,7 @@ struct FwDhResult {
     std::vector<int32_t> key;  // PC in insertion order
     std::vector<double> stat, pval;
 };
-int fwi_devhiton_run(fw_ctx *ctx, const std::vector<FwDhTarget> &in, std::vector<FwDhResult> &out);
+int fwi_devhiton_run(fw_ctx *ctx, const std::vector<FwDhTarget> &in, std::vector<FwDhResult> &out, int chain = 0);
 int fwi_mi_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, const unsigned *d_ns,
                         hipStream_t stream);
 int fwi_fz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, const unsigned *d_ns,

@@ -119,7 +119,7 @@ print("HASH", hs[0], len(net["edge_src"]), e.counters()["cond_tests_ref"])
 def test_cfg3_network_independent_of_schedule():
     # the device rounds merge segment results in rank order, so the learned network (edges, weights, directed lists,
     # p-values, reference-order test count) must not depend on how the work was cut: segment counts, look-ahead jobs on /
-    # off / deeper, every launch timed.  The knobs are read once per process -> one subprocess per setting; each also
+    # off / deeper, every launch timed, one / two / three concurrent chains.  The knobs are read once per process -> one subprocess per setting; each also
     # checks that two passes on one engine give identical bytes.
     import os
     import subprocess
@@ -127,7 +127,8 @@ def test_cfg3_network_independent_of_schedule():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     settings = [{}, {"FW_SEG_TARGET": "2048", "FW_SEG_A": "0", "FW_SEG_B": "0"}, {"FW_DH_SPEC": "0", "FW_DH_SPEC0": "0"},
                 {"FW_DH_SPEC": "8", "FW_DH_SPEC0": "4", "FW_DH_SPEC_BELOW": "100000000000", "FW_DH_SPEC0_BELOW": "100000000000",
-                 "FW_DH_SPEC0_JOBS": "100000", "FW_DH_TIME_EVERY": "1"}]
+                 "FW_DH_SPEC0_JOBS": "100000", "FW_DH_TIME_EVERY": "1"},
+                {"FW_DH_CHAINS": "1"}, {"FW_DH_CHAINS": "3"}]  # concurrent chains of device rounds (default 2)
     seen = set()
     for s in settings:
         out = subprocess.run([sys.executable, "-c", _HASH_SNIPPET % root], env=dict(os.environ, **s), cwd=root, check=True,

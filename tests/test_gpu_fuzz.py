@@ -22,3 +22,18 @@ def test_random_test_subsets_batches_match_oracle():
     for seed in range(60):
         case, msg = fuzz_gpu.run_subsets_case(seed)
         assert msg is None, (msg, case)
+
+
+def test_random_cases_with_concurrent_chains():
+    # FW_DH_CHAINS deals the targets of a round to concurrent chains of device rounds (own host thread, stream, arena); the
+    # default only does so from 512 targets on, so force it for the small random cases (the knobs are read once per
+    # process -> subprocess)
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for chains, first in (("2", 300), ("3", 400)):
+        env = dict(os.environ, FW_DH_CHAINS=chains, FW_DH_CHAIN_MIN="4")
+        out = subprocess.run([sys.executable, "-m", "tests.fuzz_gpu", "--first", str(first), "--cases", "100"], env=env, cwd=root,
+                             capture_output=True, text=True)
+        assert out.returncode == 0 and "100 cases, 0 failures" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
