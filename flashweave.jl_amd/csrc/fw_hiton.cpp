@@ -248,7 +248,9 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                     // the overlap (224 -> 167 us for launches half the size), which is what HIP events and rocprofv3 see
                     static const int dh_chains = [] { const char *e = getenv("FW_DH_CHAINS"); return std::min(std::max(e ? atoi(e) : 2, 1), FW_DH_MAX_CHAINS); }();
                     static const size_t dh_chain_min = [] { const char *e = getenv("FW_DH_CHAIN_MIN"); return e && atol(e) > 0 ? (size_t)atol(e) : (size_t)256; }();
-                    const int K = (c->P.kind == FW_FZ && din.size() >= (size_t)dh_chains * dh_chain_min) ? dh_chains : 1;
+                    static const int dh_chains_disc = [] { const char *e = getenv("FW_DH_CHAINS_DISC"); return std::min(std::max(e ? atoi(e) : 2, 1), FW_DH_MAX_CHAINS); }();  // cfg4: 248.7 / 232.9 / 227.2 / 253.1 ms with 1 / 2 / 3 / 4
+                    const int want = c->P.kind == FW_FZ ? dh_chains : dh_chains_disc;
+                    const int K = din.size() >= (size_t)want * dh_chain_min ? want : 1;
                     int rc = FW_OK;
                     if (K == 1) {
                         rc = fwi_devhiton_run(c, din, dres);

@@ -33,7 +33,7 @@ def test_random_cases_with_concurrent_chains():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for chains, first in (("2", 300), ("3", 400)):
-        env = dict(os.environ, FW_DH_CHAINS=chains, FW_DH_CHAIN_MIN="4")
+        env = dict(os.environ, FW_DH_CHAINS=chains, FW_DH_CHAINS_DISC=chains, FW_DH_CHAIN_MIN="4")
         out = subprocess.run([sys.executable, "-m", "tests.fuzz_gpu", "--first", str(first), "--cases", "100"], env=env, cwd=root,
                              capture_output=True, text=True)
         assert out.returncode == 0 and "100 cases, 0 failures" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
