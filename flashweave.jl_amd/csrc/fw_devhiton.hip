@@ -12,6 +12,7 @@
 // at dh_step_kernel (elimination phase: next members against the pools they will see if every earlier one is kept;
 // interleaving phase: first windows of the next candidates), switched on only while launches are small.
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -737,6 +738,9 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     const int ntg = (int)in.size();
     out.assign((size_t)ntg, FwDhResult{});
     if (ntg == 0) return FW_OK;
+    static const bool trace_host = getenv("FW_TRACE_HOST") != nullptr;  // host-side phase times on stderr
+    auto wall = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double th0 = wall();
     // chain > 0: a second (third, ...) instance running concurrently from its own host thread on its own stream / arena
     if (chain > 0 && !c->dh_stream[chain]) FW_HIP(c, hipStreamCreateWithFlags(&c->dh_stream[chain], hipStreamNonBlocking));
     hipStream_t st = chain == 0 ? c->pb[0].stream : c->dh_stream[chain];
@@ -934,6 +938,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         hipLaunchKernelGGL(dh_fill_kernel, dim3(g_fill), dim3(256), 0, st, (const DhTgt *)d_tg, ntg, (const DhGlobal *)d_g,
                            (const long long *)d_seg0, A, d_segs, d1, (const int32_t *)d_act);
     };
+    const double th1 = wall();
     planfill(true);  // nothing to merge yet: creates the first jobs and the first launch (plan #0)
     int rc2 = FW_OK;
     double timed_s = 0.0;
@@ -1016,6 +1021,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         (void)hipEventDestroy(ev_end[q]);
     }
     if (rc2) return rc2;
+    const double th2 = wall();
     // ---- results ----
     FW_HIP(c, hipMemcpy(tg.data(), d_tg, sizeof(DhTgt) * ntg, hipMemcpyDeviceToHost));
     if (d_log) {
@@ -1050,6 +1056,9 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         out[t].stat.assign(ps.begin() + x.co, ps.begin() + x.co + x.npc);
         out[t].pval.assign(pp.begin() + x.co, pp.begin() + x.co + x.npc);
     }
+    if (trace_host)
+        fprintf(stderr, "[fw] device rounds chain %d: %d targets, set-up %.2f ms, rounds %.2f ms, results %.2f ms\n", chain, ntg,
+                1e3 * (th1 - th0), 1e3 * (th2 - th1), 1e3 * (wall() - th2));
     std::lock_guard<std::mutex> lk(cnt_mu);
     for (const DhTgt &x : tg) {
         c->cnt.cond_tests_ref += (int64_t)x.c_ref;

@@ -240,6 +240,8 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                         din[i].wl_n = tg[i].wl_n;
                     }
                     std::vector<FwDhResult> dres;
+                    const double tdev0 = now_s();
+                    if (getenv("FW_TRACE_HOST")) fprintf(stderr, "[fw] round set-up on the host: %.2f ms\n", 1e3 * (tdev0 - t0));
                     // FW_DH_CHAINS = K (default 2, FlashWeave-S): the round's targets are dealt to K independent chains of device
                     // rounds that run concurrently (own host thread, stream and arena each): while one chain is between
                     // two launches (step / plan / fill, the thinning tail of its segment kernel) the other keeps the CUs
@@ -275,6 +277,7 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                         }
                     }
                     if (rc) return rc;
+                    if (getenv("FW_TRACE_HOST")) fprintf(stderr, "[fw] device rounds (all chains): %.2f ms\n", 1e3 * (now_s() - tdev0));
                     for (size_t i = 0; i < tg.size(); ++i) {
                         tg[i].PC.key = std::move(dres[i].key);
                         tg[i].PC.stat = std::move(dres[i].stat);
@@ -410,6 +413,7 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
         }
     }
     c->cnt.t_cond_s += now_s() - t0;
+    if (getenv("FW_TRACE_HOST")) fprintf(stderr, "[fw] conditional stage: %.2f ms\n", 1e3 * (now_s() - t0));
 
     if (discrete)
         if (int rc = fwi_nb_host_ensure(c)) return rc;
