@@ -27,7 +27,9 @@ def _rel(a, b):
 
 
 def _close(a, b, tol):
-    return (a == b) or (np.isnan(a) and np.isnan(b)) or (tol > 0 and _rel(a, b) < tol)
+    # tol > 0 (discrete kinds): relative, plus an absolute floor of a few ulps of the O(1) terms the statistic is summed
+    # from -- a mutual information of 1e-8 is the residue of a cancellation and carries their rounding, not its own
+    return (a == b) or (np.isnan(a) and np.isnan(b)) or (tol > 0 and (_rel(a, b) < tol or abs(a - b) < 1e-15))
 
 
 def draw(seed):
