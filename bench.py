@@ -9,12 +9,23 @@ CI tests counted = p(p-1)/2 level-0 tests + the reference-equivalent number of c
 sequential reference order would execute; identical to the CPU oracle's by construction).
 
     python bench.py --gpus N --steps K --warmup W
-N > 1: launched by torch.distributed.run, one rank per GPU; targets of every feed-forward round are dealt
-round-robin over ranks and the per-round neighbour sets are all-gathered over RCCL.  Total work is fixed -> "strong".
+
+N > 1: this script starts N ranks ITSELF (re-executes under `python -m torch.distributed.run --nproc-per-node N`,
+rendezvous on 127.0.0.1), one rank per GPU, backend nccl (= RCCL over xGMI); when it is already running under
+torch.distributed.run (WORLD_SIZE in the environment) it uses those ranks and insists that WORLD_SIZE == N.
+Targets of every feed-forward round are dealt round-robin over the ranks and the per-round neighbour sets are
+all-gathered (flashweave.jl_amd/dist.py).  Total work is fixed as N grows -> "strong".  It fails loudly if fewer
+than N GPUs are visible.
+
+Two schedules are measured in every run (both in the ONE JSON line rank 0 prints):
+  * headline (`value`, `ms_per_step`): --feed-forward / --round-size as given (defaults below);
+  * `other_schedule`: the other one of {feed_forward = 1 in rounds of R targets, feed_forward = 0}.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+DEFAULT_ROUND = 1024    # targets per feed-forward round (results do not depend on the number of GPUs, only on R)
 
 
 def make_input(cfg, args):
@@ -46,28 +58,7 @@ def make_input(cfg, args):
     return c, synth.checksum(counts), data
 
 
-def cpu_worker(path, w, W, seconds):
-    """One process of the multi-core CPU leg: conditional stage of the schedule positions w, w + S, ... (S = max(W,
-    p // 512)) with the oracle, for `seconds`; prints one JSON line."""
-    from oracle import oracle as O
-    z = np.load(path, allow_pickle=False)
-    kind, n, max_k = str(z["kind"]), int(z["n"]), int(z["max_k"])
-    if kind == "fz":
-        orc = O.Oracle("fz", cor_mat=z["cm"], n_obs=n)
-        p = z["cm"].shape[0]
-    else:
-        orc = O.Oracle(kind, z["data"], sparse=True, max_k=max_k)
-        p = z["data"].shape[1]
-    stride = max(W, p // 512, 1)
-    r = orc.learn(max_k=max_k, feed_forward=False, target_stride=stride, target_offset=w, max_seconds=seconds)
-    print(json.dumps({"w": w, "n_cond_tests": r["n_cond_tests"], "t_cond": r["t_cond"], "n_targets": r["n_targets"],
-                      "t_level0": r["t_level0"]}))
-
-
-def main():
-    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
-        cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]))
-        return
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -75,32 +66,172 @@ def main():
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--p", type=int, default=0, help="override #OTUs (debug)")
     ap.add_argument("--n", type=int, default=0, help="override #samples (debug)")
-    ap.add_argument("--feed-forward", type=int, default=0)
-    ap.add_argument("--round-size", type=int, default=0)
+    ap.add_argument("--feed-forward", type=int, default=1, help="reference default: true (learning.jl:469)")
+    ap.add_argument("--round-size", type=int, default=DEFAULT_ROUND,
+                    help="targets per feed-forward round (0 = one round = feed_forward off)")
+    ap.add_argument("--no-other-schedule", action="store_true", help="skip the second (other_schedule) measurement")
+    ap.add_argument("--host-seam", action="store_true",
+                    help="also time the pass with FW_HOST_HITON=1: the host job pool over fw_test_subsets_batch-style "
+                         "launches, the seam a Julia host would call (hiton.jl:100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-workers", type=int, default=-1,
-                    help="processes of the multi-core CPU leg (-1: min(32, hardware threads / 2); 0: skip it)")
+                    help="threads of the multi-core CPU leg (-1: all hardware threads; 0: skip it)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for debugging)")
     ap.add_argument("--single-device", action="store_true", help="debug: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="debug: go through the launcher + process group + exchange callback even for --gpus 1")
+    ap.add_argument("--spawn-check", action="store_true",
+                    help="start the ranks, initialise the process group, all-reduce a 1 per rank and print the count "
+                         "(no engine; used by the CPU test of the launcher)")
     ap.add_argument("--simulate-world", type=int, default=0,
                     help="debug: time rank 0's share of an N-rank job on one GPU (no peers; the JSON line is not a result)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    import torch
-    import torch.distributed as dist
+
+def launch(args, argv):
+    """Parent process of `python bench.py --gpus N`: start N ranks under torch.distributed.run and relay their output."""
+    n = args.gpus
+    if not args.spawn_check and not args.single_device:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible -- refusing to run (no silent fallback to "
+                             "fewer ranks)\n" % (n, have))
+            sys.exit(2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.stderr.write("bench.py: starting %d ranks: %s\n" % (n, " ".join(cmd)))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def cpu_baseline(args, cfg, data, n, p, eng, level0_per_step):
+    """The oracle (C restatement, kind "port") timed on this box's host cores on a bounded sample of the workload."""
+    import threading
+
+    from oracle import oracle as O
+    kind, max_k = cfg["test_name"], cfg["max_k"]
+    t_all = time.perf_counter()
+    shared = {}
+    if kind == "fz":
+        shared["cm"] = eng.cor_mat()
+
+        def mk():
+            return O.Oracle("fz", cor_mat=shared["cm"], n_obs=n)
+    else:
+        shared["csc"] = O.dense_to_csc(data)
+
+        def mk():
+            return O.Oracle(kind, csc=shared["csc"], shape=(n, p), sparse=True, max_k=max_k)
+    orc = mk()
+    nom = orc.auto_n_obs_min(-1, 5, max_k)
+    budget = args.cpu_seconds
+    # level 0: the full pass when it fits the budget (5e7 pairs at cfg3: a few seconds), else every s-th row
+    if level0_per_step <= 100_000_000:
+        t1 = time.perf_counter()
+        full = orc.level0(alpha=0.01, hps=5, n_obs_min=nom)
+        l0_tests, l0_secs = full["n_tests"], time.perf_counter() - t1
+        nb = dict(off=full["off"], idx=full["idx"], stat=full["stat"], pval=full["pval"], n_tests=l0_tests)
+        r = orc.learn(max_k=max_k, feed_forward=False, target_stride=max(1, p // 512), max_seconds=budget, nbrs=nb)
+        l0_note = "full level-0 (%d pair tests, %.2fs)" % (l0_tests, l0_secs)
+    else:
+        stride = max(1, p // 64)
+        l0_tests, l0_secs = orc.level0_sample(hps=5, n_obs_min=nom, x_start=0, x_stride=stride, max_seconds=budget)
+        nb = eng.pw_univar_neighbors()  # the conditional stage of the sampled targets needs the neighbour lists: the
+        nb["n_tests"] = level0_per_step  # device's (bit-identical to the oracle's, tests/test_gpu_fullsize.py)
+        r = orc.learn(max_k=max_k, feed_forward=False, target_stride=max(1, p // 512), max_seconds=budget, nbrs=nb)
+        l0_note = "level-0 rows 0, %d, 2*%d, ... against every later column (%d pair tests, %.2fs; neighbour lists for " \
+                  "the conditional sample taken from the device run)" % (stride, stride, l0_tests, l0_secs)
+    l0_rate = l0_tests / max(l0_secs, 1e-9)
+    c_rate = r["n_cond_tests"] / max(r["t_cond"], 1e-9)
+    cpu = {"unit": "tests/s", "cores": 1, "kind": "port",
+           "sample": "oracle/fw_oracle.c (C restatement; the Julia reference cannot run here): %s + conditional stage of "
+                     "every %d-th target of the schedule (%d targets, %d tests, %.2fs), feed_forward=0" %
+                     (l0_note, max(1, p // 512), r["n_targets"], r["n_cond_tests"], r["t_cond"]),
+           "level0_tests_per_s": l0_rate, "cond_tests_per_s": c_rate,
+           "value": (l0_tests + r["n_cond_tests"]) / max(l0_secs + r["t_cond"], 1e-9)}
+    # the same oracle on every hardware thread: T threads, one oracle context each over the shared read-only inputs,
+    # thread w takes schedule positions w, w + S, ... (the analogue of the reference's worker processes,
+    # interleaved.jl:90); level-0 stays single-threaded as in the reference (tests.jl:470-479), so only the
+    # conditional stage is reported for this leg
+    T = args.cpu_workers if args.cpu_workers >= 0 else (os.cpu_count() or 1)
+    if T > 1:
+        S = max(T, p // 512, 1)
+        outs = [None] * T
+        mbudget = max(3.0, budget * 0.6)
+
+        def work(w):
+            o = mk()
+            outs[w] = o.learn(max_k=max_k, feed_forward=False, target_stride=S, target_offset=w, max_seconds=mbudget, nbrs=nb)
+            o.close()
+
+        t2 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(w,)) for w in range(T)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        outs = [o for o in outs if o is not None]
+        tot = sum(o["n_cond_tests"] for o in outs)
+        tmax = max(o["t_cond"] for o in outs)
+        cpu["multicore"] = {"cores": T, "hardware_threads": os.cpu_count(), "cond_tests_per_s": tot / max(tmax, 1e-9),
+                            "sample": "%d oracle threads (one context each, shared inputs), thread w = schedule positions "
+                                      "w, w + %d, ... (%d targets, %d conditional tests, slowest thread %.2fs)" %
+                                      (T, S, sum(o["n_targets"] for o in outs), tot, tmax),
+                            "wall_s": time.perf_counter() - t2}
+    cpu["wall_s"] = time.perf_counter() - t_all
+    orc.close()
+    return cpu
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    in_dist = "WORLD_SIZE" in os.environ
+    if not in_dist and (args.gpus > 1 or args.force_dist):
+        launch(args, argv)  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if in_dist and world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d -- refusing to run\n" % (args.gpus, world))
+        sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+    if args.spawn_check:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend if args.backend != "nccl" or torch.cuda.is_available() else "gloo")
+        one = torch.ones(1, dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(one)
+        if rank == 0:
+            print(json.dumps({"spawn_check": True, "n_ranks": int(one.item()), "world_size": dist.get_world_size(),
+                              "backend": dist.get_backend()}))
+        dist.destroy_process_group()
+        return
+
     if args.single_device:
         local_rank = 0
-    if world > 1:
+    if not args.single_device and torch.cuda.device_count() < max(world, 1):
+        sys.stderr.write("bench.py: %d ranks but %d GPU(s) visible -- refusing to run\n" % (world, torch.cuda.device_count()))
+        sys.exit(2)
+    use_dist = in_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
+        if rank == 0:
+            sys.stderr.write("bench.py: process group up: backend=%s world_size=%d\n" % (dist.get_backend(), dist.get_world_size()))
     dev = torch.device("cuda", local_rank)
     cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collective payloads live
 
@@ -111,167 +242,150 @@ def main():
     n, p = data.shape
     eng = fw.Engine(cfg["test_name"], n, p, max_k=cfg["max_k"], device=local_rank)
     eng.set_data(data)  # host -> HBM once, outside the timed region
-    cb = make_allgather(dist, cdev) if world > 1 else None
+    xstats = {}
+    cb = make_allgather(dist, cdev, stats=xstats) if use_dist else None
     if args.simulate_world > 1 and world == 1:
-        import ctypes as C
-
         def cb(user, n_local, tgt, nbr, stat, pval, n_total, tgt_all, nbr_all, stat_all, pval_all):  # echo: no peers
             n_total[0] = n_local
             tgt_all[0], nbr_all[0], stat_all[0], pval_all[0] = tgt, nbr, stat, pval
             return 0
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
+    def step(ff, R):
         if cfg["test_name"] == "fz":
             eng.compute_cor()  # matrix stays resident in HBM
         eng.level0()
-        return eng.lgl(feed_forward=bool(args.feed_forward), round_size=args.round_size, rank=rank,
+        return eng.lgl(feed_forward=bool(ff), round_size=R, rank=rank,
                        world_size=max(world, args.simulate_world) if world == 1 else world, allgather=cb,
                        edge_dict=False)  # the network stays in the arrays the C ABI fills (no Python dictionary of tuples)
 
-    for _ in range(args.warmup):
-        step()
-    eng.reset_counters()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        net = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    cn = eng.counters()
-    # per-rank counters -> whole job
-    cond_ref = cn["cond_tests_ref"]
-    cond_eval = cn["cond_tests_evaluated"]
-    if world > 1:
-        tt = torch.tensor([cond_ref, cond_eval], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-        cond_ref, cond_eval = int(tt[0].item()), int(tt[1].item())
-    steps = max(args.steps, 1)
-    level0_per_step = p * (p - 1) // 2
-    tests_per_step = level0_per_step + cond_ref // steps
-    value = tests_per_step * steps / dt
+    def measure(ff, R, steps, warmup):
+        """-> dict with the whole-job numbers of `steps` timed passes under schedule (ff, R)."""
+        for _ in range(warmup):
+            step(ff, R)
+        eng.reset_counters()
+        xstats.clear()
+        barrier()
+        t0 = time.perf_counter()
+        net = None
+        for _ in range(steps):
+            net = step(ff, R)
+        barrier()
+        dt = time.perf_counter() - t0
+        cn = eng.counters()
+        cond_ref, cond_eval = cn["cond_tests_ref"], cn["cond_tests_evaluated"]
+        if use_dist:
+            tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+            tt = torch.tensor([cond_ref, cond_eval], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            cond_ref, cond_eval = int(tt[0].item()), int(tt[1].item())
+        s = max(steps, 1)
+        level0 = p * (p - 1) // 2
+        rounds = 1 if (not ff or R <= 0) else (p + R - 1) // R
+        return {"dt": dt, "cn": cn, "net": net, "level0": level0, "cond_ref": cond_ref // s, "cond_eval": cond_eval // s,
+                "value": (level0 + cond_ref // s) * s / dt, "ms_per_step": 1e3 * dt / s, "rounds": rounds,
+                "exchange": {"calls_per_step": xstats.get("calls", 0) / s, "collectives_per_step": xstats.get("collectives", 0) / s,
+                             "entries_per_step": xstats.get("entries", 0) / s,
+                             "seconds_per_step_rank0": xstats.get("seconds", 0.0) / s,
+                             "us_per_round_rank0": 1e6 * xstats.get("seconds", 0.0) / max(xstats.get("calls", 0), 1)}
+                if use_dist else None}
+
+    ff, R = int(bool(args.feed_forward)), args.round_size
+    if R <= 0:
+        ff = 0
+    main_m = measure(ff, R if ff else 0, args.steps, args.warmup)
+    other_m = None
+    if not args.no_other_schedule:
+        off, oR = (0, 0) if ff else (1, DEFAULT_ROUND)
+        other_m = measure(off, oR, max(1, min(args.steps, 3)), 1)
+    seam_m = None
+    if args.host_seam and world == 1:
+        os.environ["FW_HOST_HITON"] = "1"
+        seam_m = measure(0, 0, 1, 0)
+        del os.environ["FW_HOST_HITON"]
 
     out = None
     if rank == 0:
+        steps = max(args.steps, 1)
+        cn, dt, net = main_m["cn"], main_m["dt"], main_m["net"]
         launches = max(cn["kernel_launches"], 1)
         sub_launch_s = cn["t_dev_subsets_s"]
-        # dominant kernel: test_subsets batch (per launch averages over the timed region, this rank)
         n_sub_launches = max(cn["subsets_launches"], 1)
         achieved = (cn["alg_bytes_subsets"] / max(sub_launch_s, 1e-12)) / 1e9
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_cfg3_fz_pmc_summary.json")
-        if args.config == "cfg3" and not args.p and not args.n and os.path.exists(pmc_path):
-            # HBM-side bytes per launch of the same kernel on the same workload, from a separate rocprofv3 --pmc pass
-            # (PMC counters cannot be collected from inside this process); see profiles/README.md
-            traffic = json.load(open(pmc_path))["fz_subsets_seg_kernel"]["fetch_bytes_per_launch"]
-            traffic_src = "profiles/r01_cfg3_fz_pmc_summary.json (FETCH_SIZE + WRITE_SIZE per launch; 4-byte gathers, width-uncorrected)"
-        roofline = {"bound": "hbm", "kernel": "fz_subsets_seg_kernel" if cfg["test_name"] == "fz" else "mi_subsets_seg_kernel",
+        for cand in ("r02_%s_pmc_summary.json" % args.config, "r01_cfg3_fz_pmc_summary.json" if args.config == "cfg3" else ""):
+            pmc_path = os.path.join(ROOT, "profiles", cand)
+            if cand and not args.p and not args.n and os.path.exists(pmc_path):
+                # HBM-side bytes per launch of the same kernel on the same workload, from a separate rocprofv3 --pmc pass
+                # (PMC counters cannot be collected from inside this process); see profiles/README.md
+                kname = "fz_subsets_seg_kernel" if cfg["test_name"] in ("fz", "fz_nz") else "mi_subsets_seg_kernel"
+                js = json.load(open(pmc_path))
+                if kname in js:
+                    traffic = js[kname]["fetch_bytes_per_launch"]
+                    traffic_src = "profiles/%s (FETCH_SIZE + WRITE_SIZE per launch)" % cand
+                    break
+        roofline = {"bound": "hbm", "kernel": "fz_subsets_seg_kernel" if cfg["test_name"] in ("fz", "fz_nz") else "mi_subsets_seg_kernel",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": traffic_src,
                     "note": "nominal HBM roofline with the algorithmic bytes of SURVEY 8d (fz: 4*C(k+2,2)+32 B per test, discrete: "
                             "(k+2)*n*b/8+32 B); the gathered matrix entries are mostly L2-resident and the measured limiter of "
                             "the fz kernel is VALU issue of the Float64 division / square-root sequences; avg_launch_us = HIP events "
-                            "on the launch stream (device rounds: one launch in four, rotating slot, scaled to all launches); with two "
-                            "concurrent chains the launches of the two streams overlap, see roofline.stage",
-                    # FlashWeave-S runs two chains of device rounds concurrently (FW_DH_CHAINS): launches of the two streams
-                    # overlap, so the per-launch duration above (what HIP events and rocprofv3 see) counts shared time twice.
-                    # The aggregate view: algorithmic bytes of the pass / wall time of the whole conditional stage (all chains,
-                    # step / plan / fill included) -- a lower bound on the bandwidth while the kernel is running.
-                    "stage": {"chains": int(os.environ.get("FW_DH_CHAINS", "2")) if cfg["test_name"] == "fz" else 1,
-                              "achieved": cn["alg_bytes_subsets"] / max(cn["t_cond_s"], 1e-12) / 1e9,
+                            "on the launch stream (device rounds: one launch in four, rotating slot, scaled to all launches); with "
+                            "concurrent chains the launches of the streams overlap, see roofline.stage",
+                    "stage": {"achieved": cn["alg_bytes_subsets"] / max(cn["t_cond_s"], 1e-12) / 1e9,
                               "frac": cn["alg_bytes_subsets"] / max(cn["t_cond_s"], 1e-12) / 1e9 / HBM_PEAK_GBS,
                               "conditional_stage_s": cn["t_cond_s"] / steps},
                     "alg_bytes_per_launch": cn["alg_bytes_subsets"] / n_sub_launches,
                     "avg_launch_us": 1e6 * sub_launch_s / n_sub_launches, "launches": n_sub_launches,
                     "evaluated_tests_per_s_in_kernel": cn["cond_tests_evaluated"] / max(sub_launch_s, 1e-12)}
-        cpu = None
-        cpu_skipped = None
+        cpu, cpu_skipped = None, None
         if world > 1:
             cpu_skipped = "the CPU baseline is timed at N = 1 only"
-        elif not args.no_cpu_baseline and level0_per_step > 100_000_000:
-            # the oracle's level-0 is a full pass (not sampled): 4.7e8 pair tests at cfg4 would take ~10 minutes on one core
-            cpu_skipped = "skipped: %d level-0 pair tests do not fit the bounded CPU sample" % level0_per_step
         elif not args.no_cpu_baseline:
-            from oracle import oracle as O
-            cm = eng.cor_mat() if cfg["test_name"] == "fz" else None
-            t1 = time.perf_counter()
-            if cfg["test_name"] == "fz":
-                orc = O.Oracle("fz", cor_mat=cm, n_obs=n)
-            else:
-                orc = O.Oracle(cfg["test_name"], data, sparse=True, max_k=cfg["max_k"])
-            stride = max(1, p // 512)
-            r = orc.learn(max_k=cfg["max_k"], feed_forward=False, target_stride=stride, max_seconds=args.cpu_seconds)
-            t_cpu = time.perf_counter() - t1
-            cpu_tests = r["n_level0_tests"] + r["n_cond_tests"]
-            cpu_secs = r["t_level0"] + r["t_cond"]
-            cpu = {"value": cpu_tests / cpu_secs, "unit": "tests/s", "cores": 1, "kind": "port",
-                   "sample": "oracle/fw_oracle.c (C restatement; the Julia reference cannot run here): full level-0 "
-                             "(%d pair tests, %.2fs) + conditional stage of every %d-th target of the schedule "
-                             "(%d targets, %d tests, %.2fs), feed_forward=0" %
-                             (r["n_level0_tests"], r["t_level0"], stride, r["n_targets"], r["n_cond_tests"], r["t_cond"]),
-                   "level0_tests_per_s": r["n_level0_tests"] / max(r["t_level0"], 1e-9),
-                   "cond_tests_per_s": r["n_cond_tests"] / max(r["t_cond"], 1e-9), "wall_s": t_cpu}
-            # the same oracle on many host cores: W processes, each takes its own targets of the schedule (the analogue of
-            # the reference's worker processes, interleaved.jl:90); level-0 stays single-threaded as in the reference
-            # (tests.jl:470-479), so only the conditional stage is reported for this leg
-            W = args.cpu_workers if args.cpu_workers >= 0 else min(32, max(1, (os.cpu_count() or 2) // 2))
-            if W > 1:
-                import subprocess
-                import tempfile
-                t2 = time.perf_counter()
-                with tempfile.TemporaryDirectory() as td:
-                    path = os.path.join(td, "in.npz")
-                    if cfg["test_name"] == "fz":
-                        np.savez(path, kind="fz", n=n, max_k=cfg["max_k"], cm=cm)
-                    else:
-                        np.savez(path, kind=cfg["test_name"], n=n, max_k=cfg["max_k"], data=data)
-                    budget = max(3.0, args.cpu_seconds * 0.6)
-                    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(w), str(W),
-                                               str(budget)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=ROOT)
-                             for w in range(W)]
-                    outs = []
-                    for pr in procs:
-                        o, _ = pr.communicate(timeout=600)
-                        lines = [ln for ln in o.decode().splitlines() if ln.startswith("{")]
-                        if pr.returncode == 0 and lines:
-                            outs.append(json.loads(lines[-1]))
-                if outs:
-                    tot = sum(o["n_cond_tests"] for o in outs)
-                    tmax = max(o["t_cond"] for o in outs)
-                    cpu["multicore"] = {"cores": len(outs), "cond_tests_per_s": tot / max(tmax, 1e-9),
-                                        "sample": "%d oracle processes, process w = schedule positions w, w + S, ... "
-                                                  "(%d targets, %d conditional tests, slowest process %.2fs)" %
-                                                  (len(outs), sum(o["n_targets"] for o in outs), tot, tmax),
-                                        "wall_s": time.perf_counter() - t2}
-        out = {"metric": "ci_tests_per_sec", "value": value, "unit": "tests/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong",
-               "vs_baseline": None, "dtype": "f64" if cfg["test_name"] == "fz" else "i32", "data": "synthetic",
+            cpu = cpu_baseline(args, cfg, data, n, p, eng, main_m["level0"])
+
+        def sched(m, f, r):
+            return {"feed_forward": f, "round_size": r, "rounds": m["rounds"], "value": m["value"], "unit": "tests/s",
+                    "ms_per_step": m["ms_per_step"], "time_to_network_s": m["ms_per_step"] / 1e3,
+                    "edges": int(len(m["net"]["edge_src"])),
+                    "tests_per_step": {"level0": m["level0"], "conditional_ref_equivalent": m["cond_ref"],
+                                       "conditional_evaluated": m["cond_eval"]},
+                    "exchange": m["exchange"]}
+
+        out = {"metric": "ci_tests_per_sec", "value": main_m["value"], "unit": "tests/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": main_m["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f64" if cfg["test_name"] in ("fz", "fz_nz") else "i32", "data": "synthetic",
                "config": {"workload": "%s: fwsynth-v1 %d OTUs x %d samples, %s, max_k=%d, alpha=0.01" %
                                       (args.config, p, n, cfg["test_name"], cfg["max_k"]),
-                          "counts_sha256": csum, "feed_forward": args.feed_forward, "round_size": args.round_size,
-                          "parallelism": "targets round-robin over %d GPU(s)" % world},
-               "time_to_network_s": dt / steps, "edges": int(len(net["edge_src"])),
-               "tests_per_step": {"level0": level0_per_step, "conditional_ref_equivalent": cond_ref // steps,
-                                  "conditional_evaluated": cond_eval // steps},
+                          "counts_sha256": csum, "feed_forward": ff, "round_size": R if ff else 0,
+                          "parallelism": "targets of each round dealt round-robin over %d GPU(s), one rank per GPU, backend %s" %
+                                         (world, (dist.get_backend() if use_dist else "none"))},
+               "time_to_network_s": dt / steps, "edges": int(len(net["edge_src"])), "rounds": main_m["rounds"],
+               "tests_per_step": {"level0": main_m["level0"], "conditional_ref_equivalent": main_m["cond_ref"],
+                                  "conditional_evaluated": main_m["cond_eval"]},
+               "exchange": main_m["exchange"],
                "stage_seconds_rank0": {"level0": cn["t_level0_s"] / steps, "level0_host": cn["t_level0_host_s"] / steps, "conditional": cn["t_cond_s"] / steps,
                                        "subsets_kernels_device": sub_launch_s / steps,
                                        "host_advance": cn["t_host_advance_s"] / steps, "host_build": cn["t_host_build_s"] / steps,
                                        "host_launch": cn["t_host_launch_s"] / steps, "host_wait_device": cn["t_host_wait_s"] / steps, "host_merge": cn["t_host_merge_s"] / steps,
                                        "subsets_calls": cn["subsets_calls"] / steps},
                "kernel_launches_per_step": launches / steps,
+               "other_schedule": sched(other_m, *((0, 0) if ff else (1, DEFAULT_ROUND))) if other_m else None,
+               "host_seam": ({"note": "FW_HOST_HITON=1: HITON-PC state machines on the host, every pool round = one window of every "
+                                      "in-flight (T, candidate, accepted) job through the fw_test_subsets_batch kernels -- the seam "
+                                      "hiton.jl:100 would call; feed_forward=0", **sched(seam_m, 0, 0)} if seam_m else None),
                "roofline": roofline, "cpu_baseline": cpu}
         if cpu_skipped:
             out["cpu_baseline_note"] = cpu_skipped
         print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

@@ -7,6 +7,8 @@
 #include <cstdarg>
 #include <numeric>
 
+#include <mutex>
+
 #include "fw_internal.h"
 
 static thread_local std::string g_create_err;
@@ -18,10 +20,15 @@ int fw_fail(const fw_ctx *ctx, int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    if (ctx)
+    if (ctx) {
+        // concurrent device-HITON chains (fw_hiton.cpp, one host thread each) may fail at the same time: the message is
+        // a std::string, so writers are serialised; the first message of a call wins (fw_learn_network clears it)
+        static std::mutex err_mu;
+        std::lock_guard<std::mutex> lk(err_mu);
         ctx->err = buf;
-    else
+    } else {
         g_create_err = buf;
+    }
     return code;
 }
 
@@ -515,7 +522,7 @@ static uint64_t binom_sat(int64_t m, int t)
     const uint64_t SAT = 1ull << 62;
     long double r = 1.0L;
     for (int i = 1; i <= t; ++i) r = r * (long double)(m - t + i) / (long double)i;
-    if (r > 4.0e18L) return SAT;
+    if (r > 3.6e18L) return SAT;  // the intermediate v * (m - t + i) is up to t * C(m, t): stay below 2^64 / 5
     uint64_t v = 1;
     for (int i = 1; i <= t; ++i) v = v * (uint64_t)(m - t + i) / (uint64_t)i;  // exact: product of i consecutive ints / i!
     return v;

@@ -175,8 +175,11 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
         }
     } else {
         const int R = (opt.round_size <= 0) ? nt : opt.round_size;
-        for (int r0 = 0; r0 < nt; r0 += R) {
-            const int r1 = std::min(nt, r0 + R);
+        for (int r0 = 0, r1 = 0; r0 < nt; r0 = r1) {
+            // R = 1 is the reference's single_il master: job_q_buff_size = 1, so the first TWO targets of the schedule are
+            // enqueued up front with an empty whitelist (interleaved.jl:62,76-86); from the third target on a job sees
+            // neighbors(graph, T).  The first round therefore holds two targets.
+            r1 = std::min(nt, r0 + ((R == 1 && r0 == 0) ? 2 : R));
             // this rank's targets of the round: dealt round-robin in schedule order
             size_t n_my = 0;
             for (int i = r0; i < r1; ++i) n_my += ((i - r0) % opt.world_size == opt.rank);
@@ -391,7 +394,7 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
             int64_t ntot = (int64_t)lt.size();
             const int32_t *at = lt.data(), *an = ln.data();
             const double *as = ls.data(), *ap = lp.data();
-            if (opt.world_size > 1) {
+            if (allgather) {  // also with world_size = 1 (the callback then returns what it was given): one code path
                 int rc = allgather(user, (int64_t)lt.size(), lt.data(), ln.data(), ls.data(), lp.data(), &ntot, &at, &an, &as, &ap);
                 if (rc) return fw_fail(c, FW_ERR_ARG, "fw_learn_network: allgather callback failed (%d)", rc);
             }

@@ -22,7 +22,9 @@ FW_HD unsigned long long fw_binom_u64(long long m, int t)
                                                       : (t == 3) ? (double)m * (m - 1) * (m - 2) / 6.0
                                                                  : (t == 4) ? (double)m * (m - 1) * (m - 2) * (m - 3) / 24.0
                                                                             : (double)m * (m - 1) * (m - 2) * (m - 3) * (m - 4) / 120.0;
-    if (est > 4.0e18) return SAT;
+    // the exact path multiplies by up to (m - 4) before the division by t <= 5: the intermediate is t * C(m, t), so saturate
+    // where that product would leave 64 bits (2^64 / 5 = 3.69e18), not where C(m, t) itself would
+    if (est > 3.6e18) return SAT;
     const unsigned long long u = (unsigned long long)m;
     switch (t) {
         case 0: return 1ull;

@@ -6,53 +6,96 @@ exchange is the per-round all-gather of the newly found directed neighbour entri
 that feeds the next round's whitelists (the role of the master's running graph, reference
 src/interleaved.jl:124-140,166-183).  `make_allgather` builds the callback fw_learn_network expects
 (include/flashweave_amd.h: fw_allgather_fn) on top of torch.distributed -- backend "nccl" (= RCCL over xGMI) in
-bench.py, "gloo" in the CPU tests.  Payloads are KBs-MBs: latency-bound, one padded all_gather per round.
+bench.py, "gloo" in the CPU tests.
+
+Wire format: ONE all_gather per round of a fixed-capacity int64 message per rank,
+    [count | cap x (target | neighbour << 32, bits(stat), bits(p))]
+-- integers stay integers and the two Float64 travel as their bit patterns (NaN payloads and subnormal p-values
+survive).  The message is packed in a pinned host buffer, copied to the device once, gathered over RCCL and copied
+back once; if any rank's count exceeds the capacity every rank sees that in the gathered headers, doubles the
+capacity to the same value and repeats the round (a first-use event, not a steady-state one).
 """
 import ctypes as C
+import time
 import traceback
 
 import numpy as np
 
 
-def make_allgather(dist, device):
-    """-> python callable with the fw_allgather_fn signature (wrap with engine.ALLGATHER_FN or pass to Engine.lgl)."""
+def make_allgather(dist, device, capacity=4096, stats=None):
+    """-> python callable with the fw_allgather_fn signature (wrap with engine.ALLGATHER_FN or pass to Engine.lgl).
+    stats: optional dict that accumulates {"calls", "collectives", "seconds", "entries"} (bench.py reports them)."""
     import torch
+    on_gpu = device.type == "cuda"
+    st = {"cap": 0, "send": None, "send_dev": None, "recv_dev": None, "recv": None}
     keep = {}
+
+    def ensure(cap, world):
+        if st["cap"] >= cap and st.get("world") == world:
+            return
+        st["world"] = world
+        words = 1 + 3 * cap
+        st["cap"] = cap
+        st["send"] = torch.zeros(words, dtype=torch.int64, pin_memory=on_gpu)
+        st["recv"] = torch.zeros(world * words, dtype=torch.int64, pin_memory=on_gpu)  # flat: gloo insists
+        if on_gpu:
+            st["send_dev"] = torch.zeros(words, dtype=torch.int64, device=device)
+            st["recv_dev"] = torch.zeros(world * words, dtype=torch.int64, device=device)
 
     def cb(user, n_local, tgt, nbr, stat, pval, n_total, tgt_all, nbr_all, stat_all, pval_all):
         try:
+            t0 = time.perf_counter()
             n = int(n_local)
             world = dist.get_world_size()
-            local = np.zeros((n, 4), dtype=np.float64)
-            if n:
-                local[:, 0] = np.ctypeslib.as_array(tgt, shape=(n,))
-                local[:, 1] = np.ctypeslib.as_array(nbr, shape=(n,))
-                local[:, 2] = np.ctypeslib.as_array(stat, shape=(n,))
-                local[:, 3] = np.ctypeslib.as_array(pval, shape=(n,))
-            sizes = torch.zeros(world, dtype=torch.int64, device=device)
-            mine = torch.tensor([n], dtype=torch.int64, device=device)
-            dist.all_gather_into_tensor(sizes, mine)
-            sizes = sizes.cpu().numpy()
-            mx = int(sizes.max())
-            out = np.zeros((0, 4))
-            if mx > 0:
-                pad = torch.zeros((mx, 4), dtype=torch.float64, device=device)
-                if n:
-                    pad[:n] = torch.from_numpy(local).to(device)
-                allt = torch.zeros((world * mx, 4), dtype=torch.float64, device=device)
-                dist.all_gather_into_tensor(allt, pad)
-                allt = allt.cpu().numpy().reshape(world, mx, 4)
-                out = np.concatenate([allt[r, :int(sizes[r])] for r in range(world)], axis=0)
-            N = out.shape[0]
-            keep["t"] = np.ascontiguousarray(out[:, 0].astype(np.int32)) if N else np.zeros(1, np.int32)
-            keep["n"] = np.ascontiguousarray(out[:, 1].astype(np.int32)) if N else np.zeros(1, np.int32)
-            keep["s"] = np.ascontiguousarray(out[:, 2]) if N else np.zeros(1, np.float64)
-            keep["p"] = np.ascontiguousarray(out[:, 3]) if N else np.zeros(1, np.float64)
+            cap = max(st["cap"], capacity)
+            ncoll = 0
+            while True:
+                ensure(cap, world)
+                cap = st["cap"]
+                send = st["send"].numpy()
+                send[0] = n
+                m = min(n, cap)
+                if m:
+                    rows = send[1:1 + 3 * m].reshape(m, 3)
+                    t = np.ctypeslib.as_array(tgt, shape=(n,))[:m].astype(np.int64)
+                    u = np.ctypeslib.as_array(nbr, shape=(n,))[:m].astype(np.int64)
+                    rows[:, 0] = t | (u << 32)
+                    rows[:, 1] = np.ctypeslib.as_array(stat, shape=(n,))[:m].view(np.int64)
+                    rows[:, 2] = np.ctypeslib.as_array(pval, shape=(n,))[:m].view(np.int64)
+                if on_gpu:
+                    st["send_dev"].copy_(st["send"], non_blocking=True)
+                    dist.all_gather_into_tensor(st["recv_dev"], st["send_dev"])
+                    st["recv"].copy_(st["recv_dev"], non_blocking=True)
+                    torch.cuda.current_stream(device).synchronize()
+                else:
+                    dist.all_gather_into_tensor(st["recv"], st["send"])
+                ncoll += 1
+                recv = st["recv"].numpy().reshape(world, 1 + 3 * cap)
+                counts = recv[:, 0].copy()
+                mx = int(counts.max())
+                if mx <= cap:
+                    break
+                cap = 1 << (mx - 1).bit_length()  # every rank computes the same new capacity from the same headers
+            N = int(counts.sum())
+            if N:
+                rows = np.concatenate([recv[r, 1:1 + 3 * int(counts[r])].reshape(-1, 3) for r in range(world)], axis=0)
+                keep["t"] = np.ascontiguousarray((rows[:, 0] & 0xFFFFFFFF).astype(np.int32))
+                keep["n"] = np.ascontiguousarray((rows[:, 0] >> 32).astype(np.int32))
+                keep["s"] = np.ascontiguousarray(rows[:, 1]).view(np.float64)
+                keep["p"] = np.ascontiguousarray(rows[:, 2]).view(np.float64)
+            else:
+                keep["t"] = keep["n"] = np.zeros(1, np.int32)
+                keep["s"] = keep["p"] = np.zeros(1, np.float64)
             n_total[0] = N
             tgt_all[0] = keep["t"].ctypes.data_as(C.POINTER(C.c_int32))
             nbr_all[0] = keep["n"].ctypes.data_as(C.POINTER(C.c_int32))
             stat_all[0] = keep["s"].ctypes.data_as(C.POINTER(C.c_double))
             pval_all[0] = keep["p"].ctypes.data_as(C.POINTER(C.c_double))
+            if stats is not None:
+                stats["calls"] = stats.get("calls", 0) + 1
+                stats["collectives"] = stats.get("collectives", 0) + ncoll
+                stats["entries"] = stats.get("entries", 0) + N
+                stats["seconds"] = stats.get("seconds", 0.0) + (time.perf_counter() - t0)
             return 0
         except Exception:  # never let an exception cross the C boundary
             traceback.print_exc()

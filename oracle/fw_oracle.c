@@ -1390,6 +1390,57 @@ fwo_nbrs *fwo_level0(fwo_ctx *c, double alpha, int hps, int64_t n_obs_min, int F
     return nb;
 }
 
+/* Baseline-sampling helpers (bench.py cpu_baseline leg; not part of any parity check).
+ * fwo_nbrs_from_csr: wrap level-0 neighbour lists computed elsewhere so that fwo_learn can time the conditional
+ * stage of sampled targets without a full CPU level-0 pass (4.7e8 pair tests at cfg4 take minutes on one core). */
+fwo_nbrs *fwo_nbrs_from_csr(int p, const int64_t *off, const int32_t *idx, const double *stat, const double *pval,
+                            int64_t n_tests)
+{
+    fwo_nbrs *nb = (fwo_nbrs *)calloc(1, sizeof(fwo_nbrs));
+    int64_t tot = off[p];
+    nb->off = (int32_t *)malloc(sizeof(int32_t) * ((size_t)p + 1));
+    for (int v = 0; v <= p; ++v) nb->off[v] = (int32_t)off[v];
+    nb->idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(tot > 0 ? tot : 1));
+    nb->stat = (double *)malloc(sizeof(double) * (size_t)(tot > 0 ? tot : 1));
+    nb->pval = (double *)malloc(sizeof(double) * (size_t)(tot > 0 ? tot : 1));
+    memcpy(nb->idx, idx, sizeof(int32_t) * (size_t)tot);
+    memcpy(nb->stat, stat, sizeof(double) * (size_t)tot);
+    memcpy(nb->pval, pval, sizeof(double) * (size_t)tot);
+    nb->n_tests = n_tests;
+    return nb;
+}
+
+/* Level-0 pair tests of the rows X = x_start, x_start + x_stride, ... (every Y > X), as fwo_level0 runs them, until
+ * max_seconds have passed; returns the number of tests executed, *seconds = time spent. */
+int64_t fwo_level0_sample(fwo_ctx *c, int hps, int64_t n_obs_min, int x_start, int x_stride, double max_seconds,
+                          double *seconds)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    const double t0 = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+    double t1 = t0;
+    int64_t n_tests = 0;
+    volatile double sink = 0.0;
+    for (int X = x_start; X < c->p - 1; X += (x_stride > 0 ? x_stride : 1)) {
+        int x_fail = !FWO_IS_CONT(c) && c->levels[X] < 2;
+        for (int Y = X + 1; Y < c->p; ++Y) {
+            fwo_result r;
+            if (x_fail)
+                set_result(&r, 0.0, 1.0, 0, 0);
+            else
+                fwo_test(c, X, Y, NULL, 0, hps, n_obs_min, &r);
+            sink += r.pval;
+            ++n_tests;
+        }
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        t1 = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+        if (max_seconds > 0 && t1 - t0 > max_seconds) break;
+    }
+    (void)sink;
+    *seconds = t1 - t0;
+    return n_tests;
+}
+
 int64_t fwo_nbrs_total(const fwo_nbrs *nb, int p) { return nb->off[p]; }
 int64_t fwo_nbrs_ntests(const fwo_nbrs *nb) { return nb->n_tests; }
 void fwo_nbrs_copy(const fwo_nbrs *nb, int p, int32_t *off, int32_t *idx, double *stat, double *pval)
@@ -1695,7 +1746,9 @@ fwo_network *fwo_learn(fwo_ctx *c, const fwo_params *P_in, const fwo_nbrs *nb_in
         int T = order[ti].idx;
         if (P.max_seconds > 0 && now_s() - t1 > P.max_seconds) break;
         ++n_done;
-        if (ti % rs == 0)
+        /* rs = 1 is the reference's single_il master: job_q_buff_size = 1, so the first TWO targets of the schedule are
+         * enqueued up front with an empty whitelist (interleaved.jl:62,76-86) -- no snapshot refresh before target 1 */
+        if (ti % rs == 0 && !(rs == 1 && ti == 1))
             for (int v = 0; v < p; ++v) snap[v] = adj[v].n;
         const uint8_t *wlp = NULL;
         if (P.feed_forward && P.max_k > 0 && snap[T] > 0) {

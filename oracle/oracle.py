@@ -74,6 +74,10 @@ def lib():
         L.fwo_level0.restype = vp
         L.fwo_level0.argtypes = [vp, C.c_double, C.c_int, C.c_int64, C.c_int, C.c_int]
         L.fwo_nbrs_free.argtypes = [vp]
+        L.fwo_nbrs_from_csr.restype = vp
+        L.fwo_nbrs_from_csr.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int64]
+        L.fwo_level0_sample.restype = C.c_int64
+        L.fwo_level0_sample.argtypes = [vp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double)]
         L.fwo_nbrs_total.restype = C.c_int64
         L.fwo_nbrs_total.argtypes = [vp, C.c_int]
         L.fwo_nbrs_ntests.restype = C.c_int64
@@ -130,16 +134,21 @@ def cor(data, out="f32"):
 class Oracle:
     """One oracle context.  kind in {'mi', 'mi_nz', 'fz'}."""
 
-    def __init__(self, kind, data=None, sparse=True, max_k=3, cor_mat=None, n_obs=None):
+    def __init__(self, kind, data=None, sparse=True, max_k=3, cor_mat=None, n_obs=None, csc=None, shape=None):
+        """csc = (colptr, rowval, nzval) + shape = (n, p): a prebuilt CSC triple (shared by several contexts, e.g. one
+        per thread of bench.py's multi-core leg; a context only holds scratch of its own)."""
         self.kind = kind
         self.L = lib()
         self._keep = []
         if kind in ("mi", "mi_nz"):
-            mat = np.asarray(data)
-            self.n, self.p = mat.shape
+            if csc is not None:
+                self.n, self.p = shape
+            else:
+                mat = np.asarray(data)
+                self.n, self.p = mat.shape
             nz = 1 if kind == "mi_nz" else 0
             if sparse:
-                colptr, rowval, nzval = dense_to_csc(mat)
+                colptr, rowval, nzval = csc if csc is not None else dense_to_csc(mat)
                 self._keep += [colptr, rowval, nzval]
                 self.h = self.L.fwo_create_discrete_sparse(self.n, self.p, _ptr(colptr), _ptr(rowval), _ptr(nzval),
                                                             nz, max_k)
@@ -232,11 +241,30 @@ class Oracle:
         self.L.fwo_nbrs_free(h)
         return dict(off=off, idx=idx[:tot], stat=stat[:tot], pval=pval[:tot], n_tests=int(nt))
 
+    def level0_sample(self, hps=5, n_obs_min=0, x_start=0, x_stride=1, max_seconds=0.0):
+        """bench.py cpu_baseline: time the level-0 pair tests of every x_stride-th row -> (n_tests, seconds)."""
+        sec = C.c_double(0)
+        nt = self.L.fwo_level0_sample(self.h, hps, n_obs_min, x_start, x_stride, max_seconds, C.byref(sec))
+        return int(nt), sec.value
+
     def learn(self, max_k=3, alpha=0.01, hps=5, n_obs_min=-1, max_tests=10_000_000, FDR=True, feed_forward=True,
-              round_size=1, max_targets=0, target_stride=1, max_seconds=0.0, target_offset=0):
+              round_size=1, max_targets=0, target_stride=1, max_seconds=0.0, target_offset=0, nbrs=None):
+        """nbrs = dict(off, idx, stat, pval[, n_tests]): level-0 neighbour lists computed elsewhere (bench.py's
+        cpu_baseline at sizes where a full CPU level-0 pass does not fit the bounded sample)."""
         P = Params(alpha, hps, n_obs_min, max_k, max_tests, int(FDR), int(feed_forward), round_size, max_targets,
                    target_stride, max_seconds, target_offset)
-        g = self.L.fwo_learn(self.h, C.byref(P), None)
+        nb = None
+        if nbrs is not None:
+            o = np.ascontiguousarray(nbrs["off"], dtype=np.int64)
+            i = np.ascontiguousarray(nbrs["idx"], dtype=np.int32)
+            s_ = np.ascontiguousarray(nbrs["stat"], dtype=np.float64)
+            q = np.ascontiguousarray(nbrs["pval"], dtype=np.float64)
+            nb = self.L.fwo_nbrs_from_csr(self.p, _ptr(o), _ptr(i), _ptr(s_), _ptr(q), int(nbrs.get("n_tests", 0)))
+        try:
+            g = self.L.fwo_learn(self.h, C.byref(P), nb)
+        finally:
+            if nb:
+                self.L.fwo_nbrs_free(nb)
         ne = self.L.fwo_network_nedges(g)
         if ne < 0:
             self.L.fwo_network_free(g)

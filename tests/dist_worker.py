@@ -16,9 +16,11 @@ def run_callback_only(rank, world):
     from flashweave_jl_amd.dist import make_allgather
     from flashweave_jl_amd.engine import ALLGATHER_FN
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    cb = ALLGATHER_FN(make_allgather(dist, torch.device("cpu")))
+    stats = {}
+    # capacity 2: rounds with more than two entries on a rank take the grow-and-repeat path
+    cb = ALLGATHER_FN(make_allgather(dist, torch.device("cpu"), capacity=2, stats=stats))
     ok = True
-    for rnd in range(3):
+    for rnd in range(6):
         n = [3, 0, 5][(rank + rnd) % 3]  # ragged, including an empty contribution
         t = np.arange(n, dtype=np.int32) + 100 * rank + 10 * rnd
         u = np.arange(n, dtype=np.int32) + 7
@@ -43,6 +45,8 @@ def run_callback_only(rank, world):
         got_p = [pp[i] for i in range(n_total.value)]
         ok &= all(v in (1e-300, 2e-300) for v in got_p)
         ok &= sum(1 for i in range(n_total.value) if np.isnan(ps[i])) == sum(1 for r in range(world) if [3, 0, 5][(r + rnd) % 3])
+    # one collective per round once the capacity has grown (rounds 0..2 may repeat once)
+    ok &= stats["calls"] == 6 and 6 <= stats["collectives"] <= 8
     dist.barrier()
     dist.destroy_process_group()
     return ok

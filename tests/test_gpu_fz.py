@@ -389,3 +389,18 @@ def test_device_rounds_with_host_side_level0_lists(small, monkeypatch):
         nets.append(eng.lgl(feed_forward=False, round_size=0))
         eng.close()
     assert nets[0]["edges"] == nets[1]["edges"]
+
+
+def test_single_il_first_two_targets_have_no_whitelist():
+    """round_size = 1: the first two targets of the schedule both run with an empty whitelist (interleaved.jl:62,76-86)."""
+    from tests.test_oracle_golden import single_il_first_two_matrix
+    cm = single_il_first_two_matrix()
+    eng = fw.Engine("fz", 200, 6, max_k=3)
+    eng.set_cor_mat(cm)
+    got = eng.lgl(feed_forward=True, round_size=1)
+    exp = O.Oracle("fz", cor_mat=cm, n_obs=200).learn(max_k=3, feed_forward=True, round_size=1)
+    assert got["edges"] == exp["edges"]
+    assert (got["pc_off"] == exp["pc_off"]).all() and (got["pc_idx"] == exp["pc_idx"]).all()
+    assert np.array_equal(np.isnan(got["pc_pval"]), np.isnan(exp["pc_pval"]))
+    assert not np.isnan(got["pc_pval"][got["pc_off"][1]])  # target 1 tested variable 0
+    eng.close()

@@ -213,3 +213,30 @@ def test_fast_division_by_1e5_is_exact():
     L.fwo_check_fast_div1e5.restype = ctypes.c_int64
     L.fwo_check_fast_div1e5.argtypes = [ctypes.c_int64]
     assert L.fwo_check_fast_div1e5(400000) == 0
+
+
+# ---- single_il master: the first TWO targets are enqueued with an empty whitelist (interleaved.jl:62,76-86) -----------
+def single_il_first_two_matrix():
+    """6 variables: {0, 1} a correlated pair (degree 1 each: the first two targets of the schedule, mutual neighbours),
+    {2, 3, 4, 5} a clique (degree 3)."""
+    cm = np.eye(6, dtype=np.float32)
+    cm[0, 1] = cm[1, 0] = 0.6
+    for a in range(2, 6):
+        for b in range(a + 1, 6):
+            cm[a, b] = cm[b, a] = 0.5
+    return cm
+
+
+def test_single_il_first_two_targets_have_no_whitelist():
+    o = O.Oracle("fz", cor_mat=single_il_first_two_matrix(), n_obs=200)
+    r = o.learn(max_k=3, feed_forward=True, round_size=1)
+    assert (0, 1) in r["edges"]
+    # target 1 is the second job of the schedule: it must TEST variable 0 (statistic and p present), not accept it from a
+    # whitelist built from target 0's result (which would leave (NaN, NaN) in its directed result)
+    off, idx, pv = r["pc_off"], r["pc_idx"], r["pc_pval"]
+    for T in (0, 1):
+        assert list(idx[off[T]:off[T + 1]]) == [1 - T]
+        assert not np.isnan(pv[off[T]])
+    # from the third target on the whitelist applies: target 3 accepts 2 untested
+    sl = slice(off[3], off[4])
+    assert np.isnan(pv[sl][list(idx[sl]).index(2)])
