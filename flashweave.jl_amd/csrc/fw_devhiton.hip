@@ -18,6 +18,8 @@
 #include <vector>
 
 #include "fw_internal.h"
+#include "fw_mi_core.h"
+#include "fw_unrank.h"
 
 namespace {
 
@@ -71,6 +73,7 @@ struct DhParams {
     unsigned int busy_jobs;
     int spec_depth;  // elimination-phase look-ahead: candidates tested ahead of the current one per target (0 = off)
     unsigned long long spec_below;  // ... only while the last launch held fewer ranks than this
+    unsigned int mi_seq, mi_win0, mi_chunk_div, mi_chunk_min, mi_chunk_max, mi_help_jobs;  // dh_mi_target_kernel (env knobs)
     int spec0_depth;                // interleaving-phase look-ahead (first windows of the next candidates)
     unsigned long long spec0_below;
     unsigned int spec0_jobs;  // ... and fewer live jobs than this
@@ -332,6 +335,327 @@ __device__ __forceinline__ bool dh_commit(DhTgt &x, const DhArrays &A, int lane,
     else
         ++x.npc;
     return true;
+}
+
+// ---- discrete kinds: persistent wavefronts, one target at a time, big enumerations shared through a board ---------------
+// A discrete (T, candidate) job is a handful of tests (cfg4: 3.3 on average, 786 000 jobs per pass) and a test is a few
+// thousand instructions (fw_mi_core.h), so the level-synchronous rounds above (segment kernel -> step -> plan -> fill,
+// ~550 dependent rounds per chain at cfg4, a 16-rank speculative window per job) cost more than the tests themselves.
+// Here the launch holds as many wavefronts as the GPU keeps resident; each takes the next target of a heaviest-first list
+// (one atomic) and runs its whole HITON-PC: dh_advance / dh_commit are the state machine of the rounds (hiton.jl:109-149,
+// :53-78, :249-256), test_subsets (tests.jl:281-346) runs sequentially in the reference's own order, so a job that stops
+// after a few tests -- nearly all of them -- costs exactly those tests: no window, no speculation, no round trip.
+// A job that survives its first MI_SEQ tests is an enumeration that will probably run to the end (cfg4: one target owns
+// a chain of 90 000 tests).  Its owner publishes the following ranks window by window on a BOARD in device memory: chunk
+// records any wavefront can claim with one atomic.  Wavefronts look at the boards before every job of their own and when
+// they run out of targets, so a big enumeration gets the whole GPU while its owner waits; the owner claims chunks of its
+// own board too, which is why nothing ever waits on a wavefront that is not running.  Chunk results are merged in rank
+// order exactly like segment records (dh_merge): first stop wins, otherwise the (p, rank) maximum with "later wins
+// ties"; a stop found by one chunk cancels the later chunks of the board (stop_min).  num_tests is the reference's count.
+#define MI_SEQ 4u           // tests of a job its owner runs alone before it opens a board
+#define MI_WIN0 32ull       // first board window (ranks); later windows grow x8
+#define MI_BOARD_CAP (1u << 16)
+#define MI_REC_CAP (1u << 20)
+
+// one LDS table [stratum][cell] per wavefront (fw_mi_core.h); module scope so that the called test routine addresses it as LDS
+__shared__ unsigned short dh_mi_tab[4][MI_TAB16];
+
+__shared__ DhTgt dh_mi_x[4];  // the target each wavefront is working on
+
+struct MiBoard {
+    int32_t T, cand, a, chunk;       // chunk = ranks per record
+    long long acc_off;               // accepted list of the job (DhArrays::acc)
+    unsigned long long start, end;   // ranks [start, end) of the window
+    unsigned int nch, res_off;       // records of the window: res[res_off .. res_off + nch)
+    unsigned int next_chunk, done;   // claimed / finished records
+    unsigned long long stop_min;     // smallest stopping rank found so far (FW_RANK_NONE: none)
+    unsigned int ready, pad;
+};
+
+struct MiQueue {
+    unsigned int next_target, targets_done, n_boards, hint, res_top, pad[3];
+};
+
+__device__ __forceinline__ unsigned int mi_ld_u32(const unsigned int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long mi_ld_u64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// lane 0 performs the atomic, every lane gets the value
+__device__ __forceinline__ unsigned int mi_wave_add(unsigned int *p, unsigned int v, int lane)
+{
+    unsigned int r = 0u;
+    if (lane == 0) r = atomicAdd(p, v);
+    return (unsigned int)__builtin_amdgcn_readfirstlane((int)r);
+}
+
+// ranks [r0, r1) of the job (T, cand | subsets of acc[0..a)) in enumeration order, one test after the other (whole wavefront).
+// Called, not inlined: the kernel reaches it from four places (own jobs, own board, other boards while waiting / between
+// jobs / at the end) and four copies of the test made 168 KB of code -- against a 64 KB instruction cache.
+template <int L, int NXY, bool PRE>
+__device__ __noinline__ FwSegOut mi_run_ranks(const MiDev M_in, int T, int cand, const int32_t *__restrict__ acc_in, int a, int max_k,
+                                              long long max_tests, unsigned long long r0, unsigned long long r1,
+                                              const unsigned long long *stop_min_in)
+{
+    unsigned short *tab = dh_mi_tab[threadIdx.x >> 6];
+    const MiDev M = mi_uniform(M_in);
+    T = __builtin_amdgcn_readfirstlane(T);
+    cand = __builtin_amdgcn_readfirstlane(cand);
+    a = __builtin_amdgcn_readfirstlane(a);
+    max_k = __builtin_amdgcn_readfirstlane(max_k);
+    max_tests = (long long)mi_rfl64((unsigned long long)max_tests);
+    r0 = mi_rfl64(r0);
+    r1 = mi_rfl64(r1);
+    const int32_t *acc = (const int32_t *)mi_rfl64((unsigned long long)acc_in);
+    const unsigned long long *stop_min = (const unsigned long long *)mi_rfl64((unsigned long long)stop_min_in);
+    FwSegOut o;
+    o.stop_rank = FW_RANK_NONE;
+    o.stop_stat = o.stop_pval = 0.0;
+    o.best_rank = 0ull;
+    o.best_stat = 0.0;
+    o.best_pval = -3.0;  // "no test": dh_merge ignores it
+    o.stop_df = o.stop_power = o.best_df = o.pad = 0;
+    o.evaluated = 0ull;
+    unsigned long long rem = r0;
+    int s = max_k;
+    while (s > 1 && rem >= fw_binom_u64(a, s)) {
+        rem -= fw_binom_u64(a, s);
+        --s;
+    }
+    int pos[MI_MAX_K];
+#pragma unroll
+    for (int q = 0; q < MI_MAX_K; ++q) pos[q] = 0;
+    fw_unrank_comb(rem, a, s, pos);
+    MiBest mb;
+    mb.p = -3.0;
+    mb.stat = mb.g = 0.0;
+    mb.df = 0;
+    for (unsigned long long r = r0; r < r1; ++r) {
+        if (stop_min && mi_ld_u64(stop_min) < r) break;  // an earlier rank already ended the job
+        MiZs zs;
+#pragma unroll
+        for (int q = 0; q < MI_MAX_K; ++q) zs.v[q] = (q < s) ? acc[pos[q]] : 0;
+        MiRes t = mi_test_core<L, NXY, PRE>(M, T, cand, zs, s, tab);
+        ++o.evaluated;
+        const int ev = mi_account(M, t, max_tests > 0 && r + 1ull >= (unsigned long long)max_tests, mb, false);  // tests.jl:326-341
+        if (ev == 1) {
+            o.stop_rank = r;
+            o.stop_stat = t.stat;
+            o.stop_pval = t.pval;
+            o.stop_df = t.df;
+            o.stop_power = t.power;
+            break;
+        }
+        if (ev == 2) {
+            o.best_pval = mb.p;
+            o.best_stat = mb.stat;
+            o.best_rank = r;
+            o.best_df = mb.df;
+        }
+        int i = s - 1;  // next subset of this size in lexicographic order of the positions, then the next size down
+        while (i >= 0 && pos[i] == a - s + i) --i;
+        if (i < 0) {
+            --s;
+            if (s < 1) break;
+#pragma unroll
+            for (int q = 0; q < MI_MAX_K; ++q) pos[q] = q;
+        } else {
+            ++pos[i];
+            for (int j = i + 1; j < s; ++j) pos[j] = pos[j - 1] + 1;
+        }
+    }
+    return o;
+}
+
+// claim and evaluate one record of board b (if any is left); true if a record was processed
+template <int L, int NXY, bool PRE>
+__device__ __forceinline__ bool mi_board_work(MiBoard *__restrict__ b, FwSegOut *__restrict__ res, const DhArrays &A, const MiDev &M,
+                                              const DhParams &P, int lane)
+{
+    const unsigned int nch = b->nch;
+    if (mi_ld_u32(&b->next_chunk) >= nch) return false;
+    const unsigned int c = mi_wave_add(&b->next_chunk, 1u, lane);
+    if (c >= nch) return false;
+    const unsigned long long r0 = b->start + (unsigned long long)c * (unsigned long long)b->chunk;
+    unsigned long long r1 = r0 + (unsigned long long)b->chunk;
+    if (r1 > b->end) r1 = b->end;
+    FwSegOut o;
+    if (mi_ld_u64(&b->stop_min) < r0) {  // cancelled: an earlier rank stopped the job
+        o.stop_rank = FW_RANK_NONE;
+        o.stop_stat = o.stop_pval = 0.0;
+        o.best_rank = 0ull;
+        o.best_stat = 0.0;
+        o.best_pval = -3.0;
+        o.stop_df = o.stop_power = o.best_df = o.pad = 0;
+        o.evaluated = 0ull;
+    } else {
+        o = mi_run_ranks<L, NXY, PRE>(M, b->T, b->cand, A.acc + b->acc_off, b->a, P.max_k, P.max_tests, r0, r1, &b->stop_min);
+        if (o.stop_rank != FW_RANK_NONE && lane == 0) atomicMin(&b->stop_min, o.stop_rank);
+    }
+    if (lane == 0) {
+        res[b->res_off + c] = o;
+        __threadfence();  // the record before the count
+        atomicAdd(&b->done, 1u);
+    }
+    return true;
+}
+
+// look for an open board and work on one record of it; true if something was done
+template <int L, int NXY, bool PRE>
+__device__ __noinline__ bool mi_help(MiQueue *__restrict__ Q, MiBoard *__restrict__ boards, FwSegOut *__restrict__ res,
+                                        const DhArrays &A, const MiDev &M, const DhParams &P, int lane)
+{
+    unsigned int nb = mi_ld_u32(&Q->n_boards);
+    if (nb > MI_BOARD_CAP) nb = MI_BOARD_CAP;
+    unsigned int i = mi_ld_u32(&Q->hint);
+    for (; i < nb; ++i) {
+        MiBoard *b = boards + i;
+        if (mi_ld_u32(&b->ready) == 0u) return false;  // reserved, not yet filled
+        if (mi_ld_u32(&b->next_chunk) < b->nch) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the owner's accepted list
+            if (mi_board_work<L, NXY, PRE>(b, res, A, M, P, lane)) return true;
+        } else if (i == mi_ld_u32(&Q->hint) && lane == 0) {
+            atomicMax(&Q->hint, i + 1u);  // every record of this board is taken: later scans start behind it
+        }
+    }
+    return false;
+}
+
+template <int L, int NXY, bool PRE>
+__global__ __launch_bounds__(256) void dh_mi_target_kernel(DhTgt *__restrict__ tg, int ntg, const int32_t *__restrict__ order,
+                                                           DhArrays A, MiDev M, DhParams P, MiQueue *__restrict__ Q,
+                                                           MiBoard *__restrict__ boards, FwSegOut *__restrict__ res)
+{
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        const unsigned int slot = mi_wave_add(&Q->next_target, 1u, lane);
+        if (slot >= (unsigned int)ntg) break;
+        const int t = order[slot];
+        // the target's state lives in LDS (one copy per wavefront, every lane stores the same values): kept in registers
+        // it is ~45 VGPRs that stay live across the calls of the test routine
+#ifdef DH_MI_X_LDS
+        DhTgt &x = dh_mi_x[threadIdx.x >> 6];
+        x = tg[t];
+#else
+        DhTgt x = tg[t];
+#endif
+        while (dh_advance(x, A, lane, 1)) {
+            // other targets' big enumerations first: they are the critical path of the pass
+            if (P.mi_help_jobs)
+                while (mi_ld_u32(&Q->n_boards) > mi_ld_u32(&Q->hint) && mi_help<L, NXY, PRE>(Q, boards, res, A, M, P, lane)) {
+                }
+            const int32_t *cands = x.phase == 0 ? A.cand0 + x.cand_off : A.tpc_key + x.co;
+            const int32_t cand = cands[x.pos];
+            const long long acc_off = DH_ACC_OFF(x, x.cur, 1);
+            const int a = x.na;
+            unsigned long long N = 0ull;
+            for (int s = P.max_k; s >= 1; --s) {
+                N += fw_binom_u64(a, s);
+                if (N > (1ull << 62)) N = 1ull << 62;
+            }
+            if (P.max_tests > 0 && (unsigned long long)P.max_tests < N) N = (unsigned long long)P.max_tests;
+            // the first tests: alone
+            unsigned long long next = N < (unsigned long long)P.mi_seq ? N : (unsigned long long)P.mi_seq;
+            FwSegOut o = mi_run_ranks<L, NXY, PRE>(M, x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, 0ull, next, nullptr);
+            unsigned long long ev = o.evaluated, nt = 0ull;
+            bool stopped = o.stop_rank != FW_RANK_NONE;
+            double r_stat = stopped ? o.stop_stat : 0.0, r_p = stopped ? o.stop_pval : 0.0;
+            int r_pow = stopped ? o.stop_power : 1;
+            double best_p = o.best_pval, best_stat = o.best_stat;
+            if (stopped) nt = o.stop_rank + 1ull;
+            unsigned long long width = P.mi_win0;
+            while (!stopped && next < N) {
+                const unsigned long long W = (N - next) < width ? (N - next) : width;
+                unsigned long long chunk = W / (unsigned long long)P.mi_chunk_div;
+                chunk = chunk < P.mi_chunk_min ? P.mi_chunk_min : (chunk > P.mi_chunk_max ? P.mi_chunk_max : chunk);
+                const unsigned int nch = (unsigned int)((W + chunk - 1ull) / chunk);
+                unsigned int bi = MI_BOARD_CAP, ro = MI_REC_CAP;
+                if (mi_ld_u32(&Q->n_boards) < MI_BOARD_CAP && mi_ld_u32(&Q->res_top) + nch <= MI_REC_CAP) {
+                    ro = mi_wave_add(&Q->res_top, nch, lane);
+                    if (ro + nch <= MI_REC_CAP) bi = mi_wave_add(&Q->n_boards, 1u, lane);
+                }
+                DhMerge mg;
+                if (bi >= MI_BOARD_CAP) {  // out of board space (never at the benchmark sizes): the owner carries on alone
+                    const FwSegOut q = mi_run_ranks<L, NXY, PRE>(M, x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, next, next + W, nullptr);
+                    mg.stop = q.stop_rank != FW_RANK_NONE;
+                    mg.stat = mg.stop ? q.stop_stat : q.best_stat;
+                    mg.p = mg.stop ? q.stop_pval : (q.best_pval < 0.0 ? -2.0 : q.best_pval);
+                    mg.pow = q.stop_power;
+                    mg.nt = q.stop_rank + 1ull;
+                    mg.ev = q.evaluated;
+                } else {
+                    MiBoard *b = boards + bi;
+                    if (lane == 0) {
+                        b->T = x.T;
+                        b->cand = cand;
+                        b->a = a;
+                        b->chunk = (int32_t)chunk;
+                        b->acc_off = acc_off;
+                        b->start = next;
+                        b->end = next + W;
+                        b->nch = nch;
+                        b->res_off = ro;
+                        b->next_chunk = 0u;
+                        b->done = 0u;
+                        b->stop_min = FW_RANK_NONE;
+                        __threadfence();  // board and accepted list before the flag
+                        __hip_atomic_store(&b->ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    while (mi_board_work<L, NXY, PRE>(b, res, A, M, P, lane)) {
+                    }
+                    unsigned int spins = 0u;
+                    while (mi_ld_u32(&b->done) < nch) {  // records claimed by other wavefronts: they are running
+                        if (!mi_help<L, NXY, PRE>(Q, boards, res, A, M, P, lane)) {
+                            __builtin_amdgcn_s_sleep(4);
+                            if (++spins > (1u << 27)) {  // ~30 s: a logic error, not a workload -- report instead of hanging the GPU
+                                if (lane == 0) atomicExch(&Q->pad[0], 1u);
+                                break;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    mg = dh_merge(res, (long long)ro, (int)nch, lane);
+                }
+                ev += mg.ev;
+                if (mg.stop) {
+                    stopped = true;
+                    r_stat = mg.stat;
+                    r_p = mg.p;
+                    r_pow = mg.pow;
+                    nt = mg.nt;
+                } else if (mg.p != -2.0 && mg.p >= best_p) {
+                    best_p = mg.p;
+                    best_stat = mg.stat;
+                }
+                next += W;
+                width *= 8ull;
+            }
+            if (!stopped) {  // every subset significant: the maximum-p result (tests.jl:338-345)
+                r_stat = best_stat;
+                r_p = best_p < 0.0 ? 0.0 : best_p;
+                r_pow = 1;
+                nt = N;
+            }
+            x.c_ref += nt;
+            x.c_calls += 1ull;
+            x.c_eval += ev;
+            x.c_alg += dh_alg_bytes(a, ev, P.max_k, P.disc_bytes_per_col);
+            dh_commit(x, A, lane, 1, r_stat, r_p, r_pow, P.alpha);
+        }
+        if (lane == 0) {
+            tg[t] = x;
+            __threadfence();
+            atomicAdd(&Q->targets_done, 1u);
+        }
+    }
+    // no targets left to start: work on boards until every target has finished
+    unsigned int spins = 0u;
+    while (mi_ld_u32(&Q->targets_done) < (unsigned int)ntg && mi_ld_u32(&Q->pad[0]) == 0u) {
+        if (!mi_help<L, NXY, PRE>(Q, boards, res, A, M, P, lane)) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 27)) {
+                if (lane == 0) atomicExch(&Q->pad[0], 2u);
+                break;
+            }
+        }
+    }
 }
 
 // One wavefront per target: the lanes merge the job's segment records in parallel, then run the sequential part
@@ -807,6 +1131,11 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     need += pad(4 * tot + 4) * 3 + pad(4 * 2 * tot * (size_t)d1 + 4) + pad(8 * tot + 8) * 4 + pad(4 * wl.size() + 4);
     need += pad(sizeof(FwSeg) * max_ns) + pad(sizeof(FwSegOut) * max_ns);
     if (!nb_on_dev) need += pad(8 * ((size_t)p + 1)) + pad(4 * nnz + 4) + 2 * pad(8 * nnz + 8);
+    // discrete kinds: persistent wavefronts + boards (dh_mi_target_kernel); FW_MI_ROUNDS=1 keeps the level-synchronous rounds
+    // over the segment kernel (the path of the ABI's fw_test_subsets_batch) for comparison
+    static const bool mi_rounds = [] { const char *e = getenv("FW_MI_ROUNDS"); return e && atoi(e) != 0; }();
+    const bool per_target = c->P.kind != FW_FZ && !mi_rounds;
+    if (per_target) need += pad(sizeof(MiQueue)) + pad(sizeof(MiBoard) * MI_BOARD_CAP) + pad(sizeof(FwSegOut) * MI_REC_CAP);
     int rc;
     if ((rc = fw_dev_reserve(c, c->d_dh[chain], need))) return rc;
     if ((rc = fw_pin_reserve(c, c->h_dh[chain], 4096))) return rc;
@@ -840,6 +1169,9 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     FwSeg *d_segs = (FwSeg *)carve(sizeof(FwSeg) * max_ns);
     FwSegOut *d_so = (FwSegOut *)carve(sizeof(FwSegOut) * max_ns);
     ulonglong2 *d_log = log_path ? (ulonglong2 *)carve(sizeof(ulonglong2) * LOG_CAP) : nullptr;
+    MiQueue *d_mq = per_target ? (MiQueue *)carve(sizeof(MiQueue)) : nullptr;
+    MiBoard *d_boards = per_target ? (MiBoard *)carve(sizeof(MiBoard) * MI_BOARD_CAP) : nullptr;
+    FwSegOut *d_mres = per_target ? (FwSegOut *)carve(sizeof(FwSegOut) * MI_REC_CAP) : nullptr;
     FW_HIP(c, hipMemcpyAsync(d_tg, tg.data(), sizeof(DhTgt) * ntg, hipMemcpyHostToDevice, st));
     hg[0].n_act = (unsigned int)ntg;  // every target starts on the list (the pinned page is the staging copy: stream-ordered)
     FW_HIP(c, hipMemcpyAsync(d_g, hg, sizeof(DhGlobal), hipMemcpyHostToDevice, st));
@@ -896,6 +1228,12 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         P.spec0_depth = spec0_depth;
         P.spec0_below = envu("FW_DH_SPEC0_BELOW", 12000000ull);
         P.spec0_jobs = (unsigned int)envu("FW_DH_SPEC0_JOBS", 512ull);
+        P.mi_seq = (unsigned int)envu("FW_MI_SEQ", 16ull);
+        P.mi_win0 = (unsigned int)envu("FW_MI_WIN0", 128ull);
+        P.mi_chunk_div = (unsigned int)envu("FW_MI_CHUNK_DIV", 256ull);
+        P.mi_chunk_min = (unsigned int)envu("FW_MI_CHUNK_MIN", 8ull);
+        P.mi_chunk_max = (unsigned int)envu("FW_MI_CHUNK_MAX", 64ull);
+        { const char *e = getenv("FW_MI_HELP_JOBS"); P.mi_help_jobs = e ? (unsigned int)atoi(e) : 1u; }
     }
     const bool fz = c->P.kind == FW_FZ;
     P.w0_small = fz ? 256ull : 16ull;
@@ -939,11 +1277,50 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
                            (const long long *)d_seg0, A, d_segs, d1, (const int32_t *)d_act);
     };
     const double th1 = wall();
-    planfill(true);  // nothing to merge yet: creates the first jobs and the first launch (plan #0)
     int rc2 = FW_OK;
     double timed_s = 0.0;
     long timed_n = 0, launches_n = 0;
     std::vector<float> log_ms;  // FW_DH_LOG: segment-kernel time of launch i (planned by plan #i)
+    if (per_target) {
+        std::vector<int32_t> order((size_t)ntg);
+        for (int t = 0; t < ntg; ++t) order[t] = t;
+        std::stable_sort(order.begin(), order.end(), [&](int32_t u, int32_t v) { return tg[u].nc > tg[v].nc; });  // heaviest first
+        FW_HIP(c, hipMemcpyAsync(d_act, order.data(), sizeof(int32_t) * (size_t)ntg, hipMemcpyHostToDevice, st));
+        const MiDev M = fwi_mi_dev(c);
+        // as many workgroups as stay resident (one per CU: the test routine needs ~260 VGPRs, one wavefront per SIMD; cfg4:
+        // 62 ms with one, 71 ms with two requested): the wavefronts fetch targets themselves
+        static const unsigned wg_per_cu = [] { const char *e = getenv("FW_MI_WG_PER_CU"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 1u; }();
+        int n_cu = 256;
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->P.device);
+        const unsigned grid = std::min((unsigned)((ntg + 3) / 4), wg_per_cu * (unsigned)n_cu);
+        FW_HIP(c, hipMemsetAsync(d_mq, 0, sizeof(MiQueue), st));
+        FW_HIP(c, hipMemsetAsync(d_boards, 0, sizeof(MiBoard) * MI_BOARD_CAP, st));  // ready flags
+        FW_HIP(c, hipEventRecord(ev[0][0], st));
+#define DH_MI_LAUNCH(LL, NN, PP)                                                                                                  \
+    hipLaunchKernelGGL((dh_mi_target_kernel<LL, NN, PP>), dim3(grid), dim3(256), 0, st, d_tg, ntg, (const int32_t *)d_act, A, M, P, \
+                       d_mq, d_boards, d_mres)
+        const bool pre = c->P.n <= MI_PRE_N && c->P.max_k <= MI_PRE_K;
+        if (c->L == 2) {
+            if (pre) DH_MI_LAUNCH(2, 2, true); else DH_MI_LAUNCH(2, 2, false);
+        } else if (c->mi_nxy == 2) {
+            if (pre) DH_MI_LAUNCH(3, 2, true); else DH_MI_LAUNCH(3, 2, false);
+        } else {
+            if (pre) DH_MI_LAUNCH(3, 3, true); else DH_MI_LAUNCH(3, 3, false);
+        }
+#undef DH_MI_LAUNCH
+        FW_HIP(c, hipGetLastError());
+        FW_HIP(c, hipEventRecord(ev[0][1], st));
+        FW_HIP(c, hipStreamSynchronize(st));
+        MiQueue hq{};
+        FW_HIP(c, hipMemcpy(&hq, d_mq, sizeof(hq), hipMemcpyDeviceToHost));
+        if (hq.pad[0]) return fw_fail(c, FW_ERR_DEVICE, "discrete HITON kernel: watchdog %u (boards %u, targets done %u of %d)", hq.pad[0], hq.n_boards, hq.targets_done, ntg);
+        if (trace_host) fprintf(stderr, "[fw] boards %u records %u\n", hq.n_boards, hq.res_top);
+        float ms = 0.0f;
+        FW_HIP(c, hipEventElapsedTime(&ms, ev[0][0], ev[0][1]));
+        timed_s = 1e-3 * (double)ms;
+        timed_n = launches_n = 1;
+    } else {
+    planfill(true);  // nothing to merge yet: creates the first jobs and the first launch (plan #0)
     unsigned max_a_seen = 0;  // longest accepted list reported so far (lags by up to two batches)
     auto enqueue_batch = [&](unsigned b) -> int {
         const int q = (int)(b & 1u);
@@ -1009,12 +1386,13 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         }
         if (rc2) (void)hipStreamSynchronize(st);
     }
+    }  // rounds
     static std::mutex cnt_mu;  // concurrent chains share the context's counters
     {
         std::lock_guard<std::mutex> lk(cnt_mu);
         if (timed_n > 0) c->cnt.t_dev_subsets_s += timed_s * (double)launches_n / (double)timed_n;
         c->cnt.subsets_launches += launches_n;
-        c->cnt.kernel_launches += 4 * launches_n;
+        c->cnt.kernel_launches += per_target ? launches_n : 4 * launches_n;
     }
     for (int q = 0; q < 2; ++q) {
         for (hipEvent_t &e : ev[q]) (void)hipEventDestroy(e);
@@ -1055,6 +1433,18 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         out[t].key.assign(pk.begin() + x.co, pk.begin() + x.co + x.npc);
         out[t].stat.assign(ps.begin() + x.co, ps.begin() + x.co + x.npc);
         out[t].pval.assign(pp.begin() + x.co, pp.begin() + x.co + x.npc);
+    }
+    if (trace_host) {  // chain statistics: the longest per-target sequences bound the pass from below
+        unsigned long long mx_ref = 0, mx_calls = 0, tot_ref = 0, tot_calls = 0;
+        int t_ref = -1, t_calls = -1;
+        for (const DhTgt &x : tg) {
+            tot_ref += x.c_ref;
+            tot_calls += x.c_calls;
+            if (x.c_ref > mx_ref) mx_ref = x.c_ref, t_ref = x.T;
+            if (x.c_calls > mx_calls) mx_calls = x.c_calls, t_calls = x.T;
+        }
+        fprintf(stderr, "[fw] chain %d: tests %llu jobs %llu; most tests in one target %llu (T=%d), most jobs in one target %llu (T=%d)\n",
+                chain, tot_ref, tot_calls, mx_ref, t_ref, mx_calls, t_calls);
     }
     if (trace_host)
         fprintf(stderr, "[fw] device rounds chain %d: %d targets, set-up %.2f ms, rounds %.2f ms, results %.2f ms\n", chain, ntg,

@@ -186,13 +186,12 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
             // Device-resident rounds (fw_devhiton.hip; every kind but fz_nz): no host round trip per window.  FW_HOST_HITON=1
             // keeps the host pool below for every kind (it is also what rounds of fewer than 64 targets use: the
             // reference's single_il schedule posts one target per round and would pay the device set-up each time).
-            // Discrete jobs are tiny (a few tests each): the device rounds only pay once thousands of targets keep the
-            // launches busy (cfg4: 191 -> 175 ms; cfg2 with 1000 targets: 30 -> 31 ms, so it stays on the host pool).
+            // Discrete kinds run as one persistent launch (dh_mi_target_kernel): worth it from a few hundred targets on.
             const char *hh = getenv("FW_HOST_HITON");
             const bool host_only = hh && atoi(hh) == 1;
             const bool no_power = c->P.kind == FW_FZ && c->P.n < c->n_obs_min_eff;  // no device work at all
             const char *mt = getenv("FW_DEV_MIN_TARGETS");  // test knob
-            const size_t min_targets = mt ? (size_t)atol(mt) : (c->P.kind == FW_FZ ? 64 : 4096);
+            const size_t min_targets = mt ? (size_t)atol(mt) : (c->P.kind == FW_FZ ? 64 : 256);  // cfg2 (1000 targets): 19 ms on the device, 28 ms through the host pool
             const bool use_dev = !host_only && c->P.kind != FW_FZ_NZ && !no_power && n_my >= min_targets;
             const bool dev_cands = use_dev && c->d_cand != nullptr;  // candidate order already built on the device (fw_bh.hip)
             if (!dev_cands)
@@ -254,7 +253,10 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                     static const int dh_chains = [] { const char *e = getenv("FW_DH_CHAINS"); return std::min(std::max(e ? atoi(e) : 2, 1), FW_DH_MAX_CHAINS); }();
                     static const size_t dh_chain_min = [] { const char *e = getenv("FW_DH_CHAIN_MIN"); return e && atol(e) > 0 ? (size_t)atol(e) : (size_t)256; }();
                     static const int dh_chains_disc = [] { const char *e = getenv("FW_DH_CHAINS_DISC"); return std::min(std::max(e ? atoi(e) : 2, 1), FW_DH_MAX_CHAINS); }();  // cfg4: 248.7 / 232.9 / 227.2 / 253.1 ms with 1 / 2 / 3 / 4
-                    const int want = c->P.kind == FW_FZ ? dh_chains : dh_chains_disc;
+                    // discrete kinds run as ONE persistent launch that fills the GPU by itself (dh_mi_target_kernel); concurrent
+                    // chains only apply to their level-synchronous form (FW_MI_ROUNDS=1)
+                    static const bool mi_rounds = [] { const char *e = getenv("FW_MI_ROUNDS"); return e && atoi(e) != 0; }();
+                    const int want = c->P.kind == FW_FZ ? dh_chains : (mi_rounds ? dh_chains_disc : 1);
                     const int K = din.size() >= (size_t)want * dh_chain_min ? want : 1;
                     int rc = FW_OK;
                     if (K == 1) {

@@ -128,6 +128,9 @@ struct fw_ctx {
     // ---- discrete (FW_MI / FW_MI_NZ) ----
     std::vector<int32_t> levels, max_vals;
     int L = 0;                   // maximum(max_vals) + 1
+    double *d_gthr = nullptr;    // [df]: G^2 quantile with ccdf(Chisq(df), .) = alpha (significance without evaluating Q(a, x))
+    int gthr_n = 0;
+    int mi_nxy = 2;              // cells per stratum side of the conditional-test kernels (fw_mi_core.h): 3 only for "mi" on 3-valued data
     int W = 0;                   // 64-bit words per packed column
     uint64_t *d_nzbits = nullptr;  // [p][W] bit i of word w: sample 64w+i has value != 0
     uint64_t *d_hibits = nullptr;  // [p][W] value == 2 (second non-zero level); NULL when L == 2

@@ -10,356 +10,43 @@
 //   nz plane: value != 0;  hi plane: value == 2   (values are 0..2: presence/absence, or 0 + two non-zero bins).
 // Information-theoretic width: 1 bit (mi) / 2 bits (mi_nz) per value -- the (k+2)*n*b/8 algorithmic bytes of SURVEY 8d.
 //
-// A conditional test is ONE WAVEFRONT: the k+2 column words are wave-uniform loads, lane l bins sample 64w+l into a
-// per-wave LDS table (cell = x + L*y + L^2*key) with ds_add, then lanes <-> strata compute marginals, MI terms
-// (fp64 log), df, and a wave reduction yields G2 / p.  Level 0 (all pairs) is a tiled AND+popcount kernel.
+// A conditional test is ONE WAVEFRONT (fw_mi_core.h): lanes <-> 32-row words of the bit planes, a table cell is an
+// AND + popcount, a DPP reduction sums the lanes, then lanes <-> (stratum, cell) pairs compute marginals, MI terms (fp64
+// log), df, and a wave reduction yields G2 / p.  Level 0 (all pairs) is a tiled AND+popcount kernel.
 #include "fw_internal.h"
 
 #include <algorithm>
 #include <cmath>
 
-#define MI_MAXCELL 256  // L*L*L^k <= 3*3*27 = 243
-#define MI_MAX_K 3
+#include "fw_mi_core.h"
+#include "fw_unrank.h"
 
-struct MiDev {
-    const unsigned long long *nz;
-    const unsigned long long *hi;  // may be null when L == 2
-    const int32_t *levels;
-    const int32_t *maxv;
-    int W, n, L, nzmode, hps;
-    int dense;  // dense-matrix table rules (contingency.jl:7-56): every row counted, levels_z = distinct Z keys over all rows
-    long long n_obs_min;
-};
-
-// ------------------------------------------------------------------------------------------------
-// special functions: regularised upper incomplete gamma Q(a, x) (series / continued fraction, Cephes structure)
-// stands in for ccdf(Chisq(df), g) = Q(df/2, g/2)  (statfuns.jl:157-161)
-// ------------------------------------------------------------------------------------------------
-__device__ double mi_igamc(double a, double x)
-{
-    if (isnan(a) || isnan(x)) return NAN;
-    if (x <= 0.0 || a <= 0.0) return 1.0;
-    if (isinf(x)) return 0.0;
-    double ax = a * log(x) - x - lgamma(a);
-    if (x < 1.0 || x < a) {
-        if (ax < -745.2) return 1.0;
-        ax = exp(ax);
-        double r = a, c = 1.0, ans = 1.0;
-        do {
-            r += 1.0;
-            c *= x / r;
-            ans += c;
-        } while (c / ans > 1.1102230246251565e-16);
-        return 1.0 - ans * ax / a;
-    }
-    if (ax < -745.2) return 0.0;
-    ax = exp(ax);
-    const double big = 4503599627370496.0, biginv = 2.22044604925031308085e-16;
-    double y = 1.0 - a, z = x + y + 1.0, c = 0.0;
-    double pkm2 = 1.0, qkm2 = x, pkm1 = x + 1.0, qkm1 = z * x;
-    double ans = pkm1 / qkm1, t;
-    do {
-        c += 1.0;
-        y += 1.0;
-        z += 2.0;
-        const double yc = y * c;
-        const double pk = pkm1 * z - pkm2 * yc;
-        const double qk = qkm1 * z - qkm2 * yc;
-        if (qk != 0.0) {
-            const double r = pk / qk;
-            t = fabs((ans - r) / r);
-            ans = r;
-        } else {
-            t = 1.0;
-        }
-        pkm2 = pkm1;
-        pkm1 = pk;
-        qkm2 = qkm1;
-        qkm1 = qk;
-        if (fabs(pk) > big) {
-            pkm2 *= biginv;
-            pkm1 *= biginv;
-            qkm2 *= biginv;
-            qkm1 *= biginv;
-        }
-    } while (t > 1.1102230246251565e-16);
-    return ans * ax;
-}
-
-__device__ __forceinline__ double mi_pval_dev(double mi_abs, int df, long long n_obs)
-{
-    const double g = 2.0 * mi_abs * (double)n_obs;
-    return df > 0 ? mi_igamc(0.5 * (double)df, 0.5 * g) : 1.0;
-}
-
-__device__ __forceinline__ double wave_sum_d(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ long long wave_sum_ll(long long v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ int wave_sum_i(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ int wave_max_i(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int t = __shfl_xor(v, o);
-        v = t > v ? t : v;
-    }
-    return v;
-}
-
-// ------------------------------------------------------------------------------------------------
-// one wavefront = one test (X, Y | zs[0..k-1]); tab = this wave's LDS table (MI_MAXCELL ints)
-// ------------------------------------------------------------------------------------------------
-struct MiRes {
-    double stat, pval;
-    int df, power;
-};
-
-// word held by lane i (wave-uniform i) -> every lane
-__device__ __forceinline__ unsigned long long mi_rl64(unsigned long long v, int i)
-{
-    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, i);
-    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), i);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-__device__ MiRes mi_test_wave(const MiDev &P, int X, int Y, const int *zs, int k, int *tab)
-{
-    const int lane = threadIdx.x & 63;
-    const int L = P.L, L2 = L * L;
-    int nkeys = 1;
-    for (int j = 0; j < k; ++j) nkeys *= L;
-    for (int c = lane; c < MI_MAXCELL; c += 64) tab[c] = 0;
-    const bool flagX = P.nzmode && P.maxv[X] > 1, flagY = P.nzmode && P.maxv[Y] > 1;
-    const bool any_flag = flagX || flagY;
-    const bool special_k1 = (k == 1) && any_flag && !P.dense;  // contingency.jl:250-253 (sparse dispatch only)
-    const int sx = flagX ? 1 : 0, sy = flagY ? 1 : 0;
-    int lx, ly;
-    if (P.nzmode) {  // tests.jl:200-203: levels of the nz-adjusted sub-table
-        lx = L - sx;
-        ly = L - sy;
-    } else {
-        lx = P.levels[X];
-        ly = P.levels[Y];
-    }
-    MiRes res;
-    if (k == 0) {  // tests.jl:36 sufficient_power(X, Y, data, ...) pre-check (tests.jl:9-20)
-        bool ok = (long long)P.n >= P.n_obs_min;
-        if (ok) {
-            const long long vx = P.levels[X], vy = P.levels[Y];
-            const long long ox = vx > 1 ? 2 : 1, oy = vy > 1 ? 2 : 1;
-            ok = ((double)P.n / (double)((vx - ox) * (vy - oy))) > (double)P.hps;
-        }
-        if (!ok) {
-            res.stat = 0.0;
-            res.pval = 1.0;
-            res.df = 0;
-            res.power = 0;
-            return res;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // ---- binning ----
-    const unsigned long long *cx = P.nz + (size_t)X * P.W, *cy = P.nz + (size_t)Y * P.W;
-    const unsigned long long *hx = P.hi ? P.hi + (size_t)X * P.W : nullptr, *hy = P.hi ? P.hi + (size_t)Y * P.W : nullptr;
-    const unsigned long long *cz[MI_MAX_K], *hz[MI_MAX_K];
-#pragma unroll
-    for (int j = 0; j < MI_MAX_K; ++j) {
-        cz[j] = (j < k) ? P.nz + (size_t)zs[j] * P.W : nullptr;
-        hz[j] = (j < k && P.hi) ? P.hi + (size_t)zs[j] * P.W : nullptr;
-    }
-    int my_counted = 0;
-    // Lane l first loads word w0 + l of every column (coalesced, all loads in flight at once); the words are then
-    // handed to the whole wavefront one at a time with v_readlane.  (One dependent round of ~10 global loads per
-    // word was ~1.5 us x 79 words = 120 us per test at cfg4: the kernel was bound by L2 latency, not by anything else.)
-    for (int w0 = 0; w0 < P.W; w0 += 64) {
-      const int wl = w0 + lane;
-      const bool wok = wl < P.W;
-      const unsigned long long rxn = wok ? cx[wl] : 0ull, ryn = wok ? cy[wl] : 0ull;
-      const unsigned long long rxh = (wok && hx) ? hx[wl] : 0ull, ryh = (wok && hy) ? hy[wl] : 0ull;
-      unsigned long long rzn[MI_MAX_K], rzh[MI_MAX_K];
-#pragma unroll
-      for (int j = 0; j < MI_MAX_K; ++j) {
-          rzn[j] = (j < k && wok) ? cz[j][wl] : 0ull;
-          rzh[j] = (j < k && wok && hz[j]) ? hz[j][wl] : 0ull;
-      }
-      const int nw = (P.W - w0) < 64 ? (P.W - w0) : 64;
-      for (int wi = 0; wi < nw; ++wi) {
-        const int w = w0 + wi;
-        const int row = w * 64 + lane;
-        const unsigned long long xn = mi_rl64(rxn, wi), yn = mi_rl64(ryn, wi);
-        const unsigned long long xh = mi_rl64(rxh, wi), yh = mi_rl64(ryh, wi);
-        const int xv = (int)((xn >> lane) & 1ull) + (int)((xh >> lane) & 1ull);
-        const int yv = (int)((yn >> lane) & 1ull) + (int)((yh >> lane) & 1ull);
-        int key = 0, mul = 1, anyz = 0;
-#pragma unroll
-        for (int j = 0; j < MI_MAX_K; ++j)
-            if (j < k) {
-                const unsigned long long zn = mi_rl64(rzn[j], wi);
-                const unsigned long long zh = mi_rl64(rzh[j], wi);
-                const int zv = (int)((zn >> lane) & 1ull) + (int)((zh >> lane) & 1ull);
-                key += zv * mul;  // key = sum_j z_j * L^j (types.jl:32-39 cum_levels)
-                mul *= L;
-                anyz |= zv;
-            }
-        bool counted = row < P.n;
-        if (P.dense)
-            ;  // contingency.jl:42-56: the dense form visits every row; nz_adjust_cont_tab drops row/col 0 afterwards
-        else if (any_flag)
-            counted = counted && (!flagX || xv != 0) && (!flagY || yv != 0);  // rows the merge does not skip
-        else
-            counted = counted && ((xv | yv | anyz) != 0);  // rows the merge visits; the rest is added below
-        if (counted) {
-            atomicAdd(&tab[xv + L * yv + L2 * key], 1);
-            ++my_counted;
-        }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int n_counted = wave_sum_i(my_counted);
-    if (!any_flag && !P.dense) {
-        // contingency.jl:462-476: never-visited (all-zero) rows go to cell (0, 0, stratum of the all-zero key)
-        if (lane == 0) tab[0] += P.n - n_counted;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // ---- lanes <-> strata ----
-    long long nobs_part = 0, npos = 0, nneg = 0;
-    int df_part = 0, nonempty = 0, zmax = 0;
-    long long mk = 0;
-    long long mi_[3] = {0, 0, 0}, mj_[3] = {0, 0, 0};
-    int cell[3][3];
-    bool key0_seen = false;
-    const bool act = lane < nkeys;
-    if (act) {
-        const int *t = tab + L2 * lane;
-        long long stratum_total = 0;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int v = (i < L && j < L) ? t[i + L * j] : 0;
-                cell[i][j] = v;
-                stratum_total += v;
-                if (i >= sx && j >= sy) nobs_part += v;                     // sum(sub_ctab)
-                if (i >= sx && j >= sy && i - sx < lx && j - sy < ly) {    // marginals over 1:levels_x, 1:levels_y
-                    mi_[i] += v;
-                    mj_[j] += v;
-                    mk += v;
-                }
-            }
-        if (stratum_total > 0) {
-            nonempty = 1;
-            zmax = lane;  // k = 1: the key is the Z value itself
-        }
-        int alx = 0, aly = 0;  // statfuns.jl:281-297
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            alx += mi_[i] > 0;
-            aly += mj_[i] > 0;
-        }
-        alx = alx < 1 ? 1 : alx;
-        aly = aly < 1 ? 1 : aly;
-        df_part = (alx - 1) * (aly - 1);
-    }
-    const int n_nonempty = wave_sum_i(nonempty);
-    key0_seen = __shfl(nonempty, 0) != 0;
-    const long long n_obs = wave_sum_ll(nobs_part);
-    // levels_z
-    int levels_z;
-    if (k == 0) {
-        levels_z = 1;
-    } else if (special_k1) {
-        const int zm = wave_max_i(nonempty ? zmax : -1);
-        levels_z = zm < 0 ? 1 : zm + 1;  // contingency.jl:168-176,186,229
-    } else if (any_flag && !P.dense) {
-        // distinct keys among counted rows, +1 if uncounted rows exist and the all-zero key was not among them
-        levels_z = n_nonempty + ((P.n - n_counted > 0 && !key0_seen) ? 1 : 0);
-    } else {
-        levels_z = n_nonempty;  // all rows are in the table (dense rule: level_map! misc.jl:162-184)
-    }
-    // power (tests.jl:58 / :210)
-    bool power;
-    if (k == 0)
-        power = (n_obs >= P.n_obs_min) && (((double)n_obs / (double)((long long)lx * ly)) > (double)P.hps);
-    else
-        power = ((double)n_obs / (double)((long long)lx * ly * levels_z)) > (double)P.hps;
-    if (!power) {
-        res.stat = 0.0;
-        res.pval = 1.0;
-        res.df = 0;
-        res.power = 0;
-        return res;
-    }
-    // ---- mutual information (statfuns.jl:163-254) ----
-    double pos = 0.0, neg = 0.0;
-    if (act) {
-        const double denom_k = (k == 0) ? (double)n_obs : (double)mk;  // 2-D form uses n_obs = sum(ctab)
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const bool inside = i >= sx && j >= sy && i - sx < lx && j - sy < ly;
-                const long long c = cell[i][j];
-                if (inside && c != 0 && mi_[i] != 0 && mj_[j] != 0) {
-                    const double term = log((denom_k * (double)c) / (double)(mi_[i] * mj_[j])) * (double)c;
-                    if (i - sx == j - sy) {
-                        pos += term;
-                        npos += c;
-                    } else {
-                        neg += term;
-                        nneg += c;
-                    }
-                }
-            }
-    }
-    pos = wave_sum_d(pos);
-    neg = wave_sum_d(neg);
-    npos = wave_sum_ll(npos);
-    nneg = wave_sum_ll(nneg);
-    const int df = wave_sum_i(df_part);
-    const double nd = (k == 0) ? (double)n_obs : (double)(npos + nneg);
-    double mi = (pos + neg) / nd;
-    if (neg * ((double)nneg / nd) > pos * ((double)npos / nd)) mi *= -1.0;
-    res.stat = mi;
-    res.pval = mi_pval_dev(fabs(mi), df, n_obs);
-    res.df = df;
-    res.power = 1;
-    return res;
-}
+static MiDev mi_dev(const fw_ctx *ctx);
+static double host_igamc(double a, double x);
 
 // ------------------------------------------------------------------------------------------------
 // batch of single tests: one wave per test
 // ------------------------------------------------------------------------------------------------
+template <int L, int NXY, bool PRE>
 __global__ __launch_bounds__(256) void mi_test_batch_kernel(MiDev P, long long m, const int32_t *__restrict__ X,
                                                             const int32_t *__restrict__ Y,
                                                             const long long *__restrict__ zoff,
                                                             const int32_t *__restrict__ zflat,
                                                             fw_test_result *__restrict__ out)
 {
-    __shared__ int s_tab[4][MI_MAXCELL];
+    __shared__ unsigned short s_tab[4][MI_TAB16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long t = (long long)blockIdx.x * 4 + wave;
     if (t >= m) return;
     const int k = (int)(zoff[t + 1] - zoff[t]);
-    int zs[MI_MAX_K];
-    for (int q = 0; q < MI_MAX_K; ++q) zs[q] = (q < k) ? zflat[zoff[t] + q] : 0;
-    const MiRes r = mi_test_wave(P, X[t], Y[t], zs, k, s_tab[wave]);
+    MiZs zs;
+#pragma unroll
+    for (int q = 0; q < MI_MAX_K; ++q) zs.v[q] = (q < k) ? zflat[zoff[t] + q] : 0;
+    if (P.prof) P.prof += 8 * t;  // one record per test
+    MiRes r = mi_test_core<L, NXY, PRE>(P, X[t], Y[t], zs, k, s_tab[wave]);
+    const unsigned long long pt = P.prof ? __builtin_readcyclecounter() : 0ull;
+    (void)mi_res_pval(r);
+    if (P.prof && lane == 0) P.prof[3] = __builtin_readcyclecounter() - pt;
     if (lane == 0) {
         fw_test_result o;
         o.stat = r.stat;
@@ -373,45 +60,14 @@ __global__ __launch_bounds__(256) void mi_test_batch_kernel(MiDev P, long long m
 // ------------------------------------------------------------------------------------------------
 // test_subsets segments: 4 waves per workgroup, wave w evaluates ranks cbase + w*R .. (run of R consecutive ranks)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long mi_binom(long long m, int t)
-{
-    if (m < t) return 0ull;
-    const unsigned long long u = (unsigned long long)m;
-    switch (t) {
-        case 0: return 1ull;
-        case 1: return u;
-        case 2: return u * (u - 1) / 2ull;
-        default: return (u * (u - 1) / 2ull) * (u - 2) / 3ull;
-    }
-}
-
-__device__ void mi_unrank(unsigned long long rem, int a, int s, int *pos)
-{
-    int prev = -1;
-    for (int d = 0; d < s; ++d) {
-        const int t = s - d;
-        const unsigned long long tot = mi_binom(a - 1 - prev, t);
-        int lo = prev + 1, hi = a - t;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (tot - mi_binom(a - mid, t) <= rem)
-                lo = mid;
-            else
-                hi = mid - 1;
-        }
-        rem -= tot - mi_binom(a - lo, t);
-        pos[d] = lo;
-        prev = lo;
-    }
-}
-
 #define MI_RUN 4
 
+template <int L, int NXY, bool PRE>
 __device__ __forceinline__ void mi_seg_body(const MiDev &P, const FwSeg *__restrict__ segs, const int32_t *__restrict__ accflat,
                                             FwSegOut *__restrict__ out, int max_k, double alpha, long long max_tests,
-                                            const unsigned sidx /* segment this workgroup evaluates */)
+                                            const unsigned sidx /* segment this workgroup evaluates */, int need_p)
 {
-    __shared__ int s_tab[4][MI_MAXCELL];
+    __shared__ unsigned short s_tab[4][MI_TAB16];
     __shared__ unsigned long long s_stop[4], s_br[4];
     __shared__ double s_sstat[4], s_sp[4], s_bp[4], s_bstat[4];
     __shared__ int s_sdf[4], s_spow[4], s_bdf[4];
@@ -422,7 +78,7 @@ __device__ __forceinline__ void mi_seg_body(const MiDev &P, const FwSeg *__restr
     const int32_t *gacc = accflat + seg.acc_off;
     unsigned long long cnt[MI_MAX_K + 1];
 #pragma unroll
-    for (int s = MI_MAX_K; s >= 1; --s) cnt[s] = (s <= max_k) ? mi_binom(a, s) : 0ull;
+    for (int s = MI_MAX_K; s >= 1; --s) cnt[s] = (s <= max_k) ? fw_binom_u64(a, s) : 0ull;
     const unsigned long long NONE = FW_RANK_NONE;
     // running best of the segment (kept redundantly by every thread: values come from LDS broadcasts)
     double best_p = -1.0, best_stat = 0.0;
@@ -445,16 +101,22 @@ __device__ __forceinline__ void mi_seg_body(const MiDev &P, const FwSeg *__restr
                 rem -= cnt[s];
                 --s;
             }
-            int pos[MI_MAX_K] = {0, 0, 0};
-            mi_unrank(rem, a, s, pos);
-            for (unsigned long long r = r0; r < r1; ++r) {
-                int zs[MI_MAX_K];
+            int pos[MI_MAX_K];
 #pragma unroll
-                for (int q = 0; q < MI_MAX_K; ++q) zs[q] = (q < s) ? gacc[pos[q]] : 0;
-                const MiRes t = mi_test_wave(P, seg.X, seg.Y, zs, s, s_tab[wave]);
+            for (int q = 0; q < MI_MAX_K; ++q) pos[q] = 0;
+            fw_unrank_comb(rem, a, s, pos);
+            MiBest mb;
+            mb.p = -3.0;
+            mb.stat = mb.g = 0.0;
+            mb.df = 0;
+            for (unsigned long long r = r0; r < r1; ++r) {
+                MiZs zs;
+#pragma unroll
+                for (int q = 0; q < MI_MAX_K; ++q) zs.v[q] = (q < s) ? gacc[pos[q]] : 0;
+                MiRes t = mi_test_core<L, NXY, PRE>(P, seg.X, seg.Y, zs, s, s_tab[wave]);
                 ++my_done;
-                const bool sig = (t.pval < alpha) && t.power;
-                if (!sig || (max_tests > 0 && r + 1 >= (unsigned long long)max_tests)) {
+                const int ev = mi_account(P, t, max_tests > 0 && r + 1 >= (unsigned long long)max_tests, mb, need_p != 0);
+                if (ev == 1) {
                     my_stop = r;
                     stop_stat = t.stat;
                     stop_p = t.pval;
@@ -462,11 +124,11 @@ __device__ __forceinline__ void mi_seg_body(const MiDev &P, const FwSeg *__restr
                     stop_pow = t.power;
                     break;
                 }
-                if (t.pval >= my_bp) {
-                    my_bp = t.pval;
+                if (ev == 2) {
+                    my_bp = mb.p;
                     my_br = r;
-                    my_bstat = t.stat;
-                    my_bdf = t.df;
+                    my_bstat = mb.stat;
+                    my_bdf = mb.df;
                 }
                 int i = s - 1;
                 while (i >= 0 && pos[i] == a - s + i) --i;
@@ -550,15 +212,16 @@ __device__ __forceinline__ void mi_seg_body(const MiDev &P, const FwSeg *__restr
 
 // Host-driven rounds: one workgroup per segment (ns_dev == nullptr); device-driven rounds (fw_devhiton.hip): a fixed
 // grid covers the device-built segment list whose live length is *ns_dev.
+template <int L, int NXY, bool PRE>
 __global__ __launch_bounds__(256) void mi_subsets_seg_kernel(MiDev P, const FwSeg *__restrict__ segs,
                                                              const int32_t *__restrict__ accflat,
                                                              FwSegOut *__restrict__ out, int max_k, double alpha,
-                                                             long long max_tests, const unsigned *__restrict__ ns_dev)
+                                                             long long max_tests, const unsigned *__restrict__ ns_dev, int need_p)
 {
     // no grid-stride loop here: with the body inside a loop the compiler hoists its invariants and needs 254 VGPRs
     // (occupancy 1 instead of 3); the device-driven grid covers the whole segment list and surplus workgroups leave
     if (ns_dev && blockIdx.x >= *ns_dev) return;
-    mi_seg_body(P, segs, accflat, out, max_k, alpha, max_tests, blockIdx.x);
+    mi_seg_body<L, NXY, PRE>(P, segs, accflat, out, max_k, alpha, max_tests, blockIdx.x, need_p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -900,6 +563,8 @@ __global__ __launch_bounds__(256) void mi_level0_exact_kernel(MiDev P, const MiC
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+MiDev fwi_mi_dev(const fw_ctx *ctx) { return mi_dev(ctx); }
+
 static MiDev mi_dev(const fw_ctx *ctx)
 {
     MiDev P;
@@ -914,6 +579,10 @@ static MiDev mi_dev(const fw_ctx *ctx)
     P.hps = ctx->P.hps;
     P.dense = ctx->P.dense_rules != 0;
     P.n_obs_min = ctx->n_obs_min_eff;
+    P.gthr = ctx->d_gthr;
+    P.gthr_n = ctx->gthr_n;
+    P.alpha = ctx->P.alpha;
+    P.prof = nullptr;
     return P;
 }
 
@@ -921,6 +590,7 @@ int fwi_mi_upload(fw_ctx *ctx, const int64_t *colptr, const int32_t *rowval, con
 {
     const int n = ctx->P.n, p = ctx->P.p;
     if (ctx->P.max_k > MI_MAX_K) return fw_fail(ctx, FW_ERR_LIMIT, "discrete tests support max_k <= %d (got %d)", MI_MAX_K, ctx->P.max_k);
+    if (n > 65535) return fw_fail(ctx, FW_ERR_LIMIT, "discrete tests support at most 65535 samples (16-bit cell counts; got %d)", n);
     const int W = (n + 63) / 64;
     std::vector<uint64_t> nzb((size_t)p * W, 0), hib((size_t)p * W, 0);
     std::vector<int32_t> cnt_nz(p, 0), cnt_hi(p, 0);
@@ -955,6 +625,9 @@ int fwi_mi_upload(fw_ctx *ctx, const int64_t *colptr, const int32_t *rowval, con
     }
     ctx->L = maxv_all + 1;  // types.jl:89,110
     if (ctx->L < 2) ctx->L = 2;
+    // 9-cell tables only where X / Y can take three values inside the sub-table: "mi" on data that holds the value 2
+    // (nz-adjusted tests drop the zero level of such a variable, presence / absence data has two values anyway)
+    ctx->mi_nxy = (ctx->L == 3 && ctx->P.kind == FW_MI) ? 3 : 2;
     ctx->W = W;
     const size_t pb = sizeof(uint64_t) * (size_t)p * W;
     void **ptrs[] = {(void **)&ctx->d_nzbits, (void **)&ctx->d_hibits, (void **)&ctx->d_levels, (void **)&ctx->d_maxvals, (void **)&ctx->d_firstnz};
@@ -983,6 +656,29 @@ int fwi_mi_upload(fw_ctx *ctx, const int64_t *colptr, const int32_t *rowval, con
         ctx->d_xlnx = nullptr;
         FW_HIP(ctx, hipMalloc((void **)&ctx->d_xlnx, tab.size() * sizeof(float)));
         FW_HIP(ctx, hipMemcpy(ctx->d_xlnx, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    {  // alpha quantiles of G^2 per df (mi_issig): df <= (levels - 1)^2 per stratum, L^max_k strata
+        int strata = 1;
+        for (int j = 0; j < ctx->P.max_k; ++j) strata *= ctx->L;
+        const int ndf = (ctx->mi_nxy == 3 ? 4 : 1) * strata + 1;
+        std::vector<double> q((size_t)ndf, 1e300);
+        for (int df = 1; df < ndf; ++df) {
+            double lo = 0.0, hi = 16.0 + 4.0 * df;
+            while (host_igamc(0.5 * df, 0.5 * hi) >= ctx->P.alpha) hi *= 2.0;
+            for (int it = 0; it < 64; ++it) {
+                const double mid = 0.5 * (lo + hi);
+                if (host_igamc(0.5 * df, 0.5 * mid) < ctx->P.alpha)
+                    hi = mid;
+                else
+                    lo = mid;
+            }
+            q[df] = 0.5 * (lo + hi);
+        }
+        if (ctx->d_gthr) (void)hipFree(ctx->d_gthr);
+        ctx->d_gthr = nullptr;
+        FW_HIP(ctx, hipMalloc((void **)&ctx->d_gthr, sizeof(double) * (size_t)ndf));
+        FW_HIP(ctx, hipMemcpy(ctx->d_gthr, q.data(), sizeof(double) * (size_t)ndf, hipMemcpyHostToDevice));
+        ctx->gthr_n = ndf;
     }
     // d_firstnz doubles as storage for the per-column totals [cnt_nz | cnt_hi]
     FW_HIP(ctx, hipMalloc((void **)&ctx->d_firstnz, sizeof(int32_t) * 2 * (size_t)p));
@@ -1136,8 +832,18 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
 int fwi_mi_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, const unsigned *d_ns,
                         hipStream_t stream)
 {
-    hipLaunchKernelGGL(mi_subsets_seg_kernel, dim3(grid), dim3(256), 0, stream, mi_dev(ctx), d_segs, d_acc, d_out, ctx->P.max_k,
-                       ctx->P.alpha, (long long)ctx->P.max_tests, d_ns);
+#define MI_SEG_LAUNCH(LL, NN, PP)                                                                                                  \
+    hipLaunchKernelGGL((mi_subsets_seg_kernel<LL, NN, PP>), dim3(grid), dim3(256), 0, stream, mi_dev(ctx), d_segs, d_acc, d_out, \
+                       ctx->P.max_k, ctx->P.alpha, (long long)ctx->P.max_tests, d_ns, 0 /* HITON-PC never reads a rejected test's p */)
+    const bool pre = ctx->P.n <= MI_PRE_N && ctx->P.max_k <= MI_PRE_K;
+    if (ctx->L == 2) {
+        if (pre) MI_SEG_LAUNCH(2, 2, true); else MI_SEG_LAUNCH(2, 2, false);
+    } else if (ctx->mi_nxy == 2) {
+        if (pre) MI_SEG_LAUNCH(3, 2, true); else MI_SEG_LAUNCH(3, 2, false);
+    } else {
+        if (pre) MI_SEG_LAUNCH(3, 3, true); else MI_SEG_LAUNCH(3, 3, false);
+    }
+#undef MI_SEG_LAUNCH
     FW_HIP(ctx, hipGetLastError());
     return FW_OK;
 }
@@ -1161,11 +867,40 @@ int fwi_mi_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y
     FW_HIP(ctx, hipMemcpyAsync(dY, Y, (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     if (nz > 0)
         FW_HIP(ctx, hipMemcpyAsync(ctx->d_acc.ptr, zflat, (size_t)nz * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(mi_test_batch_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, ctx->stream, mi_dev(ctx), (long long)m,
-                       dX, dY, dz, (const int32_t *)ctx->d_acc.ptr, (fw_test_result *)ctx->d_out.ptr);
+    int kmax = 0;
+    for (int64_t t = 0; t < m; ++t) kmax = std::max<int>(kmax, (int)(zoff[t + 1] - zoff[t]));
+    MiDev Pd = mi_dev(ctx);
+    static const bool prof = getenv("FW_MI_PROF") != nullptr;
+    if (prof) {
+        if ((rc = fw_dev_reserve(ctx, ctx->d_tmp0, (size_t)m * 8 * sizeof(unsigned long long)))) return rc;
+        FW_HIP(ctx, hipMemsetAsync(ctx->d_tmp0.ptr, 0, (size_t)m * 8 * sizeof(unsigned long long), ctx->stream));
+        Pd.prof = (unsigned long long *)ctx->d_tmp0.ptr;
+    }
+#define MI_TB_LAUNCH(LL, NN, PP)                                                                                                         \
+    hipLaunchKernelGGL((mi_test_batch_kernel<LL, NN, PP>), dim3((unsigned)((m + 3) / 4)), dim3(256), 0, ctx->stream, Pd, \
+                       (long long)m, dX, dY, dz, (const int32_t *)ctx->d_acc.ptr, (fw_test_result *)ctx->d_out.ptr)
+    const bool pre = ctx->P.n <= MI_PRE_N && kmax <= MI_PRE_K;  // the batch's own largest conditioning set decides here
+    if (ctx->L == 2) {
+        if (pre) MI_TB_LAUNCH(2, 2, true); else MI_TB_LAUNCH(2, 2, false);
+    } else if (ctx->mi_nxy == 2) {
+        if (pre) MI_TB_LAUNCH(3, 2, true); else MI_TB_LAUNCH(3, 2, false);
+    } else {
+        if (pre) MI_TB_LAUNCH(3, 3, true); else MI_TB_LAUNCH(3, 3, false);
+    }
+#undef MI_TB_LAUNCH
     FW_HIP(ctx, hipGetLastError());
     FW_HIP(ctx, hipMemcpyAsync(out, ctx->d_out.ptr, (size_t)m * sizeof(fw_test_result), hipMemcpyDeviceToHost, ctx->stream));
     FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (prof) {
+        std::vector<unsigned long long> hv((size_t)m * 8);
+        FW_HIP(ctx, hipMemcpy(hv.data(), ctx->d_tmp0.ptr, hv.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int64_t t = 0; t < m; ++t)
+            for (int q = 0; q < 8; ++q) h[q] += hv[(size_t)t * 8 + q];
+        const double nt = (double)std::max<unsigned long long>(h[4], 1), nm = (double)std::max<unsigned long long>(h[5], 1);
+        fprintf(stderr, "[fw] mi test phases, shader cycles per test: counting %.0f, occupancy/power %.0f, MI terms %.0f (of %.0f%% with power), p-value %.0f\n",
+                h[0] / nt, h[1] / nt, h[2] / nm, 100.0 * nm / nt, h[3] / nt);
+    }
     ctx->cnt.kernel_launches += 1;
     return FW_OK;
 }
@@ -1174,8 +909,18 @@ int fwi_mi_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_
 {
     if (nseg == 0) return FW_OK;
     FW_HIP(ctx, hipEventRecord(pb.ev0, pb.launch_stream));
-    hipLaunchKernelGGL(mi_subsets_seg_kernel, dim3((unsigned)nseg), dim3(256), 0, pb.launch_stream, mi_dev(ctx), d_segs, d_acc, d_out,
-                       ctx->P.max_k, ctx->P.alpha, (long long)ctx->P.max_tests, (const unsigned *)nullptr);
+#define MI_SEG_LAUNCH(LL, NN, PP)                                                                                                       \
+    hipLaunchKernelGGL((mi_subsets_seg_kernel<LL, NN, PP>), dim3((unsigned)nseg), dim3(256), 0, pb.launch_stream, mi_dev(ctx), d_segs, \
+                       d_acc, d_out, ctx->P.max_k, ctx->P.alpha, (long long)ctx->P.max_tests, (const unsigned *)nullptr, 1)
+    const bool pre = ctx->P.n <= MI_PRE_N && ctx->P.max_k <= MI_PRE_K;
+    if (ctx->L == 2) {
+        if (pre) MI_SEG_LAUNCH(2, 2, true); else MI_SEG_LAUNCH(2, 2, false);
+    } else if (ctx->mi_nxy == 2) {
+        if (pre) MI_SEG_LAUNCH(3, 2, true); else MI_SEG_LAUNCH(3, 2, false);
+    } else {
+        if (pre) MI_SEG_LAUNCH(3, 3, true); else MI_SEG_LAUNCH(3, 3, false);
+    }
+#undef MI_SEG_LAUNCH
     FW_HIP(ctx, hipGetLastError());
     FW_HIP(ctx, hipEventRecord(pb.ev1, pb.launch_stream));
     return FW_OK;
