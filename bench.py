@@ -258,7 +258,10 @@ def main():
     def step(ff, R):
         if cfg["test_name"] == "fz":
             eng.compute_cor()  # matrix stays resident in HBM
-        eng.level0()
+        if use_dist:
+            eng.level0(rank=rank, world_size=world, allgather=cb)  # discrete kinds: pair tiles sharded, significant pairs all-gathered
+        else:
+            eng.level0()
         return eng.lgl(feed_forward=bool(ff), round_size=R, rank=rank,
                        world_size=max(world, args.simulate_world) if world == 1 else world, allgather=cb,
                        edge_dict=False)  # the network stays in the arrays the C ABI fills (no Python dictionary of tuples)

@@ -81,6 +81,7 @@ void fw_params_default(fw_params *P, int32_t kind, int32_t n, int32_t p)
     P->n_obs_min = -1;
     P->max_tests = 10000000;
     P->alpha = 0.01;
+    P->recursive_pcor = 1;
 }
 
 const char *fw_last_error(const fw_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
@@ -323,7 +324,19 @@ int64_t fw_effective_n_obs_min(const fw_ctx *c) { return c ? c->n_obs_min_eff : 
 
 // ---- level 0 --------------------------------------------------------------------------------------
 // BH (statfuns.jl:326-350) on the p < alpha subset + neighbour lists (tests.jl:372-388).
-int fw_level0(fw_ctx *c, int64_t *nnz_out)
+static int fw_level0_impl(fw_ctx *c, int64_t *nnz_out, int rank, int world, fw_allgather_fn allgather, void *user);
+
+int fw_level0(fw_ctx *c, int64_t *nnz_out) { return fw_level0_impl(c, nnz_out, 0, 1, nullptr, nullptr); }
+
+int fw_level0_sharded(fw_ctx *c, int32_t rank, int32_t world_size, fw_allgather_fn allgather, void *user, int64_t *nnz_out)
+{
+    CHECK_CTX(c);
+    if (world_size < 1 || rank < 0 || rank >= world_size) return fw_fail(c, FW_ERR_ARG, "fw_level0_sharded: rank %d outside world of %d", rank, world_size);
+    if (world_size > 1 && !allgather) return fw_fail(c, FW_ERR_ARG, "fw_level0_sharded: world_size > 1 needs an allgather callback");
+    return fw_level0_impl(c, nnz_out, rank, world_size, allgather, user);
+}
+
+static int fw_level0_impl(fw_ctx *c, int64_t *nnz_out, int rank, int world, fw_allgather_fn allgather, void *user)
 {
     CHECK_CTX(c);
     const double t0 = now_s();
@@ -349,10 +362,79 @@ int fw_level0(fw_ctx *c, int64_t *nnz_out)
     const bool host_bh = hb_env && atoi(hb_env) == 1;
     FwL0Dev dev;
     FwL0Dev *devp = host_bh ? nullptr : &dev;
+    // Target-sharded runs: for the discrete kinds, whose pair screen is the expensive part of level 0
+    // (cfg4: 73 of 140 ms), every rank screens its share of the pair tiles and the significant pairs are all-gathered; the
+    // Fisher-z kinds screen a resident matrix in well under a millisecond per 10^8 pairs and stay replicated.  BH and the
+    // neighbour lists are then built redundantly on every rank from the same merged list (their result does not depend
+    // on the order of the list).
+    const bool sharded = world > 1 && (c->P.kind == FW_MI || c->P.kind == FW_MI_NZ);
+    c->l0_rank = sharded ? rank : 0;
+    c->l0_world = sharded ? world : 1;
     int rc = (c->P.kind == FW_FZ)      ? fwi_fz_level0(c, pi, pj, stat, pval, &m, devp)
              : (c->P.kind == FW_FZ_NZ) ? fwi_fznz_level0(c, pi, pj, stat, pval, &m, devp)
-                                       : fwi_mi_level0(c, pi, pj, stat, pval, &m, devp);
+                                       : fwi_mi_level0(c, pi, pj, stat, pval, &m, sharded ? nullptr : devp);
+    c->l0_rank = 0;
+    c->l0_world = 1;
     if (rc) return rc;
+    if (sharded) {
+        // one extra record carries this rank's count of reliable tests: m = sum_r m_r - (W - 1) * npairs (every rank reports
+        // npairs minus ITS unreliable pairs)
+        pi.push_back(-1);
+        pj.push_back(rank);
+        stat.push_back((double)m);
+        pval.push_back(0.0);
+        int64_t ntot = 0;
+        const int32_t *ai = nullptr, *aj = nullptr;
+        const double *as = nullptr, *ap = nullptr;
+        rc = allgather(user, (int64_t)pi.size(), pi.data(), pj.data(), stat.data(), pval.data(), &ntot, &ai, &aj, &as, &ap);
+        if (rc) return fw_fail(c, FW_ERR_ARG, "fw_level0_sharded: allgather callback failed (%d)", rc);
+        std::vector<int32_t> qi, qj;
+        std::vector<double> qs, qp;
+        qi.reserve((size_t)ntot);
+        qj.reserve((size_t)ntot);
+        qs.reserve((size_t)ntot);
+        qp.reserve((size_t)ntot);
+        const int64_t npairs = (int64_t)p * (p - 1) / 2;
+        int64_t msum = 0;
+        int nrec = 0;
+        for (int64_t t = 0; t < ntot; ++t) {
+            if (ai[t] < 0) {
+                msum += (int64_t)as[t];
+                ++nrec;
+                continue;
+            }
+            qi.push_back(ai[t]);
+            qj.push_back(aj[t]);
+            qs.push_back(as[t]);
+            qp.push_back(ap[t]);
+        }
+        if (nrec != world) return fw_fail(c, FW_ERR_ARG, "fw_level0_sharded: %d of %d ranks reported", nrec, world);
+        m = msum - (int64_t)(world - 1) * npairs;
+        pi.swap(qi);
+        pj.swap(qj);
+        stat.swap(qs);
+        pval.swap(qp);
+        if (!host_bh) {  // back to the device for the BH / neighbour-list epilogue
+            const size_t k = pi.size();
+            if ((rc = fw_dev_reserve(c, c->d_tmp1, (k + 1) * 2 * sizeof(int32_t)))) return rc;
+            if ((rc = fw_dev_reserve(c, c->d_tmp2, (k + 1) * 2 * sizeof(double)))) return rc;
+            int32_t *oi = (int32_t *)c->d_tmp1.ptr, *oj = oi + k;
+            double *os = (double *)c->d_tmp2.ptr, *op = os + k;
+            if (k) {
+                FW_HIP(c, hipMemcpyAsync(oi, pi.data(), k * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+                FW_HIP(c, hipMemcpyAsync(oj, pj.data(), k * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+                FW_HIP(c, hipMemcpyAsync(os, stat.data(), k * sizeof(double), hipMemcpyHostToDevice, c->stream));
+                FW_HIP(c, hipMemcpyAsync(op, pval.data(), k * sizeof(double), hipMemcpyHostToDevice, c->stream));
+                FW_HIP(c, hipStreamSynchronize(c->stream));
+            }
+            dev = FwL0Dev{};
+            dev.i = oi;
+            dev.j = oj;
+            dev.stat64 = os;
+            dev.pval = op;
+            dev.k = k;
+        }
+    }
     if (!host_bh) {
         const double t_bh0 = now_s();
         if ((rc = fwi_bh_csr_device(c, dev, m))) return rc;
@@ -492,6 +574,38 @@ int fw_test_batch(fw_ctx *c, int64_t m, const int32_t *X, const int32_t *Y, cons
         if (!check_var(c, X[t]) || !check_var(c, Y[t])) return fw_fail(c, FW_ERR_ARG, "fw_test_batch: variable index out of range in test %lld", (long long)t);
         for (int64_t q = zoff[t]; q < zoff[t + 1]; ++q)
             if (!check_var(c, zflat[q])) return fw_fail(c, FW_ERR_ARG, "fw_test_batch: conditioning variable out of range in test %lld", (long long)t);
+    }
+    if (c->P.kind == FW_FZ && !c->P.recursive_pcor) {
+        // no cor_mat for conditional tests (tests.jl:253 -> pcor): they stream their sample columns; univariate tests keep
+        // the matrix path (level 0 computes the matrix anyway)
+        if (!c->have_data) return fw_fail(c, FW_ERR_STATE, "fw_test_batch: no data uploaded");
+        if ((int64_t)c->P.n < c->n_obs_min_eff) {
+            for (int64_t t = 0; t < m; ++t) out[t] = fw_test_result{0.0, 1.0, 0, 0};
+            return FW_OK;
+        }
+        std::vector<int64_t> iu, ic;
+        for (int64_t t = 0; t < m; ++t) (zoff[t + 1] == zoff[t] ? iu : ic).push_back(t);
+        for (int part = 0; part < 2; ++part) {
+            const std::vector<int64_t> &ix = part ? ic : iu;
+            if (ix.empty()) continue;
+            if (part == 0 && !c->have_cor)
+                if (int rc = fwi_fz_compute_cor(c)) return rc;
+            std::vector<int32_t> x2(ix.size()), y2(ix.size()), zf;
+            std::vector<int64_t> zo(ix.size() + 1, 0);
+            for (size_t q = 0; q < ix.size(); ++q) {
+                x2[q] = X[ix[q]];
+                y2[q] = Y[ix[q]];
+                zf.insert(zf.end(), zflat + zoff[ix[q]], zflat + zoff[ix[q] + 1]);
+                zo[q + 1] = (int64_t)zf.size();
+            }
+            if (zf.empty()) zf.push_back(0);
+            std::vector<fw_test_result> o2(ix.size());
+            const int rc = part ? fwi_fzs_test_batch(c, (int64_t)ix.size(), x2.data(), y2.data(), zo.data(), zf.data(), o2.data())
+                                : fwi_fz_test_batch(c, (int64_t)ix.size(), x2.data(), y2.data(), zo.data(), zf.data(), o2.data());
+            if (rc) return rc;
+            for (size_t q = 0; q < ix.size(); ++q) out[ix[q]] = o2[q];
+        }
+        return FW_OK;
     }
     if (c->P.kind == FW_FZ) {
         if (!c->have_cor) return fw_fail(c, FW_ERR_STATE, "fw_test_batch: no correlation matrix (fw_compute_cor_mat / fw_set_cor_mat)");
@@ -655,7 +769,8 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
         pool.live.resize(w);
     }
     if (pool.live.empty()) return FW_OK;
-    const bool fz = c->P.kind == FW_FZ || c->P.kind == FW_FZ_NZ;
+    const bool stream = c->P.kind == FW_FZ && !c->P.recursive_pcor;  // one wavefront per test on the sample columns (fw_fzs.hip)
+    const bool fz = (c->P.kind == FW_FZ || c->P.kind == FW_FZ_NZ) && !stream;  // one lane per test on a correlation matrix
     const bool nzs = c->P.kind == FW_FZ_NZ;
     if (c->P.kind == FW_FZ && c->P.n < c->n_obs_min_eff) {  // no device work: fwi_pool_collect fills the results
         pool.inflight = true;
@@ -776,7 +891,8 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
         if (rc) return rc;
         rc = fwi_fznz_segments(c, (int64_t)ns, (int64_t)ns_tab, dsegs, dacc, dout, pb);
     } else {
-        rc = fz ? fwi_fz_segments(c, (int64_t)ns, (int64_t)ns_tab, dsegs, dacc, dout, pb)
+        rc = stream ? fwi_fzs_segments(c, (int64_t)ns, dsegs, dacc, dout, pb)
+             : fz   ? fwi_fz_segments(c, (int64_t)ns, (int64_t)ns_tab, dsegs, dacc, dout, pb)
                 : fwi_mi_segments(c, (int64_t)ns, dsegs, dacc, dout, pb);
     }
     if (rc) return rc;
@@ -929,7 +1045,9 @@ double fwi_alg_bytes(const fw_ctx *c, int a, int64_t evaluated)
     for (int s = c->P.max_k; s >= 1 && left > 0; --s) {
         const double cnt = std::min(left, binom_d(a, s));
         double per;
-        if (c->P.kind == FW_FZ || c->P.kind == FW_FZ_NZ)  // gather variant (fz_nz: on the job-local matrix)
+        if (c->P.kind == FW_FZ && !c->P.recursive_pcor)  // streaming variant: k + 2 sample columns per test (B_fzS)
+            per = (double)(s + 2) * (double)c->P.n * 4.0 + 32.0;
+        else if (c->P.kind == FW_FZ || c->P.kind == FW_FZ_NZ)  // gather variant (fz_nz: on the job-local matrix)
             per = 4.0 * (double)((s + 2) * (s + 1) / 2) + 32.0;
         else
             per = (double)(s + 2) * (double)c->P.n * (c->P.kind == FW_MI ? 1.0 : 2.0) / 8.0 + 32.0;

@@ -216,7 +216,13 @@ __device__ __noinline__ double fz_pval_slow(double r, double zscale)
 {
     double z = (zscale > 0.0) ? zscale * log((1.0 + r) / (1.0 - r)) : 0.0;
     double cc = erfc(fabs(z) * 0.7071067811865476) / 2.0;
-    return cc * 2.0;
+    // p-values in the subnormal range (< 2.2e-308, |r| > 0.68 at n = 2000) are flushed to zero.  There erfc implementations
+    // differ in the last unit of the subnormal grid (device library vs glibc vs Julia's openlibm: 0 vs 9.9e-324 observed),
+    // and since candidates are ordered by p (hiton.jl:212-215) such a difference reorders the conditioning sets of a target.
+    // With the flush the order among them is the reference's rule for EQUAL p-values (stable: ascending variable index) --
+    // a tie-break the reference leaves to the bits of its libm; the oracle does the same (fwo_fz_pval).
+    const double p = cc * 2.0;
+    return p < 2.2250738585072014e-308 ? 0.0 : p;
 }
 // x-key of the max-p tracking: |z| / sqrt2 (see FZ_X_SUB)
 __device__ __noinline__ double fz_xkey_slow(double r, double zscale)
@@ -229,7 +235,8 @@ __device__ __forceinline__ double fz_pval_dev(double r, double zscale /* sqrt(n-
     // statfuns.jl:3-17; ccdf(Normal(), x) = erfc(x / sqrt2) / 2 (StatsFuns.normccdf)
     double z = (zscale > 0.0) ? zscale * log((1.0 + r) / (1.0 - r)) : 0.0;
     double cc = erfc(fabs(z) * 0.7071067811865476) / 2.0;
-    return cc * 2.0;
+    const double p = cc * 2.0;
+    return p < 2.2250738585072014e-308 ? 0.0 : p;  // subnormal p-values flushed: see fz_pval_slow
 }
 
 // round(x, digits = 5) = rint(x * 1e5) / 1e5 in the value's own type.  The division of the integer n = rint(x * 1e5)

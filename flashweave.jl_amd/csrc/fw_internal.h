@@ -128,6 +128,7 @@ struct fw_ctx {
     // ---- discrete (FW_MI / FW_MI_NZ) ----
     std::vector<int32_t> levels, max_vals;
     int L = 0;                   // maximum(max_vals) + 1
+    int l0_rank = 0, l0_world = 1;  // fw_level0_sharded: this rank's share of the level-0 pair tiles (discrete kinds)
     double *d_gthr = nullptr;    // [df]: G^2 quantile with ccdf(Chisq(df), .) = alpha (significance without evaluating Q(a, x))
     int gthr_n = 0;
     int mi_nxy = 2;              // cells per stratum side of the conditional-test kernels (fw_mi_core.h): 3 only for "mi" on 3-valued data
@@ -191,6 +192,11 @@ int fwi_fz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
 int fwi_fz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff,
                       const int32_t *zflat, fw_test_result *out);
 int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb);
+
+// ---- fz without a correlation matrix: streamed sample columns (fw_fzs.hip, fw_params.recursive_pcor = 0) ----
+int fwi_fzs_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff, const int32_t *zflat,
+                       fw_test_result *out);
+int fwi_fzs_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb);
 
 // ---- HE-S / fz_nz (fw_fz.hip) ----
 int fwi_fznz_upload(fw_ctx *ctx, const float *data);

@@ -440,7 +440,8 @@ __global__ __launch_bounds__(256) void mi_level0_kernel(MiDev P, int p, int T, c
                                                         const int32_t *__restrict__ cnt_hi, const double *gthr,
                                                         MiL0Counters *cnt, unsigned long long cap_c, MiCand *__restrict__ cands,
                                                         const float *__restrict__ xlnx, const float *__restrict__ lnx,
-                                                        int dbg /* profiling only: 1 no epilogue, 2 no loads, 4 no popcounts */)
+                                                        int dbg /* profiling only: 1 no epilogue, 2 no loads, 4 no popcounts */,
+                                                        int b_off /* first tile of this launch (rank's share, fw_level0_sharded) */)
 {
     // word-major staging: lanes of a wave read consecutive 8-byte elements of a word row (Y columns are dealt
     // tx + 16 v), X rows are wave broadcasts -> no LDS bank conflicts in the popcount loop
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(256) void mi_level0_kernel(MiDev P, int p, int T, c
     __shared__ int s_qn;
     __shared__ unsigned long long s_qbase;
     // triangular tile decode
-    int b = blockIdx.x, bi = 0;
+    int b = blockIdx.x + b_off, bi = 0;
     while (b >= T - bi) {
         b -= T - bi;
         ++bi;
@@ -754,7 +755,11 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
     }
     int rc;
     const int T = (p + L0_T - 1) / L0_T;
-    const int nblk = T * (T + 1) / 2;
+    const int nblk_all = T * (T + 1) / 2;
+    // target-sharded runs: every rank screens a contiguous range of the linearised upper-triangular tile list (tiles cost
+    // the same: the list is balanced) and the significant pairs are all-gathered afterwards (fw_level0_sharded)
+    const int b_off = (int)((long long)nblk_all * ctx->l0_rank / ctx->l0_world);
+    const int nblk = (int)((long long)nblk_all * (ctx->l0_rank + 1) / ctx->l0_world) - b_off;
     const MiDev P = mi_dev(ctx);
     // ---- kernel 1: popcounts + exact reliability/df + Float32 screen -> candidate records ----
     static const int l0_dbg = getenv("FW_L0_DBG") ? atoi(getenv("FW_L0_DBG")) : 0;  // profiling only (invalid results)
@@ -769,12 +774,14 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
         FW_HIP(ctx, hipMemsetAsync(ctx->d_tmp0.ptr, 0, 2 * sizeof(MiL0Counters), ctx->stream));
         d_gthr = (double *)((char *)ctx->d_tmp0.ptr + 2 * sizeof(MiL0Counters));
         FW_HIP(ctx, hipMemcpyAsync(d_gthr, gthr, sizeof(gthr), hipMemcpyHostToDevice, ctx->stream));
-        if (ctx->d_hibits)
+        if (nblk == 0)
+            ;  // more ranks than tiles: nothing to screen here
+        else if (ctx->d_hibits)
             hipLaunchKernelGGL(mi_level0_kernel<true>, dim3(nblk), dim3(256), 0, ctx->stream, P, p, T, ctx->d_firstnz,
-                               ctx->d_firstnz + p, d_gthr, (MiL0Counters *)ctx->d_tmp0.ptr, cap_c, (MiCand *)ctx->d_jobs.ptr, ctx->d_xlnx, ctx->d_xlnx + (ctx->P.n + 1), l0_dbg);
+                               ctx->d_firstnz + p, d_gthr, (MiL0Counters *)ctx->d_tmp0.ptr, cap_c, (MiCand *)ctx->d_jobs.ptr, ctx->d_xlnx, ctx->d_xlnx + (ctx->P.n + 1), l0_dbg, b_off);
         else
             hipLaunchKernelGGL(mi_level0_kernel<false>, dim3(nblk), dim3(256), 0, ctx->stream, P, p, T, ctx->d_firstnz,
-                               ctx->d_firstnz + p, d_gthr, (MiL0Counters *)ctx->d_tmp0.ptr, cap_c, (MiCand *)ctx->d_jobs.ptr, ctx->d_xlnx, ctx->d_xlnx + (ctx->P.n + 1), l0_dbg);
+                               ctx->d_firstnz + p, d_gthr, (MiL0Counters *)ctx->d_tmp0.ptr, cap_c, (MiCand *)ctx->d_jobs.ptr, ctx->d_xlnx, ctx->d_xlnx + (ctx->P.n + 1), l0_dbg, b_off);
         FW_HIP(ctx, hipGetLastError());
         FW_HIP(ctx, hipMemcpyAsync(&h1, ctx->d_tmp0.ptr, sizeof(h1), hipMemcpyDeviceToHost, ctx->stream));
         FW_HIP(ctx, hipStreamSynchronize(ctx->stream));

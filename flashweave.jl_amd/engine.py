@@ -24,7 +24,8 @@ class FlashWeaveError(RuntimeError):
 class _Params(C.Structure):
     _fields_ = [("kind", C.c_int32), ("n", C.c_int32), ("p", C.c_int32), ("device", C.c_int32),
                 ("max_k", C.c_int32), ("hps", C.c_int32), ("fdr", C.c_int32), ("dense_rules", C.c_int32),
-                ("n_obs_min", C.c_int64), ("max_tests", C.c_int64), ("alpha", C.c_double)]
+                ("n_obs_min", C.c_int64), ("max_tests", C.c_int64), ("alpha", C.c_double),
+                ("recursive_pcor", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class _TestResult(C.Structure):
@@ -93,6 +94,7 @@ def load_library():
     L.fw_get_cor_mat.argtypes = [vp, vp]
     L.fw_level0.argtypes = [vp, C.POINTER(C.c_int64)]
     L.fw_level0_get.argtypes = [vp, vp, vp, vp, vp]
+    L.fw_level0_sharded.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, C.POINTER(C.c_int64)]
     L.fw_test_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
     L.fw_test_subsets_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
     L.fw_learn_network.argtypes = [vp, C.POINTER(_LearnOpts), vp, vp, C.POINTER(C.c_int64)]
@@ -117,7 +119,7 @@ class Engine:
     (src/learning.jl:466-473)."""
 
     def __init__(self, test_name, n, p, max_k=3, alpha=0.01, hps=5, n_obs_min=-1, max_tests=10_000_000, FDR=True,
-                 device=0, dense_rules=False):
+                 device=0, dense_rules=False, recursive_pcor=True):
         self.L = load_library()
         self.test_name = test_name
         self.n, self.p = int(n), int(p)
@@ -125,6 +127,7 @@ class Engine:
         self.L.fw_params_default(C.byref(P), _KINDS[test_name], self.n, self.p)
         P.device, P.max_k, P.alpha, P.hps = device, max_k, alpha, hps
         P.n_obs_min, P.max_tests, P.fdr = n_obs_min, max_tests, int(FDR)
+        P.recursive_pcor = int(bool(recursive_pcor))  # False: conditional fz tests stream the sample columns (no cor_mat, statfuns.jl:19-21)
         P.dense_rules = int(bool(dense_rules))  # Matrix (dense) table methods instead of the SparseMatrixCSC ones
         self.h = C.c_void_p()
         rc = self.L.fw_ctx_create(C.byref(P), C.byref(self.h))
@@ -196,17 +199,30 @@ class Engine:
         return int(self.L.fw_effective_n_obs_min(self.h))
 
     # -- level 0 -------------------------------------------------------------------------------------
-    def level0(self):
-        """Runs level 0 and keeps the neighbour lists in the context (no copy to Python); returns the entry count."""
+    def level0(self, rank=0, world_size=1, allgather=None):
+        """Runs level 0 and keeps the neighbour lists in the context (no copy to Python); returns the entry count.
+        world_size > 1: this rank screens its share of the pair tiles (discrete kinds) and the significant pairs are
+        exchanged through `allgather` (flashweave.jl_amd/dist.py)."""
         nnz = C.c_int64(0)
-        self._ck(self.L.fw_level0(self.h, C.byref(nnz)))
+        if world_size > 1:
+            cb = ALLGATHER_FN(allgather)
+            self._cb0 = cb
+            self._ck(self.L.fw_level0_sharded(self.h, rank, world_size, C.cast(cb, C.c_void_p), None, C.byref(nnz)))
+        else:
+            self._ck(self.L.fw_level0(self.h, C.byref(nnz)))
         return nnz.value
 
     def pw_univar_neighbors(self):
         """pw_univar_neighbors (src/tests.jl:436-532) -> CSR dict(off, idx, stat, pval)."""
         nnz = C.c_int64(0)
         self._ck(self.L.fw_level0(self.h, C.byref(nnz)))
+        return self.pw_univar_neighbors_get()
+
+    def pw_univar_neighbors_get(self):
+        """The neighbour lists of the last level-0 run (fw_level0_get) -> CSR dict(off, idx, stat, pval)."""
         off = np.zeros(self.p + 1, np.int64)
+        self._ck(self.L.fw_level0_get(self.h, _ptr(off), None, None, None))
+        nnz = C.c_int64(int(off[-1]))
         k = max(nnz.value, 1)
         idx, stat, pv = np.zeros(k, np.int32), np.zeros(k, np.float64), np.zeros(k, np.float64)
         self._ck(self.L.fw_level0_get(self.h, _ptr(off), _ptr(idx), _ptr(stat), _ptr(pv)))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 1
+#define FW_ABI_VERSION 2 /* 2: fw_params.recursive_pcor, fw_level0_sharded */
 
 /* test kinds: src/types.jl:61-72 (test_name "mi" / "mi_nz" / "fz") */
 #define FW_MI 0
@@ -65,6 +65,12 @@ typedef struct fw_params {
     int64_t n_obs_min; /* default -1 = automatic (src/learning.jl:51-64, fires for every test kind) */
     int64_t max_tests; /* default 10_000_000 per (T, candidate) pair (src/learning.jl:205) */
     double alpha;      /* default 0.01 */
+    int32_t recursive_pcor; /* FW_FZ only.  1 (default): conditional tests are recursive partial correlations on the resident
+                             * Pearson matrix (pcor_rec, src/statfuns.jl:23-75).  0: no correlation matrix is used for them --
+                             * every test streams its k + 2 sample columns from HBM and computes the partial correlation from
+                             * the data (pcor -> StatsBase.partialcor, src/statfuns.jl:19-21; the FzTestCond with an empty
+                             * cor_mat of src/tests.jl:253, learn_network(recursive_pcor = false)).  Level 0 keeps the matrix. */
+    int32_t reserved1;
 } fw_params;
 
 /* One TestResult (src/types.jl:140-145) */
@@ -150,12 +156,26 @@ int fw_set_cor_mat(fw_ctx *ctx, const float *cor_mat);
 int fw_compute_cor_mat(fw_ctx *ctx);
 int fw_get_cor_mat(const fw_ctx *ctx, float *cor_mat_out); /* p*p floats */
 
+/* Exchange callback for target-sharded runs: called once per feed-forward round with this rank's newly found
+ * directed neighbour entries (target, neighbour, weight-stat, p); must return the concatenation over all ranks
+ * (rank order) through *out_* buffers allocated by the callee and valid until the next call.  NULL for
+ * world_size = 1.  (RCCL all_gather in bench.py; gloo in the CPU tests.) */
+typedef int (*fw_allgather_fn)(void *user, int64_t n_local, const int32_t *tgt, const int32_t *nbr, const double *stat,
+                               const double *pval, int64_t *n_total, const int32_t **tgt_all, const int32_t **nbr_all,
+                               const double **stat_all, const double **pval_all);
+
 /* ---- level 0 ---------------------------------------------------------------------------------- */
 
 /* replaces: pw_univar_neighbors (src/tests.jl:436-532) incl. the power/NaN rules and
  * benjamini_hochberg! (src/statfuns.jl:326-350).  Runs all p(p-1)/2 univariate tests on the device and
  * keeps the neighbour lists in the context.  *nnz_out = total number of (directed) neighbour entries. */
 int fw_level0(fw_ctx *ctx, int64_t *nnz_out);
+/* Same result, for target-sharded runs (one process per GPU): this rank screens only its share of the pair tiles (discrete
+ * kinds; the Fisher-z kinds stay replicated) and the significant pairs are exchanged through the same callback type as the
+ * per-round neighbour sets (fw_allgather_fn above: entries (i, j, stat, p)); Benjamini-Hochberg and the neighbour lists are
+ * then built on every rank from the merged list.  The role of the reference's master process, which runs
+ * pw_univar_neighbors once and ships the result to the workers (src/learning.jl:130-150, src/interleaved.jl:90-93). */
+int fw_level0_sharded(fw_ctx *ctx, int32_t rank, int32_t world_size, fw_allgather_fn allgather, void *user, int64_t *nnz_out);
 /* Neighbour lists as CSR: off[p+1]; idx/stat/adj_p have nnz entries, partners ascending per variable;
  * adj_p is the BH-adjusted p-value when fdr = 1 (src/tests.jl:372-388). */
 int fw_level0_get(const fw_ctx *ctx, int64_t *off, int32_t *idx, double *stat, double *adj_p);
@@ -186,14 +206,6 @@ typedef struct fw_learn_opts {
     int32_t max_targets;   /* > 0: stop after this many targets of the schedule (sampling; 0 = all) */
     int32_t reserved0;
 } fw_learn_opts;
-
-/* Exchange callback for target-sharded runs: called once per feed-forward round with this rank's newly found
- * directed neighbour entries (target, neighbour, weight-stat, p); must return the concatenation over all ranks
- * (rank order) through *out_* buffers allocated by the callee and valid until the next call.  NULL for
- * world_size = 1.  (RCCL all_gather in bench.py; gloo in the CPU tests.) */
-typedef int (*fw_allgather_fn)(void *user, int64_t n_local, const int32_t *tgt, const int32_t *nbr, const double *stat,
-                               const double *pval, int64_t *n_total, const int32_t **tgt_all, const int32_t **nbr_all,
-                               const double **stat_all, const double **pval_all);
 
 /* replaces: LGL minus normalisation (src/learning.jl:203-279): level 0 (if not yet run), target ordering,
  * HITON-PC per target (src/hiton.jl:283-400) in level-synchronous batches over fw_test_subsets_batch,

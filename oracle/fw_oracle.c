@@ -64,6 +64,7 @@ typedef struct fwo_ctx {
     /* fz_nz (HE-S): the normalised matrix itself (clr_nz, zeros = absences), n x p column-major */
     const double *fdata; /* values widened to double (exact) */
     int fdata_f32;       /* 1: the reference's element type is Float32 (prec = 32), 0: Float64 */
+    int fz_stream;       /* "fz" with fdata attached: conditional tests through pcor (StatsBase.partialcor), not pcor_rec */
     /* scratch (one MiTestCond sized for max_k, hiton.jl:192) */
     int max_k;
     int64_t nstrata_cap; /* L^max_k (+1 slack) */
@@ -158,7 +159,11 @@ double fwo_fz_pval(double stat, int64_t n, int64_t len_z)
 {
     double fz = fwo_fisher_z(stat, n, len_z);
     double cc = erfc(fabs(fz) * 0.7071067811865476) / 2.0;
-    return cc * 2.0;
+    /* subnormal p-values are flushed to zero on both sides of the parity check: their last bit depends on the erfc
+     * implementation (glibc / device library / openlibm), and candidates are ordered by p (hiton.jl:212-215); flushed, they
+     * tie and the reference's stable index order applies -- see fz_pval_dev in csrc/fw_fz.hip and DESIGN.md section 2 */
+    double p = cc * 2.0;
+    return p < 2.2250738585072014e-308 ? 0.0 : p;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -945,11 +950,70 @@ static void fz_test_uni(const fwo_ctx *c, int X, int Y, int64_t n_obs_min, fwo_r
     set_result(out, p_stat, pval, 0, n_obs >= n_obs_min);
 }
 
+/* statfuns.jl:19-21 pcor(X, Y, Zs, data) = StatsBase.partialcor(data[:, X], data[:, Y], data[:, collect(Zs)]) -- the path
+ * of tests.jl:253 when the test object holds no cor_mat (recursive_pcor = false / dense_cor = false, learning.jl:127,211).
+ * StatsBase is a registered dependency (Project.toml compat "0.32, 0.33"), not vendored in the reference; its published
+ * algorithm (src/partialcor.jl of those releases), restated:
+ *   _partialcor(x, y, z::Vector): ONE pass of centred sums Sxx, Syy, Szz, Sxy, Sxz, Szy (means first), pairwise
+ *       r = S_ab / sqrt(S_aa S_bb), result (rxy - rxz rzy) / (sqrt(1 - rxz^2) sqrt(1 - rzy^2));
+ *   _partialcor(x, y, Z::Matrix): z0 = first column, Zrest = the others;
+ *       (r(x,y|Zrest) - r(x,z0|Zrest) r(z0,y|Zrest)) / (sqrt(1 - r(x,z0|Zrest)^2) sqrt(1 - r(z0,y|Zrest)^2));
+ *   partialcor = clampcor(_partialcor(...)) (clamped to [-1, 1]).
+ * No 5-digit rounding here (that is pcor_rec's).  The recursion unrolls into: condition the correlation matrix of
+ * {X, Y, Z_1..Z_k} on Z_k, then Z_{k-1}, ..., finally Z_1.  Sums in Float64 (prec = 64 semantics; with Float32 data the
+ * reference accumulates in Float32 under @simd in an unknowable order: tolerance, like `cor`).
+ * Pinned on test/statfuns.jl:24-37 (exp_pcor_Z1 / exp_pcor_Z3, rtol 1e-6). */
+double fwo_pcor(const fwo_ctx *c, int X, int Y, const int *Zs, int k)
+{
+    enum { MAXM = 18 };
+    const int m = k + 2;
+    if (!c->fdata || m > MAXM) return NAN;
+    int v[MAXM];
+    double mu[MAXM], R[MAXM][MAXM];
+    v[0] = X;
+    v[1] = Y;
+    for (int j = 0; j < k; ++j) v[2 + j] = Zs[j];
+    for (int a = 0; a < m; ++a) {
+        double s = 0.0;
+        for (int i = 0; i < c->n; ++i) s += c->fdata[(int64_t)v[a] * c->n + i];
+        mu[a] = s / (double)c->n;
+    }
+    for (int a = 0; a < m; ++a)
+        for (int b = a; b < m; ++b) {
+            double s = 0.0;
+            for (int i = 0; i < c->n; ++i)
+                s += (c->fdata[(int64_t)v[a] * c->n + i] - mu[a]) * (c->fdata[(int64_t)v[b] * c->n + i] - mu[b]);
+            R[a][b] = R[b][a] = s;
+        }
+    double sd[MAXM];
+    for (int a = 0; a < m; ++a) sd[a] = R[a][a];
+    for (int a = 0; a < m; ++a)
+        for (int b = 0; b < m; ++b) R[a][b] = R[a][b] / sqrt(sd[a] * sd[b]);
+    for (int t = m - 1; t >= 2; --t)
+        for (int a = 0; a < t; ++a)
+            for (int b = a + 1; b < t; ++b) {
+                const double r = (R[a][b] - R[a][t] * R[b][t]) / (sqrt(1.0 - R[a][t] * R[a][t]) * sqrt(1.0 - R[b][t] * R[b][t]));
+                R[a][b] = R[b][a] = r;
+            }
+    double r = R[0][1];
+    if (r < -1.0) r = -1.0; /* Statistics.clampcor */
+    if (r > 1.0) r = 1.0;
+    return r;
+}
+
+/* attach the normalised data (n x p column-major, widened to double) to a "fz" context; stream != 0: conditional tests use
+ * pcor instead of pcor_rec (the reference's FzTestCond with an empty cor_mat) */
+void fwo_fz_set_data(fwo_ctx *c, const double *data, int stream)
+{
+    c->fdata = data;
+    c->fz_stream = stream;
+}
+
 /* tests.jl:250-265 */
 static void fz_test_cond(const fwo_ctx *c, int X, int Y, const int *Zs, int k, int64_t n_obs_min, fwo_result *out)
 {
     if (c->n_obs >= n_obs_min) {
-        double p_stat = pcor_rec(c, X, Y, Zs, k).v;
+        double p_stat = c->fz_stream ? fwo_pcor(c, X, Y, Zs, k) : pcor_rec(c, X, Y, Zs, k).v;
         double pval = fwo_fz_pval(p_stat, c->n_obs, 0); /* len_z hard-wired to 0, tests.jl:256 */
         set_result(out, p_stat, pval, 0, 1);
     } else {

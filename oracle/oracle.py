@@ -70,6 +70,9 @@ def lib():
         L.fwo_fz_pval.argtypes = [C.c_double, C.c_int64, C.c_int64]
         L.fwo_pcor_rec.restype = C.c_double
         L.fwo_pcor_rec.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+        L.fwo_pcor.restype = C.c_double
+        L.fwo_pcor.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+        L.fwo_fz_set_data.argtypes = [vp, vp, C.c_int]
         L.fwo_benjamini_hochberg.argtypes = [vp, C.c_int64, C.c_double, C.c_int64]
         L.fwo_level0.restype = vp
         L.fwo_level0.argtypes = [vp, C.c_double, C.c_int, C.c_int64, C.c_int, C.c_int]
@@ -203,6 +206,16 @@ class Oracle:
         r = Result()
         self.L.fwo_test(self.h, X, Y, _ptr(z), len(z), hps, n_obs_min, C.byref(r))
         return (r.stat, r.pval, int(r.df), bool(r.suff_power))
+
+    def set_fz_data(self, data, stream=True):
+        """fz: attach the normalised n x p matrix; stream=True: conditional tests use pcor (no cor_mat, statfuns.jl:19-21)."""
+        d = np.asfortranarray(np.asarray(data, dtype=np.float64))
+        self._keep.append(d)
+        self.L.fwo_fz_set_data(self.h, _ptr(d), int(stream))
+
+    def pcor(self, X, Y, Zs):
+        z = np.asarray(Zs, dtype=np.int32)
+        return float(self.L.fwo_pcor(self.h, X, Y, _ptr(z), len(z)))
 
     def pcor_rec(self, X, Y, Zs):
         z = np.asarray(Zs, dtype=np.int32)

@@ -69,6 +69,16 @@ def run_sharded_gpu(rank, world, out_path):
         eng = fw.Engine(kind, n, p, max_k=3)
         eng.set_data(data)
         cb = make_allgather(dist, torch.device("cpu"))
+        # level 0 with the pair tiles sharded over the ranks (discrete kinds) == the single-rank neighbour lists, bit for bit
+        eng.level0(rank=rank, world_size=world, allgather=cb)
+        nb = eng.pw_univar_neighbors_get()
+        res["%s_l0" % kind] = [nb["off"].tolist(), nb["idx"].tolist(), nb["stat"].tolist(), nb["pval"].tolist()]
+        if rank == 0:
+            single = fw.Engine(kind, n, p, max_k=3)
+            single.set_data(data)
+            nb1 = single.pw_univar_neighbors()
+            res["%s_l0_single" % kind] = [nb1["off"].tolist(), nb1["idx"].tolist(), nb1["stat"].tolist(), nb1["pval"].tolist()]
+            single.close()
         for ff, R in ((0, 0), (1, 32)):
             sh = eng.lgl(feed_forward=bool(ff), round_size=R, rank=rank, world_size=world, allgather=cb)
             res["%s_ff%d" % (kind, ff)] = sorted([a, b, w] for (a, b), w in sh["edges"].items())

@@ -30,7 +30,7 @@ def test_header_symbols_exported(lib):
 
 def test_abi_version_and_defaults(lib):
     from flashweave_jl_amd.engine import _Params
-    assert lib.fw_abi_version() == 1
+    assert lib.fw_abi_version() == 2
     P = _Params()
     lib.fw_params_default(ctypes.byref(P), fw.FW_FZ, 100, 10)
     # learn_network defaults, reference src/learning.jl:466-473

@@ -21,3 +21,6 @@ def test_sharded_equals_single():
             assert r0[k] == r1[k]                 # every rank ends with the full network
             assert r0[k] == r0[k + "_single"]     # and it equals the single-rank network, weights included
             assert len(r0[k]) > 0
+        for kind in ("fz", "mi"):
+            assert r0[kind + "_l0"] == r1[kind + "_l0"] == r0[kind + "_l0_single"]  # sharded level 0: same lists, bit for bit
+            assert len(r0[kind + "_l0"][1]) > 0

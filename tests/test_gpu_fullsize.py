@@ -58,15 +58,11 @@ def test_cfg3_full_size():
         a, b = list(idx[off[T]:off[T + 1]]), list(eidx[eoff[T]:eoff[T + 1]])
         wa, wb = list(w[off[T]:off[T + 1]]), list(ew[eoff[T]:eoff[T + 1]])
         assert sorted(a) == sorted(b)                      # neighbour SETS: always identical
-        if a != b or wa != wb:
-            # Level-0 p-values at the very bottom of the subnormal range (~1e-323) differ by one unit of the subnormal
-            # grid between device and host erfc (e.g. 0 vs 9.9e-324); two candidates with such p-values can then swap
-            # their order, which changes the conditioning order and the weights at the 1e-5 level.
-            ndiff += 1
-            da, db = dict(zip(a, wa)), dict(zip(b, wb))
-            assert all(abs(da[k] - db[k]) < 1e-4 for k in da)
+        # (r01 tolerated a handful of targets here: level-0 p-values in the subnormal range differed by one unit between
+        # device and host erfc and reordered candidates; both sides now flush subnormal p-values to zero)
+        ndiff += (a != b or wa != wb)
         nchk += len(b)
-    assert nchk > 1000 and ndiff <= 6                       # observed: 2 of 6 000 targets
+    assert nchk > 1000 and ndiff == 0
     eng.close()
 
 

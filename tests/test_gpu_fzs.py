@@ -1,0 +1,102 @@
+"""GPU parity of FlashWeave-S WITHOUT a correlation matrix (fw_params.recursive_pcor = 0): conditional tests stream their
+sample columns and compute StatsBase.partialcor's recursion from the data (reference statfuns.jl:19-21, tests.jl:253).
+Checked against the oracle's restatement (pinned on test/statfuns.jl:24-37 in tests/test_oracle_golden.py).
+
+Tolerance: both sides accumulate the centred cross products in Float64, in different orders (64 lane partials + a wave
+reduction vs a sequential loop): partial correlations agree to 1e-11 absolute, p-values to 1e-8 relative."""
+import numpy as np
+import pytest
+
+import flashweave_jl_amd as fw
+from flashweave_jl_amd import preprocess as pre
+from flashweave_jl_amd import synth
+from oracle import oracle as O
+from tests.util import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    counts = synth.generate(300, 260, 31, mode="S")
+    data, _, _ = pre.normalize(counts, "fz", prec=32)
+    data = np.asfortranarray(data)
+    n, p = data.shape
+    eng = fw.Engine("fz", n, p, max_k=3, recursive_pcor=False)
+    eng.set_data(data)
+    cm = eng.cor()
+    orc = O.Oracle("fz", cor_mat=cm, n_obs=n)
+    orc.set_fz_data(data.astype(np.float64))
+    return dict(data=data, n=n, p=p, eng=eng, orc=orc, cm=cm)
+
+
+def test_reference_known_answers_on_gpu():
+    # test/statfuns.jl:24-37: pcor(1, 16, (41,)) and pcor(31, 21, (7, 14, 18)) on the clr-transformed HMP table
+    raw = np.loadtxt(GOLDEN + "/HMP_SRA_gut_small.tsv", delimiter="\t", skiprows=1, usecols=range(1, 51))
+    clr, _, _ = pre.normalize(raw, "fz", prec=64)
+    eng = fw.Engine("fz", clr.shape[0], clr.shape[1], max_k=3, recursive_pcor=False, n_obs_min=0)
+    eng.set_data(clr.astype(np.float32))
+    r1 = eng.test(0, 15, (40,))
+    r3 = eng.test(30, 20, (6, 13, 17))
+    assert abs(r1.stat - (-0.16393307352649356)) < 2e-6   # Float32 input data: the reference's own rtol is 1e-6 on Float64
+    assert abs(r3.stat - (-0.07643814205965811)) < 2e-6
+    eng.close()
+
+
+def test_single_tests_stream(ctx):
+    eng, orc, p = ctx["eng"], ctx["orc"], ctx["p"]
+    rng = np.random.default_rng(5)
+    X, Y, Zs = [], [], []
+    for _ in range(3000):
+        k = int(rng.integers(0, 4))
+        v = rng.choice(p, size=k + 2, replace=False)
+        X.append(int(v[0])); Y.append(int(v[1])); Zs.append(tuple(int(t) for t in v[2:]))
+    got = eng.test_batch(X, Y, Zs)
+    for x, y, z, g in zip(X, Y, Zs, got):
+        s, pv, df, pw = orc.test(x, y, z, n_obs_min=20)
+        assert g.suff_power == pw
+        if len(z) == 0:
+            assert g.stat == s   # univariate tests stay on the (shared) Float32 matrix: bit-exact
+        else:
+            assert abs(g.stat - s) < 1e-11, (x, y, z, g, s)
+            assert abs(g.pval - pv) <= 1e-8 * max(pv, 1e-300) + 1e-300, (x, y, z, g, pv)
+
+
+def test_stream_differs_from_recursive_only_by_rounding(ctx):
+    # pcor (data) vs pcor_rec (Float32 matrix, 5-digit rounding at every level): same quantity, 1e-4 apart at most
+    eng, p, n = ctx["eng"], ctx["p"], ctx["n"]
+    rec = fw.Engine("fz", n, p, max_k=3)
+    rec.set_cor_mat(ctx["cm"])
+    rng = np.random.default_rng(6)
+    X, Y, Zs = [], [], []
+    for _ in range(500):
+        v = rng.choice(p, size=5, replace=False)
+        X.append(int(v[0])); Y.append(int(v[1])); Zs.append(tuple(int(t) for t in v[2:]))
+    a, b = eng.test_batch(X, Y, Zs), rec.test_batch(X, Y, Zs)
+    assert max(abs(u.stat - w.stat) for u, w in zip(a, b)) < 2e-4
+    rec.close()
+
+
+def test_test_subsets_and_network_stream(ctx):
+    eng, orc, p, n = ctx["eng"], ctx["orc"], ctx["p"], ctx["n"]
+    nb = orc.level0(alpha=0.01, n_obs_min=20)
+    T, C, A = [], [], []
+    for t in range(p):
+        nbr = [int(u) for u in nb["idx"][nb["off"][t]:nb["off"][t + 1]]]
+        if len(nbr) >= 3:
+            T.append(t); C.append(nbr[0]); A.append(nbr[1:8])
+    got = eng.test_subsets_batch(T, C, A)
+    nstop = 0
+    for t, c, a, g in zip(T, C, A, got):
+        e = orc.test_subsets(t, c, a, max_k=3, alpha=0.01, n_obs_min=20)
+        assert g["status"] == e["status"] and g["num_tests"] == e["num_tests"] and g["Zs"] == e["Zs"], (t, c, a, g, e)
+        assert abs(g["stat"] - e["stat"]) < 1e-11
+        nstop += e["status"] == 1
+    assert nstop > 0 and len(T) > 20
+    eng.reset_counters()
+    net = eng.lgl(feed_forward=False, round_size=0)
+    exp = orc.learn(max_k=3, feed_forward=False)
+    assert set(net["edges"]) == set(exp["edges"])
+    for e_, w in exp["edges"].items():
+        assert abs(net["edges"][e_] - w) < 1e-11
+    assert eng.counters()["cond_tests_ref"] == exp["n_cond_tests"]

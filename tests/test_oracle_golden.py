@@ -240,3 +240,20 @@ def test_single_il_first_two_targets_have_no_whitelist():
     # from the third target on the whitelist applies: target 3 accepts 2 untested
     sl = slice(off[3], off[4])
     assert np.isnan(pv[sl][list(idx[sl]).index(2)])
+
+
+# ---- test/statfuns.jl:24-37: pcor (StatsBase.partialcor on the data, no cor_mat) -------------------------------------
+def test_pcor_known_answers():
+    from flashweave_jl_amd import preprocess as pre
+    raw = np.loadtxt(GOLDEN + "/HMP_SRA_gut_small.tsv", delimiter="\t", skiprows=1, usecols=range(1, 51))
+    clr, _, _ = pre.normalize(raw, "fz", prec=64)  # preprocess_data_default(data, "fz", prec=64), test/statfuns.jl:25
+    o = O.Oracle("fz", cor_mat=O.cor(clr, "f64"), n_obs=clr.shape[0])
+    o.set_fz_data(clr)
+    assert rel(o.pcor(0, 15, (40,)), -0.16393307352649356) < 1e-6          # pcor(1, 16, (41,), data_clr)
+    assert rel(o.pcor(30, 20, (6, 13, 17)), -0.07643814205965811) < 1e-6   # pcor(31, 21, (7, 14, 18), data_clr)
+    # the same numbers through pcor_rec only to 1e-4 (5-digit rounding), as the reference's own test states
+    assert abs(o.pcor_rec(0, 15, (40,)) - (-0.16393307352649356)) < 1e-4
+    # conditional test through the stream path: p-value with len_z = 0 (tests.jl:256)
+    s_, p_, df, pw = o.test(0, 15, (40,))
+    assert rel(s_, -0.16393307352649356) < 1e-6 and pw
+    assert rel(p_, O.fz_pval(s_, clr.shape[0], 0)) < 1e-12
