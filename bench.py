@@ -69,6 +69,9 @@ def parse_args(argv=None):
     ap.add_argument("--feed-forward", type=int, default=1, help="reference default: true (learning.jl:469)")
     ap.add_argument("--round-size", type=int, default=DEFAULT_ROUND,
                     help="targets per feed-forward round (0 = one round = feed_forward off)")
+    ap.add_argument("--max-targets", type=int, default=0,
+                    help="conditional stage of the first M targets of the schedule only (a bounded SAMPLE of configs whose full "
+                         "conditional stage takes hours, e.g. cfg5; the JSON line says so and is not a whole-network result)")
     ap.add_argument("--no-other-schedule", action="store_true", help="skip the second (other_schedule) measurement")
     ap.add_argument("--host-seam", action="store_true",
                     help="also time the pass with FW_HOST_HITON=1: the host job pool over fw_test_subsets_batch-style "
@@ -133,20 +136,22 @@ def cpu_baseline(args, cfg, data, n, p, eng, level0_per_step):
     orc = mk()
     nom = orc.auto_n_obs_min(-1, 5, max_k)
     budget = args.cpu_seconds
+    nt = args.max_targets or p  # schedule positions the device run covered
+    tstride = max(1, nt // 512)
     # level 0: the full pass when it fits the budget (5e7 pairs at cfg3: a few seconds), else every s-th row
     if level0_per_step <= 100_000_000:
         t1 = time.perf_counter()
         full = orc.level0(alpha=0.01, hps=5, n_obs_min=nom)
         l0_tests, l0_secs = full["n_tests"], time.perf_counter() - t1
         nb = dict(off=full["off"], idx=full["idx"], stat=full["stat"], pval=full["pval"], n_tests=l0_tests)
-        r = orc.learn(max_k=max_k, feed_forward=False, target_stride=max(1, p // 512), max_seconds=budget, nbrs=nb)
+        r = orc.learn(max_k=max_k, feed_forward=False, target_stride=tstride, max_seconds=budget, nbrs=nb, max_targets=args.max_targets)
         l0_note = "full level-0 (%d pair tests, %.2fs)" % (l0_tests, l0_secs)
     else:
         stride = max(1, p // 64)
         l0_tests, l0_secs = orc.level0_sample(hps=5, n_obs_min=nom, x_start=0, x_stride=stride, max_seconds=budget)
         nb = eng.pw_univar_neighbors()  # the conditional stage of the sampled targets needs the neighbour lists: the
         nb["n_tests"] = level0_per_step  # device's (bit-identical to the oracle's, tests/test_gpu_fullsize.py)
-        r = orc.learn(max_k=max_k, feed_forward=False, target_stride=max(1, p // 512), max_seconds=budget, nbrs=nb)
+        r = orc.learn(max_k=max_k, feed_forward=False, target_stride=tstride, max_seconds=budget, nbrs=nb, max_targets=args.max_targets)
         l0_note = "level-0 rows 0, %d, 2*%d, ... against every later column (%d pair tests, %.2fs; neighbour lists for " \
                   "the conditional sample taken from the device run)" % (stride, stride, l0_tests, l0_secs)
     l0_rate = l0_tests / max(l0_secs, 1e-9)
@@ -154,7 +159,7 @@ def cpu_baseline(args, cfg, data, n, p, eng, level0_per_step):
     cpu = {"unit": "tests/s", "cores": 1, "kind": "port",
            "sample": "oracle/fw_oracle.c (C restatement; the Julia reference cannot run here): %s + conditional stage of "
                      "every %d-th target of the schedule (%d targets, %d tests, %.2fs), feed_forward=0" %
-                     (l0_note, max(1, p // 512), r["n_targets"], r["n_cond_tests"], r["t_cond"]),
+                     (l0_note, tstride, r["n_targets"], r["n_cond_tests"], r["t_cond"]),
            "level0_tests_per_s": l0_rate, "cond_tests_per_s": c_rate,
            "value": (l0_tests + r["n_cond_tests"]) / max(l0_secs + r["t_cond"], 1e-9)}
     # the same oracle on every hardware thread: T threads, one oracle context each over the shared read-only inputs,
@@ -163,13 +168,14 @@ def cpu_baseline(args, cfg, data, n, p, eng, level0_per_step):
     # conditional stage is reported for this leg
     T = args.cpu_workers if args.cpu_workers >= 0 else (os.cpu_count() or 1)
     if T > 1:
-        S = max(T, p // 512, 1)
+        S = max(T, tstride, 1)
         outs = [None] * T
         mbudget = max(3.0, budget * 0.6)
 
         def work(w):
             o = mk()
-            outs[w] = o.learn(max_k=max_k, feed_forward=False, target_stride=S, target_offset=w, max_seconds=mbudget, nbrs=nb)
+            outs[w] = o.learn(max_k=max_k, feed_forward=False, target_stride=S, target_offset=w, max_seconds=mbudget, nbrs=nb,
+                              max_targets=args.max_targets)
             o.close()
 
         t2 = time.perf_counter()
@@ -264,7 +270,7 @@ def main():
             eng.level0()
         return eng.lgl(feed_forward=bool(ff), round_size=R, rank=rank,
                        world_size=max(world, args.simulate_world) if world == 1 else world, allgather=cb,
-                       edge_dict=False)  # the network stays in the arrays the C ABI fills (no Python dictionary of tuples)
+                       max_targets=args.max_targets, edge_dict=False)  # the network stays in the arrays the C ABI fills (no Python dictionary of tuples)
 
     def measure(ff, R, steps, warmup):
         """-> dict with the whole-job numbers of `steps` timed passes under schedule (ff, R)."""
@@ -367,6 +373,7 @@ def main():
                "config": {"workload": "%s: fwsynth-v1 %d OTUs x %d samples, %s, max_k=%d, alpha=0.01" %
                                       (args.config, p, n, cfg["test_name"], cfg["max_k"]),
                           "counts_sha256": csum, "feed_forward": ff, "round_size": R if ff else 0,
+                          "sampled_targets": args.max_targets or None,
                           "parallelism": "targets of each round dealt round-robin over %d GPU(s), one rank per GPU, backend %s" %
                                          (world, (dist.get_backend() if use_dist else "none"))},
                "time_to_network_s": dt / steps, "edges": int(len(net["edge_src"])), "rounds": main_m["rounds"],

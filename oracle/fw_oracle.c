@@ -1194,6 +1194,14 @@ void fwo_test(fwo_ctx *c, int X, int Y, const int *Zs, int k, int hps, int64_t n
 }
 
 /* tests.jl:1-3 */
+static double hiton_now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static __thread double fwo_tls_deadline = 0.0; /* set by fwo_learn for bench.py's bounded baseline sample (max_seconds) */
+
 static inline int issig(const fwo_result *r, double alpha) { return r->pval < alpha && r->suff_power; }
 
 /* ------------------------------------------------------------------------------------------
@@ -1275,7 +1283,10 @@ int fwo_test_subsets(fwo_ctx *c, int X, int Y, const int *Z_total, int nZ, int m
             fwo_result r;
             fwo_test(c, X, Y, Zs, s, hps, n_obs_min, &r);
             ++num_tests;
-            if (!issig(&r, alpha) || (max_tests > 0 && num_tests >= max_tests)) { /* :326 */
+            /* baseline sampling only: a single enumeration can hold 10^9 subsets (cfg5); past the sample's deadline it is cut
+             * short like a max_tests stop (its result is not used, only the tests counted so far) */
+            const int timed_out = fwo_tls_deadline > 0.0 && (num_tests & 1023) == 0 && hiton_now_s() > fwo_tls_deadline;
+            if (!issig(&r, alpha) || (max_tests > 0 && num_tests >= max_tests) || timed_out) { /* :326 */
                 for (int rs = s - 1; rs >= 1; --rs) num_tests_total += binom_d(nZ, rs);
                 *out = r;
                 memcpy(Zs_out, Zs, sizeof(int) * (size_t)s);
@@ -1577,6 +1588,7 @@ typedef struct {
     int target_stride; /* > 1 (only with feed_forward = 0): process every stride-th target of the schedule */
     double max_seconds; /* > 0: stop the conditional stage after this many seconds (baseline sampling) */
     int target_offset;  /* first schedule position to process (with target_stride: worker w of W takes w, w + W, ...) */
+    double deadline;    /* internal: absolute time at which the baseline sample stops (0 = none); set by fwo_learn */
 } fwo_params;
 
 typedef struct {
@@ -1601,6 +1613,9 @@ static void hiton_phase(fwo_ctx *c, int T, const int *cands, int ncands, char ph
         for (int i = 0; i < ncands; ++i) iv_push(&acc, cands[i]); /* :124 */
     for (int ci = 0; ci < ncands; ++ci) {
         int cand = cands[ci];
+        /* baseline sampling only (max_seconds): a target with thousands of candidates must not overrun the time budget by
+         * minutes -- the tests counted so far and the time spent still give the rate; results of such a run are not used */
+        if (P->deadline > 0.0 && hiton_now_s() > P->deadline) break;
         if (whitelist && whitelist[cand]) { /* hiton.jl:20-30 */
             iv_push(&acc, cand);
             od_set(accepted_dict, cand, NAN, NAN);
@@ -1803,6 +1818,8 @@ fwo_network *fwo_learn(fwo_ctx *c, const fwo_params *P_in, const fwo_nbrs *nb_in
     int rs = P.round_size > 0 ? P.round_size : 1;
     int nt = (P.max_targets > 0 && P.max_targets < p) ? P.max_targets : p;
     double t1 = now_s();
+    P.deadline = P.max_seconds > 0 ? t1 + P.max_seconds : 0.0;
+    fwo_tls_deadline = P.deadline;
     int stride = (P.target_stride > 1 && !P.feed_forward) ? P.target_stride : 1;
     int n_done = 0;
     const int ti0 = (P.target_offset > 0 && !P.feed_forward) ? P.target_offset : 0;
@@ -1837,6 +1854,7 @@ fwo_network *fwo_learn(fwo_ctx *c, const fwo_params *P_in, const fwo_nbrs *nb_in
     }
     g->t_cond = now_s() - t1;
     g->n_targets_done = n_done;
+    fwo_tls_deadline = 0.0;
 
     /* misc.jl:137-159 make_weights ("cond_stat") -> per-direction weight, stored in PCs[].stat */
     for (int T = 0; T < p; ++T) {

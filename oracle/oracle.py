@@ -23,7 +23,7 @@ class Params(C.Structure):
     _fields_ = [("alpha", C.c_double), ("hps", C.c_int), ("n_obs_min", C.c_int64), ("max_k", C.c_int),
                 ("max_tests", C.c_int64), ("FDR", C.c_int), ("feed_forward", C.c_int),
                 ("round_size", C.c_int), ("max_targets", C.c_int), ("target_stride", C.c_int),
-                ("max_seconds", C.c_double), ("target_offset", C.c_int)]
+                ("max_seconds", C.c_double), ("target_offset", C.c_int), ("deadline", C.c_double)]
 
 
 def build(force=False):
@@ -265,7 +265,7 @@ class Oracle:
         """nbrs = dict(off, idx, stat, pval[, n_tests]): level-0 neighbour lists computed elsewhere (bench.py's
         cpu_baseline at sizes where a full CPU level-0 pass does not fit the bounded sample)."""
         P = Params(alpha, hps, n_obs_min, max_k, max_tests, int(FDR), int(feed_forward), round_size, max_targets,
-                   target_stride, max_seconds, target_offset)
+                   target_stride, max_seconds, target_offset, 0.0)
         nb = None
         if nbrs is not None:
             o = np.ascontiguousarray(nbrs["off"], dtype=np.int64)

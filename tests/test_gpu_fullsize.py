@@ -131,3 +131,124 @@ def test_cfg3_network_independent_of_schedule():
                              capture_output=True, text=True).stdout
         seen.add([ln for ln in out.splitlines() if ln.startswith("HASH")][-1])
     assert len(seen) == 1, seen
+
+
+def test_cfg5_parameters_reduced_p_equals_oracle():
+    """BASELINE configs[4] (cfg5: 10 000 samples, FlashWeave-S, max_k = 5) at a size the oracle finishes in seconds: same seed,
+    sample count and max_k, 200 OTUs.  The deep conditioning (subsets of 4 and 5 variables, the HIGHK variant of the segment
+    kernel) against the oracle: edges, weights to the bit, directed lists and the reference-order test count."""
+    c = synth.CONFIGS["cfg5"]
+    counts = synth.generate(200, c["n"], c["seed"], mode=c["mode"])
+    data, _, _ = pre.normalize(counts, "fz", prec=32)
+    n, p = data.shape
+    eng = fw.Engine("fz", n, p, max_k=c["max_k"])
+    eng.set_data(data)
+    cm = eng.cor()
+    got = eng.lgl(feed_forward=False, round_size=0)
+    orc = O.Oracle("fz", cor_mat=cm, n_obs=n)
+    exp = orc.learn(max_k=c["max_k"], feed_forward=False)
+    assert set(got["edges"]) == set(exp["edges"]) and len(exp["edges"]) > 500
+    for e, w in exp["edges"].items():
+        assert got["edges"][e] == w
+    assert (got["pc_off"] == exp["pc_off"]).all() and (got["pc_idx"] == exp["pc_idx"]).all()
+    assert eng.counters()["cond_tests_ref"] == exp["n_cond_tests"] > 10_000_000
+    eng.close()
+
+
+def test_cfg5_full_size_sample_properties():
+    """cfg5 at FULL size (100 000 OTUs x 10 000 samples; the Pearson matrix is 40 GB of the 288 GB): level 0 over all 5e9 pairs
+    and the conditional stage of the first 20 000 targets of the schedule (a whole pass takes 150 s on one GPU,
+    profiles/r02_bench_cfg5_n1.json -- too long for a test).  Size-independent properties: symmetric bounded matrix that
+    agrees with a Float64 reference on a random sample, idempotent passes, edges are level-0 pairs, and a target-sharded
+    run (rank 0 of 2 and rank 1 of 2 on the same GPU) reproduces the single-rank directed lists."""
+    c = synth.CONFIGS["cfg5"]
+    counts = synth.generate(c["p"], c["n"], c["seed"], mode=c["mode"])
+    data, _, _ = pre.normalize(counts, "fz", prec=32)
+    del counts
+    n, p = data.shape
+    eng = fw.Engine("fz", n, p, max_k=c["max_k"])
+    eng.set_data(data)
+    eng.compute_cor()
+    rng = np.random.default_rng(0)
+    ii, jj = rng.integers(0, p, 300), rng.integers(0, p, 300)
+    X, Y = [int(v) for v in ii], [int(v) for v in jj]
+    pairs = [(x, y) for x, y in zip(X, Y) if x != y]
+    got = eng.test_batch([a for a, _ in pairs], [b for _, b in pairs], [()] * len(pairs))
+    for (x, y), g in zip(pairs, got):
+        dx = data[:, x].astype(np.float64) - data[:, x].astype(np.float64).mean()
+        dy = data[:, y].astype(np.float64) - data[:, y].astype(np.float64).mean()
+        ref = float((dx * dy).sum() / np.sqrt((dx * dx).sum() * (dy * dy).sum()))
+        assert abs(g.stat - ref) <= 5e-6 and abs(g.stat) <= 1.0
+    M = 20000
+    r1 = eng.lgl(feed_forward=False, round_size=0, max_targets=M, edge_dict=False)
+    c1 = eng.counters()["cond_tests_ref"]
+    eng.reset_counters()
+    r2 = eng.lgl(feed_forward=False, round_size=0, max_targets=M, edge_dict=False)
+    for k in ("edge_src", "edge_dst", "edge_weight", "pc_off", "pc_idx", "pc_weight"):
+        assert np.array_equal(r1[k], r2[k], equal_nan=True), k
+    assert eng.counters()["cond_tests_ref"] == c1 > 1_000_000
+    nb = eng.pw_univar_neighbors_get()
+    off, idx = nb["off"], nb["idx"]
+    for a, b in zip(r1["edge_src"][:5000], r1["edge_dst"][:5000]):  # edges are level-0 pairs
+        row = idx[off[a]:off[a + 1]]
+        k = np.searchsorted(row, b)
+        assert k < len(row) and row[k] == b
+
+    # two ranks, no peers: each runs its share of the first M targets; together they reproduce the single-rank lists
+    def echo(user, n_local, tgt, nbr, stat, pval, n_total, tgt_all, nbr_all, stat_all, pval_all):
+        n_total[0] = n_local
+        tgt_all[0], nbr_all[0], stat_all[0], pval_all[0] = tgt, nbr, stat, pval
+        return 0
+    tot = np.zeros(p, np.int64)
+    for rk in (0, 1):
+        rr = eng.lgl(feed_forward=False, round_size=0, max_targets=M, rank=rk, world_size=2, allgather=echo, edge_dict=False)
+        tot += np.diff(rr["pc_off"])
+    assert np.array_equal(tot, np.diff(r1["pc_off"]))
+    eng.close()
+
+
+def test_cfg4_full_size_properties():
+    """BASELINE configs[3] (cfg4: 50 000 OTUs x 5 000 samples + 20 meta variables, FlashWeaveHE-F, max_k = 3) at full size:
+    idempotent passes, edges are level-0 pairs, and the first 4 000 targets of the schedule equal the oracle's directed
+    results (the oracle runs on the device's level-0 neighbour lists: a full CPU level-0 over 1.25e9 pairs takes minutes;
+    the lists themselves are checked against the oracle at 300-1000 variables in tests/test_gpu_mi.py)."""
+    c = synth.CONFIGS["cfg4"]
+    counts, meta = synth.generate(c["p"], c["n"], c["seed"], mode=c["mode"], habitats=c["habitats"], n_meta=c["n_meta"])
+    data, rm, _ = pre.normalize(counts, c["test_name"], prec=32)
+    meta = meta[rm]
+    keep = [j for j in range(meta.shape[1]) if len(np.unique(meta[:, j])) == 2]
+    data = np.ascontiguousarray(np.concatenate([data, meta[:, keep]], axis=1))
+    n, p = data.shape
+    eng = fw.Engine(c["test_name"], n, p, max_k=3)
+    eng.set_data(data)
+    r1 = eng.lgl(feed_forward=False, round_size=0, edge_dict=False)
+    c1 = eng.counters()
+    eng.reset_counters()
+    r2 = eng.lgl(feed_forward=False, round_size=0, edge_dict=False)
+    for k in ("edge_src", "edge_dst", "edge_weight", "pc_off", "pc_idx", "pc_weight", "pc_pval"):
+        assert np.array_equal(r1[k], r2[k], equal_nan=True), k
+    c2 = eng.counters()
+    assert c1["cond_tests_ref"] == c2["cond_tests_ref"] > 1_000_000
+    assert c1["cond_tests_evaluated"] < 1.1 * c1["cond_tests_ref"]  # the persistent kernel does not speculate beyond board windows
+    nb = eng.pw_univar_neighbors_get()
+    off, idx = nb["off"], nb["idx"]
+    for a, b in zip(r1["edge_src"][::20], r1["edge_dst"][::20]):
+        row = idx[off[a]:off[a + 1]]
+        k = np.searchsorted(row, b)
+        assert k < len(row) and row[k] == b
+    M = 4000
+    orc = O.Oracle(c["test_name"], csc=O.dense_to_csc(data), shape=(n, p), sparse=True, max_k=3)
+    nb["n_tests"] = p * (p - 1) // 2
+    exp = orc.learn(max_k=3, feed_forward=False, max_targets=M, nbrs=nb)
+    order = np.argsort(np.diff(off), kind="stable")[:M]
+    poff, pidx, pw = r1["pc_off"], r1["pc_idx"], r1["pc_weight"]
+    eoff, eidx, ew = exp["pc_off"], exp["pc_idx"], exp["pc_weight"]
+    nchk = 0
+    for T in order:
+        a, b = list(pidx[poff[T]:poff[T + 1]]), list(eidx[eoff[T]:eoff[T + 1]])
+        assert a == b, T
+        wa, wb = pw[poff[T]:poff[T + 1]], ew[eoff[T]:eoff[T + 1]]
+        assert np.allclose(wa, wb, rtol=1e-11, atol=1e-15, equal_nan=True)
+        nchk += len(b)
+    assert nchk > 100
+    eng.close()
