@@ -322,6 +322,13 @@ int fw_get_levels(const fw_ctx *c, int32_t *levels, int32_t *max_vals)
 
 int64_t fw_effective_n_obs_min(const fw_ctx *c) { return c ? c->n_obs_min_eff : -1; }
 
+int fw_set_row_views(fw_ctx *c, int32_t on)
+{
+    CHECK_CTX(c);
+    c->mi_view = on ? 1 : 0;
+    return FW_OK;
+}
+
 // ---- level 0 --------------------------------------------------------------------------------------
 // BH (statfuns.jl:326-350) on the p < alpha subset + neighbour lists (tests.jl:372-388).
 static int fw_level0_impl(fw_ctx *c, int64_t *nnz_out, int rank, int world, fw_allgather_fn allgather, void *user);

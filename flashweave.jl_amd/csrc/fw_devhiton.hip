@@ -1286,7 +1286,8 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         for (int t = 0; t < ntg; ++t) order[t] = t;
         std::stable_sort(order.begin(), order.end(), [&](int32_t u, int32_t v) { return tg[u].nc > tg[v].nc; });  // heaviest first
         FW_HIP(c, hipMemcpyAsync(d_act, order.data(), sizeof(int32_t) * (size_t)ntg, hipMemcpyHostToDevice, st));
-        const MiDev M = fwi_mi_dev(c);
+        MiDev M = fwi_mi_dev(c);
+        M.view = M.dense && M.nzmode && c->mi_view;  // HITON-PC under the dense rules tests on row views (hiton.jl:41-50)
         // as many workgroups as stay resident (one per CU: the test routine needs ~260 VGPRs, one wavefront per SIMD; cfg4:
         // 62 ms with one, 71 ms with two requested): the wavefronts fetch targets themselves
         static const unsigned wg_per_cu = [] { const char *e = getenv("FW_MI_WG_PER_CU"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 1u; }();

@@ -136,16 +136,20 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
     opt.world_size = 1;
     if (opts_in) opt = *opts_in;
     if (opt.world_size < 1) opt.world_size = 1;
-    if (c->P.kind == FW_MI_NZ && c->P.dense_rules && c->P.max_k > 0)
-        return fw_fail(c, FW_ERR_ARG,
-                       "fw_learn_network: mi_nz with dense_rules is not supported (the reference tests on per-target row "
-                       "views there, hiton.jl:41-50); use the sparse rules (default)");
     if (opt.rank < 0 || opt.rank >= opt.world_size) return fw_fail(c, FW_ERR_ARG, "fw_learn_network: rank %d outside world of %d", opt.rank, opt.world_size);
     if (opt.world_size > 1 && !allgather) return fw_fail(c, FW_ERR_ARG, "fw_learn_network: world_size > 1 needs an allgather callback");
     if (!c->have_level0) {
         int rc = fw_level0(c, nullptr);
         if (rc) return rc;
     }
+    // dense rules + mi_nz: HITON-PC hands test_subsets a row view of the data (prepare_nzdata, hiton.jl:41-50,85,193); the
+    // kernels apply it as one more AND plane.  Restored on every exit path by the guard.
+    struct ViewGuard {
+        fw_ctx *c;
+        int old;
+        ~ViewGuard() { c->mi_view = old; }
+    } view_guard{c, c->mi_view};
+    c->mi_view = 1;
     const int p = c->P.p;
     const bool discrete = c->P.kind == FW_MI || c->P.kind == FW_MI_NZ;
     const double t0 = now_s();

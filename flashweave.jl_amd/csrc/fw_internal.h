@@ -128,6 +128,7 @@ struct fw_ctx {
     // ---- discrete (FW_MI / FW_MI_NZ) ----
     std::vector<int32_t> levels, max_vals;
     int L = 0;                   // maximum(max_vals) + 1
+    int mi_view = 0;  // dense rules + mi_nz: test_subsets evaluates on the (T, candidate) row view of hiton.jl:41-50 (fw_set_row_views)
     int l0_rank = 0, l0_world = 1;  // fw_level0_sharded: this rank's share of the level-0 pair tiles (discrete kinds)
     double *d_gthr = nullptr;    // [df]: G^2 quantile with ccdf(Chisq(df), .) = alpha (significance without evaluating Q(a, x))
     int gthr_n = 0;

@@ -566,6 +566,14 @@ __global__ __launch_bounds__(256) void mi_level0_exact_kernel(MiDev P, const MiC
 // ------------------------------------------------------------------------------------------------
 MiDev fwi_mi_dev(const fw_ctx *ctx) { return mi_dev(ctx); }
 
+// test_subsets paths (the call edge hiton.jl:100): under the dense rules the reference hands them a row view of the data
+static MiDev mi_dev_subsets(const fw_ctx *ctx)
+{
+    MiDev P = mi_dev(ctx);
+    P.view = P.dense && P.nzmode && ctx->mi_view;
+    return P;
+}
+
 static MiDev mi_dev(const fw_ctx *ctx)
 {
     MiDev P;
@@ -584,6 +592,7 @@ static MiDev mi_dev(const fw_ctx *ctx)
     P.gthr_n = ctx->gthr_n;
     P.alpha = ctx->P.alpha;
     P.prof = nullptr;
+    P.view = 0;
     return P;
 }
 
@@ -840,7 +849,7 @@ int fwi_mi_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const i
                         hipStream_t stream)
 {
 #define MI_SEG_LAUNCH(LL, NN, PP)                                                                                                  \
-    hipLaunchKernelGGL((mi_subsets_seg_kernel<LL, NN, PP>), dim3(grid), dim3(256), 0, stream, mi_dev(ctx), d_segs, d_acc, d_out, \
+    hipLaunchKernelGGL((mi_subsets_seg_kernel<LL, NN, PP>), dim3(grid), dim3(256), 0, stream, mi_dev_subsets(ctx), d_segs, d_acc, d_out, \
                        ctx->P.max_k, ctx->P.alpha, (long long)ctx->P.max_tests, d_ns, 0 /* HITON-PC never reads a rejected test's p */)
     const bool pre = ctx->P.n <= MI_PRE_N && ctx->P.max_k <= MI_PRE_K;
     if (ctx->L == 2) {
@@ -917,7 +926,7 @@ int fwi_mi_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_
     if (nseg == 0) return FW_OK;
     FW_HIP(ctx, hipEventRecord(pb.ev0, pb.launch_stream));
 #define MI_SEG_LAUNCH(LL, NN, PP)                                                                                                       \
-    hipLaunchKernelGGL((mi_subsets_seg_kernel<LL, NN, PP>), dim3((unsigned)nseg), dim3(256), 0, pb.launch_stream, mi_dev(ctx), d_segs, \
+    hipLaunchKernelGGL((mi_subsets_seg_kernel<LL, NN, PP>), dim3((unsigned)nseg), dim3(256), 0, pb.launch_stream, mi_dev_subsets(ctx), d_segs, \
                        d_acc, d_out, ctx->P.max_k, ctx->P.alpha, (long long)ctx->P.max_tests, (const unsigned *)nullptr, 1)
     const bool pre = ctx->P.n <= MI_PRE_N && ctx->P.max_k <= MI_PRE_K;
     if (ctx->L == 2) {

@@ -30,6 +30,8 @@ struct MiDev {
     const int32_t *maxv;
     int W, n, L, nzmode, hps;
     int dense;  // dense-matrix table rules (contingency.jl:7-56): every row counted, levels_z = distinct Z keys over all rows
+    int view;   // dense rules inside HITON-PC: the rows of a (T, candidate) test are those where T / the candidate are non-zero if
+                // they have more than two levels (prepare_nzdata, hiton.jl:41-50,85 -> needs_nz_view, misc.jl:103-107)
     long long n_obs_min;
     const double *gthr;  // [df] -> G^2 with ccdf(Chisq(df), G^2) = alpha (host bisection), df = 0 .. gthr_n - 1; may be null
     int gthr_n;
@@ -199,14 +201,19 @@ static __device__ __forceinline__ void mi_load_words(MiWords<KM> &w, const unsig
 // adds the rows of one word to the cell counters of batch b (strata b * SB .. b * SB + SB - 1)
 template <int L, int NXY, int KM>
 static __device__ __forceinline__ void mi_count_words(const MiWords<KM> &w, unsigned (&acc)[L * L][NXY * NXY + 1], int b, int k, int SB,
-                                                      bool flagX, bool flagY, bool dense, bool tot_sep)
+                                                      bool flagX, bool flagY, bool dense, bool tot_sep, bool viewX, bool viewY)
 {
     constexpr int NC = NXY * NXY;
     constexpr int SBMAX = L * L;
     unsigned msub = w.vm;  // rows of the (nz-adjusted) sub-table
     if (flagX) msub &= w.xn;
     if (flagY) msub &= w.yn;
-    const unsigned mtab = dense ? w.vm : msub;  // rows of the table (stratum occupancy)
+    unsigned mtab = msub;  // rows of the table (stratum occupancy)
+    if (dense) {
+        mtab = w.vm;  // every row of the data handed to the test ...
+        if (viewX) mtab &= w.xn;  // ... which inside HITON-PC is a row view (MiDev::view)
+        if (viewY) mtab &= w.yn;
+    }
     unsigned xs[NXY], ys[NXY];
     if (NXY == 2) {
         const unsigned xu = flagX ? w.xh : w.xn, yu = flagY ? w.yh : w.yn;
@@ -307,6 +314,7 @@ static __device__ __forceinline__ MiRes mi_test_core(const MiDev &P, const int X
     const int SB = k >= 2 ? SBMAX : S;  // strata per batch: the digits of Z_1 and Z_2 vary inside a batch
     const int nbatch = S / SB;
     const bool tot_sep = P.dense && any_flag;  // dense rule: the table holds every row, the sub-table only the non-zero ones
+    const bool viewX = P.dense && P.view && P.nzmode && P.levels[X] > 2, viewY = P.dense && P.view && P.nzmode && P.levels[Y] > 2;
     const unsigned *pn = (const unsigned *)P.nz, *ph = (const unsigned *)P.hi;
     const size_t W2 = 2 * (size_t)P.W;
     const unsigned *xn = pn + (size_t)X * W2, *yn = pn + (size_t)Y * W2;
@@ -334,11 +342,11 @@ static __device__ __forceinline__ MiRes mi_test_core(const MiDev &P, const int X
         if (PRE) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
-                if (it * 64 < nd) mi_count_words<L, NXY, KM>(wd[it], acc, b, k, SB, flagX, flagY, P.dense != 0, tot_sep);
+                if (it * 64 < nd) mi_count_words<L, NXY, KM>(wd[it], acc, b, k, SB, flagX, flagY, P.dense != 0, tot_sep, viewX, viewY);
         } else {
             for (int d0 = 0; d0 < nd; d0 += 64) {
                 mi_load_words<L, KM>(wd[0], pn, ph, xn, xh, yn, yh, W2, zs, k, d0 + lane, nd, P.n);
-                mi_count_words<L, NXY, KM>(wd[0], acc, b, k, SB, flagX, flagY, P.dense != 0, tot_sep);
+                mi_count_words<L, NXY, KM>(wd[0], acc, b, k, SB, flagX, flagY, P.dense != 0, tot_sep, viewX, viewY);
             }
         }
         // two 16-bit counts per register (a count never exceeds n <= 65535), six DPP adds each (independent chains: the
@@ -544,6 +552,7 @@ static __device__ __forceinline__ MiDev mi_uniform(const MiDev &P)
     U.nzmode = __builtin_amdgcn_readfirstlane(P.nzmode);
     U.hps = __builtin_amdgcn_readfirstlane(P.hps);
     U.dense = __builtin_amdgcn_readfirstlane(P.dense);
+    U.view = __builtin_amdgcn_readfirstlane(P.view);
     U.n_obs_min = (long long)mi_rfl64((unsigned long long)P.n_obs_min);
     U.gthr = (const double *)mi_rfl64((unsigned long long)P.gthr);
     U.gthr_n = __builtin_amdgcn_readfirstlane(P.gthr_n);

@@ -94,6 +94,7 @@ def load_library():
     L.fw_get_cor_mat.argtypes = [vp, vp]
     L.fw_level0.argtypes = [vp, C.POINTER(C.c_int64)]
     L.fw_level0_get.argtypes = [vp, vp, vp, vp, vp]
+    L.fw_set_row_views.argtypes = [vp, C.c_int32]
     L.fw_level0_sharded.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, C.POINTER(C.c_int64)]
     L.fw_test_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
     L.fw_test_subsets_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
@@ -188,6 +189,10 @@ class Engine:
         out = np.zeros((self.p, self.p), dtype=np.float32, order="F")
         self._ck(self.L.fw_get_cor_mat(self.h, _ptr(out)))
         return out
+
+    def set_row_views(self, on=True):
+        """mi_nz + dense_rules: test_subsets on the (T, candidate) row views hiton.jl uses (include/flashweave_amd.h)."""
+        self._ck(self.L.fw_set_row_views(self.h, int(bool(on))))
 
     def levels(self):
         lv, mv = np.zeros(self.p, np.int32), np.zeros(self.p, np.int32)

@@ -60,8 +60,8 @@ typedef struct fw_params {
                           * Matrix methods (src/contingency.jl:7-56 + level_map! src/misc.jl:162-184): every row is
                           * visited and levels_z = number of distinct Z keys over all rows.  The cell counts
                           * are the same; only levels_z (power verdict) can differ, and only for FW_MI_NZ.
-                          * fw_learn_network with FW_MI_NZ + dense_rules is refused: the reference then tests on a
-                          * per-target row view (src/hiton.jl:41-50) that no golden vector pins. */
+                          * fw_learn_network with FW_MI_NZ + dense_rules tests on the per-(target, candidate) row views of
+                          * src/hiton.jl:41-50 (see fw_set_row_views). */
     int64_t n_obs_min; /* default -1 = automatic (src/learning.jl:51-64, fires for every test kind) */
     int64_t max_tests; /* default 10_000_000 per (T, candidate) pair (src/learning.jl:205) */
     double alpha;      /* default 0.01 */
@@ -194,6 +194,13 @@ int fw_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, co
  * sequential reference would have executed. */
 int fw_test_subsets_batch(fw_ctx *ctx, int64_t m, const int32_t *T, const int32_t *cand, const int64_t *accoff,
                           const int32_t *accflat, fw_subsets_result *out);
+
+/* FW_MI_NZ with dense_rules = 1 only.  hiton.jl hands test_subsets not the data but a row VIEW of it: the rows where T is
+ * non-zero if T has more than two levels, and likewise for the candidate (prepare_nzdata, src/hiton.jl:41-50,85,193 ->
+ * needs_nz_view, src/misc.jl:103-107).  on = 1: fw_test_subsets_batch evaluates job (T, candidate, .) on that view (what a
+ * GpuTest shim called from hiton.jl:100 needs); on = 0 (default): on every row of the uploaded matrix (what a direct
+ * test_subsets(T, candidate, Z, data, ...) call on the full matrix computes).  fw_learn_network always uses the views. */
+int fw_set_row_views(fw_ctx *ctx, int32_t on);
 
 /* ---- host driver: the caller side, for hosts without Julia ----------------- */
 

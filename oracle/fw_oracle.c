@@ -64,6 +64,7 @@ typedef struct fwo_ctx {
     /* fz_nz (HE-S): the normalised matrix itself (clr_nz, zeros = absences), n x p column-major */
     const double *fdata; /* values widened to double (exact) */
     int fdata_f32;       /* 1: the reference's element type is Float32 (prec = 32), 0: Float64 */
+    const uint8_t *rowmask; /* dense discrete data: rows of the current view (hiton.jl:41-50 prepare_nzdata), NULL = all rows */
     int fz_stream;       /* "fz" with fdata attached: conditional tests through pcor (StatsBase.partialcor), not pcor_rec */
     /* scratch (one MiTestCond sized for max_k, hiton.jl:192) */
     int max_k;
@@ -335,7 +336,10 @@ static inline int32_t dense_at(const fwo_ctx *c, int i, int v) { return c->dense
 static void ctab2_dense(fwo_ctx *c, int X, int Y)
 {
     ctab_reset(c, 1);
-    for (int i = 0; i < c->n; ++i) CT(c, dense_at(c, i, X), dense_at(c, i, Y), 0) += 1;
+    for (int i = 0; i < c->n; ++i) {
+        if (c->rowmask && !c->rowmask[i]) continue; /* rows outside the @view (hiton.jl:41-50) do not exist for this test */
+        CT(c, dense_at(c, i, X), dense_at(c, i, Y), 0) += 1;
+    }
 }
 
 /* contingency.jl:42-56 dense 3-way + misc.jl:162-184 level_map! */
@@ -345,6 +349,7 @@ static int ctab3_dense(fwo_ctx *c, int X, int Y, const int *Zs, int k)
     for (int64_t t = 0; t < c->zmap_len; ++t) c->zmap[t] = -1;
     int32_t levels_z = 0;
     for (int i = 0; i < c->n; ++i) {
+        if (c->rowmask && !c->rowmask[i]) continue;
         int64_t gfp = 0; /* reference is 1-based: gfp_map = 1 + sum */
         for (int j = 0; j < k; ++j) gfp += (int64_t)dense_at(c, i, Zs[j]) * c->cum_levels[j];
         int32_t lv = c->zmap[gfp];
@@ -356,7 +361,10 @@ static int ctab3_dense(fwo_ctx *c, int X, int Y, const int *Zs, int k)
             ++levels_z;
         }
     }
-    for (int i = 0; i < c->n; ++i) CT(c, dense_at(c, i, X), dense_at(c, i, Y), c->zrow[i]) += 1;
+    for (int i = 0; i < c->n; ++i) {
+        if (c->rowmask && !c->rowmask[i]) continue;
+        CT(c, dense_at(c, i, X), dense_at(c, i, Y), c->zrow[i]) += 1;
+    }
     return levels_z;
 }
 
@@ -1631,8 +1639,22 @@ static void hiton_phase(fwo_ctx *c, int T, const int *cands, int ncands, char ph
         int Zs[16], nZs;
         int64_t nt;
         double frac;
+        /* hiton.jl:193 + :85 prepare_nzdata(T, .) then prepare_nzdata(candidate, .): with a dense matrix and a zero-adjusted
+         * discrete test, the tests of this (T, candidate) pair see only the rows where T (if levels[T] > 2) and the candidate
+         * (if levels[candidate] > 2) are non-zero (needs_nz_view, misc.jl:103-107) */
+        uint8_t *view = NULL;
+        if (!FWO_IS_CONT(c) && c->nz && !c->sparse && (c->levels[T] > 2 || c->levels[cand] > 2)) {
+            view = (uint8_t *)malloc((size_t)(c->n > 0 ? c->n : 1));
+            for (int i = 0; i < c->n; ++i)
+                view[i] = (c->levels[T] <= 2 || dense_at(c, i, T) != 0) && (c->levels[cand] <= 2 || dense_at(c, i, cand) != 0);
+            c->rowmask = view;
+        }
         fwo_test_subsets(c, T, cand, acc.v, acc.n, P->max_k, P->alpha, P->hps, P->n_obs_min, P->max_tests, &r, Zs,
                          &nZs, &nt, &frac);
+        if (view) {
+            c->rowmask = NULL;
+            free(view);
+        }
         if (nt > 0) *n_tests += nt;
         /* hiton.jl:53-78 update_sig_result! (fast_elim = true) */
         if (acc.n == 0) {

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Round-2 profile of bench.py on one MI355X: kernel-trace stats + three separate PMC passes (never combined with tracing
+# domains other than --kernel-trace).  usage: bash profiles/tools/collect_r02.sh <config> [extra bench args]
+# Writes gpurun_out/prof_r02_<config>/.  Every rocprofv3 call sits under `timeout` and writes CSV.
+set -u
+cd "${GRAFT_REPO_ROOT:-.}"
+export TMPDIR=/tmp
+CFG=$1; shift
+OUT=$PWD/gpurun_out/prof_r02_$CFG
+rm -rf "$OUT"; mkdir -p "$OUT"
+BENCH="python $PWD/bench.py --config $CFG --no-cpu-baseline --no-other-schedule $*"
+ROOT=$PWD
+cd /tmp
+rm -rf /tmp/prof_stats /tmp/pmc_sq /tmp/pmc_f /tmp/pmc_w
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- $BENCH --steps 2 --warmup 1 > "$OUT/bench_under_rocprof.json" 2> /tmp/prof_stats.err
+find /tmp/prof_stats -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES --output-format csv -d /tmp/pmc_sq -- $BENCH --steps 1 --warmup 0 > /dev/null 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum --output-format csv -d /tmp/pmc_f -- $BENCH --steps 1 --warmup 0 > /dev/null 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc TCC_MISS_sum TCC_REQ_sum WRITE_SIZE --output-format csv -d /tmp/pmc_w -- $BENCH --steps 1 --warmup 0 > /dev/null 2>&1
+for d in sq f w; do python "$ROOT/profiles/tools/pmc_sum.py" /tmp/pmc_$d > "$OUT/pmc_$d.json"; done
+ls -la "$OUT"

@@ -1,0 +1,50 @@
+"""Turn the raw output of collect_r02.sh (gpurun_out/prof_r02_<cfg>/) into the tracked files profiles/r02_<cfg>_*:
+python profiles/tools/install_r02.py <cfg> <kernel-name-substring>   (run from the repo root)"""
+import csv, json, shutil, sys
+
+cfg, kname = sys.argv[1], sys.argv[2]
+P = "gpurun_out/prof_r02_%s/" % cfg
+sq, f, w = (json.load(open(P + n)) for n in ("pmc_sq.json", "pmc_f.json", "pmc_w.json"))
+bench = json.loads([l for l in open(P + "bench_under_rocprof.json") if l.startswith("{")][-1])
+allk = {}
+for d in (sq, f, w):
+    for k, v in d.items():
+        allk.setdefault(k, {}).update(v)
+keys = [k for k in allk if kname in k]
+K = {}
+for k in keys:  # several instantiations of one kernel template: add them up
+    for c, v in allk[k].items():
+        K[c] = K.get(c, 0.0) + v
+ev = bench["tests_per_step"]["conditional_evaluated"]
+alg = bench["roofline"]["alg_bytes_per_launch"] * bench["roofline"]["launches"] / bench["steps"]
+fetch, wr = K["FETCH_SIZE"] * 1024.0, K["WRITE_SIZE"] * 1024.0
+nonempty = bench["roofline"]["launches"] / bench["steps"]
+summ = {
+    "kernels": keys, "dispatches": int(K["dispatches"]), "nonempty_launches": nonempty, "evaluated_tests": ev,
+    "FETCH_SIZE_KB": K["FETCH_SIZE"], "WRITE_SIZE_KB": K["WRITE_SIZE"], "fetch_bytes_raw": fetch, "write_bytes_raw": wr,
+    "fetch_bytes_note": "FETCH_SIZE counts 64-B fabric requests; the guide's x2 correction is calibrated for wide (16 B/lane) "
+                        "streaming reads only - these kernels gather 4-byte words / 256-byte rows, so the raw value is reported",
+    "fetch_bytes_per_launch": (fetch + wr) / nonempty,
+    "l2_hit_rate": K["TCC_HIT_sum"] / K["TCC_REQ_sum"],
+    "valu_wave_insts_per_test": K["SQ_INSTS_VALU"] / ev, "salu_wave_insts_per_test": K["SQ_INSTS_SALU"] / ev,
+    "lds_wave_insts_per_test": K["SQ_INSTS_LDS"] / ev, "vmem_rd_wave_insts_per_test": K["SQ_INSTS_VMEM_RD"] / ev,
+    "wait_inst_any_frac_of_wave_cycles": K["SQ_WAIT_INST_ANY"] / K["SQ_WAVE_CYCLES"],
+    "active_inst_valu_frac_of_wave_cycles": K["SQ_ACTIVE_INST_VALU"] / K["SQ_WAVE_CYCLES"],
+    "algorithmic_bytes": alg, "fabric_over_algorithmic": (fetch + wr) / alg,
+}
+out = {
+    "command": "profiles/tools/collect_r02.sh %s: timeout 900 rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python "
+               "bench.py --config %s --steps 1 --warmup 0 --no-cpu-baseline --no-other-schedule (three separate passes: SQ_*; "
+               "FETCH_SIZE+TCC_HIT_sum; TCC_MISS_sum+TCC_REQ_sum+WRITE_SIZE), summed per kernel with profiles/tools/pmc_sum.py" % (cfg, cfg),
+    "workload": bench["config"]["workload"], "schedule": {k: bench["config"][k] for k in ("feed_forward", "round_size")},
+    "counters_per_kernel_sum_over_dispatches": allk,
+    ("fz_subsets_seg_kernel" if "fz" in kname else "mi_subsets_seg_kernel"): summ,
+}
+json.dump(out, open("profiles/r02_%s_pmc_summary.json" % cfg, "w"), indent=1)
+shutil.copy(P + "kernel_stats.csv", "profiles/r02_%s_kernel_stats.csv" % cfg)
+json.dump(bench, open("profiles/r02_%s_bench_under_rocprof.json" % cfg, "w"))
+print(json.dumps({k: v for k, v in summ.items() if k != "fetch_bytes_note"}, indent=1))
+print("under rocprof: ms %.1f launch_us %.1f launches %d" % (bench["ms_per_step"], bench["roofline"]["avg_launch_us"], bench["roofline"]["launches"]))
+for r in csv.DictReader(open(P + "kernel_stats.csv")):
+    if float(r["TotalDurationNs"]) > 2e6:
+        print(r["Name"][:70], r["Calls"], "%.3f ms total" % (float(r["TotalDurationNs"]) / 1e6), "avg %.1f us" % (float(r["AverageNs"]) / 1e3), r["Percentage"])

@@ -257,3 +257,26 @@ def test_pcor_known_answers():
     s_, p_, df, pw = o.test(0, 15, (40,))
     assert rel(s_, -0.16393307352649356) < 1e-6 and pw
     assert rel(p_, O.fz_pval(s_, clr.shape[0], 0)) < 1e-12
+
+
+# ---- test/learning.jl:369-383: dense == sparse networks for mi_nz at max_k 0 / 1 ("sparse special optim") -------------
+def dense_sparse_property_matrix():
+    """normalize_data(data, test_name="mi_nz", make_sparse=false) with the last six variables made binary, as the reference's
+    test builds it (A[:, end-5:end] .= iszero.(A[:, end-5:end]))."""
+    A = load_norm("clr_nonzero_binned", np.int64).copy()
+    A[:, -6:] = (A[:, -6:] == 0).astype(np.int64)
+    return A
+
+
+@pytest.mark.parametrize("max_k", [0, 1])
+def test_dense_equals_sparse_mi_nz(max_k):
+    # the dense path tests on per-(target, candidate) row views (hiton.jl:41-50) with the Matrix table methods; the reference
+    # asserts that its networks equal those of the SparseMatrixCSC path for max_k <= 1 -- this pins the oracle's views
+    A = dense_sparse_property_matrix()
+    nets = []
+    for sparse in (False, True):
+        o = O.Oracle("mi_nz", A, sparse=sparse, max_k=max_k)
+        nets.append(o.learn(max_k=max_k, feed_forward=True, round_size=1))
+    assert set(nets[0]["edges"]) == set(nets[1]["edges"]) and len(nets[0]["edges"]) >= 4
+    for e, w in nets[0]["edges"].items():
+        assert rel(w, nets[1]["edges"][e]) < 1e-9
