@@ -48,10 +48,9 @@ def make_input(cfg, args):
         c["n"] = args.n
     if c.get("habitats"):  # HE configs: structural absences + 20 binary meta variables
         counts, meta = synth.generate(c["p"], c["n"], c["seed"], mode=c["mode"], habitats=c["habitats"], n_meta=c["n_meta"])
-        data, rm, _ = pre.normalize(counts, c["test_name"], prec=32)
-        meta = meta[rm]
-        keep = [j for j in range(meta.shape[1]) if len(np.unique(meta[:, j])) == 2]
-        data = np.ascontiguousarray(np.concatenate([data, meta[:, keep]], axis=1))
+        # the front-end's meta-variable path (preprocess_data with a meta_mask, preprocessing.jl:412-563): row filters, one-hot /
+        # discretisation where needed, zero-variance meta columns dropped, appended behind the OTUs
+        data = np.ascontiguousarray(pre.normalize_with_meta(counts, c["test_name"], meta.astype(np.float64), prec=32)["data"])
     else:
         counts = synth.generate(c["p"], c["n"], c["seed"], mode=c["mode"])
         data, _, _ = pre.normalize(counts, c["test_name"], prec=32)

@@ -17,23 +17,34 @@ class FWResult(dict):
 
 def learn_network(data, sensitive=True, heterogeneous=False, max_k=3, alpha=0.01, feed_forward=True, normalize=True,
                   header=None, hps=5, FDR=True, n_obs_min=-1, max_tests=10_000_000, prec=32, round_size=1, device=0,
-                  **unsupported):
+                  meta_data=None, meta_header=None, make_onehot=True, recursive_pcor=True, **unsupported):
     """data: samples x OTUs count matrix (or an already normalised matrix with normalize=False).
-    round_size: targets per feed-forward round; 1 = the reference's deterministic `single_il` schedule."""
+    meta_data: optional samples x meta-variables table (numbers and / or string factors), handled like the reference's
+    meta_data_path input: one-hot encoding, discretisation for the discrete tests, +1 shift for fz_nz (preprocess.py).
+    round_size: targets per feed-forward round.  1 = the reference's deterministic `single_il` schedule (what the golden
+    networks were generated with): every round is one target, which runs through the host job pool -- exact, and far
+    slower than the benchmarked configuration.  Rounds of >= 64 (fz) / 256 (discrete) targets run as device-resident
+    rounds / one persistent launch; the whitelists then refresh once per round, so the network can differ from the
+    single_il one in the edges the feed-forward heuristic touches (bench.py reports R next to every throughput)."""
     if unsupported:
         raise TypeError("learn_network: unsupported options %s (see DESIGN.md section 7)" % sorted(unsupported))
     test_name = ("fz" if sensitive else "mi") + ("_nz" if heterogeneous else "")  # src/learning.jl:480-483
     data = np.asarray(data)
     if header is None:
         header = ["X%d" % (i + 1) for i in range(data.shape[1])]
-    if normalize:
+    meta_mask = None
+    if normalize and meta_data is not None:
+        r = pre.normalize_with_meta(data, test_name, meta_data, prec=prec, header=header, meta_header=meta_header,
+                                    make_onehot=make_onehot)
+        mat, header, meta_mask = r["data"], r["header"], [bool(v) for v in r["meta_mask"]]
+    elif normalize:
         mat, row_mask, col_mask = pre.normalize(data, test_name, prec=prec)
         header = [h for h, k in zip(header, col_mask) if k]
     else:
         mat = data
     n, p = mat.shape
     eng = Engine(test_name, n, p, max_k=max_k, alpha=alpha, hps=hps, n_obs_min=n_obs_min, max_tests=max_tests, FDR=FDR,
-                 device=device)
+                 device=device, recursive_pcor=recursive_pcor)
     try:
         eng.set_data(mat)
         if test_name == "fz":
@@ -42,6 +53,6 @@ def learn_network(data, sensitive=True, heterogeneous=False, max_k=3, alpha=0.01
         counters = eng.counters()
     finally:
         eng.close()
-    return FWResult(edges=net["edges"], variable_ids=header, meta_variable_mask=[False] * len(header),
+    return FWResult(edges=net["edges"], variable_ids=header, meta_variable_mask=meta_mask or [False] * len(header),
                     parameters=dict(sensitive=sensitive, heterogeneous=heterogeneous, max_k=max_k, alpha=alpha,
                                     feed_forward=feed_forward, test_name=test_name), counters=counters)

@@ -74,6 +74,82 @@ def discretize_nz(col, nz_mask, n_bins=3):
     return out
 
 
+# ---- meta variables (preprocessing.jl:42-117 one-hot, :293-316 discretize_meta!, :527-555) ---------------------------------
+def _is_number(v):
+    return isinstance(v, (int, float, np.integer, np.floating)) and not isinstance(v, bool)
+
+
+def onehot(meta, header=None):
+    """onehot(X, vnames) (preprocessing.jl:42-117): a string factor with more than two categories becomes one 0/1 dummy
+    column per category (sorted, named <var>_<category>); a string factor with one or two categories becomes the integers
+    1, 2 (factors_to_ints); numeric columns pass through.  -> (Float64 matrix, header)"""
+    meta = np.asarray(meta, dtype=object)
+    cols, names = [], []
+    for j in range(meta.shape[1]):
+        x = meta[:, j]
+        name = header[j] if header is not None else ""
+        if _is_number(x[0]):
+            cols.append(np.array([float(v) for v in x]))
+            names.append(name)
+            continue
+        cats = sorted(set(x))
+        if len(cats) > 2:
+            for cat in cats:
+                cols.append(np.array([1.0 if v == cat else 0.0 for v in x]))
+                names.append("%s_%s" % (name, cat) if name else "")
+        else:
+            fmap = {c: float(i + 1) for i, c in enumerate(cats)}
+            cols.append(np.array([fmap[v] for v in x]))
+            names.append(name)
+    return np.stack(cols, axis=1), names
+
+
+def is_continuous_vec(x):
+    """iscontinuous(x_vec) (preprocessing.jl:295-302)."""
+    if np.allclose(np.round(x), x):
+        return bool(x.max() > 1 or len(np.unique(x)) > 2)
+    return True
+
+
+def discretize(x, n_bins):
+    """discretize(x_vec, n_bins), disc_method = "median", rank_method = "tied" (preprocessing.jl:238-265)."""
+    if len(x) == 0:
+        return x
+    r = _tiedrank(x)
+    r = r / r.max()
+    step = (1.0 / n_bins) + 1e-5
+    return np.floor(r / step)
+
+
+def normalize_with_meta(counts, test_name, meta, prec=32, header=None, meta_header=None, make_onehot=True):
+    """preprocess_data with a meta_mask (preprocessing.jl:412-563): OTU columns are normalised as in normalize(); meta
+    variables are one-hot encoded, follow the row filters, are discretised into 2 bins for the discrete tests when they look
+    continuous, are shifted by +1 for "fz_nz" if they hold zeros (zeros mean "absent" there), lose zero-variance columns
+    and are appended.  -> dict(data, header, meta_mask, row_mask)"""
+    if make_onehot:
+        md, mh = onehot(meta, meta_header)
+    else:
+        md, mh = np.asarray(meta, dtype=np.float64), list(meta_header or [""] * np.asarray(meta).shape[1])
+    data, row_mask, col_mask = normalize(counts, test_name, prec=prec)
+    md = md[row_mask]
+    if test_name in ("mi", "mi_nz"):
+        for j in range(md.shape[1]):
+            if is_continuous_vec(md[:, j]):
+                md[:, j] = discretize(md[:, j], 2)
+    if test_name == "fz_nz":
+        for j in range(md.shape[1]):
+            if (md[:, j] == 0).any():
+                md[:, j] += 1
+    keep = np.var(md, axis=0) > 0.0
+    md, mh = md[:, keep], [h for h, k in zip(mh, keep) if k]
+    out = np.concatenate([data, md.astype(data.dtype)], axis=1)
+    hdr = None
+    if header is not None:
+        hdr = [h for h, k in zip(header, col_mask) if k] + mh
+    return dict(data=out, header=hdr, meta_header=mh, meta_mask=np.r_[np.zeros(data.shape[1], bool), np.ones(md.shape[1], bool)],
+                row_mask=row_mask)
+
+
 def normalize(counts, test_name, prec=32):
     """-> (data, row_mask, col_mask).  row/col masks refer to the input matrix."""
     counts = np.asarray(counts)

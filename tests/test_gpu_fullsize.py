@@ -214,10 +214,7 @@ def test_cfg4_full_size_properties():
     the lists themselves are checked against the oracle at 300-1000 variables in tests/test_gpu_mi.py)."""
     c = synth.CONFIGS["cfg4"]
     counts, meta = synth.generate(c["p"], c["n"], c["seed"], mode=c["mode"], habitats=c["habitats"], n_meta=c["n_meta"])
-    data, rm, _ = pre.normalize(counts, c["test_name"], prec=32)
-    meta = meta[rm]
-    keep = [j for j in range(meta.shape[1]) if len(np.unique(meta[:, j])) == 2]
-    data = np.ascontiguousarray(np.concatenate([data, meta[:, keep]], axis=1))
+    data = np.ascontiguousarray(pre.normalize_with_meta(counts, c["test_name"], meta.astype(np.float64), prec=32)["data"])
     n, p = data.shape
     eng = fw.Engine(c["test_name"], n, p, max_k=3)
     eng.set_data(data)
