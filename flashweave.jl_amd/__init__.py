@@ -7,6 +7,7 @@ argument meaning follow the reference (src/tests.jl, src/learning.jl); indices a
 
 There is no CPU fallback: creating an Engine without a gfx950 device raises FlashWeaveError.
 """
-from .engine import (FW_FZ, FW_FZ_NZ, FW_MI, FW_MI_NZ, Engine, FlashWeaveError, TestResult, lib_path, load_library)  # noqa: F401
+from .engine import (FW_FZ, FW_FZ_NZ, FW_MI, FW_MI_NZ, Engine, FlashWeaveError, TestResult, lib_path, load_library,
+                     normalize_counts)  # noqa: F401
 from .build import build_library  # noqa: F401
 from .api import FWResult, learn_network  # noqa: F401,E402

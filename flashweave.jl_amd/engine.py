@@ -95,6 +95,8 @@ def load_library():
     L.fw_level0.argtypes = [vp, C.POINTER(C.c_int64)]
     L.fw_level0_get.argtypes = [vp, vp, vp, vp, vp]
     L.fw_set_row_views.argtypes = [vp, C.c_int32]
+    L.fw_normalize_counts.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int32)]
     L.fw_level0_sharded.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, C.POINTER(C.c_int64)]
     L.fw_test_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
     L.fw_test_subsets_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
@@ -111,6 +113,24 @@ def load_library():
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def normalize_counts(counts, test_name, device=0):
+    """Normalisation front-end on the device (fw_normalize_counts): -> (data, row_mask, col_mask) like preprocess.normalize
+    for test_name in {"fz", "fz_nz", "mi"} ("mi_nz": preprocess.normalize on the host)."""
+    L = load_library()
+    x = np.asfortranarray(np.asarray(counts, dtype=np.int32))
+    n, p = x.shape
+    rm, cm = np.zeros(n, np.uint8), np.zeros(p, np.uint8)
+    no, po = C.c_int32(0), C.c_int32(0)
+    kind = _KINDS[test_name]
+    of = np.zeros(n * p, np.float32) if kind in (FW_FZ, FW_FZ_NZ) else None
+    oi = np.zeros(n * p, np.int32) if kind == FW_MI else None
+    rc = L.fw_normalize_counts(device, kind, n, p, _ptr(x), _ptr(of), _ptr(oi), _ptr(rm), _ptr(cm), C.byref(no), C.byref(po))
+    if rc != 0:
+        raise FlashWeaveError(rc, L.fw_last_error(None).decode())
+    out = (of if of is not None else oi)[:no.value * po.value].reshape((no.value, po.value), order="F")
+    return out, rm.astype(bool), cm.astype(bool)
 
 
 class Engine:

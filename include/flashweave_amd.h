@@ -224,6 +224,16 @@ int fw_network_get(const fw_ctx *ctx, int32_t *src, int32_t *dst, double *weight
 /* directed per-target results (state_results of every HitonState): CSR over targets */
 int fw_network_get_directed(const fw_ctx *ctx, int64_t *off, int32_t *idx, double *weight, double *pval);
 
+/* ---- normalisation front-end on the device -------------------------------------- */
+
+/* replaces: normalize_data / preprocess_data (src/preprocessing.jl:412-563) for a count table without meta variables:
+ * filter_by_variance (:367-409), then by kind  FW_FZ: clr_adapt (:133-214)   FW_FZ_NZ: clr_nz (:192-207)   FW_MI: binary (:475-490).
+ * counts: n x p column-major Int32.  Outputs (host buffers sized for n x p): out_f32 (FW_FZ / FW_FZ_NZ) or out_i32 (FW_MI),
+ * column-major *n_out x *p_out; row_mask[n] / col_mask[p] = kept samples / variables.  No context needed: create one with the
+ * resulting shape afterwards.  FW_MI_NZ (per-column tied ranks) is normalised by the host front-end. */
+int fw_normalize_counts(int32_t device, int32_t kind, int32_t n, int32_t p, const int32_t *counts, float *out_f32, int32_t *out_i32,
+                        uint8_t *row_mask, uint8_t *col_mask, int32_t *n_out, int32_t *p_out);
+
 int fw_get_counters(const fw_ctx *ctx, fw_counters *out);
 int fw_reset_counters(fw_ctx *ctx);
 /* effective n_obs_min after the automatic rule */
