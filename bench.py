@@ -35,7 +35,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
-DEFAULT_ROUND = 1024    # targets per feed-forward round (results do not depend on the number of GPUs, only on R)
+DEFAULT_ROUND = 1024    # granularity of the default feed-forward round size: R = 1024 * ceil(p / 10240), i.e. ~10 rounds per pass
+                        # (cfg3: R = 1024; cfg4: R = 5120); results do not depend on the number of GPUs, only on R
 
 
 def make_input(cfg, args):
@@ -66,8 +67,11 @@ def parse_args(argv=None):
     ap.add_argument("--p", type=int, default=0, help="override #OTUs (debug)")
     ap.add_argument("--n", type=int, default=0, help="override #samples (debug)")
     ap.add_argument("--feed-forward", type=int, default=1, help="reference default: true (learning.jl:469)")
-    ap.add_argument("--round-size", type=int, default=DEFAULT_ROUND,
-                    help="targets per feed-forward round (0 = one round = feed_forward off)")
+    ap.add_argument("--round-size", type=int, default=-1,
+                    help="targets per feed-forward round (-1: 1024 * ceil(p / 10240), about ten rounds; 0 = one round = feed_forward off)")
+    ap.add_argument("--shard-level0", action="store_true",
+                    help="N > 1, discrete kinds: every rank screens 1/N of the level-0 pair tiles and the significant pairs are "
+                         "all-gathered (fw_level0_sharded); default: level 0 replicated on every rank")
     ap.add_argument("--max-targets", type=int, default=0,
                     help="conditional stage of the first M targets of the schedule only (a bounded SAMPLE of configs whose full "
                          "conditional stage takes hours, e.g. cfg5; the JSON line says so and is not a whole-network result)")
@@ -263,7 +267,7 @@ def main():
     def step(ff, R):
         if cfg["test_name"] == "fz":
             eng.compute_cor()  # matrix stays resident in HBM
-        if use_dist:
+        if use_dist and args.shard_level0:
             eng.level0(rank=rank, world_size=world, allgather=cb)  # discrete kinds: pair tiles sharded, significant pairs all-gathered
         else:
             eng.level0()
@@ -304,13 +308,14 @@ def main():
                              "us_per_round_rank0": 1e6 * xstats.get("seconds", 0.0) / max(xstats.get("calls", 0), 1)}
                 if use_dist else None}
 
-    ff, R = int(bool(args.feed_forward)), args.round_size
+    auto_R = DEFAULT_ROUND * ((p + 10 * DEFAULT_ROUND - 1) // (10 * DEFAULT_ROUND))
+    ff, R = int(bool(args.feed_forward)), (auto_R if args.round_size < 0 else args.round_size)
     if R <= 0:
         ff = 0
     main_m = measure(ff, R if ff else 0, args.steps, args.warmup)
     other_m = None
     if not args.no_other_schedule:
-        off, oR = (0, 0) if ff else (1, DEFAULT_ROUND)
+        off, oR = (0, 0) if ff else (1, auto_R)
         other_m = measure(off, oR, max(1, min(args.steps, 3)), 1)
     seam_m = None
     if args.host_seam and world == 1:
@@ -385,7 +390,7 @@ def main():
                                        "host_launch": cn["t_host_launch_s"] / steps, "host_wait_device": cn["t_host_wait_s"] / steps, "host_merge": cn["t_host_merge_s"] / steps,
                                        "subsets_calls": cn["subsets_calls"] / steps},
                "kernel_launches_per_step": launches / steps,
-               "other_schedule": sched(other_m, *((0, 0) if ff else (1, DEFAULT_ROUND))) if other_m else None,
+               "other_schedule": sched(other_m, *((0, 0) if ff else (1, auto_R))) if other_m else None,
                "host_seam": ({"note": "FW_HOST_HITON=1: HITON-PC state machines on the host, every pool round = one window of every "
                                       "in-flight (T, candidate, accepted) job through the fw_test_subsets_batch kernels -- the seam "
                                       "hiton.jl:100 would call; feed_forward=0", **sched(seam_m, 0, 0)} if seam_m else None),

@@ -45,6 +45,8 @@ struct DhGlobal {
     unsigned long long cond_tests_ref, subsets_calls, evaluated;
     double alg_bytes;
     unsigned int n_act, act_sel;  // unfinished targets: act[act_sel * ntg + 0 .. n_act) (dh_compact_kernel)
+    unsigned int any_big, pad_big;  // the coming launch holds a segment with |accepted| > FW_TAB_A (set by dh_fill_kernel): the
+                                    // in-lane variant of the fz segment kernel leaves at once when it does not
     unsigned int ns_ring[64];  // segments of the last 64 planned launches (the host reads the record once per batch)
 };
 
@@ -960,6 +962,7 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
     if (tid == 0) {
         seg0[na] = (long long)ns;
         g->ns = ns;
+        g->any_big = 0u;
         g->seglen = (unsigned int)seglen;
         g->launched_ranks = total;
         g->n_live_prev = n_live;
@@ -971,7 +974,7 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
     }
 }
 
-__global__ __launch_bounds__(256) void dh_fill_kernel(const DhTgt *__restrict__ tg, int ntg, const DhGlobal *__restrict__ g,
+__global__ __launch_bounds__(256) void dh_fill_kernel(const DhTgt *__restrict__ tg, int ntg, DhGlobal *__restrict__ g,
                                                       const long long *__restrict__ seg0, const DhArrays A,
                                                       FwSeg *__restrict__ segs, int d1, const int32_t *__restrict__ act)
 {
@@ -1000,6 +1003,7 @@ __global__ __launch_bounds__(256) void dh_fill_kernel(const DhTgt *__restrict__ 
     sg.Y = cands[x.pos + (int)slot];
     sg.acc_off = DH_ACC_OFF(x, x.phase == 1 ? (x.cur + (int)slot) % d1 : x.cur, d1);
     sg.acc_len = x.na;
+    if (x.na > FW_TAB_A) g->any_big = 1u;  // same value from every writer
     sg.pad = 0;
     sg.start = x.jnext + k * seglen;
     const unsigned long long hi_r = x.jnext + x.jwin;
@@ -1273,7 +1277,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         hipLaunchKernelGGL(dh_plan_kernel, dim3(1), dim3(1024), 0, st, ntg, d_g, (const unsigned long long *)d_win,
                            (const unsigned int *)d_sp, (const int32_t *)d_act, d_seg0, seg_target, P.seg_q, P.seg_min, d_log,
                            LOG_CAP, seg_a, seg_b);
-        hipLaunchKernelGGL(dh_fill_kernel, dim3(g_fill), dim3(256), 0, st, (const DhTgt *)d_tg, ntg, (const DhGlobal *)d_g,
+        hipLaunchKernelGGL(dh_fill_kernel, dim3(g_fill), dim3(256), 0, st, (const DhTgt *)d_tg, ntg, d_g,
                            (const long long *)d_seg0, A, d_segs, d1, (const int32_t *)d_act);
     };
     const double th1 = wall();
@@ -1332,7 +1336,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
             if (timed) (void)hipEventRecord(ev[q][2 * r], st);
             // discrete segment kernel: one workgroup per record, no stride loop -> the grid follows the bound on the list
             const unsigned grid_mi = std::min(max_ns, seg_target + n_act_bound * (unsigned)(1 + std::max(spec_depth, spec0_depth)) + 256u);
-            int rc = fz ? fwi_fz_segments_dev(c, grid_seg, d_segs, A.acc, d_so, d_ns, any_big, st)
+            int rc = fz ? fwi_fz_segments_dev(c, grid_seg, d_segs, A.acc, d_so, d_ns, any_big, &d_g->any_big, st)
                         : fwi_mi_segments_dev(c, grid_mi, d_segs, A.acc, d_so, d_ns, st);
             if (rc) return rc;
             if (timed) (void)hipEventRecord(ev[q][2 * r + 1], st);

@@ -1175,8 +1175,13 @@ __global__ __launch_bounds__(256, 4) void fz_subsets_seg_kernel(const float *__r
                                                              double zscale_g, long long max_tests,
                                                              const double *__restrict__ thr_g,
                                                              const FwNzJob *__restrict__ recs, long long n_obs_min,
-                                                             const unsigned *__restrict__ ns_dev)
+                                                             const unsigned *__restrict__ ns_dev,
+                                                             const unsigned *__restrict__ big_dev)
 {
+    // device rounds launch the in-lane variant next to the table variant whenever a long accepted list is POSSIBLE (with
+    // whitelists that is nearly always); the fill kernel knows whether one EXISTS in this launch -- without one, leave
+    // before walking the segment list (r02 profile, feed-forward rounds: 26 us per launch for nothing, 40 ms per pass)
+    if (big_dev && !TAB && !HIGHK && *big_dev == 0u) return;
     // one instance of the body for both modes: host-driven = exactly one iteration, every segment of the launch is ours
     const unsigned ns = ns_dev ? *ns_dev : gridDim.x;
     for (unsigned s = blockIdx.x; s < ns; s += gridDim.x) {
@@ -1356,7 +1361,7 @@ static int fz_ensure_thresholds(fw_ctx *ctx, hipStream_t stream)
 
 // Device-driven rounds (fw_devhiton.hip): a fixed grid over an unsorted segment list whose live length is *d_ns.
 int fwi_fz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, const unsigned *d_ns,
-                        bool any_big, hipStream_t stream)
+                        bool any_big, const unsigned *d_big, hipStream_t stream)
 {
     int rc = fz_ensure_thresholds(ctx, stream);
     if (rc) return rc;
@@ -1364,15 +1369,15 @@ int fwi_fz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const i
     if (ctx->P.max_k > 3) {
         hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false, false>), dim3(grid), dim3(256), 0, stream, ctx->d_cor, ctx->P.p, d_segs,
                            d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr,
-                           (const FwNzJob *)nullptr, 0ll, d_ns);
+                           (const FwNzJob *)nullptr, 0ll, d_ns, d_big);
     } else {
         hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false, true>), dim3(grid), dim3(256), 0, stream, ctx->d_cor, ctx->P.p, d_segs,
                            d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr,
-                           (const FwNzJob *)nullptr, 0ll, d_ns);
+                           (const FwNzJob *)nullptr, 0ll, d_ns, d_big);
         if (any_big)  // some accepted set may exceed FZ_TAB_A
             hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false, false>), dim3(grid_big), dim3(256), 0, stream, ctx->d_cor, ctx->P.p,
                                d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests,
-                               ctx->d_thr, (const FwNzJob *)nullptr, 0ll, d_ns);
+                               ctx->d_thr, (const FwNzJob *)nullptr, 0ll, d_ns, d_big);
     }
     FW_HIP(ctx, hipGetLastError());
     return FW_OK;
@@ -1390,18 +1395,18 @@ int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *d_
     if (ctx->P.max_k > 3)
         hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false, false>), dim3((unsigned)nseg), dim3(256), 0, pb.launch_stream, ctx->d_cor,
                            ctx->P.p, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx),
-                           (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll, (const unsigned *)nullptr);
+                           (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll, (const unsigned *)nullptr, (const unsigned *)nullptr);
     else {
         // segments [0, nseg_tab) belong to jobs with |accepted| <= FZ_TAB_A: table kernel; the rest: in-lane caching
         if (nseg_tab > 0)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false, true>), dim3((unsigned)nseg_tab), dim3(256), 0, pb.launch_stream,
                                ctx->d_cor, ctx->P.p, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx),
-                               (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll, (const unsigned *)nullptr);
+                               (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll, (const unsigned *)nullptr, (const unsigned *)nullptr);
         if (nseg > nseg_tab)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false, false>), dim3((unsigned)(nseg - nseg_tab)), dim3(256), 0,
                                pb.launch_stream, ctx->d_cor, ctx->P.p, d_segs + nseg_tab, d_acc, d_out + nseg_tab, ctx->P.max_k,
                                ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr,
-                               0ll, (const unsigned *)nullptr);
+                               0ll, (const unsigned *)nullptr, (const unsigned *)nullptr);
     }
     FW_HIP(ctx, hipGetLastError());
     FW_HIP(ctx, hipEventRecord(pb.ev1, pb.launch_stream));
@@ -1715,18 +1720,18 @@ int fwi_fznz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *
         hipLaunchKernelGGL((fz_subsets_seg_kernel<true, true, false>), dim3((unsigned)nseg), dim3(256), 0, pb.launch_stream,
                            (const float *)ctx->d_arena.ptr, 0, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, 0.0,
                            (long long)ctx->P.max_tests, (const double *)nullptr, (const FwNzJob *)ctx->d_nzrecs.ptr,
-                           (long long)ctx->n_obs_min_eff, (const unsigned *)nullptr);
+                           (long long)ctx->n_obs_min_eff, (const unsigned *)nullptr, (const unsigned *)nullptr);
     else {
         if (nseg_tab > 0)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<false, true, true>), dim3((unsigned)nseg_tab), dim3(256), 0, pb.launch_stream,
                                (const float *)ctx->d_arena.ptr, 0, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, 0.0,
                                (long long)ctx->P.max_tests, (const double *)nullptr, (const FwNzJob *)ctx->d_nzrecs.ptr,
-                               (long long)ctx->n_obs_min_eff, (const unsigned *)nullptr);
+                               (long long)ctx->n_obs_min_eff, (const unsigned *)nullptr, (const unsigned *)nullptr);
         if (nseg > nseg_tab)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<false, true, false>), dim3((unsigned)(nseg - nseg_tab)), dim3(256), 0,
                                pb.launch_stream, (const float *)ctx->d_arena.ptr, 0, d_segs + nseg_tab, d_acc, d_out + nseg_tab,
                                ctx->P.max_k, ctx->P.alpha, 0.0, (long long)ctx->P.max_tests, (const double *)nullptr,
-                               (const FwNzJob *)ctx->d_nzrecs.ptr, (long long)ctx->n_obs_min_eff, (const unsigned *)nullptr);
+                               (const FwNzJob *)ctx->d_nzrecs.ptr, (long long)ctx->n_obs_min_eff, (const unsigned *)nullptr, (const unsigned *)nullptr);
     }
     FW_HIP(ctx, hipGetLastError());
     FW_HIP(ctx, hipEventRecord(pb.ev1, pb.launch_stream));

@@ -278,7 +278,7 @@ int fwi_devhiton_run(fw_ctx *ctx, const std::vector<FwDhTarget> &in, std::vector
 int fwi_mi_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, const unsigned *d_ns,
                         hipStream_t stream);
 int fwi_fz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, const unsigned *d_ns,
-                        bool any_big, hipStream_t stream);
+                        bool any_big, const unsigned *d_big, hipStream_t stream);
 
 // ---- host driver (fw_hiton.cpp) ----
 int fwi_subsets_dispatch(fw_ctx *ctx, int64_t m, const FwJob *jobs_host, const int32_t *acc_host, int64_t acc_total,
