@@ -11,6 +11,8 @@ for d in (sq, f, w):
     for k, v in d.items():
         allk.setdefault(k, {}).update(v)
 keys = [k for k in allk if kname in k]
+if not keys:  # pmc_sum.py cuts kernel names at the first "(": "void (anonymous namespace)::dh_mi_target_kernel<..>" becomes "void "
+    keys = [k for k in allk if k.strip() in ("", "void")]
 K = {}
 for k in keys:  # several instantiations of one kernel template: add them up
     for c, v in allk[k].items():
