@@ -356,30 +356,43 @@ __device__ __forceinline__ bool dh_commit(DhTgt &x, const DhArrays &A, int lane,
 // ties"; a stop found by one chunk cancels the later chunks of the board (stop_min).  num_tests is the reference's count.
 #define MI_SEQ 4u           // tests of a job its owner runs alone before it opens a board
 #define MI_WIN0 32ull       // first board window (ranks); later windows grow x8
-#define MI_BOARD_CAP (1u << 16)
+#define MI_BOARD_CAP (1u << 18)
 #define MI_REC_CAP (1u << 20)
 
 // one LDS table [stratum][cell] per wavefront (fw_mi_core.h); module scope so that the called test routine addresses it as LDS
 __shared__ unsigned short dh_mi_tab[4][MI_TAB16];
 
-__shared__ DhTgt dh_mi_x[4];  // the target each wavefront is working on
+__shared__ int32_t dh_mi_acc[4][1024];  // a helper's copy of the accepted list of the board it works on (MI_ACC_LDS)
 
+// Everything two wavefronts share travels as write-through messages: the producer stores with sc1 (relaxed agent-scope atomic
+// stores: the line leaves its XCD's L2), drains them with `s_waitcnt vmcnt(0)` (inline asm: the compiler drops the builtin
+// form after a release fence on ROCm 7.2, MI355X_MICROARCH.md "compiler hazard") and then raises the flag / counter; the
+// consumer polls with ONE relaxed sc1 load and reads the payload with sc1 loads.  No acquire / release fences: on this
+// multi-XCD part an agent acquire invalidates the reader's L2 -- i.e. the bit planes every test reads -- and the first
+// version of this kernel, which fenced per record, ran 15x slower with 2-rank records than with 8-rank ones.
 struct MiBoard {
-    int32_t T, cand, a, chunk;       // chunk = ranks per record
-    long long acc_off;               // accepted list of the job (DhArrays::acc)
-    unsigned long long start, end;   // ranks [start, end) of the window
-    unsigned int nch, res_off;       // records of the window: res[res_off .. res_off + nch)
-    unsigned int next_chunk, done;   // claimed / finished records
-    unsigned long long stop_min;     // smallest stopping rank found so far (FW_RANK_NONE: none)
+    unsigned long long tc;        // T | cand << 32
+    unsigned long long ac;        // a | chunk << 32            (chunk = ranks per record)
+    unsigned long long acc_off;   // accepted list of the job: write-through copy in MiShared::bacc
+    unsigned long long start, end;  // ranks [start, end) of the window
+    unsigned long long nr;        // nch | res_off << 32        (records of the window: res[res_off .. res_off + nch))
+    unsigned long long stop_min;  // smallest stopping rank found so far (FW_RANK_NONE: none)
+    unsigned int next_chunk, done;  // claimed / finished records
     unsigned int ready, pad;
 };
 
 struct MiQueue {
-    unsigned int next_target, targets_done, n_boards, hint, res_top, pad[3];
+    unsigned int next_target, targets_done, n_boards, hint, res_top, bacc_top, pad[2];
 };
+
+#define MI_BACC_CAP (1u << 22)  // ints of accepted-list copies per launch
+#define MI_ACC_LDS 1024         // accepted-list entries a helper stages in LDS (longer lists are read through sc1 loads)
 
 __device__ __forceinline__ unsigned int mi_ld_u32(const unsigned int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned long long mi_ld_u64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void mi_st_u64(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void mi_st_u32(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void mi_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // lane 0 performs the atomic, every lane gets the value
 __device__ __forceinline__ unsigned int mi_wave_add(unsigned int *p, unsigned int v, int lane)
 {
@@ -394,7 +407,7 @@ __device__ __forceinline__ unsigned int mi_wave_add(unsigned int *p, unsigned in
 template <int L, int NXY, bool PRE>
 __device__ __noinline__ FwSegOut mi_run_ranks(const MiDev M_in, int T, int cand, const int32_t *__restrict__ acc_in, int a, int max_k,
                                               long long max_tests, unsigned long long r0, unsigned long long r1,
-                                              const unsigned long long *stop_min_in)
+                                              const unsigned long long *stop_min_in, int remote_acc)
 {
     unsigned short *tab = dh_mi_tab[threadIdx.x >> 6];
     const MiDev M = mi_uniform(M_in);
@@ -407,6 +420,7 @@ __device__ __noinline__ FwSegOut mi_run_ranks(const MiDev M_in, int T, int cand,
     r1 = mi_rfl64(r1);
     const int32_t *acc = (const int32_t *)mi_rfl64((unsigned long long)acc_in);
     const unsigned long long *stop_min = (const unsigned long long *)mi_rfl64((unsigned long long)stop_min_in);
+    remote_acc = __builtin_amdgcn_readfirstlane(remote_acc);
     FwSegOut o;
     o.stop_rank = FW_RANK_NONE;
     o.stop_stat = o.stop_pval = 0.0;
@@ -433,7 +447,8 @@ __device__ __noinline__ FwSegOut mi_run_ranks(const MiDev M_in, int T, int cand,
         if (stop_min && mi_ld_u64(stop_min) < r) break;  // an earlier rank already ended the job
         MiZs zs;
 #pragma unroll
-        for (int q = 0; q < MI_MAX_K; ++q) zs.v[q] = (q < s) ? acc[pos[q]] : 0;
+        for (int q = 0; q < MI_MAX_K; ++q)  // remote_acc: another wavefront's list, read where it was written through (sc1)
+            zs.v[q] = (q < s) ? (remote_acc ? __hip_atomic_load(&acc[pos[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : acc[pos[q]]) : 0;
         MiRes t = mi_test_core<L, NXY, PRE>(M, T, cand, zs, s, tab);
         ++o.evaluated;
         const int ev = mi_account(M, t, max_tests > 0 && r + 1ull >= (unsigned long long)max_tests, mb, false);  // tests.jl:326-341
@@ -466,18 +481,104 @@ __device__ __noinline__ FwSegOut mi_run_ranks(const MiDev M_in, int T, int cand,
     return o;
 }
 
-// claim and evaluate one record of board b (if any is left); true if a record was processed
-template <int L, int NXY, bool PRE>
-__device__ __forceinline__ bool mi_board_work(MiBoard *__restrict__ b, FwSegOut *__restrict__ res, const DhArrays &A, const MiDev &M,
-                                              const DhParams &P, int lane)
+// one record = 9 64-bit words (FwSegOut), written through / read back word by word
+__device__ __forceinline__ void mi_record_store(FwSegOut *dst, const FwSegOut &o)
 {
-    const unsigned int nch = b->nch;
+    unsigned long long w[9];
+    __builtin_memcpy(w, &o, sizeof(w));
+    unsigned long long *d = (unsigned long long *)dst;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) mi_st_u64(d + q, w[q]);
+}
+__device__ __forceinline__ FwSegOut mi_record_load(const FwSegOut *src)
+{
+    unsigned long long w[9];
+    const unsigned long long *d = (const unsigned long long *)src;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) w[q] = mi_ld_u64(d + q);
+    FwSegOut o;
+    __builtin_memcpy(&o, w, sizeof(w));
+    return o;
+}
+static_assert(sizeof(FwSegOut) == 72, "FwSegOut is nine 64-bit words");
+
+// dh_merge over records another wavefront wrote through (sc1 loads)
+__device__ __forceinline__ DhMerge mi_merge(const FwSegOut *__restrict__ so, long long base, int nseg, int lane)
+{
+    unsigned long long ev = 0ull;
+    int my_stop = 0x7fffffff;
+    double st_stat = 0.0, st_p = 0.0;
+    int st_pow = 0;
+    unsigned long long st_rank = 0ull;
+    double bp = -2.0, bs = 0.0;
+    int bi = -1;
+    for (int sg = lane; sg < nseg; sg += 64) {
+        const FwSegOut o = mi_record_load(so + base + sg);
+        ev += o.evaluated;
+        if (o.stop_rank != FW_RANK_NONE) {
+            if (my_stop == 0x7fffffff) {
+                my_stop = sg;
+                st_stat = o.stop_stat;
+                st_p = o.stop_pval;
+                st_pow = o.stop_power;
+                st_rank = o.stop_rank;
+            }
+        } else if (o.best_pval >= bp) {
+            bp = o.best_pval;
+            bs = o.best_stat;
+            bi = sg;
+        }
+    }
+    int first = my_stop;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ev += __shfl_xor(ev, o);
+        const int f2 = __shfl_xor(first, o);
+        first = f2 < first ? f2 : first;
+        const double p2 = __shfl_xor(bp, o), s2 = __shfl_xor(bs, o);
+        const int i2 = __shfl_xor(bi, o);
+        if (p2 > bp || (p2 == bp && i2 > bi)) {
+            bp = p2;
+            bs = s2;
+            bi = i2;
+        }
+    }
+    DhMerge M;
+    M.ev = ev;
+    if (first != 0x7fffffff) {
+        const int owner = first & 63;
+        M.stop = true;
+        M.stat = __shfl(st_stat, owner);
+        M.p = __shfl(st_p, owner);
+        M.pow = __shfl(st_pow, owner);
+        M.nt = __shfl(st_rank, owner) + 1ull;
+    } else {
+        M.stop = false;
+        M.stat = bs;
+        M.p = bi >= 0 ? bp : -2.0;
+        M.pow = 1;
+        M.nt = 0ull;
+    }
+    return M;
+}
+
+// claim and evaluate one record of board b (if any is left); true if a record was processed.  acc_own: the caller published the board (its accepted list is at hand); otherwise the list is
+// staged from the board's write-through copy.
+template <int L, int NXY, bool PRE>
+__device__ __forceinline__ bool mi_board_work(MiBoard *__restrict__ b, FwSegOut *__restrict__ res, const int32_t *__restrict__ bacc,
+                                              const int32_t *acc_own, const MiDev &M, const DhParams &P, int lane)
+{
+    const unsigned long long nr = mi_ld_u64(&b->nr);
+    const unsigned int nch = (unsigned int)nr, res_off = (unsigned int)(nr >> 32);
     if (mi_ld_u32(&b->next_chunk) >= nch) return false;
     const unsigned int c = mi_wave_add(&b->next_chunk, 1u, lane);
     if (c >= nch) return false;
-    const unsigned long long r0 = b->start + (unsigned long long)c * (unsigned long long)b->chunk;
-    unsigned long long r1 = r0 + (unsigned long long)b->chunk;
-    if (r1 > b->end) r1 = b->end;
+    const unsigned long long tc = mi_ld_u64(&b->tc), ac = mi_ld_u64(&b->ac);
+    const int a = (int)(unsigned int)ac, chunk = (int)(unsigned int)(ac >> 32);
+    const unsigned long long start = mi_ld_u64(&b->start), end = mi_ld_u64(&b->end);
+    const unsigned long long r0 = start + (unsigned long long)c * (unsigned long long)chunk;
+    unsigned long long r1 = r0 + (unsigned long long)chunk;
+    if (r1 > end) r1 = end;
     FwSegOut o;
     if (mi_ld_u64(&b->stop_min) < r0) {  // cancelled: an earlier rank stopped the job
         o.stop_rank = FW_RANK_NONE;
@@ -488,21 +589,39 @@ __device__ __forceinline__ bool mi_board_work(MiBoard *__restrict__ b, FwSegOut 
         o.stop_df = o.stop_power = o.best_df = o.pad = 0;
         o.evaluated = 0ull;
     } else {
-        o = mi_run_ranks<L, NXY, PRE>(M, b->T, b->cand, A.acc + b->acc_off, b->a, P.max_k, P.max_tests, r0, r1, &b->stop_min);
+        const int32_t *acc = acc_own;
+        int remote = 0;
+        if (!acc_own) {
+            const int32_t *src = bacc + mi_ld_u64(&b->acc_off);
+            if (a <= MI_ACC_LDS) {  // one coalesced sc1 sweep into this wavefront's LDS slot
+                int32_t *slot = dh_mi_acc[threadIdx.x >> 6];
+                for (int i = lane; i < a; i += 64) slot[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                acc = slot;
+            } else {
+                acc = src;
+                remote = 1;
+            }
+        }
+        o = mi_run_ranks<L, NXY, PRE>(M, (int)(unsigned int)tc, (int)(unsigned int)(tc >> 32), acc, a, P.max_k, P.max_tests, r0, r1,
+                                      &b->stop_min, remote);
         if (o.stop_rank != FW_RANK_NONE && lane == 0) atomicMin(&b->stop_min, o.stop_rank);
     }
     if (lane == 0) {
-        res[b->res_off + c] = o;
-        __threadfence();  // the record before the count
+        mi_record_store(res + res_off + c, o);
+        mi_drain();  // the record before the count
         atomicAdd(&b->done, 1u);
     }
     return true;
 }
 
-// look for an open board and work on one record of it; true if something was done
+// look for an open board (from the first one that still has unclaimed records) and work on one record of it; true if
+// something was done.  (A global FIFO of records with a compare-and-swap head was tried instead of the scan: 10x slower --
+// a thousand wavefronts polling and swapping the same two words.)
 template <int L, int NXY, bool PRE>
 __device__ __noinline__ bool mi_help(MiQueue *__restrict__ Q, MiBoard *__restrict__ boards, FwSegOut *__restrict__ res,
-                                        const DhArrays &A, const MiDev &M, const DhParams &P, int lane)
+                                     const int32_t *__restrict__ bacc, const MiDev &M, const DhParams &P, int lane)
 {
     unsigned int nb = mi_ld_u32(&Q->n_boards);
     if (nb > MI_BOARD_CAP) nb = MI_BOARD_CAP;
@@ -510,9 +629,8 @@ __device__ __noinline__ bool mi_help(MiQueue *__restrict__ Q, MiBoard *__restric
     for (; i < nb; ++i) {
         MiBoard *b = boards + i;
         if (mi_ld_u32(&b->ready) == 0u) return false;  // reserved, not yet filled
-        if (mi_ld_u32(&b->next_chunk) < b->nch) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the owner's accepted list
-            if (mi_board_work<L, NXY, PRE>(b, res, A, M, P, lane)) return true;
+        if (mi_ld_u32(&b->next_chunk) < (unsigned int)mi_ld_u64(&b->nr)) {
+            if (mi_board_work<L, NXY, PRE>(b, res, bacc, nullptr, M, P, lane)) return true;
         } else if (i == mi_ld_u32(&Q->hint) && lane == 0) {
             atomicMax(&Q->hint, i + 1u);  // every record of this board is taken: later scans start behind it
         }
@@ -523,25 +641,19 @@ __device__ __noinline__ bool mi_help(MiQueue *__restrict__ Q, MiBoard *__restric
 template <int L, int NXY, bool PRE>
 __global__ __launch_bounds__(256) void dh_mi_target_kernel(DhTgt *__restrict__ tg, int ntg, const int32_t *__restrict__ order,
                                                            DhArrays A, MiDev M, DhParams P, MiQueue *__restrict__ Q,
-                                                           MiBoard *__restrict__ boards, FwSegOut *__restrict__ res)
+                                                           MiBoard *__restrict__ boards, FwSegOut *__restrict__ res,
+                                                           int32_t *__restrict__ bacc)
 {
     const int lane = threadIdx.x & 63;
     for (;;) {
         const unsigned int slot = mi_wave_add(&Q->next_target, 1u, lane);
         if (slot >= (unsigned int)ntg) break;
         const int t = order[slot];
-        // the target's state lives in LDS (one copy per wavefront, every lane stores the same values): kept in registers
-        // it is ~45 VGPRs that stay live across the calls of the test routine
-#ifdef DH_MI_X_LDS
-        DhTgt &x = dh_mi_x[threadIdx.x >> 6];
-        x = tg[t];
-#else
         DhTgt x = tg[t];
-#endif
         while (dh_advance(x, A, lane, 1)) {
             // other targets' big enumerations first: they are the critical path of the pass
             if (P.mi_help_jobs)
-                while (mi_ld_u32(&Q->n_boards) > mi_ld_u32(&Q->hint) && mi_help<L, NXY, PRE>(Q, boards, res, A, M, P, lane)) {
+                while (mi_ld_u32(&Q->n_boards) > mi_ld_u32(&Q->hint) && mi_help<L, NXY, PRE>(Q, boards, res, bacc, M, P, lane)) {
                 }
             const int32_t *cands = x.phase == 0 ? A.cand0 + x.cand_off : A.tpc_key + x.co;
             const int32_t cand = cands[x.pos];
@@ -555,7 +667,7 @@ __global__ __launch_bounds__(256) void dh_mi_target_kernel(DhTgt *__restrict__ t
             if (P.max_tests > 0 && (unsigned long long)P.max_tests < N) N = (unsigned long long)P.max_tests;
             // the first tests: alone
             unsigned long long next = N < (unsigned long long)P.mi_seq ? N : (unsigned long long)P.mi_seq;
-            FwSegOut o = mi_run_ranks<L, NXY, PRE>(M, x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, 0ull, next, nullptr);
+            FwSegOut o = mi_run_ranks<L, NXY, PRE>(M, x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, 0ull, next, nullptr, 0);
             unsigned long long ev = o.evaluated, nt = 0ull;
             bool stopped = o.stop_rank != FW_RANK_NONE;
             double r_stat = stopped ? o.stop_stat : 0.0, r_p = stopped ? o.stop_pval : 0.0;
@@ -563,19 +675,29 @@ __global__ __launch_bounds__(256) void dh_mi_target_kernel(DhTgt *__restrict__ t
             double best_p = o.best_pval, best_stat = o.best_stat;
             if (stopped) nt = o.stop_rank + 1ull;
             unsigned long long width = P.mi_win0;
+            unsigned int bacc_off = MI_BACC_CAP;  // this job's write-through copy of its accepted list (made with its first board)
             while (!stopped && next < N) {
                 const unsigned long long W = (N - next) < width ? (N - next) : width;
                 unsigned long long chunk = W / (unsigned long long)P.mi_chunk_div;
                 chunk = chunk < P.mi_chunk_min ? P.mi_chunk_min : (chunk > P.mi_chunk_max ? P.mi_chunk_max : chunk);
                 const unsigned int nch = (unsigned int)((W + chunk - 1ull) / chunk);
                 unsigned int bi = MI_BOARD_CAP, ro = MI_REC_CAP;
-                if (mi_ld_u32(&Q->n_boards) < MI_BOARD_CAP && mi_ld_u32(&Q->res_top) + nch <= MI_REC_CAP) {
+                if (bacc_off == MI_BACC_CAP && mi_ld_u32(&Q->bacc_top) + (unsigned int)a <= MI_BACC_CAP) {
+                    bacc_off = mi_wave_add(&Q->bacc_top, (unsigned int)a, lane);
+                    if (bacc_off + (unsigned int)a > MI_BACC_CAP) {
+                        bacc_off = MI_BACC_CAP;
+                    } else {
+                        const int32_t *src = A.acc + acc_off;
+                        for (int i = lane; i < a; i += 64) __hip_atomic_store(bacc + bacc_off + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                if (bacc_off != MI_BACC_CAP && mi_ld_u32(&Q->n_boards) < MI_BOARD_CAP && mi_ld_u32(&Q->res_top) + nch <= MI_REC_CAP) {
                     ro = mi_wave_add(&Q->res_top, nch, lane);
                     if (ro + nch <= MI_REC_CAP) bi = mi_wave_add(&Q->n_boards, 1u, lane);
                 }
                 DhMerge mg;
                 if (bi >= MI_BOARD_CAP) {  // out of board space (never at the benchmark sizes): the owner carries on alone
-                    const FwSegOut q = mi_run_ranks<L, NXY, PRE>(M, x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, next, next + W, nullptr);
+                    const FwSegOut q = mi_run_ranks<L, NXY, PRE>(M, x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, next, next + W, nullptr, 0);
                     mg.stop = q.stop_rank != FW_RANK_NONE;
                     mg.stat = mg.stop ? q.stop_stat : q.best_stat;
                     mg.p = mg.stop ? q.stop_pval : (q.best_pval < 0.0 ? -2.0 : q.best_pval);
@@ -584,36 +706,31 @@ __global__ __launch_bounds__(256) void dh_mi_target_kernel(DhTgt *__restrict__ t
                     mg.ev = q.evaluated;
                 } else {
                     MiBoard *b = boards + bi;
+                    mi_drain();  // the copy of the accepted list (every lane's stores) ...
                     if (lane == 0) {
-                        b->T = x.T;
-                        b->cand = cand;
-                        b->a = a;
-                        b->chunk = (int32_t)chunk;
-                        b->acc_off = acc_off;
-                        b->start = next;
-                        b->end = next + W;
-                        b->nch = nch;
-                        b->res_off = ro;
-                        b->next_chunk = 0u;
-                        b->done = 0u;
-                        b->stop_min = FW_RANK_NONE;
-                        __threadfence();  // board and accepted list before the flag
-                        __hip_atomic_store(&b->ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        mi_st_u64(&b->tc, (unsigned long long)(unsigned int)x.T | ((unsigned long long)(unsigned int)cand << 32));
+                        mi_st_u64(&b->ac, (unsigned long long)(unsigned int)a | ((unsigned long long)chunk << 32));
+                        mi_st_u64(&b->acc_off, (unsigned long long)bacc_off);
+                        mi_st_u64(&b->start, next);
+                        mi_st_u64(&b->end, next + W);
+                        mi_st_u64(&b->nr, (unsigned long long)nch | ((unsigned long long)ro << 32));
+                        mi_st_u64(&b->stop_min, FW_RANK_NONE);  // next_chunk / done are zero from the launch's memset
+                        mi_drain();  // ... and the board before the flag
+                        mi_st_u32(&b->ready, 1u);
                     }
-                    while (mi_board_work<L, NXY, PRE>(b, res, A, M, P, lane)) {
+                    while (mi_board_work<L, NXY, PRE>(b, res, bacc, A.acc + acc_off, M, P, lane)) {
                     }
                     unsigned int spins = 0u;
                     while (mi_ld_u32(&b->done) < nch) {  // records claimed by other wavefronts: they are running
-                        if (!mi_help<L, NXY, PRE>(Q, boards, res, A, M, P, lane)) {
-                            __builtin_amdgcn_s_sleep(4);
+                        if (!mi_help<L, NXY, PRE>(Q, boards, res, bacc, M, P, lane)) {
+                            __builtin_amdgcn_s_sleep(2);
                             if (++spins > (1u << 27)) {  // ~30 s: a logic error, not a workload -- report instead of hanging the GPU
                                 if (lane == 0) atomicExch(&Q->pad[0], 1u);
                                 break;
                             }
                         }
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    mg = dh_merge(res, (long long)ro, (int)nch, lane);
+                    mg = mi_merge(res, (long long)ro, (int)nch, lane);
                 }
                 ev += mg.ev;
                 if (mg.stop) {
@@ -643,14 +760,13 @@ __global__ __launch_bounds__(256) void dh_mi_target_kernel(DhTgt *__restrict__ t
         }
         if (lane == 0) {
             tg[t] = x;
-            __threadfence();
-            atomicAdd(&Q->targets_done, 1u);
+            atomicAdd(&Q->targets_done, 1u);  // (a termination count, not a hand-off: the host reads tg after the kernel)
         }
     }
     // no targets left to start: work on boards until every target has finished
     unsigned int spins = 0u;
     while (mi_ld_u32(&Q->targets_done) < (unsigned int)ntg && mi_ld_u32(&Q->pad[0]) == 0u) {
-        if (!mi_help<L, NXY, PRE>(Q, boards, res, A, M, P, lane)) {
+        if (!mi_help<L, NXY, PRE>(Q, boards, res, bacc, M, P, lane)) {
             __builtin_amdgcn_s_sleep(8);
             if (++spins > (1u << 27)) {
                 if (lane == 0) atomicExch(&Q->pad[0], 2u);
@@ -1139,7 +1255,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     // over the segment kernel (the path of the ABI's fw_test_subsets_batch) for comparison
     static const bool mi_rounds = [] { const char *e = getenv("FW_MI_ROUNDS"); return e && atoi(e) != 0; }();
     const bool per_target = c->P.kind != FW_FZ && !mi_rounds;
-    if (per_target) need += pad(sizeof(MiQueue)) + pad(sizeof(MiBoard) * MI_BOARD_CAP) + pad(sizeof(FwSegOut) * MI_REC_CAP);
+    if (per_target) need += pad(sizeof(MiQueue)) + pad(sizeof(MiBoard) * MI_BOARD_CAP) + pad(sizeof(FwSegOut) * MI_REC_CAP) + pad(sizeof(int32_t) * MI_BACC_CAP);
     int rc;
     if ((rc = fw_dev_reserve(c, c->d_dh[chain], need))) return rc;
     if ((rc = fw_pin_reserve(c, c->h_dh[chain], 4096))) return rc;
@@ -1176,6 +1292,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     MiQueue *d_mq = per_target ? (MiQueue *)carve(sizeof(MiQueue)) : nullptr;
     MiBoard *d_boards = per_target ? (MiBoard *)carve(sizeof(MiBoard) * MI_BOARD_CAP) : nullptr;
     FwSegOut *d_mres = per_target ? (FwSegOut *)carve(sizeof(FwSegOut) * MI_REC_CAP) : nullptr;
+    int32_t *d_bacc = per_target ? (int32_t *)carve(sizeof(int32_t) * MI_BACC_CAP) : nullptr;
     FW_HIP(c, hipMemcpyAsync(d_tg, tg.data(), sizeof(DhTgt) * ntg, hipMemcpyHostToDevice, st));
     hg[0].n_act = (unsigned int)ntg;  // every target starts on the list (the pinned page is the staging copy: stream-ordered)
     FW_HIP(c, hipMemcpyAsync(d_g, hg, sizeof(DhGlobal), hipMemcpyHostToDevice, st));
@@ -1299,11 +1416,11 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->P.device);
         const unsigned grid = std::min((unsigned)((ntg + 3) / 4), wg_per_cu * (unsigned)n_cu);
         FW_HIP(c, hipMemsetAsync(d_mq, 0, sizeof(MiQueue), st));
-        FW_HIP(c, hipMemsetAsync(d_boards, 0, sizeof(MiBoard) * MI_BOARD_CAP, st));  // ready flags
+        FW_HIP(c, hipMemsetAsync(d_boards, 0, sizeof(MiBoard) * MI_BOARD_CAP, st));  // ready flags, claimed / finished counts
         FW_HIP(c, hipEventRecord(ev[0][0], st));
 #define DH_MI_LAUNCH(LL, NN, PP)                                                                                                  \
     hipLaunchKernelGGL((dh_mi_target_kernel<LL, NN, PP>), dim3(grid), dim3(256), 0, st, d_tg, ntg, (const int32_t *)d_act, A, M, P, \
-                       d_mq, d_boards, d_mres)
+                       d_mq, d_boards, d_mres, d_bacc)
         const bool pre = c->P.n <= MI_PRE_N && c->P.max_k <= MI_PRE_K;
         if (c->L == 2) {
             if (pre) DH_MI_LAUNCH(2, 2, true); else DH_MI_LAUNCH(2, 2, false);
