@@ -131,6 +131,9 @@ def cpu_baseline(args, cfg, data, n, p, eng, level0_per_step):
 
         def mk():
             return O.Oracle("fz", cor_mat=shared["cm"], n_obs=n)
+    elif kind == "fz_nz":
+        def mk():
+            return O.Oracle("fz_nz", data)
     else:
         shared["csc"] = O.dense_to_csc(data)
 

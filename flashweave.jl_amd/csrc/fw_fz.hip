@@ -1502,7 +1502,37 @@ __global__ __launch_bounds__(256) void fznz_level0_kernel(const float *__restric
 }
 
 // ---- per-job correlation sub-matrix (Statistics.cor of the row view restricted to {T, cand} + accepted) ----
+// Summation order ("tree64", mirrored by oracle/fw_oracle.c fz_nz_tree64): the rows R of the view are numbered q = 0, 1, ...
+// in ascending row order; lane l of a wavefront adds the terms q = l, l + 64, ... sequentially in Float64, and the 64
+// partials are combined in a fixed tree: pairs (l, l^1), then (l, l^2), then inside every group of 16 lanes
+// (Q3 + Q2) + (Q1 + Q0), then (R3 + R2) + (R1 + R0) over the four groups -- the DPP network's natural order.  One
+// wavefront per sum (a column mean, a column norm, a pair's dot product), the four wavefronts of the workgroup take
+// the sums of a job in turn.  r01 walked the rows sequentially in one lane per pair: serial by construction, 113 of the
+// 125 ms of a pass at 3 000 variables.
 #define FZNZ_MAXM_LDS 2050
+#define FZNZ_ROWS_LDS 16384  // rows of a view kept as an LDS list (n beyond that: the sequential form)
+
+__device__ __forceinline__ double fznz_tree64(double v)  // every lane returns the total
+{
+#define FZNZ_DPP_ADDD(ctrl, rmask)                                                                                         \
+    {                                                                                                                      \
+        const long long b = __double_as_longlong(v);                                                                       \
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, ctrl, rmask, 0xf, false);           \
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), ctrl, rmask, 0xf, false);   \
+        v += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));                                       \
+    }
+    FZNZ_DPP_ADDD(0xb1, 0xf)   // quad_perm:[1,0,3,2]
+    FZNZ_DPP_ADDD(0x4e, 0xf)   // quad_perm:[2,3,0,1]
+    FZNZ_DPP_ADDD(0x114, 0xf)  // row_shr:4
+    FZNZ_DPP_ADDD(0x118, 0xf)  // row_shr:8
+    FZNZ_DPP_ADDD(0x142, 0xa)  // row_bcast:15
+    FZNZ_DPP_ADDD(0x143, 0xc)  // row_bcast:31
+#undef FZNZ_DPP_ADDD
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 __global__ __launch_bounds__(256) void fznz_submat_kernel(const float *__restrict__ data, const unsigned long long *__restrict__ nz,
                                                           int n, int W, FwNzJob *__restrict__ recs,
                                                           const int32_t *__restrict__ accflat, float *__restrict__ arena,
@@ -1510,14 +1540,88 @@ __global__ __launch_bounds__(256) void fznz_submat_kernel(const float *__restric
 {
     __shared__ double s_mean[FZNZ_MAXM_LDS], s_sd[FZNZ_MAXM_LDS], s_ss01[2];
     __shared__ int s_var[FZNZ_MAXM_LDS];
+    __shared__ unsigned short s_rows[FZNZ_ROWS_LDS];
+    __shared__ int s_woff[257];
     FwNzJob *rec = recs + blockIdx.x;
-    const int m = rec->m, tid = threadIdx.x;
+    const int m = rec->m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long *mx = nz + (size_t)rec->X * W, *my = nz + (size_t)rec->Y * W;
     for (int t = tid; t < m; t += 256) s_var[t] = t == 0 ? rec->X : (t == 1 ? rec->Y : accflat[rec->acc_off + t - 2]);
     long long nR = 0;
     for (int w = 0; w < W; ++w) nR += __popcll(mx[w] & my[w]);
+    float *local = arena + rec->cor_off;
+    const long long npairs = (long long)m * (m - 1) / 2;
+    const bool tree = rec->acc_len > 0 && n <= FZNZ_ROWS_LDS && W <= 256;  // wave-uniform (workgroup-uniform)
+    if (tree) {
+        // row list of the view, ascending: word w of the AND mask expands behind the rows of the words before it
+        if (tid < W) s_woff[tid + 1] = __popcll(mx[tid] & my[tid]);
+        if (tid == 0) s_woff[0] = 0;
+        __syncthreads();
+        if (tid == 0)
+            for (int w = 0; w < W; ++w) s_woff[w + 1] += s_woff[w];
+        __syncthreads();
+        if (tid < W) {
+            unsigned long long mk = mx[tid] & my[tid];
+            int o = s_woff[tid];
+            while (mk) {
+                s_rows[o++] = (unsigned short)(tid * 64 + __builtin_ctzll(mk));
+                mk &= mk - 1;
+            }
+        }
+        __syncthreads();
+        const int nr = (int)nR;
+        for (int t = wave; t < m; t += 4) {  // column means and norms
+            const float *col = data + (size_t)s_var[t] * n;
+            double sacc = 0.0;
+            for (int q = lane; q < nr; q += 64) sacc += (double)col[s_rows[q]];
+            const double mean = fznz_tree64(sacc) / (double)nR;
+            double ss = 0.0;
+            for (int q = lane; q < nr; q += 64) {
+                const double d = (double)col[s_rows[q]] - mean;
+                ss += d * d;
+            }
+            ss = fznz_tree64(ss);
+            if (lane == 0) {
+                s_mean[t] = mean;
+                s_sd[t] = sqrt(ss);
+            }
+        }
+        __syncthreads();
+        for (long long q0 = wave; q0 < npairs; q0 += 4) {  // one wavefront per pair
+            int a = (int)(((2.0 * m - 1.0) - sqrt((2.0 * m - 1.0) * (2.0 * m - 1.0) - 8.0 * (double)q0)) * 0.5);
+            while (a > 0 && (long long)a * (2 * m - a - 1) / 2 > q0) --a;
+            while ((long long)(a + 1) * (2 * m - a - 2) / 2 <= q0) ++a;
+            const int b = a + 1 + (int)(q0 - (long long)a * (2 * m - a - 1) / 2);
+            const float *ca = data + (size_t)s_var[a] * n, *cb = data + (size_t)s_var[b] * n;
+            const double ma = s_mean[a], mb = s_mean[b];
+            double sacc = 0.0;
+            for (int q = lane; q < nr; q += 64) {
+                const int row = s_rows[q];
+                sacc += ((double)ca[row] - ma) * ((double)cb[row] - mb);
+            }
+            sacc = fznz_tree64(sacc);
+            double r = sacc / (s_sd[a] * s_sd[b]);
+            if (r > 1.0) r = 1.0;
+            if (r < -1.0) r = -1.0;
+            if (isnan(r)) r = 0.0;  // statfuns.jl:150
+            const float rf = (float)r;  // the scratch matrix of the reference is Float32 (learning.jl:127-129)
+            if (lane == 0) {
+                local[(size_t)a * m + b] = rf;
+                local[(size_t)b * m + a] = rf;
+            }
+        }
+        for (int t = tid; t < m; t += 256) local[(size_t)t * m + t] = 1.0f;
+        if (tid == 0) {
+            rec->rxy = 0.0;  // (only univariate jobs read it: they take the sequential form below)
+            rec->nR = (int32_t)nR;
+            const long long sf = nR - 3;
+            rec->zscale = sf > 0 ? sqrt((double)sf) / 2.0 : 0.0;
+            fz_thresholds_dev(alpha, rec->zscale, rec->thr);
+        }
+        return;
+    }
     __syncthreads();
-    // column means and norms over R (sequential Float64 sums in row order)
+    // sequential form (univariate jobs -- their pair statistic must equal level 0's, statfuns.jl:91-123 in row order -- and
+    // views beyond the LDS row list): column means and norms over R, sequential Float64 sums in row order
     for (int t = tid; t < m; t += 256) {
         const float *col = data + (size_t)s_var[t] * n;
         double sacc = 0.0;
@@ -1545,8 +1649,6 @@ __global__ __launch_bounds__(256) void fznz_submat_kernel(const float *__restric
         if (t < 2) s_ss01[t] = ss;
     }
     __syncthreads();
-    float *local = arena + rec->cor_off;
-    const long long npairs = (long long)m * (m - 1) / 2;
     for (long long q = tid; q < npairs; q += 256) {
         // pair index -> (a, b), a < b, row-major over the upper triangle
         int a = (int)(((2.0 * m - 1.0) - sqrt((2.0 * m - 1.0) * (2.0 * m - 1.0) - 8.0 * (double)q)) * 0.5);

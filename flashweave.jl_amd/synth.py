@@ -68,4 +68,7 @@ CONFIGS = {
     "cfg3": dict(p=10000, n=2000, seed=20260931, mode="S", test_name="fz", max_k=3),
     "cfg4": dict(p=50000, n=5000, seed=20260932, mode="F", test_name="mi_nz", max_k=3, habitats=4, n_meta=20),
     "cfg5": dict(p=100000, n=10000, seed=20260933, mode="S", test_name="fz", max_k=5),
+    # not a BASELINE config: FlashWeaveHE-S (fz_nz) on cfg3's shape with habitat-wise structural absences and the
+    # 20 meta variables of the HE generator -- the bench / profile line of the zero-ignoring Fisher-z path
+    "cfg3he": dict(p=3000, n=2000, seed=20260934, mode="S", test_name="fz_nz", max_k=3, habitats=4, n_meta=20),
 }

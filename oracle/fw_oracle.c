@@ -1081,6 +1081,28 @@ static void fz_nz_test_uni(const fwo_ctx *c, int X, int Y, int64_t n_obs_min, fw
     set_result(out, p_stat, fwo_fz_pval(p_stat, n_obs, 0), 0, n_obs >= n_obs_min);
 }
 
+static double fz_nz_seq(const double *t, int64_t n)
+{
+    double s = 0.0;
+    for (int64_t q = 0; q < n; ++q) s += t[q];
+    return s;
+}
+/* "tree64": lane l adds the terms q = l, l + 64, ... in order; the 64 partials are combined as pairs (l, l^1), then (l, l^2),
+ * then inside every group of 16 lanes (Q3 + Q2) + (Q1 + Q0), then (R3 + R2) + (R1 + R0) -- the order of the device's DPP
+ * reduction (fznz_tree64 in csrc/fw_fz.hip) */
+static double fz_nz_tree64(const double *t, int64_t n)
+{
+    double part[64], Q[16], R[4];
+    for (int l = 0; l < 64; ++l) {
+        double s = 0.0;
+        for (int64_t q = l; q < n; q += 64) s += t[q];
+        part[l] = s;
+    }
+    for (int j = 0; j < 16; ++j) Q[j] = (part[4 * j] + part[4 * j + 1]) + (part[4 * j + 2] + part[4 * j + 3]);
+    for (int r = 0; r < 4; ++r) R[r] = (Q[4 * r + 3] + Q[4 * r + 2]) + (Q[4 * r + 1] + Q[4 * r]);
+    return (R[3] + R[2]) + (R[1] + R[0]);
+}
+
 /* statfuns.jl:138-155 cor_subset!: Statistics.cor of the rows R (both X and Y non-zero, hiton.jl:41-50,85) restricted
  * to vars; NaN -> 0; stored in a Float32 matrix (learning.jl:127-129, cont_type = Float32).  local: m x m floats. */
 static int64_t fz_nz_cor_subset(const fwo_ctx *c, int X, int Y, const int *vars, int m, float *local)
@@ -1119,24 +1141,28 @@ static int64_t fz_nz_cor_subset(const fwo_ctx *c, int X, int Y, const int *vars,
             free(xc);
             free(sd);
         } else {
+            /* Float64 sums in the device's order (csrc/fw_fz.hip fznz_submat_kernel, "tree64"): 64 interleaved partials over
+             * the rows of the view in ascending order, combined in a fixed tree.  Univariate jobs (m == 2: the pair statistic
+             * must equal level 0's sequential fz_nz_pair_cor) and views beyond the device's LDS row list keep the sequential
+             * order.  The reference's own order (Statistics.cor on a view, BLAS) is not knowable: a tolerance either way. */
+            const int tree = m > 2 && c->n <= 16384;
             double *xc = (double *)malloc(sizeof(double) * (size_t)(nr * m));
             double *sd = (double *)malloc(sizeof(double) * (size_t)m);
+            double *term = (double *)malloc(sizeof(double) * (size_t)nr);
             for (int a = 0; a < m; ++a) {
-                double s = 0.0;
-                for (int64_t q = 0; q < nR; ++q) s += FD(c, rows[q], vars[a]);
-                const double mean = s / (double)nR;
-                double ss = 0.0;
+                for (int64_t q = 0; q < nR; ++q) term[q] = FD(c, rows[q], vars[a]);
+                const double mean = (tree ? fz_nz_tree64(term, nR) : fz_nz_seq(term, nR)) / (double)nR;
                 for (int64_t q = 0; q < nR; ++q) {
                     const double d = FD(c, rows[q], vars[a]) - mean;
                     xc[(int64_t)a * nr + q] = d;
-                    ss += d * d;
+                    term[q] = d * d;
                 }
-                sd[a] = sqrt(ss);
+                sd[a] = sqrt(tree ? fz_nz_tree64(term, nR) : fz_nz_seq(term, nR));
             }
             for (int a = 0; a < m; ++a)
                 for (int b = a + 1; b < m; ++b) {
-                    double s = 0.0;
-                    for (int64_t q = 0; q < nR; ++q) s += xc[(int64_t)a * nr + q] * xc[(int64_t)b * nr + q];
+                    for (int64_t q = 0; q < nR; ++q) term[q] = xc[(int64_t)a * nr + q] * xc[(int64_t)b * nr + q];
+                    const double s = tree ? fz_nz_tree64(term, nR) : fz_nz_seq(term, nR);
                     double r = s / (sd[a] * sd[b]);
                     if (r > 1.0) r = 1.0;
                     if (r < -1.0) r = -1.0;
@@ -1145,6 +1171,7 @@ static int64_t fz_nz_cor_subset(const fwo_ctx *c, int X, int Y, const int *vars,
                 }
             free(xc);
             free(sd);
+            free(term);
         }
         for (int a = 0; a < m; ++a) local[(int64_t)a * m + a] = 1.0f;
     }
