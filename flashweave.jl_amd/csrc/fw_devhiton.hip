@@ -1177,7 +1177,7 @@ __global__ __launch_bounds__(1024) void dh_compact_kernel(const DhTgt *__restric
 
 // One round of targets on the device.  in: T ids, interleaving candidates and (sorted) whitelists per target;
 // out: PC (keys, statistics, p-values) per target in insertion order.
-int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<FwDhResult> &out, int chain)
+int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<FwDhResult> &out, FwDhFlat &flat, int chain)
 {
     const int ntg = (int)in.size();
     out.assign((size_t)ntg, FwDhResult{});
@@ -1542,8 +1542,11 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
             fclose(f);
         }
     }
-    std::vector<int32_t> pk(tot);
-    std::vector<double> ps(tot), pp(tot);
+    std::vector<int32_t> &pk = flat.key;
+    std::vector<double> &ps = flat.stat, &pp = flat.pval;
+    pk.resize(tot);
+    ps.resize(tot);
+    pp.resize(tot);
     if (tot) {
         FW_HIP(c, hipMemcpy(pk.data(), A.pc_key, 4 * tot, hipMemcpyDeviceToHost));
         FW_HIP(c, hipMemcpy(ps.data(), A.pc_stat, 8 * tot, hipMemcpyDeviceToHost));
@@ -1552,9 +1555,8 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     for (int t = 0; t < ntg; ++t) {
         const DhTgt &x = tg[t];
         if (x.phase != 2) return fw_fail(c, FW_ERR_DEVICE, "device HITON: target %d did not finish (phase %d)", x.T, x.phase);
-        out[t].key.assign(pk.begin() + x.co, pk.begin() + x.co + x.npc);
-        out[t].stat.assign(ps.begin() + x.co, ps.begin() + x.co + x.npc);
-        out[t].pval.assign(pp.begin() + x.co, pp.begin() + x.co + x.npc);
+        out[t].off = x.co;
+        out[t].n = x.npc;
     }
     if (trace_host) {  // chain statistics: the longest per-target sequences bound the pass from below
         unsigned long long mx_ref = 0, mx_calls = 0, tot_ref = 0, tot_calls = 0;

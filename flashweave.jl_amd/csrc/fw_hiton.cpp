@@ -164,18 +164,25 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
     if (opt.max_targets > 0 && opt.max_targets < p) nt = opt.max_targets;
 
     // per-target directed results (all ranks hold all of them after each round's exchange)
-    std::vector<std::vector<int32_t>> pc_key(p);
-    std::vector<std::vector<double>> pc_stat(p), pc_p(p);
+    // directed results of every target in arrival order (a target's entries arrive together, in PC insertion order); the
+    // CSR over targets is built once at the end (vectors of vectors cost 120 000 small allocations per cfg4 pass)
+    std::vector<int32_t> all_t, all_u;
+    std::vector<double> all_s, all_p;
     std::vector<std::vector<int32_t>> adj(p);  // running graph, sorted
+    std::vector<uint8_t> adj_dirty((size_t)p, 0);
+    std::vector<int32_t> dirty;
 
     if (c->P.max_k == 0) {  // learning.jl:171-172
         if (int rc = fwi_nb_host_ensure(c)) return rc;
         for (int v = 0; v < p; ++v) {
             const int64_t o = c->nb_off[v];
             const int deg = (int)(c->nb_off[v + 1] - o);
-            pc_key[v].assign(c->nb_idx.begin() + o, c->nb_idx.begin() + o + deg);
-            pc_stat[v].assign(c->nb_stat.begin() + o, c->nb_stat.begin() + o + deg);
-            pc_p[v].assign(c->nb_p.begin() + o, c->nb_p.begin() + o + deg);
+            for (int q = 0; q < deg; ++q) {
+                all_t.push_back(v);
+                all_u.push_back(c->nb_idx[o + q]);
+                all_s.push_back(c->nb_stat[o + q]);
+                all_p.push_back(c->nb_p[o + q]);
+            }
         }
     } else {
         const int R = (opt.round_size <= 0) ? nt : opt.round_size;
@@ -232,6 +239,8 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                 tg.push_back(std::move(t));
             }
             bool ran_dev = false;
+            std::vector<int32_t> dev_lt, dev_ln;  // device rounds: the round's directed results (target, neighbour, stat, p)
+            std::vector<double> dev_ls, dev_lp;
             {
                 if (use_dev) {
                     std::vector<FwDhTarget> din(tg.size());
@@ -247,6 +256,8 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                         din[i].wl_n = tg[i].wl_n;
                     }
                     std::vector<FwDhResult> dres;
+                    std::vector<std::vector<FwDhResult>> pres;
+                    std::vector<FwDhFlat> pflat;
                     const double tdev0 = now_s();
                     if (getenv("FW_TRACE_HOST")) fprintf(stderr, "[fw] round set-up on the host: %.2f ms\n", 1e3 * (tdev0 - t0));
                     // FW_DH_CHAINS = K (default 2, FlashWeave-S): the round's targets are dealt to K independent chains of device
@@ -264,34 +275,37 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                     const int want = c->P.kind == FW_FZ ? dh_chains : (mi_rounds ? dh_chains_disc : 1);
                     const int K = din.size() >= (size_t)want * dh_chain_min ? want : 1;
                     int rc = FW_OK;
+                    pres.resize((size_t)K);
+                    pflat.resize((size_t)K);
                     if (K == 1) {
-                        rc = fwi_devhiton_run(c, din, dres);
+                        rc = fwi_devhiton_run(c, din, pres[0], pflat[0]);
                     } else {
                         std::vector<std::vector<FwDhTarget>> part((size_t)K);
-                        std::vector<std::vector<FwDhResult>> pres((size_t)K);
                         for (size_t i = 0; i < din.size(); ++i) part[i % (size_t)K].push_back(std::move(din[i]));
                         std::vector<int> rcs((size_t)K, FW_OK);
                         std::vector<std::thread> th;
                         for (int q = 1; q < K; ++q)
                             th.emplace_back([&, q] {
                                 (void)hipSetDevice(c->P.device);
-                                rcs[q] = fwi_devhiton_run(c, part[q], pres[q], q);
+                                rcs[q] = fwi_devhiton_run(c, part[q], pres[q], pflat[q], q);
                             });
-                        rcs[0] = fwi_devhiton_run(c, part[0], pres[0], 0);
+                        rcs[0] = fwi_devhiton_run(c, part[0], pres[0], pflat[0], 0);
                         for (std::thread &t : th) t.join();
                         for (int q = 0; q < K; ++q)
                             if (rcs[q]) rc = rcs[q];
-                        if (!rc) {
-                            dres.resize(din.size());
-                            for (size_t i = 0; i < din.size(); ++i) dres[i] = std::move(pres[i % (size_t)K][i / (size_t)K]);
-                        }
                     }
                     if (rc) return rc;
                     if (getenv("FW_TRACE_HOST")) fprintf(stderr, "[fw] device rounds (all chains): %.2f ms\n", 1e3 * (now_s() - tdev0));
+                    // this round's directed results straight from the chains' flat arrays (target i went to chain i % K)
                     for (size_t i = 0; i < tg.size(); ++i) {
-                        tg[i].PC.key = std::move(dres[i].key);
-                        tg[i].PC.stat = std::move(dres[i].stat);
-                        tg[i].PC.pval = std::move(dres[i].pval);
+                        const FwDhResult &r = pres[i % (size_t)K][i / (size_t)K];
+                        const FwDhFlat &f = pflat[i % (size_t)K];
+                        for (int32_t j = 0; j < r.n; ++j) {
+                            dev_lt.push_back(tg[i].T);
+                            dev_ln.push_back(f.key[(size_t)r.off + j]);
+                            dev_ls.push_back(f.stat[(size_t)r.off + j]);
+                            dev_lp.push_back(f.pval[(size_t)r.off + j]);
+                        }
                         tg[i].phase = 2;
                     }
                     ran_dev = true;
@@ -389,8 +403,8 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
             c->cnt.alg_bytes_subsets += pool.dropped_alg_bytes;
             }  // host pool
             // exchange this round's directed results (target, neighbour, stat, p)
-            std::vector<int32_t> lt, ln;
-            std::vector<double> ls, lp;
+            std::vector<int32_t> lt = std::move(dev_lt), ln = std::move(dev_ln);
+            std::vector<double> ls = std::move(dev_ls), lp = std::move(dev_lp);
             for (Target &t : tg)
                 for (size_t i = 0; i < t.PC.key.size(); ++i) {
                     lt.push_back(t.T);
@@ -407,66 +421,81 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
             }
             for (int64_t i = 0; i < ntot; ++i) {
                 const int32_t T = at[i], u = an[i];
-                pc_key[T].push_back(u);
-                pc_stat[T].push_back(as[i]);
-                pc_p[T].push_back(ap[i]);
+                all_t.push_back(T);
+                all_u.push_back(u);
+                all_s.push_back(as[i]);
+                all_p.push_back(ap[i]);
             }
-            for (int64_t i = 0; i < ntot; ++i) {  // interleaved.jl:136-140 add_edge! (idempotent)
+            // interleaved.jl:136-140 add_edge! (idempotent): both directions appended, the touched lists sorted and
+            // de-duplicated once per round (sorted inserts one entry at a time were 15 ms of a 170 ms cfg4 pass)
+            for (int64_t i = 0; i < ntot; ++i) {
                 const int32_t T = at[i], u = an[i];
-                auto ins = [&](std::vector<int32_t> &v, int32_t x) {
-                    auto it = std::lower_bound(v.begin(), v.end(), x);
-                    if (it == v.end() || *it != x) v.insert(it, x);
-                };
-                ins(adj[T], u);
-                ins(adj[u], T);
+                adj[T].push_back(u);
+                adj[u].push_back(T);
+                if (!adj_dirty[T]) adj_dirty[T] = 1, dirty.push_back(T);
+                if (!adj_dirty[u]) adj_dirty[u] = 1, dirty.push_back(u);
             }
+            for (int32_t v : dirty) {
+                std::vector<int32_t> &l = adj[v];
+                std::sort(l.begin(), l.end());
+                l.erase(std::unique(l.begin(), l.end()), l.end());
+                adj_dirty[v] = 0;
+            }
+            dirty.clear();
         }
     }
     c->cnt.t_cond_s += now_s() - t0;
     if (getenv("FW_TRACE_HOST")) fprintf(stderr, "[fw] conditional stage: %.2f ms\n", 1e3 * (now_s() - t0));
 
+    const double tp0 = now_s();
     if (discrete)
         if (int rc = fwi_nb_host_ensure(c)) return rc;
-    // misc.jl:137-159 make_weights ("cond_stat"): discrete tests take the sign of the univariate statistic
-    std::vector<std::vector<double>> w(p);
-    for (int T = 0; T < p; ++T) {
-        w[T] = pc_stat[T];
-        if (!discrete) continue;
-        const int64_t o = c->nb_off[T];
-        const int deg = (int)(c->nb_off[T + 1] - o);
-        const int32_t *b = c->nb_idx.data() + o;
-        for (size_t i = 0; i < pc_key[T].size(); ++i) {
-            const int32_t *it = std::lower_bound(b, b + deg, pc_key[T][i]);
-            const double us = (it != b + deg && *it == pc_key[T][i]) ? c->nb_stat[o + (it - b)] : NAN;
-            const double sg = std::isnan(us) ? NAN : (double)((us > 0) - (us < 0));
-            w[T][i] = sg * std::fabs(pc_stat[T][i]);
+    if (getenv("FW_TRACE_HOST")) fprintf(stderr, "[fw] neighbour lists to the host: %.2f ms\n", 1e3 * (now_s() - tp0));
+    // CSR over targets (stable: arrival order inside a target = PC insertion order)
+    const size_t ne = all_t.size();
+    c->pc_off.assign((size_t)p + 1, 0);
+    for (size_t i = 0; i < ne; ++i) c->pc_off[(size_t)all_t[i] + 1]++;
+    for (int T = 0; T < p; ++T) c->pc_off[T + 1] += c->pc_off[T];
+    c->pc_idx.assign(ne, 0);
+    c->pc_w.assign(ne, 0.0);
+    c->pc_p.assign(ne, 0.0);
+    {
+        std::vector<int64_t> fill(c->pc_off.begin(), c->pc_off.end() - 1);
+        for (size_t i = 0; i < ne; ++i) {
+            const int64_t d = fill[all_t[i]]++;
+            c->pc_idx[d] = all_u[i];
+            c->pc_w[d] = all_s[i];
+            c->pc_p[d] = all_p[i];
         }
     }
-    c->pc_off.assign((size_t)p + 1, 0);
-    for (int T = 0; T < p; ++T) c->pc_off[T + 1] = c->pc_off[T] + (int64_t)pc_key[T].size();
-    c->pc_idx.clear();
-    c->pc_w.clear();
-    c->pc_p.clear();
-    for (int T = 0; T < p; ++T) {
-        c->pc_idx.insert(c->pc_idx.end(), pc_key[T].begin(), pc_key[T].end());
-        c->pc_w.insert(c->pc_w.end(), w[T].begin(), w[T].end());
-        c->pc_p.insert(c->pc_p.end(), pc_p[T].begin(), pc_p[T].end());
-    }
+    // misc.jl:137-159 make_weights ("cond_stat"): discrete tests take the sign of the univariate statistic
+    if (discrete)
+        for (int T = 0; T < p; ++T) {
+            const int64_t o = c->nb_off[T];
+            const int deg = (int)(c->nb_off[T + 1] - o);
+            const int32_t *b = c->nb_idx.data() + o;
+            for (int64_t i = c->pc_off[T]; i < c->pc_off[T + 1]; ++i) {
+                const int32_t *it = std::lower_bound(b, b + deg, c->pc_idx[i]);
+                const double us = (it != b + deg && *it == c->pc_idx[i]) ? c->nb_stat[o + (it - b)] : NAN;
+                const double sg = std::isnan(us) ? NAN : (double)((us > 0) - (us < 0));
+                c->pc_w[i] = sg * std::fabs(c->pc_w[i]);
+            }
+        }
     // misc.jl:230-272 make_symmetric_graph (OR rule, maxweight merge, NaN edges dropped)
     c->e_src.clear();
     c->e_dst.clear();
     c->e_w.clear();
-    auto find_in = [&](int T, int32_t u) -> int {
-        for (size_t i = 0; i < pc_key[T].size(); ++i)
-            if (pc_key[T][i] == u) return (int)i;
+    auto find_in = [&](int T, int32_t u) -> int64_t {
+        for (int64_t i = c->pc_off[T]; i < c->pc_off[T + 1]; ++i)
+            if (c->pc_idx[i] == u) return i;
         return -1;
     };
     for (int a = 0; a < p; ++a) {
-        for (size_t i = 0; i < pc_key[a].size(); ++i) {  // direction a -> b exists
-            const int32_t b = pc_key[a][i];
+        for (int64_t i = c->pc_off[a]; i < c->pc_off[a + 1]; ++i) {  // direction a -> b exists
+            const int32_t b = c->pc_idx[i];
             if (b <= a) continue;
-            const int ri = find_in(b, a);
-            const double ww = maxweight(w[a][i], ri >= 0 ? w[b][ri] : NAN);
+            const int64_t ri = find_in(b, a);
+            const double ww = maxweight(c->pc_w[i], ri >= 0 ? c->pc_w[ri] : NAN);
             if (std::isnan(ww)) continue;
             c->e_src.push_back(a);
             c->e_dst.push_back(b);
@@ -474,9 +503,9 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
         }
         for (int32_t b : adj[a]) {  // only b -> a exists
             if (b <= a || find_in(a, b) >= 0) continue;
-            const int ri = find_in(b, a);
+            const int64_t ri = find_in(b, a);
             if (ri < 0) continue;
-            const double ww = maxweight(w[b][ri], NAN);
+            const double ww = maxweight(c->pc_w[ri], NAN);
             if (std::isnan(ww)) continue;
             c->e_src.push_back(a);
             c->e_dst.push_back(b);
@@ -487,6 +516,7 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
         // adj was not maintained: every neighbour list is symmetric at level 0, the first loop covers all edges
     }
     c->have_network = true;
+    if (getenv("FW_TRACE_HOST")) fprintf(stderr, "[fw] weights + symmetric graph on the host: %.2f ms\n", 1e3 * (now_s() - tp0));
     if (n_edges_out) *n_edges_out = (int64_t)c->e_src.size();
     return FW_OK;
 }
