@@ -207,175 +207,14 @@ __global__ __launch_bounds__(256) void fz_cor_gemm_kernel(const float *__restric
         }
 }
 
-// ------------------------------------------------------------------------------------------------
-// 3. shared device math
-// ------------------------------------------------------------------------------------------------
-// out of line for the segment kernel: inlined, the ~70 polynomial coefficients of log / erfc are hoisted into VGPRs
-// across the hot loop, which only reaches this code for tests inside the significance guard band
-__device__ __noinline__ double fz_pval_slow(double r, double zscale)
-{
-    double z = (zscale > 0.0) ? zscale * log((1.0 + r) / (1.0 - r)) : 0.0;
-    double cc = erfc(fabs(z) * 0.7071067811865476) / 2.0;
-    // p-values in the subnormal range (< 2.2e-308, |r| > 0.68 at n = 2000) are flushed to zero.  There erfc implementations
-    // differ in the last unit of the subnormal grid (device library vs glibc vs Julia's openlibm: 0 vs 9.9e-324 observed),
-    // and since candidates are ordered by p (hiton.jl:212-215) such a difference reorders the conditioning sets of a target.
-    // With the flush the order among them is the reference's rule for EQUAL p-values (stable: ascending variable index) --
-    // a tie-break the reference leaves to the bits of its libm; the oracle does the same (fwo_fz_pval).
-    const double p = cc * 2.0;
-    return p < 2.2250738585072014e-308 ? 0.0 : p;
-}
-// x-key of the max-p tracking: |z| / sqrt2 (see FZ_X_SUB)
-__device__ __noinline__ double fz_xkey_slow(double r, double zscale)
-{
-    return fabs(zscale * log((1.0 + r) / (1.0 - r))) * 0.7071067811865476;
-}
+#include "fw_fz_core.h"
 
-__device__ __forceinline__ double fz_pval_dev(double r, double zscale /* sqrt(n-3)/2, 0 if n <= 3 */)
+__global__ void fz_thresholds_kernel(double alpha, double zscale, double *thr)
 {
-    // statfuns.jl:3-17; ccdf(Normal(), x) = erfc(x / sqrt2) / 2 (StatsFuns.normccdf)
-    double z = (zscale > 0.0) ? zscale * log((1.0 + r) / (1.0 - r)) : 0.0;
-    double cc = erfc(fabs(z) * 0.7071067811865476) / 2.0;
-    const double p = cc * 2.0;
-    return p < 2.2250738585072014e-308 ? 0.0 : p;  // subnormal p-values flushed: see fz_pval_slow
-}
-
-// round(x, digits = 5) = rint(x * 1e5) / 1e5 in the value's own type.  The division of the integer n = rint(x * 1e5)
-// by 1e5 is done as q0 = n * c, r = fma(-q0, 1e5, n), q = fma(r, c, q0) with c = RN(1e-5): this is the correctly
-// rounded quotient for every integer |n| <= 400000 in both Float32 and Float64 -- verified exhaustively on the host
-// (tests/test_oracle_golden.py::test_fast_division_by_1e5_is_exact) -- and costs 3 instructions instead of an IEEE
-// division sequence.  Every argument here is a - b * c with a, b, c in [-1, 1] (matrix entries are validated /
-// clamped to that range, every recursion level clamps its result), so |n| <= 200000; NaN propagates as in the
-// plain division.
-__device__ __forceinline__ float round5_f32(float x)
-{
-    const float n = rintf(x * 100000.0f);
-    const float q0 = n * 1e-5f;
-    const float r = fmaf(-q0, 100000.0f, n);
-    const float y = fmaf(r, 1e-5f, q0);
-    return isfinite(y) ? y : x;
-}
-__device__ __forceinline__ double round5_f64(double x)
-{
-    const double n = rint(x * 100000.0);
-    const double q0 = n * 1e-5;
-    const double r = fma(-q0, 100000.0, n);
-    const double y = fma(r, 1e-5, q0);
-    return isfinite(y) ? y : x;
-}
-
-// Partial correlation rho(X, Y | z[0..K-1]) with the reference's peel order (last element first) and its mixed
-// Float32/Float64 arithmetic, evaluated bottom-up: U = [X, Y, z_K, ..., z_1]; level j conditions
-// every remaining pair (a before b in U) on z_j.  (The recursion of statfuns.jl:44-53 touches exactly these
-// pairs in exactly these argument orders; level-1 values are symmetric.)
-template <int K>
-__device__ __forceinline__ double fz_pcor_dp(const float *__restrict__ cor, int p, int X, int Y, const int *z)
-{
-    constexpr int M = K + 2;
-    int U[M];
-    U[0] = X;
-    U[1] = Y;
-#pragma unroll
-    for (int j = 0; j < K; ++j) U[2 + j] = z[K - 1 - j];
-    double R[M][M];
-    bool is32[M][M];
-    float C0[M][M];
-#pragma unroll
-    for (int a = 0; a < M; ++a)
-#pragma unroll
-        for (int b = a + 1; b < M; ++b) C0[a][b] = cor[(size_t)U[a] * p + U[b]];
-    // level 1 (statfuns.jl:32-41), ContType = Float32
-    {
-        constexpr int last = M - 1;
-#pragma unroll
-        for (int a = 0; a < last; ++a)
-#pragma unroll
-            for (int b = a + 1; b < last; ++b) {
-                const float xy = C0[a][b], xz = C0[a][last], yz = C0[b][last];
-                const float prod = xz * yz;
-                float e = xy - prod;
-                e = round5_f32(e);
-                const float s1 = 1.0f - xz * xz, s2 = 1.0f - yz * yz;
-                const float d = sqrtf(s1) * sqrtf(s2);
-                double v;
-                bool f32;
-                if (d == 0.0f) {
-                    v = 0.0;
-                    f32 = false;
-                } else {
-                    v = (double)(e / d);
-                    f32 = true;
-                }
-                if (v < -1.0) {
-                    v = -1.0;
-                    f32 = false;
-                } else if (v >= 1.0) {
-                    v = 1.0;
-                    f32 = false;
-                }
-                R[a][b] = v;
-                is32[a][b] = f32;
-            }
-    }
-#pragma unroll
-    for (int j = 2; j <= K; ++j) {
-        const int last = M - j;
-#pragma unroll
-        for (int a = 0; a < M; ++a)
-#pragma unroll
-            for (int b = a + 1; b < M; ++b) {
-                if (b < last) {
-                    const double va = R[a][b], vb = R[a][last], vc = R[b][last];
-                    double ev, d1;
-                    if (j == 2) {
-                        const bool a32 = is32[a][b], b32 = is32[a][last], c32 = is32[b][last];
-                        double prod;
-                        bool p32;
-                        if (b32 && c32) {
-                            prod = (double)((float)vb * (float)vc);
-                            p32 = true;
-                        } else {
-                            prod = vb * vc;
-                            p32 = false;
-                        }
-                        if (a32 && p32)
-                            ev = (double)round5_f32((float)va - (float)prod);
-                        else
-                            ev = round5_f64(va - prod);
-                        if (b32) {
-                            const float bb = (float)vb * (float)vb;
-                            d1 = (double)sqrtf(1.0f - bb);
-                        } else {
-                            d1 = sqrt(1.0 - vb * vb);
-                        }
-                    } else {
-                        ev = round5_f64(va - vb * vc);
-                        d1 = sqrt(1.0 - vb * vb);
-                    }
-                    const double d2 = sqrt(1.0 - vc * vc);
-                    const double denom = d1 * d2;
-                    double v = (denom == 0.0) ? 0.0 : ev / denom;
-                    if (v < -1.0)
-                        v = -1.0;
-                    else if (v >= 1.0)
-                        v = 1.0;
-                    R[a][b] = v;
-                    is32[a][b] = false;
-                }
-            }
-    }
-    return R[0][1];
-}
-
-__device__ __forceinline__ double fz_pcor_any(const float *__restrict__ cor, int p, int X, int Y, const int *z, int k)
-{
-    switch (k) {
-        case 1: return fz_pcor_dp<1>(cor, p, X, Y, z);
-        case 2: return fz_pcor_dp<2>(cor, p, X, Y, z);
-        case 3: return fz_pcor_dp<3>(cor, p, X, Y, z);
-        case 4: return fz_pcor_dp<4>(cor, p, X, Y, z);
-        case 5: return fz_pcor_dp<5>(cor, p, X, Y, z);
-        default: return (double)cor[(size_t)X * p + Y];
-    }
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    fz_thresholds_dev(alpha, zscale, thr);
+    // thr[4]: |r| below which x = |z|/sqrt2 < FZ_X_SUB for sure (see fz_seg_body); once here instead of once per thread
+    thr[4] = zscale > 0.0 ? tanh(FZ_X_SUB * 0.7071067811865476 / zscale) * (1.0 - 1e-9) : 2.0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -535,634 +374,6 @@ __global__ __launch_bounds__(256) void fz_test_batch_kernel(const float *__restr
 //    the first non-significant rank (or the max_tests stop) ends the job, otherwise the (p, rank) maximum with
 //    "later wins ties" is carried across chunks (tests.jl:311-345).
 // ------------------------------------------------------------------------------------------------
-#define FW_ACC_LDS 2048
-
-// C(m, t) and the lexicographic unranking of subset ranks: fw_unrank.h (shared with the host-side exhaustive check)
-#define binom_u64 fw_binom_u64
-#define unrank_comb fw_unrank_comb
-
-// ---- tagged scalar forms of the pcor_rec levels (same arithmetic as fz_pcor_dp, used by the run-based kernel) ----
-struct TV {
-    double v;
-    bool f32;
-};
-
-// sqrt(x) for x in {0} U [2^-52, 1] (here: 1 - v^2 with |v| <= 1 in Float64): the library's sequence (v_rsq_f64 + two
-// Goldschmidt / Newton steps, correctly rounded) without its scaling for arguments below 2^-767 and its
-// infinity check -- the same instructions on the same values, hence the same bits, 6 instructions less per root.
-__device__ __forceinline__ double fz_sqrt_unit(double x)
-{
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y;
-    double h = 0.5 * y;
-    const double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    double d = fma(-g, g, x);
-    g = fma(d, h, g);
-    d = fma(-g, g, x);
-    g = fma(d, h, g);
-    return x == 0.0 ? 0.0 : g;  // rsq(0) = inf would poison g; NaN propagates as in sqrt
-}
-
-// statfuns.jl:32-41 with ContType = Float32
-__device__ __forceinline__ TV pc_l1(float xy, float xz, float yz)
-{
-    const float prod = xz * yz;
-    float e = xy - prod;
-    e = round5_f32(e);
-    const float s1 = 1.0f - xz * xz, s2 = 1.0f - yz * yz;
-    const float d = sqrtf(s1) * sqrtf(s2);
-    TV r;
-    if (d == 0.0f) {
-        r.v = 0.0;
-        r.f32 = false;
-    } else {
-        r.v = (double)(e / d);
-        r.f32 = true;
-    }
-    if (r.v < -1.0) {
-        r.v = -1.0;
-        r.f32 = false;
-    } else if (r.v >= 1.0) {
-        r.v = 1.0;
-        r.f32 = false;
-    }
-    return r;
-}
-
-// statfuns.jl:44-62, children from level 1 (Float32 unless they were replaced by a Float64 literal).
-// d2c = sqrt(1 - c^2) in Float64 (statfuns.jl:52, `^2.0`) is passed in so that callers can share it.
-__device__ __forceinline__ double pc_l2_d2(TV a, TV b, TV c, double d2c)
-{
-    double prod, ev, d1;
-    bool p32;
-    if (b.f32 && c.f32) {
-        prod = (double)((float)b.v * (float)c.v);
-        p32 = true;
-    } else {
-        prod = b.v * c.v;
-        p32 = false;
-    }
-    if (a.f32 && p32)
-        ev = (double)round5_f32((float)a.v - (float)prod);
-    else
-        ev = round5_f64(a.v - prod);
-    if (b.f32) {
-        const float bb = (float)b.v * (float)b.v;
-        d1 = (double)sqrtf(1.0f - bb);
-    } else {
-        d1 = sqrt(1.0 - b.v * b.v);
-    }
-    const double denom = d1 * d2c;
-    double v = (denom == 0.0) ? 0.0 : ev / denom;
-    v = v < -1.0 ? -1.0 : v;  // two selects, no branch (NaN stays NaN)
-    v = v >= 1.0 ? 1.0 : v;
-    return v;
-}
-__device__ __forceinline__ double pc_l2(TV a, TV b, TV c) { return pc_l2_d2(a, b, c, sqrt(1.0 - c.v * c.v)); }
-
-// pc_l2_d2 specialised for the overwhelmingly common case that all three children are Float32 values (no Float64
-// literal 0 / +-1 among them): identical arithmetic, no per-flag branches.
-__device__ __forceinline__ double pc_l2_all32(float a, float b, float c, double d2c)
-{
-    const float prod = b * c;
-    const double ev = (double)round5_f32(a - prod);
-    const float bb = b * b;
-    const double d1 = (double)sqrtf(1.0f - bb);
-    const double denom = d1 * d2c;
-    double v = (denom == 0.0) ? 0.0 : ev / denom;
-    v = v < -1.0 ? -1.0 : v;
-    v = v >= 1.0 ? 1.0 : v;
-    return v;
-}
-
-// the same with d1 = Float64(sqrt(1f0 - b^2)) taken from the LDS table (it only depends on the (z1, z2) entry)
-__device__ __forceinline__ double pc_l2_all32_d1(float a, float b, float c, double d1, double d2c)
-{
-    const float prod = b * c;
-    const double ev = (double)round5_f32(a - prod);
-    const double denom = d1 * d2c;
-    double v = (denom == 0.0) ? 0.0 : ev / denom;
-    v = v < -1.0 ? -1.0 : v;
-    v = v >= 1.0 ? 1.0 : v;
-    return v;
-}
-
-// pc_l1 with the two square roots sqrt(1 - xz^2), sqrt(1 - yz^2) taken from the LDS table
-__device__ __forceinline__ TV pc_l1_r(float xy, float xz, float yz, float rxz, float ryz)
-{
-    const float prod = xz * yz;
-    const float e = round5_f32(xy - prod);
-    const float d = rxz * ryz;
-    const bool nz = d != 0.0f;
-    const float q = e / (nz ? d : 1.0f);
-    TV r;
-    r.v = nz ? (double)q : 0.0;
-    r.f32 = nz;
-    const bool lo = r.v < -1.0, hi = r.v >= 1.0;
-    r.v = lo ? -1.0 : r.v;
-    r.v = hi ? 1.0 : r.v;
-    r.f32 = r.f32 && !lo && !hi;
-    return r;
-}
-
-// statfuns.jl:44-62, all-Float64 children (level >= 3)
-__device__ __forceinline__ double pc_l3(double a, double b, double c)
-{
-    const double ev = round5_f64(a - b * c);
-    const double denom = fz_sqrt_unit(1.0 - b * b) * fz_sqrt_unit(1.0 - c * c);
-    double v = (denom == 0.0) ? 0.0 : ev / denom;
-    v = v < -1.0 ? -1.0 : v;
-    v = v >= 1.0 ? 1.0 : v;
-    return v;
-}
-
-// Run-based segment kernel.  A segment [start, end) is processed in chunks of 256 * R ranks; lane l evaluates the R
-// consecutive ranks [cbase + l*R, cbase + (l+1)*R): it unranks once, then steps the combination lexicographically and
-// reuses every partial correlation that does not involve the position that changed (for max_k = 3 that is 4 of the
-// 10 formula evaluations and 6 of the 10 matrix entries).  Rank order is preserved: a lane stops at its first
-// stopping rank, the workgroup takes the minimum over lanes.
-#ifndef FW_RUN_MAX
-#define FW_RUN_MAX 32  // chunk = 8192 ranks: fewer table builds / unrankings per test (16 -> 32: -9 % kernel time at cfg3)
-#endif
-// Table path of the size-3 enumeration (accepted sets of up to FZ_TAB_A variables, max_k <= 3).  With
-// (z1, z2, z3) = accepted[(i, j, k)], i < j < k, the recursion of statfuns.jl:44-53 needs
-//   rho(X,Y|z1,z2)   = l2(A1(i), LX(i,j), LY(i,j))          -- depends on (i, j) only
-//   rho(X,z3|z1,z2)  = l2(LX(i,k), LX(i,j), F1(i,j,k))      -- LX(i,v) = rho(X,v|z1), LY(i,v) = rho(Y,v|z1)
-//   rho(Y,z3|z1,z2)  = l2(LY(i,k), LY(i,j), F1(i,j,k))      -- F1 = rho(z3,z2|z1)
-// so per chunk the workgroup first builds, for every z1-block i the chunk touches, one LDS entry per later position
-// v: {LX, LY, cor[v][z1], variable id + Float32 flags, rho(X,Y|z1,v)}.  A test then costs one matrix gather, one
-// level-1, two level-2 and one level-3 evaluation instead of 3 + 2 + 1 evaluations and 4 gathers, and -- more
-// importantly -- no lane ever recomputes a prefix while the other 63 wait (the divergence of the in-lane caching
-// path).  A chunk of 256 * FW_RUN_MAX = 8192 ranks touches at most 1021 entries for every |accepted| <= 512
-// (profiles/tools/tab_bound.py 512 8192).
-#define FZ_TAB_A FW_TAB_A
-#define FZ_TAB_CAP 1024
-#define FZ_TAB_ZMASK 0x1FFFFFFF
-// entries of blocks [i0, i): block t holds a - 1 - t entries
-__device__ __forceinline__ int fz_tab_off(int i, int i0, int a)
-{
-    return (i - i0) * (a - 1) - (i * (i - 1) - i0 * (i0 - 1)) / 2;
-}
-#define FZ_X_NONE 1.0e308    // "no candidate yet"
-#define FZ_X_SUB 26.0        // beyond this x = |z|/sqrt2, erfc(x)/2*2 leaves the normal range (ties become possible)
-#define FZ_X_SUBKEY 1.0e300  // common x-key of the underflow regime (ordered by exact p there)
-#define FZ_X_LAZY (-1.0)     // lane best taken by |r| alone; its x-key is computed at the end of the run
-
-// (xa, pa, ra) strictly better than (xb, pb, rb)?  smaller x-key = larger p; equal keys: larger exact p, then later rank
-__device__ __forceinline__ bool fz_key_better(double xa, double pa, unsigned long long ra, double xb, double pb,
-                                              unsigned long long rb)
-{
-    if (xa != xb) return xa < xb;
-    if (xa == FZ_X_NONE) return false;
-    if (pa != pb) return pa > pb;
-    return ra > rb;
-}
-
-// |r| thresholds for `p < alpha`: bisection on the exact device p-value, then a +-1e-9 relative guard band.
-// thr = {lo_pos, hi_pos, lo_neg, hi_neg}: |r| > hi -> significant for sure, |r| < lo -> not significant for sure.
-__device__ void fz_thresholds_dev(double alpha, double zscale, double *thr)
-{
-    for (int sgn = 0; sgn < 2; ++sgn) {
-        double lo = 0.0, hi = 1.0;  // p(lo) >= alpha (not sig), p(hi) < alpha (sig) unless nothing is ever significant
-        const double sg = sgn ? -1.0 : 1.0;
-        if (!(fz_pval_dev(sg * 1.0, zscale) < alpha)) {
-            thr[2 * sgn] = 2.0;
-            thr[2 * sgn + 1] = 2.0;
-            continue;
-        }
-        for (int it = 0; it < 200; ++it) {
-            const double mid = 0.5 * (lo + hi);
-            if (fz_pval_dev(sg * mid, zscale) < alpha)
-                hi = mid;
-            else
-                lo = mid;
-        }
-        thr[2 * sgn] = lo * (1.0 - 1e-9);
-        thr[2 * sgn + 1] = hi * (1.0 + 1e-9);
-    }
-}
-
-__global__ void fz_thresholds_kernel(double alpha, double zscale, double *thr)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    fz_thresholds_dev(alpha, zscale, thr);
-    // thr[4]: |r| below which x = |z|/sqrt2 < FZ_X_SUB for sure (see fz_seg_body); once here instead of once per thread
-    thr[4] = zscale > 0.0 ? tanh(FZ_X_SUB * 0.7071067811865476 / zscale) * (1.0 - 1e-9) : 2.0;
-}
-
-// HIGHK: subsets of size 4-5 possible; LOCAL: per-job matrices (fz_nz); TAB: size-3 subsets through the LDS table
-// (the host routes only segments of jobs with |accepted| <= FZ_TAB_A to a TAB launch; never together with HIGHK)
-template <bool HIGHK, bool LOCAL, bool TAB>
-__device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int p_g, const FwSeg *__restrict__ segs,
-                                            const int32_t *__restrict__ accflat, FwSegOut *__restrict__ out, int max_k,
-                                            double alpha, double zscale_g, long long max_tests,
-                                            const double *__restrict__ thr_g, const FwNzJob *__restrict__ recs,
-                                            long long n_obs_min, const unsigned sidx /* segment this workgroup evaluates */)
-{
-    __shared__ int s_acc[TAB ? FZ_TAB_A : FW_ACC_LDS];  // TAB: |accepted| <= FZ_TAB_A by the host's routing
-    __shared__ unsigned long long s_stop[4];
-    __shared__ double s_bx[4], s_bps[4];
-    __shared__ unsigned long long s_br[4];
-    __shared__ unsigned int s_evc[4];  // tests really executed by each wavefront in the current chunk
-    __shared__ double s_best_x, s_best_ps, s_best_stat;
-    __shared__ unsigned long long s_best_rank;
-    __shared__ float4 s_tab[TAB ? FZ_TAB_CAP : 1];    // {LX, LY, cor[v][z1], variable id | Float32 flags}
-    __shared__ float s_tab_r1[TAB ? FZ_TAB_CAP : 1];   // sqrt(1 - cor[v][z1]^2)                       (Float32 roots)
-    __shared__ float2 s_tab_r2[TAB ? FZ_TAB_CAP : 1];  // {sqrt(1 - LX^2), sqrt(1 - LY^2)}
-    __shared__ double s_tab_a2[TAB ? FZ_TAB_CAP : 1]; // rho(X, Y | z1, v)
-    __shared__ int s_blk[2];
-
-    const FwSeg seg = segs[sidx];
-    const int a = seg.acc_len;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int32_t *gacc = accflat + seg.acc_off;
-    const bool in_lds = a <= (TAB ? FZ_TAB_A : FW_ACC_LDS);
-    const float *cor = cor_g;
-    int p = p_g;
-    double zscale = zscale_g;
-    const double *thr = thr_g;
-    if (LOCAL) {
-        const FwNzJob *rec = recs + seg.pad;
-        cor = cor_g + rec->cor_off;
-        p = rec->m;
-        zscale = rec->zscale;
-        thr = rec->thr;
-        if ((long long)rec->nR < n_obs_min) {  // tests.jl:294-296: (0, 1, 0, false) with zero tests
-            if (tid == 0) {
-                FwSegOut o;
-                o.stop_rank = 0;
-                o.stop_stat = 0.0;
-                o.stop_pval = 1.0;
-                o.best_rank = 0;
-                o.best_stat = 0.0;
-                o.best_pval = -1.0;
-                o.stop_df = -2;  // marker: no test was executed
-                o.stop_power = 0;
-                o.best_df = 0;
-                o.pad = 0;
-                o.evaluated = 0;
-                out[sidx] = o;
-            }
-            return;
-        }
-    } else if (in_lds) {
-        for (int i = tid; i < a; i += 256) s_acc[i] = gacc[i];
-    }
-    if (tid == 0) {
-        s_best_x = FZ_X_NONE;
-        s_best_ps = 0.0;
-        s_best_stat = 0.0;
-        s_best_rank = 0;
-    }
-    unsigned long long cnt[FW_MAX_K + 1];
-#pragma unroll
-    for (int s = FW_MAX_K; s >= 1; --s) cnt[s] = (s <= max_k) ? binom_u64(a, s) : 0ull;
-    // significance thresholds on |r| (see fz_thresholds_kernel): outside [lo, hi] the verdict of p < alpha is certain
-    const double rlo_pos = thr[0], rhi_pos = thr[1], rlo_neg = thr[2], rhi_neg = thr[3];
-    // |r| below which x = |z|/sqrt2 < FZ_X_SUB for sure: x = zscale * log((1+r)/(1-r)) / sqrt2  <=>  r = tanh(x / (sqrt2 zscale))
-    const double rsub_lo = !LOCAL ? thr[4] : (zscale > 0.0 ? tanh(FZ_X_SUB * 0.7071067811865476 / zscale) * (1.0 - 1e-9) : 2.0);
-    __syncthreads();
-#define ACCV(i) (LOCAL ? ((i) + 2) : (in_lds ? s_acc[(i)] : gacc[(i)]))
-#define CORV(u, v) cor[(size_t)(u) * p + (v)]
-
-    const int X = LOCAL ? 0 : seg.X, Y = LOCAL ? 1 : seg.Y;
-    const float cXY = CORV(X, Y);
-    const unsigned long long NONE = FW_RANK_NONE;
-    const unsigned long long len = seg.end - seg.start;
-    const int R = (int)((len + 255) / 256 < FW_RUN_MAX ? (len + 255) / 256 : FW_RUN_MAX);
-    unsigned long long evaluated = 0;
-
-    for (unsigned long long cbase = seg.start; cbase < seg.end; cbase += 256ull * R) {
-        const unsigned long long r0 = cbase + (unsigned long long)tid * R;
-        unsigned long long r1 = r0 + R;
-        if (r1 > seg.end) r1 = seg.end;
-        const bool any = r0 < seg.end;
-        // ---- table of the z1-blocks this chunk touches (see FZ_TAB_A) ----
-        bool tab_ok = false;
-        int tb_i0 = 0;
-        if (TAB) {
-            const unsigned long long c3 = (max_k >= 3) ? cnt[3] : 0ull;
-            if (cbase < c3) {  // workgroup-uniform; a <= FZ_TAB_A by the host's routing
-                unsigned long long last3 = cbase + 256ull * R;
-                last3 = last3 < seg.end ? last3 : seg.end;
-                last3 = (last3 < c3 ? last3 : c3) - 1ull;
-                if (tid == 0 || tid == 64) {
-                    int q[FW_MAX_K];
-                    unrank_comb(tid == 0 ? cbase : last3, a, 3, q);
-                    s_blk[tid == 0 ? 0 : 1] = q[0];
-                }
-                __syncthreads();
-                const int i0 = s_blk[0], i1 = s_blk[1];
-                const int E = fz_tab_off(i1 + 1, i0, a);  // <= 1021 for a <= 512 and chunks of 8192 ranks
-                if (E > FZ_TAB_CAP) __builtin_trap();      // would be a routing bug on the host side: fail loudly
-                if (E <= FZ_TAB_CAP) {
-                    tab_ok = true;
-                    tb_i0 = i0;
-                    for (int e = tid; e < E; e += 256) {
-                        int i = i0, rem = e;
-                        while (rem >= a - 1 - i) {
-                            rem -= a - 1 - i;
-                            ++i;
-                        }
-                        const int z1 = ACCV(i), zv = ACCV(i + 1 + rem);
-                        const float cXz1 = CORV(X, z1), cYz1 = CORV(Y, z1), cvz1 = CORV(zv, z1);
-                        const TV A1 = pc_l1(cXY, cXz1, cYz1);
-                        const TV LX = pc_l1(CORV(X, zv), cXz1, cvz1);
-                        const TV LY = pc_l1(CORV(Y, zv), cYz1, cvz1);
-                        s_tab_a2[e] = pc_l2(A1, LX, LY);
-                        // square roots the level-1 / level-2 formulas take of this entry's values (statfuns.jl:36,52);
-                        // for a Float64-literal LX / LY (0, +-1) the Float32 root is the exact one as well
-                        const float fx = (float)LX.v, fy = (float)LY.v;
-                        s_tab_r1[e] = sqrtf(1.0f - cvz1 * cvz1);
-                        s_tab_r2[e] = make_float2(sqrtf(1.0f - fx * fx), sqrtf(1.0f - fy * fy));
-                        s_tab[e] = make_float4((float)LX.v, (float)LY.v, cvz1,
-                                               __int_as_float(zv | (LX.f32 ? (1 << 30) : 0) | (LY.f32 ? (1 << 29) : 0)));
-                    }
-                }
-                __syncthreads();
-            }
-        }
-        // lane-local results
-        unsigned long long my_stop = NONE, my_br = 0;
-        double stop_stat = 0.0, stop_p = 0.0, my_bstat = 0.0;
-        // lane best: ordered by x = |z|/sqrt2 ascending (= p descending); in the underflow regime (x > FZ_X_SUB, where
-        // different x can give the same subnormal/zero p) by the exact p instead; later rank wins ties (tests.jl:338)
-        double my_bx = FZ_X_NONE, my_bps = 0.0, my_ba = 0.0;
-        unsigned int my_done = 0;  // tests this lane executes in this chunk (it leaves its run at its first stop)
-        if (any) {
-            // unrank the first rank of the run
-            unsigned long long rem = r0;
-            int s = max_k;
-            while (s > 1 && rem >= cnt[s]) {
-                rem -= cnt[s];
-                --s;
-            }
-            int pos[FW_MAX_K];
-#pragma unroll
-            for (int q = 0; q < FW_MAX_K; ++q) pos[q] = 0;
-            unrank_comb(rem, a, s, pos);
-            int chg = 0;  // lowest position index that changed since the previous test of this lane (0 = everything)
-            // cached state for s <= 3
-            int z1 = 0, z2 = 0;
-            float cXz1 = 0.f, cYz1 = 0.f, cXz2 = 0.f, cYz2 = 0.f, cz2z1 = 0.f;
-            TV A1{0.0, false}, B1{0.0, false}, C1{0.0, false};
-            double A2 = 0.0;
-            int boff = 0;
-            for (unsigned long long r = r0; r < r1; ++r) {
-                double stat;
-                ++my_done;
-                if (TAB && s == 3 && tab_ok) {
-                    const int pi = pos[0];
-                    if (chg <= 0) boff = fz_tab_off(pi, tb_i0, a) - pi - 1;
-                    const int ej = boff + pos[1], ek = boff + pos[2];
-                    const float4 tj = s_tab[ej], tk = s_tab[ek];
-                    const float rj1 = s_tab_r1[ej], rk1 = s_tab_r1[ek];
-                    const float2 rj2 = s_tab_r2[ej];
-                    const double A2j = s_tab_a2[ej];
-                    const int fj = __float_as_int(tj.w), fk = __float_as_int(tk.w);
-                    const float c32 = CORV(fk & FZ_TAB_ZMASK, fj & FZ_TAB_ZMASK);
-                    const TV F1 = pc_l1_r(c32, tk.z, tj.z, rk1, rj1);
-                    const double dF = fz_sqrt_unit(1.0 - F1.v * F1.v);  // shared by the two level-2 values below
-                    double D2, E2;
-                    if (__all((((fj & fk) >> 29) & 3) == 3 && F1.f32)) {  // wave-uniform fast path: no Float64 literal
-                        D2 = pc_l2_all32_d1(tk.x, tj.x, (float)F1.v, (double)rj2.x, dF);
-                        E2 = pc_l2_all32_d1(tk.y, tj.y, (float)F1.v, (double)rj2.y, dF);
-                    } else {
-                        const TV D1{(double)tk.x, ((fk >> 30) & 1) != 0}, Bj{(double)tj.x, ((fj >> 30) & 1) != 0};
-                        const TV E1{(double)tk.y, ((fk >> 29) & 1) != 0}, Cj{(double)tj.y, ((fj >> 29) & 1) != 0};
-                        D2 = pc_l2_d2(D1, Bj, F1, dF);
-                        E2 = pc_l2_d2(E1, Cj, F1, dF);
-                    }
-                    stat = pc_l3(A2j, D2, E2);
-                } else if (!TAB && s == 3) {
-                    if (chg <= 0) {
-                        z1 = ACCV(pos[0]);
-                        cXz1 = CORV(X, z1);
-                        cYz1 = CORV(Y, z1);
-                        A1 = pc_l1(cXY, cXz1, cYz1);
-                    }
-                    if (chg <= 1) {
-                        z2 = ACCV(pos[1]);
-                        cXz2 = CORV(X, z2);
-                        cYz2 = CORV(Y, z2);
-                        cz2z1 = CORV(z2, z1);
-                        B1 = pc_l1(cXz2, cXz1, cz2z1);
-                        C1 = pc_l1(cYz2, cYz1, cz2z1);
-                        A2 = pc_l2(A1, B1, C1);
-                    }
-                    const int z3 = ACCV(pos[2]);
-                    const float cXz3 = CORV(X, z3), cYz3 = CORV(Y, z3), cz3z1 = CORV(z3, z1), cz3z2 = CORV(z3, z2);
-                    const TV D1 = pc_l1(cXz3, cXz1, cz3z1);
-                    const TV E1 = pc_l1(cYz3, cYz1, cz3z1);
-                    const TV F1 = pc_l1(cz3z2, cz3z1, cz2z1);
-                    const double dF = fz_sqrt_unit(1.0 - F1.v * F1.v);  // shared by the two level-2 values below
-                    double D2, E2;
-                    if (__all(D1.f32 && E1.f32 && F1.f32 && B1.f32 && C1.f32)) {  // wave-uniform fast path
-                        D2 = pc_l2_all32((float)D1.v, (float)B1.v, (float)F1.v, dF);
-                        E2 = pc_l2_all32((float)E1.v, (float)C1.v, (float)F1.v, dF);
-                    } else {
-                        D2 = pc_l2_d2(D1, B1, F1, dF);
-                        E2 = pc_l2_d2(E1, C1, F1, dF);
-                    }
-                    stat = pc_l3(A2, D2, E2);
-                } else if (s == 2) {
-                    if (chg <= 0) {
-                        z1 = ACCV(pos[0]);
-                        cXz1 = CORV(X, z1);
-                        cYz1 = CORV(Y, z1);
-                        A1 = pc_l1(cXY, cXz1, cYz1);
-                    }
-                    z2 = ACCV(pos[1]);
-                    cXz2 = CORV(X, z2);
-                    cYz2 = CORV(Y, z2);
-                    cz2z1 = CORV(z2, z1);
-                    B1 = pc_l1(cXz2, cXz1, cz2z1);
-                    C1 = pc_l1(cYz2, cYz1, cz2z1);
-                    stat = pc_l2(A1, B1, C1);
-                } else if (s == 1) {
-                    z1 = ACCV(pos[0]);
-                    stat = pc_l1(cXY, CORV(X, z1), CORV(Y, z1)).v;
-                } else if (HIGHK) {
-                    int zs[FW_MAX_K];
-#pragma unroll
-                    for (int q = 0; q < FW_MAX_K; ++q) zs[q] = (q < s) ? ACCV(pos[q]) : 0;
-                    stat = fz_pcor_any(cor, p, X, Y, zs, s);
-                } else {
-                    stat = 0.0;
-                }
-                const double av = fabs(stat);
-                const bool negr = stat < 0.0;
-                bool sig;
-                if (av > (negr ? rhi_neg : rhi_pos))
-                    sig = true;
-                else if (av < (negr ? rlo_neg : rlo_pos))
-                    sig = false;
-                else
-                    sig = fz_pval_slow(stat, zscale) < alpha;  // inside the guard band (or NaN): exact
-                if (!sig || (max_tests > 0 && r + 1 >= (unsigned long long)max_tests)) {
-                    my_stop = r;
-                    stop_stat = stat;
-                    stop_p = fz_pval_slow(stat, zscale);
-                    break;
-                }
-                // tests.jl:338 `pval >= lowest.pval`, sequential within the run, without evaluating p (or even z) for
-                // every test.  In the normal regime (|r| < rsub_lo, i.e. x < FZ_X_SUB) p is strictly decreasing in |r|
-                // once two values differ by more than rounding noise, so a clearly smaller |r| replaces the lane best
-                // "lazily" (x is computed once per run, below), a clearly larger one is skipped, and only near-ties and
-                // the underflow regime take the exact path.
-                bool exact = false, lazy_take = false;
-                if (av < rsub_lo) {
-                    if (my_bx == FZ_X_NONE || my_bx > FZ_X_SUB)
-                        lazy_take = true;  // nothing yet, or the best so far sits in the underflow regime (smaller p)
-                    else if (av < my_ba * (1.0 - 1e-12))
-                        lazy_take = true;
-                    else
-                        exact = av <= my_ba * (1.0 + 1e-12);
-                } else {
-                    exact = true;
-                }
-                if (lazy_take) {
-                    my_bx = FZ_X_LAZY;
-                    my_bps = 0.0;
-                    my_ba = av;
-                    my_br = r;
-                    my_bstat = stat;
-                }
-                if (exact) {
-                    if (my_bx == FZ_X_LAZY)
-                        my_bx = fz_xkey_slow(my_bstat, zscale);
-                    const double xz = fz_xkey_slow(stat, zscale);
-                    bool take;
-                    double ps = 0.0;
-                    if (xz > FZ_X_SUB) {
-                        ps = fz_pval_slow(stat, zscale);  // exact (possibly subnormal / zero) p
-                        take = (my_bx == FZ_X_NONE) || (my_bx > FZ_X_SUB && ps >= my_bps);
-                    } else {
-                        take = (my_bx == FZ_X_NONE) || (my_bx > FZ_X_SUB) || (xz <= my_bx);
-                    }
-                    if (take) {
-                        my_bx = xz;
-                        my_bps = ps;
-                        my_ba = av;
-                        my_br = r;
-                        my_bstat = stat;
-                    }
-                }
-                // next combination in lexicographic order (sizes descend when one is exhausted)
-                if (s == 3 && pos[2] < a - 1) {  // by far the most frequent step, with static register indices (the
-                    ++pos[2];                     // generic code below indexes pos[] dynamically: ~60 instructions)
-                    chg = 2;
-                    continue;
-                }
-                int i = s - 1;
-                while (i >= 0 && pos[i] == a - s + i) --i;
-                if (i < 0) {
-                    --s;
-#pragma unroll
-                    for (int q = 0; q < FW_MAX_K; ++q) pos[q] = q;
-                    chg = 0;
-                    if (s < 1) break;  // end of the enumeration (r1 never exceeds it)
-                } else {
-                    ++pos[i];
-                    for (int j = i + 1; j < s; ++j) pos[j] = pos[j - 1] + 1;
-                    chg = i;
-                }
-            }
-        }
-        if (my_bx == FZ_X_LAZY)  // resolve the lazily kept lane best: its x-key
-            my_bx = fz_xkey_slow(my_bstat, zscale);
-        // first stopping rank in the workgroup
-        unsigned long long ws = my_stop;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long t = __shfl_xor(ws, o);
-            ws = t < ws ? t : ws;
-        }
-        // key of the lane best: (xk, ps, rank); xk = x in the normal regime, FZ_X_SUBKEY in the underflow regime
-        double bx = (my_bx == FZ_X_NONE) ? FZ_X_NONE : (my_bx > FZ_X_SUB ? FZ_X_SUBKEY : my_bx);
-        double bps = my_bps;
-        unsigned long long br = my_br;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double ox = __shfl_xor(bx, o), ops = __shfl_xor(bps, o);
-            const unsigned long long orr = __shfl_xor(br, o);
-            if (fz_key_better(ox, ops, orr, bx, bps, br)) {
-                bx = ox;
-                bps = ops;
-                br = orr;
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) my_done += __shfl_xor(my_done, o);
-        if (lane == 0) {
-            s_evc[wave] = my_done;
-            s_stop[wave] = ws;
-            s_bx[wave] = bx;
-            s_bps[wave] = bps;
-            s_br[wave] = br;
-        }
-        __syncthreads();
-        unsigned long long first = s_stop[0];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) first = s_stop[w] < first ? s_stop[w] : first;
-        evaluated += (unsigned long long)(s_evc[0] + s_evc[1] + s_evc[2] + s_evc[3]);  // executed tests, not chunk sizes
-        if (first != NONE) {
-            if (my_stop == first) {
-                FwSegOut o;
-                o.stop_rank = first;
-                o.stop_stat = stop_stat;
-                o.stop_pval = stop_p;
-                o.best_rank = 0;
-                o.best_stat = 0.0;
-                o.best_pval = -1.0;
-                o.stop_df = 0;
-                o.stop_power = 1;
-                o.best_df = 0;
-                o.pad = 0;
-                o.evaluated = evaluated;
-                out[sidx] = o;
-            }
-            return;
-        }
-        double cbx = s_bx[0], cbps = s_bps[0];
-        unsigned long long cbr = s_br[0];
-#pragma unroll
-        for (int w = 1; w < 4; ++w)
-            if (fz_key_better(s_bx[w], s_bps[w], s_br[w], cbx, cbps, cbr)) {
-                cbx = s_bx[w];
-                cbps = s_bps[w];
-                cbr = s_br[w];
-            }
-        // chunks hold increasing ranks: the newer chunk wins ties against the running best of the segment
-        if (my_bx != FZ_X_NONE && my_br == cbr && cbx != FZ_X_NONE &&
-            (s_best_x == FZ_X_NONE || !fz_key_better(s_best_x, s_best_ps, 0ull, cbx, cbps, 1ull))) {
-            s_best_x = cbx;
-            s_best_ps = cbps;
-            s_best_stat = my_bstat;
-            s_best_rank = my_br;
-        }
-        __syncthreads();
-    }
-#undef ACCV
-#undef CORV
-    if (tid == 0) {
-        FwSegOut o;
-        o.stop_rank = NONE;
-        o.stop_stat = 0.0;
-        o.stop_pval = 0.0;
-        o.best_rank = s_best_rank;
-        o.best_stat = s_best_stat;
-        o.best_pval = (s_best_x == FZ_X_NONE) ? -1.0 : fz_pval_slow(s_best_stat, zscale);
-        o.stop_df = 0;
-        o.stop_power = 1;
-        o.best_df = 0;
-        o.pad = 0;
-        o.evaluated = evaluated;
-        out[sidx] = o;
-    }
-}
 
 // Host-driven rounds: one workgroup per segment (ns_dev == nullptr).  Device-driven rounds (fw_devhiton.hip): a fixed
 // grid strides over an unsorted segment list whose live length sits in device memory; the table / in-lane variants
@@ -1186,7 +397,8 @@ __global__ __launch_bounds__(256, 4) void fz_subsets_seg_kernel(const float *__r
     const unsigned ns = ns_dev ? *ns_dev : gridDim.x;
     for (unsigned s = blockIdx.x; s < ns; s += gridDim.x) {
         if (ns_dev && !HIGHK && ((segs[s].acc_len <= FZ_TAB_A) != TAB)) continue;  // workgroup-uniform
-        fz_seg_body<HIGHK, LOCAL, TAB>(cor_g, p_g, segs, accflat, out, max_k, alpha, zscale_g, max_tests, thr_g, recs, n_obs_min, s);
+        fz_seg_body<HIGHK, LOCAL, TAB>(cor_g, p_g, segs[s], accflat + segs[s].acc_off, false, out + s, max_k, alpha, zscale_g, max_tests, thr_g, recs,
+                                       n_obs_min);
         __syncthreads();  // the LDS state of the body is reused by the next segment
     }
 }
@@ -1360,6 +572,12 @@ static int fz_ensure_thresholds(fw_ctx *ctx, hipStream_t stream)
 }
 
 // Device-driven rounds (fw_devhiton.hip): a fixed grid over an unsorted segment list whose live length is *d_ns.
+int fwi_fz_thresholds(fw_ctx *ctx, hipStream_t stream, double *zscale)
+{
+    *zscale = fz_zscale(ctx);
+    return fz_ensure_thresholds(ctx, stream);
+}
+
 int fwi_fz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, const unsigned *d_ns,
                         bool any_big, const unsigned *d_big, hipStream_t stream)
 {

@@ -281,6 +281,7 @@ struct FwDhFlat {  // (one allocation per run instead of three per target: 150 0
 int fwi_devhiton_run(fw_ctx *ctx, const std::vector<FwDhTarget> &in, std::vector<FwDhResult> &out, FwDhFlat &flat, int chain = 0);
 int fwi_mi_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, const unsigned *d_ns,
                         hipStream_t stream);
+int fwi_fz_thresholds(fw_ctx *ctx, hipStream_t stream, double *zscale);  // ensures ctx->d_thr (fz_thresholds_kernel)
 int fwi_fz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, const unsigned *d_ns,
                         bool any_big, const unsigned *d_big, hipStream_t stream);
 
