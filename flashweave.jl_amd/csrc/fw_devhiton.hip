@@ -77,6 +77,9 @@ struct DhParams {
     int spec_depth;  // elimination-phase look-ahead: candidates tested ahead of the current one per target (0 = off)
     unsigned long long spec_below;  // ... only while the last launch held fewer ranks than this
     unsigned int mi_seq, mi_win0, mi_chunk_div, mi_chunk_min, mi_chunk_max, mi_help_jobs;  // dh_mi_target_kernel (env knobs)
+    unsigned int mi_elim_min;  // elimination-phase jobs with more ranks than this open a board for the whole enumeration at once (0: off)
+    unsigned int mi_heavy;     // targets with at least this many candidates never work on other targets' boards (0: off)
+    unsigned int mi_seq_heavy; // ... and run this many first tests of a job alone (instead of mi_seq) before they open a board
     int spec0_depth;                // interleaving-phase look-ahead (first windows of the next candidates)
     unsigned long long spec0_below;
     unsigned int spec0_jobs;  // ... and fewer live jobs than this
@@ -385,6 +388,7 @@ struct MiBoard {
 struct MiQueue {
     unsigned int next_target, targets_done, n_boards, hint, res_top, bacc_top, pad[2];
     unsigned long long t_body, t_ctl, t_sleep, n_seg;  // dh_fz_target_kernel: 100 MHz ticks summed over workgroups (FW_TRACE_HOST)
+    unsigned long long t_total;  // dh_mi_target_kernel: ticks until the wavefront ran out of targets (the fields above: see its end)
 };
 
 #define MI_BACC_CAP (1u << 22)  // ints of accepted-list copies per launch
@@ -640,13 +644,20 @@ __device__ __noinline__ bool mi_help(MiQueue *__restrict__ Q, MiBoard *__restric
     return false;
 }
 
+#ifndef DH_MI_OCC
+#define DH_MI_OCC 1  // workgroups per CU the register budget is sized for
+#endif
 template <int L, int NXY, bool PRE>
-__global__ __launch_bounds__(256) void dh_mi_target_kernel(DhTgt *__restrict__ tg, int ntg, const int32_t *__restrict__ order,
+__global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__restrict__ tg, int ntg, const int32_t *__restrict__ order,
                                                            DhArrays A, MiDev M, DhParams P, MiQueue *__restrict__ Q,
                                                            MiBoard *__restrict__ boards, FwSegOut *__restrict__ res,
                                                            int32_t *__restrict__ bacc)
 {
     const int lane = threadIdx.x & 63;
+    // 100 MHz ticks per wavefront, summed into MiQueue at the end (FW_TRACE_HOST prints the averages): own first tests, board
+    // phases (own records + waiting / helping), helping before jobs, the tail after the last target
+    unsigned long long tk_seq = 0ull, tk_board = 0ull, tk_help = 0ull, tk_tail = 0ull;
+    const unsigned long long tk_begin = wall_clock64();
     for (;;) {
         const unsigned int slot = mi_wave_add(&Q->next_target, 1u, lane);
         if (slot >= (unsigned int)ntg) break;
@@ -654,9 +665,15 @@ __global__ __launch_bounds__(256) void dh_mi_target_kernel(DhTgt *__restrict__ t
         DhTgt x = tg[t];
         while (dh_advance(x, A, lane, 1)) {
             // other targets' big enumerations first: they are the critical path of the pass
-            if (P.mi_help_jobs)
+            const unsigned long long tk0 = wall_clock64();
+            // ... unless this target is one of the heavy ones: its own chain of jobs IS the critical path (cfg2 / cfg4: the
+            // launch ended when the heaviest target did, 13 ms after the average wavefront had run out of targets)
+            const bool heavy = P.mi_heavy > 0u && (unsigned int)x.nc >= P.mi_heavy;
+            if (P.mi_help_jobs && !heavy)
                 while (mi_ld_u32(&Q->n_boards) > mi_ld_u32(&Q->hint) && mi_help<L, NXY, PRE>(Q, boards, res, bacc, M, P, lane)) {
                 }
+            const unsigned long long tk1 = wall_clock64();
+            tk_help += tk1 - tk0;
             const int32_t *cands = x.phase == 0 ? A.cand0 + x.cand_off : A.tpc_key + x.co;
             const int32_t cand = cands[x.pos];
             const long long acc_off = DH_ACC_OFF(x, x.cur, 1);
@@ -667,8 +684,11 @@ __global__ __launch_bounds__(256) void dh_mi_target_kernel(DhTgt *__restrict__ t
                 if (N > (1ull << 62)) N = 1ull << 62;
             }
             if (P.max_tests > 0 && (unsigned long long)P.max_tests < N) N = (unsigned long long)P.max_tests;
-            // the first tests: alone
-            unsigned long long next = N < (unsigned long long)P.mi_seq ? N : (unsigned long long)P.mi_seq;
+            // the first tests: alone.  Elimination-phase jobs nearly always run to the end (the member passed every test against
+            // almost this pool a moment ago): a big one goes to a board at once, whole enumeration in one window
+            const bool elim_full = x.phase == 1 && P.mi_elim_min > 0u && N > (unsigned long long)P.mi_elim_min;
+            const unsigned long long seq = heavy ? P.mi_seq_heavy : P.mi_seq;
+            unsigned long long next = elim_full ? 0ull : (N < seq ? N : seq);
             FwSegOut o = mi_run_ranks<L, NXY, PRE>(M, x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, 0ull, next, nullptr, 0);
             unsigned long long ev = o.evaluated, nt = 0ull;
             bool stopped = o.stop_rank != FW_RANK_NONE;
@@ -676,8 +696,10 @@ __global__ __launch_bounds__(256) void dh_mi_target_kernel(DhTgt *__restrict__ t
             int r_pow = stopped ? o.stop_power : 1;
             double best_p = o.best_pval, best_stat = o.best_stat;
             if (stopped) nt = o.stop_rank + 1ull;
-            unsigned long long width = P.mi_win0;
+            unsigned long long width = elim_full ? N : (unsigned long long)P.mi_win0;
             unsigned int bacc_off = MI_BACC_CAP;  // this job's write-through copy of its accepted list (made with its first board)
+            const unsigned long long tk2 = wall_clock64();
+            tk_seq += tk2 - tk1;
             while (!stopped && next < N) {
                 const unsigned long long W = (N - next) < width ? (N - next) : width;
                 unsigned long long chunk = W / (unsigned long long)P.mi_chunk_div;
@@ -724,7 +746,7 @@ __global__ __launch_bounds__(256) void dh_mi_target_kernel(DhTgt *__restrict__ t
                     }
                     unsigned int spins = 0u;
                     while (mi_ld_u32(&b->done) < nch) {  // records claimed by other wavefronts: they are running
-                        if (!mi_help<L, NXY, PRE>(Q, boards, res, bacc, M, P, lane)) {
+                        if (heavy || !mi_help<L, NXY, PRE>(Q, boards, res, bacc, M, P, lane)) {
                             __builtin_amdgcn_s_sleep(2);
                             if (++spins > (1u << 27)) {  // ~30 s: a logic error, not a workload -- report instead of hanging the GPU
                                 if (lane == 0) atomicExch(&Q->pad[0], 1u);
@@ -748,6 +770,7 @@ __global__ __launch_bounds__(256) void dh_mi_target_kernel(DhTgt *__restrict__ t
                 next += W;
                 width *= 8ull;
             }
+            tk_board += wall_clock64() - tk2;
             if (!stopped) {  // every subset significant: the maximum-p result (tests.jl:338-345)
                 r_stat = best_stat;
                 r_p = best_p < 0.0 ? 0.0 : best_p;
@@ -766,6 +789,7 @@ __global__ __launch_bounds__(256) void dh_mi_target_kernel(DhTgt *__restrict__ t
         }
     }
     // no targets left to start: work on boards until every target has finished
+    const unsigned long long tk_t0 = wall_clock64();
     unsigned int spins = 0u;
     while (mi_ld_u32(&Q->targets_done) < (unsigned int)ntg && mi_ld_u32(&Q->pad[0]) == 0u) {
         if (!mi_help<L, NXY, PRE>(Q, boards, res, bacc, M, P, lane)) {
@@ -775,6 +799,14 @@ __global__ __launch_bounds__(256) void dh_mi_target_kernel(DhTgt *__restrict__ t
                 break;
             }
         }
+    }
+    tk_tail = wall_clock64() - tk_t0;
+    if (lane == 0) {  // t_body: first tests of own jobs, t_ctl: board phases, t_sleep: helping before jobs, n_seg: tail; total in pad[1] units of 2^10 ticks
+        atomicAdd(&Q->t_body, tk_seq);
+        atomicAdd(&Q->t_ctl, tk_board);
+        atomicAdd(&Q->t_sleep, tk_help);
+        atomicAdd(&Q->n_seg, tk_tail);
+        atomicAdd(&Q->t_total, tk_t0 - tk_begin);
     }
 }
 
@@ -1745,6 +1777,9 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         P.mi_chunk_min = (unsigned int)envu("FW_MI_CHUNK_MIN", 8ull);
         P.mi_chunk_max = (unsigned int)envu("FW_MI_CHUNK_MAX", 64ull);
         { const char *e = getenv("FW_MI_HELP_JOBS"); P.mi_help_jobs = e ? (unsigned int)atoi(e) : 1u; }
+        { const char *e = getenv("FW_MI_ELIM_MIN"); P.mi_elim_min = e ? (unsigned int)atoi(e) : 64u; }
+        { const char *e = getenv("FW_MI_HEAVY"); P.mi_heavy = e ? (unsigned int)atoi(e) : 48u; }
+        { const char *e = getenv("FW_MI_SEQ_HEAVY"); P.mi_seq_heavy = e ? (unsigned int)atoi(e) : P.mi_seq; }
     }
     const bool fz = c->P.kind == FW_FZ;
     P.w0_small = fz ? 256ull : 16ull;
@@ -1865,7 +1900,12 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         MiQueue hq{};
         FW_HIP(c, hipMemcpy(&hq, d_mq, sizeof(hq), hipMemcpyDeviceToHost));
         if (hq.pad[0]) return fw_fail(c, FW_ERR_DEVICE, "discrete HITON kernel: watchdog %u (boards %u, targets done %u of %d)", hq.pad[0], hq.n_boards, hq.targets_done, ntg);
-        if (trace_host) fprintf(stderr, "[fw] boards %u records %u\n", hq.n_boards, hq.res_top);
+        if (trace_host) {
+            const double nw = 4.0 * (double)grid, ms = 1e-5;
+            fprintf(stderr, "[fw] boards %u records %u; per wavefront (%u wavefronts): until out of targets %.2f ms = own first tests %.2f + board phases %.2f + helping before jobs %.2f + state machine %.2f; tail %.2f ms\n",
+                    hq.n_boards, hq.res_top, 4u * grid, ms * hq.t_total / nw, ms * hq.t_body / nw, ms * hq.t_ctl / nw, ms * hq.t_sleep / nw,
+                    ms * ((double)hq.t_total - (double)hq.t_body - (double)hq.t_ctl - (double)hq.t_sleep) / nw, ms * hq.n_seg / nw);
+        }
         float ms = 0.0f;
         FW_HIP(c, hipEventElapsedTime(&ms, ev[0][0], ev[0][1]));
         timed_s = 1e-3 * (double)ms;
