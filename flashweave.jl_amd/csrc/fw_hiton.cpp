@@ -209,6 +209,7 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
             if (!dev_cands)
                 if (int rc = fwi_nb_host_ensure(c)) return rc;
             std::vector<Target> tg;
+            tg.reserve(n_my);
             for (int i = r0; i < r1; ++i) {
                 if ((i - r0) % opt.world_size != opt.rank) continue;
                 Target t;
@@ -298,6 +299,14 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                     if (rc) return rc;
                     if (getenv("FW_TRACE_HOST")) fprintf(stderr, "[fw] device rounds (all chains): %.2f ms\n", 1e3 * (now_s() - tdev0));
                     // this round's directed results straight from the chains' flat arrays (target i went to chain i % K)
+                    {
+                        size_t nres = 0;
+                        for (size_t i = 0; i < tg.size(); ++i) nres += (size_t)pres[i % (size_t)K][i / (size_t)K].n;
+                        dev_lt.reserve(nres);
+                        dev_ln.reserve(nres);
+                        dev_ls.reserve(nres);
+                        dev_lp.reserve(nres);
+                    }
                     for (size_t i = 0; i < tg.size(); ++i) {
                         const FwDhResult &r = pres[i % (size_t)K][i / (size_t)K];
                         const FwDhFlat &f = pflat[i % (size_t)K];
@@ -420,16 +429,16 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                 int rc = allgather(user, (int64_t)lt.size(), lt.data(), ln.data(), ls.data(), lp.data(), &ntot, &at, &an, &as, &ap);
                 if (rc) return fw_fail(c, FW_ERR_ARG, "fw_learn_network: allgather callback failed (%d)", rc);
             }
-            for (int64_t i = 0; i < ntot; ++i) {
-                const int32_t T = at[i], u = an[i];
-                all_t.push_back(T);
-                all_u.push_back(u);
-                all_s.push_back(as[i]);
-                all_p.push_back(ap[i]);
-            }
+            all_t.insert(all_t.end(), at, at + ntot);
+            all_u.insert(all_u.end(), an, an + ntot);
+            all_s.insert(all_s.end(), as, as + ntot);
+            all_p.insert(all_p.end(), ap, ap + ntot);
             // interleaved.jl:136-140 add_edge! (idempotent): both directions appended, the touched lists sorted and
             // de-duplicated once per round (sorted inserts one entry at a time were 15 ms of a 170 ms cfg4 pass)
-            for (int64_t i = 0; i < ntot; ++i) {
+            // (only the whitelists of later rounds read the running graph: nothing to maintain after the last round or
+            // without feed-forward -- cfg4, one round: 380 000 appends and 50 000 sorts for nothing)
+            const bool need_adj = opt.feed_forward && r1 < nt;
+            for (int64_t i = 0; need_adj && i < ntot; ++i) {
                 const int32_t T = at[i], u = an[i];
                 adj[T].push_back(u);
                 adj[u].push_back(T);
@@ -486,6 +495,16 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
     c->e_src.clear();
     c->e_dst.clear();
     c->e_w.clear();
+    // incoming lists (b -> a for every a), ascending: the transpose of the CSR by counting sort
+    std::vector<int64_t> in_off((size_t)p + 1, 0);
+    std::vector<int32_t> in_idx(ne);
+    {
+        for (size_t i = 0; i < ne; ++i) in_off[(size_t)c->pc_idx[i] + 1]++;
+        for (int T = 0; T < p; ++T) in_off[T + 1] += in_off[T];
+        std::vector<int64_t> fill(in_off.begin(), in_off.end() - 1);
+        for (int T = 0; T < p; ++T)  // sources visited in ascending order -> every incoming list comes out sorted
+            for (int64_t i = c->pc_off[T]; i < c->pc_off[T + 1]; ++i) in_idx[(size_t)fill[c->pc_idx[i]]++] = T;
+    }
     auto find_in = [&](int T, int32_t u) -> int64_t {
         for (int64_t i = c->pc_off[T]; i < c->pc_off[T + 1]; ++i)
             if (c->pc_idx[i] == u) return i;
@@ -502,7 +521,8 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
             c->e_dst.push_back(b);
             c->e_w.push_back(ww);
         }
-        for (int32_t b : adj[a]) {  // only b -> a exists
+        for (int64_t q = in_off[a]; q < in_off[a + 1]; ++q) {  // only b -> a exists
+            const int32_t b = in_idx[(size_t)q];
             if (b <= a || find_in(a, b) >= 0) continue;
             const int64_t ri = find_in(b, a);
             if (ri < 0) continue;
@@ -512,9 +532,6 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
             c->e_dst.push_back(b);
             c->e_w.push_back(ww);
         }
-    }
-    if (c->P.max_k == 0) {
-        // adj was not maintained: every neighbour list is symmetric at level 0, the first loop covers all edges
     }
     c->have_network = true;
     if (getenv("FW_TRACE_HOST")) fprintf(stderr, "[fw] weights + symmetric graph on the host: %.2f ms\n", 1e3 * (now_s() - tp0));

@@ -14,7 +14,11 @@ PY
   grep -E "per wavefront|watchdog" gpurun_out/mipol/${cfg}_$label.err | tail -1 | cut -c1-260
 }
 for cfg in cfg2 cfg4; do
-run $cfg occ2_wg1 FW_MI_WG_PER_CU=1
-run $cfg occ2_wg2 FW_MI_WG_PER_CU=2
-run $cfg occ2_wg2_h96 FW_MI_WG_PER_CU=2 FW_MI_HEAVY=96
+run $cfg idle_off FW_MI_IDLE_MIN=0
+run $cfg idle_def FW_X=0
+run $cfg idle_s1c1 FW_MI_SEQ_IDLE=1 FW_MI_CHUNK_IDLE=1
+run $cfg idle_s4c2 FW_MI_SEQ_IDLE=4 FW_MI_CHUNK_IDLE=2
+run $cfg idle_s2c4 FW_MI_SEQ_IDLE=2 FW_MI_CHUNK_IDLE=4
+run $cfg idle_min64 FW_MI_IDLE_MIN=64
+run $cfg idle_min768 FW_MI_IDLE_MIN=768
 done
