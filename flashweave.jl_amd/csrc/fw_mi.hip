@@ -502,12 +502,22 @@ __global__ __launch_bounds__(256) void mi_level0_kernel(MiDev P, int p, int T, c
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    A[u][v] += __popcll(xn[u] & yn[v]);
+                    // acc += popcount(a & b): v_bcnt_u32_b32 adds its second operand, so a 64-bit word costs 2 ANDs + 2 BCNTs.
+                    // Written as inline asm: the compiler expands __popcll / __builtin_popcount to bcnt(x, 0) and adds the
+                    // results with a separate v_add / v_add3 per counter -- 64 of the loop's 323 instructions (r02 ISA)
+#define L0_ACC(acc, a, b)                                                                                   \
+    {                                                                                                       \
+        const unsigned lo_ = (unsigned)(a) & (unsigned)(b), hi_ = (unsigned)((a) >> 32) & (unsigned)((b) >> 32); \
+        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(lo_));                                           \
+        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(hi_));                                           \
+    }
+                    L0_ACC(A[u][v], xn[u], yn[v]);
                     if (HAS_HI) {
-                        B[u][v] += __popcll(xh[u] & yn[v]);
-                        C[u][v] += __popcll(xn[u] & yh[v]);
-                        D[u][v] += __popcll(xh[u] & yh[v]);
+                        L0_ACC(B[u][v], xh[u], yn[v]);
+                        L0_ACC(C[u][v], xn[u], yh[v]);
+                        L0_ACC(D[u][v], xh[u], yh[v]);
                     }
+#undef L0_ACC
                 }
         }
     }
