@@ -488,7 +488,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 last3 = (last3 < c3 ? last3 : c3) - 1ull;
                 if (tid == 0 || tid == 64) {
                     int q[FW_MAX_K];
-                    unrank_comb(tid == 0 ? cbase : last3, a, 3, q);
+                    fw_unrank_comb32((uint32_t)(tid == 0 ? cbase : last3), a, 3, q);  // a <= FZ_TAB_A: 32-bit form
                     s_blk[tid == 0 ? 0 : 1] = q[0];
                 }
                 __syncthreads();
@@ -540,7 +540,10 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
             int pos[FW_MAX_K];
 #pragma unroll
             for (int q = 0; q < FW_MAX_K; ++q) pos[q] = 0;
-            unrank_comb(rem, a, s, pos);
+            if (TAB)  // |accepted| <= FZ_TAB_A and max_k <= 3: ranks below 2^25, the 32-bit unranking (fw_unrank.h)
+                fw_unrank_comb32((uint32_t)rem, a, s, pos);
+            else
+                unrank_comb(rem, a, s, pos);
             int chg = 0;  // lowest position index that changed since the previous test of this lane (0 = everything)
             // cached state for s <= 3
             int z1 = 0, z2 = 0;

@@ -92,3 +92,52 @@ FW_HD void fw_unrank_comb(unsigned long long rem, int a, int s, int *pos)
         prev = a - m;
     }
 }
+
+// ---- 32-bit forms for subsets of at most 3 positions out of a <= FW_UNRANK32_A (the LDS-table kernel: a <= 512) ----
+// C(1024, 3) < 2^28 and m (m - 1) / 2 * (m - 2) < 2^29: everything fits 32-bit integers, the divisions are by constants
+// and the root guesses are single hardware instructions -- ~100 instructions per unranking instead of ~1 500 for the
+// 64-bit general form (which pays for saturating binomials up to t = 5).  Same exact integer fix-up, same answers
+// (tests/native/unrank_check.cpp compares the two on every rank).
+#define FW_UNRANK32_A 1024
+FW_HD uint32_t fw_binom32(int m, int t)  // t in 1..3, 0 <= m <= FW_UNRANK32_A
+{
+    if (m < t) return 0u;
+    const uint32_t u = (uint32_t)m;
+    if (t == 1) return u;
+    const uint32_t h = (u * (u - 1u)) >> 1;
+    return t == 2 ? h : h * (u - 2u) / 3u;
+}
+
+// smallest m in [t, mmax] with C(m, t) >= R  (1 <= R <= C(mmax, t))
+FW_HD int fw_inv_binom32(uint32_t R, int t, int mmax)
+{
+    if (t == 1) return (int)R;
+    const float x = (float)R;
+    int m;
+    if (t == 2) {
+        m = (int)((1.0f + sqrtf(1.0f + 8.0f * x)) * 0.5f);
+    } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+        m = (int)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(6.0f * x) * 0.33333334f) + 1;  // v_log_f32 / v_exp_f32: a guess
+#else
+        m = (int)cbrtf(6.0f * x) + 1;
+#endif
+    }
+    m = m < t ? t : (m > mmax ? mmax : m);
+    while (m > t && fw_binom32(m - 1, t) >= R) --m;
+    while (fw_binom32(m, t) < R) ++m;
+    return m;
+}
+
+FW_HD void fw_unrank_comb32(uint32_t rem, int a, int s, int *pos)  // s <= 3, a <= FW_UNRANK32_A
+{
+    int prev = -1;
+    for (int d = 0; d < s; ++d) {
+        const int t = s - d, n = a - 1 - prev;
+        const uint32_t tot = fw_binom32(n, t);
+        const int m = fw_inv_binom32(tot - rem, t, n);
+        rem -= tot - fw_binom32(m, t);
+        pos[d] = a - m;
+        prev = a - m;
+    }
+}

@@ -52,6 +52,59 @@ int main(int argc, char **argv)
                 ++checked;
             }
         }
+    // the 32-bit forms of the LDS-table kernel (s <= 3, a <= FW_UNRANK32_A): every rank of every a up to A_FULL32 and of
+    // the boundary sizes, against the general form
+    const int A_FULL32 = argc > 2 ? atoi(argv[2]) : 96;
+    const int edge32[] = {127, 128, 129, 255, 256, 257, 400, 511, 512};
+    for (int s = 1; s <= 3; ++s) {
+        for (int pass = 0; pass < 2; ++pass) {
+            const int na = pass == 0 ? A_FULL32 - s + 1 : (int)(sizeof(edge32) / sizeof(edge32[0]));
+            for (int ia = 0; ia < na; ++ia) {
+                const int a = pass == 0 ? s + ia : edge32[ia];
+                const unsigned long long N = fw_binom_u64(a, s);
+                if ((unsigned long long)fw_binom32(a, s) != N) {
+                    printf("binom32 mismatch a %d s %d\n", a, s);
+                    return 1;
+                }
+                int enumr[3];
+                for (int q = 0; q < s; ++q) enumr[q] = q;
+                for (unsigned long long r = 0; r < N; ++r) {
+                    int pos[3];
+                    fw_unrank_comb32((uint32_t)r, a, s, pos);
+                    if (memcmp(pos, enumr, sizeof(int) * s)) {
+                        printf("mismatch32 a %d s %d rank %llu\n", a, s, r);
+                        return 1;
+                    }
+                    ++checked;
+                    int q = s - 1;
+                    while (q >= 0 && enumr[q] == a - s + q) --q;
+                    if (q >= 0) {
+                        ++enumr[q];
+                        for (int z = q + 1; z < s; ++z) enumr[z] = enumr[z - 1] + 1;
+                    }
+                }
+            }
+        }
+    }
+    const int big32[] = {513, 777, 1023, 1024};
+    for (int s = 1; s <= 3; ++s)
+        for (int a : big32) {
+            const unsigned long long N = fw_binom_u64(a, s);
+            for (int it = 0; it < 200000; ++it) {
+                x ^= x << 13;
+                x ^= x >> 7;
+                x ^= x << 17;
+                const unsigned long long r = it < 3 ? (it == 0 ? 0 : it == 1 ? N - 1 : N / 2) : x % N;
+                int pos[5], ref[5];
+                fw_unrank_comb32((uint32_t)r, a, s, pos);
+                fw_unrank_bsearch(r, a, s, ref);
+                if (memcmp(pos, ref, sizeof(int) * s)) {
+                    printf("mismatch32 a %d s %d rank %llu\n", a, s, r);
+                    return 1;
+                }
+                ++checked;
+            }
+        }
     printf("ok %llu\n", checked);
     return 0;
 }
