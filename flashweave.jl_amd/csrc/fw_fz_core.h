@@ -309,6 +309,80 @@ __device__ __forceinline__ TV pc_l1_r(float xy, float xz, float yz, float rxz, f
     return r;
 }
 
+// ---- NaN-free forms for the table kernel's wave-uniform fast path ----
+// There every input is known not to be NaN (table entries carry a "clean" flag, the gathered entry is checked), so no
+// intermediate can be NaN either (sums / products of values in [-1, 1], square roots of 1 - v^2 >= 0, divisions by a
+// non-zero finite denominator) and `v < -1 ? -1 : v`, `v >= 1 ? 1 : v` (six instructions in Float64: the selects keep a
+// NaN) are v_max_f64 / v_min_f64: same values for every non-NaN v.
+__device__ __forceinline__ double fz_clamp_unit_nn(double v) { return __builtin_fmin(__builtin_fmax(v, -1.0), 1.0); }
+// round5 without the "not finite: hand the argument back" select (finite arguments give finite results; a NaN comes out
+// as a NaN either way)
+__device__ __forceinline__ float round5_f32_nn(float x)
+{
+    const float n = rintf(x * 100000.0f);
+    const float q0 = n * 1e-5f;
+    const float r = fmaf(-q0, 100000.0f, n);
+    return fmaf(r, 1e-5f, q0);
+}
+__device__ __forceinline__ double round5_f64_nn(double x)
+{
+    const double n = rint(x * 100000.0);
+    const double q0 = n * 1e-5;
+    const double r = fma(-q0, 100000.0, n);
+    return fma(r, 1e-5, q0);
+}
+// fz_sqrt_unit without its x == 0 select: NaN for x = 0 (the caller tests x itself), the same bits otherwise
+__device__ __forceinline__ double fz_sqrt_unit_raw(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    d = fma(-g, g, x);
+    return fma(d, h, g);
+}
+
+// pc_l1_r with the clamps done in Float32 (the conversion to Float64 is exact, so the same values) and the "still a
+// Float32 value" flag false for a NaN as well (a NaN is a NaN in either arithmetic: the slow path decides nothing else)
+__device__ __forceinline__ float pc_l1_rf(float xy, float xz, float yz, float rxz, float ryz, bool &f32ok)
+{
+    const float prod = xz * yz;
+    const float e = round5_f32_nn(xy - prod);
+    const float d = rxz * ryz;
+    const bool nz = d != 0.0f;
+    float q = e / (nz ? d : 1.0f);
+    q = nz ? q : 0.0f;
+    const bool lo = q < -1.0f, hi = q >= 1.0f;
+    q = lo ? -1.0f : q;
+    q = hi ? 1.0f : q;
+    f32ok = nz && !lo && !hi && q == q;
+    return q;
+}
+
+__device__ __forceinline__ double pc_l2_all32_d1_nn(float a, float b, float c, double d1, double d2c)
+{
+    const float prod = b * c;
+    const double ev = (double)round5_f32_nn(a - prod);
+    const double denom = d1 * d2c;
+    const double v = (denom == 0.0) ? 0.0 : ev / denom;
+    return fz_clamp_unit_nn(v);
+}
+
+// the product of the two roots is zero exactly when one of the arguments is (roots of values >= 2^-53 are >= 2^-27: no
+// underflow in the product), so one test of the arguments replaces the two selects inside fz_sqrt_unit and `denom == 0`
+__device__ __forceinline__ double pc_l3_nn(double a, double b, double c)
+{
+    const double ev = round5_f64_nn(a - b * c);
+    const double xb = 1.0 - b * b, xc = 1.0 - c * c;
+    const double denom = fz_sqrt_unit_raw(xb) * fz_sqrt_unit_raw(xc);
+    const double v = (xb == 0.0 || xc == 0.0) ? 0.0 : ev / denom;
+    return fz_clamp_unit_nn(v);
+}
+
 // statfuns.jl:44-62, all-Float64 children (level >= 3)
 __device__ __forceinline__ double pc_l3(double a, double b, double c)
 {
@@ -341,7 +415,7 @@ __device__ __forceinline__ double pc_l3(double a, double b, double c)
 // (profiles/tools/tab_bound.py 512 8192).
 #define FZ_TAB_A FW_TAB_A
 #define FZ_TAB_CAP 1024
-#define FZ_TAB_ZMASK 0x1FFFFFFF
+#define FZ_TAB_ZMASK 0x0FFFFFFF
 // entries of blocks [i0, i): block t holds a - 1 - t entries
 __device__ __forceinline__ int fz_tab_off(int i, int i0, int a)
 {
@@ -509,14 +583,17 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                         const TV A1 = pc_l1(cXY, cXz1, cYz1);
                         const TV LX = pc_l1(CORV(X, zv), cXz1, cvz1);
                         const TV LY = pc_l1(CORV(Y, zv), cYz1, cvz1);
-                        s_tab_a2[e] = pc_l2(A1, LX, LY);
+                        const double a2 = pc_l2(A1, LX, LY);
+                        s_tab_a2[e] = a2;
+                        const bool clean = LX.v == LX.v && LY.v == LY.v && a2 == a2;  // no NaN in this entry
                         // square roots the level-1 / level-2 formulas take of this entry's values (statfuns.jl:36,52);
                         // for a Float64-literal LX / LY (0, +-1) the Float32 root is the exact one as well
                         const float fx = (float)LX.v, fy = (float)LY.v;
                         s_tab_r1[e] = sqrtf(1.0f - cvz1 * cvz1);
                         s_tab_r2[e] = make_float2(sqrtf(1.0f - fx * fx), sqrtf(1.0f - fy * fy));
                         s_tab[e] = make_float4((float)LX.v, (float)LY.v, cvz1,
-                                               __int_as_float(zv | (LX.f32 ? (1 << 30) : 0) | (LY.f32 ? (1 << 29) : 0)));
+                                               __int_as_float(zv | (LX.f32 ? (1 << 30) : 0) | (LY.f32 ? (1 << 29) : 0) |
+                                                              (clean ? (1 << 28) : 0)));
                     }
                 }
                 __syncthreads();
@@ -551,32 +628,45 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
             TV A1{0.0, false}, B1{0.0, false}, C1{0.0, false};
             double A2 = 0.0;
             int boff = 0;
+            float4 tj = make_float4(0.f, 0.f, 0.f, 0.f);
+            float rj1 = 0.f;
+            float2 rj2 = make_float2(0.f, 0.f);
+            double A2j = 0.0;
             for (unsigned long long r = r0; r < r1; ++r) {
                 double stat;
                 ++my_done;
                 if (TAB && s == 3 && tab_ok) {
                     const int pi = pos[0];
                     if (chg <= 0) boff = fz_tab_off(pi, tb_i0, a) - pi - 1;
-                    const int ej = boff + pos[1], ek = boff + pos[2];
-                    const float4 tj = s_tab[ej], tk = s_tab[ek];
-                    const float rj1 = s_tab_r1[ej], rk1 = s_tab_r1[ek];
-                    const float2 rj2 = s_tab_r2[ej];
-                    const double A2j = s_tab_a2[ej];
+                    if (chg <= 1) {  // the (z1, z2) entry stays in registers while only the last position moves
+                        const int ej = boff + pos[1];
+                        tj = s_tab[ej];
+                        rj1 = s_tab_r1[ej];
+                        rj2 = s_tab_r2[ej];
+                        A2j = s_tab_a2[ej];
+                    }
+                    const int ek = boff + pos[2];
+                    const float4 tk = s_tab[ek];
+                    const float rk1 = s_tab_r1[ek];
                     const int fj = __float_as_int(tj.w), fk = __float_as_int(tk.w);
                     const float c32 = CORV(fk & FZ_TAB_ZMASK, fj & FZ_TAB_ZMASK);
-                    const TV F1 = pc_l1_r(c32, tk.z, tj.z, rk1, rj1);
-                    const double dF = fz_sqrt_unit(1.0 - F1.v * F1.v);  // shared by the two level-2 values below
-                    double D2, E2;
-                    if (__all((((fj & fk) >> 29) & 3) == 3 && F1.f32)) {  // wave-uniform fast path: no Float64 literal
-                        D2 = pc_l2_all32_d1(tk.x, tj.x, (float)F1.v, (double)rj2.x, dF);
-                        E2 = pc_l2_all32_d1(tk.y, tj.y, (float)F1.v, (double)rj2.y, dF);
+                    bool f1ok;
+                    const float F1f = pc_l1_rf(c32, tk.z, tj.z, rk1, rj1, f1ok);
+                    const double F1v = (double)F1f;
+                    const double dF = fz_sqrt_unit(1.0 - F1v * F1v);  // shared by the two level-2 values below
+                    // wave-uniform fast path: no Float64 literal and no NaN among the inputs (bit 28 = clean entry)
+                    if (__all((((fj & fk) >> 28) & 7) == 7 && f1ok)) {
+                        const double D2 = pc_l2_all32_d1_nn(tk.x, tj.x, F1f, (double)rj2.x, dF);
+                        const double E2 = pc_l2_all32_d1_nn(tk.y, tj.y, F1f, (double)rj2.y, dF);
+                        stat = pc_l3_nn(A2j, D2, E2);
                     } else {
+                        const TV F1 = pc_l1_r(c32, tk.z, tj.z, rk1, rj1);
                         const TV D1{(double)tk.x, ((fk >> 30) & 1) != 0}, Bj{(double)tj.x, ((fj >> 30) & 1) != 0};
                         const TV E1{(double)tk.y, ((fk >> 29) & 1) != 0}, Cj{(double)tj.y, ((fj >> 29) & 1) != 0};
-                        D2 = pc_l2_d2(D1, Bj, F1, dF);
-                        E2 = pc_l2_d2(E1, Cj, F1, dF);
+                        const double D2 = pc_l2_d2(D1, Bj, F1, dF);
+                        const double E2 = pc_l2_d2(E1, Cj, F1, dF);
+                        stat = pc_l3(A2j, D2, E2);
                     }
-                    stat = pc_l3(A2j, D2, E2);
                 } else if (!TAB && s == 3) {
                     if (chg <= 0) {
                         z1 = ACCV(pos[0]);
