@@ -727,7 +727,6 @@ __global__ __launch_bounds__(256) void fznz_level0_kernel(const float *__restric
 // wavefront per sum (a column mean, a column norm, a pair's dot product), the four wavefronts of the workgroup take
 // the sums of a job in turn.  r01 walked the rows sequentially in one lane per pair: serial by construction, 113 of the
 // 125 ms of a pass at 3 000 variables.
-#define FZNZ_MAXM_LDS 2050
 #define FZNZ_ROWS_LDS 16384  // rows of a view kept as an LDS list (n beyond that: the sequential form)
 
 __device__ __forceinline__ double fznz_tree64(double v)  // every lane returns the total
@@ -751,19 +750,55 @@ __device__ __forceinline__ double fznz_tree64(double v)  // every lane returns t
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-__global__ __launch_bounds__(256) void fznz_submat_kernel(const float *__restrict__ data, const unsigned long long *__restrict__ nz,
-                                                          int n, int W, FwNzJob *__restrict__ recs,
-                                                          const int32_t *__restrict__ accflat, float *__restrict__ arena,
-                                                          double alpha)
+// Per-job |r| thresholds for `p < alpha` (every job has its own n_R, hence its own Fisher-z scale).  p = erfc(|z| / sqrt2)
+// with z = zscale * log((1 + r) / (1 - r)) is below alpha exactly when |z| / sqrt2 exceeds xcrit = erfc^-1(alpha) -- one
+// number per context, found on the host -- so the threshold is r* = tanh(xcrit / (sqrt2 zscale)) in closed form; the
+// +-1e-9 guard band (inside which the exact p-value decides, see fz_seg_body) is six orders of magnitude wider than the
+// rounding of tanh / erfc.  The r01 form bisected the device p-value 400 times per job in ONE lane: 0.4 ms, the whole
+// duration of a sub-matrix launch.  xcrit < 0 (alpha >= 1: no root) keeps the bisection.
+__device__ __forceinline__ void fznz_thresholds(double alpha, double xcrit, double zscale, double *thr)
 {
-    __shared__ double s_mean[FZNZ_MAXM_LDS], s_sd[FZNZ_MAXM_LDS], s_ss01[2];
-    __shared__ int s_var[FZNZ_MAXM_LDS];
-    __shared__ unsigned short s_rows[FZNZ_ROWS_LDS];
-    __shared__ int s_woff[257];
+    if (!(xcrit >= 0.0)) {
+        fz_thresholds_dev(alpha, zscale, thr);
+        return;
+    }
+    if (!(zscale > 0.0)) {  // p = 1 for every r: never significant
+        thr[0] = thr[1] = thr[2] = thr[3] = 2.0;
+        return;
+    }
+    const double rs = tanh(xcrit * 0.7071067811865476 / zscale);  // |z| / sqrt2 = xcrit  <=>  atanh(r) = xcrit / (sqrt2 zscale)
+    thr[0] = thr[2] = rs * (1.0 - 1e-9);
+    thr[1] = thr[3] = rs * (1.0 + 1e-9);
+}
+
+#define FZNZ_NT 256                // threads per job workgroup (4 wavefronts)
+#define FZNZ_NW (FZNZ_NT / 64)
+#define FZNZ_RED_STRIDE (8 * 72)  // per-wavefront reduction scratch: 8 accumulators x (8 x 9) padded partials
+
+// dynamic LDS of a launch (bytes): reduction scratch, then per-variable arrays for the largest job, then the row list
+static inline size_t fznz_lds_bytes(int m_cap, int n)
+{
+    const size_t rows = n <= FZNZ_ROWS_LDS ? (size_t)((n + 3) & ~3) * sizeof(unsigned short) : 0;
+    return sizeof(double) * FZNZ_NW * FZNZ_RED_STRIDE + (size_t)m_cap * (2 * sizeof(double) + sizeof(int)) + 264 * sizeof(int) + rows;
+}
+
+__global__ __launch_bounds__(FZNZ_NT) void fznz_submat_kernel(const float *__restrict__ data, const unsigned long long *__restrict__ nz,
+                                                              int n, int W, FwNzJob *__restrict__ recs,
+                                                              const int32_t *__restrict__ accflat, float *__restrict__ arena,
+                                                              double alpha, int m_cap, double xcrit)
+{
+    extern __shared__ double s_dyn[];
+    __shared__ double s_ss01[2];
+    double *s_red = s_dyn;                                   // [FZNZ_NW][FZNZ_RED_STRIDE]
+    double *s_mean = s_red + FZNZ_NW * FZNZ_RED_STRIDE;      // [m_cap]
+    double *s_sd = s_mean + m_cap;                           // [m_cap]
+    int *s_var = (int *)(s_sd + m_cap);                      // [m_cap]  (m_cap is even: 8-byte alignment holds)
+    int *s_woff = s_var + m_cap;                             // [257] (+ padding)
+    unsigned short *s_rows = (unsigned short *)(s_woff + 264);  // [n] when n <= FZNZ_ROWS_LDS
     FwNzJob *rec = recs + blockIdx.x;
     const int m = rec->m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long *mx = nz + (size_t)rec->X * W, *my = nz + (size_t)rec->Y * W;
-    for (int t = tid; t < m; t += 256) s_var[t] = t == 0 ? rec->X : (t == 1 ? rec->Y : accflat[rec->acc_off + t - 2]);
+    for (int t = tid; t < m; t += FZNZ_NT) s_var[t] = t == 0 ? rec->X : (t == 1 ? rec->Y : accflat[rec->acc_off + t - 2]);
     long long nR = 0;
     for (int w = 0; w < W; ++w) nR += __popcll(mx[w] & my[w]);
     float *local = arena + rec->cor_off;
@@ -787,12 +822,14 @@ __global__ __launch_bounds__(256) void fznz_submat_kernel(const float *__restric
         }
         __syncthreads();
         const int nr = (int)nR;
-        for (int t = wave; t < m; t += 4) {  // column means and norms
+        for (int t = wave; t < m; t += FZNZ_NW) {  // column means and norms
             const float *col = data + (size_t)s_var[t] * n;
             double sacc = 0.0;
+#pragma unroll 4
             for (int q = lane; q < nr; q += 64) sacc += (double)col[s_rows[q]];
             const double mean = fznz_tree64(sacc) / (double)nR;
             double ss = 0.0;
+#pragma unroll 4
             for (int q = lane; q < nr; q += 64) {
                 const double d = (double)col[s_rows[q]] - mean;
                 ss += d * d;
@@ -804,43 +841,100 @@ __global__ __launch_bounds__(256) void fznz_submat_kernel(const float *__restric
             }
         }
         __syncthreads();
-        for (long long q0 = wave; q0 < npairs; q0 += 4) {  // one wavefront per pair
-            int a = (int)(((2.0 * m - 1.0) - sqrt((2.0 * m - 1.0) * (2.0 * m - 1.0) - 8.0 * (double)q0)) * 0.5);
-            while (a > 0 && (long long)a * (2 * m - a - 1) / 2 > q0) --a;
-            while ((long long)(a + 1) * (2 * m - a - 2) / 2 <= q0) ++a;
-            const int b = a + 1 + (int)(q0 - (long long)a * (2 * m - a - 1) / 2);
-            const float *ca = data + (size_t)s_var[a] * n, *cb = data + (size_t)s_var[b] * n;
-            const double ma = s_mean[a], mb = s_mean[b];
-            double sacc = 0.0;
+        // Dot products in register tiles: one wavefront per 4 x 4 block of pairs (a in 4A.., b in 4B.., A <= B) -- every
+        // row costs 8 gathered values for 16 products instead of 32, and the per-pair sum is the same sequence of
+        // operations as before (lane l adds the rows l, l + 64, ... of ITS pair in Float64, then tree64 over the lanes).
+        // The 64 x 16 partials meet through LDS, eight accumulators at a time: lane (c, g) = (lane >> 3, lane & 7) adds
+        // the partials of accumulator c held by lanes 8 g .. 8 g + 7 as the balanced tree of fznz_tree64 --
+        // ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7)) -- and three shuffles add the eight groups pairwise; every
+        // node of that tree has the same two operands as in the DPP form (addition commutes bit for bit), so the
+        // oracle's mirrored order still applies.
+        const int nb = (m + 3) >> 2;
+        const int ntiles = nb * (nb + 1) / 2;
+        double *red = s_red + wave * FZNZ_RED_STRIDE;
+        for (int t = wave; t < ntiles; t += FZNZ_NW) {
+            int A = (int)(((2.0 * nb + 1.0) - sqrt((2.0 * nb + 1.0) * (2.0 * nb + 1.0) - 8.0 * (double)t)) * 0.5);
+            while (A > 0 && A * (2 * nb - A + 1) / 2 > t) --A;
+            while ((A + 1) * (2 * nb - A) / 2 <= t) ++A;
+            const int B = A + (t - A * (2 * nb - A + 1) / 2);
+            const float *ca[4], *cb[4];
+            double ma[4], mb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ia = 4 * A + i < m ? 4 * A + i : m - 1, ib = 4 * B + i < m ? 4 * B + i : m - 1;
+                ca[i] = data + (size_t)s_var[ia] * n;
+                cb[i] = data + (size_t)s_var[ib] * n;
+                ma[i] = s_mean[ia];
+                mb[i] = s_mean[ib];
+            }
+            double acc[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[c] = 0.0;
             for (int q = lane; q < nr; q += 64) {
                 const int row = s_rows[q];
-                sacc += ((double)ca[row] - ma) * ((double)cb[row] - mb);
+                double xa[4], xb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xa[i] = (double)ca[i][row] - ma[i];
+                    xb[i] = (double)cb[i][row] - mb[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[4 * i + j] += xa[i] * xb[j];
             }
-            sacc = fznz_tree64(sacc);
-            double r = sacc / (s_sd[a] * s_sd[b]);
-            if (r > 1.0) r = 1.0;
-            if (r < -1.0) r = -1.0;
-            if (isnan(r)) r = 0.0;  // statfuns.jl:150
-            const float rf = (float)r;  // the scratch matrix of the reference is Float32 (learning.jl:127-129)
-            if (lane == 0) {
-                local[(size_t)a * m + b] = rf;
-                local[(size_t)b * m + a] = rf;
+            const int c = lane >> 3, g = lane & 7;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                {
+                    double *dst = red + 9 * (lane >> 3) + (lane & 7);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) dst[72 * k] = acc[8 * h + k];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const double *src = red + 72 * c + 9 * g;
+                double x[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = src[i];
+#pragma unroll
+                for (int w = 1; w < 8; w <<= 1)
+#pragma unroll
+                    for (int i = 0; i < 8; i += 2 * w) x[i] = x[i] + x[i + w];
+                double tot = x[0];
+                tot = tot + __shfl_xor(tot, 1);
+                tot = tot + __shfl_xor(tot, 2);
+                tot = tot + __shfl_xor(tot, 4);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int k16 = 8 * h + c;
+                const int a = 4 * A + (k16 >> 2), b = 4 * B + (k16 & 3);
+                if (g == 0 && a < b && b < m) {
+                    double r = tot / (s_sd[a] * s_sd[b]);
+                    if (r > 1.0) r = 1.0;
+                    if (r < -1.0) r = -1.0;
+                    if (isnan(r)) r = 0.0;  // statfuns.jl:150
+                    const float rf = (float)r;  // the scratch matrix of the reference is Float32 (learning.jl:127-129)
+                    local[(size_t)a * m + b] = rf;
+                    local[(size_t)b * m + a] = rf;
+                }
             }
         }
-        for (int t = tid; t < m; t += 256) local[(size_t)t * m + t] = 1.0f;
+        for (int t = tid; t < m; t += FZNZ_NT) local[(size_t)t * m + t] = 1.0f;
         if (tid == 0) {
             rec->rxy = 0.0;  // (only univariate jobs read it: they take the sequential form below)
             rec->nR = (int32_t)nR;
             const long long sf = nR - 3;
             rec->zscale = sf > 0 ? sqrt((double)sf) / 2.0 : 0.0;
-            fz_thresholds_dev(alpha, rec->zscale, rec->thr);
+            fznz_thresholds(alpha, xcrit, rec->zscale, rec->thr);
         }
         return;
     }
     __syncthreads();
     // sequential form (univariate jobs -- their pair statistic must equal level 0's, statfuns.jl:91-123 in row order -- and
     // views beyond the LDS row list): column means and norms over R, sequential Float64 sums in row order
-    for (int t = tid; t < m; t += 256) {
+    for (int t = tid; t < m; t += FZNZ_NT) {
         const float *col = data + (size_t)s_var[t] * n;
         double sacc = 0.0;
         for (int w = 0; w < W; ++w) {
@@ -867,7 +961,7 @@ __global__ __launch_bounds__(256) void fznz_submat_kernel(const float *__restric
         if (t < 2) s_ss01[t] = ss;
     }
     __syncthreads();
-    for (long long q = tid; q < npairs; q += 256) {
+    for (long long q = tid; q < npairs; q += FZNZ_NT) {
         // pair index -> (a, b), a < b, row-major over the upper triangle
         int a = (int)(((2.0 * m - 1.0) - sqrt((2.0 * m - 1.0) * (2.0 * m - 1.0) - 8.0 * (double)q)) * 0.5);
         while (a > 0 && (long long)a * (2 * m - a - 1) / 2 > q) --a;
@@ -900,12 +994,12 @@ __global__ __launch_bounds__(256) void fznz_submat_kernel(const float *__restric
         local[(size_t)a * m + b] = rf;
         local[(size_t)b * m + a] = rf;
     }
-    for (int t = tid; t < m; t += 256) local[(size_t)t * m + t] = 1.0f;
+    for (int t = tid; t < m; t += FZNZ_NT) local[(size_t)t * m + t] = 1.0f;
     if (tid == 0) {
         rec->nR = (int32_t)nR;
         const long long sf = nR - 3;
         rec->zscale = sf > 0 ? sqrt((double)sf) / 2.0 : 0.0;
-        fz_thresholds_dev(alpha, rec->zscale, rec->thr);
+        fznz_thresholds(alpha, xcrit, rec->zscale, rec->thr);
     }
 }
 
@@ -1015,17 +1109,53 @@ int fwi_fznz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> 
     return fw_fail(ctx, FW_ERR_DEVICE, "fz_nz level-0: compaction buffer overflow twice");
 }
 
+// erfc^-1(alpha) by bisection on the host's erfc (-1: alpha >= 1 or not a probability, the kernel bisects per job instead)
+static double fznz_xcrit(double alpha)
+{
+    if (!(alpha > 0.0) || !(alpha < 1.0)) return -1.0;
+    double lo = 0.0, hi = 40.0;  // erfc(0) = 1 >= alpha, erfc(40) = 0 < alpha
+    for (int it = 0; it < 200; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (std::erfc(mid) < alpha)
+            hi = mid;
+        else
+            lo = mid;
+    }
+    return 0.5 * (lo + hi);
+}
+
 // recs_host: one record per job of this launch (X, Y, acc_off, acc_len, m, cor_off filled); d_acc: flat accepted ints
 int fwi_fznz_submatrices(fw_ctx *ctx, int64_t njobs, const FwNzJob *recs_host, size_t arena_floats, const int32_t *d_acc,
                          hipStream_t stream)
 {
     int rc;
+    static const bool nz_trace = getenv("FW_NZ_TRACE") != nullptr;  // profiling: shape of every sub-matrix launch
+    if (nz_trace) {
+        long long mmax = 0, pairs = 0, uni = 0;
+        for (int64_t j = 0; j < njobs; ++j) {
+            mmax = std::max<long long>(mmax, recs_host[j].m);
+            pairs += (long long)recs_host[j].m * (recs_host[j].m - 1) / 2;
+            uni += recs_host[j].acc_len == 0;
+        }
+        fprintf(stderr, "[fw] fz_nz sub-matrices: %lld jobs (%lld univariate), largest m %lld, %lld pairs\n", (long long)njobs, uni, mmax, pairs);
+    }
     if ((rc = fw_dev_reserve(ctx, ctx->d_nzrecs, (size_t)njobs * sizeof(FwNzJob)))) return rc;
     if ((rc = fw_dev_reserve(ctx, ctx->d_arena, std::max<size_t>(arena_floats, 1) * sizeof(float)))) return rc;
     FW_HIP(ctx, hipMemcpyAsync(ctx->d_nzrecs.ptr, recs_host, (size_t)njobs * sizeof(FwNzJob), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(fznz_submat_kernel, dim3((unsigned)njobs), dim3(256), 0, stream, ctx->d_data,
+    int m_cap = 4;
+    for (int64_t j = 0; j < njobs; ++j) m_cap = std::max(m_cap, (int)recs_host[j].m);
+    m_cap = (m_cap + 15) & ~15;  // LDS arrays of the launch are sized for its largest job
+    const size_t lds = fznz_lds_bytes(m_cap, ctx->P.n);
+    if (lds > 160u * 1024u - 64u)
+        return fw_fail(ctx, FW_ERR_LIMIT, "fz_nz: a job with %d variables does not fit the LDS of one workgroup", m_cap);
+    static size_t lds_attr = 0;  // raise the kernel's dynamic-LDS limit once per size class (above the 64 KB default)
+    if (lds > lds_attr) {
+        (void)hipFuncSetAttribute((const void *)fznz_submat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160u * 1024u - 64u));
+        lds_attr = 160u * 1024u;
+    }
+    hipLaunchKernelGGL(fznz_submat_kernel, dim3((unsigned)njobs), dim3(FZNZ_NT), lds, stream, ctx->d_data,
                        (const unsigned long long *)ctx->d_nzbits, ctx->P.n, ctx->W, (FwNzJob *)ctx->d_nzrecs.ptr, d_acc,
-                       (float *)ctx->d_arena.ptr, ctx->P.alpha);
+                       (float *)ctx->d_arena.ptr, ctx->P.alpha, m_cap, fznz_xcrit(ctx->P.alpha));
     FW_HIP(ctx, hipGetLastError());
     ctx->cnt.kernel_launches += 1;
     return FW_OK;
