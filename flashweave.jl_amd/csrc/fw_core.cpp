@@ -844,12 +844,15 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
     size_t staged = 0;
     // fz / fz_nz with max_k <= 3: segments of jobs with at most FW_TAB_A accepted variables come first (table kernel)
     static const bool no_tab = getenv("FW_NO_TAB") != nullptr;  // profiling knob: force the in-lane caching kernel
-    const bool split = fz && c->P.max_k <= 3 && !no_tab;
+    const bool no_hk = getenv("FW_NO_HK") != nullptr;  // profiling / test knob: generic size-4/5 kernel for every job
+    const bool hk = c->P.max_k > 3;  // max_k 4-5: level-2 table kernel up to FW_HK_A accepted variables (plain fz only)
+    const bool split = fz && !no_tab && (!hk || (c->P.kind == FW_FZ && !stream && !no_hk));
+    const size_t tab_a = hk ? (size_t)FW_HK_A : (size_t)FW_TAB_A;
     for (int pass = 0; pass < (split ? 2 : 1); ++pass) {
         for (size_t ji = 0; ji < pool.live.size(); ++ji) {
             FwPoolJob &j = pool.live[ji];
             if (!j.launched) continue;
-            if (split && (j.acc.size() <= FW_TAB_A) != (pass == 0)) continue;
+            if (split && (j.acc.size() <= tab_a) != (pass == 0)) continue;
             if (j.acc_dev_off < 0) {
                 memcpy(hacc + staged, j.acc.data(), j.acc.size() * sizeof(int32_t));
                 j.acc_dev_off = (int64_t)(pool.arena_top + staged);

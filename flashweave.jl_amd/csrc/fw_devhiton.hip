@@ -34,6 +34,8 @@ struct DhTgt {
     int32_t jactive, nsp;  // nsp: look-ahead jobs of the elimination phase in the coming launch (see dh_step_kernel)
     int32_t cur, pad0;     // accepted-list buffer in use (0 .. spec_depth)
     unsigned long long jN, jnext, jwidth, jwin, jevaluated;
+    unsigned long long c_eval_short;  // executed tests of jobs with at most FW_HK_A accepted variables (FW_TRACE_HOST)
+    int na_max, na_pad;               // longest accepted list of any job of this target
     double jbest_p, jbest_stat;
     unsigned long long c_ref, c_calls, c_eval;  // per-target totals (summed on the host: no same-address atomics)
     double c_alg;
@@ -1256,6 +1258,8 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
                 x.c_ref += r_nt;
                 x.c_calls += 1ull;
                 x.c_eval += x.jevaluated;
+                x.c_eval_short += x.na <= FW_HK_A ? x.jevaluated : 0ull;
+                x.na_max = x.na > x.na_max ? x.na : x.na_max;
                 x.c_alg += dh_alg_bytes(x.na, x.jevaluated, P.max_k, P.disc_bytes_per_col);
                 kept = dh_commit(x, A, lane, d1, r_stat, r_p, r_pow, P.alpha);
             }
@@ -1295,6 +1299,7 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
                 x.c_ref += M.stop ? M.nt : x.jN;
                 x.c_calls += 1ull;
                 x.c_eval += M.ev;
+                x.c_eval_short += n <= FW_HK_A ? M.ev : 0ull;
                 x.c_alg += dh_alg_bytes(n, M.ev, P.max_k, P.disc_bytes_per_col);
                 const bool k = dh_commit(x, A, lane, d1, r_stat, r_p, M.stop ? M.pow : 1, P.alpha);
                 valid = ph1 ? k : !k;
@@ -2039,6 +2044,15 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         }
         fprintf(stderr, "[fw] chain %d: tests %llu jobs %llu; most tests in one target %llu (T=%d), most jobs in one target %llu (T=%d)\n",
                 chain, tot_ref, tot_calls, mx_ref, t_ref, mx_calls, t_calls);
+        unsigned long long ev_all = 0, ev_short = 0;
+        int na_max = 0;
+        for (const DhTgt &x : tg) {
+            ev_all += x.c_eval;
+            ev_short += x.c_eval_short;
+            na_max = std::max(na_max, x.na_max);
+        }
+        fprintf(stderr, "[fw] chain %d: executed tests %llu, of them in jobs with at most %d accepted variables %llu; longest accepted list %d\n",
+                chain, ev_all, (int)FW_HK_A, ev_short, na_max);
     }
     if (trace_host)
         fprintf(stderr, "[fw] device rounds chain %d: %d targets, set-up %.2f ms, rounds %.2f ms, results %.2f ms\n", chain, ntg,

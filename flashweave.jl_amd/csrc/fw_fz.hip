@@ -378,8 +378,11 @@ __global__ __launch_bounds__(256) void fz_test_batch_kernel(const float *__restr
 // Host-driven rounds: one workgroup per segment (ns_dev == nullptr).  Device-driven rounds (fw_devhiton.hip): a fixed
 // grid strides over an unsorted segment list whose live length sits in device memory; the table / in-lane variants
 // each pick their own segments.
+#ifndef FW_HIGHK_OCC
+#define FW_HIGHK_OCC 4  // workgroups per CU the size-4/5 variants are compiled for (4: 128 VGPRs, 2: 256 VGPRs)
+#endif
 template <bool HIGHK, bool LOCAL, bool TAB>
-__global__ __launch_bounds__(256, 4) void fz_subsets_seg_kernel(const float *__restrict__ cor_g, int p_g,
+__global__ __launch_bounds__(256, HIGHK ? FW_HIGHK_OCC : 4) void fz_subsets_seg_kernel(const float *__restrict__ cor_g, int p_g,
                                                              const FwSeg *__restrict__ segs,
                                                              const int32_t *__restrict__ accflat,
                                                              FwSegOut *__restrict__ out, int max_k, double alpha,
@@ -396,7 +399,8 @@ __global__ __launch_bounds__(256, 4) void fz_subsets_seg_kernel(const float *__r
     // one instance of the body for both modes: host-driven = exactly one iteration, every segment of the launch is ours
     const unsigned ns = ns_dev ? *ns_dev : gridDim.x;
     for (unsigned s = blockIdx.x; s < ns; s += gridDim.x) {
-        if (ns_dev && !HIGHK && ((segs[s].acc_len <= FZ_TAB_A) != TAB)) continue;  // workgroup-uniform
+        // routing by list length (workgroup-uniform); HIGHK without the flag word: the generic variant takes every segment
+        if (ns_dev && !LOCAL && (!HIGHK || big_dev) && ((segs[s].acc_len <= (HIGHK ? FZ_HK_A : FZ_TAB_A)) != TAB)) continue;
         fz_seg_body<HIGHK, LOCAL, TAB>(cor_g, p_g, segs[s], accflat + segs[s].acc_off, false, out + s, max_k, alpha, zscale_g, max_tests, thr_g, recs,
                                        n_obs_min);
         __syncthreads();  // the LDS state of the body is reused by the next segment
@@ -585,9 +589,15 @@ int fwi_fz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const i
     if (rc) return rc;
     const unsigned grid_big = grid < 512u ? grid : 512u;  // accepted sets beyond FZ_TAB_A are rare: few striding workgroups
     if (ctx->P.max_k > 3) {
-        hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false, false>), dim3(grid), dim3(256), 0, stream, ctx->d_cor, ctx->P.p, d_segs,
-                           d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr,
-                           (const FwNzJob *)nullptr, 0ll, d_ns, d_big);
+        // level-2 table variant for |accepted| <= FZ_HK_A, generic variant for the longer lists (both stride the list)
+        const bool no_hk = getenv("FW_NO_HK") != nullptr;  // profiling / test knob (read per call)
+        if (!no_hk)
+            hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false, true>), dim3(grid), dim3(256), 0, stream, ctx->d_cor, ctx->P.p, d_segs,
+                               d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr,
+                               (const FwNzJob *)nullptr, 0ll, d_ns, d_big);
+        hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false, false>), dim3(grid), dim3(256), 0, stream, ctx->d_cor,
+                           ctx->P.p, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests,
+                           ctx->d_thr, (const FwNzJob *)nullptr, 0ll, d_ns, no_hk ? (const unsigned *)nullptr : d_big);
     } else {
         hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false, true>), dim3(grid), dim3(256), 0, stream, ctx->d_cor, ctx->P.p, d_segs,
                            d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr,
@@ -610,11 +620,18 @@ int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *d_
         int rc = fz_ensure_thresholds(ctx, pb.launch_stream);
         if (rc) return rc;
     }
-    if (ctx->P.max_k > 3)
-        hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false, false>), dim3((unsigned)nseg), dim3(256), 0, pb.launch_stream, ctx->d_cor,
-                           ctx->P.p, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx),
-                           (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll, (const unsigned *)nullptr, (const unsigned *)nullptr);
-    else {
+    if (ctx->P.max_k > 3) {
+        // segments [0, nseg_tab) belong to jobs with |accepted| <= FZ_HK_A: level-2 table kernel; the rest: generic form
+        if (nseg_tab > 0)
+            hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false, true>), dim3((unsigned)nseg_tab), dim3(256), 0, pb.launch_stream,
+                               ctx->d_cor, ctx->P.p, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx),
+                               (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll, (const unsigned *)nullptr, (const unsigned *)nullptr);
+        if (nseg > nseg_tab)
+            hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false, false>), dim3((unsigned)(nseg - nseg_tab)), dim3(256), 0,
+                               pb.launch_stream, ctx->d_cor, ctx->P.p, d_segs + nseg_tab, d_acc, d_out + nseg_tab, ctx->P.max_k,
+                               ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr,
+                               0ll, (const unsigned *)nullptr, (const unsigned *)nullptr);
+    } else {
         // segments [0, nseg_tab) belong to jobs with |accepted| <= FZ_TAB_A: table kernel; the rest: in-lane caching
         if (nseg_tab > 0)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false, true>), dim3((unsigned)nseg_tab), dim3(256), 0, pb.launch_stream,

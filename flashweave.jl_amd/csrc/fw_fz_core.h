@@ -461,8 +461,79 @@ static __device__ void fz_thresholds_dev(double alpha, double zscale, double *th
 }
 
 
+// ---- level-2 tables for subsets of 4 and 5 variables (HIGHK && TAB, |accepted| <= FZ_HK_A) ----
+// With (z1, z2) = accepted[(i, j)] fixed, the bottom-up form of statfuns.jl:44-53 (fz_pcor_dp) conditions every pair of
+// {X, Y, later positions} on z1 and then on z2 before the remaining positions are looked at: those level-2 values
+// depend on (i, j) and the pair only.  Per chunk the workgroup builds, for every (i, j) sub-block the chunk touches, the
+// table {rho(X,Y|z1,z2); rho(X,v|..), rho(Y,v|..) for every later position v; rho(p,q|..) for later positions p > q}
+// in LDS (Float64: level-2 results are never Float32 values), and a test of size 5 is 6 + 3 + 1 level >= 3 formulas on
+// ten table entries instead of 15 + 10 + 6 + 3 + 1 formulas on 21 gathered matrix entries (size 4: 3 + 1 instead of
+// 10 + 6 + 3 + 1).  Same formulas on the same values in the same order: results are bit-identical to fz_pcor_dp.
+// The square root of 1 - v^2 is taken once per conditioning value and shared by the formulas that use it.
+#define FZ_HK_A FW_HK_A
+#define FZ_HK_CAP 4096  // table entries (doubles) per workgroup: 32 KB
+#define FZ_HK_DIR 96    // sub-blocks per chunk
+__device__ __forceinline__ double pc_l3s(double a, double b, double c, double sb, double sc)
+{
+    const double ev = round5_f64(a - b * c);
+    const double denom = sb * sc;
+    double v = (denom == 0.0) ? 0.0 : ev / denom;
+    v = v < -1.0 ? -1.0 : v;
+    v = v >= 1.0 ? 1.0 : v;
+    return v;
+}
+__device__ __forceinline__ double pc_l3s_nn(double a, double b, double c, double sb, double sc)  // no NaN among the inputs
+{
+    const double ev = round5_f64_nn(a - b * c);
+    const double denom = sb * sc;
+    const double v = (denom == 0.0) ? 0.0 : ev / denom;
+    return fz_clamp_unit_nn(v);
+}
+__device__ __forceinline__ double fz_sq1(double v) { return fz_sqrt_unit(1.0 - v * v); }
+// entries of one sub-block table with n later positions
+__device__ __forceinline__ int fz_hk_entries(int n) { return 1 + 2 * n + n * (n - 1) / 2; }
+// tests of one sub-block: C(n, t) for t = 2, 3 (n <= FZ_HK_A)
+__device__ __forceinline__ unsigned int fz_hk_tests(int n, int t)
+{
+    const unsigned int u = (unsigned int)n;
+    if (n < t) return 0u;
+    const unsigned int h = u * (u - 1u) / 2u;
+    return t == 2 ? h : h * (u - 2u) / 3u;
+}
+
+template <bool NN>
+__device__ __forceinline__ double fz_hk_stat(const double *__restrict__ tb, int n, int s, int l3, int l4, int l5)
+{
+#define HK_L3(a, b, c, sb, sc) (NN ? pc_l3s_nn(a, b, c, sb, sc) : pc_l3s(a, b, c, sb, sc))
+    const double *tx = tb + 1, *ty = tb + 1 + n, *tp = tb + 1 + 2 * n;
+    const double XY = tb[0], X3 = tx[l3], Y3 = ty[l3], X4 = tx[l4], Y4 = ty[l4];
+    const double P43 = tp[l4 * (l4 - 1) / 2 + l3];
+    const double sX3 = fz_sq1(X3), sY3 = fz_sq1(Y3), s43 = fz_sq1(P43);
+    // level 3: condition on z3
+    const double T_XY = HK_L3(XY, X3, Y3, sX3, sY3);
+    const double T_X4 = HK_L3(X4, X3, P43, sX3, s43);
+    const double T_Y4 = HK_L3(Y4, Y3, P43, sY3, s43);
+    const double sX4 = fz_sq1(T_X4), sY4 = fz_sq1(T_Y4);
+    if (s == 4) return HK_L3(T_XY, T_X4, T_Y4, sX4, sY4);  // level 4: condition on z4
+    const int o5 = l5 * (l5 - 1) / 2;
+    const double X5 = tx[l5], Y5 = ty[l5], P54 = tp[o5 + l4], P53 = tp[o5 + l3];
+    const double s53 = fz_sq1(P53);
+    const double T_X5 = HK_L3(X5, X3, P53, sX3, s53);
+    const double T_Y5 = HK_L3(Y5, Y3, P53, sY3, s53);
+    const double T_54 = HK_L3(P54, P53, P43, s53, s43);
+    const double s54 = fz_sq1(T_54);
+    // level 4: condition on z4
+    const double Q_XY = HK_L3(T_XY, T_X4, T_Y4, sX4, sY4);
+    const double Q_X5 = HK_L3(T_X5, T_X4, T_54, sX4, s54);
+    const double Q_Y5 = HK_L3(T_Y5, T_Y4, T_54, sY4, s54);
+    // level 5: condition on z5
+    return HK_L3(Q_XY, Q_X5, Q_Y5, fz_sq1(Q_X5), fz_sq1(Q_Y5));
+#undef HK_L3
+}
+
 // HIGHK: subsets of size 4-5 possible; LOCAL: per-job matrices (fz_nz); TAB: size-3 subsets through the LDS table
-// (the host routes only segments of jobs with |accepted| <= FZ_TAB_A to a TAB launch; never together with HIGHK)
+// (the host routes only segments of jobs with |accepted| <= FZ_TAB_A to a TAB launch); HIGHK && TAB: subsets of 4 and 5
+// variables through the level-2 tables above (jobs with |accepted| <= FZ_HK_A), sizes <= 3 through the in-lane forms
 template <bool HIGHK, bool LOCAL, bool TAB>
 __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int p_g, const FwSeg seg /* workgroup-uniform */,
                                             const int32_t *__restrict__ gacc /* the job's accepted list */,
@@ -472,22 +543,30 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                                             const double *__restrict__ thr_g, const FwNzJob *__restrict__ recs,
                                             long long n_obs_min)
 {
-    __shared__ int s_acc[TAB ? FZ_TAB_A : FW_ACC_LDS];  // TAB: |accepted| <= FZ_TAB_A by the host's routing
+    constexpr bool TAB3 = TAB && !HIGHK;          // size-3 table (max_k <= 3)
+    constexpr bool HK = TAB && HIGHK && !LOCAL;   // level-2 tables for sizes 4 and 5
+    static_assert(!(TAB && HIGHK && LOCAL), "no level-2 table variant for per-job matrices");
+    __shared__ int s_acc[TAB3 ? FZ_TAB_A : (HK ? FZ_HK_A + 8 : FW_ACC_LDS)];  // TAB: |accepted| bounded by the host's routing
+    __shared__ double s_hk[HK ? FZ_HK_CAP : 1];
+    __shared__ int s_hk_off[HK ? FZ_HK_DIR + 1 : 1];
+    __shared__ unsigned short s_hk_ij[HK ? FZ_HK_DIR : 1];
+    __shared__ unsigned long long s_hk_end;
+    __shared__ int s_hk_n, s_hk_lin0, s_hk_nan, s_hk_skip0, s_hk_prev;
     __shared__ unsigned long long s_stop[4];
     __shared__ double s_bx[4], s_bps[4];
     __shared__ unsigned long long s_br[4];
     __shared__ unsigned int s_evc[4];  // tests really executed by each wavefront in the current chunk
     __shared__ double s_best_x, s_best_ps, s_best_stat;
     __shared__ unsigned long long s_best_rank;
-    __shared__ float4 s_tab[TAB ? FZ_TAB_CAP : 1];    // {LX, LY, cor[v][z1], variable id | Float32 flags}
-    __shared__ float s_tab_r1[TAB ? FZ_TAB_CAP : 1];   // sqrt(1 - cor[v][z1]^2)                       (Float32 roots)
-    __shared__ float2 s_tab_r2[TAB ? FZ_TAB_CAP : 1];  // {sqrt(1 - LX^2), sqrt(1 - LY^2)}
-    __shared__ double s_tab_a2[TAB ? FZ_TAB_CAP : 1]; // rho(X, Y | z1, v)
+    __shared__ float4 s_tab[TAB3 ? FZ_TAB_CAP : 1];    // {LX, LY, cor[v][z1], variable id | Float32 flags}
+    __shared__ float s_tab_r1[TAB3 ? FZ_TAB_CAP : 1];   // sqrt(1 - cor[v][z1]^2)                       (Float32 roots)
+    __shared__ float2 s_tab_r2[TAB3 ? FZ_TAB_CAP : 1];  // {sqrt(1 - LX^2), sqrt(1 - LY^2)}
+    __shared__ double s_tab_a2[TAB3 ? FZ_TAB_CAP : 1]; // rho(X, Y | z1, v)
     __shared__ int s_blk[2];
 
     const int a = seg.acc_len;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool in_lds = a <= (TAB ? FZ_TAB_A : FW_ACC_LDS);
+    const bool in_lds = a <= (TAB3 ? FZ_TAB_A : (HK ? FZ_HK_A : FW_ACC_LDS));
     const float *cor = cor_g;
     int p = p_g;
     double zscale = zscale_g;
@@ -527,6 +606,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
         s_best_ps = 0.0;
         s_best_stat = 0.0;
         s_best_rank = 0;
+        if (HK) s_hk_prev = -1;
     }
     unsigned long long cnt[FW_MAX_K + 1];
 #pragma unroll
@@ -546,19 +626,119 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     const int R = (int)((len + 255) / 256 < FW_RUN_MAX ? (len + 255) / 256 : FW_RUN_MAX);
     unsigned long long evaluated = 0;
 
-    for (unsigned long long cbase = seg.start; cbase < seg.end; cbase += 256ull * R) {
-        const unsigned long long r0 = cbase + (unsigned long long)tid * R;
-        unsigned long long r1 = r0 + R;
-        if (r1 > seg.end) r1 = seg.end;
-        const bool any = r0 < seg.end;
+    unsigned long long cnext = seg.start;
+    for (unsigned long long cbase = seg.start; cbase < seg.end; cbase = cnext) {
+        unsigned long long cend = cbase + 256ull * R;
+        cend = cend < seg.end ? cend : seg.end;
+        int Rc = R;
+        // ---- level-2 tables of the (z1, z2) sub-blocks this chunk touches (see FZ_HK_A); the chunk ends where the tables
+        // are full, where the size changes, or after 256 * FW_RUN_MAX ranks ----
+        bool hk_ok = false, hk_nn = false;
+        int hk_s = 0, hk_lin0 = 0;
+        if (HK) {
+            unsigned long long rem0 = cbase;
+            int s0 = max_k;
+            while (s0 > 1 && rem0 >= cnt[s0]) {  // workgroup-uniform
+                rem0 -= cnt[s0];
+                --s0;
+            }
+            if (s0 >= 4) {
+                if (tid == 0) {
+                    int q[FW_MAX_K];
+                    fw_unrank_comb32((uint32_t)rem0, a, s0, q);  // a <= FZ_HK_A: everything fits 32 bits
+                    int i = q[0], j = q[1];
+                    // rank (inside the size-s0 enumeration) behind the last subset of sub-block (i, j)
+                    unsigned long long cur_end = (unsigned long long)(fw_binom32(a, s0) - fw_binom32(a - i, s0)) +
+                                                 (unsigned long long)(fw_binom32(a - 1 - i, s0 - 1) - fw_binom32(a - j, s0 - 1)) +
+                                                 (unsigned long long)fz_hk_tests(a - 1 - j, s0 - 2);
+                    unsigned long long lim = rem0 + 256ull * FW_RUN_MAX;  // chunk end (inside the size-s0 enumeration)
+                    if (lim > rem0 + (seg.end - cbase)) lim = rem0 + (seg.end - cbase);
+                    if (lim > cnt[s0]) lim = cnt[s0];
+                    const int ij0 = (s0 << 16) | (i << 8) | j;
+                    s_hk_skip0 = (ij0 == s_hk_prev) ? 1 : 0;  // the previous chunk's first table is this chunk's first table
+                    s_hk_prev = ij0;
+                    s_hk_lin0 = i * (a - s0 + 1) - i * (i - 1) / 2 + (j - i - 1);
+                    int nd = 0, eoff = 0;
+                    for (;;) {
+                        const int e = fz_hk_entries(a - 1 - j);
+                        if (nd > 0 && eoff + e > FZ_HK_CAP) {  // tables full: the chunk ends in front of this sub-block
+                            lim = cur_end - (unsigned long long)fz_hk_tests(a - 1 - j, s0 - 2);
+                            break;
+                        }
+                        s_hk_ij[nd] = (unsigned short)((i << 8) | j);
+                        s_hk_off[nd] = eoff;
+                        eoff += e;
+                        ++nd;
+                        if (cur_end >= lim) break;
+                        if (nd == FZ_HK_DIR) {
+                            lim = cur_end;
+                            break;
+                        }
+                        if (++j > a - s0 + 1) {  // first sub-block of the next z1-block
+                            ++i;
+                            j = i + 1;
+                        }
+                        cur_end += (unsigned long long)fz_hk_tests(a - 1 - j, s0 - 2);
+                    }
+                    s_hk_off[nd] = eoff;
+                    s_hk_n = nd;
+                    s_hk_end = cbase + (lim - rem0);
+                    if (!s_hk_skip0) s_hk_nan = 0;
+                }
+                __syncthreads();
+                const int nd = s_hk_n, etot = s_hk_off[nd];
+                cend = s_hk_end;
+                hk_ok = true;
+                hk_s = s0;
+                hk_lin0 = s_hk_lin0;
+                for (int e = (s_hk_skip0 ? s_hk_off[1] : 0) + tid; e < etot; e += 256) {
+                    int d = 0;
+                    for (int w = 64; w > 0; w >>= 1)  // largest d with off[d] <= e (FZ_HK_DIR <= 127)
+                        if (d + w < nd && s_hk_off[d + w] <= e) d += w;
+                    const int ij = s_hk_ij[d], i = ij >> 8, j = ij & 255, n = a - 1 - j;
+                    int l = e - s_hk_off[d];
+                    int A, B;  // the pair, A before B in U = [X, Y, later positions descending]
+                    if (l == 0) {
+                        A = X;
+                        B = Y;
+                    } else if (l <= 2 * n) {
+                        A = l <= n ? X : Y;
+                        B = ACCV(j + 1 + (l <= n ? l - 1 : l - 1 - n));
+                    } else {
+                        l -= 1 + 2 * n;
+                        int pl = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)l)) * 0.5f);
+                        while (pl * (pl - 1) / 2 > l) --pl;
+                        while ((pl + 1) * pl / 2 <= l) ++pl;
+                        A = ACCV(j + 1 + pl);
+                        B = ACCV(j + 1 + (l - pl * (pl - 1) / 2));
+                    }
+                    const int z1 = ACCV(i), z2 = ACCV(j);
+                    const float cAz1 = CORV(A, z1), cBz1 = CORV(B, z1), cz2z1 = CORV(z2, z1);
+                    const TV RAB = pc_l1(CORV(A, B), cAz1, cBz1);
+                    const TV RA2 = pc_l1(CORV(A, z2), cAz1, cz2z1);
+                    const TV RB2 = pc_l1(CORV(B, z2), cBz1, cz2z1);
+                    const double v = pc_l2(RAB, RA2, RB2);
+                    s_hk[e] = v;
+                    if (!(v == v)) s_hk_nan = 1;
+                }
+                __syncthreads();
+                hk_nn = s_hk_nan == 0;
+                const unsigned long long clen = cend - cbase;
+                Rc = (int)((clen + 255ull) / 256ull);
+            }
+        }
+        cnext = cend;
+        const unsigned long long r0 = cbase + (unsigned long long)tid * Rc;
+        unsigned long long r1 = r0 + Rc;
+        if (r1 > cend) r1 = cend;
+        const bool any = r0 < cend;
         // ---- table of the z1-blocks this chunk touches (see FZ_TAB_A) ----
         bool tab_ok = false;
         int tb_i0 = 0;
-        if (TAB) {
+        if (TAB3) {
             const unsigned long long c3 = (max_k >= 3) ? cnt[3] : 0ull;
             if (cbase < c3) {  // workgroup-uniform; a <= FZ_TAB_A by the host's routing
-                unsigned long long last3 = cbase + 256ull * R;
-                last3 = last3 < seg.end ? last3 : seg.end;
+                unsigned long long last3 = cend;
                 last3 = (last3 < c3 ? last3 : c3) - 1ull;
                 if (tid == 0 || tid == 64) {
                     int q[FW_MAX_K];
@@ -617,7 +797,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
             int pos[FW_MAX_K];
 #pragma unroll
             for (int q = 0; q < FW_MAX_K; ++q) pos[q] = 0;
-            if (TAB)  // |accepted| <= FZ_TAB_A and max_k <= 3: ranks below 2^25, the 32-bit unranking (fw_unrank.h)
+            if (TAB)  // |accepted| <= FZ_TAB_A with max_k <= 3, or <= FZ_HK_A with max_k <= 5: the 32-bit unranking (fw_unrank.h)
                 fw_unrank_comb32((uint32_t)rem, a, s, pos);
             else
                 unrank_comb(rem, a, s, pos);
@@ -628,6 +808,8 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
             TV A1{0.0, false}, B1{0.0, false}, C1{0.0, false};
             double A2 = 0.0;
             int boff = 0;
+            const double *hk_tb = s_hk;
+            int hk_j = 0;
             float4 tj = make_float4(0.f, 0.f, 0.f, 0.f);
             float rj1 = 0.f;
             float2 rj2 = make_float2(0.f, 0.f);
@@ -635,7 +817,18 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
             for (unsigned long long r = r0; r < r1; ++r) {
                 double stat;
                 ++my_done;
-                if (TAB && s == 3 && tab_ok) {
+                if (HK && s >= 4) {  // (every chunk of this variant that holds subsets of 4 or 5 variables has its tables)
+                    if (!hk_ok || s != hk_s) __builtin_trap();  // would be a chunking bug: fail loudly
+                    if (chg <= 1) {  // (z1, z2) changed: this sub-block's table
+                        const int pi = pos[0], pj = pos[1];
+                        const int d = pi * (a - s + 1) - pi * (pi - 1) / 2 + (pj - pi - 1) - hk_lin0;
+                        hk_tb = s_hk + s_hk_off[d];
+                        hk_j = pj;
+                    }
+                    const int nn = a - 1 - hk_j;
+                    stat = hk_nn ? fz_hk_stat<true>(hk_tb, nn, s, pos[2] - hk_j - 1, pos[3] - hk_j - 1, pos[4] - hk_j - 1)
+                                 : fz_hk_stat<false>(hk_tb, nn, s, pos[2] - hk_j - 1, pos[3] - hk_j - 1, pos[4] - hk_j - 1);
+                } else if (TAB3 && s == 3 && tab_ok) {
                     const int pi = pos[0];
                     if (chg <= 0) boff = fz_tab_off(pi, tb_i0, a) - pi - 1;
                     if (chg <= 1) {  // the (z1, z2) entry stays in registers while only the last position moves
@@ -667,7 +860,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                         const double E2 = pc_l2_d2(E1, Cj, F1, dF);
                         stat = pc_l3(A2j, D2, E2);
                     }
-                } else if (!TAB && s == 3) {
+                } else if (!TAB3 && s == 3) {
                     if (chg <= 0) {
                         z1 = ACCV(pos[0]);
                         cXz1 = CORV(X, z1);
@@ -715,7 +908,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 } else if (s == 1) {
                     z1 = ACCV(pos[0]);
                     stat = pc_l1(cXY, CORV(X, z1), CORV(Y, z1)).v;
-                } else if (HIGHK) {
+                } else if (HIGHK && !HK) {
                     int zs[FW_MAX_K];
 #pragma unroll
                     for (int q = 0; q < FW_MAX_K; ++q) zs[q] = (q < s) ? ACCV(pos[q]) : 0;
@@ -785,6 +978,16 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 if (s == 3 && pos[2] < a - 1) {  // by far the most frequent step, with static register indices (the
                     ++pos[2];                     // generic code below indexes pos[] dynamically: ~60 instructions)
                     chg = 2;
+                    continue;
+                }
+                if (HIGHK && s == 5 && pos[4] < a - 1) {
+                    ++pos[4];
+                    chg = 4;
+                    continue;
+                }
+                if (HIGHK && s == 4 && pos[3] < a - 1) {
+                    ++pos[3];
+                    chg = 3;
                     continue;
                 }
                 int i = s - 1;

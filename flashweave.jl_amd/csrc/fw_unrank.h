@@ -99,13 +99,18 @@ FW_HD void fw_unrank_comb(unsigned long long rem, int a, int s, int *pos)
 // 64-bit general form (which pays for saturating binomials up to t = 5).  Same exact integer fix-up, same answers
 // (tests/native/unrank_check.cpp compares the two on every rank).
 #define FW_UNRANK32_A 1024
-FW_HD uint32_t fw_binom32(int m, int t)  // t in 1..3, 0 <= m <= FW_UNRANK32_A
+#define FW_UNRANK32_A5 128  // positions 4 and 5: C(m, 4) * (m - 4) < 2^32 up to m = 130
+FW_HD uint32_t fw_binom32(int m, int t)  // t in 1..5, 0 <= m <= FW_UNRANK32_A (t <= 3) / FW_UNRANK32_A5 (t = 4, 5)
 {
     if (m < t) return 0u;
     const uint32_t u = (uint32_t)m;
     if (t == 1) return u;
     const uint32_t h = (u * (u - 1u)) >> 1;
-    return t == 2 ? h : h * (u - 2u) / 3u;
+    if (t == 2) return h;
+    const uint32_t c3 = h * (u - 2u) / 3u;
+    if (t == 3) return c3;
+    const uint32_t c4 = c3 * (u - 3u) / 4u;
+    return t == 4 ? c4 : c4 * (u - 4u) / 5u;
 }
 
 // smallest m in [t, mmax] with C(m, t) >= R  (1 <= R <= C(mmax, t))
@@ -117,10 +122,12 @@ FW_HD int fw_inv_binom32(uint32_t R, int t, int mmax)
     if (t == 2) {
         m = (int)((1.0f + sqrtf(1.0f + 8.0f * x)) * 0.5f);
     } else {
+        const float f = t == 3 ? 6.0f : (t == 4 ? 24.0f : 120.0f);
 #if defined(__HIP_DEVICE_COMPILE__)
-        m = (int)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(6.0f * x) * 0.33333334f) + 1;  // v_log_f32 / v_exp_f32: a guess
+        // v_log_f32 / v_exp_f32: a guess, the integer fix-up below makes it exact
+        m = (int)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(f * x) * (t == 3 ? 0.33333334f : (t == 4 ? 0.25f : 0.2f))) + (t + 1) / 2;
 #else
-        m = (int)cbrtf(6.0f * x) + 1;
+        m = (int)(t == 3 ? cbrtf(f * x) : (t == 4 ? sqrtf(sqrtf(f * x)) : exp2f(0.2f * log2f(f * x)))) + (t + 1) / 2;
 #endif
     }
     m = m < t ? t : (m > mmax ? mmax : m);
@@ -129,7 +136,7 @@ FW_HD int fw_inv_binom32(uint32_t R, int t, int mmax)
     return m;
 }
 
-FW_HD void fw_unrank_comb32(uint32_t rem, int a, int s, int *pos)  // s <= 3, a <= FW_UNRANK32_A
+FW_HD void fw_unrank_comb32(uint32_t rem, int a, int s, int *pos)  // s <= 3: a <= FW_UNRANK32_A; s <= 5: a <= FW_UNRANK32_A5
 {
     int prev = -1;
     for (int d = 0; d < s; ++d) {

@@ -12,7 +12,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     n, p, a, m = 2000, 4000, int(os.environ.get("ABL_A", "40")), int(os.environ.get("ABL_M", "4000"))
     base = rng.standard_normal((n, 6))
     data = (base @ rng.standard_normal((6, p)) + 1.5 * rng.standard_normal((n, p))).astype(np.float32)
-    eng = fw.Engine("fz", n, p, max_k=3, alpha=0.999999)
+    eng = fw.Engine("fz", n, p, max_k=int(os.environ.get("ABL_K", "3")), alpha=0.999999)
     eng.set_data(data); eng.cor()
     T = rng.integers(0, p, m); C = (T + 1 + rng.integers(0, p - 1, m)) % p
     A = [list(rng.choice(p, a, replace=False)) for _ in range(m)]
@@ -23,6 +23,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(json.dumps(dict(a=a, tests=c["cond_tests_evaluated"], kernel_s=c["t_dev_subsets_s"],
                           tests_per_s=c["cond_tests_evaluated"] / c["t_dev_subsets_s"], launches=c["subsets_launches"])))
 else:
-    for a in (12, 40, 120):
-        env = dict(os.environ, ABL_A=str(a), ABL_M=str(max(200, 160000 // (a * a))))
+    k = int(os.environ.get("ABL_K", "3"))
+    for a in ((12, 40, 120) if k <= 3 else (16, 30, 45)):
+        env = dict(os.environ, ABL_A=str(a), ABL_M=str(max(200, 160000 // (a * a)) if k <= 3 else (2000 if a <= 16 else 200 if a <= 30 else 40)))
         subprocess.run([sys.executable, __file__, "child"], env=env)

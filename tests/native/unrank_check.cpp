@@ -86,6 +86,48 @@ int main(int argc, char **argv)
             }
         }
     }
+    // sizes 4 and 5 in 32 bits (a <= FW_UNRANK32_A5): every rank up to a = 36, random ranks beyond
+    for (int s = 4; s <= 5; ++s) {
+        for (int a = s; a <= 36; ++a) {
+            const unsigned long long N = fw_binom_u64(a, s);
+            if ((unsigned long long)fw_binom32(a, s) != N) {
+                printf("binom32 mismatch a %d s %d\n", a, s);
+                return 1;
+            }
+            for (unsigned long long r = 0; r < N; ++r) {
+                int pos[5], ref[5];
+                fw_unrank_comb32((uint32_t)r, a, s, pos);
+                fw_unrank_comb(r, a, s, ref);
+                if (memcmp(pos, ref, sizeof(int) * s)) {
+                    printf("mismatch32 a %d s %d rank %llu\n", a, s, r);
+                    return 1;
+                }
+                ++checked;
+            }
+        }
+        const int mid32[] = {37, 50, 64, 87, 88, 89, 100, 127, 128};
+        for (int a : mid32) {
+            const unsigned long long N = fw_binom_u64(a, s);
+            if ((unsigned long long)fw_binom32(a, s) != N) {
+                printf("binom32 mismatch a %d s %d\n", a, s);
+                return 1;
+            }
+            for (int it = 0; it < 200000; ++it) {
+                x ^= x << 13;
+                x ^= x >> 7;
+                x ^= x << 17;
+                const unsigned long long r = it < 3 ? (it == 0 ? 0 : it == 1 ? N - 1 : N / 2) : x % N;
+                int pos[5], ref[5];
+                fw_unrank_comb32((uint32_t)r, a, s, pos);
+                fw_unrank_bsearch(r, a, s, ref);
+                if (memcmp(pos, ref, sizeof(int) * s)) {
+                    printf("mismatch32 a %d s %d rank %llu\n", a, s, r);
+                    return 1;
+                }
+                ++checked;
+            }
+        }
+    }
     const int big32[] = {513, 777, 1023, 1024};
     for (int s = 1; s <= 3; ++s)
         for (int a : big32) {
