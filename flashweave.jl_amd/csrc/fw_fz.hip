@@ -567,6 +567,9 @@ int fwi_fz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y
 static int fz_ensure_thresholds(fw_ctx *ctx, hipStream_t stream)
 {
     if (!ctx->d_thr) {
+        const char *dbg = getenv("FW_FZ_DBG");
+        const int flags = dbg ? atoi(dbg) : 0;
+        FW_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(fz_dbg_flags), &flags, sizeof(int)));
         FW_HIP(ctx, hipMalloc((void **)&ctx->d_thr, 8 * sizeof(double)));
         hipLaunchKernelGGL(fz_thresholds_kernel, dim3(1), dim3(64), 0, stream, ctx->P.alpha, fz_zscale(ctx), ctx->d_thr);
         FW_HIP(ctx, hipGetLastError());

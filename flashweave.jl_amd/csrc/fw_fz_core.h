@@ -61,10 +61,84 @@ __device__ __forceinline__ double round5_f64(double x)
     return isfinite(y) ? y : x;
 }
 
+// sqrt(x) for x in {0} U [2^-52, 1] (here: 1 - v^2 with |v| <= 1 in Float64): the library's sequence (v_rsq_f64 + two
+// Goldschmidt / Newton steps, correctly rounded) without its scaling for arguments below 2^-767 and its
+// infinity check -- the same instructions on the same values, hence the same bits, 6 instructions less per root.
+__device__ __forceinline__ double fz_sqrt_unit(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return x == 0.0 ? 0.0 : g;  // rsq(0) = inf would poison g; NaN propagates as in sqrt
+}
+
 // Partial correlation rho(X, Y | z[0..K-1]) with the reference's peel order (last element first) and its mixed
 // Float32/Float64 arithmetic, evaluated bottom-up: U = [X, Y, z_K, ..., z_1]; level j conditions
 // every remaining pair (a before b in U) on z_j.  (The recursion of statfuns.jl:44-53 touches exactly these
 // pairs in exactly these argument orders; level-1 values are symmetric.)
+// levels 2..K of the bottom-up form, in place on the level-1 values R / is32 (pairs a < b < M - 1 of
+// U = [X, Y, z_K, ..., z_2]; z_1 has been conditioned on): returns rho(X, Y | z_1..z_K)
+template <int K>
+__device__ __forceinline__ double fz_pcor_levels(double (&R)[K + 2][K + 2], bool (&is32)[K + 2][K + 2])
+{
+    constexpr int M = K + 2;
+#pragma unroll
+    for (int j = 2; j <= K; ++j) {
+        const int last = M - j;
+#pragma unroll
+        for (int a = 0; a < M; ++a)
+#pragma unroll
+            for (int b = a + 1; b < M; ++b) {
+                if (b < last) {
+                    const double va = R[a][b], vb = R[a][last], vc = R[b][last];
+                    double ev, d1;
+                    if (j == 2) {
+                        const bool a32 = is32[a][b], b32 = is32[a][last], c32 = is32[b][last];
+                        double prod;
+                        bool p32;
+                        if (b32 && c32) {
+                            prod = (double)((float)vb * (float)vc);
+                            p32 = true;
+                        } else {
+                            prod = vb * vc;
+                            p32 = false;
+                        }
+                        if (a32 && p32)
+                            ev = (double)round5_f32((float)va - (float)prod);
+                        else
+                            ev = round5_f64(va - prod);
+                        if (b32) {
+                            const float bb = (float)vb * (float)vb;
+                            d1 = (double)sqrtf(1.0f - bb);
+                        } else {
+                            d1 = fz_sqrt_unit(1.0 - vb * vb);
+                        }
+                    } else {
+                        ev = round5_f64(va - vb * vc);
+                        d1 = fz_sqrt_unit(1.0 - vb * vb);
+                    }
+                    const double d2 = fz_sqrt_unit(1.0 - vc * vc);
+                    const double denom = d1 * d2;
+                    double v = (denom == 0.0) ? 0.0 : ev / denom;
+                    if (v < -1.0)
+                        v = -1.0;
+                    else if (v >= 1.0)
+                        v = 1.0;
+                    R[a][b] = v;
+                    is32[a][b] = false;
+                }
+            }
+    }
+    return R[0][1];
+}
+
 template <int K>
 __device__ __forceinline__ double fz_pcor_dp(const float *__restrict__ cor, int p, int X, int Y, const int *z)
 {
@@ -114,54 +188,7 @@ __device__ __forceinline__ double fz_pcor_dp(const float *__restrict__ cor, int 
                 is32[a][b] = f32;
             }
     }
-#pragma unroll
-    for (int j = 2; j <= K; ++j) {
-        const int last = M - j;
-#pragma unroll
-        for (int a = 0; a < M; ++a)
-#pragma unroll
-            for (int b = a + 1; b < M; ++b) {
-                if (b < last) {
-                    const double va = R[a][b], vb = R[a][last], vc = R[b][last];
-                    double ev, d1;
-                    if (j == 2) {
-                        const bool a32 = is32[a][b], b32 = is32[a][last], c32 = is32[b][last];
-                        double prod;
-                        bool p32;
-                        if (b32 && c32) {
-                            prod = (double)((float)vb * (float)vc);
-                            p32 = true;
-                        } else {
-                            prod = vb * vc;
-                            p32 = false;
-                        }
-                        if (a32 && p32)
-                            ev = (double)round5_f32((float)va - (float)prod);
-                        else
-                            ev = round5_f64(va - prod);
-                        if (b32) {
-                            const float bb = (float)vb * (float)vb;
-                            d1 = (double)sqrtf(1.0f - bb);
-                        } else {
-                            d1 = sqrt(1.0 - vb * vb);
-                        }
-                    } else {
-                        ev = round5_f64(va - vb * vc);
-                        d1 = sqrt(1.0 - vb * vb);
-                    }
-                    const double d2 = sqrt(1.0 - vc * vc);
-                    const double denom = d1 * d2;
-                    double v = (denom == 0.0) ? 0.0 : ev / denom;
-                    if (v < -1.0)
-                        v = -1.0;
-                    else if (v >= 1.0)
-                        v = 1.0;
-                    R[a][b] = v;
-                    is32[a][b] = false;
-                }
-            }
-    }
-    return R[0][1];
+    return fz_pcor_levels<K>(R, is32);
 }
 
 __device__ __forceinline__ double fz_pcor_any(const float *__restrict__ cor, int p, int X, int Y, const int *z, int k)
@@ -188,24 +215,6 @@ struct TV {
     double v;
     bool f32;
 };
-
-// sqrt(x) for x in {0} U [2^-52, 1] (here: 1 - v^2 with |v| <= 1 in Float64): the library's sequence (v_rsq_f64 + two
-// Goldschmidt / Newton steps, correctly rounded) without its scaling for arguments below 2^-767 and its
-// infinity check -- the same instructions on the same values, hence the same bits, 6 instructions less per root.
-__device__ __forceinline__ double fz_sqrt_unit(double x)
-{
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y;
-    double h = 0.5 * y;
-    const double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    double d = fma(-g, g, x);
-    g = fma(d, h, g);
-    d = fma(-g, g, x);
-    g = fma(d, h, g);
-    return x == 0.0 ? 0.0 : g;  // rsq(0) = inf would poison g; NaN propagates as in sqrt
-}
 
 // statfuns.jl:32-41 with ContType = Float32
 __device__ __forceinline__ TV pc_l1(float xy, float xz, float yz)
@@ -531,6 +540,50 @@ __device__ __forceinline__ double fz_hk_stat(const double *__restrict__ tb, int 
 #undef HK_L3
 }
 
+// ---- level-1 table for subsets of 4 and 5 variables over LONG accepted lists (HIGHK && !TAB, FZ_HK_A < |accepted| <= FZ_L1_A) ----
+// A (z1, z2) table does not fit LDS there, but a chunk of 8192 ranks nearly always lies inside ONE z1-block (C(a-1-i, s-1)
+// subsets), and everything level 1 needs about a later position v given z1 -- rho(X,v|z1), rho(Y,v|z1), cor[v][z1] and its
+// Float32 root, the entries of the size-3 table -- is one LDS entry per position.  A test then gathers the C(s-1, 2)
+// matrix entries among its own later positions (6 instead of 21 for size 5) and evaluates 6 level-1 formulas with
+// ready-made roots instead of 15 full ones; levels 2..K are fz_pcor_levels as before (same values, same order).
+#define FZ_L1_A 1024
+static __device__ int fz_dbg_flags;  // profiling knob (FW_FZ_DBG, set by fz_ensure_thresholds): bit 0 = no level-1 table
+template <int K>
+__device__ __forceinline__ double fz_l1t_stat(const float *__restrict__ cor, int p, const float4 *__restrict__ tab,
+                                              const unsigned char *__restrict__ tabf, const int *__restrict__ acc, const int *pos,
+                                              double a1v, bool a1f)
+{
+    constexpr int M = K + 2;
+    double R[M][M];
+    bool is32[M][M];
+    float c[K - 1], r[K - 1];
+    int zid[K - 1];
+    R[0][1] = a1v;
+    is32[0][1] = a1f;
+#pragma unroll
+    for (int t = 0; t < K - 1; ++t) {  // U[2 + t] = z_{K - t} = accepted[pos[K - 1 - t]]
+        const int pp = pos[K - 1 - t];
+        const float4 e = tab[pp];
+        const int f = tabf[pp];
+        R[0][2 + t] = (double)e.x;
+        is32[0][2 + t] = (f & 1) != 0;
+        R[1][2 + t] = (double)e.y;
+        is32[1][2 + t] = (f & 2) != 0;
+        c[t] = e.z;
+        r[t] = e.w;
+        zid[t] = acc[pp];
+    }
+#pragma unroll
+    for (int t = 0; t < K - 1; ++t)
+#pragma unroll
+        for (int u = t + 1; u < K - 1; ++u) {
+            const TV v = pc_l1_r(cor[(size_t)zid[t] * p + zid[u]], c[t], c[u], r[t], r[u]);
+            R[2 + t][2 + u] = v.v;
+            is32[2 + t][2 + u] = v.f32;
+        }
+    return fz_pcor_levels<K>(R, is32);
+}
+
 // HIGHK: subsets of size 4-5 possible; LOCAL: per-job matrices (fz_nz); TAB: size-3 subsets through the LDS table
 // (the host routes only segments of jobs with |accepted| <= FZ_TAB_A to a TAB launch); HIGHK && TAB: subsets of 4 and 5
 // variables through the level-2 tables above (jobs with |accepted| <= FZ_HK_A), sizes <= 3 through the in-lane forms
@@ -547,6 +600,11 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     constexpr bool HK = TAB && HIGHK && !LOCAL;   // level-2 tables for sizes 4 and 5
     static_assert(!(TAB && HIGHK && LOCAL), "no level-2 table variant for per-job matrices");
     __shared__ int s_acc[TAB3 ? FZ_TAB_A : (HK ? FZ_HK_A + 8 : FW_ACC_LDS)];  // TAB: |accepted| bounded by the host's routing
+    constexpr bool L1T = HIGHK && !TAB && !LOCAL;  // level-1 table for sizes 4 and 5 over long lists
+    __shared__ float4 s_l1[L1T ? FZ_L1_A : 1];         // {rho(X,v|z1), rho(Y,v|z1), cor[v][z1], sqrt(1 - cor[v][z1]^2)} per position v
+    __shared__ unsigned char s_l1f[L1T ? FZ_L1_A : 1];  // Float32 flags of the first two
+    __shared__ double s_l1a;                            // rho(X,Y|z1)
+    __shared__ int s_l1af;
     __shared__ double s_hk[HK ? FZ_HK_CAP : 1];
     __shared__ int s_hk_off[HK ? FZ_HK_DIR + 1 : 1];
     __shared__ unsigned short s_hk_ij[HK ? FZ_HK_DIR : 1];
@@ -725,6 +783,44 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 hk_nn = s_hk_nan == 0;
                 const unsigned long long clen = cend - cbase;
                 Rc = (int)((clen + 255ull) / 256ull);
+            }
+        }
+        bool l1_ok = false;
+        int l1_s = 0;
+        if (L1T && in_lds && a <= FZ_L1_A && !(fz_dbg_flags & 1)) {
+            unsigned long long rem0 = cbase;
+            int s0 = max_k;
+            while (s0 > 1 && rem0 >= cnt[s0]) {  // workgroup-uniform
+                rem0 -= cnt[s0];
+                --s0;
+            }
+            if (s0 >= 4 && rem0 + (cend - cbase) <= cnt[s0]) {  // the whole chunk holds subsets of s0 variables
+                if (tid == 0 || tid == 64) {
+                    const unsigned long long rr = tid == 0 ? rem0 : rem0 + (cend - cbase) - 1ull;
+                    s_blk[tid == 0 ? 0 : 1] = a - fw_inv_binom(cnt[s0] - rr, s0, a);  // first position of that rank
+                }
+                __syncthreads();
+                const int i0 = s_blk[0], i1 = s_blk[1];
+                if (i0 == i1) {  // ... inside one z1-block
+                    l1_ok = true;
+                    l1_s = s0;
+                    const int z1 = ACCV(i0);
+                    const float cXz1 = CORV(X, z1), cYz1 = CORV(Y, z1);
+                    for (int v = i0 + 1 + tid; v < a; v += 256) {
+                        const int zv = ACCV(v);
+                        const float cvz1 = CORV(zv, z1);
+                        const TV LX = pc_l1(CORV(X, zv), cXz1, cvz1);
+                        const TV LY = pc_l1(CORV(Y, zv), cYz1, cvz1);
+                        s_l1[v] = make_float4((float)LX.v, (float)LY.v, cvz1, sqrtf(1.0f - cvz1 * cvz1));
+                        s_l1f[v] = (unsigned char)((LX.f32 ? 1 : 0) | (LY.f32 ? 2 : 0));
+                    }
+                    if (tid == 0) {
+                        const TV A1 = pc_l1(cXY, cXz1, cYz1);
+                        s_l1a = A1.v;
+                        s_l1af = A1.f32 ? 1 : 0;
+                    }
+                }
+                __syncthreads();
             }
         }
         cnext = cend;
@@ -908,6 +1004,9 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 } else if (s == 1) {
                     z1 = ACCV(pos[0]);
                     stat = pc_l1(cXY, CORV(X, z1), CORV(Y, z1)).v;
+                } else if (L1T && l1_ok && s == l1_s) {
+                    stat = s == 5 ? fz_l1t_stat<5>(cor, p, s_l1, s_l1f, s_acc, pos, s_l1a, s_l1af != 0)
+                                  : fz_l1t_stat<4>(cor, p, s_l1, s_l1f, s_acc, pos, s_l1a, s_l1af != 0);
                 } else if (HIGHK && !HK) {
                     int zs[FW_MAX_K];
 #pragma unroll

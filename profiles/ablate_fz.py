@@ -24,6 +24,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
                           tests_per_s=c["cond_tests_evaluated"] / c["t_dev_subsets_s"], launches=c["subsets_launches"])))
 else:
     k = int(os.environ.get("ABL_K", "3"))
-    for a in ((12, 40, 120) if k <= 3 else (16, 30, 45)):
-        env = dict(os.environ, ABL_A=str(a), ABL_M=str(max(200, 160000 // (a * a)) if k <= 3 else (2000 if a <= 16 else 200 if a <= 30 else 40)))
+    sizes = (12, 40, 120) if k <= 3 else ((100, 200) if os.environ.get("ABL_LONG") else (16, 30, 45))
+    for a in sizes:
+        env = dict(os.environ, ABL_A=str(a), ABL_M=str(max(200, 160000 // (a * a)) if k <= 3 else (2000 if a <= 16 else 200 if a <= 30 else 40 if a <= 45 else 2)))
         subprocess.run([sys.executable, __file__, "child"], env=env)

@@ -437,3 +437,72 @@ def test_single_il_first_two_targets_have_no_whitelist():
     assert np.array_equal(np.isnan(got["pc_pval"]), np.isnan(exp["pc_pval"]))
     assert not np.isnan(got["pc_pval"][got["pc_off"][1]])  # target 1 tested variable 0
     eng.close()
+
+
+def _unrank_subset(rank, a, max_k):
+    """positions of the subset with this rank in the enumeration of tests.jl:281-346 (sizes max_k..1, lexicographic)"""
+    from math import comb
+    s = max_k
+    while s > 1 and rank >= comb(a, s):
+        rank -= comb(a, s)
+        s -= 1
+    pos, prev = [], -1
+    for d in range(s):
+        t = s - d
+        c = prev + 1
+        while rank >= comb(a - 1 - c, t - 1):
+            rank -= comb(a - 1 - c, t - 1)
+            c += 1
+        pos.append(c)
+        prev = c
+    return pos
+
+
+@pytest.mark.parametrize("max_k", [4, 5])
+def test_size_4_5_table_kernels_value_at_random_ranks(max_k):
+    """The level-2 table kernel (|accepted| <= 88) and the level-1 table path of the generic kernel (longer lists) against
+    the explicit-test kernel (fz_test_batch_kernel: plain fz_pcor_dp on gathered entries).  alpha ~ 1 makes every test
+    significant, so a job stops at rank max_tests - 1 (tests.jl:326-336) and reports THAT test: the statistic at
+    a random rank deep inside the enumeration -- any z1-block, any (z1, z2) sub-block -- is compared bit for bit, together
+    with the conditioning set (host-side unranking) and the test count."""
+    from math import comb
+    rng = np.random.default_rng(40 + max_k)
+    n, p = 300, 260
+    base = rng.standard_normal((n, 5))
+    data = np.asfortranarray((base @ rng.standard_normal((5, p)) * 0.7 + rng.standard_normal((n, p))).astype(np.float32))
+    ref = fw.Engine("fz", n, p, max_k=max_k, alpha=0.999999)
+    ref.set_data(data)
+    cm = ref.cor()
+    lens = [6, 17, 40, 63, 88, 89, 100, 130, 200]
+    checked = 0
+    for rep in range(10):
+        a_for_m = int(rng.choice(lens))
+        total = sum(comb(a_for_m, s) for s in range(1, max_k + 1))
+        # ranks spread over the whole enumeration of one of the list lengths (log-uniform: early and late blocks alike)
+        M = int(np.exp(rng.uniform(0.0, np.log(min(total, 3_000_000))))) + 1
+        eng = fw.Engine("fz", n, p, max_k=max_k, alpha=0.999999, max_tests=M)
+        eng.set_cor_mat(cm)
+        T, Cn, A = [], [], []
+        for a in lens:
+            for _ in range(3):
+                v = [int(x) for x in rng.choice(p, size=a + 2, replace=False)]
+                T.append(v[0]); Cn.append(v[1]); A.append(v[2:])
+        got = eng.test_subsets_batch(T, Cn, A)
+        X, Y, Z, G = [], [], [], []
+        for t, c, acc, g in zip(T, Cn, A, got):
+            tot = sum(comb(len(acc), s) for s in range(1, max_k + 1))
+            if tot < M:
+                continue  # the enumeration ends before max_tests: nothing stops this job (covered elsewhere)
+            # (a partial correlation that rounds to exactly 0 has p = 1 and stops the job earlier: then THAT test is the one)
+            assert g["num_tests"] <= M and (g["num_tests"] == M or g["pval"] >= 0.999999), (len(acc), M, g)
+            pos = _unrank_subset(g["num_tests"] - 1, len(acc), max_k)
+            zs = tuple(acc[q] for q in pos)
+            assert tuple(g["Zs"]) == zs, (len(acc), M, g, zs)
+            X.append(t); Y.append(c); Z.append(zs); G.append(g)
+        exp = ref.test_batch(X, Y, Z)
+        for g, e in zip(G, exp):
+            assert g["stat"] == e.stat and g["pval"] == e.pval, (M, g, e)
+            checked += 1
+        eng.close()
+    ref.close()
+    assert checked > 60
