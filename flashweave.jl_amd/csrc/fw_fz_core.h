@@ -79,13 +79,37 @@ __device__ __forceinline__ double fz_sqrt_unit(double x)
     return x == 0.0 ? 0.0 : g;  // rsq(0) = inf would poison g; NaN propagates as in sqrt
 }
 
+// ---- NaN-free forms for the table kernel's wave-uniform fast path ----
+// There every input is known not to be NaN (table entries carry a "clean" flag, the gathered entry is checked), so no
+// intermediate can be NaN either (sums / products of values in [-1, 1], square roots of 1 - v^2 >= 0, divisions by a
+// non-zero finite denominator) and `v < -1 ? -1 : v`, `v >= 1 ? 1 : v` (six instructions in Float64: the selects keep a
+// NaN) are v_max_f64 / v_min_f64: same values for every non-NaN v.
+__device__ __forceinline__ double fz_clamp_unit_nn(double v) { return __builtin_fmin(__builtin_fmax(v, -1.0), 1.0); }
+// round5 without the "not finite: hand the argument back" select (finite arguments give finite results; a NaN comes out
+// as a NaN either way)
+__device__ __forceinline__ float round5_f32_nn(float x)
+{
+    const float n = rintf(x * 100000.0f);
+    const float q0 = n * 1e-5f;
+    const float r = fmaf(-q0, 100000.0f, n);
+    return fmaf(r, 1e-5f, q0);
+}
+__device__ __forceinline__ double round5_f64_nn(double x)
+{
+    const double n = rint(x * 100000.0);
+    const double q0 = n * 1e-5;
+    const double r = fma(-q0, 100000.0, n);
+    return fma(r, 1e-5, q0);
+}
 // Partial correlation rho(X, Y | z[0..K-1]) with the reference's peel order (last element first) and its mixed
 // Float32/Float64 arithmetic, evaluated bottom-up: U = [X, Y, z_K, ..., z_1]; level j conditions
 // every remaining pair (a before b in U) on z_j.  (The recursion of statfuns.jl:44-53 touches exactly these
 // pairs in exactly these argument orders; level-1 values are symmetric.)
 // levels 2..K of the bottom-up form, in place on the level-1 values R / is32 (pairs a < b < M - 1 of
 // U = [X, Y, z_K, ..., z_2]; z_1 has been conditioned on): returns rho(X, Y | z_1..z_K)
-template <int K>
+// NN: no NaN among the level-1 values (checked by the caller), hence none anywhere below -- the selects that keep a NaN
+// alive (round5's isfinite, the two clamps) become plain arithmetic / v_max + v_min: same values for every non-NaN input
+template <int K, bool NN = false>
 __device__ __forceinline__ double fz_pcor_levels(double (&R)[K + 2][K + 2], bool (&is32)[K + 2][K + 2])
 {
     constexpr int M = K + 2;
@@ -111,9 +135,9 @@ __device__ __forceinline__ double fz_pcor_levels(double (&R)[K + 2][K + 2], bool
                             p32 = false;
                         }
                         if (a32 && p32)
-                            ev = (double)round5_f32((float)va - (float)prod);
+                            ev = (double)(NN ? round5_f32_nn((float)va - (float)prod) : round5_f32((float)va - (float)prod));
                         else
-                            ev = round5_f64(va - prod);
+                            ev = NN ? round5_f64_nn(va - prod) : round5_f64(va - prod);
                         if (b32) {
                             const float bb = (float)vb * (float)vb;
                             d1 = (double)sqrtf(1.0f - bb);
@@ -121,16 +145,20 @@ __device__ __forceinline__ double fz_pcor_levels(double (&R)[K + 2][K + 2], bool
                             d1 = fz_sqrt_unit(1.0 - vb * vb);
                         }
                     } else {
-                        ev = round5_f64(va - vb * vc);
+                        ev = NN ? round5_f64_nn(va - vb * vc) : round5_f64(va - vb * vc);
                         d1 = fz_sqrt_unit(1.0 - vb * vb);
                     }
                     const double d2 = fz_sqrt_unit(1.0 - vc * vc);
                     const double denom = d1 * d2;
                     double v = (denom == 0.0) ? 0.0 : ev / denom;
-                    if (v < -1.0)
-                        v = -1.0;
-                    else if (v >= 1.0)
-                        v = 1.0;
+                    if (NN) {
+                        v = fz_clamp_unit_nn(v);
+                    } else {
+                        if (v < -1.0)
+                            v = -1.0;
+                        else if (v >= 1.0)
+                            v = 1.0;
+                    }
                     R[a][b] = v;
                     is32[a][b] = false;
                 }
@@ -318,28 +346,6 @@ __device__ __forceinline__ TV pc_l1_r(float xy, float xz, float yz, float rxz, f
     return r;
 }
 
-// ---- NaN-free forms for the table kernel's wave-uniform fast path ----
-// There every input is known not to be NaN (table entries carry a "clean" flag, the gathered entry is checked), so no
-// intermediate can be NaN either (sums / products of values in [-1, 1], square roots of 1 - v^2 >= 0, divisions by a
-// non-zero finite denominator) and `v < -1 ? -1 : v`, `v >= 1 ? 1 : v` (six instructions in Float64: the selects keep a
-// NaN) are v_max_f64 / v_min_f64: same values for every non-NaN v.
-__device__ __forceinline__ double fz_clamp_unit_nn(double v) { return __builtin_fmin(__builtin_fmax(v, -1.0), 1.0); }
-// round5 without the "not finite: hand the argument back" select (finite arguments give finite results; a NaN comes out
-// as a NaN either way)
-__device__ __forceinline__ float round5_f32_nn(float x)
-{
-    const float n = rintf(x * 100000.0f);
-    const float q0 = n * 1e-5f;
-    const float r = fmaf(-q0, 100000.0f, n);
-    return fmaf(r, 1e-5f, q0);
-}
-__device__ __forceinline__ double round5_f64_nn(double x)
-{
-    const double n = rint(x * 100000.0);
-    const double q0 = n * 1e-5;
-    const double r = fma(-q0, 100000.0, n);
-    return fma(r, 1e-5, q0);
-}
 // fz_sqrt_unit without its x == 0 select: NaN for x = 0 (the caller tests x itself), the same bits otherwise
 __device__ __forceinline__ double fz_sqrt_unit_raw(double x)
 {
@@ -551,7 +557,7 @@ static __device__ int fz_dbg_flags;  // profiling knob (FW_FZ_DBG, set by fz_ens
 template <int K>
 __device__ __forceinline__ double fz_l1t_stat(const float *__restrict__ cor, int p, const float4 *__restrict__ tab,
                                               const unsigned char *__restrict__ tabf, const int *__restrict__ acc, const int *pos,
-                                              double a1v, bool a1f)
+                                              double a1v, bool a1f, bool clean /* no NaN in the table (whole chunk) */)
 {
     constexpr int M = K + 2;
     double R[M][M];
@@ -580,8 +586,12 @@ __device__ __forceinline__ double fz_l1t_stat(const float *__restrict__ cor, int
             const TV v = pc_l1_r(cor[(size_t)zid[t] * p + zid[u]], c[t], c[u], r[t], r[u]);
             R[2 + t][2 + u] = v.v;
             is32[2 + t][2 + u] = v.f32;
+            clean = clean && v.v == v.v;
         }
-    return fz_pcor_levels<K>(R, is32);
+#ifndef FW_L1T_NO_NN  // (A/B knob)
+    if (__all(clean)) return fz_pcor_levels<K, true>(R, is32);  // wave-uniform: no NaN among the level-1 values
+#endif
+    return fz_pcor_levels<K, false>(R, is32);
 }
 
 // HIGHK: subsets of size 4-5 possible; LOCAL: per-job matrices (fz_nz); TAB: size-3 subsets through the LDS table
@@ -604,7 +614,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     __shared__ float4 s_l1[L1T ? FZ_L1_A : 1];         // {rho(X,v|z1), rho(Y,v|z1), cor[v][z1], sqrt(1 - cor[v][z1]^2)} per position v
     __shared__ unsigned char s_l1f[L1T ? FZ_L1_A : 1];  // Float32 flags of the first two
     __shared__ double s_l1a;                            // rho(X,Y|z1)
-    __shared__ int s_l1af;
+    __shared__ int s_l1af, s_l1nan;
     __shared__ double s_hk[HK ? FZ_HK_CAP : 1];
     __shared__ int s_hk_off[HK ? FZ_HK_DIR + 1 : 1];
     __shared__ unsigned short s_hk_ij[HK ? FZ_HK_DIR : 1];
@@ -785,7 +795,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 Rc = (int)((clen + 255ull) / 256ull);
             }
         }
-        bool l1_ok = false;
+        bool l1_ok = false, l1_clean = false;
         int l1_s = 0;
         if (L1T && in_lds && a <= FZ_L1_A && !(fz_dbg_flags & 1)) {
             unsigned long long rem0 = cbase;
@@ -795,6 +805,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 --s0;
             }
             if (s0 >= 4 && rem0 + (cend - cbase) <= cnt[s0]) {  // the whole chunk holds subsets of s0 variables
+                if (tid == 0) s_l1nan = 0;
                 if (tid == 0 || tid == 64) {
                     const unsigned long long rr = tid == 0 ? rem0 : rem0 + (cend - cbase) - 1ull;
                     s_blk[tid == 0 ? 0 : 1] = a - fw_inv_binom(cnt[s0] - rr, s0, a);  // first position of that rank
@@ -813,14 +824,17 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                         const TV LY = pc_l1(CORV(Y, zv), cYz1, cvz1);
                         s_l1[v] = make_float4((float)LX.v, (float)LY.v, cvz1, sqrtf(1.0f - cvz1 * cvz1));
                         s_l1f[v] = (unsigned char)((LX.f32 ? 1 : 0) | (LY.f32 ? 2 : 0));
+                        if (!(LX.v == LX.v && LY.v == LY.v && cvz1 == cvz1)) s_l1nan = 1;
                     }
                     if (tid == 0) {
                         const TV A1 = pc_l1(cXY, cXz1, cYz1);
                         s_l1a = A1.v;
                         s_l1af = A1.f32 ? 1 : 0;
+                        if (!(A1.v == A1.v)) s_l1nan = 1;
                     }
                 }
                 __syncthreads();
+                l1_clean = s_l1nan == 0;
             }
         }
         cnext = cend;
@@ -1005,8 +1019,8 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                     z1 = ACCV(pos[0]);
                     stat = pc_l1(cXY, CORV(X, z1), CORV(Y, z1)).v;
                 } else if (L1T && l1_ok && s == l1_s) {
-                    stat = s == 5 ? fz_l1t_stat<5>(cor, p, s_l1, s_l1f, s_acc, pos, s_l1a, s_l1af != 0)
-                                  : fz_l1t_stat<4>(cor, p, s_l1, s_l1f, s_acc, pos, s_l1a, s_l1af != 0);
+                    stat = s == 5 ? fz_l1t_stat<5>(cor, p, s_l1, s_l1f, s_acc, pos, s_l1a, s_l1af != 0, l1_clean)
+                                  : fz_l1t_stat<4>(cor, p, s_l1, s_l1f, s_acc, pos, s_l1a, s_l1af != 0, l1_clean);
                 } else if (HIGHK && !HK) {
                     int zs[FW_MAX_K];
 #pragma unroll

@@ -9,7 +9,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     import numpy as np
     import flashweave_jl_amd as fw
     rng = np.random.default_rng(0)
-    n, p, a, m = 2000, 4000, int(os.environ.get("ABL_A", "40")), int(os.environ.get("ABL_M", "4000"))
+    n, p, a, m = 2000, 4000, int(os.environ.get("ABL_A", "40")), int(os.environ.get("ABL_M_OVERRIDE", os.environ.get("ABL_M", "4000")))
     base = rng.standard_normal((n, 6))
     data = (base @ rng.standard_normal((6, p)) + 1.5 * rng.standard_normal((n, p))).astype(np.float32)
     eng = fw.Engine("fz", n, p, max_k=int(os.environ.get("ABL_K", "3")), alpha=0.999999)
