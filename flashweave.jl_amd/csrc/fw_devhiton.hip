@@ -1768,7 +1768,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     {
         auto envu = [](const char *n, unsigned long long d) { const char *e = getenv(n); return e && atoll(e) > 0 ? (unsigned long long)atoll(e) : d; };
         P.growth_small = envu("FW_DH_GROWTH_SMALL", 256ull);
-        P.growth = envu("FW_DH_GROWTH", 8ull);  // cfg3 sweep: 4 -> 322 ms, 8 -> 321.5, 16 -> 331, 32 -> 350 (the host pool uses 16: its rounds cost 3x more)
+        P.growth = envu("FW_DH_GROWTH", 4ull);  // cfg3 sweeps: r01 4 -> 322 ms, 8 -> 321.5, 16 -> 331, 32 -> 350; r02 (three chains) 2 -> 219.6, 4 -> 218.3, 8 -> 219.7, 16 -> 241 (the host pool uses 16: its rounds cost 3x more)
         P.growth_busy = envu("FW_DH_GROWTH_BUSY", 4ull);
         P.busy_jobs = (unsigned int)envu("FW_DH_BUSY_JOBS", 2048ull);
         P.spec_depth = spec_depth;

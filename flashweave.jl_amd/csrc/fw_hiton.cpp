@@ -267,7 +267,7 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                     // busy.  cfg3, ms per pass with 1 / 2 / 3 / 4 chains: 261.8 / 229.4 / 224.2 / 274.3 on one GPU,
                     // 70.5 / 62.4 / 63.7 for one rank of eight; the per-launch duration of the segment kernel grows with
                     // the overlap (224 -> 167 us for launches half the size), which is what HIP events and rocprofv3 see
-                    static const int dh_chains = [] { const char *e = getenv("FW_DH_CHAINS"); return std::min(std::max(e ? atoi(e) : 2, 1), FW_DH_MAX_CHAINS); }();
+                    static const int dh_chains = [] { const char *e = getenv("FW_DH_CHAINS"); return std::min(std::max(e ? atoi(e) : 2, 1), FW_DH_MAX_CHAINS); }();  // r02: cfg3 227 / 218 / 268 ms with 2 / 3 / 4 in a bare process, but 226 / 298 under torch.distributed.run and 325 with GPU_MAX_HW_QUEUES=8: the third stream's hardware queue is not ours to choose -> 2
                     static const size_t dh_chain_min = [] { const char *e = getenv("FW_DH_CHAIN_MIN"); return e && atol(e) > 0 ? (size_t)atol(e) : (size_t)256; }();
                     static const int dh_chains_disc = [] { const char *e = getenv("FW_DH_CHAINS_DISC"); return std::min(std::max(e ? atoi(e) : 2, 1), FW_DH_MAX_CHAINS); }();  // cfg4: 248.7 / 232.9 / 227.2 / 253.1 ms with 1 / 2 / 3 / 4
                     // discrete kinds run as ONE persistent launch that fills the GPU by itself (dh_mi_target_kernel); concurrent

@@ -1,0 +1,8 @@
+run() { echo -n "$* : "; env "$@" python bench.py --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],1), round(d['other_schedule']['ms_per_step'],1), d['edges'], d['tests_per_step']['conditional_evaluated'], d['rounds'])"; }
+run A=0
+run FW_DH_GROWTH=4 FW_DH_CHAINS=3
+run FW_DH_GROWTH=4
+run FW_DH_CHAINS=3
+run FW_DH_GROWTH=2 FW_DH_CHAINS=3
+run FW_DH_GROWTH=4 FW_DH_CHAINS=4
