@@ -35,7 +35,7 @@ struct DhTgt {
     int32_t cur, pad0;     // accepted-list buffer in use (0 .. spec_depth)
     unsigned long long jN, jnext, jwidth, jwin, jevaluated;
     unsigned long long c_eval_short;  // executed tests of jobs with at most FW_HK_A accepted variables (FW_TRACE_HOST)
-    int na_max, na_pad;               // longest accepted list of any job of this target
+    int na_max, wl_used;              // longest accepted list of any job of this target; whitelisted candidates appended in phase 0
     double jbest_p, jbest_stat;
     unsigned long long c_ref, c_calls, c_eval;  // per-target totals (summed on the host: no same-address atomics)
     double c_alg;
@@ -48,7 +48,9 @@ struct DhGlobal {
     unsigned long long cond_tests_ref, subsets_calls, evaluated;
     double alg_bytes;
     unsigned int n_act, act_sel;  // unfinished targets: act[act_sel * ntg + 0 .. n_act) (dh_compact_kernel)
-    unsigned int any_big, pad_big;  // the coming launch holds a segment with |accepted| > FW_TAB_A (set by dh_fill_kernel): the
+    unsigned int any_big, max_ab;   // max_ab: largest (accepted + whitelisted neighbours still to come) of any target so far: what a
+                                    // list can reach without tested acceptances.  any_big:
+                                    // the coming launch holds a segment with |accepted| > FW_TAB_A (set by dh_fill_kernel): the
                                     // in-lane variant of the fz segment kernel leaves at once when it does not
     unsigned int ns_ring[64];  // segments of the last 64 planned launches (the host reads the record once per batch)
 };
@@ -154,6 +156,7 @@ __device__ bool dh_advance(DhTgt &x, const DhArrays &A, int lane, int d1)
                     dp[dn] = NAN;
                 }
                 ++x.na;
+                x.wl_used += x.phase == 0 ? 1 : 0;
                 ++dn;
                 ++x.pos;
                 continue;
@@ -1323,6 +1326,10 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
             x.jevaluated = 0ull;
             x.jactive = 1;
             if (lane == 0 && (unsigned int)x.na > g->max_a) atomicMax(&g->max_a, (unsigned int)x.na);  // rare: only on a new maximum
+            {   // phase 0: the list can still take every whitelisted neighbour it has not met; phase 1: pools never exceed TPC
+                const int abi = x.phase == 0 ? x.na + x.wl_n - x.wl_used : (x.na > x.ntpc ? x.na : x.ntpc);
+                if (lane == 0 && (unsigned int)abi > g->max_ab) atomicMax(&g->max_ab, (unsigned int)abi);
+            }
             if (x.phase == 0 && P.spec0_depth > 0 && g->launched_ranks < P.spec0_below && g->n_live_prev < P.spec0_jobs) {
                 const int32_t *cands = A.cand0 + x.cand_off;
                 int q = 0;
@@ -1617,7 +1624,9 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     std::vector<DhTgt> tg((size_t)ntg);
     std::vector<int32_t> cand0, wl;
     long long co = 0, wo = 0;
-    int max_cap = 0;
+    int max_cap = 0, max_wl = 0;  // most candidates / most whitelisted neighbours of one target
+    unsigned max_a_seen = 0;      // longest accepted list reported so far (lags by up to two batches)
+    unsigned max_ab_seen = 0;     // ... and the largest accepted + whitelisted-to-come
     for (int t = 0; t < ntg; ++t) {
         DhTgt x{};
         x.T = in[t].T;
@@ -1635,6 +1644,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         co += x.nc;
         wo += in[t].wl_n;
         max_cap = std::max(max_cap, x.nc);
+        max_wl = std::max(max_wl, (int)in[t].wl_n);
         tg[t] = x;
     }
     const size_t tot = (size_t)co;
@@ -1918,13 +1928,21 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         }
     } else {
     planfill(true);  // nothing to merge yet: creates the first jobs and the first launch (plan #0)
-    unsigned max_a_seen = 0;  // longest accepted list reported so far (lags by up to two batches)
+    max_a_seen = 0;
+    max_ab_seen = (unsigned)max_wl;  // before any record: all whitelisted neighbours are still to come
+    bool big_skipped[2] = {false, false};  // per batch slot: some round of it ran without the in-lane kernel
     auto enqueue_batch = [&](unsigned b) -> int {
         const int q = (int)(b & 1u);
         for (int r = 0; r < BATCH; ++r) {
             const bool timed = ((r + (int)(b % (unsigned)time_every)) % time_every) == 0;  // the sampled slot rotates from batch to batch
             // lists grow by at most one entry per round: 3 batches cover the lag of the record plus this batch
-            const bool any_big = any_big_static && (any_wl || max_a_seen + 3u * (unsigned)BATCH + 1u > (unsigned)FW_TAB_A);
+            // ... and a whitelisted neighbour is appended at most once per target: max_ab (accepted + whitelisted neighbours
+            // still to come, maximum over the targets, kept by dh_step_kernel) bounds what whitelists can add.  (r02
+            // profile: with whitelists the in-lane kernel was launched every round "in case" and left on the device flag --
+            // 16 us of every round's critical path, 26 ms per chain and pass at cfg3.)
+            const bool any_big = any_big_static && max_ab_seen + 3u * (unsigned)BATCH + 1u > (unsigned)FW_TAB_A;
+            if (r == 0) big_skipped[q] = false;
+            if (!any_big) big_skipped[q] = true;
             if (timed) (void)hipEventRecord(ev[q][2 * r], st);
             // discrete segment kernel: one workgroup per record, no stride loop -> the grid follows the bound on the list
             const unsigned grid_mi = std::min(max_ns, seg_target + n_act_bound * (unsigned)(1 + std::max(spec_depth, spec0_depth)) + 256u);
@@ -1958,7 +1976,10 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
                 log_ms[idx] = ms;
             }
         }
+        if (fz && c->P.max_k <= 3 && big_skipped[q] && rec.max_a > (unsigned)FW_TAB_A)  // the bound above failed: fail loudly
+            return fw_fail(c, FW_ERR_DEVICE, "device rounds: an accepted list of %u entries met a batch without the in-lane kernel", rec.max_a);
         max_a_seen = rec.max_a > max_a_seen ? rec.max_a : max_a_seen;
+        max_ab_seen = rec.max_ab > max_ab_seen ? rec.max_ab : max_ab_seen;
         n_act_bound = rec.n_act < n_act_bound ? rec.n_act : n_act_bound;
         *done = rec.done != 0u;
         return FW_OK;
@@ -2054,6 +2075,9 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         fprintf(stderr, "[fw] chain %d: executed tests %llu, of them in jobs with at most %d accepted variables %llu; longest accepted list %d\n",
                 chain, ev_all, (int)FW_HK_A, ev_short, na_max);
     }
+    if (trace_host)
+        fprintf(stderr, "[fw] chain %d: longest accepted list %u, accepted + whitelisted to come %u (most whitelisted neighbours of one target %d)\n",
+                chain, max_a_seen, max_ab_seen, max_wl);
     if (trace_host)
         fprintf(stderr, "[fw] device rounds chain %d: %d targets, set-up %.2f ms, rounds %.2f ms, results %.2f ms\n", chain, ntg,
                 1e3 * (th1 - th0), 1e3 * (th2 - th1), 1e3 * (wall() - th2));
