@@ -1683,7 +1683,11 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     static const unsigned long long seg_b_env = [] { const char *e = getenv("FW_SEG_B"); return e ? (unsigned long long)atoll(e) : 12000000ull; }();
     const unsigned long long seg_a = c->P.kind == FW_FZ ? seg_a_env : 0ull, seg_b = c->P.kind == FW_FZ ? seg_b_env : 0ull;
     const unsigned max_ns = seg_target + (unsigned)ntg * (unsigned)(1 + std::max(spec_depth, spec0_depth)) + 256u;  // capacity of the segment list
-    const unsigned grid_seg = seg_target + 512u;                // striding workgroups of the segment kernel
+    // striding workgroups of the segment kernel.  FW_SEG_GRID caps them (experiment: with fewer workgroups than resident
+    // slots the one-workgroup step / plan kernels of the OTHER chain find a free CU at once instead of queueing behind
+    // this launch's pending workgroups -- cfg5 profile: dh_plan_kernel 6.3 ms per call, all of it waiting)
+    static const unsigned seg_grid_env = [] { const char *e = getenv("FW_SEG_GRID"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 0u; }();
+    const unsigned grid_seg = seg_grid_env ? std::min(seg_target + 512u, seg_grid_env) : seg_target + 512u;
     // FW_DH_LOG=<file>: one line per planned launch (ranks, live jobs, segments) -- profiling aid, see profiles/README.md
     static const char *log_path = getenv("FW_DH_LOG");
     constexpr unsigned LOG_CAP = 1u << 16;
