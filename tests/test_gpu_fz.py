@@ -506,3 +506,33 @@ def test_size_4_5_table_kernels_value_at_random_ranks(max_k):
         eng.close()
     ref.close()
     assert checked > 60
+
+
+def test_device_rounds_max_k5_table_kernels_equal_gather_form(monkeypatch):
+    """Device rounds at max_k = 5 on data whose accepted lists run past 88 variables: the level-2 table kernel (short lists)
+    and the level-1 table path (long lists) against the plain gather form of the same kernels (FW_NO_HK=1, FW_FZ_DBG=1:
+    fz_pcor_dp on gathered matrix entries) -- network, directed lists, weights, p-values and reference-order test counts
+    must agree bit for bit; max_tests bounds the enumerations (C(100, 5) = 7.5e7 subsets per job)."""
+    rng = np.random.default_rng(77)
+    n, p = 2000, 260
+    # two blocks of noisy copies of one hidden factor each: no subset of five members separates two others (the factor is
+    # not observed), so candidates keep being accepted and the lists grow to the block size (130)
+    f = rng.standard_normal((n, 2))
+    data = np.asfortranarray((f[:, np.arange(p) % 2] + 2.0 * rng.standard_normal((n, p))).astype(np.float32))
+    res = {}
+    for tag, env in (("tables", {}), ("gather", {"FW_NO_HK": "1", "FW_FZ_DBG": "1"})):
+        for k in ("FW_NO_HK", "FW_FZ_DBG"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = fw.Engine("fz", n, p, max_k=5, alpha=0.05, max_tests=60_000)
+        eng.set_data(data)
+        eng.cor()
+        res[tag] = (eng.lgl(feed_forward=True, round_size=128), eng.counters())
+        eng.close()
+    (nt, ct), (ng, cg) = res["tables"], res["gather"]
+    assert nt["edges"] == ng["edges"] and len(nt["edges"]) > 200
+    for key in ("pc_off", "pc_idx", "pc_weight", "pc_pval"):
+        assert np.array_equal(nt[key], ng[key], equal_nan=True), key
+    assert ct["cond_tests_ref"] == cg["cond_tests_ref"] and ct["subsets_calls"] == cg["subsets_calls"]
+    assert ct["cond_tests_ref"] > 50_000_000  # (and FW_TRACE_HOST=1 shows accepted lists beyond 88 entries)
