@@ -620,6 +620,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     __shared__ unsigned short s_hk_ij[HK ? FZ_HK_DIR : 1];
     __shared__ unsigned long long s_hk_end;
     __shared__ int s_hk_n, s_hk_lin0, s_hk_nan, s_hk_skip0, s_hk_prev;
+    __shared__ unsigned int s_cstop;  // smallest stopping rank of the current chunk so far (relative to the chunk), 0xffffffff = none
     __shared__ unsigned long long s_stop[4];
     __shared__ double s_bx[4], s_bps[4];
     __shared__ unsigned long long s_br[4];
@@ -674,6 +675,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
         s_best_ps = 0.0;
         s_best_stat = 0.0;
         s_best_rank = 0;
+        s_cstop = 0xffffffffu;
         if (HK) s_hk_prev = -1;
     }
     unsigned long long cnt[FW_MAX_K + 1];
@@ -1042,8 +1044,13 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                     my_stop = r;
                     stop_stat = stat;
                     stop_p = fz_pval_slow(stat, zscale);
+                    (void)__hip_atomic_fetch_min(&s_cstop, (unsigned int)(r - cbase), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     break;
                 }
+                // a lane of this workgroup has stopped at an earlier rank of the chunk: nothing behind it matters any more
+                // (the merge takes the first stop) -- r01/r02 profile: lanes running on behind the stop were the 18 % of
+                // speculative tests
+                if (__hip_atomic_load(&s_cstop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned int)(r - cbase)) break;
                 // tests.jl:338 `pval >= lowest.pval`, sequential within the run, without evaluating p (or even z) for
                 // every test.  In the normal regime (|r| < rsub_lo, i.e. x < FZ_X_SUB) p is strictly decreasing in |r|
                 // once two values differ by more than rounding noise, so a clearly smaller |r| replaces the lane best
