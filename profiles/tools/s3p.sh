@@ -1,0 +1,9 @@
+run() { echo -n "$* : "; env "$@" python bench.py --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],1), round(d['other_schedule']['ms_per_step'],1), d['edges'], d['tests_per_step']['conditional_evaluated'])"; }
+run A=0
+run FW_SEG_TARGET=2560
+run FW_SEG_TARGET=4096
+run FW_DH_GROWTH=8
+run FW_DH_GROWTH=16
+run FW_SEG_A=4000000 FW_SEG_B=8000000
+run FW_SEG_A=16000000 FW_SEG_B=24000000
