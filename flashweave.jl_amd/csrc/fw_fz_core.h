@@ -616,7 +616,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     __shared__ double s_l1a;                            // rho(X,Y|z1)
     __shared__ int s_l1af, s_l1nan;
     __shared__ double s_hk[HK ? FZ_HK_CAP : 1];
-    __shared__ int s_hk_off[HK ? FZ_HK_DIR + 1 : 1];
+    __shared__ int s_hk_off[HK ? FZ_HK_DIR + 1 : 2];
     __shared__ unsigned short s_hk_ij[HK ? FZ_HK_DIR : 1];
     __shared__ unsigned long long s_hk_end;
     __shared__ int s_hk_n, s_hk_lin0, s_hk_nan, s_hk_skip0, s_hk_prev;
