@@ -280,3 +280,24 @@ def test_dense_equals_sparse_mi_nz(max_k):
     assert set(nets[0]["edges"]) == set(nets[1]["edges"]) and len(nets[0]["edges"]) >= 4
     for e, w in nets[0]["edges"].items():
         assert rel(w, nets[1]["edges"][e]) < 1e-9
+
+
+def test_closed_form_fz_thresholds_sit_inside_the_guard_band():
+    """csrc/fw_fz.hip fznz_thresholds: the |r| threshold of `p < alpha` for a job with n_R rows is taken in closed form,
+    r* = tanh(erfc^-1(alpha) / (sqrt2 * zscale)), zscale = sqrt(n_R - 3) / 2, and the kernels decide by the exact p-value
+    inside r* (1 +- 1e-9).  Here: the same formula against the oracle's p-value function (statfuns.jl:3-17) -- just outside
+    the band the verdict of the threshold and of the p-value must agree, for small and large n_R and alpha from 1e-12 to
+    0.9999 (the band is ~6 orders of magnitude wider than the rounding of tanh / erfc)."""
+    import math
+    from scipy.special import erfcinv
+
+    for alpha in (1e-12, 1e-6, 0.001, 0.01, 0.05, 0.5, 0.9999):
+        xcrit = float(erfcinv(alpha))
+        for n_r in (4, 5, 10, 40, 200, 2000, 100000):
+            zscale = math.sqrt(n_r - 3) / 2.0
+            rs = math.tanh(xcrit * 0.7071067811865476 / zscale)
+            for sgn in (1.0, -1.0):
+                hi, lo = sgn * rs * (1.0 + 1e-9), sgn * rs * (1.0 - 1e-9)
+                if abs(hi) < 1.0:
+                    assert O.fz_pval(hi, n_r, 0) < alpha, (alpha, n_r, sgn)
+                assert not (O.fz_pval(lo, n_r, 0) < alpha), (alpha, n_r, sgn)
