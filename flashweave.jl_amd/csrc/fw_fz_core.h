@@ -414,6 +414,9 @@ __device__ __forceinline__ double pc_l3(double a, double b, double c)
 // reuses every partial correlation that does not involve the position that changed (for max_k = 3 that is 4 of the
 // 10 formula evaluations and 6 of the 10 matrix entries).  Rank order is preserved: a lane stops at its first
 // stopping rank, the workgroup takes the minimum over lanes.
+#ifndef FW_FZ_INTERLEAVE
+#define FW_FZ_INTERLEAVE 1  // table kernel: interleaved lane <-> rank mapping for size-3 chunks (0: runs everywhere; A/B knob)
+#endif
 #ifndef FW_RUN_MAX
 #define FW_RUN_MAX 32  // chunk = 8192 ranks: fewer table builds / unrankings per test (16 -> 32: -9 % kernel time at cfg3)
 #endif
@@ -840,10 +843,18 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
             }
         }
         cnext = cend;
-        const unsigned long long r0 = cbase + (unsigned long long)tid * Rc;
-        unsigned long long r1 = r0 + Rc;
+        // Lane <-> rank mapping.  Runs: lane l of the workgroup takes Rc consecutive ranks (one unranking, unit steps).
+        // Interleaved (table kernel, chunk entirely inside the size-3 enumeration): wavefront w owns the 64 Rc consecutive
+        // ranks behind cbase + w 64 Rc and lane l takes every 64th of them -- in step t the wavefront tests 64 consecutive
+        // ranks, so a stop in step t ends the whole wavefront (all later steps hold later ranks): no lanes running on in
+        // a half-empty wavefront behind a stop, at the price of a step of 64 ranks (a short carry loop) instead of 1.
+        const bool ilv = TAB3 && FW_FZ_INTERLEAVE && max_k >= 3 && cend <= cnt[3];  // workgroup-uniform
+        const unsigned long long r0 = ilv ? cbase + (unsigned long long)wave * 64ull * Rc + (unsigned long long)lane
+                                          : cbase + (unsigned long long)tid * Rc;
+        unsigned long long r1 = ilv ? cbase + (unsigned long long)(wave + 1) * 64ull * Rc : r0 + Rc;
         if (r1 > cend) r1 = cend;
-        const bool any = r0 < cend;
+        const unsigned long long rstep = ilv ? 64ull : 1ull;
+        const bool any = r0 < r1;
         // ---- table of the z1-blocks this chunk touches (see FZ_TAB_A) ----
         bool tab_ok = false;
         int tb_i0 = 0;
@@ -926,7 +937,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
             float rj1 = 0.f;
             float2 rj2 = make_float2(0.f, 0.f);
             double A2j = 0.0;
-            for (unsigned long long r = r0; r < r1; ++r) {
+            for (unsigned long long r = r0; r < r1; r += rstep) {
                 double stat;
                 ++my_done;
                 if (HK && s >= 4) {  // (every chunk of this variant that holds subsets of 4 or 5 variables has its tables)
@@ -1095,6 +1106,26 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                     }
                 }
                 // next combination in lexicographic order (sizes descend when one is exhausted)
+                if (TAB3 && ilv) {  // 64 ranks ahead, only if that rank is still this lane's (it is then inside the size-3
+                    if (r + 64ull >= r1) break;  // enumeration and the carry loop below ends)
+                    int i = pos[0], j = pos[1], k = pos[2] + 64;
+                    chg = 2;
+                    while (k > a - 1) {  // row (i, j) holds k = j + 1 .. a - 1: carry the overflow into the next rows
+                        const int over = k - a;
+                        if (++j > a - 2) {
+                            ++i;
+                            j = i + 1;
+                            chg = 0;
+                        } else if (chg > 1) {
+                            chg = 1;
+                        }
+                        k = j + 1 + over;
+                    }
+                    pos[0] = i;
+                    pos[1] = j;
+                    pos[2] = k;
+                    continue;
+                }
                 if (s == 3 && pos[2] < a - 1) {  // by far the most frequent step, with static register indices (the
                     ++pos[2];                     // generic code below indexes pos[] dynamically: ~60 instructions)
                     chg = 2;
