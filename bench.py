@@ -92,6 +92,9 @@ def parse_args(argv=None):
                          "(no engine; used by the CPU test of the launcher)")
     ap.add_argument("--simulate-world", type=int, default=0,
                     help="debug: time rank 0's share of an N-rank job on one GPU (no peers; the JSON line is not a result)")
+    ap.add_argument("--simulate-rank", type=int, default=0,
+                    help="debug: with --simulate-world N, which rank's share to time (-1: every rank in turn; the line then "
+                         "reports the slowest rank, i.e. what the N-rank job would take without its exchange)")
     return ap.parse_args(argv)
 
 
@@ -256,10 +259,29 @@ def main():
     eng.set_data(data)  # host -> HBM once, outside the timed region
     xstats = {}
     cb = make_allgather(dist, cdev, stats=xstats) if use_dist else None
+    sim = {"mode": None, "rounds": [], "k": 0, "local": 0}
     if args.simulate_world > 1 and world == 1:
-        def cb(user, n_local, tgt, nbr, stat, pval, n_total, tgt_all, nbr_all, stat_all, pval_all):  # echo: no peers
-            n_total[0] = n_local
-            tgt_all[0], nbr_all[0], stat_all[0], pval_all[0] = tgt, nbr, stat, pval
+        # One GPU standing in for one rank of an N-rank job.  The learned network does not depend on N (only on the round
+        # size), so the union over the ranks of what round k finds IS what a single-rank run finds in round k: a first pass
+        # with world_size = 1 RECORDS every round's exchange, and the pass of rank r then gets the recorded round back from
+        # its all-gather -- exactly the whitelists it would see among N real ranks, without peers.
+        import ctypes as C
+
+        def cb(user, n_local, tgt, nbr, stat, pval, n_total, tgt_all, nbr_all, stat_all, pval_all):
+            n = int(n_local)
+            if sim["mode"] == "record":
+                sim["rounds"].append(tuple(np.ctypeslib.as_array(a, shape=(max(n, 1),))[:n].copy() for a in (tgt, nbr, stat, pval)))
+                n_total[0] = n_local
+                tgt_all[0], nbr_all[0], stat_all[0], pval_all[0] = tgt, nbr, stat, pval
+                return 0
+            t, u, s_, q = sim["rounds"][sim["k"]]
+            sim["k"] += 1
+            sim["local"] += n
+            n_total[0] = len(t)
+            tgt_all[0] = t.ctypes.data_as(C.POINTER(C.c_int32))
+            nbr_all[0] = u.ctypes.data_as(C.POINTER(C.c_int32))
+            stat_all[0] = s_.ctypes.data_as(C.POINTER(C.c_double))
+            pval_all[0] = q.ctypes.data_as(C.POINTER(C.c_double))
             return 0
 
     def barrier():
@@ -274,7 +296,11 @@ def main():
             eng.level0(rank=rank, world_size=world, allgather=cb)  # discrete kinds: pair tiles sharded, significant pairs all-gathered
         else:
             eng.level0()
-        return eng.lgl(feed_forward=bool(ff), round_size=R, rank=rank,
+        sim["k"] = 0
+        if sim["mode"] == "record":
+            sim["rounds"] = []
+            return eng.lgl(feed_forward=bool(ff), round_size=R, allgather=cb, max_targets=args.max_targets, edge_dict=False)
+        return eng.lgl(feed_forward=bool(ff), round_size=R, rank=sim.get("rank", rank),
                        world_size=max(world, args.simulate_world) if world == 1 else world, allgather=cb,
                        max_targets=args.max_targets, edge_dict=False)  # the network stays in the arrays the C ABI fills (no Python dictionary of tuples)
 
@@ -315,11 +341,44 @@ def main():
     ff, R = int(bool(args.feed_forward)), (auto_R if args.round_size < 0 else args.round_size)
     if R <= 0:
         ff = 0
-    main_m = measure(ff, R if ff else 0, args.steps, args.warmup)
+    def measure_sim(f, r, steps, warmup):
+        """--simulate-world N: record one single-rank pass, then time every rank's share in turn (see `cb` above); the
+        result is the SLOWEST rank's -- what the N-rank job takes apart from the exchange itself."""
+        sim["mode"] = "record"
+        step(f, r)
+        recorded = sum(len(x[0]) for x in sim["rounds"])
+        sim["mode"] = "replay"
+        ranks = range(args.simulate_world) if args.simulate_rank < 0 else [args.simulate_rank]
+        per, found = [], 0
+        for rk in ranks:
+            sim["rank"], sim["local"] = rk, 0
+            m = measure(f, r, steps, warmup)
+            found += sim["local"] // (steps + warmup)
+            per.append(m)
+        if args.simulate_rank < 0 and found != recorded:
+            raise SystemExit("simulate-world: the ranks' shares found %d directed entries, the single-rank pass %d" % (found, recorded))
+        worst = max(per, key=lambda m: m["ms_per_step"])
+        worst = dict(worst)
+        worst["simulated_world"] = {"world_size": args.simulate_world, "ranks_timed": list(ranks),
+                                    "ms_per_step_by_rank": [m["ms_per_step"] for m in per],
+                                    "conditional_s_by_rank": [m["cn"]["t_cond_s"] / max(steps, 1) for m in per],
+                                    "cond_ref_by_rank": [m["cond_ref"] for m in per],
+                                    "directed_entries": recorded,
+                                    "note": "one GPU timing each rank's share in turn; all-gathers replayed from a recorded "
+                                            "single-rank pass (same whitelists as among N real ranks), no exchange cost"}
+        # whole-job figures: every rank's tests, the slowest rank's time
+        worst["cond_ref"] = sum(m["cond_ref"] for m in per) if args.simulate_rank < 0 else worst["cond_ref"]
+        worst["cond_eval"] = sum(m["cond_eval"] for m in per) if args.simulate_rank < 0 else worst["cond_eval"]
+        worst["value"] = (worst["level0"] + worst["cond_ref"]) / (worst["ms_per_step"] / 1e3)
+        return worst
+
+    simulating = args.simulate_world > 1 and world == 1
+    meas = measure_sim if simulating else measure
+    main_m = meas(ff, R if ff else 0, args.steps, args.warmup)
     other_m = None
     if not args.no_other_schedule:
         off, oR = (0, 0) if ff else (1, auto_R)
-        other_m = measure(off, oR, max(1, min(args.steps, 3)), 1)
+        other_m = meas(off, oR, max(1, min(args.steps, 3)), 1)
     seam_m = None
     if args.host_seam and world == 1:
         os.environ["FW_HOST_HITON"] = "1"
@@ -372,7 +431,7 @@ def main():
                     "edges": int(len(m["net"]["edge_src"])),
                     "tests_per_step": {"level0": m["level0"], "conditional_ref_equivalent": m["cond_ref"],
                                        "conditional_evaluated": m["cond_eval"]},
-                    "exchange": m["exchange"]}
+                    "exchange": m["exchange"], "simulated_world": m.get("simulated_world")}
 
         out = {"metric": "ci_tests_per_sec", "value": main_m["value"], "unit": "tests/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": main_m["ms_per_step"], "higher_is_better": True, "scaling": "strong",
@@ -386,7 +445,7 @@ def main():
                "time_to_network_s": dt / steps, "edges": int(len(net["edge_src"])), "rounds": main_m["rounds"],
                "tests_per_step": {"level0": main_m["level0"], "conditional_ref_equivalent": main_m["cond_ref"],
                                   "conditional_evaluated": main_m["cond_eval"]},
-               "exchange": main_m["exchange"],
+               "exchange": main_m["exchange"], "simulated_world": main_m.get("simulated_world"),
                "stage_seconds_rank0": {"level0": cn["t_level0_s"] / steps, "level0_host": cn["t_level0_host_s"] / steps, "conditional": cn["t_cond_s"] / steps,
                                        "subsets_kernels_device": sub_launch_s / steps,
                                        "host_advance": cn["t_host_advance_s"] / steps, "host_build": cn["t_host_build_s"] / steps,

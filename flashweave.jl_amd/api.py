@@ -33,6 +33,11 @@ def learn_network(data, sensitive=True, heterogeneous=False, max_k=3, alpha=0.01
     if header is None:
         header = ["X%d" % (i + 1) for i in range(data.shape[1])]
     meta_mask = None
+    if meta_data is not None and not normalize:
+        # the reference appends the meta columns as they are and keeps their mask (learning.jl:500-520); here an already
+        # normalised matrix must already hold them -- silently dropping the argument would lose the mask
+        raise ValueError("learn_network: meta_data with normalize=False is not supported: append the prepared meta columns to "
+                         "`data` yourself (preprocess.normalize_with_meta) or pass normalize=True")
     if normalize and meta_data is not None:
         r = pre.normalize_with_meta(data, test_name, meta_data, prec=prec, header=header, meta_header=meta_header,
                                     make_onehot=make_onehot)

@@ -1075,8 +1075,11 @@ int fw_test_subsets_batch(fw_ctx *c, int64_t m, const int32_t *T, const int32_t 
     CHECK_CTX(c);
     if (m < 0 || (m > 0 && (!T || !cand || !accoff || !out))) return fw_fail(c, FW_ERR_ARG, "fw_test_subsets_batch: NULL argument");
     if (m == 0) return FW_OK;
-    if (c->P.kind == FW_FZ ? !c->have_cor : !c->have_data)
-        return fw_fail(c, FW_ERR_STATE, "fw_test_subsets_batch: no %s resident", c->P.kind == FW_FZ ? "correlation matrix" : "data");
+    // FW_FZ with the recursive form reads the resident Pearson matrix; with recursive_pcor = 0 the tests stream the sample columns
+    // and need the data only (the same split as fw_test_batch)
+    const bool needs_cor = c->P.kind == FW_FZ && c->P.recursive_pcor;
+    if (needs_cor ? !c->have_cor : !c->have_data)
+        return fw_fail(c, FW_ERR_STATE, "fw_test_subsets_batch: no %s resident", needs_cor ? "correlation matrix" : "data");
     if (c->P.max_k < 1) return fw_fail(c, FW_ERR_ARG, "fw_test_subsets_batch: max_k must be >= 1");
     std::vector<FwJob> jobs;
     std::vector<int64_t> map;

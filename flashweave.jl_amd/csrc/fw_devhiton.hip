@@ -39,6 +39,7 @@ struct DhTgt {
     double jbest_p, jbest_stat;
     unsigned long long c_ref, c_calls, c_eval;  // per-target totals (summed on the host: no same-address atomics)
     double c_alg;
+    unsigned int r_first0, r_more0, r_first1, r_more1;  // FW_TRACE_HOST: rounds this target spent on first / later windows of interleaving (0) and elimination (1) jobs
 };
 
 struct DhGlobal {
@@ -392,7 +393,7 @@ struct MiBoard {
 
 struct MiQueue {
     unsigned int next_target, targets_done, n_boards, hint, res_top, bacc_top, pad[2];
-    unsigned long long t_body, t_ctl, t_sleep, n_seg;  // dh_fz_target_kernel: 100 MHz ticks summed over workgroups (FW_TRACE_HOST)
+    unsigned long long t_body, t_ctl, t_sleep, n_seg;  // dh_mi_target_kernel: 100 MHz ticks summed over wavefronts (FW_TRACE_HOST; see the end of the kernel)
     unsigned long long t_total;  // dh_mi_target_kernel: ticks until the wavefront ran out of targets (the fields above: see its end)
 };
 
@@ -815,390 +816,6 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
     }
 }
 
-// ---- Fisher-z: persistent workgroups, one target at a time, big enumerations shared through boards ------------------------
-// The same scheme as dh_mi_target_kernel with the WORKGROUP as the agent: a Fisher-z test is ~200 instructions of one lane,
-// the unit of work is the run-based body of the segment kernel (fw_fz_core.h: 256 lanes x up to FW_RUN_MAX consecutive ranks,
-// the size-3 enumeration through the LDS table).  Wavefront 0 of every workgroup is its controller: it fetches targets, runs
-// the HITON-PC state machine (dh_advance / dh_commit), opens boards for windows of more than two records, claims records and
-// merges them; wavefronts 1-3 sleep on the workgroup barrier and join in whenever the controller posts a segment (fzp_act).
-// Compared with the level-synchronous rounds (segment kernel -> step -> plan -> fill, ~1 400 dependent rounds per chain at
-// cfg3) a job costs its own tests plus one board hand-shake, and a target's chain never waits for the slowest job of a round.
-#define FZP_REC 8192ull            // ranks per chunk of the body (256 lanes x FW_RUN_MAX): the granule of board records
-#define FZP_ALONE (2ull * FZP_REC)  // windows up to this size are evaluated by the owner without a board
-#define FZP_REC_CAP (1u << 22)
-#define FZP_BACC_CAP (1u << 26)
-
-struct FzpK {
-    const float *cor;
-    const double *thr;
-    double alpha, zscale;
-    long long max_tests;
-    int p, max_k;
-};
-
-struct FzpAct {
-    FwSeg seg;
-    const int32_t *acc;
-    int kind, remote;  // kind 0: leave the kernel
-};
-
-// The controller is a resumable state machine (fzp_step): the body of the segment kernel is inlined at ONE place of the kernel's
-// main loop, where all four wavefronts meet, so that its register budget is the kernel's (a called body takes 248 VGPRs: one
-// workgroup per CU).  Its state lives in LDS between two steps.
-enum { FZS_FETCH = 0, FZS_ADV, FZS_PREHELP, FZS_WINDOW, FZS_OWNBOARD, FZS_WAIT, FZS_FINAL };
-
-struct FzpCtl {
-    DhTgt x;
-    int st, t, ret_st, purpose;  // purpose of the posted segment: 0 = a window of the own job (alone), 1 = a board record
-    int cand, a, stopped, r_pow;
-    long long acc_off;
-    unsigned long long N, next, width, ev, nt, W, cq;
-    double r_stat, r_p, best_p, best_stat;
-    unsigned int bacc_off, nch, ro, bi, spins;
-    unsigned int e_board, e_rec;  // board / record index of the posted board record
-    unsigned long long t_sleep;   // ticks spent in the waiting branches (nothing to claim)
-};
-
-__device__ __forceinline__ FwSegOut fzp_empty_record()
-{
-    FwSegOut o;
-    o.stop_rank = FW_RANK_NONE;
-    o.stop_stat = o.stop_pval = 0.0;
-    o.best_rank = 0ull;
-    o.best_stat = 0.0;
-    o.best_pval = -3.0;  // dh_merge ignores it
-    o.stop_df = o.stop_power = o.best_df = o.pad = 0;
-    o.evaluated = 0ull;
-    return o;
-}
-
-__device__ __forceinline__ void fzp_post(FzpAct *act, int X, int Y, const int32_t *acc, int a, int remote, unsigned long long r0,
-                                         unsigned long long r1, int lane)
-{
-    if (lane == 0) {
-        FwSeg sg;
-        sg.X = X;
-        sg.Y = Y;
-        sg.acc_off = 0;
-        sg.acc_len = a;
-        sg.pad = 0;
-        sg.start = r0;
-        sg.end = r1;
-        act->seg = sg;
-        act->acc = acc;
-        act->remote = remote;
-        act->kind = 1;
-    }
-}
-
-__device__ __forceinline__ void fzp_finish_record(MiBoard *b, FwSegOut *__restrict__ res, unsigned int c, const FwSegOut &o, int lane)
-{
-    if (lane == 0) {
-        const unsigned int res_off = (unsigned int)(mi_ld_u64(&b->nr) >> 32);
-        mi_record_store(res + res_off + c, o);
-        mi_drain();  // the record before the count
-        atomicAdd(&b->done, 1u);
-    }
-}
-
-// claim one record of board bidx; 0: nothing left, 1: a record was claimed and settled without work (cancelled), 2: a segment
-// was posted (C.e_board / C.e_rec say which record it is)
-__device__ __forceinline__ int fzp_claim(FzpCtl &C, FzpAct *act, MiBoard *__restrict__ boards, unsigned int bidx, FwSegOut *__restrict__ res,
-                                         const int32_t *__restrict__ bacc, const int32_t *acc_own, int lane)
-{
-    MiBoard *b = boards + bidx;
-    const unsigned int nch = (unsigned int)mi_ld_u64(&b->nr);
-    if (mi_ld_u32(&b->next_chunk) >= nch) return 0;
-    const unsigned int c = mi_wave_add(&b->next_chunk, 1u, lane);
-    if (c >= nch) return 0;
-    const unsigned long long tc = mi_ld_u64(&b->tc), ac = mi_ld_u64(&b->ac);
-    const int a = (int)(unsigned int)ac;
-    const unsigned long long chunk = (ac >> 32) * FZP_REC;
-    const unsigned long long start = mi_ld_u64(&b->start), end = mi_ld_u64(&b->end);
-    const unsigned long long r0 = start + (unsigned long long)c * chunk;
-    unsigned long long r1 = r0 + chunk;
-    if (r1 > end) r1 = end;
-    if (mi_ld_u64(&b->stop_min) < r0) {  // cancelled: an earlier rank stopped the job
-        fzp_finish_record(b, res, c, fzp_empty_record(), lane);
-        return 1;
-    }
-    const int32_t *acc = acc_own ? acc_own : bacc + mi_ld_u64(&b->acc_off);
-    fzp_post(act, (int)(unsigned int)tc, (int)(unsigned int)(tc >> 32), acc, a, acc_own ? 0 : 1, r0, r1, lane);
-    C.e_board = bidx;
-    C.e_rec = c;
-    C.purpose = 1;
-    return 2;
-}
-
-// look for an open board of another workgroup; true if a segment was posted
-__device__ __forceinline__ bool fzp_help(FzpCtl &C, FzpAct *act, MiQueue *__restrict__ Q, MiBoard *__restrict__ boards,
-                                         FwSegOut *__restrict__ res, const int32_t *__restrict__ bacc, int lane)
-{
-    unsigned int nb = mi_ld_u32(&Q->n_boards);
-    if (nb > MI_BOARD_CAP) nb = MI_BOARD_CAP;
-    unsigned int i = mi_ld_u32(&Q->hint);
-    for (; i < nb; ++i) {
-        MiBoard *b = boards + i;
-        if (mi_ld_u32(&b->ready) == 0u) return false;  // reserved, not yet filled
-        if (mi_ld_u32(&b->next_chunk) < (unsigned int)mi_ld_u64(&b->nr)) {
-            for (;;) {
-                const int r = fzp_claim(C, act, boards, i, res, bacc, nullptr, lane);
-                if (r == 2) return true;
-                if (r == 0) break;
-            }
-        } else if (i == mi_ld_u32(&Q->hint) && lane == 0) {
-            atomicMax(&Q->hint, i + 1u);
-        }
-    }
-    return false;
-}
-
-// One step of the controller (wavefront 0): consumes the result of the segment it posted last (if any) and runs until it posts
-// the next one (returns with act->kind = 1) or until the launch is over (act->kind = 0).
-__device__ __forceinline__ void fzp_step(FzpCtl *sc, FzpAct *act, const FwSegOut *sout, bool have_result, DhTgt *__restrict__ tg, int ntg,
-                                         const int32_t *__restrict__ order, const DhArrays &A, const DhParams &P, MiQueue *__restrict__ Q,
-                                         MiBoard *__restrict__ boards, FwSegOut *__restrict__ res, int32_t *__restrict__ bacc, int lane)
-{
-    FzpCtl C = *sc;
-    if (have_result) {
-        const FwSegOut o = *sout;
-        if (C.purpose == 1) {
-            MiBoard *b = boards + C.e_board;
-            if (o.stop_rank != FW_RANK_NONE && lane == 0) atomicMin(&b->stop_min, o.stop_rank);
-            fzp_finish_record(b, res, C.e_rec, o, lane);
-            C.st = C.ret_st;
-        } else {  // a window of the own job
-            C.ev += o.evaluated;
-            if (o.stop_rank != FW_RANK_NONE) {
-                C.stopped = 1;
-                C.r_stat = o.stop_stat;
-                C.r_p = o.stop_pval;
-                C.r_pow = o.stop_power;
-                C.nt = o.stop_rank + 1ull;
-            } else if (o.best_pval >= C.best_p) {
-                C.best_p = o.best_pval;
-                C.best_stat = o.best_stat;
-            }
-            C.next += C.W;
-            C.width *= P.growth;
-            C.st = FZS_WINDOW;
-        }
-    }
-    for (;;) {
-        if (C.st == FZS_FETCH) {
-            const unsigned int slot = mi_wave_add(&Q->next_target, 1u, lane);
-            if (slot >= (unsigned int)ntg) {
-                C.st = FZS_FINAL;
-                C.spins = 0u;
-                continue;
-            }
-            C.t = order[slot];
-            C.x = tg[C.t];
-            C.st = FZS_ADV;
-        } else if (C.st == FZS_ADV) {
-            if (!dh_advance(C.x, A, lane, 1)) {
-                if (lane == 0) {
-                    tg[C.t] = C.x;
-                    atomicAdd(&Q->targets_done, 1u);
-                }
-                C.st = FZS_FETCH;
-                continue;
-            }
-            const int32_t *cands = C.x.phase == 0 ? A.cand0 + C.x.cand_off : A.tpc_key + C.x.co;
-            C.cand = cands[C.x.pos];
-            C.acc_off = DH_ACC_OFF(C.x, C.x.cur, 1);
-            C.a = C.x.na;
-            unsigned long long N = 0ull;
-            for (int s = P.max_k; s >= 1; --s) {
-                N += fw_binom_u64(C.a, s);
-                if (N > (1ull << 62)) N = 1ull << 62;
-            }
-            if (P.max_tests > 0 && (unsigned long long)P.max_tests < N) N = (unsigned long long)P.max_tests;
-            C.N = N;
-            // windows as in dh_step_kernel: elimination-phase jobs nearly always run to the end (whole enumeration at once),
-            // interleaving-phase jobs nearly always stop within the first few tests (small first window, then x growth)
-            C.width = (C.x.phase == 1 && P.elim_full) ? N : (C.a >= 64 ? P.w0_big : P.w0_small);
-            C.next = C.ev = C.nt = 0ull;
-            C.stopped = 0;
-            C.r_stat = C.r_p = C.best_stat = 0.0;
-            C.best_p = -1.0;
-            C.r_pow = 1;
-            C.bacc_off = FZP_BACC_CAP;
-            C.st = FZS_PREHELP;
-        } else if (C.st == FZS_PREHELP) {
-            // other targets' big enumerations first: they are the critical path of the pass
-            if (P.mi_help_jobs && mi_ld_u32(&Q->n_boards) > mi_ld_u32(&Q->hint) && fzp_help(C, act, Q, boards, res, bacc, lane)) {
-                C.ret_st = FZS_PREHELP;
-                break;
-            }
-            C.st = FZS_WINDOW;
-        } else if (C.st == FZS_WINDOW) {
-            if (C.stopped || C.next >= C.N) {
-                if (!C.stopped) {  // every subset significant: the maximum-p result (tests.jl:338-345)
-                    C.r_stat = C.best_stat;
-                    C.r_p = C.best_p < 0.0 ? 0.0 : C.best_p;
-                    C.r_pow = 1;
-                    C.nt = C.N;
-                }
-                C.x.c_ref += C.nt;
-                C.x.c_calls += 1ull;
-                C.x.c_eval += C.ev;
-                C.x.c_alg += dh_alg_bytes(C.a, C.ev, P.max_k, 0.0);
-                dh_commit(C.x, A, lane, 1, C.r_stat, C.r_p, C.r_pow, P.alpha);
-                C.st = FZS_ADV;
-                continue;
-            }
-            const unsigned long long W = (C.N - C.next) < C.width ? (C.N - C.next) : C.width;
-            C.W = W;
-            // records: multiples of the body's chunk, at most ~512 per window
-            unsigned long long cq = (W / 512ull + FZP_REC - 1ull) / FZP_REC;
-            cq = cq < 1ull ? 1ull : cq;
-            C.cq = cq;
-            const unsigned long long chunk = cq * FZP_REC;
-            const unsigned int nch = (unsigned int)((W + chunk - 1ull) / chunk);
-            C.nch = nch;
-            unsigned int bi = MI_BOARD_CAP, ro = FZP_REC_CAP;
-            const int a = C.a;
-            if (W > FZP_ALONE) {
-                if (C.bacc_off == FZP_BACC_CAP && mi_ld_u32(&Q->bacc_top) + (unsigned int)a <= FZP_BACC_CAP) {
-                    C.bacc_off = mi_wave_add(&Q->bacc_top, (unsigned int)a, lane);
-                    if (C.bacc_off + (unsigned int)a > FZP_BACC_CAP) {
-                        C.bacc_off = FZP_BACC_CAP;
-                    } else {
-                        const int32_t *src = A.acc + C.acc_off;
-                        for (int i = lane; i < a; i += 64) __hip_atomic_store(bacc + C.bacc_off + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-                if (C.bacc_off != FZP_BACC_CAP && mi_ld_u32(&Q->n_boards) < MI_BOARD_CAP && mi_ld_u32(&Q->res_top) + nch <= FZP_REC_CAP) {
-                    ro = mi_wave_add(&Q->res_top, nch, lane);
-                    if (ro + nch <= FZP_REC_CAP) bi = mi_wave_add(&Q->n_boards, 1u, lane);
-                }
-            }
-            C.bi = bi;
-            C.ro = ro;
-            if (bi >= MI_BOARD_CAP) {  // a small window, or out of board space: the owner's workgroup alone
-                fzp_post(act, C.x.T, C.cand, A.acc + C.acc_off, a, 0, C.next, C.next + W, lane);
-                C.purpose = 0;
-                break;
-            }
-            MiBoard *b = boards + bi;
-            mi_drain();  // the copy of the accepted list (every lane's stores) ...
-            if (lane == 0) {
-                mi_st_u64(&b->tc, (unsigned long long)(unsigned int)C.x.T | ((unsigned long long)(unsigned int)C.cand << 32));
-                mi_st_u64(&b->ac, (unsigned long long)(unsigned int)a | (cq << 32));
-                mi_st_u64(&b->acc_off, (unsigned long long)C.bacc_off);
-                mi_st_u64(&b->start, C.next);
-                mi_st_u64(&b->end, C.next + W);
-                mi_st_u64(&b->nr, (unsigned long long)nch | ((unsigned long long)ro << 32));
-                mi_st_u64(&b->stop_min, FW_RANK_NONE);  // next_chunk / done are zero from the launch's memset
-                mi_drain();  // ... and the board before the flag
-                mi_st_u32(&b->ready, 1u);
-            }
-            C.spins = 0u;
-            C.st = FZS_OWNBOARD;
-        } else if (C.st == FZS_OWNBOARD) {
-            const int r = fzp_claim(C, act, boards, C.bi, res, bacc, A.acc + C.acc_off, lane);
-            if (r == 2) {
-                C.ret_st = FZS_OWNBOARD;
-                break;
-            }
-            if (r == 0) C.st = FZS_WAIT;
-        } else if (C.st == FZS_WAIT) {
-            MiBoard *b = boards + C.bi;
-            if (mi_ld_u32(&b->done) >= C.nch || mi_ld_u32(&Q->pad[0]) != 0u) {
-                const DhMerge mg = mi_merge(res, (long long)C.ro, (int)C.nch, lane);
-                C.ev += mg.ev;
-                if (mg.stop) {
-                    C.stopped = 1;
-                    C.r_stat = mg.stat;
-                    C.r_p = mg.p;
-                    C.r_pow = mg.pow;
-                    C.nt = mg.nt;
-                } else if (mg.p != -2.0 && mg.p >= C.best_p) {
-                    C.best_p = mg.p;
-                    C.best_stat = mg.stat;
-                }
-                C.next += C.W;
-                C.width *= P.growth;
-                C.st = FZS_WINDOW;
-                continue;
-            }
-            if (fzp_help(C, act, Q, boards, res, bacc, lane)) {  // records claimed by other workgroups: they are running
-                C.ret_st = FZS_WAIT;
-                break;
-            }
-            const unsigned long long ts = wall_clock64();
-            __builtin_amdgcn_s_sleep(2);
-            if (++C.spins > (1u << 26)) {  // a logic error, not a workload: report instead of hanging the GPU
-                if (lane == 0) atomicExch(&Q->pad[0], 1u);
-            }
-            C.t_sleep += wall_clock64() - ts;
-        } else {  // FZS_FINAL: no targets left to start -- work on boards until every target has finished
-            if (mi_ld_u32(&Q->targets_done) >= (unsigned int)ntg || mi_ld_u32(&Q->pad[0]) != 0u) {
-                if (lane == 0) act->kind = 0;
-                break;
-            }
-            if (fzp_help(C, act, Q, boards, res, bacc, lane)) {
-                C.ret_st = FZS_FINAL;
-                break;
-            }
-            const unsigned long long ts = wall_clock64();
-            __builtin_amdgcn_s_sleep(8);
-            if (++C.spins > (1u << 26)) {
-                if (lane == 0) atomicExch(&Q->pad[0], 2u);
-            }
-            C.t_sleep += wall_clock64() - ts;
-        }
-    }
-    if (lane == 0) *sc = C;
-}
-
-__global__ __launch_bounds__(256, 3) void dh_fz_target_kernel(DhTgt *__restrict__ tg, int ntg, const int32_t *__restrict__ order,
-                                                              DhArrays A, FzpK K, DhParams P, MiQueue *__restrict__ Q,
-                                                              MiBoard *__restrict__ boards, FwSegOut *__restrict__ res,
-                                                              int32_t *__restrict__ bacc)
-{
-    __shared__ FzpCtl s_ctl;
-    __shared__ FzpAct s_act;
-    __shared__ FwSegOut s_out;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) {
-        s_ctl.st = FZS_FETCH;
-        s_ctl.purpose = 0;
-        s_ctl.t_sleep = 0ull;
-        s_act.kind = 1;
-    }
-    bool have = false;
-    unsigned long long t_body = 0ull, t_ctl = 0ull, n_seg = 0ull;
-    for (;;) {
-        const unsigned long long t0 = wall_clock64();
-        if (wave == 0) fzp_step(&s_ctl, &s_act, &s_out, have, tg, ntg, order, A, P, Q, boards, res, bacc, lane);
-        __syncthreads();
-        const unsigned long long t1 = wall_clock64();
-        t_ctl += t1 - t0;
-        if (s_act.kind == 0) break;
-        const FwSeg seg = s_act.seg;
-        const int32_t *acc = s_act.acc;
-        const bool remote = s_act.remote != 0;
-        if (seg.acc_len <= FW_TAB_A)
-            fz_seg_body<false, false, true>(K.cor, K.p, seg, acc, remote, &s_out, K.max_k, K.alpha, K.zscale, K.max_tests, K.thr,
-                                            (const FwNzJob *)nullptr, 0ll);
-        else
-            fz_seg_body<false, false, false>(K.cor, K.p, seg, acc, remote, &s_out, K.max_k, K.alpha, K.zscale, K.max_tests, K.thr,
-                                             (const FwNzJob *)nullptr, 0ll);
-        __syncthreads();  // the record in s_out is complete; the body's LDS state may be reused
-        have = true;
-        t_body += wall_clock64() - t1;
-        ++n_seg;
-    }
-    if (threadIdx.x == 0) {
-        atomicAdd(&Q->t_body, t_body);
-        atomicAdd(&Q->t_ctl, t_ctl);
-        atomicAdd(&Q->t_sleep, s_ctl.t_sleep);
-        atomicAdd(&Q->n_seg, n_seg);
-    }
-}
-
 // One wavefront per target: the lanes merge the job's segment records in parallel, then run the sequential part
 // (commit, advance, next job) in lock-step -- every lane holds the same copy of the state, lane 0 writes.
 //
@@ -1227,6 +844,8 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
         x.nsp = 0;
         bool finished = false, kept = false;
         if (x.jactive) {
+            if (x.phase == 0) (x.jnext == 0ull ? x.r_first0 : x.r_more0) += 1u;
+            else (x.jnext == 0ull ? x.r_first1 : x.r_more1) += 1u;
             const DhMerge M = dh_merge(so, jseg0, jnseg, lane);
             double r_stat = 0.0, r_p = 1.0;
             int r_pow = 0;
@@ -1660,21 +1279,19 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     // 317.3 / 104.6, below 12M 314.8 / 103.6, below 16M 341 -- a launch that already fills the GPU only pays for the
     // jobs wasted behind every dropped member (3.7 % of the members at cfg3)
     static const int spec_env = [] { const char *e = getenv("FW_DH_SPEC"); return e ? atoi(e) : 4; }();
-    // discrete kinds: persistent wavefronts + boards (dh_mi_target_kernel); Fisher-z: persistent workgroups + boards
-    // (dh_fz_target_kernel) when every accepted list fits the body's LDS copy and max_k <= 3.  FW_MI_ROUNDS=1 / FW_FZ_PERSIST=0
-    // keep the level-synchronous rounds over the segment kernels (the path of the ABI's fw_test_subsets_batch) for comparison
+    // discrete kinds: persistent wavefronts + boards (dh_mi_target_kernel); FW_MI_ROUNDS=1 keeps the level-synchronous rounds over
+    // the segment kernels (the path of the ABI's fw_test_subsets_batch) for comparison.  Fisher-z always runs as rounds (a
+    // persistent-workgroup variant was built in r02, lost 140 vs 58 ms on the heavy rounds, and was removed in r03).
     static const bool mi_rounds = [] { const char *e = getenv("FW_MI_ROUNDS"); return e && atoi(e) != 0; }();
-    const bool fz_rounds = [] { const char *e = getenv("FW_FZ_PERSIST"); return !(e && atoi(e) != 0); }();  // read per run (tests switch it)
-    const bool fz_persist = c->P.kind == FW_FZ && !fz_rounds && c->P.max_k <= 3 && (wl.empty() ? max_cap : 2 * max_cap) <= FW_ACC_LDS;
-    const bool per_target = (c->P.kind != FW_FZ && !mi_rounds) || fz_persist;
-    const int spec_depth = (c->P.kind == FW_FZ && !fz_persist) ? std::min(std::max(spec_env, 0), DH_MAX_SPEC) : 0;
+    const bool per_target = c->P.kind != FW_FZ && !mi_rounds;
+    const int spec_depth = c->P.kind == FW_FZ ? std::min(std::max(spec_env, 0), DH_MAX_SPEC) : 0;
     const int d1 = spec_depth + 1;
     // interleaving-phase look-ahead (first windows of the next candidates, same accepted list): FW_DH_SPEC0 candidates,
     // only while the last launch held fewer than FW_DH_SPEC0_BELOW ranks and fewer than FW_DH_SPEC0_JOBS jobs -- it
     // pays where the rounds are latency-bound, i.e. on a rank of a multi-GPU job (one rank of 8: 103.6 -> 95.2 ms,
     // one of 2: 208 -> 204.7 ms) and in the tail of a single-GPU pass (315.8 -> 314.2 ms)
     static const int spec0_env = [] { const char *e = getenv("FW_DH_SPEC0"); return e ? atoi(e) : 2; }();
-    const int spec0_depth = (c->P.kind == FW_FZ && !fz_persist) ? std::min(std::max(spec0_env, 0), DH_MAX_SPEC) : 0;
+    const int spec0_depth = c->P.kind == FW_FZ ? std::min(std::max(spec0_env, 0), DH_MAX_SPEC) : 0;
     // segments per launch by launch size (fz): below FW_SEG_A ranks a third of seg_target, below FW_SEG_B two thirds.
     // cfg3, ms per pass on one GPU / one rank of 2 / of 8: fixed 3 072: 298.8 / 200.3 / 94.9; A, B = 4M, 8M: 295.8 /
     // 194.4 / 82.3; 6M, 10M: 295.8 / 192.8 / 80.3; 8M, 12M: 295.1 / 193.7 / 79.8 (fixed 1 024: 81.1 for the rank of 8
@@ -1695,7 +1312,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     need += pad(4 * tot + 4) * 3 + pad(4 * 2 * tot * (size_t)d1 + 4) + pad(8 * tot + 8) * 4 + pad(4 * wl.size() + 4);
     need += pad(sizeof(FwSeg) * max_ns) + pad(sizeof(FwSegOut) * max_ns);
     if (!nb_on_dev) need += pad(8 * ((size_t)p + 1)) + pad(4 * nnz + 4) + 2 * pad(8 * nnz + 8);
-    const size_t rec_cap = fz_persist ? FZP_REC_CAP : MI_REC_CAP, bacc_cap = fz_persist ? FZP_BACC_CAP : MI_BACC_CAP;
+    const size_t rec_cap = MI_REC_CAP, bacc_cap = MI_BACC_CAP;
     if (per_target) need += pad(sizeof(MiQueue)) + pad(sizeof(MiBoard) * MI_BOARD_CAP) + pad(sizeof(FwSegOut) * rec_cap) + pad(sizeof(int32_t) * bacc_cap);
     int rc;
     if ((rc = fw_dev_reserve(c, c->d_dh[chain], need))) return rc;
@@ -1825,11 +1442,36 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     // idle GPU per 16 rounds).  Rounds after the last one are no-ops (no live segment, nothing to merge).
     constexpr int BATCH = 16;
     static const int time_every = [] { const char *e = getenv("FW_DH_TIME_EVERY"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
-    hipEvent_t ev[2][2 * BATCH], ev_end[2];
-    for (int q = 0; q < 2; ++q) {
-        for (hipEvent_t &e : ev[q]) FW_HIP(c, hipEventCreate(&e));
-        FW_HIP(c, hipEventCreateWithFlags(&ev_end[q], hipEventDisableTiming));
-    }
+    // events live in a holder whose destructor synchronises the stream and destroys them on EVERY exit path (error returns
+    // and the watchdog of the persistent kernel included: r02 leaked 66 events per failed call and left the stream running)
+    struct EvHolder {
+        hipStream_t st;
+        hipEvent_t ev[2][2 * BATCH], ev_end[2];
+        bool ok = true;
+        explicit EvHolder(hipStream_t s) : st(s)
+        {
+            for (int q = 0; q < 2; ++q) {
+                for (hipEvent_t &e : ev[q]) e = nullptr;
+                ev_end[q] = nullptr;
+            }
+            for (int q = 0; q < 2 && ok; ++q) {
+                for (hipEvent_t &e : ev[q]) ok = ok && hipEventCreate(&e) == hipSuccess;
+                ok = ok && hipEventCreateWithFlags(&ev_end[q], hipEventDisableTiming) == hipSuccess;
+            }
+        }
+        ~EvHolder()
+        {
+            (void)hipStreamSynchronize(st);
+            for (int q = 0; q < 2; ++q) {
+                for (hipEvent_t &e : ev[q])
+                    if (e) (void)hipEventDestroy(e);
+                if (ev_end[q]) (void)hipEventDestroy(ev_end[q]);
+            }
+        }
+    } evh(st);
+    if (!evh.ok) return fw_fail(c, FW_ERR_DEVICE, "device HITON: hipEventCreate failed");
+    auto &ev = evh.ev;
+    auto &ev_end = evh.ev_end;
     auto planfill = [&](bool compact) {
         hipLaunchKernelGGL(dh_step_kernel, dim3((n_act_bound + 3u) / 4u), dim3(256), 0, st, d_tg, ntg, d_g, A,
                            (const FwSegOut *)d_so, (const long long *)d_seg0, d_win, d_sp, (const int32_t *)d_act, P);
@@ -1851,45 +1493,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         for (int t = 0; t < ntg; ++t) order[t] = t;
         std::stable_sort(order.begin(), order.end(), [&](int32_t u, int32_t v) { return tg[u].nc > tg[v].nc; });  // heaviest first
         FW_HIP(c, hipMemcpyAsync(d_act, order.data(), sizeof(int32_t) * (size_t)ntg, hipMemcpyHostToDevice, st));
-        if (fz_persist) {
-            FzpK K{};
-            if ((rc = fwi_fz_thresholds(c, st, &K.zscale))) return rc;
-            K.cor = c->d_cor;
-            K.thr = c->d_thr;
-            K.alpha = c->P.alpha;
-            K.max_tests = c->P.max_tests;
-            K.p = p;
-            K.max_k = c->P.max_k;
-            // every workgroup of the launch must be resident (owners wait for records claimed by other workgroups)
-            static int occ = 0;
-            if (occ == 0) {
-                FW_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, dh_fz_target_kernel, 256, 0));
-                if (const char *e = getenv("FW_FZ_WG_PER_CU")) occ = std::min(occ, std::max(atoi(e), 1));
-                if (occ < 1) occ = 1;
-            }
-            int n_cu = 256;
-            (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->P.device);
-            const unsigned grid = std::min((unsigned)ntg, (unsigned)occ * (unsigned)n_cu);
-            FW_HIP(c, hipMemsetAsync(d_mq, 0, sizeof(MiQueue), st));
-            FW_HIP(c, hipMemsetAsync(d_boards, 0, sizeof(MiBoard) * MI_BOARD_CAP, st));
-            FW_HIP(c, hipEventRecord(ev[0][0], st));
-            hipLaunchKernelGGL(dh_fz_target_kernel, dim3(grid), dim3(256), 0, st, d_tg, ntg, (const int32_t *)d_act, A, K, P, d_mq, d_boards,
-                               d_mres, d_bacc);
-            FW_HIP(c, hipGetLastError());
-            FW_HIP(c, hipEventRecord(ev[0][1], st));
-            FW_HIP(c, hipStreamSynchronize(st));
-            MiQueue hq{};
-            FW_HIP(c, hipMemcpy(&hq, d_mq, sizeof(hq), hipMemcpyDeviceToHost));
-            if (hq.pad[0]) return fw_fail(c, FW_ERR_DEVICE, "Fisher-z HITON kernel: watchdog %u (boards %u, targets done %u of %d)", hq.pad[0], hq.n_boards, hq.targets_done, ntg);
-            if (trace_host)
-                fprintf(stderr, "[fw] grid %u boards %u records %u bacc %u; per workgroup: body %.2f ms, control %.2f ms (of it asleep %.2f ms), %.0f segments\n", grid,
-                        hq.n_boards, hq.res_top, hq.bacc_top, 1e-5 * (double)hq.t_body / grid, 1e-5 * (double)hq.t_ctl / grid, 1e-5 * (double)hq.t_sleep / grid,
-                        (double)hq.n_seg / grid);
-            float ms = 0.0f;
-            FW_HIP(c, hipEventElapsedTime(&ms, ev[0][0], ev[0][1]));
-            timed_s = 1e-3 * (double)ms;
-            timed_n = launches_n = 1;
-        } else {
+        {
         MiDev M = fwi_mi_dev(c);
         M.view = M.dense && M.nzmode && c->mi_view;  // HITON-PC under the dense rules tests on row views (hiton.jl:41-50)
         // as many workgroups as stay resident (one per CU: the test routine needs ~260 VGPRs, one wavefront per SIMD; cfg4:
@@ -2016,10 +1620,6 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         c->cnt.subsets_launches += launches_n;
         c->cnt.kernel_launches += per_target ? launches_n : 4 * launches_n;
     }
-    for (int q = 0; q < 2; ++q) {
-        for (hipEvent_t &e : ev[q]) (void)hipEventDestroy(e);
-        (void)hipEventDestroy(ev_end[q]);
-    }
     if (rc2) return rc2;
     const double th2 = wall();
     // ---- results ----
@@ -2078,6 +1678,13 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         }
         fprintf(stderr, "[fw] chain %d: executed tests %llu, of them in jobs with at most %d accepted variables %llu; longest accepted list %d\n",
                 chain, ev_all, (int)FW_HK_A, ev_short, na_max);
+        {   // the target that was busy for the most rounds: where its rounds went
+            const DhTgt *w = &tg[0];
+            for (const DhTgt &x : tg)
+                if (x.r_first0 + x.r_more0 + x.r_first1 + x.r_more1 > w->r_first0 + w->r_more0 + w->r_first1 + w->r_more1) w = &x;
+            fprintf(stderr, "[fw] chain %d: longest-busy target T=%d: %d candidates, %d in TPC, %d in PC, %llu jobs; rounds: interleaving first windows %u, later windows %u; elimination first %u, later %u\n",
+                    chain, w->T, w->cap, w->ntpc, w->npc, w->c_calls, w->r_first0, w->r_more0, w->r_first1, w->r_more1);
+        }
     }
     if (trace_host)
         fprintf(stderr, "[fw] chain %d: longest accepted list %u, accepted + whitelisted to come %u (most whitelisted neighbours of one target %d)\n",

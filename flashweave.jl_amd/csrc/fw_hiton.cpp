@@ -273,8 +273,7 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                     // discrete kinds run as ONE persistent launch that fills the GPU by itself (dh_mi_target_kernel); concurrent
                     // chains only apply to their level-synchronous form (FW_MI_ROUNDS=1)
                     static const bool mi_rounds = [] { const char *e = getenv("FW_MI_ROUNDS"); return e && atoi(e) != 0; }();
-                    const bool fz_rounds = [] { const char *e = getenv("FW_FZ_PERSIST"); return !(e && atoi(e) != 0); }();
-                    const int want = c->P.kind == FW_FZ ? ((fz_rounds || c->P.max_k > 3) ? dh_chains : 1) : (mi_rounds ? dh_chains_disc : 1);
+                    const int want = c->P.kind == FW_FZ ? dh_chains : (mi_rounds ? dh_chains_disc : 1);
                     const int K = din.size() >= (size_t)want * dh_chain_min ? want : 1;
                     int rc = FW_OK;
                     pres.resize((size_t)K);

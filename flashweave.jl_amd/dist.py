@@ -59,7 +59,7 @@ def make_allgather(dist, device, capacity=4096, stats=None):
                     rows = send[1:1 + 3 * m].reshape(m, 3)
                     t = np.ctypeslib.as_array(tgt, shape=(n,))[:m].astype(np.int64)
                     u = np.ctypeslib.as_array(nbr, shape=(n,))[:m].astype(np.int64)
-                    rows[:, 0] = t | (u << 32)
+                    rows[:, 0] = (t & 0xFFFFFFFF) | (u << 32)  # low half masked: a negative marker (level-0 sharding sends target -1) must not sign-extend into the neighbour half
                     rows[:, 1] = np.ctypeslib.as_array(stat, shape=(n,))[:m].view(np.int64)
                     rows[:, 2] = np.ctypeslib.as_array(pval, shape=(n,))[:m].view(np.int64)
                 if on_gpu:
@@ -79,7 +79,7 @@ def make_allgather(dist, device, capacity=4096, stats=None):
             N = int(counts.sum())
             if N:
                 rows = np.concatenate([recv[r, 1:1 + 3 * int(counts[r])].reshape(-1, 3) for r in range(world)], axis=0)
-                keep["t"] = np.ascontiguousarray((rows[:, 0] & 0xFFFFFFFF).astype(np.int32))
+                keep["t"] = np.ascontiguousarray((rows[:, 0] & 0xFFFFFFFF).astype(np.uint32).view(np.int32))  # through uint32: -1 comes back as -1
                 keep["n"] = np.ascontiguousarray((rows[:, 0] >> 32).astype(np.int32))
                 keep["s"] = np.ascontiguousarray(rows[:, 1]).view(np.float64)
                 keep["p"] = np.ascontiguousarray(rows[:, 2]).view(np.float64)

@@ -119,7 +119,15 @@ def normalize_counts(counts, test_name, device=0):
     """Normalisation front-end on the device (fw_normalize_counts): -> (data, row_mask, col_mask) like preprocess.normalize
     for test_name in {"fz", "fz_nz", "mi"} ("mi_nz": preprocess.normalize on the host)."""
     L = load_library()
-    x = np.asfortranarray(np.asarray(counts, dtype=np.int32))
+    raw = np.asarray(counts)
+    if raw.ndim != 2:
+        raise ValueError("normalize_counts: counts must be a samples x OTUs matrix")
+    if not np.issubdtype(raw.dtype, np.integer):  # a silent cast would truncate relative abundances / floats to zero
+        if not np.all(np.isfinite(raw)) or np.any(raw != np.floor(raw)):
+            raise TypeError("normalize_counts: the device front-end takes integer counts (got non-integral %s values)" % raw.dtype)
+    if raw.size and (raw.min() < 0 or raw.max() > np.iinfo(np.int32).max):
+        raise ValueError("normalize_counts: counts must lie in [0, 2^31 - 1]")
+    x = np.asfortranarray(raw.astype(np.int32))
     n, p = x.shape
     rm, cm = np.zeros(n, np.uint8), np.zeros(p, np.uint8)
     no, po = C.c_int32(0), C.c_int32(0)

@@ -357,39 +357,6 @@ def test_device_rounds_long_accepted_lists(monkeypatch):
     assert ch["cond_tests_ref"] == cd["cond_tests_ref"]
 
 
-@pytest.mark.parametrize("case", ["plain", "whitelists", "long_lists"])
-def test_persistent_workgroups_equal_device_rounds(small, case, monkeypatch):
-    # FW_FZ_PERSIST=1: dh_fz_target_kernel (persistent workgroups + boards, an opt-in alternative to the level-synchronous
-    # rounds) must give the same directed lists, statistics, p-values and reference-order test count.
-    # "long_lists" drives accepted lists past FW_TAB_A (the in-lane variant of the body inside the persistent kernel).
-    if case == "long_lists":
-        rng = np.random.default_rng(7)
-        n, p = 2000, 600
-        data = (rng.standard_normal((n, 1)) + 0.9 * rng.standard_normal((n, p))).astype(np.float32)
-        kw, run = dict(max_k=3, max_tests=300), dict(feed_forward=False, round_size=0)
-    else:
-        n, p, data = small["n"], small["p"], None
-        kw, run = dict(max_k=3), (dict(feed_forward=False, round_size=0) if case == "plain" else dict(feed_forward=True, round_size=64))
-    res = {}
-    for persist in ("0", "1"):
-        monkeypatch.setenv("FW_FZ_PERSIST", persist)
-        eng = fw.Engine("fz", n, p, **kw)
-        if data is None:
-            eng.set_cor_mat(small["cm"])
-        else:
-            eng.set_data(data)
-            eng.cor()
-        net = eng.lgl(**run)
-        res[persist] = (net, eng.counters())
-        eng.close()
-    (nr, cr), (np_, cp) = res["0"], res["1"]
-    assert nr["edges"] == np_["edges"] and len(nr["edges"]) > 100
-    for key in ("pc_off", "pc_idx", "pc_weight", "pc_pval"):
-        assert np.array_equal(nr[key], np_[key], equal_nan=True), key
-    assert cr["cond_tests_ref"] == cp["cond_tests_ref"] and cr["subsets_calls"] == cp["subsets_calls"]
-    assert cp["subsets_launches"] < cr["subsets_launches"]  # one launch per host round instead of one per device round
-
-
 @pytest.mark.parametrize("max_k", [1, 2, 5])
 def test_device_rounds_other_max_k(small, max_k, monkeypatch):
     # max_k = 5 runs the HIGHK variant of the segment kernel grid-strided under the device rounds; 1 and 2 the table
