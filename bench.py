@@ -13,7 +13,7 @@ sequential reference order would execute; identical to the CPU oracle's by const
 N > 1: this script starts N ranks ITSELF (re-executes under `python -m torch.distributed.run --nproc-per-node N`,
 rendezvous on 127.0.0.1), one rank per GPU, backend nccl (= RCCL over xGMI); when it is already running under
 torch.distributed.run (WORLD_SIZE in the environment) it uses those ranks and insists that WORLD_SIZE == N.
-Targets of every feed-forward round are dealt round-robin over the ranks and the per-round neighbour sets are
+Targets of every feed-forward round are dealt over the ranks by estimated work (heaviest first, least loaded rank) and the per-round neighbour sets are
 all-gathered (flashweave.jl_amd/dist.py).  Total work is fixed as N grows -> "strong".  It fails loudly if fewer
 than N GPUs are visible.
 
@@ -40,6 +40,10 @@ DEFAULT_ROUND = 1024    # granularity of the default feed-forward round size: R 
 
 
 def make_input(cfg, args):
+    """-> (config, checksum of the counts, normalised matrix, normalisation record).  The count table is normalised by the
+    device front-end (fw_normalize_counts: clr_adapt / clr_nz / binary / binned_nz_clr; --host-normalize: preprocess.py);
+    its seconds are reported separately and are never part of `value`."""
+    import flashweave_jl_amd as fw
     from flashweave_jl_amd import preprocess as pre
     from flashweave_jl_amd import synth
     c = dict(synth.CONFIGS[cfg])
@@ -47,15 +51,23 @@ def make_input(cfg, args):
         c["p"] = args.p
     if args.n:
         c["n"] = args.n
+    dev = (lambda cnt, t: fw.normalize_counts(cnt, t, device=int(os.environ.get("LOCAL_RANK", "0")) if not args.single_device else 0)) \
+        if not args.host_normalize else None
+    t0 = time.perf_counter()
     if c.get("habitats"):  # HE configs: structural absences + 20 binary meta variables
         counts, meta = synth.generate(c["p"], c["n"], c["seed"], mode=c["mode"], habitats=c["habitats"], n_meta=c["n_meta"])
+        t1 = time.perf_counter()
         # the front-end's meta-variable path (preprocess_data with a meta_mask, preprocessing.jl:412-563): row filters, one-hot /
         # discretisation where needed, zero-variance meta columns dropped, appended behind the OTUs
-        data = np.ascontiguousarray(pre.normalize_with_meta(counts, c["test_name"], meta.astype(np.float64), prec=32)["data"])
+        data = np.ascontiguousarray(pre.normalize_with_meta(counts, c["test_name"], meta.astype(np.float64), prec=32, normalizer=dev)["data"])
     else:
         counts = synth.generate(c["p"], c["n"], c["seed"], mode=c["mode"])
-        data, _, _ = pre.normalize(counts, c["test_name"], prec=32)
-    return c, synth.checksum(counts), data
+        t1 = time.perf_counter()
+        data, _, _ = dev(counts, c["test_name"]) if dev else pre.normalize(counts, c["test_name"], prec=32)
+    t2 = time.perf_counter()
+    norm = {"seconds": t2 - t1, "where": "host (preprocess.py)" if args.host_normalize else "device (fw_normalize_counts, includes the H2D upload "
+            "of the Int32 counts and the D2H copy of the result)", "generate_counts_seconds": t1 - t0}
+    return c, synth.checksum(counts), data, norm
 
 
 def parse_args(argv=None):
@@ -76,9 +88,11 @@ def parse_args(argv=None):
                     help="conditional stage of the first M targets of the schedule only (a bounded SAMPLE of configs whose full "
                          "conditional stage takes hours, e.g. cfg5; the JSON line says so and is not a whole-network result)")
     ap.add_argument("--no-other-schedule", action="store_true", help="skip the second (other_schedule) measurement")
+    ap.add_argument("--no-one-chain", action="store_true", help="skip the one-chain pass the per-kernel roofline figures come from")
     ap.add_argument("--host-seam", action="store_true",
                     help="also time the pass with FW_HOST_HITON=1: the host job pool over fw_test_subsets_batch-style "
                          "launches, the seam a Julia host would call (hiton.jl:100)")
+    ap.add_argument("--host-normalize", action="store_true", help="normalise the count table with the host front-end (preprocess.py) instead of the device one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-workers", type=int, default=-1,
@@ -253,7 +267,7 @@ def main():
     import flashweave_jl_amd as fw
     from flashweave_jl_amd.dist import make_allgather
 
-    cfg, csum, data = make_input(args.config, args)
+    cfg, csum, data, norm_rec = make_input(args.config, args)
     n, p = data.shape
     eng = fw.Engine(cfg["test_name"], n, p, max_k=cfg["max_k"], device=local_rank)
     eng.set_data(data)  # host -> HBM once, outside the timed region
@@ -379,6 +393,15 @@ def main():
     if not args.no_other_schedule:
         off, oR = (0, 0) if ff else (1, auto_R)
         other_m = meas(off, oR, max(1, min(args.steps, 3)), 1)
+    # per-kernel figures: with the default two concurrent chains the launches of the two streams overlap, and per-launch
+    # durations double-count the shared time (r02: kernel seconds 0.2355 > ms_per_step 0.2097).  The roofline therefore
+    # comes from one extra pass with ONE chain -- the segment kernel alone on the GPU -- so that its kernel seconds are
+    # a lower bound of that pass and comparable with the headline step.
+    one_m = None
+    if world == 1 and not simulating and not args.no_one_chain and cfg["test_name"] in ("fz", "fz_nz"):
+        os.environ["FW_DH_CHAINS"] = "1"
+        one_m = measure(ff, R if ff else 0, max(1, min(args.steps, 3)), 1)
+        del os.environ["FW_DH_CHAINS"]
     seam_m = None
     if args.host_seam and world == 1:
         os.environ["FW_HOST_HITON"] = "1"
@@ -390,35 +413,57 @@ def main():
         steps = max(args.steps, 1)
         cn, dt, net = main_m["cn"], main_m["dt"], main_m["net"]
         launches = max(cn["kernel_launches"], 1)
-        sub_launch_s = cn["t_dev_subsets_s"]
-        n_sub_launches = max(cn["subsets_launches"], 1)
-        achieved = (cn["alg_bytes_subsets"] / max(sub_launch_s, 1e-12)) / 1e9
-        traffic, traffic_src = None, None
-        for cand in ("r02_%s_pmc_summary.json" % args.config, "r01_cfg3_fz_pmc_summary.json" if args.config == "cfg3" else ""):
+        kname = "fz_subsets_seg_kernel" if cfg["test_name"] in ("fz", "fz_nz") else ("dh_mi_target_kernel" if cfg["test_name"] in ("mi", "mi_nz") else "mi_subsets_seg_kernel")
+        rcn, rsteps, rsrc = (one_m["cn"], max(1, min(args.steps, 3)), "one-chain pass (FW_DH_CHAINS=1: the kernel alone on the GPU)") if one_m else \
+                            (cn, steps, "headline pass")
+        sub_launch_s = rcn["t_dev_subsets_s"]
+        n_sub_launches = max(rcn["subsets_launches"], 1)
+        achieved = (rcn["alg_bytes_subsets"] / max(sub_launch_s, 1e-12)) / 1e9
+        # counters of the same kernel on the same workload from separate rocprofv3 --pmc passes (they cannot be read from inside
+        # this process): HBM-side traffic per launch, VALU instructions per test, VALU-busy share.  profiles/README.md
+        pmc, pmc_src = None, None
+        for cand in ("r03_%s_pmc_summary.json" % args.config, "r02_%s_pmc_summary.json" % args.config):
             pmc_path = os.path.join(ROOT, "profiles", cand)
-            if cand and not args.p and not args.n and os.path.exists(pmc_path):
-                # HBM-side bytes per launch of the same kernel on the same workload, from a separate rocprofv3 --pmc pass
-                # (PMC counters cannot be collected from inside this process); see profiles/README.md
-                kname = "fz_subsets_seg_kernel" if cfg["test_name"] in ("fz", "fz_nz") else "mi_subsets_seg_kernel"
+            if not args.p and not args.n and os.path.exists(pmc_path):
                 js = json.load(open(pmc_path))
-                if kname in js:
-                    traffic = js[kname]["fetch_bytes_per_launch"]
-                    traffic_src = "profiles/%s (FETCH_SIZE + WRITE_SIZE per launch)" % cand
+                hit = [k for k in js if isinstance(js[k], dict) and k.startswith(kname.split("<")[0]) and "evaluated_tests" in js[k]]
+                if hit:
+                    pmc, pmc_src = js[hit[0]], "profiles/" + cand
                     break
-        roofline = {"bound": "hbm", "kernel": "fz_subsets_seg_kernel" if cfg["test_name"] in ("fz", "fz_nz") else "mi_subsets_seg_kernel",
+        traffic = pmc.get("fetch_bytes_per_launch") if pmc else None
+        valu = None
+        if pmc and "valu_wave_insts_per_test" in pmc:
+            wps = pmc.get("waves_per_simd", 4)
+            ipt = pmc["valu_wave_insts_per_test"]
+            tps = rcn["cond_tests_evaluated"] / max(sub_launch_s, 1e-12)
+            # issue roof: 256 CUs x 4 SIMDs, a 64-lane instruction holds a SIMD >= 2 cycles (32 lanes / clock for 32-bit ops, 16 for Float64)
+            peak_wi = 256 * 4 * 2.4e9 / 2
+            valu = {"wave_insts_per_test": ipt, "busy_frac": min(1.0, pmc.get("active_inst_valu_frac_of_wave_cycles", 0.0) * wps),
+                    "waves_per_simd": wps, "achieved_wave_insts_per_s": ipt * tps, "issue_peak_wave_insts_per_s": peak_wi,
+                    "issue_frac_if_all_32bit": ipt * tps / peak_wi,
+                    "note": "busy_frac = SQ_ACTIVE_INST_VALU x waves per SIMD / SQ_WAVE_CYCLES from the tracked PMC pass: the share of "
+                            "cycles in which the SIMD's vector ALU is executing; Float64 and transcendental instructions hold it 4-16 "
+                            "cycles, so the issue fraction computed at the 32-bit rate understates it", "source": pmc_src}
+        bound = "valu" if (valu and valu["busy_frac"] >= 0.6 and (traffic or 0) < 0.5 * rcn["alg_bytes_subsets"] / n_sub_launches) else "hbm"
+        roofline = {"bound": bound, "kernel": kname,
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "traffic_source": traffic_src,
-                    "note": "nominal HBM roofline with the algorithmic bytes of SURVEY 8d (fz: 4*C(k+2,2)+32 B per test, discrete: "
-                            "(k+2)*n*b/8+32 B); the gathered matrix entries are mostly L2-resident and the measured limiter of "
-                            "the fz kernel is VALU issue of the Float64 division / square-root sequences; avg_launch_us = HIP events "
-                            "on the launch stream (device rounds: one launch in four, rotating slot, scaled to all launches); with "
-                            "concurrent chains the launches of the streams overlap, see roofline.stage",
+                    "traffic": traffic, "traffic_source": (pmc_src + " (FETCH_SIZE + WRITE_SIZE per launch)") if traffic else None,
+                    "valu": valu, "measured_on": rsrc,
+                    "note": "achieved / peak / frac: nominal HBM roofline with the algorithmic bytes of SURVEY 8d (fz: 4*C(k+2,2)+32 B per "
+                            "test, discrete: (k+2)*n*b/8+32 B) over the HIP-event time of the kernel's launches (device rounds: one launch "
+                            "in four, rotating slot, scaled to all launches).  bound = the resource the counters name: with `valu`, the "
+                            "gathered entries are L2-resident (traffic << algorithmic bytes) and the Float64 division / square-root "
+                            "sequences keep the vector ALUs busy",
+                    "kernel_seconds_per_step": sub_launch_s / rsteps,
+                    "step_seconds_of_that_pass": (one_m["ms_per_step"] / 1e3) if one_m else dt / steps,
                     "stage": {"achieved": cn["alg_bytes_subsets"] / max(cn["t_cond_s"], 1e-12) / 1e9,
                               "frac": cn["alg_bytes_subsets"] / max(cn["t_cond_s"], 1e-12) / 1e9 / HBM_PEAK_GBS,
-                              "conditional_stage_s": cn["t_cond_s"] / steps},
-                    "alg_bytes_per_launch": cn["alg_bytes_subsets"] / n_sub_launches,
+                              "conditional_stage_s": cn["t_cond_s"] / steps,
+                              "note": "headline pass (two concurrent chains): algorithmic bytes / wall time of the whole conditional stage"},
+                    "alg_bytes_per_launch": rcn["alg_bytes_subsets"] / n_sub_launches,
                     "avg_launch_us": 1e6 * sub_launch_s / n_sub_launches, "launches": n_sub_launches,
-                    "evaluated_tests_per_s_in_kernel": cn["cond_tests_evaluated"] / max(sub_launch_s, 1e-12)}
+                    "evaluated_tests_per_s_in_kernel": rcn["cond_tests_evaluated"] / max(sub_launch_s, 1e-12)}
+        sub_launch_s = cn["t_dev_subsets_s"]  # the stage table below reports the headline pass
         cpu, cpu_skipped = None, None
         if world > 1:
             cpu_skipped = "the CPU baseline is timed at N = 1 only"
@@ -440,9 +485,9 @@ def main():
                                       (args.config, p, n, cfg["test_name"], cfg["max_k"]),
                           "counts_sha256": csum, "feed_forward": ff, "round_size": R if ff else 0,
                           "sampled_targets": args.max_targets or None,
-                          "parallelism": "targets of each round dealt round-robin over %d GPU(s), one rank per GPU, backend %s" %
+                          "parallelism": "targets of each round dealt by estimated work over %d GPU(s), one rank per GPU, backend %s" %
                                          (world, (dist.get_backend() if use_dist else "none"))},
-               "time_to_network_s": dt / steps, "edges": int(len(net["edge_src"])), "rounds": main_m["rounds"],
+               "time_to_network_s": dt / steps, "normalisation": norm_rec, "edges": int(len(net["edge_src"])), "rounds": main_m["rounds"],
                "tests_per_step": {"level0": main_m["level0"], "conditional_ref_equivalent": main_m["cond_ref"],
                                   "conditional_evaluated": main_m["cond_eval"]},
                "exchange": main_m["exchange"], "simulated_world": main_m.get("simulated_world"),

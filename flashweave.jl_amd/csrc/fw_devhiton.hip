@@ -40,6 +40,11 @@ struct DhTgt {
     unsigned long long c_ref, c_calls, c_eval;  // per-target totals (summed on the host: no same-address atomics)
     double c_alg;
     unsigned int r_first0, r_more0, r_first1, r_more1;  // FW_TRACE_HOST: rounds this target spent on first / later windows of interleaving (0) and elimination (1) jobs
+    // look-ahead jobs of the coming launch: spmode 0 = same accepted list / elimination pools, window = the job's own (jwin2 = jwin);
+    // spmode 1 = interleaving "assume the current candidate is accepted": list = accepted + [candidate], own first window jwin2 of
+    // an enumeration of jN2 subsets (see dh_step_kernel)
+    int32_t spmode, pad1;
+    unsigned long long jwin2, jN2;
 };
 
 struct DhGlobal {
@@ -88,6 +93,7 @@ struct DhParams {
     int spec0_depth;                // interleaving-phase look-ahead (first windows of the next candidates)
     unsigned long long spec0_below;
     unsigned int spec0_jobs;  // ... and fewer live jobs than this
+    int spec1_depth;          // interleaving-phase look-ahead behind a candidate that is about to be accepted (same two conditions)
 };
 
 __device__ __forceinline__ unsigned long long dh_binom(long long m, int t)
@@ -102,18 +108,19 @@ __device__ __forceinline__ unsigned long long dh_binom(long long m, int t)
     return v;
 }
 
+// Is v one of the target's whitelisted neighbours?  Called by the whole wavefront with a uniform v: the lanes read 64 entries of
+// the (sorted) list at a time and vote -- ONE load latency per 64 entries.  (r02: a binary search, i.e. log2(n) + 1 DEPENDENT global
+// loads per call, up to four calls per target and round: a third of dh_step_kernel's 19 us.)
 __device__ __forceinline__ bool dh_in_wl(const DhTgt &x, const DhArrays &A, int32_t v)
 {
-    int lo = 0, hi = x.wl_n;
+    const int lane = (int)(threadIdx.x & 63u);
     const int32_t *w = A.wl + x.wl_off;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (w[mid] < v)
-            lo = mid + 1;
-        else
-            hi = mid;
+    for (int base = 0; base < x.wl_n; base += 64) {
+        const int32_t e = base + lane < x.wl_n ? w[base + lane] : -1;
+        if (__ballot(e == v) != 0ull) return true;
+        if (__shfl(e, 63) > v) return false;  // sorted: nothing further on can match (an invalid last lane reads -1: the loop ends anyway)
     }
-    return lo < x.wl_n && w[lo] == v;
+    return false;
 }
 
 // algorithmic bytes of the first `evaluated` ranks of a job over `a` accepted variables (fwi_alg_bytes, fz form)
@@ -829,7 +836,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
 __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, int ntg, DhGlobal *__restrict__ g, DhArrays A,
                                                       const FwSegOut *__restrict__ so, const long long *__restrict__ seg0,
                                                       unsigned long long *__restrict__ win, unsigned int *__restrict__ sp,
-                                                      const int32_t *__restrict__ act, DhParams P)
+                                                      unsigned long long *__restrict__ win2, const int32_t *__restrict__ act, DhParams P)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ci = blockIdx.x * 4 + wave;  // position in the list of unfinished targets (seg0 is indexed by it)
@@ -840,8 +847,17 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
         DhTgt x = tg[t];
         const long long jseg0 = seg0[ci];
         const int nsp_done = x.nsp;
-        const int jnseg = (int)(seg0[ci + 1] - jseg0) / (1 + nsp_done);  // records per job (look-ahead jobs: same window)
+        const int spmode_done = x.spmode;
+        // records of the target's own job, then of each look-ahead job (their window jwin2 can differ from the job's)
+        const int nseg_all = (int)(seg0[ci + 1] - jseg0);
+        int jnseg = nseg_all / (1 + nsp_done), jnseg2 = jnseg;
+        if (nsp_done > 0 && spmode_done == 1) {
+            const unsigned long long sl = g->seglen;  // the finished launch's segment length (the next plan has not run yet)
+            jnseg = (int)dh_ceil_div(x.jwin, sl, 1.0 / (double)sl);
+            jnseg2 = (nseg_all - jnseg) / nsp_done;
+        }
         x.nsp = 0;
+        x.spmode = 0;
         bool finished = false, kept = false;
         if (x.jactive) {
             if (x.phase == 0) (x.jnext == 0ull ? x.r_first0 : x.r_more0) += 1u;
@@ -891,12 +907,16 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
             // phase -- every earlier member kept (own pool buffers, whole enumerations); interleaving phase -- every
             // earlier candidate dropped (same accepted list, first window only: a candidate that survives its first
             // window becomes the target's job and ends the chain)
-            const bool ph1 = x.phase == 1;
-            const int n = x.na - (kept ? 1 : 0), cur0 = x.cur;
-            const unsigned long long wsp = x.jwin;  // look-ahead jobs ride with the first window of the target's job
-            bool valid = finished && (ph1 ? kept : !kept);
+            // ... interleaving phase, spmode 1 (the job was in its LAST window, i.e. it had survived its first one and was about
+            // to be accepted): first windows of the next candidates against accepted + [candidate]; they count if the candidate
+            // was indeed accepted, and then follow the same in-order rule
+            const bool ph1 = x.phase == 1, acc_mode = spmode_done == 1;
+            const int n = acc_mode ? x.na : x.na - (kept ? 1 : 0), cur0 = x.cur;
+            const unsigned long long wsp = acc_mode ? x.jwin2 : x.jwin;  // look-ahead jobs ride with the first window of the target's job
+            if (acc_mode) x.jN = x.jN2;  // the enumeration the look-ahead jobs belong to (accepted list one entry longer)
+            bool valid = finished && ((ph1 || acc_mode) ? kept : !kept);
             for (int j = 1; j <= nsp_done; ++j) {
-                const DhMerge M = dh_merge(so, jseg0 + (long long)j * jnseg, jnseg, lane);
+                const DhMerge M = dh_merge(so, jseg0 + (long long)jnseg + (long long)(j - 1) * jnseg2, jnseg2, lane);
                 if (!valid) {  // built on an assumption that failed: executed for nothing
                     x.c_eval += M.ev;
                     continue;
@@ -1022,10 +1042,40 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
             mywin = x.jwidth < left ? x.jwidth : left;
         }
         x.jwin = mywin;
+        if (x.nsp > 0) x.jwin2 = mywin, x.jN2 = x.jN;  // spmode 0: the look-ahead jobs share the job's window
+        if (x.jactive && x.phase == 0 && x.jnext > 0ull && mywin == x.jN - x.jnext && x.nsp == 0 && P.spec1_depth > 0 &&
+            g->launched_ranks < P.spec0_below && g->n_live_prev < P.spec0_jobs) {
+            // The candidate survived its first window(s) and this launch finishes its enumeration: it is about to be accepted
+            // (cfg3: a heavy target accepts half of its candidates, and each of them cost a first window, a last window and only
+            // then the next candidate -- the longest chain of the pass).  The first windows of the next candidates ride along
+            // against accepted + [candidate]: the entry is written behind the list now (dh_commit writes the same value there)
+            const int32_t *cands = A.cand0 + x.cand_off;
+            int q = 0;
+            while (q < P.spec1_depth && x.pos + 1 + q < x.nc) {
+                if (x.wl_n > 0 && dh_in_wl(x, A, cands[x.pos + 1 + q])) break;  // whitelisted: joins without a test
+                ++q;
+            }
+            if (q > 0) {
+                if (lane == 0) A.acc[DH_ACC_OFF(x, x.cur, d1) + x.na] = cands[x.pos];
+                unsigned long long N2 = 0ull;
+                for (int s = P.max_k; s >= 1; --s) {
+                    N2 += dh_binom(x.na + 1, s);
+                    if (N2 > (1ull << 62)) N2 = 1ull << 62;
+                }
+                if (P.max_tests > 0 && (unsigned long long)P.max_tests < N2) N2 = (unsigned long long)P.max_tests;
+                const unsigned long long w0 = x.na + 1 >= 64 ? P.w0_big : P.w0_small;
+                x.nsp = q;
+                x.spmode = 1;
+                x.jN2 = N2;
+                x.jwin2 = w0 < N2 ? w0 : N2;
+                if (lane == 0 && (unsigned int)(x.na + 1) > g->max_a) atomicMax(&g->max_a, (unsigned int)(x.na + 1));
+            }
+        }
         if (lane == 0) {
             tg[t] = x;
             win[t] = mywin;  // 0 = no job in the coming launch
             sp[t] = (unsigned int)x.nsp;
+            win2[t] = x.nsp > 0 ? x.jwin2 : 0ull;
         }
     }
 }
@@ -1033,9 +1083,10 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
 // one workgroup: totals of the coming launch, its segment length, per-target segment counts and their exclusive scan.
 // The segment length has no upper cap here, so the launch never holds more than seg_target + (live jobs) segments:
 // the fixed grid (seg_target + targets) always covers it.
-#define DH_PER 32  // targets per planning thread held in registers (more targets: extra passes over global memory)
+#define DH_PER 16  // targets per planning thread held in registers (more targets: extra passes over global memory)
 __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__restrict__ g, const unsigned long long *__restrict__ win,
-                                                       const unsigned int *__restrict__ sp, const int32_t *__restrict__ act_all,
+                                                       const unsigned int *__restrict__ sp, const unsigned long long *__restrict__ win2,
+                                                       const int32_t *__restrict__ act_all,
                                                        long long *__restrict__ seg0, unsigned int seg_target, unsigned int seg_q,
                                                        unsigned int seg_min, ulonglong2 *__restrict__ log, unsigned int log_cap,
                                                        unsigned long long seg_a, unsigned long long seg_b)
@@ -1049,24 +1100,26 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
     const int b = tid * per, e = (b + per) < na ? (b + per) : na;
     unsigned long long tot = 0ull;
     unsigned int live = 0u;
-    unsigned long long wr[DH_PER];  // this thread's windows (registers when per <= DH_PER)
-    unsigned int mr[DH_PER];        // jobs with that window: 1 + look-ahead jobs
+    unsigned long long wr[DH_PER];   // this thread's windows (registers when per <= DH_PER)
+    unsigned long long w2r[DH_PER];  // window of each look-ahead job (win2: equal to the job's own except in spmode 1)
+    unsigned int mr[DH_PER];         // look-ahead jobs
 #pragma unroll
     for (int q = 0; q < DH_PER; ++q) {
         const int tq = (b + q < e) ? act[b + q] : 0;
         wr[q] = (b + q < e) ? win[tq] : 0ull;
-        mr[q] = (b + q < e) ? 1u + sp[tq] : 1u;
+        mr[q] = (b + q < e) ? sp[tq] : 0u;
+        w2r[q] = (b + q < e && mr[q] > 0u) ? win2[tq] : 0ull;
     }
 #pragma unroll
     for (int q = 0; q < DH_PER; ++q) {
-        tot += wr[q] * mr[q];
-        live += wr[q] != 0ull ? mr[q] : 0u;
+        tot += wr[q] + w2r[q] * mr[q];
+        live += wr[q] != 0ull ? 1u + mr[q] : 0u;
     }
     for (int t = b + DH_PER; t < e; ++t) {
         const unsigned long long w = win[act[t]];
-        const unsigned int m = 1u + sp[act[t]];
-        tot += w * m;
-        live += w != 0ull ? m : 0u;
+        const unsigned int m = sp[act[t]];
+        tot += w + (m ? win2[act[t]] * m : 0ull);
+        live += w != 0ull ? 1u + m : 0u;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -1095,10 +1148,11 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
     unsigned int nr[DH_PER];
 #pragma unroll
     for (int q = 0; q < DH_PER; ++q) {
-        nr[q] = dh_ceil_div(wr[q], seglen, inv) * mr[q];
+        nr[q] = dh_ceil_div(wr[q], seglen, inv) + dh_ceil_div(w2r[q], seglen, inv) * mr[q];
         local += nr[q];
     }
-    for (int t = b + DH_PER; t < e; ++t) local += dh_ceil_div(win[act[t]], seglen, inv) * (1u + sp[act[t]]);
+    for (int t = b + DH_PER; t < e; ++t)
+        local += dh_ceil_div(win[act[t]], seglen, inv) + (sp[act[t]] ? dh_ceil_div(win2[act[t]], seglen, inv) * sp[act[t]] : 0u);
     unsigned int incl = local;  // inclusive scan inside the wavefront, then over the 16 wavefront totals
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -1122,7 +1176,7 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
         }
     for (int t = b + DH_PER; t < e; ++t) {
         seg0[t] = (long long)run;
-        run += dh_ceil_div(win[act[t]], seglen, inv) * (1u + sp[act[t]]);
+        run += dh_ceil_div(win[act[t]], seglen, inv) + (sp[act[t]] ? dh_ceil_div(win2[act[t]], seglen, inv) * sp[act[t]] : 0u);
     }
     if (tid == 0) {
         seg0[na] = (long long)ns;
@@ -1157,21 +1211,27 @@ __global__ __launch_bounds__(256) void dh_fill_kernel(const DhTgt *__restrict__ 
     const unsigned long long seglen = g->seglen;
     unsigned long long k = (unsigned long long)((long long)s - seg0[lo - 1]);
     const int32_t *cands = x.phase == 0 ? A.cand0 + x.cand_off : A.tpc_key + x.co;
-    unsigned int slot = 0;  // 0 = the target's job, j = its j-th look-ahead job (same window, own pool buffer)
+    unsigned int slot = 0;  // 0 = the target's job, j = its j-th look-ahead job (own window jwin2; elimination: own pool buffer)
     if (x.nsp > 0) {
-        const unsigned int per = (unsigned int)(seg0[lo] - seg0[lo - 1]) / (1u + (unsigned int)x.nsp);
-        slot = (unsigned int)k / per;
-        k -= (unsigned long long)slot * per;
+        const unsigned int all = (unsigned int)(seg0[lo] - seg0[lo - 1]);
+        const unsigned int n0 = x.spmode == 1 ? dh_ceil_div(x.jwin, seglen, 1.0 / (double)seglen) : all / (1u + (unsigned int)x.nsp);
+        if ((unsigned int)k >= n0) {
+            const unsigned int per = (all - n0) / (unsigned int)x.nsp;
+            slot = 1u + ((unsigned int)k - n0) / per;
+            k -= (unsigned long long)n0 + (unsigned long long)(slot - 1u) * per;
+        }
     }
+    const bool acc_mode = slot > 0u && x.spmode == 1;  // list = accepted + [current candidate], first window of its own enumeration
     FwSeg sg;
     sg.X = x.T;
     sg.Y = cands[x.pos + (int)slot];
     sg.acc_off = DH_ACC_OFF(x, x.phase == 1 ? (x.cur + (int)slot) % d1 : x.cur, d1);
-    sg.acc_len = x.na;
-    if (x.na > FW_TAB_A) g->any_big = 1u;  // same value from every writer
+    sg.acc_len = x.na + (acc_mode ? 1 : 0);
+    if (sg.acc_len > FW_TAB_A) g->any_big = 1u;  // same value from every writer
     sg.pad = 0;
-    sg.start = x.jnext + k * seglen;
-    const unsigned long long hi_r = x.jnext + x.jwin;
+    const unsigned long long lo_r = acc_mode ? 0ull : x.jnext;
+    sg.start = lo_r + k * seglen;
+    const unsigned long long hi_r = lo_r + (slot > 0u ? x.jwin2 : x.jwin);
     sg.end = sg.start + seglen < hi_r ? sg.start + seglen : hi_r;
     segs[s] = sg;
 }
@@ -1299,7 +1359,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     static const unsigned long long seg_a_env = [] { const char *e = getenv("FW_SEG_A"); return e ? (unsigned long long)atoll(e) : 8000000ull; }();
     static const unsigned long long seg_b_env = [] { const char *e = getenv("FW_SEG_B"); return e ? (unsigned long long)atoll(e) : 12000000ull; }();
     const unsigned long long seg_a = c->P.kind == FW_FZ ? seg_a_env : 0ull, seg_b = c->P.kind == FW_FZ ? seg_b_env : 0ull;
-    const unsigned max_ns = seg_target + (unsigned)ntg * (unsigned)(1 + std::max(spec_depth, spec0_depth)) + 256u;  // capacity of the segment list
+    const unsigned max_ns = seg_target + (unsigned)ntg * (unsigned)(1 + DH_MAX_SPEC) + 256u;  // capacity of the segment list (a job + its look-ahead jobs each round up)
     // striding workgroups of the segment kernel.  FW_SEG_GRID caps them (experiment: with fewer workgroups than resident
     // slots the one-workgroup step / plan kernels of the OTHER chain find a free CU at once instead of queueing behind
     // this launch's pending workgroups -- cfg5 profile: dh_plan_kernel 6.3 ms per call, all of it waiting)
@@ -1308,7 +1368,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     // FW_DH_LOG=<file>: one line per planned launch (ranks, live jobs, segments) -- profiling aid, see profiles/README.md
     static const char *log_path = getenv("FW_DH_LOG");
     constexpr unsigned LOG_CAP = 1u << 16;
-    size_t need = (log_path ? pad(sizeof(ulonglong2) * LOG_CAP) : 0) + pad(sizeof(int32_t) * 2 * (size_t)ntg) + pad(sizeof(unsigned int) * ((size_t)ntg + 1)) + pad(sizeof(DhTgt) * ntg) + pad(sizeof(DhGlobal)) + 2 * pad(sizeof(long long) * ((size_t)ntg + 1));
+    size_t need = (log_path ? pad(sizeof(ulonglong2) * LOG_CAP) : 0) + pad(sizeof(int32_t) * 2 * (size_t)ntg) + pad(sizeof(unsigned int) * ((size_t)ntg + 1)) + pad(sizeof(DhTgt) * ntg) + pad(sizeof(DhGlobal)) + 3 * pad(sizeof(long long) * ((size_t)ntg + 1));
     need += pad(4 * tot + 4) * 3 + pad(4 * 2 * tot * (size_t)d1 + 4) + pad(8 * tot + 8) * 4 + pad(4 * wl.size() + 4);
     need += pad(sizeof(FwSeg) * max_ns) + pad(sizeof(FwSegOut) * max_ns);
     if (!nb_on_dev) need += pad(8 * ((size_t)p + 1)) + pad(4 * nnz + 4) + 2 * pad(8 * nnz + 8);
@@ -1331,6 +1391,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     long long *d_seg0 = (long long *)carve(sizeof(long long) * ((size_t)ntg + 1));
     unsigned long long *d_win = (unsigned long long *)carve(sizeof(unsigned long long) * ((size_t)ntg + 1));
     unsigned int *d_sp = (unsigned int *)carve(sizeof(unsigned int) * ((size_t)ntg + 1));
+    unsigned long long *d_win2 = (unsigned long long *)carve(sizeof(unsigned long long) * ((size_t)ntg + 1));
     int32_t *d_act = (int32_t *)carve(sizeof(int32_t) * 2 * (size_t)ntg);  // ping-pong list of the unfinished targets
     DhArrays A{};
     int32_t *d_cand0 = (int32_t *)carve(4 * tot + 4);
@@ -1407,6 +1468,10 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         P.spec0_depth = spec0_depth;
         P.spec0_below = envu("FW_DH_SPEC0_BELOW", 12000000ull);
         P.spec0_jobs = (unsigned int)envu("FW_DH_SPEC0_JOBS", 512ull);
+        {   // look-ahead behind a candidate that is about to be accepted (dh_step_kernel, spmode 1)
+            const char *e = getenv("FW_DH_SPEC1");
+            P.spec1_depth = c->P.kind == FW_FZ ? std::min(std::max(e ? atoi(e) : 2, 0), DH_MAX_SPEC) : 0;
+        }
         P.mi_seq = (unsigned int)envu("FW_MI_SEQ", 16ull);
         P.mi_win0 = (unsigned int)envu("FW_MI_WIN0", 128ull);
         P.mi_chunk_div = (unsigned int)envu("FW_MI_CHUNK_DIV", 256ull);
@@ -1441,6 +1506,11 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     // never runs dry while the host looks at the round record (a stream synchronisation per batch left ~200 us of
     // idle GPU per 16 rounds).  Rounds after the last one are no-ops (no live segment, nothing to merge).
     constexpr int BATCH = 16;
+    // Rounds per batch.  The host sees "every target has finished" one batch late, so a pass of few, light targets (a rank of an
+    // 8-rank job holds 128 targets per feed-forward round at cfg3, 15 dependent rounds) ran 33 rounds, half of them empty: short
+    // batches for short lists (r03: 1.05 -> 0.75 ms per light round; the host enqueues 4 rounds in ~60 us, a round takes 25-100 us)
+    static const int nb_env = [] { const char *e = getenv("FW_DH_BATCH"); return e && atoi(e) > 0 ? std::min(atoi(e), 16) : 0; }();
+    const int nb = nb_env ? nb_env : (ntg <= 1024 ? 4 : BATCH);
     static const int time_every = [] { const char *e = getenv("FW_DH_TIME_EVERY"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
     // events live in a holder whose destructor synchronises the stream and destroys them on EVERY exit path (error returns
     // and the watchdog of the persistent kernel included: r02 leaked 66 events per failed call and left the stream running)
@@ -1474,11 +1544,11 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     auto &ev_end = evh.ev_end;
     auto planfill = [&](bool compact) {
         hipLaunchKernelGGL(dh_step_kernel, dim3((n_act_bound + 3u) / 4u), dim3(256), 0, st, d_tg, ntg, d_g, A,
-                           (const FwSegOut *)d_so, (const long long *)d_seg0, d_win, d_sp, (const int32_t *)d_act, P);
+                           (const FwSegOut *)d_so, (const long long *)d_seg0, d_win, d_sp, d_win2, (const int32_t *)d_act, P);
         if (compact)  // between step and plan: seg0 of the coming launch is built on the new list
             hipLaunchKernelGGL(dh_compact_kernel, dim3(1), dim3(1024), 0, st, (const DhTgt *)d_tg, ntg, d_g, d_act);
         hipLaunchKernelGGL(dh_plan_kernel, dim3(1), dim3(1024), 0, st, ntg, d_g, (const unsigned long long *)d_win,
-                           (const unsigned int *)d_sp, (const int32_t *)d_act, d_seg0, seg_target, P.seg_q, P.seg_min, d_log,
+                           (const unsigned int *)d_sp, (const unsigned long long *)d_win2, (const int32_t *)d_act, d_seg0, seg_target, P.seg_q, P.seg_min, d_log,
                            LOG_CAP, seg_a, seg_b);
         hipLaunchKernelGGL(dh_fill_kernel, dim3(g_fill), dim3(256), 0, st, (const DhTgt *)d_tg, ntg, d_g,
                            (const long long *)d_seg0, A, d_segs, d1, (const int32_t *)d_act);
@@ -1541,7 +1611,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     bool big_skipped[2] = {false, false};  // per batch slot: some round of it ran without the in-lane kernel
     auto enqueue_batch = [&](unsigned b) -> int {
         const int q = (int)(b & 1u);
-        for (int r = 0; r < BATCH; ++r) {
+        for (int r = 0; r < nb; ++r) {
             const bool timed = ((r + (int)(b % (unsigned)time_every)) % time_every) == 0;  // the sampled slot rotates from batch to batch
             // lists grow by at most one entry per round: 3 batches cover the lag of the record plus this batch
             // ... and a whitelisted neighbour is appended at most once per target: max_ab (accepted + whitelisted neighbours
@@ -1558,7 +1628,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
                         : fwi_mi_segments_dev(c, grid_mi, d_segs, A.acc, d_so, d_ns, st);
             if (rc) return rc;
             if (timed) (void)hipEventRecord(ev[q][2 * r + 1], st);
-            planfill(r == 0);
+            planfill((b * (unsigned)nb + (unsigned)r) % 16u == 0u);  // the list of unfinished targets is compacted every 16 rounds
         }
         FW_HIP(c, hipGetLastError());
         FW_HIP(c, hipMemcpyAsync(hg + q, d_g, sizeof(DhGlobal), hipMemcpyDeviceToHost, st));
@@ -1570,8 +1640,8 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         const int q = (int)(b & 1u);
         FW_HIP(c, hipEventSynchronize(ev_end[q]));
         const DhGlobal &rec = hg[q];
-        for (int r = 0; r < BATCH; ++r) {
-            if (rec.ns_ring[(b * (unsigned)BATCH + (unsigned)r) & 63u] == 0) continue;  // empty launch after the last round
+        for (int r = 0; r < nb; ++r) {
+            if (rec.ns_ring[(b * (unsigned)nb + (unsigned)r) & 63u] == 0) continue;  // empty launch after the last round
             ++launches_n;
             if (((r + (int)(b % (unsigned)time_every)) % time_every) != 0) continue;
             float ms = 0.0f;
@@ -1579,7 +1649,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
             timed_s += 1e-3 * (double)ms;
             ++timed_n;
             if (log_path) {
-                const size_t idx = (size_t)b * BATCH + (size_t)r;
+                const size_t idx = (size_t)b * (size_t)nb + (size_t)r;
                 if (log_ms.size() <= idx) log_ms.resize(idx + 1, 0.0f);
                 log_ms[idx] = ms;
             }
@@ -1606,7 +1676,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
                 break;
             }
             if (b > 250000u) {  // every round finishes at least one window: this is a logic error, not a workload
-                rc2 = fw_fail(c, FW_ERR_DEVICE, "device HITON: no convergence after %u rounds", b * (unsigned)BATCH);
+                rc2 = fw_fail(c, FW_ERR_DEVICE, "device HITON: no convergence after %u rounds", b * (unsigned)nb);
                 break;
             }
         }

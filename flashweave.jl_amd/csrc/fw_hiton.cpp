@@ -191,9 +191,33 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
             // enqueued up front with an empty whitelist (interleaved.jl:62,76-86); from the third target on a job sees
             // neighbors(graph, T).  The first round therefore holds two targets.
             r1 = std::min(nt, r0 + ((R == 1 && r0 == 0) ? 2 : R));
-            // this rank's targets of the round: dealt round-robin in schedule order
+            // this rank's targets of the round.  The targets of a round are independent of each other (whitelists only change
+            // between rounds), so any deal gives the same network; what matters is the balance.  r02 dealt them round-robin in
+            // schedule order, and at cfg3 / 8 ranks the heaviest rank carried 1.86e9 of the round's tests against a mean of
+            // 1.49e9.  Now: longest-processing-time-first on an estimate of a target's work -- the number of conditioning
+            // subsets its candidate list can span, C(deg, <= max_k) ~ deg^max_k (+ a constant for the chain of jobs every
+            // target pays) -- heaviest first, each to the least loaded rank, ties to the lower rank.  Every rank computes the
+            // same deal from the replicated level-0 lists.
+            std::vector<int32_t> owner((size_t)(r1 - r0), 0);
+            if (opt.world_size > 1) {
+                std::vector<int32_t> by((size_t)(r1 - r0));
+                std::iota(by.begin(), by.end(), 0);
+                auto est = [&](int32_t j) {
+                    const double d = (double)(c->nb_off[order[r0 + j] + 1] - c->nb_off[order[r0 + j]]);
+                    return std::pow(d, (double)std::min(std::max(c->P.max_k, 1), 3)) + 64.0;
+                };
+                std::stable_sort(by.begin(), by.end(), [&](int32_t x, int32_t y) { return est(x) > est(y); });
+                std::vector<double> load((size_t)opt.world_size, 0.0);
+                for (int32_t j : by) {
+                    int best = 0;
+                    for (int w = 1; w < opt.world_size; ++w)
+                        if (load[w] < load[best]) best = w;
+                    owner[j] = best;
+                    load[best] += est(j);
+                }
+            }
             size_t n_my = 0;
-            for (int i = r0; i < r1; ++i) n_my += ((i - r0) % opt.world_size == opt.rank);
+            for (int i = r0; i < r1; ++i) n_my += (owner[i - r0] == opt.rank);
             // Device-resident rounds (fw_devhiton.hip; every kind but fz_nz): no host round trip per window.  FW_HOST_HITON=1
             // keeps the host pool below for every kind (it is also what rounds of fewer than 64 targets use: the
             // reference's single_il schedule posts one target per round and would pay the device set-up each time).
@@ -211,7 +235,7 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
             std::vector<Target> tg;
             tg.reserve(n_my);
             for (int i = r0; i < r1; ++i) {
-                if ((i - r0) % opt.world_size != opt.rank) continue;
+                if (owner[i - r0] != opt.rank) continue;
                 Target t;
                 t.T = order[i];
                 if (discrete && c->levels[t.T] < 2) {  // hiton.jl:182-184
@@ -267,8 +291,8 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                     // busy.  cfg3, ms per pass with 1 / 2 / 3 / 4 chains: 261.8 / 229.4 / 224.2 / 274.3 on one GPU,
                     // 70.5 / 62.4 / 63.7 for one rank of eight; the per-launch duration of the segment kernel grows with
                     // the overlap (224 -> 167 us for launches half the size), which is what HIP events and rocprofv3 see
-                    static const int dh_chains = [] { const char *e = getenv("FW_DH_CHAINS"); return std::min(std::max(e ? atoi(e) : 2, 1), FW_DH_MAX_CHAINS); }();  // r02: cfg3 227 / 218 / 268 ms with 2 / 3 / 4 in a bare process, but 226 / 298 under torch.distributed.run and 325 with GPU_MAX_HW_QUEUES=8: the third stream's hardware queue is not ours to choose -> 2
-                    static const size_t dh_chain_min = [] { const char *e = getenv("FW_DH_CHAIN_MIN"); return e && atol(e) > 0 ? (size_t)atol(e) : (size_t)256; }();
+                    const int dh_chains = [] { const char *e = getenv("FW_DH_CHAINS"); return std::min(std::max(e ? atoi(e) : 2, 1), FW_DH_MAX_CHAINS); }();  /* read per round: bench.py times a one-chain pass for the per-kernel figures */  // r02: cfg3 227 / 218 / 268 ms with 2 / 3 / 4 in a bare process, but 226 / 298 under torch.distributed.run and 325 with GPU_MAX_HW_QUEUES=8: the third stream's hardware queue is not ours to choose -> 2
+                    static const size_t dh_chain_min = [] { const char *e = getenv("FW_DH_CHAIN_MIN"); return e && atol(e) > 0 ? (size_t)atol(e) : (size_t)48; }();  // r03: 256 -> 48 (one rank of eight holds 98 targets in cfg3's last round: 75 -> 69 ms with two chains)
                     static const int dh_chains_disc = [] { const char *e = getenv("FW_DH_CHAINS_DISC"); return std::min(std::max(e ? atoi(e) : 2, 1), FW_DH_MAX_CHAINS); }();  // cfg4: 248.7 / 232.9 / 227.2 / 253.1 ms with 1 / 2 / 3 / 4
                     // discrete kinds run as ONE persistent launch that fills the GPU by itself (dh_mi_target_kernel); concurrent
                     // chains only apply to their level-synchronous form (FW_MI_ROUNDS=1)

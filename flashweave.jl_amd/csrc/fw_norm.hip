@@ -4,7 +4,9 @@
 //   "fz"     clr_adapt                  :133-214   adaptive pseudo-counts (adaptive_pseudocount!) + centred log-ratio
 //   "fz_nz"  clr_nz                     :192-207   log(x / geometric mean of the row's non-zeros), zeros stay zeros
 //   "mi"     binary                     :475-490   presence / absence, columns with exactly two levels
-// ("mi_nz" needs a per-column tied ranking of the clr_nz values: flashweave.jl_amd/preprocess.py on the host.)
+//   "mi_nz"  binned_nz_clr              :217-291,492-521  clr_nz, then per column the tied (average) ranks of the non-zero entries,
+//                                       rank / max rank, bin = floor(. / (1/2 + 1e-5)) + 1 (two bins, disc_method "median"), zeros stay 0;
+//                                       columns whose non-zeros show exactly two bins
 // Arithmetic is Float64 like the reference (clrnorm converts to Matrix{Float64}); the continuous modes return Float32
 // (convert_to_target_prec with prec = 32).  Layout: n samples x p variables, column-major, as Julia holds it; one thread
 // per sample row and column chunk (adjacent lanes = adjacent samples: coalesced), chunk partials reduced in a fixed order.
@@ -122,6 +124,103 @@ __global__ __launch_bounds__(256) void norm_col_levels_kernel(const int32_t *__r
     if (threadIdx.x == 0) two[q] = s_z && s_nz;
 }
 
+// binned_nz_clr, one workgroup per kept column: the clr_nz values log(x / g_row) of the column's non-zero entries (kept rows) go
+// to LDS and are sorted there (bitonic, +inf padding); an entry's tied rank is then (#smaller) + (#equal + 1) / 2 from two binary
+// searches, the largest rank m - (e_max - 1) / 2, and bin = floor((rank / max rank) / (1/2 + 1e-5)) + 1 exactly as discretize()
+// computes it in Float64 (preprocessing.jl:238-265 with n_bins - 1 = 2 for the non-zeros, :267-291).  two[q] = the non-zeros show
+// both bins.  LDS: 8 bytes per padded entry (n <= 16 384 kept rows).
+#define NORM_BIN_MAX 16384
+__global__ __launch_bounds__(1024) void norm_binned_kernel(const int32_t *__restrict__ x, int n, const int32_t *__restrict__ rows, int nk,
+                                                           const int32_t *__restrict__ cols, const double *__restrict__ gmean,
+                                                           int32_t *__restrict__ out, int32_t *__restrict__ two, int M)
+{
+    extern __shared__ double s_key[];
+    __shared__ int s_cnt, s_b1, s_b2;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int32_t *col = x + (size_t)cols[q] * n;
+    if (tid == 0) s_cnt = s_b1 = s_b2 = 0;
+    __syncthreads();
+    for (int r = tid; r < nk; r += 1024) {
+        const int32_t v = col[rows[r]];
+        if (v != 0) s_key[atomicAdd(&s_cnt, 1)] = log((double)v / gmean[r]);  // order does not matter: sorted below
+    }
+    __syncthreads();
+    const int m = s_cnt;
+    for (int i = m + tid; i < M; i += 1024) s_key[i] = INFINITY;
+    __syncthreads();
+    for (int k = 2; k <= M; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < M; i += 1024) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const double a = s_key[i], b = s_key[l];
+                    const bool up = (i & k) == 0;
+                    if (up ? (a > b) : (a < b)) {
+                        s_key[i] = b;
+                        s_key[l] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    double rmax = 1.0;
+    if (m > 0) {
+        const double top = s_key[m - 1];
+        int lo = 0, hi = m;  // first index with key >= top
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_key[mid] < top)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        rmax = (double)m - ((double)(m - lo) - 1.0) / 2.0;
+    }
+    const double step = (1.0 / 2.0) + 1e-5;
+    int b1 = 0, b2 = 0;
+    for (int r = tid; r < nk; r += 1024) {
+        const int32_t v = col[rows[r]];
+        int bin = 0;
+        if (v != 0) {
+            const double c = log((double)v / gmean[r]);  // the same operations as above: the same bits
+            int lo = 0, hi = m;
+            while (lo < hi) {  // #smaller
+                const int mid = (lo + hi) >> 1;
+                if (s_key[mid] < c)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            int lo2 = lo, hi2 = m;
+            while (lo2 < hi2) {  // first index with key > c
+                const int mid = (lo2 + hi2) >> 1;
+                if (s_key[mid] <= c)
+                    lo2 = mid + 1;
+                else
+                    hi2 = mid;
+            }
+            const double rank = (double)lo + ((double)(lo2 - lo) + 1.0) / 2.0;
+            bin = (int)floor((rank / rmax) / step) + 1;
+            b1 |= bin == 1;
+            b2 |= bin == 2;
+        }
+        out[(size_t)q * nk + r] = bin;
+    }
+    if (b1) s_b1 = 1;
+    if (b2) s_b2 = 1;
+    __syncthreads();
+    if (tid == 0) two[q] = s_b1 && s_b2;
+}
+
+// dst column q2 = src column sel[q2] (nk entries each)
+__global__ __launch_bounds__(256) void norm_gather_cols_kernel(const int32_t *__restrict__ src, const int32_t *__restrict__ sel, int nk,
+                                                               int32_t *__restrict__ dst)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= nk) return;
+    dst[(size_t)blockIdx.y * nk + r] = src[(size_t)sel[blockIdx.y] * nk + r];
+}
+
 #define NHIP(call)                                                                                           \
     do {                                                                                                     \
         hipError_t e__ = (call);                                                                             \
@@ -138,12 +237,13 @@ extern "C" int fw_normalize_counts(int32_t device, int32_t kind, int32_t n, int3
 {
     if (!counts || !row_mask || !col_mask || !n_out || !p_out || n <= 0 || p <= 0)
         return fw_fail(nullptr, FW_ERR_ARG, "fw_normalize_counts: invalid argument");
-    if (kind != FW_FZ && kind != FW_FZ_NZ && kind != FW_MI)
-        return fw_fail(nullptr, FW_ERR_ARG, "fw_normalize_counts: kind %d is normalised on the host (preprocess.py)", kind);
-    if ((kind == FW_MI) ? !out_i32 : !out_f32) return fw_fail(nullptr, FW_ERR_ARG, "fw_normalize_counts: missing output buffer");
+    if (kind != FW_FZ && kind != FW_FZ_NZ && kind != FW_MI && kind != FW_MI_NZ)
+        return fw_fail(nullptr, FW_ERR_ARG, "fw_normalize_counts: unknown kind %d", kind);
+    const bool discrete = kind == FW_MI || kind == FW_MI_NZ;
+    if (discrete ? !out_i32 : !out_f32) return fw_fail(nullptr, FW_ERR_ARG, "fw_normalize_counts: missing output buffer");
     int rc = FW_OK;
     int32_t *d_x = nullptr, *d_cmin = nullptr, *d_cmax = nullptr, *d_cols = nullptr, *d_rows = nullptr, *d_rzero = nullptr, *d_rmin = nullptr,
-            *d_two = nullptr, *d_oi = nullptr;
+            *d_two = nullptr, *d_oi = nullptr, *d_tmp = nullptr, *d_sel = nullptr;
     double *d_rsum = nullptr, *d_rlog = nullptr, *d_pseudo = nullptr, *d_g = nullptr;
     float *d_of = nullptr;
     std::vector<int32_t> cmin((size_t)p), cmax((size_t)p), cols, rows, rzero, rmin;
@@ -242,7 +342,7 @@ extern "C" int fw_normalize_counts(int32_t device, int32_t kind, int32_t n, int3
                 const int i = rows[r];
                 g[r] = std::exp((SL[i] + (double)NZ[i] * std::log(pseudo[r])) / P);
             }
-        } else if (kind == FW_FZ_NZ) {  // geometric mean of the non-zeros
+        } else if (kind == FW_FZ_NZ || kind == FW_MI_NZ) {  // geometric mean of the non-zeros
             g.resize((size_t)nk);
             for (int r = 0; r < nk; ++r) {
                 const int i = rows[r];
@@ -277,6 +377,39 @@ extern "C" int fw_normalize_counts(int32_t device, int32_t kind, int32_t n, int3
             hipLaunchKernelGGL(norm_binary_out_kernel, dim3((nk + 255) / 256, pk), dim3(256), 0, 0, d_x, n, d_rows, nk, d_cols, pk, d_oi);
             NHIP(hipGetLastError());
             NHIP(hipMemcpy(out_i32, d_oi, sizeof(int32_t) * (size_t)nk * pk, hipMemcpyDeviceToHost));
+        } else if (kind == FW_MI_NZ) {
+            if (nk > NORM_BIN_MAX) {
+                rc = fw_fail(nullptr, FW_ERR_LIMIT, "fw_normalize_counts: binned_nz_clr sorts a column's non-zeros in LDS (at most %d samples, got %d)", NORM_BIN_MAX, nk);
+                goto done;
+            }
+            int M = 2;
+            while (M < nk) M <<= 1;
+            NHIP(hipMalloc((void **)&d_g, sizeof(double) * nk));
+            NHIP(hipMemcpy(d_g, g.data(), sizeof(double) * nk, hipMemcpyHostToDevice));
+            NHIP(hipMalloc((void **)&d_two, sizeof(int32_t) * pk));
+            NHIP(hipMalloc((void **)&d_tmp, sizeof(int32_t) * (size_t)nk * pk));
+            NHIP(hipFuncSetAttribute((const void *)norm_binned_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * NORM_BIN_MAX)));
+            hipLaunchKernelGGL(norm_binned_kernel, dim3(pk), dim3(1024), sizeof(double) * (size_t)M, 0, d_x, n, d_rows, nk, d_cols, d_g, d_tmp, d_two, M);
+            NHIP(hipGetLastError());
+            std::vector<int32_t> two((size_t)pk), sel;
+            NHIP(hipMemcpy(two.data(), d_two, sizeof(int32_t) * pk, hipMemcpyDeviceToHost));
+            for (int q = 0; q < pk; ++q) {
+                if (two[q])
+                    sel.push_back(q);
+                else
+                    col_mask[cols[q]] = 0;
+            }
+            pk = (int)sel.size();
+            if (pk == 0) {
+                rc = fw_fail(nullptr, FW_ERR_ARG, "fw_normalize_counts: no column whose non-zero abundances fall into two bins");
+                goto done;
+            }
+            NHIP(hipMalloc((void **)&d_sel, sizeof(int32_t) * pk));
+            NHIP(hipMemcpy(d_sel, sel.data(), sizeof(int32_t) * pk, hipMemcpyHostToDevice));
+            NHIP(hipMalloc((void **)&d_oi, sizeof(int32_t) * (size_t)nk * pk));
+            hipLaunchKernelGGL(norm_gather_cols_kernel, dim3((nk + 255) / 256, pk), dim3(256), 0, 0, d_tmp, d_sel, nk, d_oi);
+            NHIP(hipGetLastError());
+            NHIP(hipMemcpy(out_i32, d_oi, sizeof(int32_t) * (size_t)nk * pk, hipMemcpyDeviceToHost));
         } else {
             NHIP(hipMalloc((void **)&d_pseudo, sizeof(double) * nk));
             NHIP(hipMalloc((void **)&d_g, sizeof(double) * nk));
@@ -292,7 +425,7 @@ extern "C" int fw_normalize_counts(int32_t device, int32_t kind, int32_t n, int3
         *p_out = pk;
     }
 done:
-    void *ptrs[] = {d_x, d_cmin, d_cmax, d_cols, d_rows, d_rzero, d_rmin, d_two, d_oi, d_rsum, d_rlog, d_pseudo, d_g, d_of};
+    void *ptrs[] = {d_x, d_cmin, d_cmax, d_cols, d_rows, d_rzero, d_rmin, d_two, d_oi, d_tmp, d_sel, d_rsum, d_rlog, d_pseudo, d_g, d_of};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     return rc;

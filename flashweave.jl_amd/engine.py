@@ -116,8 +116,8 @@ def _ptr(a):
 
 
 def normalize_counts(counts, test_name, device=0):
-    """Normalisation front-end on the device (fw_normalize_counts): -> (data, row_mask, col_mask) like preprocess.normalize
-    for test_name in {"fz", "fz_nz", "mi"} ("mi_nz": preprocess.normalize on the host)."""
+    """Normalisation front-end on the device (fw_normalize_counts): -> (data, row_mask, col_mask) like preprocess.normalize,
+    for every test_name ("fz": clr_adapt, "fz_nz": clr_nz, "mi": binary, "mi_nz": binned_nz_clr)."""
     L = load_library()
     raw = np.asarray(counts)
     if raw.ndim != 2:
@@ -133,7 +133,7 @@ def normalize_counts(counts, test_name, device=0):
     no, po = C.c_int32(0), C.c_int32(0)
     kind = _KINDS[test_name]
     of = np.zeros(n * p, np.float32) if kind in (FW_FZ, FW_FZ_NZ) else None
-    oi = np.zeros(n * p, np.int32) if kind == FW_MI else None
+    oi = np.zeros(n * p, np.int32) if kind in (FW_MI, FW_MI_NZ) else None
     rc = L.fw_normalize_counts(device, kind, n, p, _ptr(x), _ptr(of), _ptr(oi), _ptr(rm), _ptr(cm), C.byref(no), C.byref(po))
     if rc != 0:
         raise FlashWeaveError(rc, L.fw_last_error(None).decode())

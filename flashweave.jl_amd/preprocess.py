@@ -121,7 +121,7 @@ def discretize(x, n_bins):
     return np.floor(r / step)
 
 
-def normalize_with_meta(counts, test_name, meta, prec=32, header=None, meta_header=None, make_onehot=True):
+def normalize_with_meta(counts, test_name, meta, prec=32, header=None, meta_header=None, make_onehot=True, normalizer=None):
     """preprocess_data with a meta_mask (preprocessing.jl:412-563): OTU columns are normalised as in normalize(); meta
     variables are one-hot encoded, follow the row filters, are discretised into 2 bins for the discrete tests when they look
     continuous, are shifted by +1 for "fz_nz" if they hold zeros (zeros mean "absent" there), lose zero-variance columns
@@ -130,7 +130,8 @@ def normalize_with_meta(counts, test_name, meta, prec=32, header=None, meta_head
         md, mh = onehot(meta, meta_header)
     else:
         md, mh = np.asarray(meta, dtype=np.float64), list(meta_header or [""] * np.asarray(meta).shape[1])
-    data, row_mask, col_mask = normalize(counts, test_name, prec=prec)
+    # normalizer: the OTU part on the device (engine.normalize_counts); the handful of meta columns stay here
+    data, row_mask, col_mask = normalizer(counts, test_name) if normalizer is not None else normalize(counts, test_name, prec=prec)
     md = md[row_mask]
     if test_name in ("mi", "mi_nz"):
         for j in range(md.shape[1]):

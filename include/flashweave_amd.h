@@ -209,7 +209,7 @@ typedef struct fw_learn_opts {
     int32_t round_size;    /* targets per feed-forward round; 1 = the reference's deterministic single_il schedule;
                               0 = one round (no whitelist can form: identical to feed_forward = 0 / parallel="single") */
     int32_t rank;          /* this process' rank in a target-sharded run (0 for single GPU) */
-    int32_t world_size;    /* number of ranks; targets of a round are dealt round-robin in schedule order */
+    int32_t world_size;    /* number of ranks; the targets of a round are dealt by estimated work (heaviest first to the least loaded rank) */
     int32_t max_targets;   /* > 0: stop after this many targets of the schedule (sampling; 0 = all) */
     int32_t reserved0;
 } fw_learn_opts;
@@ -227,10 +227,12 @@ int fw_network_get_directed(const fw_ctx *ctx, int64_t *off, int32_t *idx, doubl
 /* ---- normalisation front-end on the device -------------------------------------- */
 
 /* replaces: normalize_data / preprocess_data (src/preprocessing.jl:412-563) for a count table without meta variables:
- * filter_by_variance (:367-409), then by kind  FW_FZ: clr_adapt (:133-214)   FW_FZ_NZ: clr_nz (:192-207)   FW_MI: binary (:475-490).
- * counts: n x p column-major Int32.  Outputs (host buffers sized for n x p): out_f32 (FW_FZ / FW_FZ_NZ) or out_i32 (FW_MI),
- * column-major *n_out x *p_out; row_mask[n] / col_mask[p] = kept samples / variables.  No context needed: create one with the
- * resulting shape afterwards.  FW_MI_NZ (per-column tied ranks) is normalised by the host front-end. */
+ * filter_by_variance (:367-409), then by kind  FW_FZ: clr_adapt (:133-214)   FW_FZ_NZ: clr_nz (:192-207)   FW_MI: binary (:475-490)
+ * FW_MI_NZ: binned_nz_clr (clr_nz, then per column the tied ranks of the non-zero entries in two bins, :217-291,492-521; at most
+ * 16 384 samples).  counts: n x p column-major Int32.  Outputs (host buffers sized for n x p): out_f32 (FW_FZ / FW_FZ_NZ) or
+ * out_i32 (FW_MI / FW_MI_NZ), column-major *n_out x *p_out; row_mask[n] / col_mask[p] = kept samples / variables.  No context
+ * needed: create one with the resulting shape afterwards.  Meta variables (a handful of columns) are prepared by the caller
+ * (one-hot, discretisation: preprocess.py) and appended. */
 int fw_normalize_counts(int32_t device, int32_t kind, int32_t n, int32_t p, const int32_t *counts, float *out_f32, int32_t *out_i32,
                         uint8_t *row_mask, uint8_t *col_mask, int32_t *n_out, int32_t *p_out);
 

@@ -1,14 +1,15 @@
 #!/bin/bash
-# Round-2 profile of bench.py on one MI355X: kernel-trace stats + three separate PMC passes (never combined with tracing
-# domains other than --kernel-trace).  usage: bash profiles/tools/collect_r02.sh <config> [extra bench args]
+# Profile of bench.py on one MI355X: kernel-trace stats + three separate PMC passes (never combined with tracing
+# domains other than --kernel-trace).  usage: [ROUND=r03] bash profiles/tools/collect_profile.sh <config> [extra bench args]
 # Writes gpurun_out/prof_r02_<config>/.  Every rocprofv3 call sits under `timeout` and writes CSV.
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 CFG=$1; shift
-OUT=$PWD/gpurun_out/prof_r02_$CFG
+ROUND=${ROUND:-r03}
+OUT=$PWD/gpurun_out/prof_${ROUND}_$CFG
 rm -rf "$OUT"; mkdir -p "$OUT"
-BENCH="python $PWD/bench.py --config $CFG --no-cpu-baseline --no-other-schedule $*"
+BENCH="python $PWD/bench.py --config $CFG --no-cpu-baseline --no-other-schedule --no-one-chain $*"
 ROOT=$PWD
 cd /tmp
 rm -rf /tmp/prof_stats /tmp/pmc_sq /tmp/pmc_f /tmp/pmc_w

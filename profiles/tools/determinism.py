@@ -8,7 +8,7 @@ import flashweave_jl_amd as fw
 
 class A: pass
 args = A(); args.p = 0; args.n = 0
-cfg, csum, data = bench.make_input("cfg3", args)
+cfg, csum, data, _ = bench.make_input("cfg3", args)
 n, p = data.shape
 eng = fw.Engine("fz", n, p, max_k=3)
 eng.set_data(data)

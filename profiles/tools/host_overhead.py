@@ -9,7 +9,7 @@ from flashweave_jl_amd import engine as E
 
 class A: pass
 args = A(); args.p = 0; args.n = 0
-cfg, csum, data = bench.make_input("cfg3", args)
+cfg, csum, data, _ = bench.make_input("cfg3", args)
 n, p = data.shape
 eng = fw.Engine("fz", n, p, max_k=3)
 eng.set_data(data)

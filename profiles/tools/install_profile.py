@@ -1,9 +1,10 @@
-"""Turn the raw output of collect_r02.sh (gpurun_out/prof_r02_<cfg>/) into the tracked files profiles/r02_<cfg>_*:
-python profiles/tools/install_r02.py <cfg> <kernel-name-substring>   (run from the repo root)"""
+"""Turn the raw output of collect_profile.sh (gpurun_out/prof_<round>_<cfg>/) into the tracked files profiles/<round>_<cfg>_*:
+python profiles/tools/install_profile.py <cfg> <kernel-name-substring> [round, default r03]   (run from the repo root)"""
 import csv, json, shutil, sys
 
 cfg, kname = sys.argv[1], sys.argv[2]
-P = "gpurun_out/prof_r02_%s/" % cfg
+RND = sys.argv[3] if len(sys.argv) > 3 else "r03"
+P = "gpurun_out/prof_%s_%s/" % (RND, cfg)
 sq, f, w = (json.load(open(P + n)) for n in ("pmc_sq.json", "pmc_f.json", "pmc_w.json"))
 bench = json.loads([l for l in open(P + "bench_under_rocprof.json") if l.startswith("{")][-1])
 allk = {}
@@ -33,18 +34,19 @@ summ = {
     "wait_inst_any_frac_of_wave_cycles": K["SQ_WAIT_INST_ANY"] / K["SQ_WAVE_CYCLES"],
     "active_inst_valu_frac_of_wave_cycles": K["SQ_ACTIVE_INST_VALU"] / K["SQ_WAVE_CYCLES"],
     "algorithmic_bytes": alg, "fabric_over_algorithmic": (fetch + wr) / alg,
+    "waves_per_simd": (K["SQ_WAVES"] and round(K["SQ_WAVE_CYCLES"] / max(K.get("SQ_BUSY_CYCLES", 0.0), 1.0), 2)) if K.get("SQ_BUSY_CYCLES") else 4,
 }
 out = {
-    "command": "profiles/tools/collect_r02.sh %s: timeout 900 rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python "
-               "bench.py --config %s --steps 1 --warmup 0 --no-cpu-baseline --no-other-schedule (three separate passes: SQ_*; "
+    "command": "profiles/tools/collect_profile.sh %s: timeout 900 rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python "
+               "bench.py --config %s --steps 1 --warmup 0 --no-cpu-baseline --no-other-schedule --no-one-chain (three separate passes: SQ_*; "
                "FETCH_SIZE+TCC_HIT_sum; TCC_MISS_sum+TCC_REQ_sum+WRITE_SIZE), summed per kernel with profiles/tools/pmc_sum.py" % (cfg, cfg),
     "workload": bench["config"]["workload"], "schedule": {k: bench["config"][k] for k in ("feed_forward", "round_size")},
     "counters_per_kernel_sum_over_dispatches": allk,
-    ("fz_subsets_seg_kernel" if "fz" in kname else "mi_subsets_seg_kernel"): summ,
+    ("fz_subsets_seg_kernel" if "fz" in kname else ("dh_mi_target_kernel" if "dh_mi" in kname else "mi_subsets_seg_kernel")): summ,
 }
-json.dump(out, open("profiles/r02_%s_pmc_summary.json" % cfg, "w"), indent=1)
-shutil.copy(P + "kernel_stats.csv", "profiles/r02_%s_kernel_stats.csv" % cfg)
-json.dump(bench, open("profiles/r02_%s_bench_under_rocprof.json" % cfg, "w"))
+json.dump(out, open("profiles/%s_%s_pmc_summary.json" % (RND, cfg), "w"), indent=1)
+shutil.copy(P + "kernel_stats.csv", "profiles/%s_%s_kernel_stats.csv" % (RND, cfg))
+json.dump(bench, open("profiles/%s_%s_bench_under_rocprof.json" % (RND, cfg), "w"))
 print(json.dumps({k: v for k, v in summ.items() if k != "fetch_bytes_note"}, indent=1))
 print("under rocprof: ms %.1f launch_us %.1f launches %d" % (bench["ms_per_step"], bench["roofline"]["avg_launch_us"], bench["roofline"]["launches"]))
 for r in csv.DictReader(open(P + "kernel_stats.csv")):

@@ -7,7 +7,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     import bench, argparse
     import flashweave_jl_amd as fw
     args = argparse.Namespace(p=0, n=0)
-    cfg, _, data = bench.make_input("cfg4", args)
+    cfg, _, data, _ = bench.make_input("cfg4", args)
     n, p = data.shape
     eng = fw.Engine(cfg["test_name"], n, p, max_k=3)
     eng.set_data(data)

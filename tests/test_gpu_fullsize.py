@@ -95,9 +95,8 @@ import hashlib, sys
 sys.path.insert(0, %r)
 import bench
 import flashweave_jl_amd as fw
-class A: pass
-a = A(); a.p = 0; a.n = 0
-cfg, cs, data = bench.make_input("cfg3", a)
+a = bench.parse_args([])
+cfg, cs, data, _ = bench.make_input("cfg3", a)
 n, p = data.shape
 e = fw.Engine("fz", n, p, max_k=3)
 e.set_data(data)
@@ -248,4 +247,103 @@ def test_cfg4_full_size_properties():
         assert np.allclose(wa, wb, rtol=1e-11, atol=1e-15, equal_nan=True)
         nchk += len(b)
     assert nchk > 100
+    eng.close()
+
+
+def _cfg3_engine():
+    c = synth.CONFIGS["cfg3"]
+    counts = synth.generate(c["p"], c["n"], c["seed"], mode=c["mode"])
+    data, _, _ = pre.normalize(counts, "fz", prec=32)
+    n, p = data.shape
+    eng = fw.Engine("fz", n, p, max_k=3)
+    eng.set_data(data)
+    return eng, n, p
+
+
+def test_cfg3_full_size_headline_schedule_equals_oracle():
+    """The schedule bench.py reports (feed_forward = 1, rounds of R = 1024 targets) at the BASELINE size against the oracle, on
+    the part of the schedule the oracle finishes in seconds: the first three rounds (3 072 targets; rounds two and three run
+    with whitelists of hundreds of entries per round).  Directed lists and weights to the bit, p-values to 1e-12, reference-order
+    test count.  (r02 compared this schedule with the oracle only at p <= 800, R <= 128.)"""
+    eng, n, p = _cfg3_engine()
+    cm = eng.cor()
+    M, R = 3072, 1024
+    got = eng.lgl(feed_forward=True, round_size=R, max_targets=M, edge_dict=False)
+    cn = eng.counters()
+    orc = O.Oracle("fz", cor_mat=cm, n_obs=n)
+    exp = orc.learn(max_k=3, feed_forward=True, round_size=R, max_targets=M)
+    assert np.array_equal(got["pc_off"], exp["pc_off"])
+    assert np.array_equal(got["pc_idx"], exp["pc_idx"])
+    assert np.array_equal(got["pc_weight"], exp["pc_weight"], equal_nan=True)   # NaN = whitelisted without a test (hiton.jl:20-30)
+    assert np.allclose(got["pc_pval"], exp["pc_pval"], rtol=1e-12, atol=0.0, equal_nan=True)   # device log / erfc vs libm (DESIGN.md section 2)
+    assert int(np.isnan(exp["pc_weight"]).sum()) > 100                          # the whitelists were really in play
+    assert cn["cond_tests_ref"] == exp["n_cond_tests"] > 10_000
+    ge = dict(zip(zip(got["edge_src"].tolist(), got["edge_dst"].tolist()), got["edge_weight"].tolist()))
+    assert ge == exp["edges"] and len(ge) > 1000
+    eng.close()
+
+
+def test_cfg3_full_size_headline_schedule_device_rounds_equal_host_pool(monkeypatch):
+    """... and over the WHOLE schedule (ten rounds, the last one with the 784 heaviest targets, accepted lists up to ~180 entries
+    plus whitelisted neighbours): device-resident rounds (look-ahead jobs of all three kinds, two concurrent chains) against
+    the host job pool, which shares only the segment kernels with them."""
+    res = {}
+    for host in ("1", "0"):
+        monkeypatch.setenv("FW_HOST_HITON", host)
+        eng, n, p = _cfg3_engine()
+        eng.compute_cor()
+        res[host] = (eng.lgl(feed_forward=True, round_size=1024, edge_dict=False), eng.counters())
+        eng.close()
+    (nh, ch), (nd, cd) = res["1"], res["0"]
+    for key in ("edge_src", "edge_dst", "edge_weight", "pc_off", "pc_idx", "pc_weight", "pc_pval"):
+        assert np.array_equal(nh[key], nd[key], equal_nan=True), key
+    assert len(nd["edge_src"]) > 10000
+    assert ch["cond_tests_ref"] == cd["cond_tests_ref"] > 10**10
+    assert ch["subsets_calls"] == cd["subsets_calls"]
+
+
+def test_cfg5_full_size_long_list_jobs_equal_oracle():
+    """cfg5 at FULL size: real (T, candidate, accepted) jobs of its heaviest targets -- accepted lists of 89 ... 480 variables,
+    max_k = 5, i.e. the level-1 table form of the segment kernel that carries 85 % of cfg5's tests -- through
+    fw_test_subsets_batch against the oracle's sequential test_subsets on the same Float32 matrix, with max_tests capped so
+    that the oracle finishes: status, reference-order test count, conditioning set, statistic to the bit, p-value to 1e-12.
+    Two engines: alpha = 0.01 (the jobs stop where the reference stops) and alpha = 0.9999 (nearly every test is
+    "significant": the enumeration runs to the cap, so the max-p bookkeeping over 150 000 ranks is compared too)."""
+    c = synth.CONFIGS["cfg5"]
+    counts = synth.generate(c["p"], c["n"], c["seed"], mode=c["mode"])
+    data, _, _ = pre.normalize(counts, "fz", prec=32)
+    del counts
+    n, p = data.shape
+    cap = 150_000
+    eng = fw.Engine("fz", n, p, max_k=c["max_k"], max_tests=cap)
+    eng.set_data(data)
+    cm = eng.cor()  # 40 GB on the host: the oracle reads the device's own matrix
+    nb = eng.pw_univar_neighbors()
+    off, idx, pv = nb["off"], nb["idx"], nb["pval"]
+    deg = np.diff(off)
+    heavy = np.argsort(-deg, kind="stable")[:25]
+    assert deg[heavy[-1]] >= 200
+    T, C, A = [], [], []
+    lens = [89, 120, 200, 333, 480]
+    for i, t in enumerate(heavy):
+        cand = idx[off[t]:off[t + 1]][np.argsort(pv[off[t]:off[t + 1]], kind="stable")]  # hiton.jl:211-217 order
+        for L in (lens[i % 5], lens[(i + 2) % 5]):
+            L = min(L, len(cand) - 1)
+            T.append(int(t)); C.append(int(cand[L])); A.append([int(v) for v in cand[:L]])
+    orc = O.Oracle("fz", cor_mat=cm, n_obs=n)
+    for alpha in (0.01, 0.9999):
+        if alpha != 0.01:
+            eng.close()
+            eng = fw.Engine("fz", n, p, max_k=c["max_k"], max_tests=cap, alpha=alpha)
+            eng.set_cor_mat(cm)
+        got = eng.test_subsets_batch(T, C, A)
+        deep = 0
+        for t, cc, a, g in zip(T, C, A, got):
+            e = orc.test_subsets(t, cc, a, max_k=c["max_k"], alpha=alpha, n_obs_min=20, max_tests=cap)
+            assert g["status"] == e["status"] and g["num_tests"] == e["num_tests"], (t, cc, len(a), g, e)
+            assert g["Zs"] == e["Zs"] and g["stat"] == e["stat"], (t, cc, len(a), g, e)
+            assert g["pval"] == e["pval"] or abs(g["pval"] - e["pval"]) <= 1e-12 * abs(e["pval"]), (g, e)
+            deep += e["num_tests"] >= cap
+        if alpha != 0.01:
+            assert deep >= len(T) // 2  # most jobs ran to the cap
     eng.close()

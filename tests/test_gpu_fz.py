@@ -269,7 +269,10 @@ def test_learn_network_api_reproduces_all_golden_networks(tmp_path):
     for sensitive, het, name, wtol in ((True, False, "fz", 5e-5), (True, True, "fz_nz", 2e-5),
                                        (False, False, "mi", 1e-13), (False, True, "mi_nz", 1e-13)):
         for max_k in (0, 3):
-            net = fw.learn_network(raw, sensitive=sensitive, heterogeneous=het, max_k=max_k)
+            # round_size=1: the reference's deterministic single_il schedule the goldens were generated with (the default
+            # schedule is the device one: default_round_size(p) targets per feed-forward round)
+            net = fw.learn_network(raw, sensitive=sensitive, heterogeneous=het, max_k=max_k, round_size=1)
+            assert net["counters"]["normalized_on_device"]
             exp = read_edgelist("%s/learning_expected/exp_%s_maxk%d.edgelist" % (GOLDEN, name, max_k))
             assert set(net["edges"]) == set(exp), (name, max_k)
             assert all(abs(net["edges"][e] - exp[e]) <= wtol for e in exp)
