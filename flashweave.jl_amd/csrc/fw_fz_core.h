@@ -597,6 +597,23 @@ __device__ __forceinline__ double fz_l1t_stat(const float *__restrict__ cor, int
     return fz_pcor_levels<K, false>(R, is32);
 }
 
+// ---- level-3 position tables for subsets of 4 and 5 variables over long lists (r03; on top of the level-1 table) ----
+// Inside one z1-block, fix (z2, z3) = accepted[(j, k)] as well.  Everything the bottom-up form of statfuns.jl:44-53 needs about a
+// later position w given (z1, z2, z3) is a handful of numbers per POSITION (not per pair):
+//     P2[w] = rho(w,z2|z1)            Q3[w] = rho(w,z3|z1,z2)
+//     X3[w] = rho(X,w|z1,z2,z3)       Y3[w] = rho(Y,w|z1,z2,z3)       A4[w] = rho(X,Y|z1,z2,z3,w)
+// and the square roots the next level takes of them.  Per chunk the workgroup builds them for the (z2, z3) sub-blocks the chunk
+// touches (8 formulas + 2 matrix gathers per position; a sub-block of n later positions holds C(n, 2) size-5 tests).  A size-5
+// test (z4, v) = positions (l, m) is then: ONE gather cor[v][z4], the chain of that pair -- rho(v,z4|z1) (level-1 table),
+// rho(v,z4|z1,z2) from P2[m], P2[l], rho(v,z4|z1,z2,z3) from Q3[m], Q3[l] -- then rho(X,v|z1..z4), rho(Y,v|z1..z4) from X3 / Y3
+// and the final value from A4[l]: 6 formulas and 3 Float64 square roots instead of the 6 + 20 formulas of the level-1 form
+// (r02 PMC: 21.7 VALU wave-instructions per executed cfg5 test).  A size-4 test (z4 = position l) IS A4[l].  Same formulas on
+// the same values with the same argument roles as fz_pcor_dp (level 2 is not symmetric in its two conditioning values: the
+// later position is the first argument, as in U = [X, Y, z_K, ..., z_2]): bit-identical, checked by
+// tests/test_gpu_fz.py::test_size_4_5_table_kernels_value_at_random_ranks and the cfg5 long-list oracle test.
+#define FZ_L3_CAP 384  // positions (over all sub-blocks of a chunk)
+#define FZ_L3_DIR 64   // sub-blocks per chunk
+
 // HIGHK: subsets of size 4-5 possible; LOCAL: per-job matrices (fz_nz); TAB: size-3 subsets through the LDS table
 // (the host routes only segments of jobs with |accepted| <= FZ_TAB_A to a TAB launch); HIGHK && TAB: subsets of 4 and 5
 // variables through the level-2 tables above (jobs with |accepted| <= FZ_HK_A), sizes <= 3 through the in-lane forms
@@ -618,6 +635,18 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     __shared__ unsigned char s_l1f[L1T ? FZ_L1_A : 1];  // Float32 flags of the first two
     __shared__ double s_l1a;                            // rho(X,Y|z1)
     __shared__ int s_l1af, s_l1nan;
+    // level-3 position tables (L1T chunks, see "level-3 position tables" below)
+    __shared__ float s3_p2[L1T ? FZ_L3_CAP : 1];
+    __shared__ unsigned char s3_fl[L1T ? FZ_L3_CAP : 1];
+    __shared__ double s3_d2c[L1T ? FZ_L3_CAP : 1], s3_q3[L1T ? FZ_L3_CAP : 1], s3_sq3[L1T ? FZ_L3_CAP : 1], s3_x3[L1T ? FZ_L3_CAP : 1],
+        s3_sx3[L1T ? FZ_L3_CAP : 1], s3_y3[L1T ? FZ_L3_CAP : 1], s3_sy3[L1T ? FZ_L3_CAP : 1], s3_a4[L1T ? FZ_L3_CAP : 1];
+    __shared__ int s3_off[L1T ? FZ_L3_DIR + 1 : 2], s3_low[L1T ? FZ_L3_DIR : 1], s3_jk[L1T ? FZ_L3_DIR : 1];
+    __shared__ float s3_bp2[L1T ? FZ_L3_DIR : 1];  // block scalars of sub-block (z2, z3): rho(z3,z2|z1) ...
+    __shared__ unsigned char s3_bfl[L1T ? FZ_L3_DIR : 1];
+    __shared__ double s3_bd2c[L1T ? FZ_L3_DIR : 1], s3_bx2[L1T ? FZ_L3_DIR : 1], s3_bsx2[L1T ? FZ_L3_DIR : 1], s3_by2[L1T ? FZ_L3_DIR : 1],
+        s3_bsy2[L1T ? FZ_L3_DIR : 1], s3_ba3[L1T ? FZ_L3_DIR : 1];
+    __shared__ int s3_n, s3_lin0, s3_okf;
+    __shared__ unsigned long long s3_end;
     __shared__ double s_hk[HK ? FZ_HK_CAP : 1];
     __shared__ int s_hk_off[HK ? FZ_HK_DIR + 1 : 2];
     __shared__ unsigned short s_hk_ij[HK ? FZ_HK_DIR : 1];
@@ -800,8 +829,8 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 Rc = (int)((clen + 255ull) / 256ull);
             }
         }
-        bool l1_ok = false, l1_clean = false;
-        int l1_s = 0;
+        bool l1_ok = false, l1_clean = false, l3_ok = false;
+        int l1_s = 0, l3_lin0 = 0, l3_i = 0;
         if (L1T && in_lds && a <= FZ_L1_A && !(fz_dbg_flags & 1)) {
             unsigned long long rem0 = cbase;
             int s0 = max_k;
@@ -840,6 +869,123 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 }
                 __syncthreads();
                 l1_clean = s_l1nan == 0;
+                // ---- level-3 position tables of the (z2, z3) sub-blocks this chunk touches; the chunk ends where they are full ----
+                if (l1_ok && !(fz_dbg_flags & 2)) {
+                    const int i = i0;
+                    if (tid == 0) {
+                        int q[FW_MAX_K];
+                        unrank_comb(rem0, a, s0, q);
+                        int j = q[1], k = q[2];
+                        const int l0 = q[3];
+                        const int t3 = s0 - 3;  // positions behind z3: C(n, t3) subsets per sub-block
+                        unsigned long long cur_end = (binom_u64(a, s0) - binom_u64(a - i, s0)) + (binom_u64(a - 1 - i, s0 - 1) - binom_u64(a - j, s0 - 1)) +
+                                                     (binom_u64(a - 1 - j, s0 - 2) - binom_u64(a - k, s0 - 2)) + binom_u64(a - 1 - k, t3);
+                        unsigned long long lim = rem0 + (cend - cbase);
+                        int nd = 0, eoff = 0, okf = 1;
+                        const int jfirst = i + 1;
+                        s3_lin0 = (j - jfirst) * (a - s0 + 1 - i) - (j - jfirst) * (j - jfirst - 1) / 2 + (k - j - 1);
+                        for (;;) {
+                            const int lo_w = nd == 0 ? l0 : k + 1;
+                            const int ne = a - lo_w;
+                            if (eoff + ne > FZ_L3_CAP) {
+                                if (nd == 0) {  // one sub-block alone does not fit: this chunk takes the level-1 form
+                                    okf = 0;
+                                    break;
+                                }
+                                lim = cur_end - binom_u64(a - 1 - k, t3);  // the chunk ends in front of this sub-block
+                                break;
+                            }
+                            s3_jk[nd] = (j << 16) | k;
+                            s3_off[nd] = eoff;
+                            s3_low[nd] = lo_w;
+                            eoff += ne;
+                            ++nd;
+                            if (cur_end >= lim) break;
+                            if (nd == FZ_L3_DIR) {
+                                lim = cur_end;
+                                break;
+                            }
+                            if (++k > a - s0 + 2) {  // first sub-block of the next z2 (still inside the z1-block: lim is)
+                                ++j;
+                                k = j + 1;
+                            }
+                            cur_end += binom_u64(a - 1 - k, t3);
+                        }
+                        s3_off[nd] = eoff;
+                        s3_n = nd;
+                        s3_okf = okf;
+                        s3_end = cbase + (lim - rem0);
+                    }
+                    __syncthreads();
+                    if (s3_okf) {
+                        l3_ok = true;
+                        l3_lin0 = s3_lin0;
+                        l3_i = i;
+                        cend = s3_end;
+                        Rc = (int)((cend - cbase + 255ull) / 256ull);
+                        const int nd = s3_n, etot = s3_off[nd];
+                        const int z1 = ACCV(i);
+                        (void)z1;
+                        const TV A1{s_l1a, s_l1af != 0};
+                        // block scalars: one thread per sub-block
+                        for (int d = tid; d < nd; d += 256) {
+                            const int j = s3_jk[d] >> 16, k = s3_jk[d] & 0xffff;
+                            const float4 e2 = s_l1[j], e3 = s_l1[k];
+                            const int f2 = s_l1f[j], f3 = s_l1f[k];
+                            const TV LXz2{(double)e2.x, (f2 & 1) != 0}, LYz2{(double)e2.y, (f2 & 2) != 0};
+                            const TV LXz3{(double)e3.x, (f3 & 1) != 0}, LYz3{(double)e3.y, (f3 & 2) != 0};
+                            const TV P2z3 = pc_l1_r(CORV(ACCV(k), ACCV(j)), e3.z, e2.z, e3.w, e2.w);  // rho(z3,z2|z1)
+                            const double dP = fz_sq1(P2z3.v);
+                            const double A2 = pc_l2(A1, LXz2, LYz2);           // rho(X,Y|z1,z2)
+                            const double X2 = pc_l2_d2(LXz3, LXz2, P2z3, dP);  // rho(X,z3|z1,z2)
+                            const double Y2 = pc_l2_d2(LYz3, LYz2, P2z3, dP);  // rho(Y,z3|z1,z2)
+                            const double sx = fz_sq1(X2), sy = fz_sq1(Y2);
+                            s3_bp2[d] = (float)P2z3.v;
+                            s3_bfl[d] = P2z3.f32 ? 1 : 0;
+                            s3_bd2c[d] = dP;
+                            s3_bx2[d] = X2;
+                            s3_bsx2[d] = sx;
+                            s3_by2[d] = Y2;
+                            s3_bsy2[d] = sy;
+                            s3_ba3[d] = pc_l3s(A2, X2, Y2, sx, sy);            // rho(X,Y|z1,z2,z3)
+                        }
+                        __syncthreads();
+                        for (int e = tid; e < etot; e += 256) {
+                            int d = 0;
+                            for (int w = 32; w > 0; w >>= 1)  // largest d with off[d] <= e (FZ_L3_DIR <= 64)
+                                if (d + w < nd && s3_off[d + w] <= e) d += w;
+                            const int j = s3_jk[d] >> 16, k = s3_jk[d] & 0xffff;
+                            const int wv = s3_low[d] + (e - s3_off[d]);
+                            const int zw = ACCV(wv), z2 = ACCV(j), z3 = ACCV(k);
+                            const float4 ew = s_l1[wv], e2 = s_l1[j], e3 = s_l1[k];
+                            const int fw_ = s_l1f[wv], f2 = s_l1f[j];
+                            const TV LXw{(double)ew.x, (fw_ & 1) != 0}, LYw{(double)ew.y, (fw_ & 2) != 0};
+                            const TV LXz2{(double)e2.x, (f2 & 1) != 0}, LYz2{(double)e2.y, (f2 & 2) != 0};
+                            const TV P2z3{(double)s3_bp2[d], s3_bfl[d] != 0};
+                            const TV P2w = pc_l1_r(CORV(zw, z2), ew.z, e2.z, ew.w, e2.w);  // rho(w,z2|z1)
+                            const TV P3w = pc_l1_r(CORV(zw, z3), ew.z, e3.z, ew.w, e3.w);  // rho(w,z3|z1)
+                            const double dw = fz_sq1(P2w.v);
+                            const double Q3 = pc_l2_d2(P3w, P2w, P2z3, s3_bd2c[d]);  // rho(w,z3|z1,z2): w is the first of the pair
+                            const double X2w = pc_l2_d2(LXw, LXz2, P2w, dw);        // rho(X,w|z1,z2)
+                            const double Y2w = pc_l2_d2(LYw, LYz2, P2w, dw);
+                            const double sq = fz_sq1(Q3);
+                            const double X3 = pc_l3s(X2w, s3_bx2[d], Q3, s3_bsx2[d], sq);  // rho(X,w|z1,z2,z3)
+                            const double Y3 = pc_l3s(Y2w, s3_by2[d], Q3, s3_bsy2[d], sq);
+                            const double sx = fz_sq1(X3), sy = fz_sq1(Y3);
+                            s3_p2[e] = (float)P2w.v;
+                            s3_fl[e] = P2w.f32 ? 1 : 0;
+                            s3_d2c[e] = dw;
+                            s3_q3[e] = Q3;
+                            s3_sq3[e] = sq;
+                            s3_x3[e] = X3;
+                            s3_sx3[e] = sx;
+                            s3_y3[e] = Y3;
+                            s3_sy3[e] = sy;
+                            s3_a4[e] = pc_l3s(s3_ba3[d], X3, Y3, sx, sy);  // rho(X,Y|z1,z2,z3,w): the size-4 statistic
+                        }
+                        __syncthreads();
+                    }
+                }
             }
         }
         cnext = cend;
@@ -937,6 +1083,12 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
             float rj1 = 0.f;
             float2 rj2 = make_float2(0.f, 0.f);
             double A2j = 0.0;
+            // level-3 position tables: the z4 entry of the running sub-block
+            int l3_base = 0, zl = 0;
+            float4 t1l = make_float4(0.f, 0.f, 0.f, 0.f);
+            float p2l = 0.f;
+            bool fl3 = false;
+            double d2cl = 0.0, q3l = 0.0, sq3l = 0.0, x3l = 0.0, sx3l = 0.0, y3l = 0.0, sy3l = 0.0, a4l = 0.0;
             for (unsigned long long r = r0; r < r1; r += rstep) {
                 double stat;
                 ++my_done;
@@ -1031,6 +1183,42 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 } else if (s == 1) {
                     z1 = ACCV(pos[0]);
                     stat = pc_l1(cXY, CORV(X, z1), CORV(Y, z1)).v;
+                } else if (L1T && l3_ok && s == l1_s) {  // level-3 position tables (see FZ_L3_CAP)
+                    if (chg <= 2) {  // (z2, z3) changed: this sub-block's entries
+                        const int pj = pos[1], pk = pos[2], u = pj - (l3_i + 1);
+                        const int d = u * (a - s + 1 - l3_i) - u * (u - 1) / 2 + (pk - pj - 1) - l3_lin0;
+                        l3_base = s3_off[d] - s3_low[d];
+                    }
+                    if (s == 4) {
+                        stat = s3_a4[l3_base + pos[3]];
+                    } else {
+                        if (chg <= 3) {  // z4 changed: its entry stays in registers while only the last position moves
+                            const int pl = pos[3], el = l3_base + pl;
+                            t1l = s_l1[pl];
+                            zl = s_acc[pl];
+                            p2l = s3_p2[el];
+                            fl3 = s3_fl[el] != 0;
+                            d2cl = s3_d2c[el];
+                            q3l = s3_q3[el];
+                            sq3l = s3_sq3[el];
+                            x3l = s3_x3[el];
+                            sx3l = s3_sx3[el];
+                            y3l = s3_y3[el];
+                            sy3l = s3_sy3[el];
+                            a4l = s3_a4[el];
+                        }
+                        const int pm = pos[4], em = l3_base + pm;
+                        const float4 t1m = s_l1[pm];
+                        const float c45 = CORV(s_acc[pm], zl);
+                        const TV R1 = pc_l1_r(c45, t1m.z, t1l.z, t1m.w, t1l.w);              // rho(v,z4|z1)
+                        const TV Bm{(double)s3_p2[em], s3_fl[em] != 0}, Cl{(double)p2l, fl3};
+                        const double R2 = pc_l2_d2(R1, Bm, Cl, d2cl);                          // rho(v,z4|z1,z2): v is the first of the pair
+                        const double R3 = pc_l3s(R2, s3_q3[em], q3l, s3_sq3[em], sq3l);        // rho(v,z4|z1,z2,z3)
+                        const double s45 = fz_sq1(R3);
+                        const double X4 = pc_l3s(s3_x3[em], x3l, R3, sx3l, s45);               // rho(X,v|z1..z4)
+                        const double Y4 = pc_l3s(s3_y3[em], y3l, R3, sy3l, s45);               // rho(Y,v|z1..z4)
+                        stat = pc_l3s(a4l, X4, Y4, fz_sq1(X4), fz_sq1(Y4));                    // rho(X,Y|z1..z4,v)
+                    }
                 } else if (L1T && l1_ok && s == l1_s) {
                     stat = s == 5 ? fz_l1t_stat<5>(cor, p, s_l1, s_l1f, s_acc, pos, s_l1a, s_l1af != 0, l1_clean)
                                   : fz_l1t_stat<4>(cor, p, s_l1, s_l1f, s_acc, pos, s_l1a, s_l1af != 0, l1_clean);
