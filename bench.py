@@ -87,6 +87,9 @@ def parse_args(argv=None):
     ap.add_argument("--max-targets", type=int, default=0,
                     help="conditional stage of the first M targets of the schedule only (a bounded SAMPLE of configs whose full "
                          "conditional stage takes hours, e.g. cfg5; the JSON line says so and is not a whole-network result)")
+    ap.add_argument("--stream-columns", action="store_true",
+                    help="fz: recursive_pcor = 0 -- no correlation matrix for the conditional tests, every test streams its sample columns "
+                         "(statfuns.jl:19-21; fw_fzs.hip, host job pool); bound the run with --max-targets")
     ap.add_argument("--no-other-schedule", action="store_true", help="skip the second (other_schedule) measurement")
     ap.add_argument("--no-one-chain", action="store_true", help="skip the one-chain pass the per-kernel roofline figures come from")
     ap.add_argument("--host-seam", action="store_true",
@@ -269,7 +272,7 @@ def main():
 
     cfg, csum, data, norm_rec = make_input(args.config, args)
     n, p = data.shape
-    eng = fw.Engine(cfg["test_name"], n, p, max_k=cfg["max_k"], device=local_rank)
+    eng = fw.Engine(cfg["test_name"], n, p, max_k=cfg["max_k"], device=local_rank, recursive_pcor=not args.stream_columns)
     eng.set_data(data)  # host -> HBM once, outside the timed region
     xstats = {}
     cb = make_allgather(dist, cdev, stats=xstats) if use_dist else None
@@ -398,7 +401,7 @@ def main():
     # comes from one extra pass with ONE chain -- the segment kernel alone on the GPU -- so that its kernel seconds are
     # a lower bound of that pass and comparable with the headline step.
     one_m = None
-    if world == 1 and not simulating and not args.no_one_chain and cfg["test_name"] in ("fz", "fz_nz"):
+    if world == 1 and not simulating and not args.no_one_chain and not args.stream_columns and cfg["test_name"] in ("fz", "fz_nz"):
         os.environ["FW_DH_CHAINS"] = "1"
         one_m = measure(ff, R if ff else 0, max(1, min(args.steps, 3)), 1)
         del os.environ["FW_DH_CHAINS"]
@@ -413,7 +416,7 @@ def main():
         steps = max(args.steps, 1)
         cn, dt, net = main_m["cn"], main_m["dt"], main_m["net"]
         launches = max(cn["kernel_launches"], 1)
-        kname = "fz_subsets_seg_kernel" if cfg["test_name"] in ("fz", "fz_nz") else ("dh_mi_target_kernel" if cfg["test_name"] in ("mi", "mi_nz") else "mi_subsets_seg_kernel")
+        kname = "fzs_subsets_seg_kernel" if args.stream_columns else "fz_subsets_seg_kernel" if cfg["test_name"] in ("fz", "fz_nz") else ("dh_mi_target_kernel" if cfg["test_name"] in ("mi", "mi_nz") else "mi_subsets_seg_kernel")
         rcn, rsteps, rsrc = (one_m["cn"], max(1, min(args.steps, 3)), "one-chain pass (FW_DH_CHAINS=1: the kernel alone on the GPU)") if one_m else \
                             (cn, steps, "headline pass")
         sub_launch_s = rcn["t_dev_subsets_s"]
@@ -483,7 +486,7 @@ def main():
                "vs_baseline": None, "dtype": "f64" if cfg["test_name"] in ("fz", "fz_nz") else "i32", "data": "synthetic",
                "config": {"workload": "%s: fwsynth-v1 %d OTUs x %d samples, %s, max_k=%d, alpha=0.01" %
                                       (args.config, p, n, cfg["test_name"], cfg["max_k"]),
-                          "counts_sha256": csum, "feed_forward": ff, "round_size": R if ff else 0,
+                          "counts_sha256": csum, "recursive_pcor": 0 if args.stream_columns else 1, "feed_forward": ff, "round_size": R if ff else 0,
                           "sampled_targets": args.max_targets or None,
                           "parallelism": "targets of each round dealt by estimated work over %d GPU(s), one rank per GPU, backend %s" %
                                          (world, (dist.get_backend() if use_dist else "none"))},

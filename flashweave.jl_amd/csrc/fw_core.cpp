@@ -153,7 +153,7 @@ int fw_ctx_destroy(fw_ctx *c)
     if (!c) return FW_OK;
     (void)hipSetDevice(c->P.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->d_data, c->d_xc, c->d_sd, c->d_cor, c->d_thr, c->d_nzbits, c->d_hibits, c->d_levels, c->d_maxvals, c->d_firstnz, c->d_xlnx, c->d_gthr};
+    void *ptrs[] = {c->d_data, c->d_xc, c->d_sd, c->d_cor, c->d_thr, c->d_fzs_stat, c->d_nzbits, c->d_hibits, c->d_levels, c->d_maxvals, c->d_firstnz, c->d_xlnx, c->d_gthr};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     free_dev(c->d_jobs);
@@ -217,6 +217,7 @@ int fw_set_data_dense_f32(fw_ctx *c, const float *data)
     if (!c->d_data) FW_HIP(c, hipMalloc(&c->d_data, bytes));
     FW_HIP(c, hipMemcpy(c->d_data, data, bytes, hipMemcpyHostToDevice));
     c->have_data = true;
+    c->have_fzs_stat = false;
     c->have_cor = false;
     c->have_level0 = false;
     c->have_network = false;

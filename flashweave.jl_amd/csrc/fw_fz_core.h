@@ -555,7 +555,7 @@ __device__ __forceinline__ double fz_hk_stat(const double *__restrict__ tb, int 
 // Float32 root, the entries of the size-3 table -- is one LDS entry per position.  A test then gathers the C(s-1, 2)
 // matrix entries among its own later positions (6 instead of 21 for size 5) and evaluates 6 level-1 formulas with
 // ready-made roots instead of 15 full ones; levels 2..K are fz_pcor_levels as before (same values, same order).
-#define FZ_L1_A 1024
+#define FZ_L1_A 512  // (r03: 1024 -> 512: with the level-3 tables LDS bounds the occupancy of this variant; cfg5's longest list is 480)
 static __device__ int fz_dbg_flags;  // profiling knob (FW_FZ_DBG, set by fz_ensure_thresholds): bit 0 = no level-1 table
 template <int K>
 __device__ __forceinline__ double fz_l1t_stat(const float *__restrict__ cor, int p, const float4 *__restrict__ tab,
@@ -611,7 +611,7 @@ __device__ __forceinline__ double fz_l1t_stat(const float *__restrict__ cor, int
 // the same values with the same argument roles as fz_pcor_dp (level 2 is not symmetric in its two conditioning values: the
 // later position is the first argument, as in U = [X, Y, z_K, ..., z_2]): bit-identical, checked by
 // tests/test_gpu_fz.py::test_size_4_5_table_kernels_value_at_random_ranks and the cfg5 long-list oracle test.
-#define FZ_L3_CAP 384  // positions (over all sub-blocks of a chunk)
+#define FZ_L3_CAP 448  // positions (over all sub-blocks of a chunk): 31 KB; with the level-1 table and the list 48 KB -> three workgroups per CU
 #define FZ_L3_DIR 64   // sub-blocks per chunk
 
 // HIGHK: subsets of size 4-5 possible; LOCAL: per-job matrices (fz_nz); TAB: size-3 subsets through the LDS table
@@ -629,8 +629,11 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     constexpr bool TAB3 = TAB && !HIGHK;          // size-3 table (max_k <= 3)
     constexpr bool HK = TAB && HIGHK && !LOCAL;   // level-2 tables for sizes 4 and 5
     static_assert(!(TAB && HIGHK && LOCAL), "no level-2 table variant for per-job matrices");
-    __shared__ int s_acc[TAB3 ? FZ_TAB_A : (HK ? FZ_HK_A + 8 : FW_ACC_LDS)];  // TAB: |accepted| bounded by the host's routing
     constexpr bool L1T = HIGHK && !TAB && !LOCAL;  // level-1 table for sizes 4 and 5 over long lists
+    // the accepted list in LDS.  TAB: |accepted| bounded by the host's routing; long-list variant: up to FZ_L1_A entries (the table
+    // forms), longer lists are read from global memory by the generic gather form -- LDS is what bounds this variant's occupancy
+    constexpr int ACC_LDS = TAB3 ? FZ_TAB_A : (HK ? FZ_HK_A + 8 : (L1T ? FZ_L1_A : FW_ACC_LDS));
+    __shared__ int s_acc[ACC_LDS];
     __shared__ float4 s_l1[L1T ? FZ_L1_A : 1];         // {rho(X,v|z1), rho(Y,v|z1), cor[v][z1], sqrt(1 - cor[v][z1]^2)} per position v
     __shared__ unsigned char s_l1f[L1T ? FZ_L1_A : 1];  // Float32 flags of the first two
     __shared__ double s_l1a;                            // rho(X,Y|z1)
@@ -667,7 +670,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
 
     const int a = seg.acc_len;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool in_lds = a <= (TAB3 ? FZ_TAB_A : (HK ? FZ_HK_A : FW_ACC_LDS));
+    const bool in_lds = a <= (TAB3 ? FZ_TAB_A : (HK ? FZ_HK_A : (L1T ? FZ_L1_A : FW_ACC_LDS)));
     const float *cor = cor_g;
     int p = p_g;
     double zscale = zscale_g;

@@ -123,6 +123,8 @@ struct fw_ctx {
     float *d_sd = nullptr;    // sqrt(sum xc^2) per column, [p_pad]
     float *d_cor = nullptr;   // p x p (symmetric)
     double *d_thr = nullptr;  // |r| significance thresholds of the segment kernel (fz_thresholds_kernel)
+    double *d_fzs_stat = nullptr;  // recursive_pcor = 0: per column {mean, sum of squared deviations} in Float64 (fw_fzs.hip)
+    bool have_fzs_stat = false;
     int n_pad = 0, p_pad = 0;
     bool have_data = false, have_cor = false;
 
