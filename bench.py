@@ -81,9 +81,11 @@ def parse_args(argv=None):
     ap.add_argument("--feed-forward", type=int, default=1, help="reference default: true (learning.jl:469)")
     ap.add_argument("--round-size", type=int, default=-1,
                     help="targets per feed-forward round (-1: 1024 * ceil(p / 10240), about ten rounds; 0 = one round = feed_forward off)")
-    ap.add_argument("--shard-level0", action="store_true",
-                    help="N > 1, discrete kinds: every rank screens 1/N of the level-0 pair tiles and the significant pairs are "
-                         "all-gathered (fw_level0_sharded); default: level 0 replicated on every rank")
+    ap.add_argument("--replicate-level0", action="store_true",
+                    help="N > 1, discrete kinds: every rank screens ALL level-0 pair tiles (r02 behaviour); default: 1/N of them, "
+                         "significant pairs all-gathered in device memory (fw_level0_sharded_dev)")
+    ap.add_argument("--shard-cor", action="store_true",
+                    help="N > 1, fz: row-block sharding of the Pearson GEMM with an in-place all-gather (default from p = 30 000 on)")
     ap.add_argument("--max-targets", type=int, default=0,
                     help="conditional stage of the first M targets of the schedule only (a bounded SAMPLE of configs whose full "
                          "conditional stage takes hours, e.g. cfg5; the JSON line says so and is not a whole-network result)")
@@ -306,11 +308,73 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    discrete = cfg["test_name"] in ("mi", "mi_nz")
+    # level 0 of an N-rank job.  Discrete kinds: every rank screens 1/N of the pair tiles and the significant pairs are all-gathered
+    # in device memory (fw_level0_sharded_dev; --replicate-level0 switches it off).  Fisher-z: the GEMM is row-block sharded with an
+    # in-place all-gather of the matrix from p = 30 000 on (--shard-cor forces it): below that the replicated GEMM (cfg3: 2 ms) is
+    # cheaper than moving 400 MB.
+    shard_l0 = discrete and not args.replicate_level0
+    shard_cor = cfg["test_name"] == "fz" and (args.shard_cor or p >= 30000)
+    xdev = None
+    if use_dist and shard_l0:
+        from flashweave_jl_amd.dist import make_dev_exchange
+        xdev = make_dev_exchange(dist, dev, stats=xstats)
+    l0sim = {"mode": None, "all": None, "counts": None, "aux": None, "send": None, "cap": 0, "rank": 0}
+    if args.simulate_world > 1 and world == 1 and shard_l0:
+        # one GPU standing in for one rank: pass A lets every rank screen its tiles once and keeps its packed records; pass B
+        # (timed) hands every rank the complete gathered buffer, as the collective among N real ranks would
+        NW = args.simulate_world
+
+        def l0_prepare(user, n_local, aux_local, rec_bytes, d_send, d_recv, counts, aux, cap_records):
+            r = l0sim["rank"]
+            if l0sim["mode"] == "collect":
+                cap = max(int(n_local), 1)
+                if l0sim["cap"] < cap:
+                    capn = max(1 << (cap - 1).bit_length(), 2 * l0sim["cap"])
+                    old, oc = l0sim["all"], l0sim["cap"]
+                    l0sim["all"] = torch.zeros(NW * capn * rec_bytes, dtype=torch.uint8, device=dev)
+                    if old is not None:
+                        for q in range(NW):
+                            l0sim["all"][q * capn * rec_bytes:q * capn * rec_bytes + oc * rec_bytes] = old[q * oc * rec_bytes:(q + 1) * oc * rec_bytes]
+                    l0sim["send"] = torch.zeros(capn * rec_bytes, dtype=torch.uint8, device=dev)
+                    l0sim["cap"] = capn
+                l0sim["counts"][r], l0sim["aux"][r], l0sim["rec"] = int(n_local), int(aux_local), rec_bytes
+            for q in range(NW):
+                counts[q] = l0sim["counts"][q]
+                aux[q] = l0sim["aux"][q]
+            d_send[0] = l0sim["send"].data_ptr()
+            d_recv[0] = l0sim["all"].data_ptr()
+            cap_records[0] = l0sim["cap"]
+            return 0
+
+        def l0_exchange(user):
+            if l0sim["mode"] == "collect":
+                r, cb_, rb = l0sim["rank"], l0sim["cap"], l0sim["rec"]
+                n = l0sim["counts"][r]
+                l0sim["all"][r * cb_ * rb:r * cb_ * rb + n * rb] = l0sim["send"][:n * rb]
+                torch.cuda.synchronize()
+            return 0
+
+        def l0_collect():
+            npairs = p * (p - 1) // 2
+            l0sim.update(mode="collect", counts=[0] * NW, aux=[npairs] * NW)
+            for r in range(NW):
+                l0sim["rank"] = r
+                eng.level0_dev(r, NW, (l0_prepare, l0_exchange))
+            l0sim["mode"] = "replay"
+
     def step(ff, R):
         if cfg["test_name"] == "fz":
-            eng.compute_cor()  # matrix stays resident in HBM
-        if use_dist and args.shard_level0:
-            eng.level0(rank=rank, world_size=world, allgather=cb)  # discrete kinds: pair tiles sharded, significant pairs all-gathered
+            if use_dist and shard_cor:
+                from flashweave_jl_amd.dist import sharded_cor
+                sim["corbuf"] = sharded_cor(eng, dist, dev, rank, world, keep=sim.get("corbuf"))
+            else:
+                eng.compute_cor()  # matrix stays resident in HBM
+        if use_dist and xdev is not None:
+            eng.level0_dev(rank, world, xdev)
+        elif l0sim["mode"] == "replay":
+            l0sim["rank"] = sim.get("rank", 0)
+            eng.level0_dev(l0sim["rank"], args.simulate_world, (l0_prepare, l0_exchange))
         else:
             eng.level0()
         sim["k"] = 0
@@ -365,6 +429,8 @@ def main():
         step(f, r)
         recorded = sum(len(x[0]) for x in sim["rounds"])
         sim["mode"] = "replay"
+        if shard_l0:
+            l0_collect()
         ranks = range(args.simulate_world) if args.simulate_rank < 0 else [args.simulate_rank]
         per, found = [], 0
         for rk in ranks:

@@ -153,6 +153,7 @@ int fw_ctx_destroy(fw_ctx *c)
     if (!c) return FW_OK;
     (void)hipSetDevice(c->P.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->cor_external) c->d_cor = nullptr;  // caller-owned (fw_use_cor_buffer)
     void *ptrs[] = {c->d_data, c->d_xc, c->d_sd, c->d_cor, c->d_thr, c->d_fzs_stat, c->d_nzbits, c->d_hibits, c->d_levels, c->d_maxvals, c->d_firstnz, c->d_xlnx, c->d_gthr};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -167,6 +168,8 @@ int fw_ctx_destroy(fw_ctx *c)
     free_dev(c->d_nzrecs);
     free_dev(c->d_arena);
     free_dev(c->d_bh);
+    free_dev(c->d_l0m_i);
+    free_dev(c->d_l0m_d);
     for (int q = 0; q < FW_DH_MAX_CHAINS; ++q) {
         free_dev(c->d_dh[q]);
         free_pin(c->h_dh[q]);
@@ -332,9 +335,51 @@ int fw_set_row_views(fw_ctx *c, int32_t on)
 
 // ---- level 0 --------------------------------------------------------------------------------------
 // BH (statfuns.jl:326-350) on the p < alpha subset + neighbour lists (tests.jl:372-388).
-static int fw_level0_impl(fw_ctx *c, int64_t *nnz_out, int rank, int world, fw_allgather_fn allgather, void *user);
+static int fw_level0_impl(fw_ctx *c, int64_t *nnz_out, int rank, int world, fw_allgather_fn allgather, void *user,
+                          const fw_dev_exchange *xdev = nullptr);
 
 int fw_level0(fw_ctx *c, int64_t *nnz_out) { return fw_level0_impl(c, nnz_out, 0, 1, nullptr, nullptr); }
+
+int fw_level0_sharded_dev(fw_ctx *c, int32_t rank, int32_t world_size, const fw_dev_exchange *x, int64_t *nnz_out)
+{
+    CHECK_CTX(c);
+    if (world_size < 1 || rank < 0 || rank >= world_size) return fw_fail(c, FW_ERR_ARG, "fw_level0_sharded_dev: rank %d outside world of %d", rank, world_size);
+    if (world_size > 1 && (!x || !x->prepare || !x->exchange)) return fw_fail(c, FW_ERR_ARG, "fw_level0_sharded_dev: world_size > 1 needs both exchange callbacks");
+    return fw_level0_impl(c, nnz_out, rank, world_size, nullptr, nullptr, x);
+}
+
+int fw_use_cor_buffer(fw_ctx *c, void *d_cor, int64_t capacity_floats)
+{
+    CHECK_CTX(c);
+    if (c->P.kind != FW_FZ) return fw_fail(c, FW_ERR_ARG, "fw_use_cor_buffer: context is not FW_FZ");
+    if (!d_cor || capacity_floats < (int64_t)c->P.p * c->P.p) return fw_fail(c, FW_ERR_ARG, "fw_use_cor_buffer: needs at least p * p floats of device memory");
+    if (c->d_cor && !c->cor_external) (void)hipFree(c->d_cor);
+    c->d_cor = (float *)d_cor;
+    c->cor_external = true;
+    c->cor_capacity = capacity_floats;
+    c->have_cor = false;
+    c->have_level0 = false;
+    c->have_network = false;
+    return FW_OK;
+}
+
+int fw_compute_cor_mat_rows(fw_ctx *c, int32_t rank, int32_t world_size, int64_t *row0, int64_t *rows_per_rank)
+{
+    CHECK_CTX(c);
+    if (c->P.kind != FW_FZ) return fw_fail(c, FW_ERR_ARG, "fw_compute_cor_mat_rows: context is not FW_FZ");
+    if (world_size < 1 || rank < 0 || rank >= world_size || !row0 || !rows_per_rank) return fw_fail(c, FW_ERR_ARG, "fw_compute_cor_mat_rows: invalid argument");
+    c->have_level0 = false;
+    c->have_network = false;
+    return fwi_fz_compute_cor_rows(c, rank, world_size, row0, rows_per_rank);
+}
+
+int fw_cor_mat_ready(fw_ctx *c)
+{
+    CHECK_CTX(c);
+    if (c->P.kind != FW_FZ || !c->d_cor) return fw_fail(c, FW_ERR_STATE, "fw_cor_mat_ready: no correlation matrix buffer");
+    c->have_cor = true;
+    return FW_OK;
+}
 
 int fw_level0_sharded(fw_ctx *c, int32_t rank, int32_t world_size, fw_allgather_fn allgather, void *user, int64_t *nnz_out)
 {
@@ -344,7 +389,8 @@ int fw_level0_sharded(fw_ctx *c, int32_t rank, int32_t world_size, fw_allgather_
     return fw_level0_impl(c, nnz_out, rank, world_size, allgather, user);
 }
 
-static int fw_level0_impl(fw_ctx *c, int64_t *nnz_out, int rank, int world, fw_allgather_fn allgather, void *user)
+static int fw_level0_impl(fw_ctx *c, int64_t *nnz_out, int rank, int world, fw_allgather_fn allgather, void *user,
+                          const fw_dev_exchange *xdev)
 {
     CHECK_CTX(c);
     const double t0 = now_s();
@@ -380,11 +426,20 @@ static int fw_level0_impl(fw_ctx *c, int64_t *nnz_out, int rank, int world, fw_a
     c->l0_world = sharded ? world : 1;
     int rc = (c->P.kind == FW_FZ)      ? fwi_fz_level0(c, pi, pj, stat, pval, &m, devp)
              : (c->P.kind == FW_FZ_NZ) ? fwi_fznz_level0(c, pi, pj, stat, pval, &m, devp)
-                                       : fwi_mi_level0(c, pi, pj, stat, pval, &m, sharded ? nullptr : devp);
+                                       : fwi_mi_level0(c, pi, pj, stat, pval, &m, (sharded && !xdev) ? nullptr : devp);
     c->l0_rank = 0;
     c->l0_world = 1;
     if (rc) return rc;
-    if (sharded) {
+    if (sharded && xdev) {
+        // payload stays on the device: pack -> caller's collective -> unpack (fw_xchg.hip).  m = sum_r m_r - (W - 1) * npairs
+        // (every rank reports npairs minus ITS unreliable pairs)
+        if (host_bh) return fw_fail(c, FW_ERR_ARG, "fw_level0_sharded_dev: FW_HOST_BH=1 is a single-rank debugging mode");
+        FwL0Dev merged;
+        int64_t msum = 0;
+        if ((rc = fwi_l0_exchange_dev(c, xdev, world, dev, m, &merged, &msum))) return rc;
+        dev = merged;
+        m = msum - (int64_t)(world - 1) * ((int64_t)p * (p - 1) / 2);
+    } else if (sharded) {
         // one extra record carries this rank's count of reliable tests: m = sum_r m_r - (W - 1) * npairs (every rank reports
         // npairs minus ITS unreliable pairs)
         pi.push_back(-1);

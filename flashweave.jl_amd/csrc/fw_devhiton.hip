@@ -90,6 +90,7 @@ struct DhParams {
     unsigned int mi_elim_min;  // elimination-phase jobs with more ranks than this open a board for the whole enumeration at once (0: off)
     unsigned int mi_heavy;     // targets with at least this many candidates never work on other targets' boards (0: off)
     unsigned int mi_seq_heavy; // ... and run this many first tests of a job alone (instead of mi_seq) before they open a board
+    unsigned int mi_seq_tail;  // ... and every target this many once the target list is exhausted (idle wavefronts are waiting for work)
     int spec0_depth;                // interleaving-phase look-ahead (first windows of the next candidates)
     unsigned long long spec0_below;
     unsigned int spec0_jobs;  // ... and fewer live jobs than this
@@ -700,7 +701,15 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
             // the first tests: alone.  Elimination-phase jobs nearly always run to the end (the member passed every test against
             // almost this pool a moment ago): a big one goes to a board at once, whole enumeration in one window
             const bool elim_full = x.phase == 1 && P.mi_elim_min > 0u && N > (unsigned long long)P.mi_elim_min;
-            const unsigned long long seq = heavy ? P.mi_seq_heavy : P.mi_seq;
+            // the owner's sequential prefix.  While every wavefront still has targets of its own, boards cost more than they give
+            // (a prefix of 4 instead of 16: 55 -> 72 ms at cfg4 on one GPU); once the target list is exhausted the idle wavefronts
+            // do nothing but poll, and the chains of the last heavy targets ARE the rest of the pass: hand over after mi_seq_tail
+            // tests (one rank of eight, cfg4: 46.9 -> 37.2 ms of conditional stage)
+            // (tail: no target left to claim AND fewer than one wavefront in eight still owns one -- cfg2 has as many targets as
+            // the launch has wavefronts: "list exhausted" alone switched every job of the pass to the short prefix, 15 -> 22 ms)
+            const bool tail = mi_ld_u32(&Q->next_target) >= (unsigned int)ntg &&
+                              ((unsigned int)ntg - mi_ld_u32(&Q->targets_done)) * 8u <= gridDim.x * 4u;
+            const unsigned long long seq = tail ? P.mi_seq_tail : (heavy ? P.mi_seq_heavy : P.mi_seq);
             unsigned long long next = elim_full ? 0ull : (N < seq ? N : seq);
             FwSegOut o = mi_run_ranks<L, NXY, PRE>(M, x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, 0ull, next, nullptr, 0);
             unsigned long long ev = o.evaluated, nt = 0ull;
@@ -1481,6 +1490,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         { const char *e = getenv("FW_MI_ELIM_MIN"); P.mi_elim_min = e ? (unsigned int)atoi(e) : 64u; }
         { const char *e = getenv("FW_MI_HEAVY"); P.mi_heavy = e ? (unsigned int)atoi(e) : 48u; }
         { const char *e = getenv("FW_MI_SEQ_HEAVY"); P.mi_seq_heavy = e ? (unsigned int)atoi(e) : P.mi_seq; }
+        { const char *e = getenv("FW_MI_SEQ_TAIL"); P.mi_seq_tail = e ? (unsigned int)atoi(e) : 4u; }
     }
     const bool fz = c->P.kind == FW_FZ;
     P.w0_small = fz ? 256ull : 16ull;

@@ -79,14 +79,21 @@ __device__ __forceinline__ void tri_decode(int b, int T, int &bi, int &bj)
 }
 
 __global__ __launch_bounds__(256) void fz_cor_gemm_kernel(const float *__restrict__ xc, const float *__restrict__ sd,
-                                                          float *__restrict__ cor, int p, int n_pad, int T)
+                                                          float *__restrict__ cor, int p, int n_pad, int T,
+                                                          int row_mode /* 1: whole tile rows from bi0 on, no mirrored writes (row-block sharding) */,
+                                                          int bi0)
 {
     // two LDS stages (73.7 KB): while a tile is being multiplied, the next one is already in registers and is written
     // to the other stage right after the MFMA block -- one barrier per k-tile
     __shared__ __attribute__((aligned(16))) float sA[2][GEMM_BM * GEMM_LD];
     __shared__ __attribute__((aligned(16))) float sB[2][GEMM_BM * GEMM_LD];
     int bi, bj;
-    tri_decode(blockIdx.x, T, bi, bj);
+    if (row_mode) {
+        bi = bi0 + (int)blockIdx.x / T;
+        bj = (int)blockIdx.x % T;
+    } else {
+        tri_decode(blockIdx.x, T, bi, bj);
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lm = lane & 31, lh = lane >> 5;
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(256) void fz_cor_gemm_kernel(const float *__restric
                     vals[e] = r;
                     if (i < p && j < p) cor[(size_t)i * p + j] = r;
                 }
-                if (bi != bj && j < p) {
+                if (bi != bj && j < p && !row_mode) {
                     if (vec_ok && i0 + 3 < p) {
                         *reinterpret_cast<float4 *>(&cor[(size_t)j * p + i0]) = make_float4(vals[0], vals[1], vals[2], vals[3]);
                     } else {
@@ -432,11 +439,42 @@ int fwi_fz_compute_cor(fw_ctx *ctx)
     const int T = ctx->p_pad / GEMM_BM;
     const int nblk = T * (T + 1) / 2;
     hipLaunchKernelGGL(fz_cor_gemm_kernel, dim3(nblk), dim3(256), 0, ctx->stream, ctx->d_xc, ctx->d_sd, ctx->d_cor, p,
-                       ctx->n_pad, T);
+                       ctx->n_pad, T, 0, 0);
     FW_HIP(ctx, hipGetLastError());
     FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cnt.kernel_launches += 2;
     ctx->have_cor = true;
+    return FW_OK;
+}
+
+// Row-block share of the matrix (fw_compute_cor_mat_rows): tile rows [t0, t1) against every tile column, written as whole rows.
+// An element computed here and its mirror image computed by another rank are the same bits: the two MFMA operands swap roles, the
+// products and their order over k do not change.
+int fwi_fz_compute_cor_rows(fw_ctx *ctx, int rank, int world, int64_t *row0, int64_t *rows_per_rank)
+{
+    if (!ctx->have_data) return fw_fail(ctx, FW_ERR_STATE, "fw_compute_cor_mat_rows: no data uploaded (fw_set_data_dense_f32)");
+    const int n = ctx->P.n, p = ctx->P.p;
+    ctx->n_pad = (n + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+    ctx->p_pad = (p + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
+    const int T = ctx->p_pad / GEMM_BM;
+    const int tpr = (T + world - 1) / world;
+    *rows_per_rank = (int64_t)tpr * GEMM_BM;
+    *row0 = (int64_t)rank * tpr * GEMM_BM;
+    if (!ctx->d_cor || ctx->cor_capacity < (int64_t)world * tpr * GEMM_BM * p)
+        return fw_fail(ctx, FW_ERR_STATE, "fw_compute_cor_mat_rows: needs a caller-owned matrix of at least %lld floats (fw_use_cor_buffer)",
+                       (long long)world * tpr * GEMM_BM * p);
+    if (!ctx->d_xc) FW_HIP(ctx, hipMalloc(&ctx->d_xc, sizeof(float) * (size_t)ctx->n_pad * ctx->p_pad));
+    if (!ctx->d_sd) FW_HIP(ctx, hipMalloc(&ctx->d_sd, sizeof(float) * (size_t)ctx->p_pad));
+    hipLaunchKernelGGL(fz_center_kernel, dim3(ctx->p_pad), dim3(256), 0, ctx->stream, ctx->d_data, ctx->d_xc, ctx->d_sd, n,
+                       p, ctx->n_pad);
+    const int t0 = std::min(rank * tpr, T), t1 = std::min(t0 + tpr, T);
+    if (t1 > t0)
+        hipLaunchKernelGGL(fz_cor_gemm_kernel, dim3((unsigned)((t1 - t0) * T)), dim3(256), 0, ctx->stream, ctx->d_xc, ctx->d_sd, ctx->d_cor,
+                           p, ctx->n_pad, T, 1, t0);
+    FW_HIP(ctx, hipGetLastError());
+    FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->cnt.kernel_launches += 2;
+    ctx->have_cor = false;  // until the caller has gathered the other ranks' rows (fw_cor_mat_ready)
     return FW_OK;
 }
 

@@ -122,6 +122,8 @@ struct fw_ctx {
     float *d_xc = nullptr;    // centred columns, [p_pad][n_pad], zero padded
     float *d_sd = nullptr;    // sqrt(sum xc^2) per column, [p_pad]
     float *d_cor = nullptr;   // p x p (symmetric)
+    bool cor_external = false;  // d_cor is caller-owned device memory (fw_use_cor_buffer): never freed here
+    int64_t cor_capacity = 0;   // ... and holds this many floats
     double *d_thr = nullptr;  // |r| significance thresholds of the segment kernel (fz_thresholds_kernel)
     double *d_fzs_stat = nullptr;  // recursive_pcor = 0: per column {mean, sum of squared deviations} in Float64 (fw_fzs.hip)
     bool have_fzs_stat = false;
@@ -161,6 +163,7 @@ struct fw_ctx {
 
     // grow-only scratch
     FwDevBuf d_jobs, d_acc, d_out, d_tmp0, d_tmp1, d_tmp2, d_segs, d_segout, d_nzrecs, d_arena;
+    FwDevBuf d_l0m_i, d_l0m_d;  // level-0 pairs merged over the ranks (fw_xchg.hip)
     FwDevBuf d_bh;  // scratch of the device-side BH / neighbour-list epilogue (fw_bh.hip)
     // device copies of the level-0 neighbour CSR (inside d_bh, valid until the next fw_level0); null after a host-side BH
     const long long *d_nb_off = nullptr;
@@ -191,6 +194,7 @@ int fw_pin_reserve(fw_ctx *ctx, FwPinned &b, size_t bytes);
 
 // ---- fz (fw_fz.hip) ----
 int fwi_fz_compute_cor(fw_ctx *ctx);
+int fwi_fz_compute_cor_rows(fw_ctx *ctx, int rank, int world, int64_t *row0, int64_t *rows_per_rank);
 int fwi_fz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &pj, std::vector<double> &stat,
                   std::vector<double> &pval, int64_t *m_reliable, FwL0Dev *dev);
 int fwi_fz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff,
@@ -263,6 +267,8 @@ int fwi_pool_round(fw_ctx *ctx, FwPool &pool, std::vector<FwPoolJob> &finished);
 
 // device-side Benjamini-Hochberg + neighbour CSR (fw_bh.hip); fills ctx->nb_off / nb_idx / nb_stat / nb_p
 int fwi_bh_csr_device(fw_ctx *ctx, const FwL0Dev &in, int64_t m_reliable);
+// device-resident all-gather of the ranks' significant level-0 pairs (fw_xchg.hip)
+int fwi_l0_exchange_dev(fw_ctx *c, const fw_dev_exchange *x, int world, const FwL0Dev &local, int64_t m_local, FwL0Dev *merged, int64_t *m_sum);
 int fwi_nb_host_ensure(fw_ctx *ctx);  // download partners / statistics / adjusted p if only the device holds them
 
 // ---- device-resident HITON rounds (fw_devhiton.hip, FW_FZ) ----

@@ -382,7 +382,7 @@ __device__ __forceinline__ int mi_pair_screen(const MiDev &P, const int4 mX, con
     const int tt[3][3] = {{t00, t01, t02}, {t10, t11, t12}, {t20, t21, t22}};
     int n_obs = 0, S = 0;
     int mi_[3] = {0, 0, 0}, mj_[3] = {0, 0, 0};  // indexed by sub-table row / column
-    float g = 0.0f;
+    int tv[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -395,8 +395,10 @@ __device__ __forceinline__ int mi_pair_screen(const MiDev &P, const int4 mX, con
             if (sx == 0) mi_[i] += v; else if (i >= 1) mi_[i - 1] += v;
             if (sy == 0) mj_[j] += v; else if (j >= 1) mj_[j - 1] += v;
             S += v;
-            g += xlnx[v];
+            tv[i][j] = v;
         }
+    // integer verdicts first: an unreliable pair or one without degrees of freedom needs none of the 16 table lookups below
+    // (r03: they were interleaved with the counting loop and paid for by every pair)
     reliable = reliable && (long long)n_obs >= P.n_obs_min && (long long)n_obs > (long long)P.hps * lx * ly;
     if (!reliable) return 1;  // counted per workgroup by the caller (one atomic per pair serialised the whole kernel)
     int alx = (mi_[0] > 0) + (mi_[1] > 0) + (mi_[2] > 0), aly = (mj_[0] > 0) + (mj_[1] > 0) + (mj_[2] > 0);
@@ -404,6 +406,11 @@ __device__ __forceinline__ int mi_pair_screen(const MiDev &P, const int4 mX, con
     aly = aly < 1 ? 1 : aly;
     const int df = (alx - 1) * (aly - 1);
     if (df == 0) return 0;  // p = 1
+    float g = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) g += xlnx[tv[i][j]];
     g += (float)S * lnx[n_obs];
     g -= (xlnx[mi_[0]] + xlnx[mi_[1]] + xlnx[mi_[2]]) + (xlnx[mj_[0]] + xlnx[mj_[1]] + xlnx[mj_[2]]);
     // |g - G/2| <= 16 table roundings of <= 0.003 each at n <= 65536: far inside the margin below

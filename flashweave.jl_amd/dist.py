@@ -102,3 +102,85 @@ def make_allgather(dist, device, capacity=4096, stats=None):
             return 1
 
     return cb
+
+
+def make_dev_exchange(dist, device, stats=None):
+    """-> (prepare, exchange): the two callbacks of fw_dev_exchange (include/flashweave_amd.h) on torch.distributed.  The send /
+    receive buffers are torch tensors in DEVICE memory; the library packs into and unpacks from them with its own kernels, and the
+    all-gather runs on them directly (backend nccl = RCCL over xGMI).  With a CPU backend (gloo: the world_size-2 tests, two ranks
+    sharing one GPU) the same tensors are staged through the host for the collective only."""
+    import torch
+    st = {"send": None, "recv": None, "cap": 0, "rec": 0, "world": 0}
+    on_gpu_coll = dist.get_backend() == "nccl"
+
+    def prepare(user, n_local, aux_local, rec_bytes, d_send, d_recv, counts, aux, cap_records):
+        try:
+            world = dist.get_world_size()
+            hdr = torch.tensor([int(n_local), int(aux_local)], dtype=torch.int64, device=device if on_gpu_coll else "cpu")
+            allh = torch.empty(2 * world, dtype=torch.int64, device=hdr.device)
+            dist.all_gather_into_tensor(allh, hdr)
+            allh = allh.cpu().view(world, 2)
+            cap = max(int(allh[:, 0].max()), 1)
+            if st["cap"] < cap or st["rec"] != rec_bytes or st["world"] != world:
+                cap2 = 1 << (cap - 1).bit_length()
+                st["send"] = torch.empty(cap2 * rec_bytes, dtype=torch.uint8, device=device)
+                st["recv"] = torch.empty(world * cap2 * rec_bytes, dtype=torch.uint8, device=device)
+                st["cap"], st["rec"], st["world"] = cap2, rec_bytes, world
+            for r in range(world):
+                counts[r] = int(allh[r, 0])
+                aux[r] = int(allh[r, 1])
+            d_send[0] = st["send"].data_ptr()
+            d_recv[0] = st["recv"].data_ptr()
+            cap_records[0] = st["cap"]
+            if stats is not None:
+                stats["level0_records"] = int(allh[:, 0].sum())
+            return 0
+        except Exception:
+            traceback.print_exc()
+            return 1
+
+    def exchange(user):
+        try:
+            t0 = time.perf_counter()
+            if on_gpu_coll:
+                dist.all_gather_into_tensor(st["recv"], st["send"])
+                torch.cuda.current_stream(device).synchronize()
+            else:
+                h = torch.empty(st["recv"].numel(), dtype=torch.uint8)
+                dist.all_gather_into_tensor(h, st["send"].cpu())
+                st["recv"].copy_(h)
+                torch.cuda.synchronize(device)
+            if stats is not None:
+                stats["level0_exchange_s"] = stats.get("level0_exchange_s", 0.0) + time.perf_counter() - t0
+                stats["level0_exchange_bytes"] = st["recv"].numel()
+            return 0
+        except Exception:
+            traceback.print_exc()
+            return 1
+
+    return prepare, exchange
+
+
+def sharded_cor(eng, dist, device, rank, world, keep=None):
+    """cor(data_dense) with the row blocks dealt to the ranks: every rank computes rows_per_rank rows on its MFMA units, the
+    blocks are all-gathered IN PLACE inside one torch tensor that the engine uses as its matrix (fw_use_cor_buffer), so every
+    rank ends with the whole matrix resident.  -> the tensor (keep a reference as long as the engine lives)."""
+    import torch
+    p = eng.p
+    T = (p + 127) // 128
+    rpr = 128 * ((T + world - 1) // world)
+    buf = keep if keep is not None and keep.numel() >= world * rpr * p else torch.empty(world * rpr * p, dtype=torch.float32, device=device)
+    eng.use_cor_buffer(buf.data_ptr(), buf.numel())
+    row0, rows = eng.compute_cor_rows(rank, world)
+    assert rows == rpr and row0 == rank * rpr
+    mine = buf[rank * rpr * p:(rank + 1) * rpr * p]
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(buf[:world * rpr * p], mine)
+        torch.cuda.current_stream(device).synchronize()
+    else:
+        h = torch.empty(world * rpr * p, dtype=torch.float32)
+        dist.all_gather_into_tensor(h, mine.cpu())
+        buf[:world * rpr * p].copy_(h)
+        torch.cuda.synchronize(device)
+    eng.cor_ready()
+    return buf

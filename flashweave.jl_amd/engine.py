@@ -51,6 +51,15 @@ class _LearnOpts(C.Structure):
                 ("world_size", C.c_int32), ("max_targets", C.c_int32), ("reserved0", C.c_int32)]
 
 
+PREPARE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                         C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64))
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+class _DevExchange(C.Structure):  # fw_dev_exchange
+    _fields_ = [("user", C.c_void_p), ("prepare", PREPARE_FN), ("exchange", EXCHANGE_FN)]
+
+
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                            C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64),
                            C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32)),
@@ -98,6 +107,10 @@ def load_library():
     L.fw_normalize_counts.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32)]
     L.fw_level0_sharded.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, C.POINTER(C.c_int64)]
+    L.fw_level0_sharded_dev.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(_DevExchange), C.POINTER(C.c_int64)]
+    L.fw_use_cor_buffer.argtypes = [vp, vp, C.c_int64]
+    L.fw_compute_cor_mat_rows.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.fw_cor_mat_ready.argtypes = [vp]
     L.fw_test_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
     L.fw_test_subsets_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
     L.fw_learn_network.argtypes = [vp, C.POINTER(_LearnOpts), vp, vp, C.POINTER(C.c_int64)]
@@ -244,6 +257,29 @@ class Engine:
         else:
             self._ck(self.L.fw_level0(self.h, C.byref(nnz)))
         return nnz.value
+
+    def level0_dev(self, rank, world_size, exchange):
+        """Level 0 of a target-sharded run with the exchange kept in device memory (fw_level0_sharded_dev): `exchange` is a
+        (prepare, exchange) pair of Python callables (dist.make_dev_exchange)."""
+        nnz = C.c_int64(0)
+        x = _DevExchange(None, PREPARE_FN(exchange[0]), EXCHANGE_FN(exchange[1]))
+        self._xdev = x
+        self._ck(self.L.fw_level0_sharded_dev(self.h, rank, world_size, C.byref(x), C.byref(nnz)))
+        return nnz.value
+
+    # -- row-block sharding of cor() ------------------------------------------------------------------
+    def use_cor_buffer(self, device_ptr, capacity_floats):
+        """Keep the p x p matrix in caller-owned device memory (a torch tensor's data_ptr()): fw_use_cor_buffer."""
+        self._ck(self.L.fw_use_cor_buffer(self.h, C.c_void_p(device_ptr), int(capacity_floats)))
+
+    def compute_cor_rows(self, rank, world_size):
+        """This rank's row block of the matrix -> (row0, rows_per_rank); gather the blocks, then cor_ready()."""
+        r0, rp = C.c_int64(0), C.c_int64(0)
+        self._ck(self.L.fw_compute_cor_mat_rows(self.h, rank, world_size, C.byref(r0), C.byref(rp)))
+        return r0.value, rp.value
+
+    def cor_ready(self):
+        self._ck(self.L.fw_cor_mat_ready(self.h))
 
     def pw_univar_neighbors(self):
         """pw_univar_neighbors (src/tests.jl:436-532) -> CSR dict(off, idx, stat, pval)."""

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 2 /* 2: fw_params.recursive_pcor, fw_level0_sharded */
+#define FW_ABI_VERSION 3 /* 2: fw_params.recursive_pcor, fw_level0_sharded; 3: device-resident exchange (fw_dev_exchange), sharded cor */
 
 /* test kinds: src/types.jl:61-72 (test_name "mi" / "mi_nz" / "fz") */
 #define FW_MI 0
@@ -176,6 +176,32 @@ int fw_level0(fw_ctx *ctx, int64_t *nnz_out);
  * then built on every rank from the merged list.  The role of the reference's master process, which runs
  * pw_univar_neighbors once and ships the result to the workers (src/learning.jl:130-150, src/interleaved.jl:90-93). */
 int fw_level0_sharded(fw_ctx *ctx, int32_t rank, int32_t world_size, fw_allgather_fn allgather, void *user, int64_t *nnz_out);
+/* Device-resident exchange for target-sharded runs: the caller owns the communication buffers in DEVICE memory (torch tensors in
+ * bench.py, all-gathered by RCCL over xGMI), the library packs into / unpacks from them with its own kernels -- no host copy of the
+ * payload.  prepare(): every rank reports its record count and one auxiliary integer; the callee all-gathers both (counts[],
+ * aux[], world_size entries each), makes room for cap = max(count) records of rec_bytes bytes in a send buffer and for world_size
+ * blocks of cap records in a receive buffer, and returns their device addresses.  exchange(): all-gather the send buffers
+ * (cap * rec_bytes bytes per rank) into the receive buffer in rank order; returns when the data is in place. */
+typedef struct fw_dev_exchange {
+    void *user;
+    int (*prepare)(void *user, int64_t n_local, int64_t aux_local, int32_t rec_bytes, void **d_send, void **d_recv, int64_t *counts,
+                   int64_t *aux, int64_t *cap_records);
+    int (*exchange)(void *user);
+} fw_dev_exchange;
+/* fw_level0_sharded with the payload kept on the device: this rank screens its share of the pair tiles (discrete kinds), the
+ * significant pairs are packed into the caller's send buffer, gathered, and Benjamini-Hochberg + the neighbour lists are built
+ * from the gathered buffer on every rank.  (The Fisher-z kinds stay replicated: see fw_compute_cor_mat_rows for their share.) */
+int fw_level0_sharded_dev(fw_ctx *ctx, int32_t rank, int32_t world_size, const fw_dev_exchange *exchange, int64_t *nnz_out);
+
+/* FW_FZ, row-block sharding of cor(data_dense) (src/learning.jl:44) over the ranks: fw_use_cor_buffer makes the context keep its
+ * p x p matrix in caller-owned device memory (capacity in floats >= world_size * rows_per_rank * p, see below);
+ * fw_compute_cor_mat_rows computes the rows [*row0, *row0 + *rows_per_rank) of this rank (whole rows, no mirrored writes:
+ * rows_per_rank = 128 * ceil(ceil(p / 128) / world_size), the same on every rank) and leaves the rest untouched; the caller then
+ * all-gathers the row blocks in place (contiguous: rows_per_rank * p floats per rank) and calls fw_cor_mat_ready. */
+int fw_use_cor_buffer(fw_ctx *ctx, void *d_cor, int64_t capacity_floats);
+int fw_compute_cor_mat_rows(fw_ctx *ctx, int32_t rank, int32_t world_size, int64_t *row0, int64_t *rows_per_rank);
+int fw_cor_mat_ready(fw_ctx *ctx);
+
 /* Neighbour lists as CSR: off[p+1]; idx/stat/adj_p have nnz entries, partners ascending per variable;
  * adj_p is the BH-adjusted p-value when fdr = 1 (src/tests.jl:372-388). */
 int fw_level0_get(const fw_ctx *ctx, int64_t *off, int32_t *idx, double *stat, double *adj_p);

@@ -4,9 +4,9 @@ import os, sys, time, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 if len(sys.argv) > 1 and sys.argv[1] == "child":
-    import bench, argparse
+    import bench
     import flashweave_jl_amd as fw
-    args = argparse.Namespace(p=0, n=0)
+    args = bench.parse_args([])
     cfg, _, data, _ = bench.make_input("cfg4", args)
     n, p = data.shape
     eng = fw.Engine(cfg["test_name"], n, p, max_k=3)

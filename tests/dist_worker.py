@@ -88,6 +88,27 @@ def run_sharded_gpu(rank, world, out_path):
                 one = single.lgl(feed_forward=bool(ff), round_size=R)
                 res["%s_ff%d_single" % (kind, ff)] = sorted([a, b, w] for (a, b), w in one["edges"].items())
                 single.close()
+        # r03: the same exchange with the payload kept in device memory (fw_level0_sharded_dev: pack / unpack kernels around a
+        # collective on torch-owned device buffers; gloo stages them through the host for the collective only)
+        from flashweave_jl_amd.dist import make_dev_exchange, sharded_cor
+        xs = {}
+        eng.level0_dev(rank, world, make_dev_exchange(dist, torch.device("cuda", 0), stats=xs))
+        nb = eng.pw_univar_neighbors_get()
+        res["%s_l0_dev" % kind] = [nb["off"].tolist(), nb["idx"].tolist(), nb["stat"].tolist(), nb["pval"].tolist()]
+        res["%s_l0_dev_records" % kind] = xs.get("level0_records", 0)
+        if kind == "fz":
+            # row-block sharding of cor(): each rank computes half of the rows, the blocks are gathered in place inside a
+            # torch tensor the engine uses as its matrix; bit-identical to the single-rank matrix, and so is the network on it
+            cm1 = eng.cor()
+            e2 = fw.Engine(kind, n, p, max_k=3)
+            e2.set_data(data)
+            buf = sharded_cor(e2, dist, torch.device("cuda", 0), rank, world)
+            cm2 = e2.cor_mat()
+            res["fz_cor_sharded_equal"] = bool(np.array_equal(cm1, cm2, equal_nan=True))
+            net = e2.lgl(feed_forward=True, round_size=32, rank=rank, world_size=world, allgather=cb)
+            res["fz_ff1_sharded_cor"] = sorted([a, b, w] for (a, b), w in net["edges"].items())
+            e2.close()
+            del buf
         eng.close()
     json.dump(res, open(out_path + ".%d" % rank, "w"))
     dist.barrier()

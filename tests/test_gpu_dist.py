@@ -24,3 +24,9 @@ def test_sharded_equals_single():
         for kind in ("fz", "mi"):
             assert r0[kind + "_l0"] == r1[kind + "_l0"] == r0[kind + "_l0_single"]  # sharded level 0: same lists, bit for bit
             assert len(r0[kind + "_l0"][1]) > 0
+            # ... and with the exchange kept in device memory (fw_level0_sharded_dev)
+            assert r0[kind + "_l0_dev"] == r1[kind + "_l0_dev"] == r0[kind + "_l0_single"]
+        assert r0["mi_l0_dev_records"] > 0          # the discrete kind really exchanged its significant pairs
+        # row-block sharding of the Pearson matrix: same bits as the single-rank GEMM, same network on it
+        assert r0["fz_cor_sharded_equal"] and r1["fz_cor_sharded_equal"]
+        assert r0["fz_ff1_sharded_cor"] == r1["fz_ff1_sharded_cor"] == r0["fz_ff1_single"]
