@@ -421,6 +421,13 @@ __device__ __forceinline__ unsigned int mi_wave_add(unsigned int *p, unsigned in
     return (unsigned int)__builtin_amdgcn_readfirstlane((int)r);
 }
 
+// 64-bit v_readlane
+__device__ __forceinline__ unsigned long long mi_rfl_lane64(unsigned long long v, int src)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 // ranks [r0, r1) of the job (T, cand | subsets of acc[0..a)) in enumeration order, one test after the other (whole wavefront).
 // Called, not inlined: the kernel reaches it from four places (own jobs, own board, other boards while waiting / between
 // jobs / at the end) and four copies of the test made 168 KB of code -- against a 64 KB instruction cache.
@@ -499,6 +506,156 @@ __device__ __noinline__ FwSegOut mi_run_ranks(const MiDev M_in, int T, int cand,
         }
     }
     return o;
+}
+
+// The same enumeration, four subsets per step (mi_test_core4: one DPP row of 16 lanes per test; n <= MI4_N, max_k <= 3, 2 x 2 cells
+// per stratum): the four tests of a step are ranks r .. r + 3 of the same size; they are accounted for in rank order exactly as the
+// sequential loop would (first stop wins, `>=` maximum before it), so the tests behind a stop inside a step are the only
+// speculation (counted in `evaluated`).
+template <int L>
+__device__ __noinline__ FwSegOut mi_run_ranks4(const MiDev M_in, int T, int cand, const int32_t *__restrict__ acc_in, int a, int max_k,
+                                               long long max_tests, unsigned long long r0, unsigned long long r1,
+                                               const unsigned long long *stop_min_in, int remote_acc)
+{
+    unsigned short *tab = dh_mi_tab[threadIdx.x >> 6];
+    const MiDev M = mi_uniform(M_in);
+    T = __builtin_amdgcn_readfirstlane(T);
+    cand = __builtin_amdgcn_readfirstlane(cand);
+    a = __builtin_amdgcn_readfirstlane(a);
+    max_k = __builtin_amdgcn_readfirstlane(max_k);
+    max_tests = (long long)mi_rfl64((unsigned long long)max_tests);
+    r0 = mi_rfl64(r0);
+    r1 = mi_rfl64(r1);
+    const int32_t *acc = (const int32_t *)mi_rfl64((unsigned long long)acc_in);
+    const unsigned long long *stop_min = (const unsigned long long *)mi_rfl64((unsigned long long)stop_min_in);
+    remote_acc = __builtin_amdgcn_readfirstlane(remote_acc);
+    const int row = (threadIdx.x & 63) >> 4;
+    FwSegOut o;
+    o.stop_rank = FW_RANK_NONE;
+    o.stop_stat = o.stop_pval = 0.0;
+    o.best_rank = 0ull;
+    o.best_stat = 0.0;
+    o.best_pval = -3.0;
+    o.stop_df = o.stop_power = o.best_df = o.pad = 0;
+    o.evaluated = 0ull;
+    unsigned long long rem = r0;
+    int s = max_k;
+    while (s > 1 && rem >= fw_binom_u64(a, s)) {
+        rem -= fw_binom_u64(a, s);
+        --s;
+    }
+    int p0 = 0, p1 = 0, p2 = 0;  // positions of the running subset (s <= 3), scalar
+    {
+        int pos[MI_MAX_K];
+#pragma unroll
+        for (int q = 0; q < MI_MAX_K; ++q) pos[q] = 0;
+        fw_unrank_comb(rem, a, s, pos);
+        p0 = pos[0];
+        p1 = pos[1];
+        p2 = pos[2];
+    }
+    MiBest mb;
+    mb.p = -3.0;
+    mb.stat = mb.g = 0.0;
+    mb.df = 0;
+    unsigned long long r = r0;
+    while (r < r1 && s >= 1) {
+        if (stop_min && mi_ld_u64(stop_min) < r) break;  // an earlier rank already ended the job
+        // up to four subsets of size s: row t takes the t-th; rows beyond the step's count repeat the first (ignored)
+        int zrow[3] = {0, 0, 0};
+        int nb = 0;
+        const int s_step = s;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool have = r + (unsigned long long)t < r1 && s == s_step;  // uniform
+            if (have) {
+                ++nb;
+                const int q0 = p0, q1 = s_step >= 2 ? p1 : p0, q2 = s_step >= 3 ? p2 : p0;
+                const int v0 = remote_acc ? __hip_atomic_load(&acc[q0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : acc[q0];
+                const int v1 = remote_acc ? __hip_atomic_load(&acc[q1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : acc[q1];
+                const int v2 = remote_acc ? __hip_atomic_load(&acc[q2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : acc[q2];
+                if (row == t || t == 0) {  // t == 0 first: the default of every row
+                    zrow[0] = v0;
+                    zrow[1] = v1;
+                    zrow[2] = v2;
+                }
+                // next subset in lexicographic order of the positions, then the next size down (scalar)
+                if (s_step == 1) {
+                    if (p0 < a - 1) ++p0; else s = 0;
+                } else if (s_step == 2) {
+                    if (p1 < a - 1) {
+                        ++p1;
+                    } else if (p0 < a - 2) {
+                        ++p0;
+                        p1 = p0 + 1;
+                    } else {
+                        s = 1;
+                        p0 = 0;
+                    }
+                } else {
+                    if (p2 < a - 1) {
+                        ++p2;
+                    } else if (p1 < a - 2) {
+                        ++p1;
+                        p2 = p1 + 1;
+                    } else if (p0 < a - 3) {
+                        ++p0;
+                        p1 = p0 + 1;
+                        p2 = p0 + 2;
+                    } else {
+                        s = 2;
+                        p0 = 0;
+                        p1 = 1;
+                    }
+                }
+            }
+        }
+        MiRes mine = mi_test_core4<L>(M, T, cand, zrow, s_step, tab);
+        o.evaluated += (unsigned long long)nb;
+        bool stopped = false;
+        for (int t = 0; t < nb; ++t) {  // rank order (uniform: every lane reads row t's result)
+            MiRes tt;
+            const int src = 16 * t;
+            tt.stat = __longlong_as_double((long long)mi_rfl_lane64((unsigned long long)__double_as_longlong(mine.stat), src));
+            tt.g = __longlong_as_double((long long)mi_rfl_lane64((unsigned long long)__double_as_longlong(mine.g), src));
+            tt.pval = __longlong_as_double((long long)mi_rfl_lane64((unsigned long long)__double_as_longlong(mine.pval), src));
+            tt.df = __builtin_amdgcn_readlane(mine.df, src);
+            tt.power = __builtin_amdgcn_readlane(mine.power, src);
+            tt.n_obs = (long long)mi_rfl_lane64((unsigned long long)mine.n_obs, src);
+            const unsigned long long rr = r + (unsigned long long)t;
+            const int ev = mi_account(M, tt, max_tests > 0 && rr + 1ull >= (unsigned long long)max_tests, mb, false);  // tests.jl:326-341
+            if (ev == 1) {
+                o.stop_rank = rr;
+                o.stop_stat = tt.stat;
+                o.stop_pval = tt.pval;
+                o.stop_df = tt.df;
+                o.stop_power = tt.power;
+                stopped = true;
+                break;
+            }
+            if (ev == 2) {
+                o.best_pval = mb.p;
+                o.best_stat = mb.stat;
+                o.best_rank = rr;
+                o.best_df = mb.df;
+            }
+        }
+        if (stopped) break;
+        r += (unsigned long long)nb;
+    }
+    return o;
+}
+
+// R4: the four-subsets-per-step form (host: n <= MI4_N, max_k <= 3, 2 x 2 cells); one of the two routines per instantiation
+template <int L, int NXY, bool PRE, bool R4>
+__device__ __forceinline__ FwSegOut mi_run_ranks_sel(const MiDev &M, int T, int cand, const int32_t *__restrict__ acc, int a, int max_k,
+                                                     long long max_tests, unsigned long long r0, unsigned long long r1,
+                                                     const unsigned long long *stop_min, int remote_acc)
+{
+    if constexpr (R4)
+        return mi_run_ranks4<L>(M, T, cand, acc, a, max_k, max_tests, r0, r1, stop_min, remote_acc);
+    else
+        return mi_run_ranks<L, NXY, PRE>(M, T, cand, acc, a, max_k, max_tests, r0, r1, stop_min, remote_acc);
 }
 
 // one record = 9 64-bit words (FwSegOut), written through / read back word by word
@@ -584,7 +741,7 @@ __device__ __forceinline__ DhMerge mi_merge(const FwSegOut *__restrict__ so, lon
 
 // claim and evaluate one record of board b (if any is left); true if a record was processed.  acc_own: the caller published the board (its accepted list is at hand); otherwise the list is
 // staged from the board's write-through copy.
-template <int L, int NXY, bool PRE>
+template <int L, int NXY, bool PRE, bool R4>
 __device__ __forceinline__ bool mi_board_work(MiBoard *__restrict__ b, FwSegOut *__restrict__ res, const int32_t *__restrict__ bacc,
                                               const int32_t *acc_own, const MiDev &M, const DhParams &P, int lane)
 {
@@ -624,7 +781,7 @@ __device__ __forceinline__ bool mi_board_work(MiBoard *__restrict__ b, FwSegOut 
                 remote = 1;
             }
         }
-        o = mi_run_ranks<L, NXY, PRE>(M, (int)(unsigned int)tc, (int)(unsigned int)(tc >> 32), acc, a, P.max_k, P.max_tests, r0, r1,
+        o = mi_run_ranks_sel<L, NXY, PRE, R4>(M, (int)(unsigned int)tc, (int)(unsigned int)(tc >> 32), acc, a, P.max_k, P.max_tests, r0, r1,
                                       &b->stop_min, remote);
         if (o.stop_rank != FW_RANK_NONE && lane == 0) atomicMin(&b->stop_min, o.stop_rank);
     }
@@ -639,7 +796,7 @@ __device__ __forceinline__ bool mi_board_work(MiBoard *__restrict__ b, FwSegOut 
 // look for an open board (from the first one that still has unclaimed records) and work on one record of it; true if
 // something was done.  (A global FIFO of records with a compare-and-swap head was tried instead of the scan: 10x slower --
 // a thousand wavefronts polling and swapping the same two words.)
-template <int L, int NXY, bool PRE>
+template <int L, int NXY, bool PRE, bool R4>
 __device__ __noinline__ bool mi_help(MiQueue *__restrict__ Q, MiBoard *__restrict__ boards, FwSegOut *__restrict__ res,
                                      const int32_t *__restrict__ bacc, const MiDev &M, const DhParams &P, int lane)
 {
@@ -650,7 +807,7 @@ __device__ __noinline__ bool mi_help(MiQueue *__restrict__ Q, MiBoard *__restric
         MiBoard *b = boards + i;
         if (mi_ld_u32(&b->ready) == 0u) return false;  // reserved, not yet filled
         if (mi_ld_u32(&b->next_chunk) < (unsigned int)mi_ld_u64(&b->nr)) {
-            if (mi_board_work<L, NXY, PRE>(b, res, bacc, nullptr, M, P, lane)) return true;
+            if (mi_board_work<L, NXY, PRE, R4>(b, res, bacc, nullptr, M, P, lane)) return true;
         } else if (i == mi_ld_u32(&Q->hint) && lane == 0) {
             atomicMax(&Q->hint, i + 1u);  // every record of this board is taken: later scans start behind it
         }
@@ -661,7 +818,7 @@ __device__ __noinline__ bool mi_help(MiQueue *__restrict__ Q, MiBoard *__restric
 #ifndef DH_MI_OCC
 #define DH_MI_OCC 1  // workgroups per CU the register budget is sized for
 #endif
-template <int L, int NXY, bool PRE>
+template <int L, int NXY, bool PRE, bool R4>
 __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__restrict__ tg, int ntg, const int32_t *__restrict__ order,
                                                            DhArrays A, MiDev M, DhParams P, MiQueue *__restrict__ Q,
                                                            MiBoard *__restrict__ boards, FwSegOut *__restrict__ res,
@@ -684,7 +841,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
             // launch ended when the heaviest target did, 13 ms after the average wavefront had run out of targets)
             const bool heavy = P.mi_heavy > 0u && (unsigned int)x.nc >= P.mi_heavy;
             if (P.mi_help_jobs && !heavy)
-                while (mi_ld_u32(&Q->n_boards) > mi_ld_u32(&Q->hint) && mi_help<L, NXY, PRE>(Q, boards, res, bacc, M, P, lane)) {
+                while (mi_ld_u32(&Q->n_boards) > mi_ld_u32(&Q->hint) && mi_help<L, NXY, PRE, R4>(Q, boards, res, bacc, M, P, lane)) {
                 }
             const unsigned long long tk1 = wall_clock64();
             tk_help += tk1 - tk0;
@@ -711,7 +868,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
                               ((unsigned int)ntg - mi_ld_u32(&Q->targets_done)) * 8u <= gridDim.x * 4u;
             const unsigned long long seq = tail ? P.mi_seq_tail : (heavy ? P.mi_seq_heavy : P.mi_seq);
             unsigned long long next = elim_full ? 0ull : (N < seq ? N : seq);
-            FwSegOut o = mi_run_ranks<L, NXY, PRE>(M, x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, 0ull, next, nullptr, 0);
+            FwSegOut o = mi_run_ranks_sel<L, NXY, PRE, R4>(M, x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, 0ull, next, nullptr, 0);
             unsigned long long ev = o.evaluated, nt = 0ull;
             bool stopped = o.stop_rank != FW_RANK_NONE;
             double r_stat = stopped ? o.stop_stat : 0.0, r_p = stopped ? o.stop_pval : 0.0;
@@ -743,7 +900,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
                 }
                 DhMerge mg;
                 if (bi >= MI_BOARD_CAP) {  // out of board space (never at the benchmark sizes): the owner carries on alone
-                    const FwSegOut q = mi_run_ranks<L, NXY, PRE>(M, x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, next, next + W, nullptr, 0);
+                    const FwSegOut q = mi_run_ranks_sel<L, NXY, PRE, R4>(M, x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, next, next + W, nullptr, 0);
                     mg.stop = q.stop_rank != FW_RANK_NONE;
                     mg.stat = mg.stop ? q.stop_stat : q.best_stat;
                     mg.p = mg.stop ? q.stop_pval : (q.best_pval < 0.0 ? -2.0 : q.best_pval);
@@ -764,11 +921,11 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
                         mi_drain();  // ... and the board before the flag
                         mi_st_u32(&b->ready, 1u);
                     }
-                    while (mi_board_work<L, NXY, PRE>(b, res, bacc, A.acc + acc_off, M, P, lane)) {
+                    while (mi_board_work<L, NXY, PRE, R4>(b, res, bacc, A.acc + acc_off, M, P, lane)) {
                     }
                     unsigned int spins = 0u;
                     while (mi_ld_u32(&b->done) < nch) {  // records claimed by other wavefronts: they are running
-                        if (heavy || !mi_help<L, NXY, PRE>(Q, boards, res, bacc, M, P, lane)) {
+                        if (heavy || !mi_help<L, NXY, PRE, R4>(Q, boards, res, bacc, M, P, lane)) {
                             __builtin_amdgcn_s_sleep(2);
                             if (++spins > (1u << 27)) {  // ~30 s: a logic error, not a workload -- report instead of hanging the GPU
                                 if (lane == 0) atomicExch(&Q->pad[0], 1u);
@@ -814,7 +971,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
     const unsigned long long tk_t0 = wall_clock64();
     unsigned int spins = 0u;
     while (mi_ld_u32(&Q->targets_done) < (unsigned int)ntg && mi_ld_u32(&Q->pad[0]) == 0u) {
-        if (!mi_help<L, NXY, PRE>(Q, boards, res, bacc, M, P, lane)) {
+        if (!mi_help<L, NXY, PRE, R4>(Q, boards, res, bacc, M, P, lane)) {
             __builtin_amdgcn_s_sleep(8);
             if (++spins > (1u << 27)) {
                 if (lane == 0) atomicExch(&Q->pad[0], 2u);
@@ -1585,16 +1742,24 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         FW_HIP(c, hipMemsetAsync(d_mq, 0, sizeof(MiQueue), st));
         FW_HIP(c, hipMemsetAsync(d_boards, 0, sizeof(MiBoard) * MI_BOARD_CAP, st));  // ready flags, claimed / finished counts
         FW_HIP(c, hipEventRecord(ev[0][0], st));
-#define DH_MI_LAUNCH(LL, NN, PP)                                                                                                  \
-    hipLaunchKernelGGL((dh_mi_target_kernel<LL, NN, PP>), dim3(grid), dim3(256), 0, st, d_tg, ntg, (const int32_t *)d_act, A, M, P, \
+#define DH_MI_LAUNCH(LL, NN, PP, RR)                                                                                                  \
+    hipLaunchKernelGGL((dh_mi_target_kernel<LL, NN, PP, RR>), dim3(grid), dim3(256), 0, st, d_tg, ntg, (const int32_t *)d_act, A, M, P, \
                        d_mq, d_boards, d_mres, d_bacc)
         const bool pre = c->P.n <= MI_PRE_N && c->P.max_k <= MI_PRE_K;
+        // four subsets per wavefront step (mi_test_core4): n <= 5120, max_k <= 3, 2 x 2 cells per stratum.  FW_MI_ROW4=0: one per step
+        static const bool row4_env = [] { const char *e = getenv("FW_MI_ROW4"); return !(e && atoi(e) == 0); }();
+        // ... used up to 2048 samples (four words per lane): cfg2 (n = 500) 15.2 -> 12.5 ms.  At cfg4's n = 5000 a step of four
+        // tests takes as long as four one-test steps (34 us: ten words per lane, 390 registers with the spills parked in AGPRs),
+        // and since most jobs stop at their first test the three speculative ones are pure cost: measured 56.2 vs 56.8 ms on one
+        // GPU, 35.3 vs 39.2 ms for one rank of eight -- FW_MI_ROW4=2 forces it on up to MI4_N for such experiments
+        static const bool row4_force = [] { const char *e = getenv("FW_MI_ROW4"); return e && atoi(e) == 2; }();
+        const bool r4 = row4_env && pre && c->P.n <= (row4_force ? MI4_N : 2048) && (c->L == 2 || c->mi_nxy == 2);
         if (c->L == 2) {
-            if (pre) DH_MI_LAUNCH(2, 2, true); else DH_MI_LAUNCH(2, 2, false);
+            if (r4) DH_MI_LAUNCH(2, 2, true, true); else if (pre) DH_MI_LAUNCH(2, 2, true, false); else DH_MI_LAUNCH(2, 2, false, false);
         } else if (c->mi_nxy == 2) {
-            if (pre) DH_MI_LAUNCH(3, 2, true); else DH_MI_LAUNCH(3, 2, false);
+            if (r4) DH_MI_LAUNCH(3, 2, true, true); else if (pre) DH_MI_LAUNCH(3, 2, true, false); else DH_MI_LAUNCH(3, 2, false, false);
         } else {
-            if (pre) DH_MI_LAUNCH(3, 3, true); else DH_MI_LAUNCH(3, 3, false);
+            if (pre) DH_MI_LAUNCH(3, 3, true, false); else DH_MI_LAUNCH(3, 3, false, false);
         }
 #undef DH_MI_LAUNCH
         FW_HIP(c, hipGetLastError());

@@ -506,6 +506,283 @@ static __device__ __forceinline__ MiRes mi_test_core(const MiDev &P, const int X
     return res;
 }
 
+// ------------------------------------------------------------------------------------------------
+// FOUR tests per wavefront (r03): row r of 16 lanes (one DPP row) evaluates (X, Y | Zs_r) -- four consecutive subsets of one
+// test_subsets job, same X, Y and k.  n <= 5120 (lane i of a row owns the 32-row words i, i + 16, ..., i + 144 of every plane),
+// k <= 3, NXY = 2.  Why: at n = 5000 a lane of the one-test form holds 2.45 words per plane, and the wavefront spends more
+// instructions reducing 64 lanes (six DPP steps per packed counter, ~490 per k = 3 test) and waiting for its one memory round trip
+// than counting; here a reduction ends inside the row (four DPP steps for four tests at once), the lanes are 98 % occupied, and
+// four tests share one memory round trip -- the sequential prefix of a job (the chain that bounds the discrete stage) advances
+// four subsets per step.  Same tables, same rules, same arithmetic per test as mi_test_core (the cell counts are integers; the
+// Float64 sums over (stratum, cell) pairs run over 16 lanes instead of 64, in a different order: within the 1e-12 of
+// DESIGN.md section 2).  Every lane of a row returns that row's result.
+// ------------------------------------------------------------------------------------------------
+#define MI4_NW 10      // words per lane and plane
+#define MI4_N 5120     // samples
+#define MI4_TAB16 192  // u16 entries of one row's table: 27 strata x 6 (4 cells + total + pad), rounded up
+
+// sum over the 16 lanes of a DPP row, every lane gets it
+static __device__ __forceinline__ unsigned mi_row_sum_u(unsigned v)
+{
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false);   // quad_perm:[1,0,3,2]
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false);   // quad_perm:[2,3,0,1]
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);  // row_ror:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);  // row_ror:8
+    return v;
+}
+static __device__ __forceinline__ int mi_row_max_i(int v)
+{
+#define MI_ROW_MAX(ctrl)                                                         \
+    {                                                                            \
+        const int t = __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false);  \
+        v = t > v ? t : v;                                                       \
+    }
+    MI_ROW_MAX(0xb1)
+    MI_ROW_MAX(0x4e)
+    MI_ROW_MAX(0x124)
+    MI_ROW_MAX(0x128)
+#undef MI_ROW_MAX
+    return v;
+}
+static __device__ __forceinline__ double mi_row_sum_d(double v)
+{
+#define MI_ROW_ADDD(ctrl)                                                                                           \
+    {                                                                                                               \
+        const long long b = __double_as_longlong(v);                                                                \
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, ctrl, 0xf, 0xf, false);        \
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), ctrl, 0xf, 0xf, false); \
+        v += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));                                \
+    }
+    MI_ROW_ADDD(0xb1)
+    MI_ROW_ADDD(0x4e)
+    MI_ROW_ADDD(0x124)
+    MI_ROW_ADDD(0x128)
+#undef MI_ROW_ADDD
+    return v;
+}
+
+// zrow: the conditioning variables of THIS lane's row; k (1..3) and X, Y are wave-uniform.  tab4: MI4_TAB16 u16 per row.
+template <int L>
+static __device__ __forceinline__ MiRes mi_test_core4(const MiDev &P, const int X_in, const int Y_in, const int (&zrow)[3], const int k_in,
+                                                      unsigned short *tab4)
+{
+    constexpr int NXY = 2, NC = 4, NCT = 5, NCT16 = 6, SBMAX = L * L;
+    const int X = __builtin_amdgcn_readfirstlane(X_in), Y = __builtin_amdgcn_readfirstlane(Y_in);
+    const int k = __builtin_amdgcn_readfirstlane(k_in);
+    const int lane = threadIdx.x & 63, li = lane & 15, row = lane >> 4;
+    const bool flagX = P.nzmode && P.maxv[X] > 1, flagY = P.nzmode && P.maxv[Y] > 1;
+    const bool any_flag = flagX || flagY;
+    const bool special_k1 = (k == 1) && any_flag && !P.dense;  // contingency.jl:250-253 (sparse dispatch only)
+    int lx, ly;
+    if (P.nzmode) {  // tests.jl:200-203
+        lx = L - (flagX ? 1 : 0);
+        ly = L - (flagY ? 1 : 0);
+    } else {
+        lx = P.levels[X];
+        ly = P.levels[Y];
+    }
+    MiRes res;
+    res.stat = 0.0;
+    res.pval = 1.0;
+    res.df = 0;
+    res.power = 0;
+    res.g = 0.0;
+    res.n_obs = 0;
+    int S = 1;
+    for (int j = 0; j < k; ++j) S *= L;
+    const int SB = k >= 2 ? SBMAX : S;
+    const int nbatch = S / SB;
+    const bool tot_sep = P.dense && any_flag;
+    const bool viewX = P.dense && P.view && P.nzmode && P.levels[X] > 2, viewY = P.dense && P.view && P.nzmode && P.levels[Y] > 2;
+    const unsigned *pn = (const unsigned *)P.nz, *ph = (const unsigned *)P.hi;
+    const size_t W2 = 2 * (size_t)P.W;
+    const unsigned *xn = pn + (size_t)X * W2, *yn = pn + (size_t)Y * W2;
+    const unsigned *xh = (L == 3 && ph) ? ph + (size_t)X * W2 : nullptr, *yh = (L == 3 && ph) ? ph + (size_t)Y * W2 : nullptr;
+    const int nd = (P.n + 31) >> 5;
+    const int nw = (nd + 15) >> 4;  // words per lane (uniform)
+    // ---- X / Y part of every cell mask of this lane's words (the same for the four rows; batch independent) ----
+    unsigned cm[MI4_NW][NC], mt[MI4_NW];
+#pragma unroll
+    for (int w = 0; w < MI4_NW; ++w) {
+        const int dw = li + 16 * w;
+        const bool ok = w < nw && dw < nd;
+        const unsigned wxn = ok ? xn[dw] : 0u, wyn = ok ? yn[dw] : 0u;
+        const unsigned wxh = (ok && xh) ? xh[dw] : 0u, wyh = (ok && yh) ? yh[dw] : 0u;
+        const int left = P.n - dw * 32;
+        const unsigned vm = !ok ? 0u : (left >= 32 ? 0xffffffffu : ((1u << left) - 1u));
+        unsigned msub = vm;
+        if (flagX) msub &= wxn;
+        if (flagY) msub &= wyn;
+        unsigned mtab = msub;
+        if (P.dense) {
+            mtab = vm;
+            if (viewX) mtab &= wxn;
+            if (viewY) mtab &= wyn;
+        }
+        const unsigned xu = flagX ? wxh : wxn, yu = flagY ? wyh : wyn;
+        cm[w][0] = msub & ~xu & ~yu;
+        cm[w][1] = msub & xu & ~yu;
+        cm[w][2] = msub & ~xu & yu;
+        cm[w][3] = msub & xu & yu;
+        mt[w] = mtab;
+    }
+    const unsigned *z0n = pn + (size_t)zrow[0] * W2, *z1n = pn + (size_t)zrow[k >= 2 ? 1 : 0] * W2, *z2n = pn + (size_t)zrow[k >= 3 ? 2 : 0] * W2;
+    const unsigned *z0h = (L == 3 && ph) ? ph + (size_t)zrow[0] * W2 : nullptr;
+    const unsigned *z1h = (L == 3 && ph) ? ph + (size_t)zrow[k >= 2 ? 1 : 0] * W2 : nullptr;
+    const unsigned *z2h = (L == 3 && ph) ? ph + (size_t)zrow[k >= 3 ? 2 : 0] * W2 : nullptr;
+    unsigned short *tab = tab4 + row * MI4_TAB16;
+    unsigned *tab32 = (unsigned *)tab;
+    // every word of the conditioning columns up front, all loads in flight together: ONE memory round trip per step (loading
+    // inside the batch / word loops made a step 30 dependent round trips: 38 us, as long as four one-test steps)
+    unsigned zwn[3][MI4_NW], zwh[3][MI4_NW];
+#pragma unroll
+    for (int w = 0; w < MI4_NW; ++w) {
+        const int dw = li + 16 * w;
+        const bool ok = w < nw && dw < nd;
+        zwn[0][w] = ok ? z0n[dw] : 0u;
+        zwh[0][w] = (ok && z0h) ? z0h[dw] : 0u;
+        zwn[1][w] = (ok && k >= 2) ? z1n[dw] : 0u;
+        zwh[1][w] = (ok && k >= 2 && z1h) ? z1h[dw] : 0u;
+        zwn[2][w] = (ok && k >= 3) ? z2n[dw] : 0u;
+        zwh[2][w] = (ok && k >= 3 && z2h) ? z2h[dw] : 0u;
+    }
+    for (int b = 0; b < nbatch; ++b) {  // the digit of Z_3 is fixed inside a batch
+        unsigned acc[SBMAX][NCT];
+#pragma unroll
+        for (int s = 0; s < SBMAX; ++s)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc[s][c] = 0u;
+#pragma unroll
+        for (int w = 0; w < MI4_NW; ++w)
+            if (w < nw) {
+                const unsigned a0n = zwn[0][w], a0h = zwh[0][w];
+                const unsigned a1n = zwn[1][w], a1h = zwh[1][w];
+                unsigned hm = 0xffffffffu;
+                if (k >= 3) hm = mi_level_mask<L>(zwn[2][w], zwh[2][w], b);
+                unsigned z0[L], z1[L];
+#pragma unroll
+                for (int d = 0; d < L; ++d) {
+                    z0[d] = mi_level_mask<L>(a0n, a0h, d);
+                    z1[d] = (k >= 2) ? (mi_level_mask<L>(a1n, a1h, d) & hm) : (d == 0 ? hm : 0u);
+                }
+#pragma unroll
+                for (int s = 0; s < SBMAX; ++s)
+                    if (s < SB) {
+                        const unsigned zk = z0[s % L] & z1[s / L];
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) acc[s][c] += (unsigned)__builtin_popcount(cm[w][c] & zk);
+                        if (tot_sep) acc[s][NC] += (unsigned)__builtin_popcount(mt[w] & zk);
+                    }
+            }
+        // two 16-bit counts per register (a count never exceeds n <= 5120), four DPP adds inside the row
+#pragma unroll
+        for (int s = 0; s < SBMAX; ++s)
+            if (s < SB) {
+                const unsigned r0 = mi_row_sum_u(acc[s][0] | (acc[s][1] << 16));
+                const unsigned r1 = mi_row_sum_u(acc[s][2] | (acc[s][3] << 16));
+                const unsigned r2 = tot_sep ? mi_row_sum_u(acc[s][4]) : 0u;
+                if (li == 0) {
+                    unsigned *t = tab32 + ((b * SB + s) * NCT16) / 2;
+                    t[0] = r0;
+                    t[1] = r1;
+                    t[2] = r2;
+                }
+            }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- lanes of the row <-> strata: occupancy, n_obs ----
+    int n_nonempty = 0, zmax = -1, key0_seen = 0;
+    unsigned n_obs_u = 0u, n_counted_u = 0u;
+    for (int base = 0; base < S; base += 16) {
+        const int key = base + li;
+        if (key < S) {
+            const unsigned short *t = tab + key * NCT16;
+            int sub = 0;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) sub += (int)t[c];
+            const int tot = tot_sep ? (int)t[NC] : sub;
+            if (tot > 0) {
+                ++n_nonempty;
+                zmax = key;
+                if (key == 0) key0_seen = 1;
+            }
+            n_obs_u += (unsigned)sub;
+            n_counted_u += (unsigned)tot;
+        }
+    }
+    n_nonempty = (int)mi_row_sum_u((unsigned)n_nonempty);
+    key0_seen = (int)mi_row_sum_u((unsigned)key0_seen);  // only the lane with key 0 can have set it
+    const long long n_obs = (long long)mi_row_sum_u(n_obs_u);
+    int levels_z;
+    if (special_k1) {
+        const int zm = mi_row_max_i(zmax);
+        levels_z = zm < 0 ? 1 : zm + 1;
+    } else if (any_flag && !P.dense) {
+        const long long n_counted = (long long)mi_row_sum_u(n_counted_u);
+        levels_z = n_nonempty + ((P.n - n_counted > 0 && !key0_seen) ? 1 : 0);
+    } else {
+        levels_z = n_nonempty;
+    }
+    const bool power = ((double)n_obs / (double)((long long)lx * ly * levels_z)) > (double)P.hps;  // tests.jl:210
+    // ---- mutual information: lanes of the row <-> (stratum, cell) pairs; rows without power ride along (masked) ----
+    double pos = 0.0, neg = 0.0;
+    unsigned npos = 0u, nneg = 0u;
+    int df_part = 0;
+    const int npairs = S * NC;
+    for (int base = 0; base < npairs; base += 16) {
+        const int q = base + li;
+        if (q < npairs && power) {
+            const int key = q >> 2, c = q & 3;
+            const int i = c & 1, j = c >> 1;
+            const unsigned short *t = tab + key * NCT16;
+            long long mi_[NXY] = {0, 0}, mj_[NXY] = {0, 0}, mk = 0, mine = 0;
+#pragma unroll
+            for (int jj = 0; jj < NXY; ++jj)
+#pragma unroll
+                for (int ii = 0; ii < NXY; ++ii) {
+                    const long long v = (ii < lx && jj < ly) ? (long long)t[ii + NXY * jj] : 0;
+                    mi_[ii] += v;
+                    mj_[jj] += v;
+                    mk += v;
+                    if (ii == i && jj == j) mine = v;
+                }
+            const long long my_mi = i == 0 ? mi_[0] : mi_[1], my_mj = j == 0 ? mj_[0] : mj_[1];
+            if (mine != 0 && my_mi != 0 && my_mj != 0) {
+                const double term = log(((double)mk * (double)mine) / (double)(my_mi * my_mj)) * (double)mine;
+                if (i == j) {
+                    pos += term;
+                    npos += (unsigned)mine;
+                } else {
+                    neg += term;
+                    nneg += (unsigned)mine;
+                }
+            }
+            if (c == 0) {  // adjust_df, once per stratum
+                int alx = (mi_[0] > 0) + (mi_[1] > 0), aly = (mj_[0] > 0) + (mj_[1] > 0);
+                alx = alx < 1 ? 1 : alx;
+                aly = aly < 1 ? 1 : aly;
+                df_part += (alx - 1) * (aly - 1);
+            }
+        }
+    }
+    pos = mi_row_sum_d(pos);
+    neg = mi_row_sum_d(neg);
+    const long long np_ = (long long)mi_row_sum_u(npos), nn_ = (long long)mi_row_sum_u(nneg);
+    const int df = (int)mi_row_sum_u((unsigned)df_part);
+    if (!power) return res;
+    const double nd_ = (double)(np_ + nn_);
+    double mi = (pos + neg) / nd_;
+    if (neg * ((double)nn_ / nd_) > pos * ((double)np_ / nd_)) mi *= -1.0;
+    res.stat = mi;
+    res.pval = NAN;
+    res.df = df;
+    res.power = 1;
+    res.g = 2.0 * fabs(mi) * (double)n_obs;
+    res.n_obs = n_obs;
+    return res;
+}
+
 // p-value of a finished test (statfuns.jl:157-161); tests without power keep (0, 1)
 static __device__ __forceinline__ double mi_res_pval(MiRes &r)
 {

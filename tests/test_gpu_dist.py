@@ -19,8 +19,14 @@ def test_sharded_equals_single():
         r1 = json.load(open(out + ".1"))
         for k in ("fz_ff0", "fz_ff1", "mi_ff0", "mi_ff1"):
             assert r0[k] == r1[k]                 # every rank ends with the full network
-            assert r0[k] == r0[k + "_single"]     # and it equals the single-rank network, weights included
             assert len(r0[k]) > 0
+            if k.startswith("fz"):
+                assert r0[k] == r0[k + "_single"]     # and it equals the single-rank network, weights included
+            else:
+                # discrete: 150 targets per rank run through the host pool (one test per wavefront), the single rank's 300 through
+                # the persistent kernel (four per wavefront at n <= 2048): same edges, statistics to the summation order (1e-12)
+                assert [e[:2] for e in r0[k]] == [e[:2] for e in r0[k + "_single"]]
+                assert all(abs(a[2] - b[2]) <= 1e-12 * abs(b[2]) for a, b in zip(r0[k], r0[k + "_single"]))
         for kind in ("fz", "mi"):
             assert r0[kind + "_l0"] == r1[kind + "_l0"] == r0[kind + "_l0_single"]  # sharded level 0: same lists, bit for bit
             assert len(r0[kind + "_l0"][1]) > 0

@@ -286,9 +286,16 @@ def test_device_rounds_equal_host_driver_and_oracle(ctx, ff, R, monkeypatch):
         res[host] = (net, eng.counters())
         eng.close()
     (nh, ch), (nd, cd) = res["1"], res["0"]
-    assert nh["edges"] == nd["edges"]
-    for key in ("pc_off", "pc_idx", "pc_weight", "pc_pval"):
-        assert np.array_equal(nh[key], nd[key], equal_nan=True), key
+    # same edges, directed lists and counts; statistics to 1e-12: the host pool runs one test per wavefront (Float64 sums over 64
+    # lanes), the persistent kernel four per wavefront (mi_test_core4: sums over the 16 lanes of a row) -- a different summation
+    # order of the same terms (discrete MI rel <= 1e-12)
+    assert set(nh["edges"]) == set(nd["edges"])
+    for e, w in nh["edges"].items():
+        assert _close(nd["edges"][e], w, 1e-12), e
+    for key in ("pc_off", "pc_idx"):
+        assert np.array_equal(nh[key], nd[key]), key
+    assert np.allclose(nh["pc_weight"], nd["pc_weight"], rtol=1e-12, atol=1e-15, equal_nan=True)
+    assert np.allclose(nh["pc_pval"], nd["pc_pval"], rtol=1e-10, atol=0.0, equal_nan=True)
     assert ch["cond_tests_ref"] == cd["cond_tests_ref"] and ch["subsets_calls"] == cd["subsets_calls"]
     exp = orc.learn(max_k=3, feed_forward=ff, round_size=max(R, 1) if ff else 1)
     assert set(nd["edges"]) == set(exp["edges"])
