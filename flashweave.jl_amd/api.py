@@ -12,7 +12,8 @@ class FWResult(dict):
     """Edge list + bookkeeping (the reference's FWResult, src/types.jl:172-200, reduced to plain data)."""
 
     def save(self, path):
-        fio.write_edgelist(path, self["edges"], self["variable_ids"], self["meta_variable_mask"])
+        """save_network (src/io.jl:300-336): .edgelist or .gml by extension."""
+        fio.save_network(path, self["edges"], self["variable_ids"], self["meta_variable_mask"])
 
 
 def default_round_size(p):

@@ -639,7 +639,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     __shared__ double s_l1a;                            // rho(X,Y|z1)
     __shared__ int s_l1af, s_l1nan;
     // level-3 position tables (L1T chunks, see "level-3 position tables" below)
-    __shared__ float s3_p2[L1T ? FZ_L3_CAP : 1];
+    __shared__ float s3_p2[L1T ? FZ_L3_CAP : 1], s3_r2[L1T ? FZ_L3_CAP : 1];  // rho(w,z2|z1) and sqrt(1 - .^2) in Float32
     __shared__ unsigned char s3_fl[L1T ? FZ_L3_CAP : 1];
     __shared__ double s3_d2c[L1T ? FZ_L3_CAP : 1], s3_q3[L1T ? FZ_L3_CAP : 1], s3_sq3[L1T ? FZ_L3_CAP : 1], s3_x3[L1T ? FZ_L3_CAP : 1],
         s3_sx3[L1T ? FZ_L3_CAP : 1], s3_y3[L1T ? FZ_L3_CAP : 1], s3_sy3[L1T ? FZ_L3_CAP : 1], s3_a4[L1T ? FZ_L3_CAP : 1];
@@ -648,7 +648,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     __shared__ unsigned char s3_bfl[L1T ? FZ_L3_DIR : 1];
     __shared__ double s3_bd2c[L1T ? FZ_L3_DIR : 1], s3_bx2[L1T ? FZ_L3_DIR : 1], s3_bsx2[L1T ? FZ_L3_DIR : 1], s3_by2[L1T ? FZ_L3_DIR : 1],
         s3_bsy2[L1T ? FZ_L3_DIR : 1], s3_ba3[L1T ? FZ_L3_DIR : 1];
-    __shared__ int s3_n, s3_lin0, s3_okf;
+    __shared__ int s3_n, s3_lin0, s3_okf, s3_dirty;  // s3_dirty: a NaN or a Float64-literal level-1 value somewhere in the chunk's tables
     __shared__ unsigned long long s3_end;
     __shared__ double s_hk[HK ? FZ_HK_CAP : 1];
     __shared__ int s_hk_off[HK ? FZ_HK_DIR + 1 : 2];
@@ -832,7 +832,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 Rc = (int)((clen + 255ull) / 256ull);
             }
         }
-        bool l1_ok = false, l1_clean = false, l3_ok = false;
+        bool l1_ok = false, l1_clean = false, l3_ok = false, l3_nn = false;
         int l1_s = 0, l3_lin0 = 0, l3_i = 0;
         if (L1T && in_lds && a <= FZ_L1_A && !(fz_dbg_flags & 1)) {
             unsigned long long rem0 = cbase;
@@ -917,6 +917,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                         s3_off[nd] = eoff;
                         s3_n = nd;
                         s3_okf = okf;
+                        s3_dirty = 0;
                         s3_end = cbase + (lim - rem0);
                     }
                     __syncthreads();
@@ -950,7 +951,9 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                             s3_bsx2[d] = sx;
                             s3_by2[d] = Y2;
                             s3_bsy2[d] = sy;
-                            s3_ba3[d] = pc_l3s(A2, X2, Y2, sx, sy);            // rho(X,Y|z1,z2,z3)
+                            const double A3 = pc_l3s(A2, X2, Y2, sx, sy);      // rho(X,Y|z1,z2,z3)
+                            s3_ba3[d] = A3;
+                            if (!(P2z3.f32 && X2 == X2 && Y2 == Y2 && A3 == A3)) s3_dirty = 1;
                         }
                         __syncthreads();
                         for (int e = tid; e < etot; e += 256) {
@@ -975,7 +978,9 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                             const double X3 = pc_l3s(X2w, s3_bx2[d], Q3, s3_bsx2[d], sq);  // rho(X,w|z1,z2,z3)
                             const double Y3 = pc_l3s(Y2w, s3_by2[d], Q3, s3_bsy2[d], sq);
                             const double sx = fz_sq1(X3), sy = fz_sq1(Y3);
-                            s3_p2[e] = (float)P2w.v;
+                            const float p2f = (float)P2w.v;
+                            s3_p2[e] = p2f;
+                            s3_r2[e] = sqrtf(1.0f - p2f * p2f);  // the d1 of a level-2 formula whose first conditioning value is this one
                             s3_fl[e] = P2w.f32 ? 1 : 0;
                             s3_d2c[e] = dw;
                             s3_q3[e] = Q3;
@@ -984,9 +989,12 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                             s3_sx3[e] = sx;
                             s3_y3[e] = Y3;
                             s3_sy3[e] = sy;
-                            s3_a4[e] = pc_l3s(s3_ba3[d], X3, Y3, sx, sy);  // rho(X,Y|z1,z2,z3,w): the size-4 statistic
+                            const double A4 = pc_l3s(s3_ba3[d], X3, Y3, sx, sy);  // rho(X,Y|z1,z2,z3,w): the size-4 statistic
+                            s3_a4[e] = A4;
+                            if (!(P2w.f32 && Q3 == Q3 && X3 == X3 && Y3 == Y3 && A4 == A4)) s3_dirty = 1;
                         }
                         __syncthreads();
+                        l3_nn = s3_dirty == 0 && l1_clean;
                     }
                 }
             }
@@ -1213,14 +1221,27 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                         const int pm = pos[4], em = l3_base + pm;
                         const float4 t1m = s_l1[pm];
                         const float c45 = CORV(s_acc[pm], zl);
-                        const TV R1 = pc_l1_r(c45, t1m.z, t1l.z, t1m.w, t1l.w);              // rho(v,z4|z1)
-                        const TV Bm{(double)s3_p2[em], s3_fl[em] != 0}, Cl{(double)p2l, fl3};
-                        const double R2 = pc_l2_d2(R1, Bm, Cl, d2cl);                          // rho(v,z4|z1,z2): v is the first of the pair
-                        const double R3 = pc_l3s(R2, s3_q3[em], q3l, s3_sq3[em], sq3l);        // rho(v,z4|z1,z2,z3)
-                        const double s45 = fz_sq1(R3);
-                        const double X4 = pc_l3s(s3_x3[em], x3l, R3, sx3l, s45);               // rho(X,v|z1..z4)
-                        const double Y4 = pc_l3s(s3_y3[em], y3l, R3, sy3l, s45);               // rho(Y,v|z1..z4)
-                        stat = pc_l3s(a4l, X4, Y4, fz_sq1(X4), fz_sq1(Y4));                    // rho(X,Y|z1..z4,v)
+                        bool f1ok;
+                        const float R1f = pc_l1_rf(c45, t1m.z, t1l.z, t1m.w, t1l.w, f1ok);     // rho(v,z4|z1)
+                        if (__all(l3_nn && f1ok)) {
+                            // wave-uniform fast path: no NaN and no Float64 literal among the inputs -- the NaN-preserving selects of
+                            // the clamps / round5 become v_max + v_min and plain arithmetic: the same values for these inputs
+                            const double R2 = pc_l2_all32_d1_nn(R1f, s3_p2[em], p2l, (double)s3_r2[em], d2cl);  // rho(v,z4|z1,z2)
+                            const double R3 = pc_l3s_nn(R2, s3_q3[em], q3l, s3_sq3[em], sq3l);                  // rho(v,z4|z1,z2,z3)
+                            const double s45 = fz_sq1(R3);
+                            const double X4 = pc_l3s_nn(s3_x3[em], x3l, R3, sx3l, s45);                         // rho(X,v|z1..z4)
+                            const double Y4 = pc_l3s_nn(s3_y3[em], y3l, R3, sy3l, s45);                         // rho(Y,v|z1..z4)
+                            stat = pc_l3s_nn(a4l, X4, Y4, fz_sq1(X4), fz_sq1(Y4));                              // rho(X,Y|z1..z4,v)
+                        } else {
+                            const TV R1 = pc_l1_r(c45, t1m.z, t1l.z, t1m.w, t1l.w);
+                            const TV Bm{(double)s3_p2[em], s3_fl[em] != 0}, Cl{(double)p2l, fl3};
+                            const double R2 = pc_l2_d2(R1, Bm, Cl, d2cl);                      // v is the first of the pair
+                            const double R3 = pc_l3s(R2, s3_q3[em], q3l, s3_sq3[em], sq3l);
+                            const double s45 = fz_sq1(R3);
+                            const double X4 = pc_l3s(s3_x3[em], x3l, R3, sx3l, s45);
+                            const double Y4 = pc_l3s(s3_y3[em], y3l, R3, sy3l, s45);
+                            stat = pc_l3s(a4l, X4, Y4, fz_sq1(X4), fz_sq1(Y4));
+                        }
                     }
                 } else if (L1T && l1_ok && s == l1_s) {
                     stat = s == 5 ? fz_l1t_stat<5>(cor, p, s_l1, s_l1f, s_acc, pos, s_l1a, s_l1af != 0, l1_clean)
