@@ -21,7 +21,7 @@ def test_header_symbols_exported(lib):
     hdr = open(os.path.join(ROOT, "include", "flashweave_amd.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     names = set(re.findall(r"\b(fw_[a-z0-9_]+)\s*\(", hdr))
-    names -= {"fw_allgather_fn"}
+    names -= {"fw_allgather_fn", "fw_dev_exchange"}
     assert len(names) >= 20
     raw = ctypes.CDLL(fw.lib_path())
     missing = [n for n in sorted(names) if not hasattr(raw, n)]
@@ -30,7 +30,7 @@ def test_header_symbols_exported(lib):
 
 def test_abi_version_and_defaults(lib):
     from flashweave_jl_amd.engine import _Params
-    assert lib.fw_abi_version() == 2
+    assert lib.fw_abi_version() == 3  # 3: fw_dev_exchange, fw_level0_sharded_dev, fw_use_cor_buffer / fw_compute_cor_mat_rows / fw_cor_mat_ready
     P = _Params()
     lib.fw_params_default(ctypes.byref(P), fw.FW_FZ, 100, 10)
     # learn_network defaults, reference src/learning.jl:466-473
