@@ -280,6 +280,8 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                         din[i].wl_n = tg[i].wl_n;
                     }
                     std::vector<FwDhResult> dres;
+                    std::vector<int> chain_of;
+                    std::vector<size_t> chain_idx;
                     std::vector<std::vector<FwDhResult>> pres;
                     std::vector<FwDhFlat> pflat;
                     const double tdev0 = now_s();
@@ -302,10 +304,34 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                     pres.resize((size_t)K);
                     pflat.resize((size_t)K);
                     if (K == 1) {
+                        chain_of.assign(din.size(), 0);
+                        chain_idx.resize(din.size());
+                        std::iota(chain_idx.begin(), chain_idx.end(), (size_t)0);
                         rc = fwi_devhiton_run(c, din, pres[0], pflat[0]);
                     } else {
                         std::vector<std::vector<FwDhTarget>> part((size_t)K);
-                        for (size_t i = 0; i < din.size(); ++i) part[i % (size_t)K].push_back(std::move(din[i]));
+                        // which chain target i goes to (and its index there).  Default: dealt in schedule order.  Few targets (the
+                        // latency-bound regime: a rank of a multi-GPU job, the last feed-forward round): the heaviest FW_DH_HEAVY_FRAC of
+                        // them get chain 0 to themselves -- its launches stay small, so the rounds of the longest chains are short
+                        static const int heavy_pct = [] { const char *e = getenv("FW_DH_HEAVY_PCT"); return e ? atoi(e) : 0; }();
+                        static const size_t heavy_below = [] { const char *e = getenv("FW_DH_HEAVY_BELOW"); return e ? (size_t)atol(e) : (size_t)512; }();
+                        chain_of.assign(din.size(), 0);
+                        chain_idx.assign(din.size(), 0);
+                        {
+                            std::vector<size_t> cnt((size_t)K, 0);
+                            const bool split = K >= 2 && heavy_pct > 0 && din.size() <= heavy_below;
+                            const size_t n_heavy = split ? std::max<size_t>(1, din.size() * (size_t)heavy_pct / 100) : 0;
+                            for (size_t i = 0; i < din.size(); ++i) {
+                                int q;
+                                if (split)  // schedule order = ascending degree: the last n_heavy targets are the heaviest
+                                    q = i >= din.size() - n_heavy ? 0 : 1 + (int)(i % (size_t)(K - 1));
+                                else
+                                    q = (int)(i % (size_t)K);
+                                chain_of[i] = q;
+                                chain_idx[i] = cnt[(size_t)q]++;
+                            }
+                        }
+                        for (size_t i = 0; i < din.size(); ++i) part[(size_t)chain_of[i]].push_back(std::move(din[i]));
                         std::vector<int> rcs((size_t)K, FW_OK);
                         std::vector<std::thread> th;
                         for (int q = 1; q < K; ++q)
@@ -323,15 +349,15 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                     // this round's directed results straight from the chains' flat arrays (target i went to chain i % K)
                     {
                         size_t nres = 0;
-                        for (size_t i = 0; i < tg.size(); ++i) nres += (size_t)pres[i % (size_t)K][i / (size_t)K].n;
+                        for (size_t i = 0; i < tg.size(); ++i) nres += (size_t)pres[(size_t)chain_of[i]][chain_idx[i]].n;
                         dev_lt.reserve(nres);
                         dev_ln.reserve(nres);
                         dev_ls.reserve(nres);
                         dev_lp.reserve(nres);
                     }
                     for (size_t i = 0; i < tg.size(); ++i) {
-                        const FwDhResult &r = pres[i % (size_t)K][i / (size_t)K];
-                        const FwDhFlat &f = pflat[i % (size_t)K];
+                        const FwDhResult &r = pres[(size_t)chain_of[i]][chain_idx[i]];
+                        const FwDhFlat &f = pflat[(size_t)chain_of[i]];
                         for (int32_t j = 0; j < r.n; ++j) {
                             dev_lt.push_back(tg[i].T);
                             dev_ln.push_back(f.key[(size_t)r.off + j]);
