@@ -1077,7 +1077,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
             int pos[FW_MAX_K];
 #pragma unroll
             for (int q = 0; q < FW_MAX_K; ++q) pos[q] = 0;
-            if (TAB)  // |accepted| <= FZ_TAB_A with max_k <= 3, or <= FZ_HK_A with max_k <= 5: the 32-bit unranking (fw_unrank.h)
+            if (TAB || (L1T && a <= FW_UNRANK32_A5))  // |accepted| <= FZ_TAB_A with max_k <= 3, or <= 128 with max_k <= 5: the 32-bit unranking (fw_unrank.h)
                 fw_unrank_comb32((uint32_t)rem, a, s, pos);
             else
                 unrank_comb(rem, a, s, pos);

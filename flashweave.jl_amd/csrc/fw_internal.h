@@ -57,7 +57,9 @@ struct FwSeg {
 
 #define FW_RANK_NONE (~0ull)
 #define FW_TAB_A 512  // fz / fz_nz: largest |accepted| served by the LDS-table kernel (csrc/fw_fz.hip, FZ_TAB_CAP)
+#ifndef FW_HK_A
 #define FW_HK_A 88    // fz, max_k 4-5: largest |accepted| served by the level-2 table kernel (one (z1, z2) table <= FZ_HK_CAP)
+#endif
 
 // Per-job record of the HE-S (fz_nz) path: the correlation sub-matrix of a job is computed over the rows where both
 // T and the candidate are non-zero (statfuns.jl:138-155 cor_subset!), lives in a device arena and is indexed locally
