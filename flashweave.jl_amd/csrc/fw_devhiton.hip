@@ -381,6 +381,7 @@ __device__ __forceinline__ bool dh_commit(DhTgt &x, const DhArrays &A, int lane,
 __shared__ unsigned short dh_mi_tab[4][MI_TAB16];
 
 __shared__ int32_t dh_mi_acc[4][1024];  // a helper's copy of the accepted list of the board it works on (MI_ACC_LDS)
+__shared__ DhTgt dh_mi_x[4];            // the state of the target each wavefront of dh_mi_target_kernel is working on
 
 // Everything two wavefronts share travels as write-through messages: the producer stores with sc1 (relaxed agent-scope atomic
 // stores: the line leaves its XCD's L2), drains them with `s_waitcnt vmcnt(0)` (inline asm: the compiler drops the builtin
@@ -833,7 +834,12 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
         const unsigned int slot = mi_wave_add(&Q->next_target, 1u, lane);
         if (slot >= (unsigned int)ntg) break;
         const int t = order[slot];
-        DhTgt x = tg[t];
+        // the target's state lives in LDS while its jobs run: every lane holds the same copy, and ~50 registers of it live across
+        // the out-of-line test routine were part of what kept this kernel at one wavefront per SIMD
+        DhTgt &x = dh_mi_x[threadIdx.x >> 6];
+        if (lane == 0) x = tg[t];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         while (dh_advance(x, A, lane, 1)) {
             // other targets' big enumerations first: they are the critical path of the pass
             const unsigned long long tk0 = wall_clock64();
