@@ -47,6 +47,22 @@ def run_callback_only(rank, world):
         ok &= sum(1 for i in range(n_total.value) if np.isnan(ps[i])) == sum(1 for r in range(world) if [3, 0, 5][(r + rnd) % 3])
     # one collective per round once the capacity has grown (rounds 0..2 may repeat once)
     ok &= stats["calls"] == 6 and 6 <= stats["collectives"] <= 8
+    # a NEGATIVE target (the marker record fw_level0_sharded sends: target -1, neighbour = rank, statistic = reliable-test count) must
+    # come back as -1 with its neighbour half intact (r02 packed t | u << 32 without masking: the sign extension wiped the rank)
+    t = np.array([-1, 5], dtype=np.int32)
+    u = np.array([rank, 123456], dtype=np.int32)
+    s = np.array([1e9 + rank, -0.5], dtype=np.float64)
+    p = np.array([0.0, 1e-310], dtype=np.float64)  # a subnormal p-value travels as its bits
+    n_total = C.c_int64(0)
+    pt, pn = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+    ps, pp = C.POINTER(C.c_double)(), C.POINTER(C.c_double)()
+    rc = cb(None, 2, t.ctypes.data_as(C.POINTER(C.c_int32)), u.ctypes.data_as(C.POINTER(C.c_int32)),
+            s.ctypes.data_as(C.POINTER(C.c_double)), p.ctypes.data_as(C.POINTER(C.c_double)), C.byref(n_total),
+            C.byref(pt), C.byref(pn), C.byref(ps), C.byref(pp))
+    ok &= rc == 0 and n_total.value == 2 * world
+    for r in range(world):
+        ok &= pt[2 * r] == -1 and pn[2 * r] == r and ps[2 * r] == 1e9 + r
+        ok &= pt[2 * r + 1] == 5 and pn[2 * r + 1] == 123456 and pp[2 * r + 1] == 1e-310
     dist.barrier()
     dist.destroy_process_group()
     return ok
