@@ -100,3 +100,29 @@ def test_test_subsets_and_network_stream(ctx):
     for e_, w in exp["edges"].items():
         assert abs(net["edges"][e_] - w) < 1e-11
     assert eng.counters()["cond_tests_ref"] == exp["n_cond_tests"]
+
+
+def test_test_subsets_streams_without_a_correlation_matrix():
+    # recursive_pcor = 0 needs the DATA only: fw_test_subsets_batch must not ask for a resident Pearson matrix (r02 gated both
+    # entry points on it).  Also the generic form of the kernel: n = 346 is not a multiple of 4, so X and Y are streamed too
+    # (no 16-byte rows, nothing held in registers).
+    raw = np.loadtxt(GOLDEN + "/HMP_SRA_gut_small.tsv", delimiter="\t", skiprows=1, usecols=range(1, 51))
+    clr, _, _ = pre.normalize(raw, "fz", prec=32)
+    data = np.asfortranarray(clr)
+    n, p = data.shape
+    assert n % 4 != 0
+    eng = fw.Engine("fz", n, p, max_k=3, recursive_pcor=False)
+    eng.set_data(data)                      # no cor(), no set_cor_mat()
+    orc = O.Oracle("fz", cor_mat=O.cor(data.astype(np.float64), "f32"), n_obs=n)
+    orc.set_fz_data(data.astype(np.float64))
+    rng = np.random.default_rng(11)
+    T, C, A = [], [], []
+    for _ in range(60):
+        v = rng.choice(p, size=int(rng.integers(3, 12)), replace=False)
+        T.append(int(v[0])); C.append(int(v[1])); A.append([int(t) for t in v[2:]])
+    got = eng.test_subsets_batch(T, C, A)
+    for t, c, a, g in zip(T, C, A, got):
+        e = orc.test_subsets(t, c, a, max_k=3, alpha=0.01, n_obs_min=20)
+        assert g["status"] == e["status"] and g["num_tests"] == e["num_tests"] and g["Zs"] == e["Zs"], (t, c, a, g, e)
+        assert abs(g["stat"] - e["stat"]) < 1e-11
+    eng.close()
