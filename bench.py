@@ -468,14 +468,20 @@ def main():
     # a lower bound of that pass and comparable with the headline step.
     one_m = None
     if world == 1 and not simulating and not args.no_one_chain and not args.stream_columns and cfg["test_name"] in ("fz", "fz_nz"):
-        os.environ["FW_DH_CHAINS"] = "1"
+        knobs_were = os.environ.get("FW_KNOBS")
+        os.environ["FW_KNOBS"], os.environ["FW_DH_CHAINS"] = "1", "1"  # (the library reads FW_* knobs only under FW_KNOBS=1)
         one_m = measure(ff, R if ff else 0, max(1, min(args.steps, 3)), 1)
         del os.environ["FW_DH_CHAINS"]
+        if knobs_were is None:
+            del os.environ["FW_KNOBS"]
     seam_m = None
     if args.host_seam and world == 1:
-        os.environ["FW_HOST_HITON"] = "1"
+        knobs_were = os.environ.get("FW_KNOBS")
+        os.environ["FW_KNOBS"], os.environ["FW_HOST_HITON"] = "1", "1"
         seam_m = measure(0, 0, 1, 0)
         del os.environ["FW_HOST_HITON"]
+        if knobs_were is None:
+            del os.environ["FW_KNOBS"]
 
     out = None
     if rank == 0:

@@ -412,7 +412,7 @@ static int fw_level0_impl(fw_ctx *c, int64_t *nnz_out, int rank, int world, fw_a
     int64_t m = 0;
     // BH + neighbour lists run on the device (fw_bh.hip); FW_HOST_BH=1 keeps the host restatement below, which
     // tests/test_gpu_*.py use to cross-check the two
-    const char *hb_env = getenv("FW_HOST_BH");
+    const char *hb_env = fw_knob("FW_HOST_BH");
     const bool host_bh = hb_env && atoi(hb_env) == 1;
     FwL0Dev dev;
     FwL0Dev *devp = host_bh ? nullptr : &dev;
@@ -736,7 +736,7 @@ static void unrank_host(uint64_t r, int a, int max_k, int *s_out, int *pos)
 static uint64_t fw_window_growth(size_t n_live, uint64_t launched_ranks)
 {
     static const long forced = [] {
-        const char *e = getenv("FW_WINDOW_GROWTH");
+        const char *e = fw_knob("FW_WINDOW_GROWTH");
         long v = e ? atol(e) : 0;
         return (v >= 2 && v <= 64) ? v : 0l;
     }();
@@ -746,7 +746,7 @@ static uint64_t fw_window_growth(size_t n_live, uint64_t launched_ranks)
     // a launch that does not even fill the GPU (a few thousand workgroups of 256 ranks) costs the same whether its
     // windows are 16 or 256 times larger: grow faster there, the extra speculative tests are free
     static const uint64_t small = [] {
-        const char *e = getenv("FW_SMALL_LAUNCH");
+        const char *e = fw_knob("FW_SMALL_LAUNCH");
         return e ? (uint64_t)atoll(e) : (uint64_t)(1u << 22);  // cfg3 sweep: 0 -> 630 ms, 1M 613, 4M 569, 8M 588, 64M 582
     }();
     if (launched_ranks < small) return 256;
@@ -786,7 +786,7 @@ int fwi_pool_add(fw_ctx *c, FwPool &pool, int32_t X, int32_t Y, const int32_t *a
     // first window: fz 256 ranks (one test per lane of one workgroup), 16384 once |accepted| >= 64 -- a job that large
     // either stops within the first few tests or runs for tens of thousands, so small first windows are wasted round
     // trips (cfg3: 1731 -> 1154 launches per pass, +4 % evaluated tests, 0.527 -> 0.50 s); discrete: 16
-    static const uint64_t w0_big = [] { const char *e = getenv("FW_W0_BIG"); return e ? (uint64_t)atoll(e) : (uint64_t)16384; }();
+    static const uint64_t w0_big = [] { const char *e = fw_knob("FW_W0_BIG"); return e ? (uint64_t)atoll(e) : (uint64_t)16384; }();
     j.width = (c->P.kind == FW_FZ || c->P.kind == FW_FZ_NZ) ? (a >= 64 ? w0_big : 256ull) : 16ull;
     j.best_p = -1.0;
     j.best_stat = 0.0;
@@ -856,7 +856,7 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
     // fz: one lane per test (256-rank granularity); discrete: one wavefront per test (4-rank granularity)
     const uint64_t q = fz ? 256 : 4, smin = fz ? 256 : 8, smax = fz ? 8192 : 256;
     static const uint64_t seg_target = [] {
-        const char *e = getenv("FW_SEG_TARGET");  // workgroups per launch the segment length aims for
+        const char *e = fw_knob("FW_SEG_TARGET");  // workgroups per launch the segment length aims for
         return e && atoll(e) > 0 ? (uint64_t)atoll(e) : (uint64_t)0;
     }();
     const uint64_t seg_tgt = seg_target ? seg_target : (fz ? 3072 : 4096);  // fz: runs of up to 32 ranks per lane
@@ -888,7 +888,7 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
     if ((rc = fw_dev_reserve(c, pb.d_in, ns * sizeof(FwSeg)))) return rc;
     // results: one 64-byte record per workgroup, written straight into pinned host memory (posted PCIe writes) -- saves
     // the device-to-host copy of every round; FW_ZC_OUT=0 stages them through device memory instead (profiling knob)
-    static const bool zc_out = !(getenv("FW_ZC_OUT") && atoi(getenv("FW_ZC_OUT")) == 0);
+    static const bool zc_out = !(fw_knob("FW_ZC_OUT") && atoi(fw_knob("FW_ZC_OUT")) == 0);
     if (!zc_out && (rc = fw_dev_reserve(c, pb.d_out, ns * sizeof(FwSegOut)))) return rc;
     FwSegOut *dout = zc_out ? (FwSegOut *)pb.h_out.ptr : (FwSegOut *)pb.d_out.ptr;
     FwSeg *segs = (FwSeg *)pb.h_in.ptr;
@@ -899,8 +899,8 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
     size_t si = 0, ns_tab = 0;
     size_t staged = 0;
     // fz / fz_nz with max_k <= 3: segments of jobs with at most FW_TAB_A accepted variables come first (table kernel)
-    static const bool no_tab = getenv("FW_NO_TAB") != nullptr;  // profiling knob: force the in-lane caching kernel
-    const bool no_hk = getenv("FW_NO_HK") != nullptr;  // profiling / test knob: generic size-4/5 kernel for every job
+    static const bool no_tab = fw_knob("FW_NO_TAB") != nullptr;  // profiling knob: force the in-lane caching kernel
+    const bool no_hk = fw_knob("FW_NO_HK") != nullptr;  // profiling / test knob: generic size-4/5 kernel for every job
     const bool hk = c->P.max_k > 3;  // max_k 4-5: level-2 table kernel up to FW_HK_A accepted variables (plain fz only)
     const bool split = fz && !no_tab && (!hk || (c->P.kind == FW_FZ && !stream && !no_hk));
     const size_t tab_a = hk ? (size_t)FW_HK_A : (size_t)FW_TAB_A;
@@ -995,7 +995,7 @@ int fwi_pool_collect(fw_ctx *c, FwPool &pool, std::vector<FwPoolJob> &finished)
     c->cnt.t_dev_subsets_s += 1e-3 * (double)ms;
     {  // FW_TRACE_ROUNDS=<file>: one line per pool round (profiling aid; see profiles/README.md)
         static FILE *tf = [] {
-            const char *e = getenv("FW_TRACE_ROUNDS");
+            const char *e = fw_knob("FW_TRACE_ROUNDS");
             return e ? fopen(e, "w") : (FILE *)nullptr;
         }();
         static double t_prev = 0.0;
@@ -1059,7 +1059,7 @@ int fwi_pool_collect(fw_ctx *c, FwPool &pool, std::vector<FwPoolJob> &finished)
             finish_job(c, j, pool.want_zs);
             {  // FW_TRACE_JOBS=<file>: |accepted|, evaluated tests, reference-order tests, status per finished job
                 static FILE *jf = [] {
-                    const char *e = getenv("FW_TRACE_JOBS");
+                    const char *e = fw_knob("FW_TRACE_JOBS");
                     return e ? fopen(e, "w") : (FILE *)nullptr;
                 }();
                 if (jf) fprintf(jf, "%zu %lld %lld %d\n", j.acc.size(), (long long)j.out.evaluated, (long long)j.out.num_tests, j.out.status);

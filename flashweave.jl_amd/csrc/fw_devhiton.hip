@@ -1463,7 +1463,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     const int ntg = (int)in.size();
     out.assign((size_t)ntg, FwDhResult{});
     if (ntg == 0) return FW_OK;
-    static const bool trace_host = getenv("FW_TRACE_HOST") != nullptr;  // host-side phase times on stderr
+    static const bool trace_host = fw_knob("FW_TRACE_HOST") != nullptr;  // host-side phase times on stderr
     auto wall = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double th0 = wall();
     // chain > 0: a second (third, ...) instance running concurrently from its own host thread on its own stream / arena
@@ -1503,18 +1503,18 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     const bool nb_on_dev = c->d_nb_idx != nullptr;
     const size_t nnz = (size_t)c->nb_off[p];
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    static const unsigned seg_target_env = [] { const char *e = getenv("FW_SEG_TARGET"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 0u; }();
+    static const unsigned seg_target_env = [] { const char *e = fw_knob("FW_SEG_TARGET"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 0u; }();
     const unsigned seg_target = seg_target_env ? seg_target_env : (c->P.kind == FW_FZ ? 3072u : 4096u);  // cfg3 sweep: 3072
     // elimination-phase look-ahead (fz, FW_ELIM_FULL windows; see dh_step_kernel): FW_DH_SPEC = members tested ahead per
     // target, FW_DH_SPEC_BELOW = only while the last launch held fewer ranks than this.  cfg3 sweep (ms per pass, one
     // GPU / one rank of 8): off 326.7 / 112.0; depth 4 always 338 / 103; depth 4 below 4M 318.5 / 104.4, below 8M
     // 317.3 / 104.6, below 12M 314.8 / 103.6, below 16M 341 -- a launch that already fills the GPU only pays for the
     // jobs wasted behind every dropped member (3.7 % of the members at cfg3)
-    static const int spec_env = [] { const char *e = getenv("FW_DH_SPEC"); return e ? atoi(e) : 4; }();
+    static const int spec_env = [] { const char *e = fw_knob("FW_DH_SPEC"); return e ? atoi(e) : 4; }();
     // discrete kinds: persistent wavefronts + boards (dh_mi_target_kernel); FW_MI_ROUNDS=1 keeps the level-synchronous rounds over
     // the segment kernels (the path of the ABI's fw_test_subsets_batch) for comparison.  Fisher-z always runs as rounds (a
     // persistent-workgroup variant was built in r02, lost 140 vs 58 ms on the heavy rounds, and was removed in r03).
-    static const bool mi_rounds = [] { const char *e = getenv("FW_MI_ROUNDS"); return e && atoi(e) != 0; }();
+    static const bool mi_rounds = [] { const char *e = fw_knob("FW_MI_ROUNDS"); return e && atoi(e) != 0; }();
     const bool per_target = c->P.kind != FW_FZ && !mi_rounds;
     const int spec_depth = c->P.kind == FW_FZ ? std::min(std::max(spec_env, 0), DH_MAX_SPEC) : 0;
     const int d1 = spec_depth + 1;
@@ -1522,23 +1522,23 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     // only while the last launch held fewer than FW_DH_SPEC0_BELOW ranks and fewer than FW_DH_SPEC0_JOBS jobs -- it
     // pays where the rounds are latency-bound, i.e. on a rank of a multi-GPU job (one rank of 8: 103.6 -> 95.2 ms,
     // one of 2: 208 -> 204.7 ms) and in the tail of a single-GPU pass (315.8 -> 314.2 ms)
-    static const int spec0_env = [] { const char *e = getenv("FW_DH_SPEC0"); return e ? atoi(e) : 2; }();
+    static const int spec0_env = [] { const char *e = fw_knob("FW_DH_SPEC0"); return e ? atoi(e) : 2; }();
     const int spec0_depth = c->P.kind == FW_FZ ? std::min(std::max(spec0_env, 0), DH_MAX_SPEC) : 0;
     // segments per launch by launch size (fz): below FW_SEG_A ranks a third of seg_target, below FW_SEG_B two thirds.
     // cfg3, ms per pass on one GPU / one rank of 2 / of 8: fixed 3 072: 298.8 / 200.3 / 94.9; A, B = 4M, 8M: 295.8 /
     // 194.4 / 82.3; 6M, 10M: 295.8 / 192.8 / 80.3; 8M, 12M: 295.1 / 193.7 / 79.8 (fixed 1 024: 81.1 for the rank of 8
     // but 221 for the rank of 2; 512: 102)
-    static const unsigned long long seg_a_env = [] { const char *e = getenv("FW_SEG_A"); return e ? (unsigned long long)atoll(e) : 8000000ull; }();
-    static const unsigned long long seg_b_env = [] { const char *e = getenv("FW_SEG_B"); return e ? (unsigned long long)atoll(e) : 12000000ull; }();
+    static const unsigned long long seg_a_env = [] { const char *e = fw_knob("FW_SEG_A"); return e ? (unsigned long long)atoll(e) : 8000000ull; }();
+    static const unsigned long long seg_b_env = [] { const char *e = fw_knob("FW_SEG_B"); return e ? (unsigned long long)atoll(e) : 12000000ull; }();
     const unsigned long long seg_a = c->P.kind == FW_FZ ? seg_a_env : 0ull, seg_b = c->P.kind == FW_FZ ? seg_b_env : 0ull;
     const unsigned max_ns = seg_target + (unsigned)ntg * (unsigned)(1 + DH_MAX_SPEC) + 256u;  // capacity of the segment list (a job + its look-ahead jobs each round up)
     // striding workgroups of the segment kernel.  FW_SEG_GRID caps them (experiment: with fewer workgroups than resident
     // slots the one-workgroup step / plan kernels of the OTHER chain find a free CU at once instead of queueing behind
     // this launch's pending workgroups -- cfg5 profile: dh_plan_kernel 6.3 ms per call, all of it waiting)
-    static const unsigned seg_grid_env = [] { const char *e = getenv("FW_SEG_GRID"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 0u; }();
+    static const unsigned seg_grid_env = [] { const char *e = fw_knob("FW_SEG_GRID"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 0u; }();
     const unsigned grid_seg = seg_grid_env ? std::min(seg_target + 512u, seg_grid_env) : seg_target + 512u;
     // FW_DH_LOG=<file>: one line per planned launch (ranks, live jobs, segments) -- profiling aid, see profiles/README.md
-    static const char *log_path = getenv("FW_DH_LOG");
+    static const char *log_path = fw_knob("FW_DH_LOG");
     constexpr unsigned LOG_CAP = 1u << 16;
     size_t need = (log_path ? pad(sizeof(ulonglong2) * LOG_CAP) : 0) + pad(sizeof(int32_t) * 2 * (size_t)ntg) + pad(sizeof(unsigned int) * ((size_t)ntg + 1)) + pad(sizeof(DhTgt) * ntg) + pad(sizeof(DhGlobal)) + 3 * pad(sizeof(long long) * ((size_t)ntg + 1));
     need += pad(4 * tot + 4) * 3 + pad(4 * 2 * tot * (size_t)d1 + 4) + pad(8 * tot + 8) * 4 + pad(4 * wl.size() + 4);
@@ -1620,13 +1620,13 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     P.max_k = c->P.max_k;
     P.max_tests = c->P.max_tests;
     {
-        const char *e = getenv("FW_SMALL_LAUNCH");
+        const char *e = fw_knob("FW_SMALL_LAUNCH");
         P.small_launch = e ? (unsigned long long)atoll(e) : (1ull << 22);
-        const char *w = getenv("FW_W0_BIG");
+        const char *w = fw_knob("FW_W0_BIG");
         P.w0_big = w ? (unsigned long long)atoll(w) : 16384ull;
     }
     {
-        const char *e = getenv("FW_ELIM_FULL");
+        const char *e = fw_knob("FW_ELIM_FULL");
         P.elim_full = e ? atoi(e) : 1;
     }
     {
@@ -1641,7 +1641,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         P.spec0_below = envu("FW_DH_SPEC0_BELOW", 12000000ull);
         P.spec0_jobs = (unsigned int)envu("FW_DH_SPEC0_JOBS", 512ull);
         {   // look-ahead behind a candidate that is about to be accepted (dh_step_kernel, spmode 1)
-            const char *e = getenv("FW_DH_SPEC1");
+            const char *e = fw_knob("FW_DH_SPEC1");
             P.spec1_depth = c->P.kind == FW_FZ ? std::min(std::max(e ? atoi(e) : 2, 0), DH_MAX_SPEC) : 0;
         }
         P.mi_seq = (unsigned int)envu("FW_MI_SEQ", 16ull);
@@ -1649,11 +1649,11 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         P.mi_chunk_div = (unsigned int)envu("FW_MI_CHUNK_DIV", 256ull);
         P.mi_chunk_min = (unsigned int)envu("FW_MI_CHUNK_MIN", 8ull);
         P.mi_chunk_max = (unsigned int)envu("FW_MI_CHUNK_MAX", 64ull);
-        { const char *e = getenv("FW_MI_HELP_JOBS"); P.mi_help_jobs = e ? (unsigned int)atoi(e) : 1u; }
-        { const char *e = getenv("FW_MI_ELIM_MIN"); P.mi_elim_min = e ? (unsigned int)atoi(e) : 64u; }
-        { const char *e = getenv("FW_MI_HEAVY"); P.mi_heavy = e ? (unsigned int)atoi(e) : 48u; }
-        { const char *e = getenv("FW_MI_SEQ_HEAVY"); P.mi_seq_heavy = e ? (unsigned int)atoi(e) : P.mi_seq; }
-        { const char *e = getenv("FW_MI_SEQ_TAIL"); P.mi_seq_tail = e ? (unsigned int)atoi(e) : 4u; }
+        { const char *e = fw_knob("FW_MI_HELP_JOBS"); P.mi_help_jobs = e ? (unsigned int)atoi(e) : 1u; }
+        { const char *e = fw_knob("FW_MI_ELIM_MIN"); P.mi_elim_min = e ? (unsigned int)atoi(e) : 64u; }
+        { const char *e = fw_knob("FW_MI_HEAVY"); P.mi_heavy = e ? (unsigned int)atoi(e) : 48u; }
+        { const char *e = fw_knob("FW_MI_SEQ_HEAVY"); P.mi_seq_heavy = e ? (unsigned int)atoi(e) : P.mi_seq; }
+        { const char *e = fw_knob("FW_MI_SEQ_TAIL"); P.mi_seq_tail = e ? (unsigned int)atoi(e) : 4u; }
     }
     const bool fz = c->P.kind == FW_FZ;
     P.w0_small = fz ? 256ull : 16ull;
@@ -1682,9 +1682,9 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     // Rounds per batch.  The host sees "every target has finished" one batch late, so a pass of few, light targets (a rank of an
     // 8-rank job holds 128 targets per feed-forward round at cfg3, 15 dependent rounds) ran 33 rounds, half of them empty: short
     // batches for short lists (r03: 1.05 -> 0.75 ms per light round; the host enqueues 4 rounds in ~60 us, a round takes 25-100 us)
-    static const int nb_env = [] { const char *e = getenv("FW_DH_BATCH"); return e && atoi(e) > 0 ? std::min(atoi(e), 16) : 0; }();
+    static const int nb_env = [] { const char *e = fw_knob("FW_DH_BATCH"); return e && atoi(e) > 0 ? std::min(atoi(e), 16) : 0; }();
     const int nb = nb_env ? nb_env : (ntg <= 1024 ? 4 : BATCH);
-    static const int time_every = [] { const char *e = getenv("FW_DH_TIME_EVERY"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
+    static const int time_every = [] { const char *e = fw_knob("FW_DH_TIME_EVERY"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
     // events live in a holder whose destructor synchronises the stream and destroys them on EVERY exit path (error returns
     // and the watchdog of the persistent kernel included: r02 leaked 66 events per failed call and left the stream running)
     struct EvHolder {
@@ -1741,7 +1741,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         M.view = M.dense && M.nzmode && c->mi_view;  // HITON-PC under the dense rules tests on row views (hiton.jl:41-50)
         // as many workgroups as stay resident (one per CU: the test routine needs ~260 VGPRs, one wavefront per SIMD; cfg4:
         // 62 ms with one, 71 ms with two requested): the wavefronts fetch targets themselves
-        static const unsigned wg_per_cu = [] { const char *e = getenv("FW_MI_WG_PER_CU"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 1u; }();
+        static const unsigned wg_per_cu = [] { const char *e = fw_knob("FW_MI_WG_PER_CU"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 1u; }();
         int n_cu = 256;
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->P.device);
         const unsigned grid = std::min((unsigned)((ntg + 3) / 4), wg_per_cu * (unsigned)n_cu);
@@ -1753,12 +1753,12 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
                        d_mq, d_boards, d_mres, d_bacc)
         const bool pre = c->P.n <= MI_PRE_N && c->P.max_k <= MI_PRE_K;
         // four subsets per wavefront step (mi_test_core4): n <= 5120, max_k <= 3, 2 x 2 cells per stratum.  FW_MI_ROW4=0: one per step
-        static const bool row4_env = [] { const char *e = getenv("FW_MI_ROW4"); return !(e && atoi(e) == 0); }();
+        static const bool row4_env = [] { const char *e = fw_knob("FW_MI_ROW4"); return !(e && atoi(e) == 0); }();
         // ... used up to 2048 samples (four words per lane): cfg2 (n = 500) 15.2 -> 12.5 ms.  At cfg4's n = 5000 a step of four
         // tests takes as long as four one-test steps (34 us: ten words per lane, 390 registers with the spills parked in AGPRs),
         // and since most jobs stop at their first test the three speculative ones are pure cost: measured 56.2 vs 56.8 ms on one
         // GPU, 35.3 vs 39.2 ms for one rank of eight -- FW_MI_ROW4=2 forces it on up to MI4_N for such experiments
-        static const bool row4_force = [] { const char *e = getenv("FW_MI_ROW4"); return e && atoi(e) == 2; }();
+        static const bool row4_force = [] { const char *e = fw_knob("FW_MI_ROW4"); return e && atoi(e) == 2; }();
         const bool r4 = row4_env && pre && c->P.n <= (row4_force ? MI4_N : 2048) && (c->L == 2 || c->mi_nxy == 2);
         if (c->L == 2) {
             if (r4) DH_MI_LAUNCH(2, 2, true, true); else if (pre) DH_MI_LAUNCH(2, 2, true, false); else DH_MI_LAUNCH(2, 2, false, false);

@@ -605,7 +605,7 @@ int fwi_fz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y
 static int fz_ensure_thresholds(fw_ctx *ctx, hipStream_t stream)
 {
     if (!ctx->d_thr) {
-        const char *dbg = getenv("FW_FZ_DBG");
+        const char *dbg = fw_knob("FW_FZ_DBG");
         const int flags = dbg ? atoi(dbg) : 0;
         FW_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(fz_dbg_flags), &flags, sizeof(int)));
         FW_HIP(ctx, hipMalloc((void **)&ctx->d_thr, 8 * sizeof(double)));
@@ -631,7 +631,7 @@ int fwi_fz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const i
     const unsigned grid_big = grid < 512u ? grid : 512u;  // accepted sets beyond FZ_TAB_A are rare: few striding workgroups
     if (ctx->P.max_k > 3) {
         // level-2 table variant for |accepted| <= FZ_HK_A, generic variant for the longer lists (both stride the list)
-        const bool no_hk = getenv("FW_NO_HK") != nullptr;  // profiling / test knob (read per call)
+        const bool no_hk = fw_knob("FW_NO_HK") != nullptr;  // profiling / test knob (read per call)
         if (!no_hk)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false, true>), dim3(grid), dim3(256), 0, stream, ctx->d_cor, ctx->P.p, d_segs,
                                d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr,
@@ -1187,7 +1187,7 @@ int fwi_fznz_submatrices(fw_ctx *ctx, int64_t njobs, const FwNzJob *recs_host, s
                          hipStream_t stream)
 {
     int rc;
-    static const bool nz_trace = getenv("FW_NZ_TRACE") != nullptr;  // profiling: shape of every sub-matrix launch
+    static const bool nz_trace = fw_knob("FW_NZ_TRACE") != nullptr;  // profiling: shape of every sub-matrix launch
     if (nz_trace) {
         long long mmax = 0, pairs = 0, uni = 0;
         for (int64_t j = 0; j < njobs; ++j) {

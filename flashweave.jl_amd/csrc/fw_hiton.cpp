@@ -221,10 +221,10 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
             // keeps the host pool below for every kind (it is also what rounds of fewer than 64 targets use: the
             // reference's single_il schedule posts one target per round and would pay the device set-up each time).
             // Discrete kinds run as one persistent launch (dh_mi_target_kernel): worth it from a few hundred targets on.
-            const char *hh = getenv("FW_HOST_HITON");
+            const char *hh = fw_knob("FW_HOST_HITON");
             const bool host_only = hh && atoi(hh) == 1;
             const bool no_power = c->P.kind == FW_FZ && c->P.n < c->n_obs_min_eff;  // no device work at all
-            const char *mt = getenv("FW_DEV_MIN_TARGETS");  // test knob
+            const char *mt = fw_knob("FW_DEV_MIN_TARGETS");  // test knob
             const size_t min_targets = mt ? (size_t)atol(mt) : (c->P.kind == FW_FZ ? 64 : 256);  // cfg2 (1000 targets): 19 ms on the device, 28 ms through the host pool
             const bool stream = c->P.kind == FW_FZ && !c->P.recursive_pcor;  // streamed-column tests: host pool over fw_fzs.hip
             const bool use_dev = !host_only && c->P.kind != FW_FZ_NZ && !stream && !no_power && n_my >= min_targets;
@@ -285,19 +285,19 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                     std::vector<std::vector<FwDhResult>> pres;
                     std::vector<FwDhFlat> pflat;
                     const double tdev0 = now_s();
-                    if (getenv("FW_TRACE_HOST")) fprintf(stderr, "[fw] round set-up on the host: %.2f ms\n", 1e3 * (tdev0 - t0));
+                    if (fw_knob("FW_TRACE_HOST")) fprintf(stderr, "[fw] round set-up on the host: %.2f ms\n", 1e3 * (tdev0 - t0));
                     // FW_DH_CHAINS = K (default 2, FlashWeave-S): the round's targets are dealt to K independent chains of device
                     // rounds that run concurrently (own host thread, stream and arena each): while one chain is between
                     // two launches (step / plan / fill, the thinning tail of its segment kernel) the other keeps the CUs
                     // busy.  cfg3, ms per pass with 1 / 2 / 3 / 4 chains: 261.8 / 229.4 / 224.2 / 274.3 on one GPU,
                     // 70.5 / 62.4 / 63.7 for one rank of eight; the per-launch duration of the segment kernel grows with
                     // the overlap (224 -> 167 us for launches half the size), which is what HIP events and rocprofv3 see
-                    const int dh_chains = [] { const char *e = getenv("FW_DH_CHAINS"); return std::min(std::max(e ? atoi(e) : 2, 1), FW_DH_MAX_CHAINS); }();  /* read per round: bench.py times a one-chain pass for the per-kernel figures */  // r02: cfg3 227 / 218 / 268 ms with 2 / 3 / 4 in a bare process, but 226 / 298 under torch.distributed.run and 325 with GPU_MAX_HW_QUEUES=8: the third stream's hardware queue is not ours to choose -> 2
-                    static const size_t dh_chain_min = [] { const char *e = getenv("FW_DH_CHAIN_MIN"); return e && atol(e) > 0 ? (size_t)atol(e) : (size_t)48; }();  // r03: 256 -> 48 (one rank of eight holds 98 targets in cfg3's last round: 75 -> 69 ms with two chains)
-                    static const int dh_chains_disc = [] { const char *e = getenv("FW_DH_CHAINS_DISC"); return std::min(std::max(e ? atoi(e) : 2, 1), FW_DH_MAX_CHAINS); }();  // cfg4: 248.7 / 232.9 / 227.2 / 253.1 ms with 1 / 2 / 3 / 4
+                    const int dh_chains = [] { const char *e = fw_knob("FW_DH_CHAINS"); return std::min(std::max(e ? atoi(e) : 2, 1), FW_DH_MAX_CHAINS); }();  /* read per round: bench.py times a one-chain pass for the per-kernel figures */  // r02: cfg3 227 / 218 / 268 ms with 2 / 3 / 4 in a bare process, but 226 / 298 under torch.distributed.run and 325 with GPU_MAX_HW_QUEUES=8: the third stream's hardware queue is not ours to choose -> 2
+                    static const size_t dh_chain_min = [] { const char *e = fw_knob("FW_DH_CHAIN_MIN"); return e && atol(e) > 0 ? (size_t)atol(e) : (size_t)48; }();  // r03: 256 -> 48 (one rank of eight holds 98 targets in cfg3's last round: 75 -> 69 ms with two chains)
+                    static const int dh_chains_disc = [] { const char *e = fw_knob("FW_DH_CHAINS_DISC"); return std::min(std::max(e ? atoi(e) : 2, 1), FW_DH_MAX_CHAINS); }();  // cfg4: 248.7 / 232.9 / 227.2 / 253.1 ms with 1 / 2 / 3 / 4
                     // discrete kinds run as ONE persistent launch that fills the GPU by itself (dh_mi_target_kernel); concurrent
                     // chains only apply to their level-synchronous form (FW_MI_ROUNDS=1)
-                    static const bool mi_rounds = [] { const char *e = getenv("FW_MI_ROUNDS"); return e && atoi(e) != 0; }();
+                    static const bool mi_rounds = [] { const char *e = fw_knob("FW_MI_ROUNDS"); return e && atoi(e) != 0; }();
                     const int want = c->P.kind == FW_FZ ? dh_chains : (mi_rounds ? dh_chains_disc : 1);
                     const int K = din.size() >= (size_t)want * dh_chain_min ? want : 1;
                     int rc = FW_OK;
@@ -313,8 +313,8 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                         // which chain target i goes to (and its index there).  Default: dealt in schedule order.  Few targets (the
                         // latency-bound regime: a rank of a multi-GPU job, the last feed-forward round): the heaviest FW_DH_HEAVY_FRAC of
                         // them get chain 0 to themselves -- its launches stay small, so the rounds of the longest chains are short
-                        static const int heavy_pct = [] { const char *e = getenv("FW_DH_HEAVY_PCT"); return e ? atoi(e) : 0; }();
-                        static const size_t heavy_below = [] { const char *e = getenv("FW_DH_HEAVY_BELOW"); return e ? (size_t)atol(e) : (size_t)512; }();
+                        static const int heavy_pct = [] { const char *e = fw_knob("FW_DH_HEAVY_PCT"); return e ? atoi(e) : 0; }();
+                        static const size_t heavy_below = [] { const char *e = fw_knob("FW_DH_HEAVY_BELOW"); return e ? (size_t)atol(e) : (size_t)512; }();
                         chain_of.assign(din.size(), 0);
                         chain_idx.assign(din.size(), 0);
                         {
@@ -345,7 +345,7 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                             if (rcs[q]) rc = rcs[q];
                     }
                     if (rc) return rc;
-                    if (getenv("FW_TRACE_HOST")) fprintf(stderr, "[fw] device rounds (all chains): %.2f ms\n", 1e3 * (now_s() - tdev0));
+                    if (fw_knob("FW_TRACE_HOST")) fprintf(stderr, "[fw] device rounds (all chains): %.2f ms\n", 1e3 * (now_s() - tdev0));
                     // this round's directed results straight from the chains' flat arrays (target i went to chain i % K)
                     {
                         size_t nres = 0;
@@ -376,8 +376,8 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
             // first acceptance bumps the target's epoch, which cancels / voids everything posted after it.  The sequence
             // of committed (T, candidate, accepted) jobs is therefore exactly the reference's; only the number of
             // latency-bound rounds shrinks.  Every pool round = one window of every in-flight job = ONE kernel launch.
-            static const int FW_SPEC_DEPTH = [] { const char *e = getenv("FW_SPEC_DEPTH"); return e ? atoi(e) : 8; }();
-            static const long FW_SPEC_TARGETS = [] { const char *e = getenv("FW_SPEC_TARGETS"); return e ? atol(e) : 512l; }();
+            static const int FW_SPEC_DEPTH = [] { const char *e = fw_knob("FW_SPEC_DEPTH"); return e ? atoi(e) : 8; }();
+            static const long FW_SPEC_TARGETS = [] { const char *e = fw_knob("FW_SPEC_TARGETS"); return e ? atol(e) : 512l; }();
 
             long n_unfinished = (long)tg.size();
             FwPool pool;
@@ -503,12 +503,12 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
         }
     }
     c->cnt.t_cond_s += now_s() - t0;
-    if (getenv("FW_TRACE_HOST")) fprintf(stderr, "[fw] conditional stage: %.2f ms\n", 1e3 * (now_s() - t0));
+    if (fw_knob("FW_TRACE_HOST")) fprintf(stderr, "[fw] conditional stage: %.2f ms\n", 1e3 * (now_s() - t0));
 
     const double tp0 = now_s();
     if (discrete)
         if (int rc = fwi_nb_host_ensure(c)) return rc;
-    if (getenv("FW_TRACE_HOST")) fprintf(stderr, "[fw] neighbour lists to the host: %.2f ms\n", 1e3 * (now_s() - tp0));
+    if (fw_knob("FW_TRACE_HOST")) fprintf(stderr, "[fw] neighbour lists to the host: %.2f ms\n", 1e3 * (now_s() - tp0));
     // CSR over targets (stable: arrival order inside a target = PC insertion order)
     const size_t ne = all_t.size();
     c->pc_off.assign((size_t)p + 1, 0);
@@ -582,7 +582,7 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
         }
     }
     c->have_network = true;
-    if (getenv("FW_TRACE_HOST")) fprintf(stderr, "[fw] weights + symmetric graph on the host: %.2f ms\n", 1e3 * (now_s() - tp0));
+    if (fw_knob("FW_TRACE_HOST")) fprintf(stderr, "[fw] weights + symmetric graph on the host: %.2f ms\n", 1e3 * (now_s() - tp0));
     if (n_edges_out) *n_edges_out = (int64_t)c->e_src.size();
     return FW_OK;
 }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -181,6 +182,15 @@ struct fw_ctx {
     FwPinned h_jobs, h_acc, h_out;
     FwPoolBuf pb[2];
 };
+
+// Tuning / test knobs (environment variables FW_*: DESIGN.md section 5 lists them) are read ONLY when FW_KNOBS=1 is set.  The
+// compiled-in defaults are the product; a stray FW_* variable in a user's environment must not change what the library does.
+// tests/conftest.py, bench.py (for its one-chain / host-seam passes) and the scripts under profiles/tools set FW_KNOBS=1.
+inline const char *fw_knob(const char *name)
+{
+    const char *on = getenv("FW_KNOBS");
+    return (on && on[0] == '1') ? getenv(name) : nullptr;
+}
 
 int fw_fail(const fw_ctx *ctx, int code, const char *fmt, ...);
 int fw_dev_reserve(fw_ctx *ctx, FwDevBuf &b, size_t bytes);

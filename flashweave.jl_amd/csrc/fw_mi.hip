@@ -788,7 +788,7 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
     const int nblk = (int)((long long)nblk_all * (ctx->l0_rank + 1) / ctx->l0_world) - b_off;
     const MiDev P = mi_dev(ctx);
     // ---- kernel 1: popcounts + exact reliability/df + Float32 screen -> candidate records ----
-    static const int l0_dbg = getenv("FW_L0_DBG") ? atoi(getenv("FW_L0_DBG")) : 0;  // profiling only (invalid results)
+    static const int l0_dbg = fw_knob("FW_L0_DBG") ? atoi(fw_knob("FW_L0_DBG")) : 0;  // profiling only (invalid results)
     unsigned long long cap_c = (unsigned long long)std::min<long long>(npairs, 8ll << 20);
     if (cap_c < ctx->l0_cap_hint) cap_c = ctx->l0_cap_hint;  // a repeated call does not overflow (and re-run the kernel) again
     if (cap_c == 0) cap_c = 1;
@@ -819,7 +819,7 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
     }
     const unsigned long long ncand = h1.n_sig;
     *m_reliable = npairs - (long long)h1.n_unreliable;
-    if (getenv("FW_L0_VERBOSE")) fprintf(stderr, "[fw] discrete level-0: pairs %lld reliable %lld candidates %llu\n", npairs, (long long)*m_reliable, ncand);
+    if (fw_knob("FW_L0_VERBOSE")) fprintf(stderr, "[fw] discrete level-0: pairs %lld reliable %lld candidates %llu\n", npairs, (long long)*m_reliable, ncand);
     pi.clear();
     pj.clear();
     stat.clear();
@@ -903,7 +903,7 @@ int fwi_mi_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y
     int kmax = 0;
     for (int64_t t = 0; t < m; ++t) kmax = std::max<int>(kmax, (int)(zoff[t + 1] - zoff[t]));
     MiDev Pd = mi_dev(ctx);
-    static const bool prof = getenv("FW_MI_PROF") != nullptr;
+    static const bool prof = fw_knob("FW_MI_PROF") != nullptr;
     if (prof) {
         if ((rc = fw_dev_reserve(ctx, ctx->d_tmp0, (size_t)m * 8 * sizeof(unsigned long long)))) return rc;
         FW_HIP(ctx, hipMemsetAsync(ctx->d_tmp0.ptr, 0, (size_t)m * 8 * sizeof(unsigned long long), ctx->stream));

@@ -1,6 +1,7 @@
 """Profiling tool: time of the discrete level-0 stage at cfg4 with parts of mi_level0_kernel disabled (FW_L0_DBG bits:
 1 = no screening epilogue, 2 = no global loads, 4 = no popcount loop).  Results are invalid in those modes."""
 import os, sys, time, subprocess, json
+import os as _os; _os.environ.setdefault("FW_KNOBS", "1")  # the library reads FW_* knobs only when this is set
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 if len(sys.argv) > 1 and sys.argv[1] == "child":

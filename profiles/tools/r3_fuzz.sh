@@ -1,4 +1,5 @@
 #!/bin/bash
+export FW_KNOBS=1  # the library reads FW_* knobs only when this is set
 # long randomised parity sweep on the final kernels of round 3 (tests/fuzz_gpu.py; seeds disjoint from rounds 1-2)
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r3_fuzz; mkdir -p $O
 timeout 1500 python -m tests.fuzz_gpu --first 100000 --cases 4000 > $O/networks.txt 2>&1; tail -2 $O/networks.txt

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FW_KNOBS=1  # the library reads FW_* knobs only when this is set
 # discrete persistent kernel: owner prefix in the tail (FW_MI_SEQ_TAIL), one rank of eight (rank 6) and the single-rank pass, cfg4 / cfg2
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r3_mi_knobs

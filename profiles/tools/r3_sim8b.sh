@@ -1,4 +1,5 @@
 #!/bin/bash
+export FW_KNOBS=1  # the library reads FW_* knobs only when this is set
 # one rank of eight (rank 3: the slowest of r3_sim8), knob sweep + where the longest-busy target spends its rounds
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r3_sim8b

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FW_KNOBS=1  # the library reads FW_* knobs only when this is set
 # one rank of eight (cfg3, headline schedule): the heaviest targets in a chain of their own
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r3_sim8c

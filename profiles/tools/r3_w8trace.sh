@@ -1,4 +1,5 @@
 #!/bin/bash
+export FW_KNOBS=1  # the library reads FW_* knobs only when this is set
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/w8

@@ -1,3 +1,4 @@
+export FW_KNOBS=1  # the library reads FW_* knobs only when this is set
 run() { echo -n "$* : "; env "$@" python bench.py --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],1), round(d['other_schedule']['ms_per_step'],1), d['edges'], d['tests_per_step']['conditional_evaluated'], d['rounds'])"; }
 run A=0

@@ -8,6 +8,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the library reads its tuning / test knobs (FW_HOST_HITON, FW_DEV_MIN_TARGETS, FW_DH_*, ...) only when FW_KNOBS=1 is set
+# (csrc/fw_internal.h: fw_knob); the tests switch code paths with them, also in the subprocesses they start
+os.environ.setdefault("FW_KNOBS", "1")
 
 
 def pytest_configure(config):

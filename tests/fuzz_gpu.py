@@ -20,6 +20,7 @@ from oracle import oracle as O
 STOL = 1e-12  # discrete statistics: summation order, device log (tests/test_gpu_mi.py)
 PTOL = 1e-10  # discrete p-values: device lgamma / exp in Q(a, x) (tests/test_gpu_mi.py)
 ENV_KEYS = ("FW_HOST_HITON", "FW_DEV_MIN_TARGETS", "FW_HOST_BH")
+os.environ.setdefault("FW_KNOBS", "1")  # the library reads FW_* knobs only under FW_KNOBS=1 (csrc/fw_internal.h)
 
 
 def _rel(a, b):

@@ -506,3 +506,25 @@ def test_device_rounds_max_k5_table_kernels_equal_gather_form(monkeypatch):
         assert np.array_equal(nt[key], ng[key], equal_nan=True), key
     assert ct["cond_tests_ref"] == cg["cond_tests_ref"] and ct["subsets_calls"] == cg["subsets_calls"]
     assert ct["cond_tests_ref"] > 50_000_000  # (and FW_TRACE_HOST=1 shows accepted lists beyond 88 entries)
+
+
+def test_env_knobs_are_inert_without_fw_knobs():
+    # The FW_* environment variables of DESIGN.md section 5 steer profiling and tests; the library reads them only under
+    # FW_KNOBS=1 (csrc/fw_internal.h: fw_knob).  A stray FW_HOST_HITON=1 in a user's environment must not move the conditional
+    # stage onto the host job pool.
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    snippet = ("import sys; sys.path.insert(0, %r)\n"
+               "import numpy as np, flashweave_jl_amd as fw\n"
+               "rng = np.random.default_rng(3)\n"
+               "d = (rng.standard_normal((300, 1)) + rng.standard_normal((300, 200))).astype(np.float32)\n"
+               "e = fw.Engine('fz', 300, 200, max_k=2); e.set_data(d); e.compute_cor(); e.lgl(feed_forward=False, round_size=0)\n"
+               "print('HOST_ADVANCE', e.counters()['t_host_advance_s'] > 0)\n") % root
+    out = {}
+    for knobs in ("0", "1"):
+        env = dict(os.environ, FW_HOST_HITON="1", FW_KNOBS=knobs)
+        r = subprocess.run([sys.executable, "-c", snippet], env=env, cwd=root, check=True, capture_output=True, text=True).stdout
+        out[knobs] = [ln for ln in r.splitlines() if ln.startswith("HOST_ADVANCE")][-1].split()[-1]
+    assert out == {"0": "False", "1": "True"}, out
