@@ -84,6 +84,8 @@ def parse_args(argv=None):
     ap.add_argument("--replicate-level0", action="store_true",
                     help="N > 1, discrete kinds: every rank screens ALL level-0 pair tiles (r02 behaviour); default: 1/N of them, "
                          "significant pairs all-gathered in device memory (fw_level0_sharded_dev)")
+    ap.add_argument("--host-exchange", action="store_true",
+                    help="N > 1: per-round exchange through the host callback (numpy packing, r02 form) instead of fw_learn_network_dev")
     ap.add_argument("--shard-cor", action="store_true",
                     help="N > 1, fz: row-block sharding of the Pearson GEMM with an in-place all-gather (default from p = 30 000 on)")
     ap.add_argument("--max-targets", type=int, default=0,
@@ -315,6 +317,10 @@ def main():
     # cheaper than moving 400 MB.
     shard_l0 = discrete and not args.replicate_level0
     shard_cor = cfg["test_name"] == "fz" and (args.shard_cor or p >= 30000)
+    xround = None
+    if use_dist and not args.host_exchange:
+        from flashweave_jl_amd.dist import make_dev_exchange
+        xround = make_dev_exchange(dist, dev, stats=xstats)
     xdev = None
     if use_dist and shard_l0:
         from flashweave_jl_amd.dist import make_dev_exchange
@@ -381,6 +387,10 @@ def main():
         if sim["mode"] == "record":
             sim["rounds"] = []
             return eng.lgl(feed_forward=bool(ff), round_size=R, allgather=cb, max_targets=args.max_targets, edge_dict=False)
+        if use_dist and not args.host_exchange:
+            # per-round exchange with the payload packed / unpacked by the library and gathered in device memory (fw_learn_network_dev)
+            return eng.lgl(feed_forward=bool(ff), round_size=R, rank=rank, world_size=world, dev_exchange=xround,
+                           max_targets=args.max_targets, edge_dict=False)
         return eng.lgl(feed_forward=bool(ff), round_size=R, rank=sim.get("rank", rank),
                        world_size=max(world, args.simulate_world) if world == 1 else world, allgather=cb,
                        max_targets=args.max_targets, edge_dict=False)  # the network stays in the arrays the C ABI fills (no Python dictionary of tuples)

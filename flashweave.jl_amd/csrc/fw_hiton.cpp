@@ -125,6 +125,83 @@ static double maxweight(double w1, double w2)
     return std::max(std::fabs(w1), std::fabs(w2)) * s1;
 }
 
+// The per-round exchange of fw_learn_network through a fw_dev_exchange (fw_learn_network_dev): the round's directed entries are
+// packed into 24-byte records here (no numpy on the way), copied into the caller's device send buffer, all-gathered by the caller's
+// collective (RCCL on torch tensors in bench.py) and unpacked from the gathered buffer.  Implements fw_allgather_fn.
+namespace {
+struct DevXRec {
+    int32_t t, u;
+    double s, p;
+};
+static_assert(sizeof(DevXRec) == 24, "round exchange record");
+struct DevXAdapter {
+    fw_ctx *c;
+    const fw_dev_exchange *x;
+    int world;
+    std::vector<DevXRec> stage;
+    std::vector<int32_t> t, u;
+    std::vector<double> s, p;
+};
+int devx_allgather(void *user, int64_t n, const int32_t *tgt, const int32_t *nbr, const double *stat, const double *pval, int64_t *n_total,
+                   const int32_t **tgt_all, const int32_t **nbr_all, const double **stat_all, const double **pval_all)
+{
+    DevXAdapter *A = (DevXAdapter *)user;
+    std::vector<int64_t> counts((size_t)A->world, 0), aux((size_t)A->world, 0);
+    void *d_send = nullptr, *d_recv = nullptr;
+    int64_t cap = 0;
+    if (A->x->prepare(A->x->user, n, 0, (int32_t)sizeof(DevXRec), &d_send, &d_recv, counts.data(), aux.data(), &cap)) return 1;
+    if (n > cap || !d_recv || (n > 0 && !d_send)) return 2;
+    A->stage.resize((size_t)std::max<int64_t>(n, 1));
+    for (int64_t i = 0; i < n; ++i) A->stage[(size_t)i] = DevXRec{tgt[i], nbr[i], stat[i], pval[i]};
+    if (n > 0 && hipMemcpy(d_send, A->stage.data(), (size_t)n * sizeof(DevXRec), hipMemcpyHostToDevice) != hipSuccess) return 3;
+    if (A->x->exchange(A->x->user)) return 4;
+    int64_t total = 0;
+    for (int r = 0; r < A->world; ++r) {
+        if (counts[(size_t)r] < 0 || counts[(size_t)r] > cap) return 5;
+        total += counts[(size_t)r];
+    }
+    A->stage.resize((size_t)std::max<int64_t>(total, 1));
+    int64_t off = 0;
+    for (int r = 0; r < A->world; ++r) {
+        const int64_t k = counts[(size_t)r];
+        if (k > 0 && hipMemcpy(A->stage.data() + off, (const char *)d_recv + (size_t)r * (size_t)cap * sizeof(DevXRec), (size_t)k * sizeof(DevXRec),
+                               hipMemcpyDeviceToHost) != hipSuccess)
+            return 6;
+        off += k;
+    }
+    A->t.resize((size_t)std::max<int64_t>(total, 1));
+    A->u.resize(A->t.size());
+    A->s.resize(A->t.size());
+    A->p.resize(A->t.size());
+    for (int64_t i = 0; i < total; ++i) {
+        const DevXRec &q = A->stage[(size_t)i];
+        A->t[(size_t)i] = q.t;
+        A->u[(size_t)i] = q.u;
+        A->s[(size_t)i] = q.s;
+        A->p[(size_t)i] = q.p;
+    }
+    *n_total = total;
+    *tgt_all = A->t.data();
+    *nbr_all = A->u.data();
+    *stat_all = A->s.data();
+    *pval_all = A->p.data();
+    return 0;
+}
+}  // namespace
+
+extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allgather_fn allgather, void *user, int64_t *n_edges_out);
+
+extern "C" int fw_learn_network_dev(fw_ctx *c, const fw_learn_opts *opts_in, const fw_dev_exchange *x, int64_t *n_edges_out)
+{
+    if (!c) return fw_fail(nullptr, FW_ERR_ARG, "NULL context");
+    const int world = opts_in ? std::max(opts_in->world_size, 1) : 1;
+    if (world > 1 && (!x || !x->prepare || !x->exchange)) return fw_fail(c, FW_ERR_ARG, "fw_learn_network_dev: world_size > 1 needs both exchange callbacks");
+    if (!x) return fw_learn_network(c, opts_in, nullptr, nullptr, n_edges_out);
+    (void)hipSetDevice(c->P.device);
+    DevXAdapter A{c, x, world, {}, {}, {}, {}, {}};
+    return fw_learn_network(c, opts_in, devx_allgather, &A, n_edges_out);
+}
+
 extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allgather_fn allgather, void *user,
                                 int64_t *n_edges_out)
 {

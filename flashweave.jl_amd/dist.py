@@ -115,6 +115,7 @@ def make_dev_exchange(dist, device, stats=None):
 
     def prepare(user, n_local, aux_local, rec_bytes, d_send, d_recv, counts, aux, cap_records):
         try:
+            st["t0"] = time.perf_counter()
             world = dist.get_world_size()
             hdr = torch.tensor([int(n_local), int(aux_local)], dtype=torch.int64, device=device if on_gpu_coll else "cpu")
             allh = torch.empty(2 * world, dtype=torch.int64, device=hdr.device)
@@ -132,8 +133,9 @@ def make_dev_exchange(dist, device, stats=None):
             d_send[0] = st["send"].data_ptr()
             d_recv[0] = st["recv"].data_ptr()
             cap_records[0] = st["cap"]
+            st["n_all"] = int(allh[:, 0].sum())
             if stats is not None:
-                stats["level0_records"] = int(allh[:, 0].sum())
+                stats["level0_records"] = st["n_all"]
             return 0
         except Exception:
             traceback.print_exc()
@@ -153,6 +155,11 @@ def make_dev_exchange(dist, device, stats=None):
             if stats is not None:
                 stats["level0_exchange_s"] = stats.get("level0_exchange_s", 0.0) + time.perf_counter() - t0
                 stats["level0_exchange_bytes"] = st["recv"].numel()
+                # the same counters make_allgather keeps (bench.py reports them per step): one call = header + payload collectives
+                stats["calls"] = stats.get("calls", 0) + 1
+                stats["collectives"] = stats.get("collectives", 0) + 2
+                stats["entries"] = stats.get("entries", 0) + st.get("n_all", 0)
+                stats["seconds"] = stats.get("seconds", 0.0) + (time.perf_counter() - st.get("t0", t0))
             return 0
         except Exception:
             traceback.print_exc()

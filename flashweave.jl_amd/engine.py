@@ -114,6 +114,7 @@ def load_library():
     L.fw_test_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
     L.fw_test_subsets_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
     L.fw_learn_network.argtypes = [vp, C.POINTER(_LearnOpts), vp, vp, C.POINTER(C.c_int64)]
+    L.fw_learn_network_dev.argtypes = [vp, C.POINTER(_LearnOpts), C.POINTER(_DevExchange), C.POINTER(C.c_int64)]
     L.fw_network_get.argtypes = [vp, vp, vp, vp]
     L.fw_network_get_directed.argtypes = [vp, vp, vp, vp, vp]
     L.fw_get_counters.argtypes = [vp, C.POINTER(_Counters)]
@@ -330,7 +331,7 @@ class Engine:
         return self.test_subsets_batch([T], [cand], [list(accepted)])[0]
 
     # -- LGL -----------------------------------------------------------------------------------------
-    def lgl(self, feed_forward=True, round_size=1, rank=0, world_size=1, max_targets=0, allgather=None, edge_dict=True):
+    def lgl(self, feed_forward=True, round_size=1, rank=0, world_size=1, max_targets=0, allgather=None, edge_dict=True, dev_exchange=None):
         """LGL minus normalisation (src/learning.jl:203-279).  Returns dict(edges={(i,j): w}, directed=CSR);
         edge_dict=False leaves the edges as the three arrays fw_network_get fills (edge_src, edge_dst, edge_weight) and
         skips the Python dictionary (48 000 tuples cost ~8 ms at cfg3)."""
@@ -340,7 +341,12 @@ class Engine:
         if allgather is not None:
             cb = ALLGATHER_FN(allgather)
             self._cb = cb
-        self._ck(self.L.fw_learn_network(self.h, C.byref(opts), C.cast(cb, C.c_void_p) if cb else None, None, C.byref(ne)))
+        if dev_exchange is not None:  # (prepare, exchange) of dist.make_dev_exchange: the library packs / unpacks, Python runs the collective
+            x = _DevExchange(None, PREPARE_FN(dev_exchange[0]), EXCHANGE_FN(dev_exchange[1]))
+            self._xdev_lgl = x
+            self._ck(self.L.fw_learn_network_dev(self.h, C.byref(opts), C.byref(x), C.byref(ne)))
+        else:
+            self._ck(self.L.fw_learn_network(self.h, C.byref(opts), C.cast(cb, C.c_void_p) if cb else None, None, C.byref(ne)))
         k = max(ne.value, 1)
         src, dst, w = np.zeros(k, np.int32), np.zeros(k, np.int32), np.zeros(k, np.float64)
         self._ck(self.L.fw_network_get(self.h, _ptr(src), _ptr(dst), _ptr(w)))

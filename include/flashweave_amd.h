@@ -246,6 +246,11 @@ typedef struct fw_learn_opts {
  * *n_edges_out = number of undirected edges; fetch them with fw_network_get. */
 int fw_learn_network(fw_ctx *ctx, const fw_learn_opts *opts, fw_allgather_fn allgather, void *user,
                      int64_t *n_edges_out);
+/* The same with the per-round exchange through a fw_dev_exchange (see fw_level0_sharded_dev): the round's directed entries are packed
+ * into 24-byte records (int32 target, int32 neighbour, Float64 statistic, Float64 p) by the library, copied into the caller's device
+ * send buffer, all-gathered by the caller's collective and unpacked from the gathered buffer -- the host language only runs the
+ * collective (r02's callback packed and unpacked in numpy: ~0.9 ms per round of a cfg3 pass). */
+int fw_learn_network_dev(fw_ctx *ctx, const fw_learn_opts *opts, const fw_dev_exchange *exchange, int64_t *n_edges_out);
 int fw_network_get(const fw_ctx *ctx, int32_t *src, int32_t *dst, double *weight); /* src < dst */
 /* directed per-target results (state_results of every HitonState): CSR over targets */
 int fw_network_get_directed(const fw_ctx *ctx, int64_t *off, int32_t *idx, double *weight, double *pval);

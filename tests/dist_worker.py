@@ -112,6 +112,10 @@ def run_sharded_gpu(rank, world, out_path):
         nb = eng.pw_univar_neighbors_get()
         res["%s_l0_dev" % kind] = [nb["off"].tolist(), nb["idx"].tolist(), nb["stat"].tolist(), nb["pval"].tolist()]
         res["%s_l0_dev_records" % kind] = xs.get("level0_records", 0)
+        # ... and the per-round exchange of the conditional stage the same way (fw_learn_network_dev)
+        net = eng.lgl(feed_forward=True, round_size=32, rank=rank, world_size=world,
+                      dev_exchange=make_dev_exchange(dist, torch.device("cuda", 0)))
+        res["%s_ff1_devx" % kind] = sorted([a, b, w] for (a, b), w in net["edges"].items())
         if kind == "fz":
             # row-block sharding of cor(): each rank computes half of the rows, the blocks are gathered in place inside a
             # torch tensor the engine uses as its matrix; bit-identical to the single-rank matrix, and so is the network on it

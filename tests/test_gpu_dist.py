@@ -32,6 +32,7 @@ def test_sharded_equals_single():
             assert len(r0[kind + "_l0"][1]) > 0
             # ... and with the exchange kept in device memory (fw_level0_sharded_dev)
             assert r0[kind + "_l0_dev"] == r1[kind + "_l0_dev"] == r0[kind + "_l0_single"]
+            assert r0[kind + "_ff1_devx"] == r1[kind + "_ff1_devx"] == r0[kind + "_ff1"]   # rounds exchanged through fw_learn_network_dev
         assert r0["mi_l0_dev_records"] > 0          # the discrete kind really exchanged its significant pairs
         # row-block sharding of the Pearson matrix: same bits as the single-rank GEMM, same network on it
         assert r0["fz_cor_sharded_equal"] and r1["fz_cor_sharded_equal"]
