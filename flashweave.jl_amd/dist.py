@@ -182,7 +182,13 @@ def sharded_cor(eng, dist, device, rank, world, keep=None):
     assert rows == rpr and row0 == rank * rpr
     mine = buf[rank * rpr * p:(rank + 1) * rpr * p]
     if dist.get_backend() == "nccl":
-        dist.all_gather_into_tensor(buf[:world * rpr * p], mine)
+        try:  # in place: this rank's block already sits at offset rank * block inside the output (what RCCL's in-place form expects)
+            dist.all_gather_into_tensor(buf[:world * rpr * p], mine)
+        except RuntimeError:  # a backend build that refuses aliased input / output: gather through a second buffer
+            tmp = torch.empty(world * rpr * p, dtype=torch.float32, device=device)
+            dist.all_gather_into_tensor(tmp, mine.clone())
+            buf[:world * rpr * p].copy_(tmp)
+            del tmp
         torch.cuda.current_stream(device).synchronize()
     else:
         h = torch.empty(world * rpr * p, dtype=torch.float32)
