@@ -69,3 +69,9 @@ def test_unranking_root_guess_equals_enumeration(tmp_path):
     subprocess.run(["g++", "-O2", "-o", exe, os.path.join(root, "tests", "native", "unrank_check.cpp")], check=True)
     out = subprocess.run([exe, "32"], check=True, capture_output=True, text=True).stdout
     assert out.startswith("ok "), out
+
+
+def test_graft_entry_build_passes():
+    # the driver's "does it build" check: compiles (or finds up to date) the HIP library + the oracle and asserts the ABI version
+    import __graft_entry__ as g
+    assert g.build().endswith("libflashweave_amd.so")
