@@ -8,10 +8,15 @@
 //   * column means and sums of squared deviations (Float64) are computed ONCE per data upload (fzs_colstat_kernel), so a test
 //     needs only the cross products, and  sum (x_a - mu_a)(x_b - mu_b) = sum x_a (x_b - mu_b)  (the dropped term is mu_a times the
 //     rounding residue of a centred sum: < 1e-14 relative) -- one conversion + one FMA per element and pair;
-//   * inside a test_subsets job the wavefront keeps the X and Y columns in registers (n <= 2048: 2 x 8 float4 per lane) and their
-//     cross product for all the subsets it evaluates: a test streams its k conditioning columns only;
-//   * then every lane conditions the (k+2) x (k+2) correlation matrix on Z_k, ..., Z_1 (the unrolled recursion of
-//     StatsBase._partialcor, oracle/fw_oracle.c fwo_pcor), clamps and takes the Fisher-z p-value with len_z = 0 (tests.jl:256).
+//   * inside a test_subsets job the workgroup keeps the X and Y columns in LDS (n <= 2048: 16 KB) and every wavefront their cross
+//     product for all the subsets it evaluates: a test streams its k conditioning columns only;
+//   * the (k+2) x (k+2) correlation matrix is then conditioned on Z_k, ..., Z_1 (the unrolled recursion of StatsBase._partialcor,
+//     oracle/fw_oracle.c fwo_pcor), clamped, and the Fisher-z p-value taken with len_z = 0 (tests.jl:256) -- for up to four tests
+//     of a wavefront at once, one lane per matrix entry (fzs_finish below);
+//   * bookkeeping of a run (ranks, positions, best / stop records) is wave-uniform and lives in scalar registers.
+// 128 VGPRs, four workgroups per CU.  History on the micro-benchmark (|accepted| = 40, n = 2000; tests/s in the kernel): r02 form
+// not timed; one pass + X / Y in registers 1.36e8; X / Y in LDS + arithmetic out of line 1.79e8; lane-parallel arithmetic 2.72e8;
+// four tests finished together 3.67e8 (= 1.8 x the 8 TB/s nominal B_fzS rate: X / Y come from LDS and the Z columns of a job from L2).
 // Algorithmic bytes: B_fzS(k, n) = (k + 2) * n * 4 + 32 per test (variant S): what a test that shares nothing
 // with its neighbours streams.  With X / Y held, the bytes really requested are k * n * 4 per test.
 #include <cmath>
@@ -60,10 +65,13 @@ __device__ __forceinline__ double fzs_wave_sum(double v)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-struct FzsRes {
-    double stat, pval;
-    int power;
-};
+// a value every lane holds -> scalar registers (the bookkeeping around the tests then stays out of the vector file)
+__device__ __forceinline__ double fzs_uniform(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 
 // per column: {mean, sum of squared deviations} in Float64, one wavefront per column (two passes over the column: it is read from
 // L2 the second time).  Once per data upload.
@@ -87,18 +95,22 @@ __global__ __launch_bounds__(256) void fzs_colstat_kernel(const float *__restric
     }
 }
 
-// X and Y of a job, as the wavefront holds them across its subsets.  T > 0: float4 registers (n % 4 == 0, n <= 256 T);
-// T == 0: nothing is held, the columns are streamed with every test (any n)
+// X and Y of a job.  T > 0 (n % 4 == 0, n <= 256 T): the workgroup keeps both columns in LDS for all the subsets its four
+// wavefronts evaluate (16 KB at n = 2000; the first r03 version held them in 64 registers per lane, which together with the
+// ~150 registers of the then sequential arithmetic left one wavefront per SIMD and 700 B of scratch); T == 0: streamed with every test.
 template <int T>
 struct FzsXY {
-    float4 x[T > 0 ? T : 1], y[T > 0 ? T : 1];
-    double sxy;            // sum x (y - mu_y)
-    const float *cx, *cy;  // the columns
+    const float4 *lx, *ly;  // LDS copies (T > 0)
+    double sxy;             // sum x (y - mu_y)
+    const float *cx, *cy;   // the columns in global memory
     double mux, muy, ssx, ssy;
 };
 
+#define FZS_LDS_N 2048  // samples per column the LDS copy holds
+
+// wavefront-level: statistics + the X-Y cross product; lds != nullptr: the columns are already there (filled by the workgroup)
 template <int T>
-__device__ __forceinline__ void fzs_load_xy(const FzsDev &P, int X, int Y, FzsXY<T> &H)
+__device__ __forceinline__ void fzs_load_xy(const FzsDev &P, int X, int Y, FzsXY<T> &H, const float *lds)
 {
     const int lane = threadIdx.x & 63;
     H.cx = P.data + (size_t)X * P.n;
@@ -107,41 +119,99 @@ __device__ __forceinline__ void fzs_load_xy(const FzsDev &P, int X, int Y, FzsXY
     H.ssx = P.st[2 * (size_t)X + 1];
     H.muy = P.st[2 * (size_t)Y];
     H.ssy = P.st[2 * (size_t)Y + 1];
+    H.lx = (const float4 *)lds;
+    H.ly = (const float4 *)(lds + FZS_LDS_N);
     double s = 0.0;
     if (T > 0) {
         const int n4 = P.n >> 2;
-#pragma unroll
-        for (int t = 0; t < (T > 0 ? T : 1); ++t) {
-            const int q = lane + 64 * t;
-            const bool in = q < n4;
-            const float4 z0 = make_float4(0.f, 0.f, 0.f, 0.f);
-            H.x[t] = in ? ((const float4 *)H.cx)[q] : z0;
-            H.y[t] = in ? ((const float4 *)H.cy)[q] : z0;
-            if (in) {  // (masked lanes: x = 0 contributes nothing whatever the deviation of y)
-                s = fma((double)H.x[t].x, (double)H.y[t].x - H.muy, s);
-                s = fma((double)H.x[t].y, (double)H.y[t].y - H.muy, s);
-                s = fma((double)H.x[t].z, (double)H.y[t].z - H.muy, s);
-                s = fma((double)H.x[t].w, (double)H.y[t].w - H.muy, s);
-            }
+        for (int q = lane; q < n4; q += 64) {
+            const float4 x = H.lx[q], y = H.ly[q];
+            s = fma((double)x.x, (double)y.x - H.muy, s);
+            s = fma((double)x.y, (double)y.y - H.muy, s);
+            s = fma((double)x.z, (double)y.z - H.muy, s);
+            s = fma((double)x.w, (double)y.w - H.muy, s);
         }
     } else {
         for (int i = lane; i < P.n; i += 64) s = fma((double)H.cx[i], (double)H.cy[i] - H.muy, s);
     }
-    H.sxy = fzs_wave_sum(s);
+    H.sxy = fzs_uniform(fzs_wave_sum(s));
 }
 
-// K = compile-time bound of the conditioning-set size (register arrays); every lane returns the same result
-template <int K, int T>
-__device__ __forceinline__ FzsRes fzs_test_wave(const FzsDev &P, const FzsXY<T> &H, const int *zs, int k)
-{
-    constexpr int M = K + 2;
-    FzsRes res;
-    if ((long long)P.n < P.n_obs_min) {  // sufficient_power(X, Y, data, test_obj, n_obs_min), tests.jl:9-12,252
-        res.stat = 0.0;
-        res.pval = 1.0;
-        res.power = 0;
-        return res;
+// ---- from the sums to the p-value ---------------------------------------------------------------------------------------------
+// pairwise correlations from the cross products, conditioned on Z_k, ..., Z_1 (StatsBase._partialcor unrolled), clampcor, p-value.
+// A wavefront first STREAMS up to G tests (fzs_stream: sums into the test's LDS slot), then FINISHES them together (fzs_finish):
+// one lane per pair (a, b) of a test, LPT lanes per test.  The M (M - 1) / 2 correlations of a conditioning step are independent,
+// so the lanes of a test update them side by side (K = 3: 3 steps of one division + two square roots instead of 10 such updates one
+// after the other on every lane), the pivot column comes out of LDS, the working set is one register instead of ~150, and the
+// log / erfc sequence of the p-value is paid once per G tests.  Same formula and order per element as the sequential form (the
+// first r03 version: 1.8e8 tests/s; this one: see profiles/r03_fzs_micro.json).
+#ifndef FZS_GMAX
+#define FZS_GMAX 4
+#endif
+template <int K>
+struct FzsLay {
+    static constexpr int M = K + 2, PAIRS = M * (M - 1) / 2;
+    static constexpr int LPT = PAIRS <= 4 ? 4 : (PAIRS <= 16 ? 16 : 32);           // lanes per test
+    static constexpr int G = (64 / LPT) < FZS_GMAX ? (64 / LPT) : FZS_GMAX;        // tests finished together
+    // slot of a test (doubles): centred cross products s[a * M + b] (a < b), sums of squared deviations, working correlations,
+    // {statistic, p-value}.  (By value through the stack the sums were 15 KB of scratch written and read back per test: 266 GB of
+    // HBM writes in the micro-benchmark, a third of the algorithmic bytes.)
+    static constexpr int SS = M * M, WORK = M * M + M, RES = 2 * M * M + M, QD = 2 * M * M + M + 2;
+};
+#define FZS_WAVE_SYNC()                                        \
+    {                                                          \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
     }
+
+template <int K>
+__device__ __noinline__ void fzs_finish(double *q, const int *mm, int ng, double zscale)
+{
+    using L = FzsLay<K>;
+    constexpr int M = L::M;
+    const int lane = threadIdx.x & 63;
+    const int g = lane / L::LPT, pi = lane % L::LPT;
+    int la = 0, off = pi;  // pair index -> (a, b), a < b, row by row
+#pragma unroll
+    for (int i = 0; i < M - 1; ++i)
+        if (la == i && off >= M - 1 - i) {
+            off -= M - 1 - i;
+            la = i + 1;
+        }
+    const int lb = la + 1 + off;
+    const bool live = g < ng && g < L::G && pi < L::PAIRS;
+    double *qs = q + (live ? g : 0) * L::QD;
+    const int m = live ? mm[g] : 0;
+    int mmax = 2;
+    for (int i = 0; i < ng; ++i) mmax = mm[i] > mmax ? mm[i] : mmax;
+    mmax = __builtin_amdgcn_readfirstlane(mmax);
+    const bool pair = live && lb < m;
+    double R = pair ? qs[la * M + lb] / sqrt(qs[L::SS + la] * qs[L::SS + lb]) : 0.0;
+    for (int t = mmax - 1; t >= 2; --t) {
+        if (pair) qs[L::WORK + la * M + lb] = R;
+        FZS_WAVE_SYNC()
+        if (pair && lb < t && t < m) {
+            const double rat = qs[L::WORK + la * M + t], rbt = qs[L::WORK + lb * M + t];
+            R = (R - rat * rbt) / (sqrt(1.0 - rat * rat) * sqrt(1.0 - rbt * rbt));
+        }
+        FZS_WAVE_SYNC()
+    }
+    if (R < -1.0) R = -1.0;  // Statistics.clampcor
+    if (R > 1.0) R = 1.0;
+    const double pv = fzs_pval(R, zscale);
+    if (live && pi == 0) {  // pair (0, 1)
+        qs[L::RES] = R;
+        qs[L::RES + 1] = pv;
+    }
+    FZS_WAVE_SYNC()
+}
+
+// K = compile-time bound of the conditioning-set size (register arrays); the sums of the test land in its LDS slot qs
+template <int K, int T>
+__device__ __forceinline__ void fzs_stream(const FzsDev &P, const FzsXY<T> &H, const int *zs, int k, double *qs)
+{
+    using L = FzsLay<K>;
+    constexpr int M = K + 2;
     const int lane = threadIdx.x & 63;
     const int m = k + 2;
     const float *col[K > 0 ? K : 1];
@@ -179,26 +249,24 @@ __device__ __forceinline__ FzsRes fzs_test_wave(const FzsDev &P, const FzsXY<T> 
     }
     if (T > 0) {
         const int n4 = P.n >> 2;
+#pragma unroll 2
+        for (int q = lane; q < n4; q += 64) {
+            float4 z4[K > 0 ? K : 1];
 #pragma unroll
-        for (int t = 0; t < (T > 0 ? T : 1); ++t) {
-            const int q = lane + 64 * t;
-            if (q < n4) {
-                float4 z4[K > 0 ? K : 1];
-#pragma unroll
-                for (int j = 0; j < K; ++j) z4[j] = ((const float4 *)col[j])[q];  // all loads of the row in flight together
+            for (int j = 0; j < K; ++j) z4[j] = ((const float4 *)col[j])[q];  // the k loads of a row in flight together
+            const float4 x4 = H.lx[q], y4 = H.ly[q];
 #define ZX(j) z4[j].x
 #define ZY(j) z4[j].y
 #define ZZ(j) z4[j].z
 #define ZW(j) z4[j].w
-                FZS_ACC(H.x[t].x, H.y[t].x, ZX)
-                FZS_ACC(H.x[t].y, H.y[t].y, ZY)
-                FZS_ACC(H.x[t].z, H.y[t].z, ZZ)
-                FZS_ACC(H.x[t].w, H.y[t].w, ZW)
+            FZS_ACC(x4.x, y4.x, ZX)
+            FZS_ACC(x4.y, y4.y, ZY)
+            FZS_ACC(x4.z, y4.z, ZZ)
+            FZS_ACC(x4.w, y4.w, ZW)
 #undef ZX
 #undef ZY
 #undef ZZ
 #undef ZW
-            }
         }
     } else {
         for (int i = lane; i < P.n; i += 64) {
@@ -217,28 +285,14 @@ __device__ __forceinline__ FzsRes fzs_test_wave(const FzsDev &P, const FzsXY<T> 
         for (int b = a + 1; b < M; ++b)
             if (b >= 2 && b < m) S[a][b] = fzs_wave_sum(S[a][b]);
     S[0][1] = H.sxy;
-    // pairwise correlations, then condition on Z_k, ..., Z_1
-    double R[M][M];
+    if (lane == 0) {
 #pragma unroll
-    for (int a = 0; a < M; ++a)
+        for (int a = 0; a < M; ++a) {
+            qs[L::SS + a] = ss[a];
 #pragma unroll
-        for (int b = a + 1; b < M; ++b) R[a][b] = (b < m) ? S[a][b] / sqrt(ss[a] * ss[b]) : 0.0;
-#pragma unroll
-    for (int t = M - 1; t >= 2; --t)
-        if (t < m) {
-#pragma unroll
-            for (int a = 0; a < t; ++a)
-#pragma unroll
-                for (int b = a + 1; b < t; ++b)
-                    R[a][b] = (R[a][b] - R[a][t] * R[b][t]) / (sqrt(1.0 - R[a][t] * R[a][t]) * sqrt(1.0 - R[b][t] * R[b][t]));
+            for (int b = a + 1; b < M; ++b) qs[a * M + b] = S[a][b];
         }
-    double r = R[0][1];
-    if (r < -1.0) r = -1.0;  // Statistics.clampcor
-    if (r > 1.0) r = 1.0;
-    res.stat = r;
-    res.pval = fzs_pval(r, P.zscale);
-    res.power = 1;
-    return res;
+    }
 }
 
 template <int K, int T>
@@ -253,15 +307,37 @@ __global__ __launch_bounds__(256) void fzs_test_batch_kernel(FzsDev P, long long
     int zs[K > 0 ? K : 1];
 #pragma unroll
     for (int q = 0; q < K; ++q) zs[q] = __builtin_amdgcn_readfirstlane((q < k) ? zflat[zoff[t] + q] : 0);
+    // explicit tests: every wavefront has its own X and Y -> its own LDS slot (T > 0)
+    __shared__ __attribute__((aligned(16))) float s_xy[T > 0 ? 4 : 1][T > 0 ? 2 * FZS_LDS_N : 4];
+    const int Xu = __builtin_amdgcn_readfirstlane(X[t]), Yu = __builtin_amdgcn_readfirstlane(Y[t]);
+    if (T > 0) {
+        const int n4 = P.n >> 2;
+        float4 *dx = (float4 *)s_xy[wave], *dy = (float4 *)(s_xy[wave] + FZS_LDS_N);
+        const float4 *gx = (const float4 *)(P.data + (size_t)Xu * P.n), *gy = (const float4 *)(P.data + (size_t)Yu * P.n);
+        for (int q = lane; q < n4; q += 64) {
+            dx[q] = gx[q];
+            dy[q] = gy[q];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     FzsXY<T> H;
-    fzs_load_xy<T>(P, __builtin_amdgcn_readfirstlane(X[t]), __builtin_amdgcn_readfirstlane(Y[t]), H);
-    const FzsRes r = fzs_test_wave<K, T>(P, H, zs, k);
+    fzs_load_xy<T>(P, Xu, Yu, H, s_xy[T > 0 ? wave : 0]);
+    __shared__ double s_q[4][FzsLay<K>::QD];
+    __shared__ int s_m[4][FZS_GMAX];
+    const bool power = (long long)P.n >= P.n_obs_min;  // sufficient_power(X, Y, data, test_obj, n_obs_min), tests.jl:9-12,252
+    if (power) {
+        fzs_stream<K, T>(P, H, zs, k, s_q[wave]);
+        if (lane == 0) s_m[wave][0] = k + 2;
+        FZS_WAVE_SYNC()
+        fzs_finish<K>(s_q[wave], s_m[wave], 1, P.zscale);
+    }
     if (lane == 0) {
         fw_test_result o;
-        o.stat = r.stat;
-        o.pval = r.pval;
+        o.stat = power ? s_q[wave][FzsLay<K>::RES] : 0.0;
+        o.pval = power ? s_q[wave][FzsLay<K>::RES + 1] : 1.0;
         o.df = 0;
-        o.suff_power = r.power;
+        o.suff_power = power ? 1 : 0;
         out[t] = o;
     }
 }
@@ -269,8 +345,11 @@ __global__ __launch_bounds__(256) void fzs_test_batch_kernel(FzsDev P, long long
 // test_subsets segments: 4 wavefronts per workgroup, wavefront w evaluates a run of consecutive ranks (tests.jl:281-346;
 // same segment / merge protocol as the other kinds: first stop, else the (p, rank) maximum with "later wins ties")
 #define FZS_RUN 16  // (r02: 4; the wavefront now pays for X and Y once per run)
+#ifndef FZS_SEG_OCC
+#define FZS_SEG_OCC 4  // workgroups per CU (= waves per SIMD) the segment kernel is compiled for; 3 / 4 / 5: 3.31 / 3.67 / 1.65 e8 tests/s (5: spills inside the loop)
+#endif
 template <int K, int T>
-__global__ __launch_bounds__(256) void fzs_subsets_seg_kernel(FzsDev P, const FwSeg *__restrict__ segs,
+__global__ __launch_bounds__(256, FZS_SEG_OCC) void fzs_subsets_seg_kernel(FzsDev P, const FwSeg *__restrict__ segs,
                                                               const int32_t *__restrict__ accflat, FwSegOut *__restrict__ out,
                                                               int max_k, double alpha, long long max_tests)
 {
@@ -280,13 +359,28 @@ __global__ __launch_bounds__(256) void fzs_subsets_seg_kernel(FzsDev P, const Fw
     __shared__ unsigned int s_evc[4];
     const FwSeg seg = segs[blockIdx.x];
     const int a = seg.acc_len;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int32_t *gacc = accflat + seg.acc_off;
     const unsigned long long NONE = FW_RANK_NONE;
     double best_p = -1.0, best_stat = 0.0;
     unsigned long long best_rank = 0, evaluated = 0;
     const unsigned long long len = seg.end - seg.start;
     const int R = (int)((len + 3) / 4 < FZS_RUN ? (len + 3) / 4 : FZS_RUN);
+    // X and Y of the segment's job: one LDS copy for the four wavefronts
+    __shared__ __attribute__((aligned(16))) float s_xy[T > 0 ? 2 * FZS_LDS_N : 4];
+    using L = FzsLay<K>;
+    __shared__ double s_q[4][L::G * L::QD];
+    __shared__ int s_m[4][FZS_GMAX];
+    const bool power = (long long)P.n >= P.n_obs_min;  // sufficient_power(X, Y, data, test_obj, n_obs_min), tests.jl:9-12,252
+    if (T > 0) {
+        const int n4 = P.n >> 2;
+        const float4 *gx = (const float4 *)(P.data + (size_t)seg.X * P.n), *gy = (const float4 *)(P.data + (size_t)seg.Y * P.n);
+        for (int q = threadIdx.x; q < n4; q += 256) {
+            ((float4 *)s_xy)[q] = gx[q];
+            ((float4 *)(s_xy + FZS_LDS_N))[q] = gy[q];
+        }
+        __syncthreads();
+    }
     FzsXY<T> H;
     bool xy_loaded = false;
     for (unsigned long long cbase = seg.start; cbase < seg.end; cbase += 4ull * R) {
@@ -309,39 +403,62 @@ __global__ __launch_bounds__(256) void fzs_subsets_seg_kernel(FzsDev P, const Fw
             for (int q = 0; q < K; ++q) pos[q] = 0;
             fw_unrank_comb(rem, a, s, pos);
             if (!xy_loaded) {  // X and Y of the job: once per wavefront and segment
-                fzs_load_xy<T>(P, seg.X, seg.Y, H);
+                fzs_load_xy<T>(P, seg.X, seg.Y, H, s_xy);
                 xy_loaded = true;
             }
-            for (unsigned long long r = r0; r < r1; ++r) {
-                int zs[K > 0 ? K : 1];
+            for (unsigned long long r = r0; r < r1;) {
+                // stream up to G consecutive ranks, finish them together
+                int ng = 0;
+                unsigned long long rg = r;
+                while (ng < L::G && rg < r1 && s >= 1) {
+                    if (power) {
+                        int zs[K > 0 ? K : 1];
 #pragma unroll
-                for (int q = 0; q < K; ++q) zs[q] = __builtin_amdgcn_readfirstlane((q < s) ? gacc[pos[q]] : 0);
-                const FzsRes t = fzs_test_wave<K, T>(P, H, zs, s);
-                ++my_done;
-                const bool sig = (t.pval < alpha) && t.power;
-                if (!sig || (max_tests > 0 && r + 1 >= (unsigned long long)max_tests)) {
-                    my_stop = r;
-                    stop_stat = t.stat;
-                    stop_p = t.pval;
-                    stop_pow = t.power;
-                    break;
-                }
-                if (t.pval >= my_bp) {
-                    my_bp = t.pval;
-                    my_br = r;
-                    my_bstat = t.stat;
-                }
-                int i = s - 1;
-                while (i >= 0 && pos[i] == a - s + i) --i;
-                if (i < 0) {
-                    --s;
+                        for (int q = 0; q < K; ++q) zs[q] = __builtin_amdgcn_readfirstlane((q < s) ? gacc[pos[q]] : 0);
+                        fzs_stream<K, T>(P, H, zs, s, s_q[wave] + ng * L::QD);  // (s uniform: scalar branches on k)
+                        if (lane == 0) s_m[wave][ng] = s + 2;
+                    }
+                    ++ng;
+                    ++rg;
+                    int i = s - 1;  // next subset (sizes max_k .. 1, lexicographic inside a size)
+                    while (i >= 0 && pos[i] == a - s + i) --i;
+                    if (i < 0) {
+                        --s;
 #pragma unroll
-                    for (int q = 0; q < K; ++q) pos[q] = q;
-                    if (s < 1) break;
-                } else {
-                    ++pos[i];
-                    for (int j = i + 1; j < s; ++j) pos[j] = pos[j - 1] + 1;
+                        for (int q = 0; q < K; ++q) pos[q] = q;
+                    } else {
+                        ++pos[i];
+                        for (int j = i + 1; j < s; ++j) pos[j] = pos[j - 1] + 1;
+                    }
                 }
+                if (power) {
+                    FZS_WAVE_SYNC()
+                    fzs_finish<K>(s_q[wave], s_m[wave], ng, P.zscale);
+                }
+                my_done += (unsigned int)ng;
+                bool stopped = false;
+                for (int g = 0; g < ng; ++g) {
+                    const double t_stat = power ? fzs_uniform(s_q[wave][g * L::QD + L::RES]) : 0.0;
+                    const double t_pval = power ? fzs_uniform(s_q[wave][g * L::QD + L::RES + 1]) : 1.0;
+                    const unsigned long long rr = r + (unsigned long long)g;
+                    const bool sig = (t_pval < alpha) && power;
+                    if (!sig || (max_tests > 0 && rr + 1 >= (unsigned long long)max_tests)) {
+                        my_stop = rr;
+                        stop_stat = t_stat;
+                        stop_p = t_pval;
+                        stop_pow = power ? 1 : 0;
+                        stopped = true;
+                        break;
+                    }
+                    if (t_pval >= my_bp) {
+                        my_bp = t_pval;
+                        my_br = rr;
+                        my_bstat = t_stat;
+                    }
+                }
+                if (stopped || s < 1) break;
+                FZS_WAVE_SYNC()  // (the slots are rewritten by the next group)
+                r = rg;
             }
         }
         if (lane == 0) {
@@ -433,7 +550,7 @@ int fzs_ensure_stat(fw_ctx *ctx, hipStream_t st)
     return FW_OK;
 }
 
-// X / Y columns in registers: n a multiple of 4 (16-byte rows) and at most 2048 samples (8 float4 per lane and column)
+// X / Y columns in LDS: n a multiple of 4 (16-byte rows) and at most FZS_LDS_N samples
 bool fzs_hold_xy(const fw_ctx *ctx) { return ctx->P.n % 4 == 0 && ctx->P.n <= 2048; }
 
 }  // namespace
