@@ -548,6 +548,11 @@ def main():
                     "alg_bytes_per_launch": rcn["alg_bytes_subsets"] / n_sub_launches,
                     "avg_launch_us": 1e6 * sub_launch_s / n_sub_launches, "launches": n_sub_launches,
                     "evaluated_tests_per_s_in_kernel": rcn["cond_tests_evaluated"] / max(sub_launch_s, 1e-12)}
+        if args.stream_columns:
+            # variant S: X / Y of a job are held in LDS and a job's accepted columns stay in L2, so the kernel runs ABOVE the nominal
+            # HBM rate of tests that share nothing (profiles/r03_fzs_micro_pmc.json: 18 % of the algorithmic bytes cross the fabric)
+            roofline["bound"] = "valu" if roofline["frac"] > 1.0 else "hbm"
+            roofline["served_by"] = "LDS (X, Y) + L2 (accepted columns of the job); profiles/r03_fzs_micro_pmc.json"
         sub_launch_s = cn["t_dev_subsets_s"]  # the stage table below reports the headline pass
         cpu, cpu_skipped = None, None
         if world > 1:
