@@ -91,6 +91,10 @@ struct DhParams {
     unsigned int mi_heavy;     // targets with at least this many candidates never work on other targets' boards (0: off)
     unsigned int mi_seq_heavy; // ... and run this many first tests of a job alone (instead of mi_seq) before they open a board
     unsigned int mi_seq_tail;  // ... and every target this many once the target list is exhausted (idle wavefronts are waiting for work)
+    unsigned int mi_chunk_tail, mi_win0_tail;  // ranks per record / first window once the launch is in its tail (idle wavefronts waiting)
+    unsigned int mi_team;      // the first mi_team targets of the (heaviest-first) list are run by a whole workgroup each (dh_mi_team)
+    unsigned int mi_team_tail;   // team targets publish tail-mode boards (short records, wide first window) from the start
+    unsigned int mi_team_steps;  // lock-step rounds of a team job (4 wavefronts x 1 or 4 ranks each) before its enumeration goes to a board
     int spec0_depth;                // interleaving-phase look-ahead (first windows of the next candidates)
     unsigned long long spec0_below;
     unsigned int spec0_jobs;  // ... and fewer live jobs than this
@@ -267,6 +271,8 @@ struct DhMerge {
     int pow;
     unsigned long long nt;  // stop: tests up to and including the stopping one
     unsigned long long ev;  // tests executed by the segments
+    double g;               // mi_merge, !stop: G^2 and df of the maximum-p test (the seed of later records of the job)
+    int df;
 };
 
 __device__ __forceinline__ DhMerge dh_merge(const FwSegOut *__restrict__ so, long long base, int nseg, int lane)
@@ -325,6 +331,8 @@ __device__ __forceinline__ DhMerge dh_merge(const FwSegOut *__restrict__ so, lon
         M.pow = 1;
         M.nt = 0ull;
     }
+    M.g = 0.0;
+    M.df = 0;
     return M;
 }
 
@@ -382,6 +390,10 @@ __shared__ unsigned short dh_mi_tab[4][MI_TAB16];
 
 __shared__ int32_t dh_mi_acc[4][1024];  // a helper's copy of the accepted list of the board it works on (MI_ACC_LDS)
 __shared__ DhTgt dh_mi_x[4];            // the state of the target each wavefront of dh_mi_target_kernel is working on
+__shared__ MiBest dh_mi_seed[4];        // the seed a wavefront hands to the test routine (mi_run_ranks)
+#ifdef FW_MI_TICKS
+__shared__ unsigned long long dh_mi_ticks[4][6];  // per wavefront: calls, tests, ticks in the prologue / the test core / the accounting (Q) / sizes
+#endif
 
 // Everything two wavefronts share travels as write-through messages: the producer stores with sc1 (relaxed agent-scope atomic
 // stores: the line leaves its XCD's L2), drains them with `s_waitcnt vmcnt(0)` (inline asm: the compiler drops the builtin
@@ -397,13 +409,16 @@ struct MiBoard {
     unsigned long long nr;        // nch | res_off << 32        (records of the window: res[res_off .. res_off + nch))
     unsigned long long stop_min;  // smallest stopping rank found so far (FW_RANK_NONE: none)
     unsigned int next_chunk, done;  // claimed / finished records
-    unsigned int ready, pad;
+    unsigned int ready, seed_df;
+    double seed_p, seed_g;        // the job's maximum-p test so far (seed_p < 0: none): records skip the Q(a, x) of tests it dominates
 };
 
 struct MiQueue {
-    unsigned int next_target, targets_done, n_boards, hint, res_top, bacc_top, pad[2];
+    unsigned int next_target, targets_done, n_boards, hint, res_top, bacc_top, pad[1], next_team;  // pad[0]: watchdog code
     unsigned long long t_body, t_ctl, t_sleep, n_seg;  // dh_mi_target_kernel: 100 MHz ticks summed over wavefronts (FW_TRACE_HOST; see the end of the kernel)
     unsigned long long t_total;  // dh_mi_target_kernel: ticks until the wavefront ran out of targets (the fields above: see its end)
+    unsigned long long tick[6];  // FW_MI_TICKS builds: calls of the test routine, tests, ticks before / in the test core / in the accounting, sum of set sizes
+    unsigned long long tm_run, tm_wait, tm_steps, tm_tests;  // dh_mi_team: ticks inside the test routine / at the barrier behind it, lock-step rounds, tests in them (all wavefronts)
 };
 
 #define MI_BACC_CAP (1u << 22)  // ints of accepted-list copies per launch
@@ -435,7 +450,7 @@ __device__ __forceinline__ unsigned long long mi_rfl_lane64(unsigned long long v
 template <int L, int NXY, bool PRE>
 __device__ __noinline__ FwSegOut mi_run_ranks(const MiDev M_in, int T, int cand, const int32_t *__restrict__ acc_in, int a, int max_k,
                                               long long max_tests, unsigned long long r0, unsigned long long r1,
-                                              const unsigned long long *stop_min_in, int remote_acc)
+                                              const unsigned long long *stop_min_in, int remote_acc, const MiBest *seed_in)
 {
     unsigned short *tab = dh_mi_tab[threadIdx.x >> 6];
     const MiDev M = mi_uniform(M_in);
@@ -457,29 +472,74 @@ __device__ __noinline__ FwSegOut mi_run_ranks(const MiDev M_in, int T, int cand,
     o.best_pval = -3.0;  // "no test": dh_merge ignores it
     o.stop_df = o.stop_power = o.best_df = o.pad = 0;
     o.evaluated = 0ull;
-    unsigned long long rem = r0;
     int s = max_k;
-    while (s > 1 && rem >= fw_binom_u64(a, s)) {
-        rem -= fw_binom_u64(a, s);
-        --s;
-    }
     int pos[MI_MAX_K];
 #pragma unroll
     for (int q = 0; q < MI_MAX_K; ++q) pos[q] = 0;
-    fw_unrank_comb(rem, a, s, pos);
+    if (max_k <= 3 && a <= FW_UNRANK32_A) {
+        // every rank of the job fits 28 bits: 32-bit binomials, divisions by constants (fw_unrank.h: ~100 instructions instead of
+        // ~1 500 -- the r03 trace of cfg4 showed 9.3 us of prologue per call of this routine, as much as a test)
+        uint32_t rem = (uint32_t)r0;
+        while (s > 1 && rem >= fw_binom32(a, s)) {
+            rem -= fw_binom32(a, s);
+            --s;
+        }
+        fw_unrank_comb32(rem, a, s, pos);
+    } else {
+        unsigned long long rem = r0;
+        while (s > 1 && rem >= fw_binom_u64(a, s)) {
+            rem -= fw_binom_u64(a, s);
+            --s;
+        }
+        fw_unrank_comb(rem, a, s, pos);
+    }
+    // the maximum-p record the job holds so far (seed: what earlier ranks of the job found -- LDS, every lane reads the same words).
+    // A test the seed dominates (mi_account: df <= and G^2 >) skips its Q(a, x); without a seed every record pays one Q for its
+    // first significant test -- 18-25 us at cfg4, three tests' worth.  A record reports a maximum only if it improved on the seed.
+    const MiBest *seed = (const MiBest *)mi_rfl64((unsigned long long)seed_in);
     MiBest mb;
     mb.p = -3.0;
     mb.stat = mb.g = 0.0;
     mb.df = 0;
+    if (seed) {
+        mb.p = seed->p;
+        mb.stat = seed->stat;
+        mb.g = seed->g;
+        mb.df = seed->df;
+    }
+#ifdef FW_MI_TICKS
+    unsigned long long *tkw = dh_mi_ticks[threadIdx.x >> 6];
+    unsigned long long tka = wall_clock64();
+    if ((threadIdx.x & 63) == 0) tkw[0] += 1ull;
+#endif
     for (unsigned long long r = r0; r < r1; ++r) {
         if (stop_min && mi_ld_u64(stop_min) < r) break;  // an earlier rank already ended the job
         MiZs zs;
 #pragma unroll
         for (int q = 0; q < MI_MAX_K; ++q)  // remote_acc: another wavefront's list, read where it was written through (sc1)
             zs.v[q] = (q < s) ? (remote_acc ? __hip_atomic_load(&acc[pos[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : acc[pos[q]]) : 0;
+#ifdef FW_MI_TICKS
+        const unsigned long long tkb = wall_clock64();
+#endif
         MiRes t = mi_test_core<L, NXY, PRE>(M, T, cand, zs, s, tab);
         ++o.evaluated;
+#ifdef FW_MI_TICKS
+        const unsigned long long tkc = wall_clock64();
+#endif
         const int ev = mi_account(M, t, max_tests > 0 && r + 1ull >= (unsigned long long)max_tests, mb, false);  // tests.jl:326-341
+#ifdef FW_MI_TICKS
+        {
+            const unsigned long long tkd = wall_clock64();
+            if ((threadIdx.x & 63) == 0) {
+                tkw[1] += 1ull;
+                tkw[2] += tkb - tka;
+                tkw[3] += tkc - tkb;
+                tkw[4] += tkd - tkc;
+                tkw[5] += (unsigned long long)s;
+            }
+            tka = tkd;
+        }
+#endif
         if (ev == 1) {
             o.stop_rank = r;
             o.stop_stat = t.stat;
@@ -493,6 +553,7 @@ __device__ __noinline__ FwSegOut mi_run_ranks(const MiDev M_in, int T, int cand,
             o.best_stat = mb.stat;
             o.best_rank = r;
             o.best_df = mb.df;
+            o.stop_stat = mb.g;  // (records without a stop: G^2 of the maximum-p test, the seed of later records)
         }
         int i = s - 1;  // next subset of this size in lexicographic order of the positions, then the next size down
         while (i >= 0 && pos[i] == a - s + i) --i;
@@ -516,7 +577,7 @@ __device__ __noinline__ FwSegOut mi_run_ranks(const MiDev M_in, int T, int cand,
 template <int L>
 __device__ __noinline__ FwSegOut mi_run_ranks4(const MiDev M_in, int T, int cand, const int32_t *__restrict__ acc_in, int a, int max_k,
                                                long long max_tests, unsigned long long r0, unsigned long long r1,
-                                               const unsigned long long *stop_min_in, int remote_acc)
+                                               const unsigned long long *stop_min_in, int remote_acc, const MiBest *seed_in)
 {
     unsigned short *tab = dh_mi_tab[threadIdx.x >> 6];
     const MiDev M = mi_uniform(M_in);
@@ -539,26 +600,45 @@ __device__ __noinline__ FwSegOut mi_run_ranks4(const MiDev M_in, int T, int cand
     o.best_pval = -3.0;
     o.stop_df = o.stop_power = o.best_df = o.pad = 0;
     o.evaluated = 0ull;
-    unsigned long long rem = r0;
     int s = max_k;
-    while (s > 1 && rem >= fw_binom_u64(a, s)) {
-        rem -= fw_binom_u64(a, s);
-        --s;
-    }
     int p0 = 0, p1 = 0, p2 = 0;  // positions of the running subset (s <= 3), scalar
     {
         int pos[MI_MAX_K];
 #pragma unroll
         for (int q = 0; q < MI_MAX_K; ++q) pos[q] = 0;
-        fw_unrank_comb(rem, a, s, pos);
+        if (a <= FW_UNRANK32_A) {  // (max_k <= 3 here: 32-bit binomials, see mi_run_ranks)
+            uint32_t rem = (uint32_t)r0;
+            while (s > 1 && rem >= fw_binom32(a, s)) {
+                rem -= fw_binom32(a, s);
+                --s;
+            }
+            fw_unrank_comb32(rem, a, s, pos);
+        } else {
+            unsigned long long rem = r0;
+            while (s > 1 && rem >= fw_binom_u64(a, s)) {
+                rem -= fw_binom_u64(a, s);
+                --s;
+            }
+            fw_unrank_comb(rem, a, s, pos);
+        }
         p0 = pos[0];
         p1 = pos[1];
         p2 = pos[2];
     }
+    // the maximum-p record the job holds so far (seed: what earlier ranks of the job found -- LDS, every lane reads the same words).
+    // A test the seed dominates (mi_account: df <= and G^2 >) skips its Q(a, x); without a seed every record pays one Q for its
+    // first significant test -- 18-25 us at cfg4, three tests' worth.  A record reports a maximum only if it improved on the seed.
+    const MiBest *seed = (const MiBest *)mi_rfl64((unsigned long long)seed_in);
     MiBest mb;
     mb.p = -3.0;
     mb.stat = mb.g = 0.0;
     mb.df = 0;
+    if (seed) {
+        mb.p = seed->p;
+        mb.stat = seed->stat;
+        mb.g = seed->g;
+        mb.df = seed->df;
+    }
     unsigned long long r = r0;
     while (r < r1 && s >= 1) {
         if (stop_min && mi_ld_u64(stop_min) < r) break;  // an earlier rank already ended the job
@@ -639,6 +719,7 @@ __device__ __noinline__ FwSegOut mi_run_ranks4(const MiDev M_in, int T, int cand
                 o.best_stat = mb.stat;
                 o.best_rank = rr;
                 o.best_df = mb.df;
+                o.stop_stat = mb.g;  // (records without a stop: G^2 of the maximum-p test, the seed of later records)
             }
         }
         if (stopped) break;
@@ -651,12 +732,12 @@ __device__ __noinline__ FwSegOut mi_run_ranks4(const MiDev M_in, int T, int cand
 template <int L, int NXY, bool PRE, bool R4>
 __device__ __forceinline__ FwSegOut mi_run_ranks_sel(const MiDev &M, int T, int cand, const int32_t *__restrict__ acc, int a, int max_k,
                                                      long long max_tests, unsigned long long r0, unsigned long long r1,
-                                                     const unsigned long long *stop_min, int remote_acc)
+                                                     const unsigned long long *stop_min, int remote_acc, const MiBest *seed)
 {
     if constexpr (R4)
-        return mi_run_ranks4<L>(M, T, cand, acc, a, max_k, max_tests, r0, r1, stop_min, remote_acc);
+        return mi_run_ranks4<L>(M, T, cand, acc, a, max_k, max_tests, r0, r1, stop_min, remote_acc, seed);
     else
-        return mi_run_ranks<L, NXY, PRE>(M, T, cand, acc, a, max_k, max_tests, r0, r1, stop_min, remote_acc);
+        return mi_run_ranks<L, NXY, PRE>(M, T, cand, acc, a, max_k, max_tests, r0, r1, stop_min, remote_acc, seed);
 }
 
 // one record = 9 64-bit words (FwSegOut), written through / read back word by word
@@ -688,8 +769,8 @@ __device__ __forceinline__ DhMerge mi_merge(const FwSegOut *__restrict__ so, lon
     double st_stat = 0.0, st_p = 0.0;
     int st_pow = 0;
     unsigned long long st_rank = 0ull;
-    double bp = -2.0, bs = 0.0;
-    int bi = -1;
+    double bp = -2.0, bs = 0.0, bg = 0.0;
+    int bi = -1, bdf = 0;
     for (int sg = lane; sg < nseg; sg += 64) {
         const FwSegOut o = mi_record_load(so + base + sg);
         ev += o.evaluated;
@@ -704,6 +785,8 @@ __device__ __forceinline__ DhMerge mi_merge(const FwSegOut *__restrict__ so, lon
         } else if (o.best_pval >= bp) {
             bp = o.best_pval;
             bs = o.best_stat;
+            bg = o.stop_stat;  // (records without a stop carry the G^2 of their maximum here)
+            bdf = o.best_df;
             bi = sg;
         }
     }
@@ -713,11 +796,13 @@ __device__ __forceinline__ DhMerge mi_merge(const FwSegOut *__restrict__ so, lon
         ev += __shfl_xor(ev, o);
         const int f2 = __shfl_xor(first, o);
         first = f2 < first ? f2 : first;
-        const double p2 = __shfl_xor(bp, o), s2 = __shfl_xor(bs, o);
-        const int i2 = __shfl_xor(bi, o);
+        const double p2 = __shfl_xor(bp, o), s2 = __shfl_xor(bs, o), g2 = __shfl_xor(bg, o);
+        const int i2 = __shfl_xor(bi, o), d2 = __shfl_xor(bdf, o);
         if (p2 > bp || (p2 == bp && i2 > bi)) {
             bp = p2;
             bs = s2;
+            bg = g2;
+            bdf = d2;
             bi = i2;
         }
     }
@@ -737,6 +822,8 @@ __device__ __forceinline__ DhMerge mi_merge(const FwSegOut *__restrict__ so, lon
         M.pow = 1;
         M.nt = 0ull;
     }
+    M.g = bg;
+    M.df = bdf;
     return M;
 }
 
@@ -782,8 +869,20 @@ __device__ __forceinline__ bool mi_board_work(MiBoard *__restrict__ b, FwSegOut 
                 remote = 1;
             }
         }
+        const MiBest *seed = nullptr;
+        const double sp = __longlong_as_double((long long)mi_ld_u64((const unsigned long long *)&b->seed_p));
+        if (sp >= 0.0) {
+            MiBest &sd = dh_mi_seed[threadIdx.x >> 6];
+            sd.p = sp;
+            sd.stat = 0.0;  // (never reported: a record reports a maximum only if one of its own tests reaches the seed's p)
+            sd.g = __longlong_as_double((long long)mi_ld_u64((const unsigned long long *)&b->seed_g));
+            sd.df = (int)mi_ld_u32(&b->seed_df);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            seed = &sd;
+        }
         o = mi_run_ranks_sel<L, NXY, PRE, R4>(M, (int)(unsigned int)tc, (int)(unsigned int)(tc >> 32), acc, a, P.max_k, P.max_tests, r0, r1,
-                                      &b->stop_min, remote);
+                                      &b->stop_min, remote, seed);
         if (o.stop_rank != FW_RANK_NONE && lane == 0) atomicMin(&b->stop_min, o.stop_rank);
     }
     if (lane == 0) {
@@ -816,6 +915,281 @@ __device__ __noinline__ bool mi_help(MiQueue *__restrict__ Q, MiBoard *__restric
     return false;
 }
 
+// ---- heavy targets: one WORKGROUP per target -------------------------------------------------------------------------------------
+// cfg4's last feed-forward round (r03 trace, `FW_TRACE_HOST`): the six targets that finish last (126-196 candidates, ~200 jobs each)
+// are taken at t = 0 and end at 39-49 ms of a 48 ms launch, 21 ms of it in the owner's sequential prefixes (16 tests x 7 us, one after
+// the other) and 26 ms in board phases of ~40 tests in which helpers arrive late (every other wavefront is inside a prefix of its own).
+// The chain of such a target is the launch.  So the first mi_team targets of the heaviest-first list get the four wavefronts of a
+// workgroup: the leader (wavefront 0) runs the state machine; every job starts with lock-step rounds in which wavefront w evaluates
+// rank(s) base + w (the records meet in LDS and are merged in rank order exactly like board records: first stop wins, else the
+// `>=` maximum), and what is left of a long enumeration goes to a board as before -- with three helpers that are there at once.
+struct MiTeamJob {
+    int go, cand, a, tail;
+    long long acc_off;
+    unsigned long long N;
+    unsigned int board;       // board of the current window (MI_BOARD_CAP: none, the leader ran the window alone)
+    DhMerge mg;               // merged outcome of the current window
+};
+__shared__ MiTeamJob dh_mi_tj;
+__shared__ FwSegOut dh_mi_trec[2][4];
+
+// allocate + publish a board for ranks [next, next + W) of the job; returns false if the launch is out of board / record space
+__device__ __forceinline__ bool mi_publish(MiQueue *__restrict__ Q, MiBoard *__restrict__ boards, int32_t *__restrict__ bacc, unsigned int &bacc_off,
+                                           const int32_t *__restrict__ acc, int a, int T, int cand, unsigned long long next, unsigned long long W,
+                                           unsigned long long chunk, unsigned int nch, int lane, unsigned int &bi, unsigned int &ro,
+                                           double seed_p, double seed_g, int seed_df)
+{
+    bi = MI_BOARD_CAP;
+    ro = MI_REC_CAP;
+    if (bacc_off == MI_BACC_CAP && mi_ld_u32(&Q->bacc_top) + (unsigned int)a <= MI_BACC_CAP) {
+        bacc_off = mi_wave_add(&Q->bacc_top, (unsigned int)a, lane);
+        if (bacc_off + (unsigned int)a > MI_BACC_CAP) {
+            bacc_off = MI_BACC_CAP;
+        } else {
+            for (int i = lane; i < a; i += 64) __hip_atomic_store(bacc + bacc_off + i, acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (bacc_off != MI_BACC_CAP && mi_ld_u32(&Q->n_boards) < MI_BOARD_CAP && mi_ld_u32(&Q->res_top) + nch <= MI_REC_CAP) {
+        ro = mi_wave_add(&Q->res_top, nch, lane);
+        if (ro + nch <= MI_REC_CAP) bi = mi_wave_add(&Q->n_boards, 1u, lane);
+    }
+    if (bi >= MI_BOARD_CAP) return false;
+    MiBoard *b = boards + bi;
+    mi_drain();  // the copy of the accepted list (every lane's stores) ...
+    if (lane == 0) {
+        mi_st_u64(&b->tc, (unsigned long long)(unsigned int)T | ((unsigned long long)(unsigned int)cand << 32));
+        mi_st_u64(&b->ac, (unsigned long long)(unsigned int)a | ((unsigned long long)chunk << 32));
+        mi_st_u64(&b->acc_off, (unsigned long long)bacc_off);
+        mi_st_u64(&b->start, next);
+        mi_st_u64(&b->end, next + W);
+        mi_st_u64(&b->nr, (unsigned long long)nch | ((unsigned long long)ro << 32));
+        mi_st_u64(&b->stop_min, FW_RANK_NONE);  // next_chunk / done are zero from the launch's memset
+        mi_st_u64((unsigned long long *)&b->seed_p, (unsigned long long)__double_as_longlong(seed_p > 1e-290 ? seed_p : -1.0));  // (p = 0 seeds nothing: ties)
+        mi_st_u64((unsigned long long *)&b->seed_g, (unsigned long long)__double_as_longlong(seed_g));
+        mi_st_u32(&b->seed_df, (unsigned int)seed_df);
+        mi_drain();  // ... and the board before the flag
+        mi_st_u32(&b->ready, 1u);
+    }
+    return true;
+}
+
+// the whole HITON-PC of target t on the four wavefronts of this workgroup (every wavefront calls it; uniform control flow
+// between the barriers: every decision is taken from LDS values all four read)
+template <int L, int NXY, bool PRE, bool R4>
+__device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, const DhArrays &A, const MiDev &M, const DhParams &P, MiQueue *__restrict__ Q,
+                                        MiBoard *__restrict__ boards, FwSegOut *__restrict__ res, int32_t *__restrict__ bacc)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    DhTgt &x = dh_mi_x[0];
+    MiTeamJob &J = dh_mi_tj;
+    if (wave == 0 && lane == 0) {
+        x = tg[t];
+        x.r_first0 = (unsigned int)wall_clock64();
+    }
+    __syncthreads();
+    const unsigned long long per = R4 ? 4ull : 1ull;  // ranks per wavefront and lock-step round
+    for (;;) {
+        if (wave == 0) {
+            const bool more = dh_advance(x, A, lane, 1);
+            if (lane == 0) {
+                J.go = more ? 1 : 0;
+                if (more) {
+                    const int32_t *cands = x.phase == 0 ? A.cand0 + x.cand_off : A.tpc_key + x.co;
+                    J.cand = cands[x.pos];
+                    J.acc_off = DH_ACC_OFF(x, x.cur, 1);
+                    J.a = x.na;
+                    unsigned long long N = 0ull;
+                    for (int s = P.max_k; s >= 1; --s) {
+                        N += fw_binom_u64(x.na, s);
+                        if (N > (1ull << 62)) N = 1ull << 62;
+                    }
+                    if (P.max_tests > 0 && (unsigned long long)P.max_tests < N) N = (unsigned long long)P.max_tests;
+                    J.N = N;
+                    J.tail = (P.mi_team_tail || (mi_ld_u32(&Q->next_target) + P.mi_team >= (unsigned int)ntg &&
+                                                 ((unsigned int)ntg - mi_ld_u32(&Q->targets_done)) * 8u <= gridDim.x * 4u)) ? 1 : 0;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (wave == 0 && J.go && J.a <= MI_ACC_LDS) {  // the job's accepted list: one LDS copy for the four wavefronts (the leader wrote the
+            const int32_t *src = A.acc + J.acc_off;    // global one itself: the others must not meet it in a cache of their own)
+            for (int i = lane; i < J.a; i += 64) dh_mi_acc[0][i] = src[i];
+        }
+        __syncthreads();
+        if (!J.go) break;
+        const int cand = J.cand, a = J.a, T = x.T;
+        const int32_t *acc = a <= MI_ACC_LDS ? (const int32_t *)dh_mi_acc[0] : A.acc + J.acc_off;
+        const unsigned long long N = J.N;
+        const unsigned long long tk1 = wall_clock64();
+        // lock-step rounds: wavefront w takes ranks next + w * per ...
+        unsigned long long next = 0ull, ev = 0ull, nt = 0ull;
+        bool stopped = false;
+        double r_stat = 0.0, r_p = 0.0, best_p = -1.0, best_stat = 0.0, best_g = 0.0;
+        int r_pow = 1, best_df = 0;
+        unsigned int n_rounds = 0u;
+        for (unsigned int step = 0u; !stopped && next < N && step < P.mi_team_steps; ++step) {
+            ++n_rounds;
+            const unsigned long long r0 = next + (unsigned long long)wave * per;
+            unsigned long long r1 = r0 + per;
+            if (r1 > N) r1 = N;
+            FwSegOut o;
+            const unsigned long long tq0 = wall_clock64();
+            if (r0 < N) {
+                const MiBest *seed = nullptr;
+                if (best_p > 1e-290) {  // what the earlier rounds found: the tests it dominates skip their Q(a, x)
+                    MiBest &sd = dh_mi_seed[wave];
+                    sd.p = best_p;
+                    sd.stat = best_stat;
+                    sd.g = best_g;
+                    sd.df = best_df;
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    seed = &sd;
+                }
+                o = mi_run_ranks_sel<L, NXY, PRE, R4>(M, T, cand, acc, a, P.max_k, P.max_tests, r0, r1, nullptr, 0, seed);
+            } else {
+                o.stop_rank = FW_RANK_NONE;
+                o.stop_stat = o.stop_pval = 0.0;
+                o.best_rank = 0ull;
+                o.best_stat = 0.0;
+                o.best_pval = -3.0;
+                o.stop_df = o.stop_power = o.best_df = o.pad = 0;
+                o.evaluated = 0ull;
+            }
+            if (lane == 0) dh_mi_trec[step & 1u][wave] = o;
+            const unsigned long long tq1 = wall_clock64();
+            __syncthreads();  // (two buffers: the records of round s are rewritten in round s + 2, behind the barrier of round s + 1)
+#ifdef FW_MI_TICKS
+            if (lane == 0) {
+                atomicAdd(&Q->tm_run, tq1 - tq0);
+                atomicAdd(&Q->tm_wait, wall_clock64() - tq1);
+                atomicAdd(&Q->tm_steps, 1ull);
+                atomicAdd(&Q->tm_tests, o.evaluated);
+            }
+#else
+            (void)tq0;
+            (void)tq1;
+#endif
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const FwSegOut &q = dh_mi_trec[step & 1u][w];
+                ev += q.evaluated;
+                if (stopped) continue;
+                if (q.stop_rank != FW_RANK_NONE) {
+                    stopped = true;
+                    r_stat = q.stop_stat;
+                    r_p = q.stop_pval;
+                    r_pow = q.stop_power;
+                    nt = q.stop_rank + 1ull;
+                } else if (q.best_pval >= 0.0 && q.best_pval >= best_p) {
+                    best_p = q.best_pval;
+                    best_stat = q.best_stat;
+                    best_g = q.stop_stat;
+                    best_df = q.best_df;
+                }
+            }
+            next += 4ull * per;
+            if (next > N) next = N;
+        }
+        const unsigned long long tk2 = wall_clock64();
+        // ... the rest of a long enumeration: boards (the leader publishes and merges, all four work on the records)
+        const bool tail = J.tail != 0;
+        unsigned long long width = (unsigned long long)(tail ? P.mi_win0_tail : P.mi_win0);
+        const unsigned long long chunk_min = tail ? P.mi_chunk_tail : P.mi_chunk_min;
+        unsigned int bacc_off = MI_BACC_CAP;
+        bool boarded = false;
+        while (!stopped && next < N) {
+            boarded = true;
+            const unsigned long long W = (N - next) < width ? (N - next) : width;
+            unsigned long long chunk = W / (unsigned long long)P.mi_chunk_div;
+            chunk = chunk < chunk_min ? chunk_min : (chunk > P.mi_chunk_max ? P.mi_chunk_max : chunk);
+            const unsigned int nch = (unsigned int)((W + chunk - 1ull) / chunk);
+            if (wave == 0) {
+                unsigned int bi, ro;
+                const bool ok = mi_publish(Q, boards, bacc, bacc_off, acc, a, T, cand, next, W, chunk, nch, lane, bi, ro, best_p, best_g, best_df);
+                if (!ok) {  // out of board space (never at the benchmark sizes): the leader carries on alone
+                    const FwSegOut q = mi_run_ranks_sel<L, NXY, PRE, R4>(M, T, cand, acc, a, P.max_k, P.max_tests, next, next + W, nullptr, 0, nullptr);
+                    if (lane == 0) {
+                        J.mg.g = q.stop_stat;
+                        J.mg.df = q.best_df;
+                        J.mg.stop = q.stop_rank != FW_RANK_NONE;
+                        J.mg.stat = J.mg.stop ? q.stop_stat : q.best_stat;
+                        J.mg.p = J.mg.stop ? q.stop_pval : (q.best_pval < 0.0 ? -2.0 : q.best_pval);
+                        J.mg.pow = q.stop_power;
+                        J.mg.nt = q.stop_rank + 1ull;
+                        J.mg.ev = q.evaluated;
+                    }
+                }
+                if (lane == 0) J.board = ok ? bi : MI_BOARD_CAP;
+            }
+            __syncthreads();
+            const unsigned int bi = J.board;
+            if (bi < MI_BOARD_CAP) {
+                MiBoard *b = boards + bi;
+                while (mi_board_work<L, NXY, PRE, R4>(b, res, bacc, acc, M, P, lane)) {
+                }
+                if (wave == 0) {
+                    unsigned int spins = 0u;
+                    while (mi_ld_u32(&b->done) < nch) {  // records claimed by other wavefronts: they are running
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1u << 27)) {
+                            if (lane == 0) atomicExch(&Q->pad[0], 3u);
+                            break;
+                        }
+                    }
+                    const DhMerge mg = mi_merge(res, (long long)(unsigned int)(mi_ld_u64(&b->nr) >> 32), (int)nch, lane);
+                    if (lane == 0) J.mg = mg;
+                }
+            }
+            __syncthreads();
+            const DhMerge mg = J.mg;
+            ev += mg.ev;
+            if (mg.stop) {
+                stopped = true;
+                r_stat = mg.stat;
+                r_p = mg.p;
+                r_pow = mg.pow;
+                nt = mg.nt;
+            } else if (mg.p != -2.0 && mg.p >= best_p) {
+                best_p = mg.p;
+                best_stat = mg.stat;
+                best_g = mg.g;
+                best_df = mg.df;
+            }
+            next += W;
+            width *= 8ull;
+        }
+        if (!stopped) {  // every subset significant: the maximum-p result (tests.jl:338-345)
+            r_stat = best_stat;
+            r_p = best_p < 0.0 ? 0.0 : best_p;
+            r_pow = 1;
+            nt = N;
+        }
+        if (wave == 0) {
+            const unsigned long long tk3 = wall_clock64();
+            if (lane == 0) {
+                x.r_first1 += (unsigned int)(tk2 - tk1);
+                x.r_more1 += (unsigned int)(tk3 - tk2);
+                if (boarded) x.c_eval_short += 1ull;
+                x.c_eval_short += (unsigned long long)n_rounds << 32;  // (trace: lock-step rounds of the target in the high word)
+            }
+            x.c_ref += nt;
+            x.c_calls += 1ull;
+            x.c_eval += ev;
+            x.c_alg += dh_alg_bytes(a, ev, P.max_k, P.disc_bytes_per_col);
+            dh_commit(x, A, lane, 1, r_stat, r_p, r_pow, P.alpha);
+        }
+        __syncthreads();  // (the next job's descriptor is written behind this)
+    }
+    if (wave == 0 && lane == 0) {
+        x.r_more0 = (unsigned int)wall_clock64();
+        tg[t] = x;
+        atomicAdd(&Q->targets_done, 1u);
+    }
+    __syncthreads();
+}
+
 #ifndef DH_MI_OCC
 #define DH_MI_OCC 1  // workgroups per CU the register budget is sized for
 #endif
@@ -829,15 +1203,33 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
     // 100 MHz ticks per wavefront, summed into MiQueue at the end (FW_TRACE_HOST prints the averages): own first tests, board
     // phases (own records + waiting / helping), helping before jobs, the tail after the last target
     unsigned long long tk_seq = 0ull, tk_board = 0ull, tk_help = 0ull, tk_tail = 0ull;
+#ifdef FW_MI_TICKS
+    if (lane < 6) dh_mi_ticks[threadIdx.x >> 6][lane] = 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#endif
     const unsigned long long tk_begin = wall_clock64();
+    // the heaviest targets (the first mi_team of the list): a workgroup each, all four wavefronts on it (dh_mi_team), taken in list
+    // order by whichever workgroup is free; the list proper starts behind them
     for (;;) {
-        const unsigned int slot = mi_wave_add(&Q->next_target, 1u, lane);
+        if (threadIdx.x == 0) dh_mi_tj.go = (int)atomicAdd(&Q->next_team, 1u);
+        __syncthreads();
+        const unsigned int ts = (unsigned int)dh_mi_tj.go;
+        __syncthreads();  // (dh_mi_team rewrites the descriptor)
+        if (ts >= P.mi_team) break;
+        dh_mi_team<L, NXY, PRE, R4>(tg, ntg, order[ts], A, M, P, Q, boards, res, bacc);
+    }
+    for (;;) {
+        const unsigned int slot = P.mi_team + mi_wave_add(&Q->next_target, 1u, lane);
         if (slot >= (unsigned int)ntg) break;
         const int t = order[slot];
         // the target's state lives in LDS while its jobs run: every lane holds the same copy, and ~50 registers of it live across
         // the out-of-line test routine were part of what kept this kernel at one wavefront per SIMD
         DhTgt &x = dh_mi_x[threadIdx.x >> 6];
-        if (lane == 0) x = tg[t];
+        if (lane == 0) {
+            x = tg[t];
+            x.r_first0 = (unsigned int)wall_clock64();  // FW_TRACE_HOST: when the target was taken / finished (100 MHz ticks, low word)
+        }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         while (dh_advance(x, A, lane, 1)) {
@@ -870,63 +1262,46 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
             // tests (one rank of eight, cfg4: 46.9 -> 37.2 ms of conditional stage)
             // (tail: no target left to claim AND fewer than one wavefront in eight still owns one -- cfg2 has as many targets as
             // the launch has wavefronts: "list exhausted" alone switched every job of the pass to the short prefix, 15 -> 22 ms)
-            const bool tail = mi_ld_u32(&Q->next_target) >= (unsigned int)ntg &&
+            const bool tail = mi_ld_u32(&Q->next_target) + P.mi_team >= (unsigned int)ntg &&
                               ((unsigned int)ntg - mi_ld_u32(&Q->targets_done)) * 8u <= gridDim.x * 4u;
             const unsigned long long seq = tail ? P.mi_seq_tail : (heavy ? P.mi_seq_heavy : P.mi_seq);
             unsigned long long next = elim_full ? 0ull : (N < seq ? N : seq);
-            FwSegOut o = mi_run_ranks_sel<L, NXY, PRE, R4>(M, x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, 0ull, next, nullptr, 0);
+            FwSegOut o = mi_run_ranks_sel<L, NXY, PRE, R4>(M, x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, 0ull, next, nullptr, 0, nullptr);
             unsigned long long ev = o.evaluated, nt = 0ull;
             bool stopped = o.stop_rank != FW_RANK_NONE;
             double r_stat = stopped ? o.stop_stat : 0.0, r_p = stopped ? o.stop_pval : 0.0;
             int r_pow = stopped ? o.stop_power : 1;
-            double best_p = o.best_pval, best_stat = o.best_stat;
+            double best_p = o.best_pval, best_stat = o.best_stat, best_g = stopped ? 0.0 : o.stop_stat;  // (+ G^2, df: the seed of the boards)
+            int best_df = o.best_df;
             if (stopped) nt = o.stop_rank + 1ull;
-            unsigned long long width = elim_full ? N : (unsigned long long)P.mi_win0;
+            // (in the tail the records are short and the first window wide: the wavefronts that poll outnumber the records of a window)
+            unsigned long long width = elim_full ? N : (unsigned long long)(tail ? P.mi_win0_tail : P.mi_win0);
+            const unsigned long long chunk_min = tail ? P.mi_chunk_tail : P.mi_chunk_min;
             unsigned int bacc_off = MI_BACC_CAP;  // this job's write-through copy of its accepted list (made with its first board)
             const unsigned long long tk2 = wall_clock64();
             tk_seq += tk2 - tk1;
+            if (lane == 0) x.r_first1 += (unsigned int)(tk2 - tk1);  // FW_TRACE_HOST: this target's ticks in sequential prefixes / board phases
             while (!stopped && next < N) {
                 const unsigned long long W = (N - next) < width ? (N - next) : width;
                 unsigned long long chunk = W / (unsigned long long)P.mi_chunk_div;
-                chunk = chunk < P.mi_chunk_min ? P.mi_chunk_min : (chunk > P.mi_chunk_max ? P.mi_chunk_max : chunk);
+                chunk = chunk < chunk_min ? chunk_min : (chunk > P.mi_chunk_max ? P.mi_chunk_max : chunk);
                 const unsigned int nch = (unsigned int)((W + chunk - 1ull) / chunk);
-                unsigned int bi = MI_BOARD_CAP, ro = MI_REC_CAP;
-                if (bacc_off == MI_BACC_CAP && mi_ld_u32(&Q->bacc_top) + (unsigned int)a <= MI_BACC_CAP) {
-                    bacc_off = mi_wave_add(&Q->bacc_top, (unsigned int)a, lane);
-                    if (bacc_off + (unsigned int)a > MI_BACC_CAP) {
-                        bacc_off = MI_BACC_CAP;
-                    } else {
-                        const int32_t *src = A.acc + acc_off;
-                        for (int i = lane; i < a; i += 64) __hip_atomic_store(bacc + bacc_off + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-                if (bacc_off != MI_BACC_CAP && mi_ld_u32(&Q->n_boards) < MI_BOARD_CAP && mi_ld_u32(&Q->res_top) + nch <= MI_REC_CAP) {
-                    ro = mi_wave_add(&Q->res_top, nch, lane);
-                    if (ro + nch <= MI_REC_CAP) bi = mi_wave_add(&Q->n_boards, 1u, lane);
-                }
+                unsigned int bi, ro;
+                const bool published = mi_publish(Q, boards, bacc, bacc_off, A.acc + acc_off, a, x.T, cand, next, W, chunk, nch, lane, bi, ro,
+                                                  best_p, best_g, best_df);
                 DhMerge mg;
-                if (bi >= MI_BOARD_CAP) {  // out of board space (never at the benchmark sizes): the owner carries on alone
-                    const FwSegOut q = mi_run_ranks_sel<L, NXY, PRE, R4>(M, x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, next, next + W, nullptr, 0);
+                if (!published) {  // out of board space (never at the benchmark sizes): the owner carries on alone
+                    const FwSegOut q = mi_run_ranks_sel<L, NXY, PRE, R4>(M, x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, next, next + W, nullptr, 0, nullptr);
                     mg.stop = q.stop_rank != FW_RANK_NONE;
                     mg.stat = mg.stop ? q.stop_stat : q.best_stat;
                     mg.p = mg.stop ? q.stop_pval : (q.best_pval < 0.0 ? -2.0 : q.best_pval);
                     mg.pow = q.stop_power;
                     mg.nt = q.stop_rank + 1ull;
                     mg.ev = q.evaluated;
+                    mg.g = q.stop_stat;
+                    mg.df = q.best_df;
                 } else {
                     MiBoard *b = boards + bi;
-                    mi_drain();  // the copy of the accepted list (every lane's stores) ...
-                    if (lane == 0) {
-                        mi_st_u64(&b->tc, (unsigned long long)(unsigned int)x.T | ((unsigned long long)(unsigned int)cand << 32));
-                        mi_st_u64(&b->ac, (unsigned long long)(unsigned int)a | ((unsigned long long)chunk << 32));
-                        mi_st_u64(&b->acc_off, (unsigned long long)bacc_off);
-                        mi_st_u64(&b->start, next);
-                        mi_st_u64(&b->end, next + W);
-                        mi_st_u64(&b->nr, (unsigned long long)nch | ((unsigned long long)ro << 32));
-                        mi_st_u64(&b->stop_min, FW_RANK_NONE);  // next_chunk / done are zero from the launch's memset
-                        mi_drain();  // ... and the board before the flag
-                        mi_st_u32(&b->ready, 1u);
-                    }
                     while (mi_board_work<L, NXY, PRE, R4>(b, res, bacc, A.acc + acc_off, M, P, lane)) {
                     }
                     unsigned int spins = 0u;
@@ -951,11 +1326,20 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
                 } else if (mg.p != -2.0 && mg.p >= best_p) {
                     best_p = mg.p;
                     best_stat = mg.stat;
+                    best_g = mg.g;
+                    best_df = mg.df;
                 }
                 next += W;
                 width *= 8ull;
             }
-            tk_board += wall_clock64() - tk2;
+            {
+                const unsigned long long tk3 = wall_clock64();
+                tk_board += tk3 - tk2;
+                if (lane == 0) {
+                    x.r_more1 += (unsigned int)(tk3 - tk2);
+                    if (next > (elim_full ? 0ull : (N < seq ? N : seq))) x.c_eval_short += 1ull;  // jobs that went to a board
+                }
+            }
             if (!stopped) {  // every subset significant: the maximum-p result (tests.jl:338-345)
                 r_stat = best_stat;
                 r_p = best_p < 0.0 ? 0.0 : best_p;
@@ -969,6 +1353,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
             dh_commit(x, A, lane, 1, r_stat, r_p, r_pow, P.alpha);
         }
         if (lane == 0) {
+            x.r_more0 = (unsigned int)wall_clock64();
             tg[t] = x;
             atomicAdd(&Q->targets_done, 1u);  // (a termination count, not a hand-off: the host reads tg after the kernel)
         }
@@ -992,6 +1377,9 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
         atomicAdd(&Q->t_sleep, tk_help);
         atomicAdd(&Q->n_seg, tk_tail);
         atomicAdd(&Q->t_total, tk_t0 - tk_begin);
+#ifdef FW_MI_TICKS
+        for (int q = 0; q < 6; ++q) atomicAdd(&Q->tick[q], dh_mi_ticks[threadIdx.x >> 6][q]);
+#endif
     }
 }
 
@@ -1654,6 +2042,8 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         { const char *e = fw_knob("FW_MI_HEAVY"); P.mi_heavy = e ? (unsigned int)atoi(e) : 48u; }
         { const char *e = fw_knob("FW_MI_SEQ_HEAVY"); P.mi_seq_heavy = e ? (unsigned int)atoi(e) : P.mi_seq; }
         { const char *e = fw_knob("FW_MI_SEQ_TAIL"); P.mi_seq_tail = e ? (unsigned int)atoi(e) : 4u; }
+        { const char *e = fw_knob("FW_MI_CHUNK_TAIL"); P.mi_chunk_tail = e ? (unsigned int)std::max(1, atoi(e)) : P.mi_chunk_min; }
+        { const char *e = fw_knob("FW_MI_WIN0_TAIL"); P.mi_win0_tail = e ? (unsigned int)std::max(1, atoi(e)) : 1024u; }
     }
     const bool fz = c->P.kind == FW_FZ;
     P.w0_small = fz ? 256ull : 16ull;
@@ -1745,6 +2135,24 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         int n_cu = 256;
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->P.device);
         const unsigned grid = std::min((unsigned)((ntg + 3) / 4), wg_per_cu * (unsigned)n_cu);
+        {   // targets with at least FW_MI_TEAM_MIN candidates (at most FW_MI_TEAM_MAX of them): a workgroup each
+            static const unsigned team_min = [] { const char *e = fw_knob("FW_MI_TEAM_MIN"); return e ? (unsigned)atoi(e) : 64u; }();
+            static const unsigned team_max = [] { const char *e = fw_knob("FW_MI_TEAM_MAX"); return e ? (unsigned)atoi(e) : 256u; }();
+            static const unsigned team_steps = [] { const char *e = fw_knob("FW_MI_TEAM_STEPS"); return e ? (unsigned)atoi(e) : 2u; }();
+            unsigned team = 0u;
+            while (team_min > 0u && team < team_max && (int)team < ntg && (unsigned)tg[order[team]].nc >= team_min) ++team;
+            P.mi_team = team;
+            P.mi_team_steps = team_steps;
+            static const unsigned team_tail = [] { const char *e = fw_knob("FW_MI_TEAM_TAIL"); return e ? (unsigned)atoi(e) : 0u; }();
+            P.mi_team_tail = team_tail;
+            if (trace_host) {
+                int c32 = 0, c64 = 0, c128 = 0, c192 = 0;
+                for (int t = 0; t < ntg; ++t) c32 += tg[t].nc >= 32, c64 += tg[t].nc >= 64, c128 += tg[t].nc >= 128, c192 += tg[t].nc >= 192;
+                fprintf(stderr, "[fw] chain %d: %u targets run by a workgroup each (>= %u candidates); targets with >= 32 / 64 / 128 / 192 candidates: %d / %d / %d / %d; "
+                                "candidates of the 1st / 64th / 256th heaviest: %d / %d / %d\n", chain, team, team_min, c32, c64, c128, c192,
+                        tg[order[0]].nc, ntg > 63 ? tg[order[63]].nc : -1, ntg > 255 ? tg[order[255]].nc : -1);
+            }
+        }
         FW_HIP(c, hipMemsetAsync(d_mq, 0, sizeof(MiQueue), st));
         FW_HIP(c, hipMemsetAsync(d_boards, 0, sizeof(MiBoard) * MI_BOARD_CAP, st));  // ready flags, claimed / finished counts
         FW_HIP(c, hipEventRecord(ev[0][0], st));
@@ -1776,6 +2184,13 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         if (hq.pad[0]) return fw_fail(c, FW_ERR_DEVICE, "discrete HITON kernel: watchdog %u (boards %u, targets done %u of %d)", hq.pad[0], hq.n_boards, hq.targets_done, ntg);
         if (trace_host) {
             const double nw = 4.0 * (double)grid, ms = 1e-5;
+            if (hq.tick[1])
+                fprintf(stderr, "[fw] test routine: %llu calls, %llu tests (mean set size %.2f); per test %.2f us before the core (unranking, list), %.2f us in the core, %.2f us in the accounting (Q)\n",
+                        hq.tick[0], hq.tick[1], (double)hq.tick[5] / (double)hq.tick[1], 1e-2 * hq.tick[2] / (double)hq.tick[1],
+                        1e-2 * hq.tick[3] / (double)hq.tick[1], 1e-2 * hq.tick[4] / (double)hq.tick[1]);
+            if (hq.tm_steps)
+                fprintf(stderr, "[fw] team rounds: %llu wavefront-rounds, %llu tests in them; per wavefront-round %.2f us in the test routine, %.2f us at the barrier\n",
+                        hq.tm_steps, hq.tm_tests, 1e-2 * hq.tm_run / (double)hq.tm_steps, 1e-2 * hq.tm_wait / (double)hq.tm_steps);
             fprintf(stderr, "[fw] boards %u records %u; per wavefront (%u wavefronts): until out of targets %.2f ms = own first tests %.2f + board phases %.2f + helping before jobs %.2f + state machine %.2f; tail %.2f ms\n",
                     hq.n_boards, hq.res_top, 4u * grid, ms * hq.t_total / nw, ms * hq.t_body / nw, ms * hq.t_ctl / nw, ms * hq.t_sleep / nw,
                     ms * ((double)hq.t_total - (double)hq.t_body - (double)hq.t_ctl - (double)hq.t_sleep) / nw, ms * hq.n_seg / nw);
@@ -1929,7 +2344,20 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         }
         fprintf(stderr, "[fw] chain %d: executed tests %llu, of them in jobs with at most %d accepted variables %llu; longest accepted list %d\n",
                 chain, ev_all, (int)FW_HK_A, ev_short, na_max);
-        {   // the target that was busy for the most rounds: where its rounds went
+        if (per_target) {  // the targets that finished last: when they were taken, how long they ran, what they ran
+            unsigned int t0 = ~0u;
+            for (const DhTgt &x : tg) t0 = std::min(t0, x.r_first0);
+            std::vector<const DhTgt *> by_end;
+            for (const DhTgt &x : tg) by_end.push_back(&x);
+            std::sort(by_end.begin(), by_end.end(), [&](const DhTgt *a, const DhTgt *b) { return a->r_more0 - t0 > b->r_more0 - t0; });
+            for (size_t i = 0; i < by_end.size() && i < 6; ++i) {
+                const DhTgt *w = by_end[i];
+                fprintf(stderr, "[fw]   finished at %.2f ms (taken at %.2f): T=%d, %d candidates, %d in PC, %llu jobs, %llu tests (%llu executed); "
+                                "sequential prefixes %.2f ms, board phases %.2f ms (%llu jobs went to a board; %llu team rounds)\n",
+                        1e-5 * (w->r_more0 - t0), 1e-5 * (w->r_first0 - t0), w->T, w->cap, w->npc, w->c_calls, w->c_ref, w->c_eval,
+                        1e-5 * w->r_first1, 1e-5 * w->r_more1, w->c_eval_short & 0xffffffffull, w->c_eval_short >> 32);
+            }
+        } else {  // the target that was busy for the most rounds: where its rounds went
             const DhTgt *w = &tg[0];
             for (const DhTgt &x : tg)
                 if (x.r_first0 + x.r_more0 + x.r_first1 + x.r_more1 > w->r_first0 + w->r_more0 + w->r_first1 + w->r_more1) w = &x;
