@@ -929,7 +929,7 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
                 pool.seg_job[si] = (int64_t)ji;
                 ++si;
             }
-            if (nzs) {
+            if (nzs || stream) {  // per-job record: fz_nz sub-matrix / recursive_pcor = 0 job-local correlation matrix
                 FwNzJob r{};
                 r.X = j.X;
                 r.Y = j.Y;
@@ -957,7 +957,7 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
         if (rc) return rc;
         rc = fwi_fznz_segments(c, (int64_t)ns, (int64_t)ns_tab, dsegs, dacc, dout, pb);
     } else {
-        rc = stream ? fwi_fzs_segments(c, (int64_t)ns, dsegs, dacc, dout, pb)
+        rc = stream ? fwi_fzs_segments(c, (int64_t)ns, dsegs, dacc, dout, pb, pool.nzrecs.data(), (int64_t)pool.nzrecs.size(), arena_floats)
              : fz   ? fwi_fz_segments(c, (int64_t)ns, (int64_t)ns_tab, dsegs, dacc, dout, pb)
                 : fwi_mi_segments(c, (int64_t)ns, dsegs, dacc, dout, pb);
     }

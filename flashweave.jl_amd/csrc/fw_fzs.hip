@@ -104,6 +104,7 @@ struct FzsXY {
     double sxy;             // sum x (y - mu_y)
     const float *cx, *cy;   // the columns in global memory
     double mux, muy, ssx, ssy;
+    int vx, vy;             // the variables
 };
 
 #define FZS_LDS_N 2048  // samples per column the LDS copy holds
@@ -113,6 +114,8 @@ template <int T>
 __device__ __forceinline__ void fzs_load_xy(const FzsDev &P, int X, int Y, FzsXY<T> &H, const float *lds)
 {
     const int lane = threadIdx.x & 63;
+    H.vx = X;
+    H.vy = Y;
     H.cx = P.data + (size_t)X * P.n;
     H.cy = P.data + (size_t)Y * P.n;
     H.mux = P.st[2 * (size_t)X];
@@ -164,8 +167,8 @@ struct FzsLay {
         __builtin_amdgcn_wave_barrier();                       \
     }
 
-template <int K>
-__device__ __noinline__ void fzs_finish(double *q, const int *mm, int ng, double zscale)
+template <int K, bool GRAM>
+__device__ __noinline__ void fzs_finish(double *q, const int *mm, int ng, double zscale, const double *cjob, int mj, const int *idx)
 {
     using L = FzsLay<K>;
     constexpr int M = L::M;
@@ -186,7 +189,14 @@ __device__ __noinline__ void fzs_finish(double *q, const int *mm, int ng, double
     for (int i = 0; i < ng; ++i) mmax = mm[i] > mmax ? mm[i] : mmax;
     mmax = __builtin_amdgcn_readfirstlane(mmax);
     const bool pair = live && lb < m;
-    double R = pair ? qs[la * M + lb] / sqrt(qs[L::SS + la] * qs[L::SS + lb]) : 0.0;
+    // GRAM: the pair's correlation is an entry of the job's matrix (fzs_gram_kernel; LDS or L2), addressed by the job-local indices
+    // of the test's variables (0 = X, 1 = Y, 2 + position in the accepted list)
+    double R = 0.0;
+    if (GRAM) {
+        if (pair) R = cjob[idx[(live ? g : 0) * M + la] * mj + idx[(live ? g : 0) * M + lb]];
+    } else {
+        R = pair ? qs[la * M + lb] / sqrt(qs[L::SS + la] * qs[L::SS + lb]) : 0.0;
+    }
     for (int t = mmax - 1; t >= 2; --t) {
         if (pair) qs[L::WORK + la * M + lb] = R;
         FZS_WAVE_SYNC()
@@ -285,6 +295,19 @@ __device__ __forceinline__ void fzs_stream(const FzsDev &P, const FzsXY<T> &H, c
         for (int b = a + 1; b < M; ++b)
             if (b >= 2 && b < m) S[a][b] = fzs_wave_sum(S[a][b]);
     S[0][1] = H.sxy;
+    {   // the same variable twice in a test (feed-forward whitelists can repeat a member of the elimination pool, hiton.jl:24-26):
+        // its cross product with itself is its sum of squares exactly -> correlation exactly 1, as StatsBase's identical sums give
+        int id[M];
+        id[0] = H.vx;
+        id[1] = H.vy;
+#pragma unroll
+        for (int j = 0; j < K; ++j) id[2 + j] = j < k ? zs[j] : -1 - j;
+#pragma unroll
+        for (int a = 0; a < M; ++a)
+#pragma unroll
+            for (int b = a + 1; b < M; ++b)
+                if (id[a] == id[b]) S[a][b] = ss[a];
+    }
     if (lane == 0) {
 #pragma unroll
         for (int a = 0; a < M; ++a) {
@@ -330,7 +353,7 @@ __global__ __launch_bounds__(256) void fzs_test_batch_kernel(FzsDev P, long long
         fzs_stream<K, T>(P, H, zs, k, s_q[wave]);
         if (lane == 0) s_m[wave][0] = k + 2;
         FZS_WAVE_SYNC()
-        fzs_finish<K>(s_q[wave], s_m[wave], 1, P.zscale);
+        fzs_finish<K, false>(s_q[wave], s_m[wave], 1, P.zscale, nullptr, 0, nullptr);
     }
     if (lane == 0) {
         fw_test_result o;
@@ -348,11 +371,15 @@ __global__ __launch_bounds__(256) void fzs_test_batch_kernel(FzsDev P, long long
 #ifndef FZS_SEG_OCC
 #define FZS_SEG_OCC 4  // workgroups per CU (= waves per SIMD) the segment kernel is compiled for; 3 / 4 / 5: 3.31 / 3.67 / 1.65 e8 tests/s (5: spills inside the loop)
 #endif
-template <int K, int T>
+// GRAM: the correlations of a job are not streamed per test but read from the job's (a + 2) x (a + 2) Float64 matrix, computed once
+// per job and pool round by fzs_gram_kernel (see there); the workgroup stages it in LDS (dynamic, lds_m variables) when it fits.
+template <int K, int T, bool GRAM>
 __global__ __launch_bounds__(256, FZS_SEG_OCC) void fzs_subsets_seg_kernel(FzsDev P, const FwSeg *__restrict__ segs,
                                                               const int32_t *__restrict__ accflat, FwSegOut *__restrict__ out,
-                                                              int max_k, double alpha, long long max_tests)
+                                                              int max_k, double alpha, long long max_tests,
+                                                              const FwNzJob *__restrict__ recs, const double *__restrict__ arena, int lds_m)
 {
+    extern __shared__ double s_cjob[];
     __shared__ unsigned long long s_stop[4], s_br[4];
     __shared__ double s_sstat[4], s_sp[4], s_bp[4], s_bstat[4];
     __shared__ int s_spow[4];
@@ -371,6 +398,19 @@ __global__ __launch_bounds__(256, FZS_SEG_OCC) void fzs_subsets_seg_kernel(FzsDe
     using L = FzsLay<K>;
     __shared__ double s_q[4][L::G * L::QD];
     __shared__ int s_m[4][FZS_GMAX];
+    __shared__ int s_idx[GRAM ? 4 : 1][GRAM ? FZS_GMAX : 1][GRAM ? K + 2 : 1];
+    const double *cjob = nullptr;
+    int mjob = 0;
+    if (GRAM) {
+        const FwNzJob rec = recs[seg.pad];
+        mjob = rec.m;
+        cjob = arena + rec.cor_off;
+        if (mjob <= lds_m) {
+            for (int i = threadIdx.x; i < mjob * mjob; i += 256) s_cjob[i] = cjob[i];
+            __syncthreads();
+            cjob = s_cjob;
+        }
+    }
     const bool power = (long long)P.n >= P.n_obs_min;  // sufficient_power(X, Y, data, test_obj, n_obs_min), tests.jl:9-12,252
     if (T > 0) {
         const int n4 = P.n >> 2;
@@ -402,7 +442,7 @@ __global__ __launch_bounds__(256, FZS_SEG_OCC) void fzs_subsets_seg_kernel(FzsDe
 #pragma unroll
             for (int q = 0; q < K; ++q) pos[q] = 0;
             fw_unrank_comb(rem, a, s, pos);
-            if (!xy_loaded) {  // X and Y of the job: once per wavefront and segment
+            if (!GRAM && !xy_loaded) {  // X and Y of the job: once per wavefront and segment
                 fzs_load_xy<T>(P, seg.X, seg.Y, H, s_xy);
                 xy_loaded = true;
             }
@@ -411,7 +451,16 @@ __global__ __launch_bounds__(256, FZS_SEG_OCC) void fzs_subsets_seg_kernel(FzsDe
                 int ng = 0;
                 unsigned long long rg = r;
                 while (ng < L::G && rg < r1 && s >= 1) {
-                    if (power) {
+                    if (power && GRAM) {
+                        if (lane < K + 2) {
+                            int v = lane;  // job-local index: 0 = X, 1 = Y, 2 + position
+#pragma unroll
+                            for (int q = 0; q < K; ++q)
+                                if (lane == 2 + q) v = q < s ? 2 + pos[q] : 0;
+                            s_idx[wave][ng][lane] = v;
+                        }
+                        if (lane == 0) s_m[wave][ng] = s + 2;
+                    } else if (power) {
                         int zs[K > 0 ? K : 1];
 #pragma unroll
                         for (int q = 0; q < K; ++q) zs[q] = __builtin_amdgcn_readfirstlane((q < s) ? gacc[pos[q]] : 0);
@@ -433,7 +482,7 @@ __global__ __launch_bounds__(256, FZS_SEG_OCC) void fzs_subsets_seg_kernel(FzsDe
                 }
                 if (power) {
                     FZS_WAVE_SYNC()
-                    fzs_finish<K>(s_q[wave], s_m[wave], ng, P.zscale);
+                    fzs_finish<K, GRAM>(s_q[wave], s_m[wave], ng, P.zscale, cjob, mjob, GRAM ? &s_idx[wave][0][0] : nullptr);
                 }
                 my_done += (unsigned int)ng;
                 bool stopped = false;
@@ -525,6 +574,130 @@ __global__ __launch_bounds__(256, FZS_SEG_OCC) void fzs_subsets_seg_kernel(FzsDe
     }
 }
 
+// ---- job-local correlation matrices ---------------------------------------------------------------------------------------------
+// Every test of a (X, Y | subsets of the accepted list) job conditions a sub-matrix of ONE matrix: the Float64 correlations of
+// {X, Y} u accepted.  Streaming the columns per test (above) computes each of them C(a, k - 1) times over; this kernel computes
+// them once per job and pool round -- one workgroup per job, one wavefront per 4 x 4 tile of pairs (8 columns in 16-byte loads feed
+// 16 sums x 4 samples), the same sum  x_i (x_j - mu_j), i < j in job order (X, Y, accepted positions), as the streamed form, the
+// same DPP wave sums -- and the segment kernel (GRAM) then only gathers and conditions: tests/s go from 3.7e8 (streamed, itself
+// 1.8 x the nominal HBM rate) to the rate of the conditioning arithmetic.  Row-major m x m doubles per job in the launch's arena.
+__global__ __launch_bounds__(256) void fzs_gram_kernel(FzsDev P, const FwNzJob *__restrict__ recs, const int32_t *__restrict__ accflat,
+                                                       double *__restrict__ arena)
+{
+    const FwNzJob J = recs[blockIdx.x];
+    const int m = J.m;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int32_t *acc = accflat + J.acc_off;
+    double *C = arena + J.cor_off;
+    const int T4 = (m + 3) >> 2, ntiles = T4 * (T4 + 1) / 2;
+    for (int tile = wave; tile < ntiles; tile += 4) {
+        int ti = 0, rem = tile;  // tile -> (ti, tj), ti <= tj, row by row over the upper triangle
+        while (rem >= T4 - ti) {
+            rem -= T4 - ti;
+            ++ti;
+        }
+        const int tj = ti + rem;
+        const float *ci[4], *cj[4];
+        double muj[4], ssi[4], ssj[4];
+        int idi[4], idj[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int li = 4 * ti + q, lj = 4 * tj + q;
+            li = li < m ? li : m - 1;
+            lj = lj < m ? lj : m - 1;
+            const int vi = __builtin_amdgcn_readfirstlane(li == 0 ? J.X : (li == 1 ? J.Y : acc[li - 2]));
+            const int vj = __builtin_amdgcn_readfirstlane(lj == 0 ? J.X : (lj == 1 ? J.Y : acc[lj - 2]));
+            idi[q] = vi;
+            idj[q] = vj;
+            ci[q] = P.data + (size_t)vi * P.n;
+            cj[q] = P.data + (size_t)vj * P.n;
+            ssi[q] = P.st[2 * (size_t)vi + 1];
+            muj[q] = P.st[2 * (size_t)vj];
+            ssj[q] = P.st[2 * (size_t)vj + 1];
+        }
+        double S[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) S[a][b] = 0.0;
+#define FZS_GACC(XS, YS)                                                     \
+    {                                                                        \
+        double d[4];                                                         \
+        _Pragma("unroll") for (int b = 0; b < 4; ++b) d[b] = (double)(YS(b)) - muj[b]; \
+        _Pragma("unroll") for (int a = 0; a < 4; ++a)                       \
+        {                                                                    \
+            const double xa = (double)(XS(a));                               \
+            _Pragma("unroll") for (int b = 0; b < 4; ++b) S[a][b] = fma(xa, d[b], S[a][b]); \
+        }                                                                    \
+    }
+        if ((P.n & 3) == 0) {
+            const int n4 = P.n >> 2;
+            for (int q = lane; q < n4; q += 64) {
+                float4 xi[4], xj[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    xi[a] = ((const float4 *)ci[a])[q];
+                    xj[a] = ((const float4 *)cj[a])[q];
+                }
+#define GX(a) xi[a].x
+#define GY(b) xj[b].x
+                FZS_GACC(GX, GY)
+#undef GX
+#undef GY
+#define GX(a) xi[a].y
+#define GY(b) xj[b].y
+                FZS_GACC(GX, GY)
+#undef GX
+#undef GY
+#define GX(a) xi[a].z
+#define GY(b) xj[b].z
+                FZS_GACC(GX, GY)
+#undef GX
+#undef GY
+#define GX(a) xi[a].w
+#define GY(b) xj[b].w
+                FZS_GACC(GX, GY)
+#undef GX
+#undef GY
+            }
+        } else {
+            for (int i = lane; i < P.n; i += 64) {
+                float xi[4], xj[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    xi[a] = ci[a][i];
+                    xj[a] = cj[a][i];
+                }
+#define GX(a) xi[a]
+#define GY(b) xj[b]
+                FZS_GACC(GX, GY)
+#undef GX
+#undef GY
+            }
+        }
+#undef FZS_GACC
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int li = 4 * ti + a, lj = 4 * tj + b;
+                if (li < lj && lj < m) {  // (uniform)
+                    const double v = fzs_wave_sum(S[a][b]);
+                    if (lane == 0) {
+                        // the same variable twice in a job (feed-forward whitelists: hiton.jl:24-26 pushes a whitelisted member of the
+                        // elimination pool again): its correlation with itself is exactly 1, as StatsBase's identical sums give it
+                        // (S / sqrt(S S)), and the conditioning then divides by zero exactly as the reference does -- not by the
+                        // rounding residue of x (x - mu) against (x - mu)^2
+                        const double r = idi[a] == idj[b] ? 1.0 : v / sqrt(ssi[a] * ssj[b]);
+                        C[(size_t)li * m + lj] = r;
+                        C[(size_t)lj * m + li] = r;
+                    }
+                }
+            }
+    }
+    for (int i = threadIdx.x; i < m; i += 256) C[(size_t)i * m + i] = 1.0;
+}
+
 FzsDev fzs_dev(const fw_ctx *ctx)
 {
     FzsDev P;
@@ -592,20 +765,43 @@ int fwi_fzs_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *
     return FW_OK;
 }
 
-int fwi_fzs_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb)
+int fwi_fzs_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb,
+                     const FwNzJob *recs_host, int64_t njobs, size_t arena_doubles)
 {
     if (nseg == 0) return FW_OK;
     if (!ctx->d_data) return fw_fail(ctx, FW_ERR_STATE, "recursive_pcor = 0 needs the data matrix on the device (fw_set_data_dense_f32)");
     if (int rc = fzs_ensure_stat(ctx, pb.launch_stream)) return rc;
+    // job-local correlation matrices (fzs_gram_kernel) unless FW_FZS_GRAM=0 (profiling / parity knob: every test streams its columns)
+    // or the launch's matrices would not fit a sensible arena
+    const bool gram_env = !(fw_knob("FW_FZS_GRAM") && atoi(fw_knob("FW_FZS_GRAM")) == 0);  // (read per launch: the tests switch it)
+    const bool gram = gram_env && recs_host && njobs > 0 && arena_doubles * sizeof(double) <= ((size_t)8 << 30);
+    int lds_m = 0;
+    if (gram) {
+        int rc;
+        if ((rc = fw_dev_reserve(ctx, ctx->d_nzrecs, (size_t)njobs * sizeof(FwNzJob)))) return rc;
+        if ((rc = fw_dev_reserve(ctx, ctx->d_arena, std::max<size_t>(arena_doubles, 1) * sizeof(double)))) return rc;
+        FW_HIP(ctx, hipMemcpyAsync(ctx->d_nzrecs.ptr, recs_host, (size_t)njobs * sizeof(FwNzJob), hipMemcpyHostToDevice, pb.launch_stream));
+        for (int64_t j = 0; j < njobs; ++j) lds_m = std::max(lds_m, (int)recs_host[j].m);
+        lds_m = std::min(lds_m, 90);  // 90 x 90 doubles = 63.3 KB: the default dynamic-LDS limit; longer jobs read their matrix through L2
+    }
     FW_HIP(ctx, hipEventRecord(pb.ev0, pb.launch_stream));
     const FzsDev P = fzs_dev(ctx);
-#define FZS_SEG(KK, TT)                                                                                                               \
-    hipLaunchKernelGGL((fzs_subsets_seg_kernel<KK, TT>), dim3((unsigned)nseg), dim3(256), 0, pb.launch_stream, P, d_segs, d_acc, d_out, \
-                       ctx->P.max_k, ctx->P.alpha, (long long)ctx->P.max_tests)
-    if (fzs_hold_xy(ctx)) {
-        if (ctx->P.max_k <= 3) FZS_SEG(3, 8); else FZS_SEG(FW_MAX_K, 8);
+    if (gram) {
+        hipLaunchKernelGGL(fzs_gram_kernel, dim3((unsigned)njobs), dim3(256), 0, pb.launch_stream, P, (const FwNzJob *)ctx->d_nzrecs.ptr, d_acc,
+                           (double *)ctx->d_arena.ptr);
+        ctx->cnt.kernel_launches += 1;
+    }
+    const size_t lds = gram ? (size_t)lds_m * lds_m * sizeof(double) : 0;
+#define FZS_SEG(KK, TT, GG)                                                                                                        \
+    hipLaunchKernelGGL((fzs_subsets_seg_kernel<KK, TT, GG>), dim3((unsigned)nseg), dim3(256), lds, pb.launch_stream, P, d_segs, d_acc, \
+                       d_out, ctx->P.max_k, ctx->P.alpha, (long long)ctx->P.max_tests, (const FwNzJob *)ctx->d_nzrecs.ptr,         \
+                       (const double *)ctx->d_arena.ptr, lds_m)
+    if (gram) {
+        if (ctx->P.max_k <= 3) FZS_SEG(3, 0, true); else FZS_SEG(FW_MAX_K, 0, true);
+    } else if (fzs_hold_xy(ctx)) {
+        if (ctx->P.max_k <= 3) FZS_SEG(3, 8, false); else FZS_SEG(FW_MAX_K, 8, false);
     } else {
-        if (ctx->P.max_k <= 3) FZS_SEG(3, 0); else FZS_SEG(FW_MAX_K, 0);
+        if (ctx->P.max_k <= 3) FZS_SEG(3, 0, false); else FZS_SEG(FW_MAX_K, 0, false);
     }
 #undef FZS_SEG
     FW_HIP(ctx, hipGetLastError());

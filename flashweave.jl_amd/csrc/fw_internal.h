@@ -216,7 +216,8 @@ int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *d_
 // ---- fz without a correlation matrix: streamed sample columns (fw_fzs.hip, fw_params.recursive_pcor = 0) ----
 int fwi_fzs_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff, const int32_t *zflat,
                        fw_test_result *out);
-int fwi_fzs_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb);
+int fwi_fzs_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb,
+                     const FwNzJob *recs_host, int64_t njobs, size_t arena_doubles);  // recs: one per launched job (FwSeg::pad indexes them)
 
 // ---- HE-S / fz_nz (fw_fz.hip) ----
 int fwi_fznz_upload(fw_ctx *ctx, const float *data);

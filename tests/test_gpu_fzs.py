@@ -126,3 +126,43 @@ def test_test_subsets_streams_without_a_correlation_matrix():
         assert g["status"] == e["status"] and g["num_tests"] == e["num_tests"] and g["Zs"] == e["Zs"], (t, c, a, g, e)
         assert abs(g["stat"] - e["stat"]) < 1e-11
     eng.close()
+
+
+@pytest.mark.parametrize("max_k", [3, 5])
+def test_job_matrix_and_streamed_forms_agree(ctx, monkeypatch, max_k):
+    # default: the correlations of a job come from its (a + 2) x (a + 2) Float64 matrix (fzs_gram_kernel), staged in LDS up to 90
+    # variables and read through L2 beyond; FW_FZS_GRAM=0: every test streams its columns.  Same sums, same order per pair -> the two
+    # forms agree far inside the oracle tolerance; both are compared with the oracle.  Lists of 3 .. 120 accepted variables.
+    data, n, p, orc = ctx["data"], ctx["n"], ctx["p"], ctx["orc"]
+    rng = np.random.default_rng(5 + max_k)
+    T, C, A = [], [], []
+    for la in [3, 5, 8, 13, 21, 40, 64, 88, 89, 95, 120] * 2:
+        v = rng.choice(p, size=la + 2, replace=False)
+        T.append(int(v[0])); C.append(int(v[1])); A.append([int(t) for t in v[2:]])
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FW_FZS_GRAM", mode)
+        eng = fw.Engine("fz", n, p, max_k=max_k, recursive_pcor=False, max_tests=3000)
+        eng.set_data(data)
+        res[mode] = eng.test_subsets_batch(T, C, A)
+        eng.close()
+    for t, c, a, g, s in zip(T, C, A, res["1"], res["0"]):
+        assert g["status"] == s["status"] and g["num_tests"] == s["num_tests"] and g["Zs"] == s["Zs"], (t, c, len(a), g, s)
+        assert abs(g["stat"] - s["stat"]) < 1e-12 and abs(g["pval"] - s["pval"]) <= 1e-9 * max(abs(s["pval"]), 1e-300)
+    for t, c, a, g in list(zip(T, C, A, res["1"]))[:12]:
+        e = orc.test_subsets(t, c, a, max_k=max_k, alpha=0.01, n_obs_min=20, max_tests=3000)
+        assert g["status"] == e["status"] and g["num_tests"] == e["num_tests"] and g["Zs"] == e["Zs"], (t, c, len(a), g, e)
+        assert abs(g["stat"] - e["stat"]) < 1e-11
+
+
+@pytest.mark.parametrize("round_size", [32, 100])
+def test_feed_forward_network_without_a_correlation_matrix(ctx, round_size):
+    # the reference's default schedule (feed-forward rounds with whitelists) on the recursive_pcor = 0 path
+    eng, orc = ctx["eng"], ctx["orc"]
+    eng.reset_counters()
+    net = eng.lgl(feed_forward=True, round_size=round_size)
+    exp = orc.learn(max_k=3, feed_forward=True, round_size=round_size)
+    assert set(net["edges"]) == set(exp["edges"]), (len(net["edges"]), len(exp["edges"]))
+    for e_, w in exp["edges"].items():
+        assert abs(net["edges"][e_] - w) < 1e-11
+    assert eng.counters()["cond_tests_ref"] == exp["n_cond_tests"]
