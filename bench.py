@@ -549,10 +549,13 @@ def main():
                     "avg_launch_us": 1e6 * sub_launch_s / n_sub_launches, "launches": n_sub_launches,
                     "evaluated_tests_per_s_in_kernel": rcn["cond_tests_evaluated"] / max(sub_launch_s, 1e-12)}
         if args.stream_columns:
-            # variant S: X / Y of a job are held in LDS and a job's accepted columns stay in L2, so the kernel runs ABOVE the nominal
-            # HBM rate of tests that share nothing (profiles/r03_fzs_micro_pmc.json: 18 % of the algorithmic bytes cross the fabric)
+            # variant S (recursive_pcor = 0).  B_fzS = what a test that shares nothing streams.  The kernels share: the correlations of a
+            # job are computed once per job and pool round from its columns (fzs_gram_kernel) and the tests condition sub-matrices of
+            # that matrix out of LDS, so `achieved` is a multiple of the HBM rate and the bound is the conditioning arithmetic
+            # (FW_FZS_GRAM=0: the per-test streaming form, 1.8 x the nominal rate with X / Y in LDS and the accepted columns in L2)
             roofline["bound"] = "valu" if roofline["frac"] > 1.0 else "hbm"
-            roofline["served_by"] = "LDS (X, Y) + L2 (accepted columns of the job); profiles/r03_fzs_micro_pmc.json"
+            roofline["served_by"] = ("job-local Float64 correlation matrices in LDS (fw_fzs.hip: fzs_gram_kernel + fzs_subsets_seg_kernel<.., GRAM>); "
+                                     "profiles/r03_fzs_micro*.json")
         sub_launch_s = cn["t_dev_subsets_s"]  # the stage table below reports the headline pass
         cpu, cpu_skipped = None, None
         if world > 1:
