@@ -94,6 +94,9 @@ def parse_args(argv=None):
     ap.add_argument("--stream-columns", action="store_true",
                     help="fz: recursive_pcor = 0 -- no correlation matrix for the conditional tests, every test streams its sample columns "
                          "(statfuns.jl:19-21; fw_fzs.hip, host job pool); bound the run with --max-targets")
+    ap.add_argument("--no-cor-matrix", action="store_true",
+                    help="fz: dense_cor = false (fw_params.no_cor_mat) on top of --stream-columns: no p x p matrix at any time, level 0 "
+                         "multiplies and screens the centred columns tile by tile (learning.jl:42, tests.jl:118-147)")
     ap.add_argument("--no-other-schedule", action="store_true", help="skip the second (other_schedule) measurement")
     ap.add_argument("--no-one-chain", action="store_true", help="skip the one-chain pass the per-kernel roofline figures come from")
     ap.add_argument("--host-seam", action="store_true",
@@ -276,7 +279,10 @@ def main():
 
     cfg, csum, data, norm_rec = make_input(args.config, args)
     n, p = data.shape
-    eng = fw.Engine(cfg["test_name"], n, p, max_k=cfg["max_k"], device=local_rank, recursive_pcor=not args.stream_columns)
+    if args.no_cor_matrix:
+        args.stream_columns = True
+    eng = fw.Engine(cfg["test_name"], n, p, max_k=cfg["max_k"], device=local_rank, recursive_pcor=not args.stream_columns,
+                    dense_cor=not args.no_cor_matrix)
     eng.set_data(data)  # host -> HBM once, outside the timed region
     xstats = {}
     cb = make_allgather(dist, cdev, stats=xstats) if use_dist else None
@@ -370,7 +376,7 @@ def main():
             l0sim["mode"] = "replay"
 
     def step(ff, R):
-        if cfg["test_name"] == "fz":
+        if cfg["test_name"] == "fz" and not args.no_cor_matrix:
             if use_dist and shard_cor:
                 from flashweave_jl_amd.dist import sharded_cor
                 sim["corbuf"] = sharded_cor(eng, dist, dev, rank, world, keep=sim.get("corbuf"))
@@ -576,7 +582,7 @@ def main():
                "vs_baseline": None, "dtype": "f64" if cfg["test_name"] in ("fz", "fz_nz") else "i32", "data": "synthetic",
                "config": {"workload": "%s: fwsynth-v1 %d OTUs x %d samples, %s, max_k=%d, alpha=0.01" %
                                       (args.config, p, n, cfg["test_name"], cfg["max_k"]),
-                          "counts_sha256": csum, "recursive_pcor": 0 if args.stream_columns else 1, "feed_forward": ff, "round_size": R if ff else 0,
+                          "counts_sha256": csum, "recursive_pcor": 0 if args.stream_columns else 1, "dense_cor": 0 if args.no_cor_matrix else 1, "feed_forward": ff, "round_size": R if ff else 0,
                           "sampled_targets": args.max_targets or None,
                           "parallelism": "targets of each round dealt by estimated work over %d GPU(s), one rank per GPU, backend %s" %
                                          (world, (dist.get_backend() if use_dist else "none"))},

@@ -29,7 +29,7 @@ def _integral(a):
 
 def learn_network(data, sensitive=True, heterogeneous=False, max_k=3, alpha=0.01, feed_forward=True, normalize=True,
                   header=None, hps=5, FDR=True, n_obs_min=-1, max_tests=10_000_000, prec=32, round_size=None, device=0,
-                  meta_data=None, meta_header=None, make_onehot=True, recursive_pcor=True, device_normalize=True, **unsupported):
+                  meta_data=None, meta_header=None, make_onehot=True, recursive_pcor=True, dense_cor=True, device_normalize=True, **unsupported):
     """data: samples x OTUs count matrix (or an already normalised matrix with normalize=False).
     meta_data: optional samples x meta-variables table (numbers and / or string factors), handled like the reference's
     meta_data_path input: one-hot encoding, discretisation for the discrete tests, +1 shift for fz_nz (preprocess.py).
@@ -37,6 +37,9 @@ def learn_network(data, sensitive=True, heterogeneous=False, max_k=3, alpha=0.01
     them on the device (the benchmarked configuration); the whitelists refresh once per round.  1 = the reference's deterministic
     `single_il` schedule (what the golden networks were generated with): every round is one target and runs through the host
     job pool -- exact reproduction of the reference's edge lists, and far slower.  0 = one round (parallel="single").
+    recursive_pcor / dense_cor (sensitive mode, learning.jl:42,127): recursive_pcor=False takes the conditional tests from the data
+    instead of the Pearson matrix; dense_cor=False (needs recursive_pcor=False) never builds the p x p matrix at all -- level 0
+    multiplies and screens the centred columns tile by tile (same network as dense_cor=True, memory bounded by the data).
     device_normalize: normalise integer count tables on the device (fw_normalize_counts; all four modes); False, or a table of
     non-integral abundances, takes the host front-end (preprocess.py)."""
     if unsupported:
@@ -69,10 +72,10 @@ def learn_network(data, sensitive=True, heterogeneous=False, max_k=3, alpha=0.01
     if round_size is None:
         round_size = default_round_size(p)
     eng = Engine(test_name, n, p, max_k=max_k, alpha=alpha, hps=hps, n_obs_min=n_obs_min, max_tests=max_tests, FDR=FDR,
-                 device=device, recursive_pcor=recursive_pcor)
+                 device=device, recursive_pcor=recursive_pcor, dense_cor=dense_cor)
     try:
         eng.set_data(mat)
-        if test_name == "fz":
+        if test_name == "fz" and dense_cor:
             eng.compute_cor()
         net = eng.lgl(feed_forward=feed_forward, round_size=round_size)
         counters = eng.counters()

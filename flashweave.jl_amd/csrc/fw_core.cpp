@@ -99,6 +99,9 @@ int fw_ctx_create(const fw_params *P, fw_ctx **out)
     if (P->hps < 0) return fw_fail(nullptr, FW_ERR_ARG, "fw_ctx_create: hps must be >= 0");
     if (P->dense_rules && (P->kind == FW_FZ || P->kind == FW_FZ_NZ))
         return fw_fail(nullptr, FW_ERR_ARG, "fw_ctx_create: dense_rules applies to the discrete tests only");
+    if (P->no_cor_mat && (P->kind != FW_FZ || P->recursive_pcor))
+        return fw_fail(nullptr, FW_ERR_ARG, "fw_ctx_create: no_cor_mat (dense_cor = false) needs FW_FZ with recursive_pcor = 0 "
+                                            "(without a matrix the conditional tests come from the data, tests.jl:253)");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -231,6 +234,7 @@ int fw_set_cor_mat(fw_ctx *c, const float *cor)
 {
     CHECK_CTX(c);
     if (c->P.kind != FW_FZ) return fw_fail(c, FW_ERR_ARG, "fw_set_cor_mat: context is not FW_FZ");
+    if (c->P.no_cor_mat) return fw_fail(c, FW_ERR_STATE, "fw_set_cor_mat: the context was created with no_cor_mat (dense_cor = false)");
     if (!cor) return fw_fail(c, FW_ERR_ARG, "fw_set_cor_mat: NULL matrix");
     const size_t cells = (size_t)c->P.p * c->P.p, bytes = sizeof(float) * cells;
     // the device arithmetic relies on |entries| <= 1 (what cor() produces, cov2cor clamps); NaN is allowed and propagates
@@ -250,6 +254,7 @@ int fw_compute_cor_mat(fw_ctx *c)
 {
     CHECK_CTX(c);
     if (c->P.kind != FW_FZ) return fw_fail(c, FW_ERR_ARG, "fw_compute_cor_mat: context is not FW_FZ");
+    if (c->P.no_cor_mat) return fw_fail(c, FW_ERR_STATE, "fw_compute_cor_mat: the context was created with no_cor_mat (dense_cor = false)");
     return fwi_fz_compute_cor(c);
 }
 
@@ -352,6 +357,7 @@ int fw_use_cor_buffer(fw_ctx *c, void *d_cor, int64_t capacity_floats)
 {
     CHECK_CTX(c);
     if (c->P.kind != FW_FZ) return fw_fail(c, FW_ERR_ARG, "fw_use_cor_buffer: context is not FW_FZ");
+    if (c->P.no_cor_mat) return fw_fail(c, FW_ERR_STATE, "fw_use_cor_buffer: the context was created with no_cor_mat (dense_cor = false)");
     if (!d_cor || capacity_floats < (int64_t)c->P.p * c->P.p) return fw_fail(c, FW_ERR_ARG, "fw_use_cor_buffer: needs at least p * p floats of device memory");
     if (c->d_cor && !c->cor_external) (void)hipFree(c->d_cor);
     c->d_cor = (float *)d_cor;
@@ -367,6 +373,7 @@ int fw_compute_cor_mat_rows(fw_ctx *c, int32_t rank, int32_t world_size, int64_t
 {
     CHECK_CTX(c);
     if (c->P.kind != FW_FZ) return fw_fail(c, FW_ERR_ARG, "fw_compute_cor_mat_rows: context is not FW_FZ");
+    if (c->P.no_cor_mat) return fw_fail(c, FW_ERR_STATE, "fw_compute_cor_mat_rows: the context was created with no_cor_mat (dense_cor = false)");
     if (world_size < 1 || rank < 0 || rank >= world_size || !row0 || !rows_per_rank) return fw_fail(c, FW_ERR_ARG, "fw_compute_cor_mat_rows: invalid argument");
     c->have_level0 = false;
     c->have_network = false;
@@ -395,12 +402,12 @@ static int fw_level0_impl(fw_ctx *c, int64_t *nnz_out, int rank, int world, fw_a
     CHECK_CTX(c);
     const double t0 = now_s();
     const int p = c->P.p;
-    if (c->P.kind == FW_FZ) {
+    if (c->P.kind == FW_FZ && !c->P.no_cor_mat) {
         if (!c->have_cor) {
             int rc = fwi_fz_compute_cor(c);
             if (rc) return rc;
         }
-    } else if (!c->have_data) {
+    } else if (!c->have_data) {  // (no_cor_mat: the level-0 kernels multiply and screen the centred columns themselves)
         return fw_fail(c, FW_ERR_STATE, "fw_level0: no data uploaded");
     }
     if (c->n_obs_min_eff > c->P.n)  // learning.jl:66-73
@@ -647,7 +654,8 @@ int fw_test_batch(fw_ctx *c, int64_t m, const int32_t *X, const int32_t *Y, cons
             return FW_OK;
         }
         std::vector<int64_t> iu, ic;
-        for (int64_t t = 0; t < m; ++t) (zoff[t + 1] == zoff[t] ? iu : ic).push_back(t);
+        // (no_cor_mat: univariate tests come from the data too -- Float64 sums of the two columns, not the Float32 MFMA value level 0 screens)
+        for (int64_t t = 0; t < m; ++t) ((zoff[t + 1] == zoff[t] && !c->P.no_cor_mat) ? iu : ic).push_back(t);
         for (int part = 0; part < 2; ++part) {
             const std::vector<int64_t> &ix = part ? ic : iu;
             if (ix.empty()) continue;

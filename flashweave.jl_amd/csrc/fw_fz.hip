@@ -78,10 +78,21 @@ __device__ __forceinline__ void tri_decode(int b, int T, int &bi, int &bj)
     bj = r + (b - (int)((long long)r * T - (long long)r * (r - 1) / 2));
 }
 
+struct FzL0Counters {
+    unsigned long long n_sig;  // pairs with p < alpha (raw)
+    unsigned long long n_nan;  // pairs with NaN p (excluded from m)
+};
+
+// SCREEN (fw_params.no_cor_mat, the reference's dense_cor = false): the tile of correlations is never written -- the epilogue runs the
+// level-0 screen of fz_level0_kernel on the accumulators (same Float32 values, same thresholds) and appends the pairs that pass to
+// the candidate list of fz_level0_exact_kernel.  No p x p matrix exists at any time: p is bounded by the data, not by p^2 floats.
+#define GEMM_QCAP (2 * GEMM_BM * GEMM_LD / 3)  // screened pairs a workgroup queues in LDS (the first operand stage, free after the k loop)
+template <bool SCREEN>
 __global__ __launch_bounds__(256) void fz_cor_gemm_kernel(const float *__restrict__ xc, const float *__restrict__ sd,
                                                           float *__restrict__ cor, int p, int n_pad, int T,
                                                           int row_mode /* 1: whole tile rows from bi0 on, no mirrored writes (row-block sharding) */,
-                                                          int bi0)
+                                                          int bi0, const double *__restrict__ thr, FzL0Counters *cnt, unsigned long long cap,
+                                                          int32_t *__restrict__ out_i, int32_t *__restrict__ out_j, float *__restrict__ out_r)
 {
     // two LDS stages (73.7 KB): while a tile is being multiplied, the next one is already in registers and is written
     // to the other stage right after the MFMA block -- one barrier per k-tile
@@ -180,6 +191,19 @@ __global__ __launch_bounds__(256) void fz_cor_gemm_kernel(const float *__restric
 #undef GEMM_SSTORE
     // epilogue: cov2cor! (C[i,j] / (xsd[i] * xsd[j]), clampcor, unit diagonal), write (i,j) and the mirror (j,i)
     const bool vec_ok = (p & 3) == 0;
+    __shared__ int s_qn;
+    __shared__ unsigned long long s_qbase;
+    int *q_i = (int *)&sA[0][0], *q_j = q_i + GEMM_QCAP;
+    float *q_r = (float *)(q_j + GEMM_QCAP);
+    float flo_pos = 0.0f, flo_neg = 0.0f;
+    unsigned int n_nan = 0;
+    if (SCREEN) {
+        if (tid == 0) s_qn = 0;
+        // (fz_level0_kernel: thresholds lowered by 1e-6 relative -- it can only let a few more pairs through to the exact kernel)
+        flo_pos = (float)thr[0] * 0.999999f;
+        flo_neg = (float)thr[2] * 0.999999f;
+        __syncthreads();
+    }
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -199,9 +223,30 @@ __global__ __launch_bounds__(256) void fz_cor_gemm_kernel(const float *__restric
                     r = r > 1.0f ? 1.0f : (r < -1.0f ? -1.0f : r);  // NaN stays NaN
                     if (i == j) r = 1.0f;
                     vals[e] = r;
-                    if (i < p && j < p) cor[(size_t)i * p + j] = r;
+                    if (SCREEN) {
+                        const bool in = i < j && j < p;
+                        const bool isn = in && isnan(r);
+                        n_nan += isn;
+                        if (in && !isn && fabsf(r) >= (r < 0.0f ? flo_neg : flo_pos)) {
+                            const int q = atomicAdd(&s_qn, 1);  // LDS
+                            if (q < GEMM_QCAP) {
+                                q_i[q] = i;
+                                q_j[q] = j;
+                                q_r[q] = r;
+                            } else {
+                                const unsigned long long slot = atomicAdd(&cnt->n_sig, 1ull);
+                                if (slot < cap) {
+                                    out_i[slot] = i;
+                                    out_j[slot] = j;
+                                    out_r[slot] = r;
+                                }
+                            }
+                        }
+                    } else if (i < p && j < p) {
+                        cor[(size_t)i * p + j] = r;
+                    }
                 }
-                if (bi != bj && j < p && !row_mode) {
+                if (!SCREEN && bi != bj && j < p && !row_mode) {
                     if (vec_ok && i0 + 3 < p) {
                         *reinterpret_cast<float4 *>(&cor[(size_t)j * p + i0]) = make_float4(vals[0], vals[1], vals[2], vals[3]);
                     } else {
@@ -212,6 +257,23 @@ __global__ __launch_bounds__(256) void fz_cor_gemm_kernel(const float *__restric
                 }
             }
         }
+    if (SCREEN) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) n_nan += __shfl_xor(n_nan, o);
+        if (lane == 0 && n_nan) atomicAdd(&cnt->n_nan, (unsigned long long)n_nan);
+        __syncthreads();
+        const int nq = s_qn < GEMM_QCAP ? s_qn : GEMM_QCAP;
+        if (tid == 0 && nq > 0) s_qbase = atomicAdd(&cnt->n_sig, (unsigned long long)nq);
+        __syncthreads();
+        for (int q = tid; q < nq; q += 256) {
+            const unsigned long long slot = s_qbase + (unsigned long long)q;
+            if (slot < cap) {
+                out_i[slot] = q_i[q];
+                out_j[slot] = q_j[q];
+                out_r[slot] = q_r[q];
+            }
+        }
+    }
 }
 
 #include "fw_fz_core.h"
@@ -227,10 +289,6 @@ __global__ void fz_thresholds_kernel(double alpha, double zscale, double *thr)
 // ------------------------------------------------------------------------------------------------
 // 4. level 0: all pairs i < j of the resident matrix (tests.jl:149-159 + the NaN/m rule of :397-398,522-526)
 // ------------------------------------------------------------------------------------------------
-struct FzL0Counters {
-    unsigned long long n_sig;  // pairs with p < alpha (raw)
-    unsigned long long n_nan;  // pairs with NaN p (excluded from m)
-};
 
 // Kernel 1 (screen): p < alpha  <=>  |r| beyond the exact thresholds of fz_thresholds_kernel (lower edge of the
 // guard band); only those pairs (3 % at cfg3) go on to the Float64 log / erfc of kernel 2, densely packed, instead of
@@ -438,8 +496,9 @@ int fwi_fz_compute_cor(fw_ctx *ctx)
                        p, ctx->n_pad);
     const int T = ctx->p_pad / GEMM_BM;
     const int nblk = T * (T + 1) / 2;
-    hipLaunchKernelGGL(fz_cor_gemm_kernel, dim3(nblk), dim3(256), 0, ctx->stream, ctx->d_xc, ctx->d_sd, ctx->d_cor, p,
-                       ctx->n_pad, T, 0, 0);
+    hipLaunchKernelGGL(fz_cor_gemm_kernel<false>, dim3(nblk), dim3(256), 0, ctx->stream, ctx->d_xc, ctx->d_sd, ctx->d_cor, p,
+                       ctx->n_pad, T, 0, 0, (const double *)nullptr, (FzL0Counters *)nullptr, 0ull, (int32_t *)nullptr, (int32_t *)nullptr,
+                       (float *)nullptr);
     FW_HIP(ctx, hipGetLastError());
     FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cnt.kernel_launches += 2;
@@ -469,8 +528,9 @@ int fwi_fz_compute_cor_rows(fw_ctx *ctx, int rank, int world, int64_t *row0, int
                        p, ctx->n_pad);
     const int t0 = std::min(rank * tpr, T), t1 = std::min(t0 + tpr, T);
     if (t1 > t0)
-        hipLaunchKernelGGL(fz_cor_gemm_kernel, dim3((unsigned)((t1 - t0) * T)), dim3(256), 0, ctx->stream, ctx->d_xc, ctx->d_sd, ctx->d_cor,
-                           p, ctx->n_pad, T, 1, t0);
+        hipLaunchKernelGGL(fz_cor_gemm_kernel<false>, dim3((unsigned)((t1 - t0) * T)), dim3(256), 0, ctx->stream, ctx->d_xc, ctx->d_sd, ctx->d_cor,
+                           p, ctx->n_pad, T, 1, t0, (const double *)nullptr, (FzL0Counters *)nullptr, 0ull, (int32_t *)nullptr, (int32_t *)nullptr,
+                           (float *)nullptr);
     FW_HIP(ctx, hipGetLastError());
     FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cnt.kernel_launches += 2;
@@ -515,9 +575,23 @@ int fwi_fz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
         int32_t *ci = (int32_t *)ctx->d_jobs.ptr;
         int32_t *cj = ci + cap;
         float *cr = (float *)(cj + cap);
-        dim3 grid((p + FZ_L0_COLS - 1) / FZ_L0_COLS, (p + FZ_L0_ROWS - 1) / FZ_L0_ROWS);
-        hipLaunchKernelGGL(fz_level0_kernel, grid, dim3(256), 0, ctx->stream, ctx->d_cor, p, (const double *)ctx->d_thr, d_c1, cap, ci,
-                           cj, cr);
+        if (ctx->P.no_cor_mat) {  // dense_cor = false: centred columns -> MFMA tiles -> screen, no matrix
+            const int n = ctx->P.n;
+            ctx->n_pad = (n + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+            ctx->p_pad = (p + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
+            if (!ctx->d_xc) FW_HIP(ctx, hipMalloc(&ctx->d_xc, sizeof(float) * (size_t)ctx->n_pad * ctx->p_pad));
+            if (!ctx->d_sd) FW_HIP(ctx, hipMalloc(&ctx->d_sd, sizeof(float) * (size_t)ctx->p_pad));
+            if (attempt == 0)
+                hipLaunchKernelGGL(fz_center_kernel, dim3(ctx->p_pad), dim3(256), 0, ctx->stream, ctx->d_data, ctx->d_xc, ctx->d_sd, n, p,
+                                   ctx->n_pad);
+            const int T = ctx->p_pad / GEMM_BM;
+            hipLaunchKernelGGL(fz_cor_gemm_kernel<true>, dim3((unsigned)(T * (T + 1) / 2)), dim3(256), 0, ctx->stream, ctx->d_xc, ctx->d_sd,
+                               (float *)nullptr, p, ctx->n_pad, T, 0, 0, (const double *)ctx->d_thr, d_c1, cap, ci, cj, cr);
+        } else {
+            dim3 grid((p + FZ_L0_COLS - 1) / FZ_L0_COLS, (p + FZ_L0_ROWS - 1) / FZ_L0_ROWS);
+            hipLaunchKernelGGL(fz_level0_kernel, grid, dim3(256), 0, ctx->stream, ctx->d_cor, p, (const double *)ctx->d_thr, d_c1, cap, ci,
+                               cj, cr);
+        }
         FW_HIP(ctx, hipGetLastError());
         FzL0Counters h1{};
         FW_HIP(ctx, hipMemcpyAsync(&h1, d_c1, sizeof(h1), hipMemcpyDeviceToHost, ctx->stream));

@@ -25,7 +25,7 @@ class _Params(C.Structure):
     _fields_ = [("kind", C.c_int32), ("n", C.c_int32), ("p", C.c_int32), ("device", C.c_int32),
                 ("max_k", C.c_int32), ("hps", C.c_int32), ("fdr", C.c_int32), ("dense_rules", C.c_int32),
                 ("n_obs_min", C.c_int64), ("max_tests", C.c_int64), ("alpha", C.c_double),
-                ("recursive_pcor", C.c_int32), ("reserved1", C.c_int32)]
+                ("recursive_pcor", C.c_int32), ("no_cor_mat", C.c_int32)]
 
 
 class _TestResult(C.Structure):
@@ -162,7 +162,7 @@ class Engine:
     (src/learning.jl:466-473)."""
 
     def __init__(self, test_name, n, p, max_k=3, alpha=0.01, hps=5, n_obs_min=-1, max_tests=10_000_000, FDR=True,
-                 device=0, dense_rules=False, recursive_pcor=True):
+                 device=0, dense_rules=False, recursive_pcor=True, dense_cor=True):
         self.L = load_library()
         self.test_name = test_name
         self.n, self.p = int(n), int(p)
@@ -171,6 +171,7 @@ class Engine:
         P.device, P.max_k, P.alpha, P.hps = device, max_k, alpha, hps
         P.n_obs_min, P.max_tests, P.fdr = n_obs_min, max_tests, int(FDR)
         P.recursive_pcor = int(bool(recursive_pcor))  # False: conditional fz tests stream the sample columns (no cor_mat, statfuns.jl:19-21)
+        P.no_cor_mat = int(not dense_cor)  # dense_cor = False (learning.jl:42): no p x p matrix at all; needs recursive_pcor = False
         P.dense_rules = int(bool(dense_rules))  # Matrix (dense) table methods instead of the SparseMatrixCSC ones
         self.h = C.c_void_p()
         rc = self.L.fw_ctx_create(C.byref(P), C.byref(self.h))

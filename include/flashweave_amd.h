@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 3 /* 2: fw_params.recursive_pcor, fw_level0_sharded; 3: device-resident exchange (fw_dev_exchange), sharded cor */
+#define FW_ABI_VERSION 4 /* 2: fw_params.recursive_pcor, fw_level0_sharded; 3: device-resident exchange (fw_dev_exchange), sharded cor; 4: fw_params.no_cor_mat */
 
 /* test kinds: src/types.jl:61-72 (test_name "mi" / "mi_nz" / "fz") */
 #define FW_MI 0
@@ -70,7 +70,13 @@ typedef struct fw_params {
                              * every test streams its k + 2 sample columns from HBM and computes the partial correlation from
                              * the data (pcor -> StatsBase.partialcor, src/statfuns.jl:19-21; the FzTestCond with an empty
                              * cor_mat of src/tests.jl:253, learn_network(recursive_pcor = false)).  Level 0 keeps the matrix. */
-    int32_t reserved1;
+    int32_t no_cor_mat;     /* FW_FZ with recursive_pcor = 0 only.  0 (default, the reference's dense_cor = true): level 0 reads the
+                             * resident p x p Pearson matrix (src/learning.jl:42-45).  1 (dense_cor = false, src/tests.jl:118-147 with an
+                             * empty cor_mat): no matrix exists at any time -- fw_level0 multiplies the centred columns tile by tile
+                             * on the matrix cores and screens every tile in the epilogue (the same Float32 correlations and
+                             * thresholds as the matrix path, hence the same network as no_cor_mat = 0), conditional tests come
+                             * from the data (recursive_pcor = 0).  p is then bounded by the data (2 x n x p floats), not by p^2.
+                             * fw_compute_cor_mat / fw_set_cor_mat / fw_get_cor_mat / fw_use_cor_buffer fail with FW_ERR_STATE. */
 } fw_params;
 
 /* One TestResult (src/types.jl:140-145) */

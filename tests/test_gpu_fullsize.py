@@ -347,3 +347,21 @@ def test_cfg5_full_size_long_list_jobs_equal_oracle():
         if alpha != 0.01:
             assert deep >= len(T) // 2  # most jobs ran to the cap
     eng.close()
+
+
+def test_cfg3_full_size_level0_without_a_matrix_equals_the_matrix_path():
+    # dense_cor = False at the metric's size: the tile-by-tile screen in the GEMM epilogue finds exactly the neighbour lists (and
+    # statistics, p-values) level 0 reads off the resident 10 000 x 10 000 matrix
+    c = synth.CONFIGS["cfg3"]
+    counts = synth.generate(c["p"], c["n"], c["seed"], mode=c["mode"])
+    data, _, _ = pre.normalize(counts, "fz", prec=32)
+    n, p = data.shape
+    res = []
+    for dense in (True, False):
+        eng = fw.Engine("fz", n, p, max_k=3, recursive_pcor=False, dense_cor=dense)
+        eng.set_data(data)
+        res.append(eng.pw_univar_neighbors())
+        eng.close()
+    a, b = res
+    assert (a["off"] == b["off"]).all() and (a["idx"] == b["idx"]).all() and a["off"][-1] > 10**5
+    assert (a["stat"] == b["stat"]).all() and (a["pval"] == b["pval"]).all()

@@ -166,3 +166,35 @@ def test_feed_forward_network_without_a_correlation_matrix(ctx, round_size):
     for e_, w in exp["edges"].items():
         assert abs(net["edges"][e_] - w) < 1e-11
     assert eng.counters()["cond_tests_ref"] == exp["n_cond_tests"]
+
+
+def test_network_without_any_correlation_matrix(ctx):
+    # dense_cor = False (fw_params.no_cor_mat, learning.jl:42 / tests.jl:118-147): level 0 multiplies the centred columns on the matrix
+    # cores and screens every tile in the epilogue -- the same Float32 correlations and thresholds as the matrix path, so the
+    # network is the one of dense_cor = True, recursive_pcor = False to the bit; no p x p matrix is ever allocated.
+    data, n, p, eng = ctx["data"], ctx["n"], ctx["p"], ctx["eng"]
+    with pytest.raises(fw.FlashWeaveError):
+        fw.Engine("fz", n, p, max_k=3, recursive_pcor=True, dense_cor=False)
+    e2 = fw.Engine("fz", n, p, max_k=3, recursive_pcor=False, dense_cor=False)
+    e2.set_data(data)
+    with pytest.raises(fw.FlashWeaveError):
+        e2.cor()
+    for ff, rs in ((False, 0), (True, 64)):
+        a = eng.lgl(feed_forward=ff, round_size=rs)
+        b = e2.lgl(feed_forward=ff, round_size=rs)
+        assert a["edges"] == b["edges"] and len(a["edges"]) > 100
+    # explicit tests: conditional ones are the data path's; univariate ones come from the data too (Float64 sums of the two
+    # columns instead of the Float32 matrix entry)
+    cm = ctx["cm"]
+    got = e2.test_batch([0, 3, 5], [1, 4, 9], [[], [], [2, 7]])
+    ref = eng.test_batch([0, 3, 5], [1, 4, 9], [[], [], [2, 7]])
+    assert abs(got[0].stat - cm[0, 1]) < 1e-6 and abs(got[1].stat - cm[3, 4]) < 1e-6
+    assert got[2].stat == ref[2].stat and got[2].pval == ref[2].pval
+    e2.close()
+
+
+def test_learn_network_dense_cor_false():
+    raw = np.loadtxt(GOLDEN + "/HMP_SRA_gut_small.tsv", delimiter="\t", skiprows=1, usecols=range(1, 51))
+    a = fw.learn_network(raw, sensitive=True, heterogeneous=False, recursive_pcor=False)
+    b = fw.learn_network(raw, sensitive=True, heterogeneous=False, recursive_pcor=False, dense_cor=False)
+    assert a["edges"] == b["edges"] and len(a["edges"]) > 5
