@@ -198,3 +198,35 @@ def test_learn_network_dense_cor_false():
     a = fw.learn_network(raw, sensitive=True, heterogeneous=False, recursive_pcor=False)
     b = fw.learn_network(raw, sensitive=True, heterogeneous=False, recursive_pcor=False, dense_cor=False)
     assert a["edges"] == b["edges"] and len(a["edges"]) > 5
+
+
+def test_no_matrix_level0_never_allocates_the_matrix():
+    # p = 40 000: the fp32 matrix takes 5.96 GiB.  The same level 0 with dense_cor = False must use that much less device memory
+    # (what remains is proportional to the data and to the number of significant pairs) and find the same neighbour lists.
+    import torch
+    rng = np.random.default_rng(3)
+    n, p = 128, 40_000
+    # (nearly independent columns, no FDR: about 1 % of the 8e8 pairs pass)
+    base = rng.standard_normal((n, 4)).astype(np.float32)
+    data = np.asfortranarray(0.2 * base @ rng.standard_normal((4, p)).astype(np.float32) + rng.standard_normal((n, p)).astype(np.float32))
+    used, nbs = {}, {}
+    for dense in (False, True):
+        torch.cuda.synchronize()
+        free0, _ = torch.cuda.mem_get_info()
+        eng = fw.Engine("fz", n, p, max_k=0, recursive_pcor=False, dense_cor=dense, FDR=False)
+        eng.set_data(data)
+        nbs[dense] = eng.pw_univar_neighbors()
+        torch.cuda.synchronize()
+        free1, _ = torch.cuda.mem_get_info()
+        used[dense] = free0 - free1
+        eng.close()
+    assert used[True] - used[False] > 0.9 * 4 * p * p, (used[True] / 2**30, used[False] / 2**30)
+    a, b = nbs[True], nbs[False]
+    assert (a["off"] == b["off"]).all() and (a["idx"] == b["idx"]).all() and (a["pval"] == b["pval"]).all() and a["off"][-1] > 10**6
+    # a sample of the neighbour lists against Float64 correlations of the same columns
+    d64 = data.astype(np.float64)
+    dc = (d64 - d64.mean(axis=0)) / d64.std(axis=0)
+    for t in (0, 17, 39_999):
+        idx = b["idx"][b["off"][t]:b["off"][t + 1]]
+        r = (dc[:, [t]] * dc[:, idx]).mean(axis=0)
+        assert np.abs(r - b["stat"][b["off"][t]:b["off"][t + 1]]).max() < 1e-5
