@@ -92,6 +92,7 @@ struct DhParams {
     unsigned int mi_seq_heavy; // ... and run this many first tests of a job alone (instead of mi_seq) before they open a board
     unsigned int mi_seq_tail;  // ... and every target this many once the target list is exhausted (idle wavefronts are waiting for work)
     unsigned int mi_chunk_tail, mi_win0_tail;  // ranks per record / first window once the launch is in its tail (idle wavefronts waiting)
+    unsigned int mi_ahead;     // R4 kernels: first tests of up to four interleaving candidates in one step (mi_first4); 0: off
     unsigned int mi_team;      // the first mi_team targets of the (heaviest-first) list are run by a whole workgroup each (dh_mi_team)
     unsigned int mi_team_tail;   // team targets publish tail-mode boards (short records, wide first window) from the start
     unsigned int mi_team_steps;  // lock-step rounds of a team job (4 wavefronts x 1 or 4 ranks each) before its enumeration goes to a board
@@ -691,7 +692,7 @@ __device__ __noinline__ FwSegOut mi_run_ranks4(const MiDev M_in, int T, int cand
                 }
             }
         }
-        MiRes mine = mi_test_core4<L>(M, T, cand, zrow, s_step, tab);
+        MiRes mine = mi_test_core4<L>(M, T, cand, zrow, s_step, tab, cand);
         o.evaluated += (unsigned long long)nb;
         bool stopped = false;
         for (int t = 0; t < nb; ++t) {  // rank order (uniform: every lane reads row t's result)
@@ -726,6 +727,84 @@ __device__ __noinline__ FwSegOut mi_run_ranks4(const MiDev M_in, int T, int cand
         r += (unsigned long long)nb;
     }
     return o;
+}
+
+// ---- first tests of four candidates at once (R4 kernels) ------------------------------------------------------------------------
+// Most interleaving jobs end with their FIRST test (cfg2: 2.6 tests per job, a target with 190 candidates is a chain of ~200 jobs of
+// ~20 us).  While a candidate is rejected the accepted list does not change, so the first test of the next candidates -- (T, c | the
+// first subset of the same list) -- can be evaluated before the current one is decided: one mi_test_core4 step takes candidates
+// pos .. pos + 3 on its four rows (same X, same Z, the row's own Y).  The results are kept per wavefront and consumed in
+// candidate order as long as (target, accepted length) still match; the first accepted candidate invalidates the rest.  A
+// candidate whose first test is significant continues with rank 1 of its own job, seeded with that test.
+struct MiAhead {
+    int T, pos0, na, n;  // results for candidates pos0 .. pos0 + n - 1 of target T's interleaving list, accepted length na
+    int stop[4], df[4], power[4];
+    double stat[4], pval[4], g[4];  // stop: the test ended the job (stat / pval / df / power of it); else its p is materialised
+};
+__shared__ MiAhead dh_mi_ahead[4];
+
+template <int L>
+__device__ __noinline__ void mi_first4(const MiDev M_in, int T, int pos0, const int32_t *__restrict__ cands_in, int nb, const int32_t *__restrict__ acc_in,
+                                       int a, int max_k, long long max_tests)
+{
+    unsigned short *tab = dh_mi_tab[threadIdx.x >> 6];
+    MiAhead &H = dh_mi_ahead[threadIdx.x >> 6];
+    const MiDev M = mi_uniform(M_in);
+    T = __builtin_amdgcn_readfirstlane(T);
+    pos0 = __builtin_amdgcn_readfirstlane(pos0);
+    nb = __builtin_amdgcn_readfirstlane(nb);
+    a = __builtin_amdgcn_readfirstlane(a);
+    max_k = __builtin_amdgcn_readfirstlane(max_k);
+    max_tests = (long long)mi_rfl64((unsigned long long)max_tests);
+    const int32_t *cands = (const int32_t *)mi_rfl64((unsigned long long)cands_in);
+    const int32_t *acc = (const int32_t *)mi_rfl64((unsigned long long)acc_in);
+    const int lane = threadIdx.x & 63, row = lane >> 4;
+    const int s = max_k < a ? max_k : a;  // rank 0: the first subset of the largest size the list allows (tests.jl:300-311)
+    int zrow[3];
+    zrow[0] = acc[0];
+    zrow[1] = acc[s >= 2 ? 1 : 0];
+    zrow[2] = acc[s >= 3 ? 2 : 0];
+    // the uniform decisions of the test core read levels / maxv > 1 of Y: only candidates that agree with the first one share a step
+    const int c0 = cands[0];
+    int n = 1;
+    for (int t = 1; t < nb; ++t) {
+        const int ct = cands[t];
+        if (M.levels[ct] != M.levels[c0] || (M.maxv[ct] > 1) != (M.maxv[c0] > 1)) break;
+        ++n;
+    }
+    const int my_c = cands[row < n ? row : 0];
+    MiRes mine = mi_test_core4<L>(M, T, c0, zrow, s, tab, my_c);
+    for (int t = 0; t < n; ++t) {
+        MiRes tt;
+        const int src = 16 * t;
+        tt.stat = __longlong_as_double((long long)mi_rfl_lane64((unsigned long long)__double_as_longlong(mine.stat), src));
+        tt.g = __longlong_as_double((long long)mi_rfl_lane64((unsigned long long)__double_as_longlong(mine.g), src));
+        tt.pval = __longlong_as_double((long long)mi_rfl_lane64((unsigned long long)__double_as_longlong(mine.pval), src));
+        tt.df = __builtin_amdgcn_readlane(mine.df, src);
+        tt.power = __builtin_amdgcn_readlane(mine.power, src);
+        tt.n_obs = (long long)mi_rfl_lane64((unsigned long long)mine.n_obs, src);
+        MiBest mb;
+        mb.p = -3.0;
+        mb.stat = mb.g = 0.0;
+        mb.df = 0;
+        const int ev = mi_account(M, tt, max_tests == 1, mb, false);  // tests.jl:326-341 for rank 0
+        if (lane == 0) {
+            H.stop[t] = ev == 1;
+            H.stat[t] = tt.stat;
+            H.pval[t] = ev == 1 ? tt.pval : mb.p;
+            H.g[t] = tt.g;
+            H.df[t] = tt.df;
+            H.power[t] = tt.power;
+        }
+    }
+    if (lane == 0) {
+        H.T = T;
+        H.pos0 = pos0;
+        H.na = a;
+        H.n = n;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // R4: the four-subsets-per-step form (host: n <= MI4_N, max_k <= 3, 2 x 2 cells); one of the two routines per instantiation
@@ -1208,6 +1287,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #endif
+    if (lane == 0) dh_mi_ahead[threadIdx.x >> 6].n = 0;  // (no look-ahead results yet)
     const unsigned long long tk_begin = wall_clock64();
     // the heaviest targets (the first mi_team of the list): a workgroup each, all four wavefronts on it (dh_mi_team), taken in list
     // order by whichever workgroup is free; the list proper starts behind them
@@ -1219,6 +1299,8 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
         if (ts >= P.mi_team) break;
         dh_mi_team<L, NXY, PRE, R4>(tg, ntg, order[ts], A, M, P, Q, boards, res, bacc);
     }
+    unsigned int jobctr = 0u;
+    bool tail_seen = false;
     for (;;) {
         const unsigned int slot = P.mi_team + mi_wave_add(&Q->next_target, 1u, lane);
         if (slot >= (unsigned int)ntg) break;
@@ -1238,7 +1320,11 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
             // ... unless this target is one of the heavy ones: its own chain of jobs IS the critical path (cfg2 / cfg4: the
             // launch ended when the heaviest target did, 13 ms after the average wavefront had run out of targets)
             const bool heavy = P.mi_heavy > 0u && (unsigned int)x.nc >= P.mi_heavy;
-            if (P.mi_help_jobs && !heavy)
+            // the shared words (boards, target counters) are looked at before every FOURTH job: each look is two to four sc1 round
+            // trips of ~2 us, and a chain of jobs that end with their first test (or cost nothing at all: mi_first4) paid more for
+            // them than for its tests (cfg2 trace: 18.8 us per job against a 12 us test)
+            const bool poll = (jobctr++ & 3u) == 0u;
+            if (P.mi_help_jobs && !heavy && poll)
                 while (mi_ld_u32(&Q->n_boards) > mi_ld_u32(&Q->hint) && mi_help<L, NXY, PRE, R4>(Q, boards, res, bacc, M, P, lane)) {
                 }
             const unsigned long long tk1 = wall_clock64();
@@ -1262,11 +1348,68 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
             // tests (one rank of eight, cfg4: 46.9 -> 37.2 ms of conditional stage)
             // (tail: no target left to claim AND fewer than one wavefront in eight still owns one -- cfg2 has as many targets as
             // the launch has wavefronts: "list exhausted" alone switched every job of the pass to the short prefix, 15 -> 22 ms)
-            const bool tail = mi_ld_u32(&Q->next_target) + P.mi_team >= (unsigned int)ntg &&
-                              ((unsigned int)ntg - mi_ld_u32(&Q->targets_done)) * 8u <= gridDim.x * 4u;
+            if (poll)
+                tail_seen = mi_ld_u32(&Q->next_target) + P.mi_team >= (unsigned int)ntg &&
+                            ((unsigned int)ntg - mi_ld_u32(&Q->targets_done)) * 8u <= gridDim.x * 4u;
+            const bool tail = tail_seen;
             const unsigned long long seq = tail ? P.mi_seq_tail : (heavy ? P.mi_seq_heavy : P.mi_seq);
             unsigned long long next = elim_full ? 0ull : (N < seq ? N : seq);
-            FwSegOut o = mi_run_ranks_sel<L, NXY, PRE, R4>(M, x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, 0ull, next, nullptr, 0, nullptr);
+            FwSegOut o;
+            bool first_known = false;
+            if constexpr (R4) {
+                MiAhead &H = dh_mi_ahead[threadIdx.x >> 6];
+                if (P.mi_ahead && x.phase == 0 && a >= 1 && next >= 1ull) {
+                    bool hit = H.T == x.T && H.na == a && x.pos >= H.pos0 && x.pos < H.pos0 + H.n;
+                    unsigned long long computed = 0ull;
+                    if (!hit && x.nc - x.pos >= 2) {
+                        const int nb = x.nc - x.pos < 4 ? x.nc - x.pos : 4;
+                        mi_first4<L>(M, x.T, x.pos, cands + x.pos, nb, A.acc + acc_off, a, P.max_k, P.max_tests);
+                        computed = (unsigned long long)H.n;
+                        hit = true;
+                    }
+                    if (hit) {
+                        const int t = x.pos - H.pos0;
+                        first_known = true;
+                        o.stop_rank = FW_RANK_NONE;
+                        o.stop_stat = o.stop_pval = 0.0;
+                        o.best_rank = 0ull;
+                        o.best_stat = 0.0;
+                        o.best_pval = -3.0;
+                        o.stop_df = o.stop_power = o.best_df = o.pad = 0;
+                        o.evaluated = 0ull;
+                        if (H.stop[t]) {
+                            o.stop_rank = 0ull;
+                            o.stop_stat = H.stat[t];
+                            o.stop_pval = H.pval[t];
+                            o.stop_df = H.df[t];
+                            o.stop_power = H.power[t];
+                        } else {
+                            if (next > 1ull) {  // ranks 1 .. of this candidate's own job, seeded with its first test
+                                MiBest &sd = dh_mi_seed[threadIdx.x >> 6];
+                                if (lane == 0) {
+                                    sd.p = H.pval[t];
+                                    sd.stat = H.stat[t];
+                                    sd.g = H.g[t];
+                                    sd.df = H.df[t];
+                                }
+                                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                                __builtin_amdgcn_wave_barrier();
+                                o = mi_run_ranks_sel<L, NXY, PRE, R4>(M, x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, 1ull, next, nullptr, 0,
+                                                                      H.pval[t] > 1e-290 ? &sd : nullptr);
+                            }
+                            if (o.stop_rank == FW_RANK_NONE && !(o.best_pval >= H.pval[t])) {  // the first test is still the maximum
+                                o.best_pval = H.pval[t];
+                                o.best_stat = H.stat[t];
+                                o.best_df = H.df[t];
+                                o.stop_stat = H.g[t];
+                            }
+                        }
+                        o.evaluated += computed;
+                    }
+                }
+            }
+            if (!first_known)
+                o = mi_run_ranks_sel<L, NXY, PRE, R4>(M, x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, 0ull, next, nullptr, 0, nullptr);
             unsigned long long ev = o.evaluated, nt = 0ull;
             bool stopped = o.stop_rank != FW_RANK_NONE;
             double r_stat = stopped ? o.stop_stat : 0.0, r_p = stopped ? o.stop_pval : 0.0;
@@ -2042,6 +2185,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         { const char *e = fw_knob("FW_MI_HEAVY"); P.mi_heavy = e ? (unsigned int)atoi(e) : 48u; }
         { const char *e = fw_knob("FW_MI_SEQ_HEAVY"); P.mi_seq_heavy = e ? (unsigned int)atoi(e) : P.mi_seq; }
         { const char *e = fw_knob("FW_MI_SEQ_TAIL"); P.mi_seq_tail = e ? (unsigned int)atoi(e) : 4u; }
+        { const char *e = fw_knob("FW_MI_AHEAD"); P.mi_ahead = e ? (unsigned int)atoi(e) : 1u; }
         { const char *e = fw_knob("FW_MI_CHUNK_TAIL"); P.mi_chunk_tail = e ? (unsigned int)std::max(1, atoi(e)) : P.mi_chunk_min; }
         { const char *e = fw_knob("FW_MI_WIN0_TAIL"); P.mi_win0_tail = e ? (unsigned int)std::max(1, atoi(e)) : 1024u; }
     }
@@ -2136,8 +2280,8 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->P.device);
         const unsigned grid = std::min((unsigned)((ntg + 3) / 4), wg_per_cu * (unsigned)n_cu);
         {   // targets with at least FW_MI_TEAM_MIN candidates (at most FW_MI_TEAM_MAX of them): a workgroup each
-            static const unsigned team_min = [] { const char *e = fw_knob("FW_MI_TEAM_MIN"); return e ? (unsigned)atoi(e) : 64u; }();
-            static const unsigned team_max = [] { const char *e = fw_knob("FW_MI_TEAM_MAX"); return e ? (unsigned)atoi(e) : 256u; }();
+            static const unsigned team_min = [] { const char *e = fw_knob("FW_MI_TEAM_MIN"); return e ? (unsigned)atoi(e) : 96u; }();
+            static const unsigned team_max = [] { const char *e = fw_knob("FW_MI_TEAM_MAX"); return e ? (unsigned)atoi(e) : 192u; }();  // (64 / 256: cfg2 10.5 ms, cfg4 161.7; 128 / 128: 9.4, 162.7; 96 / 192: 9.3, 159.6)
             static const unsigned team_steps = [] { const char *e = fw_knob("FW_MI_TEAM_STEPS"); return e ? (unsigned)atoi(e) : 2u; }();
             unsigned team = 0u;
             while (team_min > 0u && team < team_max && (int)team < ntg && (unsigned)tg[order[team]].nc >= team_min) ++team;

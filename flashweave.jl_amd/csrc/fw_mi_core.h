@@ -563,8 +563,11 @@ static __device__ __forceinline__ double mi_row_sum_d(double v)
 
 // zrow: the conditioning variables of THIS lane's row; k (1..3) and X, Y are wave-uniform.  tab4: MI4_TAB16 u16 per row.
 template <int L>
+// y_lane: the Y variable of THIS lane's row.  The four rows of a step are four subsets of one (X, Y) job (y_lane = Y_in) or the first
+// subsets of four candidates of one target (mi_first4: y_lane differs per row; Y_in is then any of them -- the caller makes sure they
+// agree in everything the uniform decisions below read: levels, maxv > 1).
 static __device__ __forceinline__ MiRes mi_test_core4(const MiDev &P, const int X_in, const int Y_in, const int (&zrow)[3], const int k_in,
-                                                      unsigned short *tab4)
+                                                      unsigned short *tab4, const int y_lane)
 {
     constexpr int NXY = 2, NC = 4, NCT = 5, NCT16 = 6, SBMAX = L * L;
     const int X = __builtin_amdgcn_readfirstlane(X_in), Y = __builtin_amdgcn_readfirstlane(Y_in);
@@ -596,8 +599,8 @@ static __device__ __forceinline__ MiRes mi_test_core4(const MiDev &P, const int 
     const bool viewX = P.dense && P.view && P.nzmode && P.levels[X] > 2, viewY = P.dense && P.view && P.nzmode && P.levels[Y] > 2;
     const unsigned *pn = (const unsigned *)P.nz, *ph = (const unsigned *)P.hi;
     const size_t W2 = 2 * (size_t)P.W;
-    const unsigned *xn = pn + (size_t)X * W2, *yn = pn + (size_t)Y * W2;
-    const unsigned *xh = (L == 3 && ph) ? ph + (size_t)X * W2 : nullptr, *yh = (L == 3 && ph) ? ph + (size_t)Y * W2 : nullptr;
+    const unsigned *xn = pn + (size_t)X * W2, *yn = pn + (size_t)y_lane * W2;
+    const unsigned *xh = (L == 3 && ph) ? ph + (size_t)X * W2 : nullptr, *yh = (L == 3 && ph) ? ph + (size_t)y_lane * W2 : nullptr;
     const int nd = (P.n + 31) >> 5;
     const int nw = (nd + 15) >> 4;  // words per lane (uniform)
     // ---- X / Y part of every cell mask of this lane's words (the same for the four rows; batch independent) ----
