@@ -2170,7 +2170,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         P.spec_below = envu("FW_DH_SPEC_BELOW", 12000000ull);
         P.spec0_depth = spec0_depth;
         P.spec0_below = envu("FW_DH_SPEC0_BELOW", 12000000ull);
-        P.spec0_jobs = (unsigned int)envu("FW_DH_SPEC0_JOBS", 512ull);
+        P.spec0_jobs = (unsigned int)envu("FW_DH_SPEC0_JOBS", 4096ull);  // (r03: 512 kept it off in the light feed-forward rounds of 1 024 targets: cfg3 204.8 -> 198.6 ms, 9 222 -> 7 966 launches)
         {   // look-ahead behind a candidate that is about to be accepted (dh_step_kernel, spmode 1)
             const char *e = fw_knob("FW_DH_SPEC1");
             P.spec1_depth = c->P.kind == FW_FZ ? std::min(std::max(e ? atoi(e) : 2, 0), DH_MAX_SPEC) : 0;

@@ -10,7 +10,7 @@ print('$name', round(d['ms_per_step'],2), 'cond', round(1e3*d['stage_seconds_ran
 }
 for occ in 1 2; do
   touch flashweave.jl_amd/csrc/fw_devhiton.hip; make -C flashweave.jl_amd/csrc EXTRA=-DDH_MI_OCC=$occ > /dev/null 2>&1
-  for ff in 0 1; do for cfg in cfg4 cfg2; do
+  for ff in 0 1; do for cfg in cfg4; do
     run occ${occ}_${cfg}_ff${ff}_wg1 $cfg $ff FW_MI_WG_PER_CU=1
     [ $occ = 2 ] && run occ${occ}_${cfg}_ff${ff}_wg2 $cfg $ff FW_MI_WG_PER_CU=2
   done; done
