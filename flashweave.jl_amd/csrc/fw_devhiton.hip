@@ -99,6 +99,8 @@ struct DhParams {
     int spec0_depth;                // interleaving-phase look-ahead (first windows of the next candidates)
     unsigned long long spec0_below;
     unsigned int spec0_jobs;  // ... and fewer live jobs than this
+    int spec0_depth_light;          // ... and this many candidates while the last launch held fewer than spec0_light_below ranks
+    unsigned long long spec0_light_below;
     int spec1_depth;          // interleaving-phase look-ahead behind a candidate that is about to be accepted (same two conditions)
 };
 
@@ -1675,7 +1677,10 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
             if (x.phase == 0 && P.spec0_depth > 0 && g->launched_ranks < P.spec0_below && g->n_live_prev < P.spec0_jobs) {
                 const int32_t *cands = A.cand0 + x.cand_off;
                 int q = 0;
-                while (q < P.spec0_depth && x.pos + 1 + q < x.nc) {
+                // (light launches -- the first feed-forward rounds, a rank of a multi-GPU job: the tests are nearly free, the dependent
+                // rounds are the cost -> more candidates per round)
+                const int depth = g->launched_ranks < P.spec0_light_below ? P.spec0_depth_light : P.spec0_depth;
+                while (q < depth && x.pos + 1 + q < x.nc) {
                     if (x.wl_n > 0 && dh_in_wl(x, A, cands[x.pos + 1 + q])) break;  // whitelisted: joins without a test
                     ++q;
                 }
@@ -2170,6 +2175,8 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         P.spec_below = envu("FW_DH_SPEC_BELOW", 12000000ull);
         P.spec0_depth = spec0_depth;
         P.spec0_below = envu("FW_DH_SPEC0_BELOW", 12000000ull);
+        { const char *e = fw_knob("FW_DH_SPEC0_LIGHT"); P.spec0_depth_light = spec0_depth > 0 ? std::min(std::max(e ? atoi(e) : spec0_depth, spec0_depth), DH_MAX_SPEC) : 0; }
+        P.spec0_light_below = envu("FW_DH_SPEC0_LIGHT_BELOW", 400000ull);
         P.spec0_jobs = (unsigned int)envu("FW_DH_SPEC0_JOBS", 4096ull);  // (r03: 512 kept it off in the light feed-forward rounds of 1 024 targets: cfg3 204.8 -> 198.6 ms, 9 222 -> 7 966 launches)
         {   // look-ahead behind a candidate that is about to be accepted (dh_step_kernel, spmode 1)
             const char *e = fw_knob("FW_DH_SPEC1");
