@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void fzs_test_batch_kernel(FzsDev P, long long
 #define FZS_SEG_OCC 4  // workgroups per CU (= waves per SIMD) the segment kernel is compiled for; 3 / 4 / 5: 3.31 / 3.67 / 1.65 e8 tests/s (5: spills inside the loop)
 #endif
 // GRAM: the correlations of a job are not streamed per test but read from the job's (a + 2) x (a + 2) Float64 matrix, computed once
-// per job and pool round by fzs_gram_kernel (see there); the workgroup stages it in LDS (dynamic, lds_m variables) when it fits.
+// per job and pool round by fzs_gram_kernel (see there); the workgroup stages it in LDS (dynamic, lds_m <= 80 variables) when it fits.
 template <int K, int T, bool GRAM>
 __global__ __launch_bounds__(256, FZS_SEG_OCC) void fzs_subsets_seg_kernel(FzsDev P, const FwSeg *__restrict__ segs,
                                                               const int32_t *__restrict__ accflat, FwSegOut *__restrict__ out,
@@ -782,7 +782,7 @@ int fwi_fzs_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32
         if ((rc = fw_dev_reserve(ctx, ctx->d_arena, std::max<size_t>(arena_doubles, 1) * sizeof(double)))) return rc;
         FW_HIP(ctx, hipMemcpyAsync(ctx->d_nzrecs.ptr, recs_host, (size_t)njobs * sizeof(FwNzJob), hipMemcpyHostToDevice, pb.launch_stream));
         for (int64_t j = 0; j < njobs; ++j) lds_m = std::max(lds_m, (int)recs_host[j].m);
-        lds_m = std::min(lds_m, 90);  // 90 x 90 doubles = 63.3 KB: the default dynamic-LDS limit; longer jobs read their matrix through L2
+        lds_m = std::min(lds_m, 80);  // 80 x 80 doubles = 50 KB + 9 KB of static LDS: inside the 64 KB a workgroup gets without asking; longer jobs read their matrix through L2
     }
     FW_HIP(ctx, hipEventRecord(pb.ev0, pb.launch_stream));
     const FzsDev P = fzs_dev(ctx);
