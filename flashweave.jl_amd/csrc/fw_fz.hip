@@ -447,7 +447,10 @@ __global__ __launch_bounds__(256) void fz_test_batch_kernel(const float *__restr
 #define FW_HIGHK_OCC 4  // workgroups per CU the size-4/5 variants are compiled for (4: 128 VGPRs, 2: 256 VGPRs)
 #endif
 template <bool HIGHK, bool LOCAL, bool TAB>
-__global__ __launch_bounds__(256, HIGHK ? ((TAB || LOCAL) ? FW_HIGHK_OCC : 3) : 4) void fz_subsets_seg_kernel(const float *__restrict__ cor_g, int p_g,
+#ifndef FW_HIGHK_OCC_LONG
+#define FW_HIGHK_OCC_LONG 3  // ... and the long-list variant with its level-3 position tables (48 KB of LDS, 168 VGPRs)
+#endif
+__global__ __launch_bounds__(256, HIGHK ? ((TAB || LOCAL) ? FW_HIGHK_OCC : FW_HIGHK_OCC_LONG) : 4) void fz_subsets_seg_kernel(const float *__restrict__ cor_g, int p_g,
                                                              const FwSeg *__restrict__ segs,
                                                              const int32_t *__restrict__ accflat,
                                                              FwSegOut *__restrict__ out, int max_k, double alpha,

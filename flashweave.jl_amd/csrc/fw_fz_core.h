@@ -611,7 +611,10 @@ __device__ __forceinline__ double fz_l1t_stat(const float *__restrict__ cor, int
 // the same values with the same argument roles as fz_pcor_dp (level 2 is not symmetric in its two conditioning values: the
 // later position is the first argument, as in U = [X, Y, z_K, ..., z_2]): bit-identical, checked by
 // tests/test_gpu_fz.py::test_size_4_5_table_kernels_value_at_random_ranks and the cfg5 long-list oracle test.
-#define FZ_L3_CAP 448  // positions (over all sub-blocks of a chunk): 31 KB; with the level-1 table and the list 48 KB -> three workgroups per CU
+#ifndef FZ_L3_CAP
+#define FZ_L3_CAP 448
+#endif
+// FZ_L3_CAP: positions (over all sub-blocks of a chunk): 31 KB; with the level-1 table and the list 48 KB -> three workgroups per CU
 #define FZ_L3_DIR 64   // sub-blocks per chunk
 
 // HIGHK: subsets of size 4-5 possible; LOCAL: per-job matrices (fz_nz); TAB: size-3 subsets through the LDS table
