@@ -2051,7 +2051,8 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     // the segment kernels (the path of the ABI's fw_test_subsets_batch) for comparison.  Fisher-z always runs as rounds (a
     // persistent-workgroup variant was built in r02, lost 140 vs 58 ms on the heavy rounds, and was removed in r03).
     static const bool mi_rounds = [] { const char *e = fw_knob("FW_MI_ROUNDS"); return e && atoi(e) != 0; }();
-    const bool per_target = c->P.kind != FW_FZ && !mi_rounds;
+    // (more than 65 535 samples: 32-bit cell counts -- only the segment kernels have that form, so such data takes the rounds)
+    const bool per_target = c->P.kind != FW_FZ && !mi_rounds && c->P.n <= 65535;
     const int spec_depth = c->P.kind == FW_FZ ? std::min(std::max(spec_env, 0), DH_MAX_SPEC) : 0;
     const int d1 = spec_depth + 1;
     // interleaving-phase look-ahead (first windows of the next candidates, same accepted list): FW_DH_SPEC0 candidates,

@@ -27,14 +27,14 @@ static double host_igamc(double a, double x);
 // ------------------------------------------------------------------------------------------------
 // batch of single tests: one wave per test
 // ------------------------------------------------------------------------------------------------
-template <int L, int NXY, bool PRE>
+template <int L, int NXY, bool PRE, bool WIDE>
 __global__ __launch_bounds__(256) void mi_test_batch_kernel(MiDev P, long long m, const int32_t *__restrict__ X,
                                                             const int32_t *__restrict__ Y,
                                                             const long long *__restrict__ zoff,
                                                             const int32_t *__restrict__ zflat,
                                                             fw_test_result *__restrict__ out)
 {
-    __shared__ unsigned short s_tab[4][MI_TAB16];
+    __shared__ unsigned short s_tab[4][WIDE ? 2 * MI_TAB16 : MI_TAB16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long t = (long long)blockIdx.x * 4 + wave;
     if (t >= m) return;
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void mi_test_batch_kernel(MiDev P, long long m
 #pragma unroll
     for (int q = 0; q < MI_MAX_K; ++q) zs.v[q] = (q < k) ? zflat[zoff[t] + q] : 0;
     if (P.prof) P.prof += 8 * t;  // one record per test
-    MiRes r = mi_test_core<L, NXY, PRE>(P, X[t], Y[t], zs, k, s_tab[wave]);
+    MiRes r = mi_test_core<L, NXY, PRE, WIDE>(P, X[t], Y[t], zs, k, s_tab[wave]);
     const unsigned long long pt = P.prof ? __builtin_readcyclecounter() : 0ull;
     (void)mi_res_pval(r);
     if (P.prof && lane == 0) P.prof[3] = __builtin_readcyclecounter() - pt;
@@ -62,12 +62,12 @@ __global__ __launch_bounds__(256) void mi_test_batch_kernel(MiDev P, long long m
 // ------------------------------------------------------------------------------------------------
 #define MI_RUN 4
 
-template <int L, int NXY, bool PRE>
+template <int L, int NXY, bool PRE, bool WIDE>
 __device__ __forceinline__ void mi_seg_body(const MiDev &P, const FwSeg *__restrict__ segs, const int32_t *__restrict__ accflat,
                                             FwSegOut *__restrict__ out, int max_k, double alpha, long long max_tests,
                                             const unsigned sidx /* segment this workgroup evaluates */, int need_p)
 {
-    __shared__ unsigned short s_tab[4][MI_TAB16];
+    __shared__ unsigned short s_tab[4][WIDE ? 2 * MI_TAB16 : MI_TAB16];
     __shared__ unsigned long long s_stop[4], s_br[4];
     __shared__ double s_sstat[4], s_sp[4], s_bp[4], s_bstat[4];
     __shared__ int s_sdf[4], s_spow[4], s_bdf[4];
@@ -113,7 +113,7 @@ __device__ __forceinline__ void mi_seg_body(const MiDev &P, const FwSeg *__restr
                 MiZs zs;
 #pragma unroll
                 for (int q = 0; q < MI_MAX_K; ++q) zs.v[q] = (q < s) ? gacc[pos[q]] : 0;
-                MiRes t = mi_test_core<L, NXY, PRE>(P, seg.X, seg.Y, zs, s, s_tab[wave]);
+                MiRes t = mi_test_core<L, NXY, PRE, WIDE>(P, seg.X, seg.Y, zs, s, s_tab[wave]);
                 ++my_done;
                 const int ev = mi_account(P, t, max_tests > 0 && r + 1 >= (unsigned long long)max_tests, mb, need_p != 0);
                 if (ev == 1) {
@@ -212,7 +212,7 @@ __device__ __forceinline__ void mi_seg_body(const MiDev &P, const FwSeg *__restr
 
 // Host-driven rounds: one workgroup per segment (ns_dev == nullptr); device-driven rounds (fw_devhiton.hip): a fixed
 // grid covers the device-built segment list whose live length is *ns_dev.
-template <int L, int NXY, bool PRE>
+template <int L, int NXY, bool PRE, bool WIDE>
 __global__ __launch_bounds__(256) void mi_subsets_seg_kernel(MiDev P, const FwSeg *__restrict__ segs,
                                                              const int32_t *__restrict__ accflat,
                                                              FwSegOut *__restrict__ out, int max_k, double alpha,
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void mi_subsets_seg_kernel(MiDev P, const FwSe
     // no grid-stride loop here: with the body inside a loop the compiler hoists its invariants and needs 254 VGPRs
     // (occupancy 1 instead of 3); the device-driven grid covers the whole segment list and surplus workgroups leave
     if (ns_dev && blockIdx.x >= *ns_dev) return;
-    mi_seg_body<L, NXY, PRE>(P, segs, accflat, out, max_k, alpha, max_tests, blockIdx.x, need_p);
+    mi_seg_body<L, NXY, PRE, WIDE>(P, segs, accflat, out, max_k, alpha, max_tests, blockIdx.x, need_p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -617,7 +617,6 @@ int fwi_mi_upload(fw_ctx *ctx, const int64_t *colptr, const int32_t *rowval, con
 {
     const int n = ctx->P.n, p = ctx->P.p;
     if (ctx->P.max_k > MI_MAX_K) return fw_fail(ctx, FW_ERR_LIMIT, "discrete tests support max_k <= %d (got %d)", MI_MAX_K, ctx->P.max_k);
-    if (n > 65535) return fw_fail(ctx, FW_ERR_LIMIT, "discrete tests support at most 65535 samples (16-bit cell counts; got %d)", n);
     const int W = (n + 63) / 64;
     std::vector<uint64_t> nzb((size_t)p * W, 0), hib((size_t)p * W, 0);
     std::vector<int32_t> cnt_nz(p, 0), cnt_hi(p, 0);
@@ -865,16 +864,17 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
 int fwi_mi_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, const unsigned *d_ns,
                         hipStream_t stream)
 {
-#define MI_SEG_LAUNCH(LL, NN, PP)                                                                                                  \
-    hipLaunchKernelGGL((mi_subsets_seg_kernel<LL, NN, PP>), dim3(grid), dim3(256), 0, stream, mi_dev_subsets(ctx), d_segs, d_acc, d_out, \
+#define MI_SEG_LAUNCH(LL, NN, PP, WW)                                                                                                  \
+    hipLaunchKernelGGL((mi_subsets_seg_kernel<LL, NN, PP, WW>), dim3(grid), dim3(256), 0, stream, mi_dev_subsets(ctx), d_segs, d_acc, d_out, \
                        ctx->P.max_k, ctx->P.alpha, (long long)ctx->P.max_tests, d_ns, 0 /* HITON-PC never reads a rejected test's p */)
     const bool pre = ctx->P.n <= MI_PRE_N && ctx->P.max_k <= MI_PRE_K;
+    const bool wide = ctx->P.n > 65535;  // 32-bit cell counts and tables (fw_mi_core.h)
     if (ctx->L == 2) {
-        if (pre) MI_SEG_LAUNCH(2, 2, true); else MI_SEG_LAUNCH(2, 2, false);
+        if (wide) MI_SEG_LAUNCH(2, 2, false, true); else if (pre) MI_SEG_LAUNCH(2, 2, true, false); else MI_SEG_LAUNCH(2, 2, false, false);
     } else if (ctx->mi_nxy == 2) {
-        if (pre) MI_SEG_LAUNCH(3, 2, true); else MI_SEG_LAUNCH(3, 2, false);
+        if (wide) MI_SEG_LAUNCH(3, 2, false, true); else if (pre) MI_SEG_LAUNCH(3, 2, true, false); else MI_SEG_LAUNCH(3, 2, false, false);
     } else {
-        if (pre) MI_SEG_LAUNCH(3, 3, true); else MI_SEG_LAUNCH(3, 3, false);
+        if (wide) MI_SEG_LAUNCH(3, 3, false, true); else if (pre) MI_SEG_LAUNCH(3, 3, true, false); else MI_SEG_LAUNCH(3, 3, false, false);
     }
 #undef MI_SEG_LAUNCH
     FW_HIP(ctx, hipGetLastError());
@@ -909,16 +909,17 @@ int fwi_mi_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y
         FW_HIP(ctx, hipMemsetAsync(ctx->d_tmp0.ptr, 0, (size_t)m * 8 * sizeof(unsigned long long), ctx->stream));
         Pd.prof = (unsigned long long *)ctx->d_tmp0.ptr;
     }
-#define MI_TB_LAUNCH(LL, NN, PP)                                                                                                         \
-    hipLaunchKernelGGL((mi_test_batch_kernel<LL, NN, PP>), dim3((unsigned)((m + 3) / 4)), dim3(256), 0, ctx->stream, Pd, \
+#define MI_TB_LAUNCH(LL, NN, PP, WW)                                                                                                         \
+    hipLaunchKernelGGL((mi_test_batch_kernel<LL, NN, PP, WW>), dim3((unsigned)((m + 3) / 4)), dim3(256), 0, ctx->stream, Pd, \
                        (long long)m, dX, dY, dz, (const int32_t *)ctx->d_acc.ptr, (fw_test_result *)ctx->d_out.ptr)
     const bool pre = ctx->P.n <= MI_PRE_N && kmax <= MI_PRE_K;  // the batch's own largest conditioning set decides here
+    const bool wide = ctx->P.n > 65535;
     if (ctx->L == 2) {
-        if (pre) MI_TB_LAUNCH(2, 2, true); else MI_TB_LAUNCH(2, 2, false);
+        if (wide) MI_TB_LAUNCH(2, 2, false, true); else if (pre) MI_TB_LAUNCH(2, 2, true, false); else MI_TB_LAUNCH(2, 2, false, false);
     } else if (ctx->mi_nxy == 2) {
-        if (pre) MI_TB_LAUNCH(3, 2, true); else MI_TB_LAUNCH(3, 2, false);
+        if (wide) MI_TB_LAUNCH(3, 2, false, true); else if (pre) MI_TB_LAUNCH(3, 2, true, false); else MI_TB_LAUNCH(3, 2, false, false);
     } else {
-        if (pre) MI_TB_LAUNCH(3, 3, true); else MI_TB_LAUNCH(3, 3, false);
+        if (wide) MI_TB_LAUNCH(3, 3, false, true); else if (pre) MI_TB_LAUNCH(3, 3, true, false); else MI_TB_LAUNCH(3, 3, false, false);
     }
 #undef MI_TB_LAUNCH
     FW_HIP(ctx, hipGetLastError());
@@ -942,16 +943,17 @@ int fwi_mi_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_
 {
     if (nseg == 0) return FW_OK;
     FW_HIP(ctx, hipEventRecord(pb.ev0, pb.launch_stream));
-#define MI_SEG_LAUNCH(LL, NN, PP)                                                                                                       \
-    hipLaunchKernelGGL((mi_subsets_seg_kernel<LL, NN, PP>), dim3((unsigned)nseg), dim3(256), 0, pb.launch_stream, mi_dev_subsets(ctx), d_segs, \
+#define MI_SEG_LAUNCH(LL, NN, PP, WW)                                                                                                       \
+    hipLaunchKernelGGL((mi_subsets_seg_kernel<LL, NN, PP, WW>), dim3((unsigned)nseg), dim3(256), 0, pb.launch_stream, mi_dev_subsets(ctx), d_segs, \
                        d_acc, d_out, ctx->P.max_k, ctx->P.alpha, (long long)ctx->P.max_tests, (const unsigned *)nullptr, 1)
     const bool pre = ctx->P.n <= MI_PRE_N && ctx->P.max_k <= MI_PRE_K;
+    const bool wide = ctx->P.n > 65535;  // 32-bit cell counts and tables (fw_mi_core.h)
     if (ctx->L == 2) {
-        if (pre) MI_SEG_LAUNCH(2, 2, true); else MI_SEG_LAUNCH(2, 2, false);
+        if (wide) MI_SEG_LAUNCH(2, 2, false, true); else if (pre) MI_SEG_LAUNCH(2, 2, true, false); else MI_SEG_LAUNCH(2, 2, false, false);
     } else if (ctx->mi_nxy == 2) {
-        if (pre) MI_SEG_LAUNCH(3, 2, true); else MI_SEG_LAUNCH(3, 2, false);
+        if (wide) MI_SEG_LAUNCH(3, 2, false, true); else if (pre) MI_SEG_LAUNCH(3, 2, true, false); else MI_SEG_LAUNCH(3, 2, false, false);
     } else {
-        if (pre) MI_SEG_LAUNCH(3, 3, true); else MI_SEG_LAUNCH(3, 3, false);
+        if (wide) MI_SEG_LAUNCH(3, 3, false, true); else if (pre) MI_SEG_LAUNCH(3, 3, true, false); else MI_SEG_LAUNCH(3, 3, false, false);
     }
 #undef MI_SEG_LAUNCH
     FW_HIP(ctx, hipGetLastError());

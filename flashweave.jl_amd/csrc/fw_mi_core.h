@@ -266,10 +266,22 @@ static __device__ __forceinline__ void mi_count_words(const MiWords<KM> &w, unsi
 // absence, or the two non-zero bins of an nz-adjusted variable) -> 4 cells per stratum; NXY = 3: 9 cells (mi on 3-valued data).
 // tab: this wave's LDS table (MI_TAB16 u16).  Every lane returns the same result.
 // ------------------------------------------------------------------------------------------------
-template <int L, int NXY, bool PRE>
+// WIDE (n > 65 535; never with PRE): the cell counts no longer fit 16 bits -- one count per register through the reduction and a
+// 32-bit table (the caller's table slot is twice as large); everything else is the same code.
+template <bool WIDE>
+struct MiTabT {
+    typedef unsigned short type;
+};
+template <>
+struct MiTabT<true> {
+    typedef unsigned type;
+};
+template <int L, int NXY, bool PRE, bool WIDE = false>
 static __device__ __forceinline__ MiRes mi_test_core(const MiDev &P, const int X_in, const int Y_in, const MiZs &zs_in, const int k_in,
-                                                     unsigned short *tab)
+                                                     unsigned short *tab_raw)
 {
+    typedef typename MiTabT<WIDE>::type TabT;
+    TabT *tab = (TabT *)tab_raw;
     // the test is the same in every lane: say so (scalar registers, scalar branches -- the compiler cannot prove that values
     // loaded through a wave-indexed pointer are uniform, and predicated every stratum of the unrolled loops instead)
     const int X = __builtin_amdgcn_readfirstlane(X_in), Y = __builtin_amdgcn_readfirstlane(Y_in);
@@ -320,7 +332,7 @@ static __device__ __forceinline__ MiRes mi_test_core(const MiDev &P, const int X
     const unsigned *xn = pn + (size_t)X * W2, *yn = pn + (size_t)Y * W2;
     const unsigned *xh = ph ? ph + (size_t)X * W2 : nullptr, *yh = ph ? ph + (size_t)Y * W2 : nullptr;
     const int nd = (P.n + 31) >> 5;
-    unsigned *tab32 = (unsigned *)tab;
+    unsigned *tab32 = (unsigned *)tab_raw;  // (!WIDE: two 16-bit counts per word)
     const unsigned long long pt0 = P.prof ? __builtin_readcyclecounter() : 0ull;
     // ---- counting ----
     // PRE (n <= 6144: at most three 32-row words per lane and plane): every word of the k + 2 columns is loaded once, up
@@ -351,30 +363,41 @@ static __device__ __forceinline__ MiRes mi_test_core(const MiDev &P, const int X
         }
         // two 16-bit counts per register (a count never exceeds n <= 65535), six DPP adds each (independent chains: the
         // compiler interleaves them and the DPP wait states disappear), then lane 63 files the totals in one go
-        unsigned red[SBMAX][NCT16 / 2];
-#pragma unroll
-        for (int s = 0; s < SBMAX; ++s)
-#pragma unroll
-            for (int q = 0; q < NCT16 / 2; ++q) {
-                const unsigned lo = acc[s][2 * q], hi = (2 * q + 1 < NCT) ? acc[s][2 * q + 1] : 0u;
-                // unconditional for the cell pairs (strata beyond SB hold zeros): straight-line code, chains interleave
-                red[s][q] = (2 * q < NC) ? mi_dpp_sum63(lo | (hi << 16)) : 0u;
-            }
-        if (tot_sep) {
+        if constexpr (WIDE) {
 #pragma unroll
             for (int s = 0; s < SBMAX; ++s)
 #pragma unroll
-                for (int q = 0; q < NCT16 / 2; ++q)
-                    if (2 * q >= NC) red[s][q] = mi_dpp_sum63(acc[s][2 * q] | ((2 * q + 1 < NCT ? acc[s][2 * q + 1] : 0u) << 16));
-        }
-        if (lane == 63) {
-#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+                    if (c < NC || tot_sep) {
+                        const unsigned r = mi_dpp_sum63(acc[s][c]);
+                        if (lane == 63 && s < SB) tab[(b * SB + s) * NCT16 + c] = r;
+                    }
+        } else {
+            unsigned red[SBMAX][NCT16 / 2];
+    #pragma unroll
             for (int s = 0; s < SBMAX; ++s)
-                if (s < SB) {
-#pragma unroll
-                    for (int q = 0; q < NCT16 / 2; ++q)
-                        if (2 * q < NC || tot_sep) tab32[((b * SB + s) * NCT16) / 2 + q] = red[s][q];
+    #pragma unroll
+                for (int q = 0; q < NCT16 / 2; ++q) {
+                    const unsigned lo = acc[s][2 * q], hi = (2 * q + 1 < NCT) ? acc[s][2 * q + 1] : 0u;
+                    // unconditional for the cell pairs (strata beyond SB hold zeros): straight-line code, chains interleave
+                    red[s][q] = (2 * q < NC) ? mi_dpp_sum63(lo | (hi << 16)) : 0u;
                 }
+            if (tot_sep) {
+    #pragma unroll
+                for (int s = 0; s < SBMAX; ++s)
+    #pragma unroll
+                    for (int q = 0; q < NCT16 / 2; ++q)
+                        if (2 * q >= NC) red[s][q] = mi_dpp_sum63(acc[s][2 * q] | ((2 * q + 1 < NCT ? acc[s][2 * q + 1] : 0u) << 16));
+            }
+            if (lane == 63) {
+    #pragma unroll
+                for (int s = 0; s < SBMAX; ++s)
+                    if (s < SB) {
+    #pragma unroll
+                        for (int q = 0; q < NCT16 / 2; ++q)
+                            if (2 * q < NC || tot_sep) tab32[((b * SB + s) * NCT16) / 2 + q] = red[s][q];
+                    }
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -386,7 +409,7 @@ static __device__ __forceinline__ MiRes mi_test_core(const MiDev &P, const int X
     for (int base = 0; base < S; base += 64) {
         const int key = base + lane;
         if (key < S) {
-            const unsigned short *t = tab + key * NCT16;
+            const TabT *t = tab + key * NCT16;
             int sub = 0;
 #pragma unroll
             for (int c = 0; c < NC; ++c) sub += (int)t[c];
@@ -440,7 +463,7 @@ static __device__ __forceinline__ MiRes mi_test_core(const MiDev &P, const int X
         if (q < npairs) {
             const int key = q / NC, c = q - key * NC;
             const int i = c % NXY, j = c / NXY;
-            const unsigned short *t = tab + key * NCT16;
+            const TabT *t = tab + key * NCT16;
             long long mi_[NXY], mj_[NXY], mk = 0;
 #pragma unroll
             for (int u = 0; u < NXY; ++u) mi_[u] = mj_[u] = 0;

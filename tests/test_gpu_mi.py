@@ -422,3 +422,55 @@ def test_row_views_flag_for_test_subsets():
             ndiff += (r0["suff_power"], r0["df"]) != (r1["suff_power"], r1["df"])
     assert ndiff > 0  # rows where T / the candidate are zero really left the tables
     eng.close()
+
+
+def _big_n_data(kind, n, p, seed):
+    """Discretised data with more rows than a 16-bit count holds: 'mi' through the usual front-end; 'mi_nz' built directly
+    (0 = absent, 1 / 2 = the two bins of the non-zeros: the front-end drops too many rows of the synthetic habitats)."""
+    if kind == "mi":
+        return np.ascontiguousarray(_synth(kind, 24, n, seed)[:, :p])
+    rng = np.random.default_rng(seed)
+    base = rng.standard_normal((n, 3))
+    x = base @ rng.standard_normal((3, p)) + 1.5 * rng.standard_normal((n, p))
+    habitat = rng.random((n, 1)) < 0.5
+    present = rng.random((n, p)) < np.where(habitat, 0.8, 0.45)
+    return np.ascontiguousarray(np.where(present, 1 + (x > 0), 0).astype(np.int64))
+
+
+@pytest.mark.parametrize("kind,rows", [("mi", 70_000), ("mi_nz", 70_000)])
+def test_more_than_65535_samples(kind, rows):
+    # cell counts beyond 16 bits: the segment / batch kernels switch to 32-bit counts and tables (fw_mi_core.h, WIDE), level 0 counts in
+    # 32 bits anyway; the HITON-PC runs through the level-synchronous rounds.  Single tests of every size and a max_k = 2 network of ten
+    # variables against the oracle (with this many samples every pair is associated, and the oracle pays every row of every test).
+    data = _big_n_data(kind, rows, 10, 41)
+    n, p = data.shape
+    assert n > 65_535
+    eng = fw.Engine(kind, n, p, max_k=3)
+    eng.set_data(data)
+    orc = O.Oracle(kind, data, sparse=True, max_k=3)
+    rng = np.random.default_rng(9)
+    X, Y, Zs = [], [], []
+    for _ in range(300):
+        k = int(rng.integers(0, 4))
+        v = rng.choice(p, size=k + 2, replace=False)
+        X.append(int(v[0])); Y.append(int(v[1])); Zs.append(tuple(int(t) for t in v[2:]))
+    got = eng.test_batch(X, Y, Zs)
+    nom = eng.n_obs_min
+    big = 0
+    for x, y, z, g in zip(X, Y, Zs, got):
+        s, pv, df, pw = orc.test(x, y, z, hps=5, n_obs_min=nom)
+        assert (g.df, g.suff_power) == (df, pw), (x, y, z, g, (s, pv, df, pw))
+        assert _close(g.stat, s, STOL) and _close(g.pval, pv, PTOL), (x, y, z, g, (s, pv, df, pw))
+        big += pw
+    assert big > 50
+    eng.close()
+    eng = fw.Engine(kind, n, p, max_k=2)
+    eng.set_data(data)
+    orc = O.Oracle(kind, data, sparse=True, max_k=2)
+    net = eng.lgl(feed_forward=False)
+    exp = orc.learn(max_k=2, feed_forward=False)
+    assert set(net["edges"]) == set(exp["edges"]) and len(exp["edges"]) > 5
+    for e_, w in exp["edges"].items():
+        assert _close(net["edges"][e_], w, STOL)
+    assert eng.counters()["cond_tests_ref"] == exp["n_cond_tests"]
+    eng.close()
