@@ -432,6 +432,22 @@ __device__ __forceinline__ unsigned long long mi_ld_u64(const unsigned long long
 __device__ __forceinline__ void mi_st_u64(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void mi_st_u32(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void mi_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#ifndef MI_NAP_WAIT
+#define MI_NAP_WAIT 2  // x 128 cycles between two looks at a board the wavefront waits for
+#endif
+#ifndef MI_NAP_TAIL
+#define MI_NAP_TAIL 32  // (1 / 1: cfg4 159.8 ms, 2 / 32: 156.2 -- and the idle wavefronts stop inflating the instruction counters) x 512 cycles between two looks at the boards once the wavefront has run out of targets
+#endif
+__device__ __forceinline__ void mi_nap_wait()
+{
+#pragma unroll
+    for (int i = 0; i < MI_NAP_WAIT; ++i) __builtin_amdgcn_s_sleep(2);
+}
+__device__ __forceinline__ void mi_nap_tail()
+{
+#pragma unroll
+    for (int i = 0; i < MI_NAP_TAIL; ++i) __builtin_amdgcn_s_sleep(8);
+}
 // lane 0 performs the atomic, every lane gets the value
 __device__ __forceinline__ unsigned int mi_wave_add(unsigned int *p, unsigned int v, int lane)
 {
@@ -1213,7 +1229,7 @@ __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, 
                 if (wave == 0) {
                     unsigned int spins = 0u;
                     while (mi_ld_u32(&b->done) < nch) {  // records claimed by other wavefronts: they are running
-                        __builtin_amdgcn_s_sleep(2);
+                        mi_nap_wait();
                         if (++spins > (1u << 27)) {
                             if (lane == 0) atomicExch(&Q->pad[0], 3u);
                             break;
@@ -1452,7 +1468,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
                     unsigned int spins = 0u;
                     while (mi_ld_u32(&b->done) < nch) {  // records claimed by other wavefronts: they are running
                         if (heavy || !mi_help<L, NXY, PRE, R4>(Q, boards, res, bacc, M, P, lane)) {
-                            __builtin_amdgcn_s_sleep(2);
+                            mi_nap_wait();
                             if (++spins > (1u << 27)) {  // ~30 s: a logic error, not a workload -- report instead of hanging the GPU
                                 if (lane == 0) atomicExch(&Q->pad[0], 1u);
                                 break;
@@ -1508,7 +1524,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
     unsigned int spins = 0u;
     while (mi_ld_u32(&Q->targets_done) < (unsigned int)ntg && mi_ld_u32(&Q->pad[0]) == 0u) {
         if (!mi_help<L, NXY, PRE, R4>(Q, boards, res, bacc, M, P, lane)) {
-            __builtin_amdgcn_s_sleep(8);
+            mi_nap_tail();
             if (++spins > (1u << 27)) {
                 if (lane == 0) atomicExch(&Q->pad[0], 2u);
                 break;
