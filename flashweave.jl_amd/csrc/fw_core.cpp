@@ -847,6 +847,12 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
         pool.inflight = true;
         return FW_OK;
     }
+    if (stream) {  // job matrices kept across the rounds of this pool (ctx->d_arena): a new pool, or an arena another pool used, starts empty
+        if (pool.gram_epoch == 0 || pool.gram_epoch != c->gram_epoch || pool.gram_top * sizeof(double) > ((size_t)4 << 30)) {
+            pool.gram_epoch = ++c->gram_epoch;
+            pool.gram_top = 0;
+        }
+    }
     const double tb0 = now_s();
     FwPoolBuf &pb = c->pb[pool.buf];
     // window of every live job, then a segment length that yields a few thousand workgroups
@@ -944,12 +950,42 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
                 r.acc_off = aoff;
                 r.acc_len = (int32_t)j.acc.size();
                 r.m = r.acc_len + 2;
-                r.cor_off = (long long)arena_floats;
-                arena_floats += (size_t)r.m * r.m;
+                if (stream) {
+                    // the matrix of a job stays in the arena while the job lives: a job that takes several windows (pool rounds) has it
+                    // computed once (whole cfg3: fzs_gram_kernel was 30 % of the kernel time with one computation per round)
+                    if (j.gram_off < 0 || j.gram_epoch != pool.gram_epoch) {
+                        j.gram_off = (int64_t)pool.gram_top;
+                        j.gram_epoch = pool.gram_epoch;
+                        pool.gram_top += (size_t)r.m * r.m;
+                        r.nR = 1;  // to be computed in this launch
+                    }
+                    r.cor_off = (long long)j.gram_off;
+                    arena_floats = pool.gram_top;
+                } else {
+                    r.cor_off = (long long)arena_floats;
+                    arena_floats += (size_t)r.m * r.m;
+                }
                 pool.nzrecs.push_back(r);
             }
         }
         if (split && pass == 0) ns_tab = si;
+    }
+    if (stream && pool.gram_top * sizeof(double) > c->d_arena.cap) {
+        // the arena has to grow and loses its contents: every matrix of this launch is computed again at fresh offsets (the jobs
+        // that sit this round out are caught by the epoch)
+        pool.gram_epoch = ++c->gram_epoch;
+        pool.gram_top = 0;
+        size_t ri = 0;
+        for (FwPoolJob &j : pool.live) {
+            if (!j.launched) continue;
+            FwNzJob &r = pool.nzrecs[ri++];
+            j.gram_off = (int64_t)pool.gram_top;
+            j.gram_epoch = pool.gram_epoch;
+            r.cor_off = (long long)j.gram_off;
+            r.nR = 1;
+            pool.gram_top += (size_t)r.m * r.m;
+        }
+        arena_floats = pool.gram_top;
     }
     const double tb1 = now_s();
     c->cnt.t_host_build_s += tb1 - tb0;

@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256, FZS_SEG_OCC) void fzs_subsets_seg_kernel(FzsDe
 // ---- job-local correlation matrices ---------------------------------------------------------------------------------------------
 // Every test of a (X, Y | subsets of the accepted list) job conditions a sub-matrix of ONE matrix: the Float64 correlations of
 // {X, Y} u accepted.  Streaming the columns per test (above) computes each of them C(a, k - 1) times over; this kernel computes
-// them once per job and pool round -- one workgroup per job, one wavefront per 4 x 4 tile of pairs (8 columns in 16-byte loads feed
+// them once per job (the matrix stays in the launch arena while the job's pool lives) -- one workgroup per job, one wavefront per 4 x 4 tile of pairs (8 columns in 16-byte loads feed
 // 16 sums x 4 samples), the same sum  x_i (x_j - mu_j), i < j in job order (X, Y, accepted positions), as the streamed form, the
 // same DPP wave sums -- and the segment kernel (GRAM) then only gathers and conditions: tests/s go from 3.7e8 (streamed, itself
 // 1.8 x the nominal HBM rate) to the rate of the conditioning arithmetic.  Row-major m x m doubles per job in the launch's arena.
@@ -585,6 +585,7 @@ __global__ __launch_bounds__(256) void fzs_gram_kernel(FzsDev P, const FwNzJob *
                                                        double *__restrict__ arena)
 {
     const FwNzJob J = recs[blockIdx.x];
+    if (J.nR == 0) return;  // the job's matrix is still in the arena from an earlier round of its pool (fwi_pool_launch)
     const int m = J.m;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int32_t *acc = accflat + J.acc_off;

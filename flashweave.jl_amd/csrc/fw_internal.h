@@ -129,6 +129,7 @@ struct fw_ctx {
     int64_t cor_capacity = 0;   // ... and holds this many floats
     double *d_thr = nullptr;  // |r| significance thresholds of the segment kernel (fz_thresholds_kernel)
     double *d_fzs_stat = nullptr;  // recursive_pcor = 0: per column {mean, sum of squared deviations} in Float64 (fw_fzs.hip)
+    uint64_t gram_epoch = 0;       // recursive_pcor = 0: bumped whenever the job-matrix arena loses its contents (new pool, reallocation, reset)
     bool have_fzs_stat = false;
     int n_pad = 0, p_pad = 0;
     bool have_data = false, have_cor = false;
@@ -217,7 +218,7 @@ int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *d_
 int fwi_fzs_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff, const int32_t *zflat,
                        fw_test_result *out);
 int fwi_fzs_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb,
-                     const FwNzJob *recs_host, int64_t njobs, size_t arena_doubles);  // recs: one per launched job (FwSeg::pad indexes them)
+                     const FwNzJob *recs_host, int64_t njobs, size_t arena_doubles);  // recs: one per launched job (FwSeg::pad indexes them); rec.nR != 0: matrix to be computed
 
 // ---- HE-S / fz_nz (fw_fz.hip) ----
 int fwi_fznz_upload(fw_ctx *ctx, const float *data);
@@ -251,6 +252,8 @@ struct FwPoolJob {
     bool no_zs = false;    // the returned result has no conditioning set (fz_nz job without a test)
     std::vector<int32_t> acc;
     int64_t acc_dev_off = -1;  // offset (ints) of this job's accepted list in the pool buffer's device arena, -1 = not uploaded
+    int64_t gram_off = -1;     // recursive_pcor = 0: offset (doubles) of the job's correlation matrix in ctx->d_arena, valid while
+    uint64_t gram_epoch = 0;   // ... gram_epoch == ctx->gram_epoch (the arena was neither reallocated nor reset since)
     uint64_t N = 0, next = 0, width = 0;
     double best_p = -1.0, best_stat = 0.0;
     uint64_t best_rank = 0;
@@ -271,6 +274,8 @@ struct FwPool {
     size_t ns = 0;
     uint64_t launched_ranks = 0;  // ranks of the pending / last launch (window-growth policy)
     size_t arena_top = 0;         // ints used in pb.d_acc (accepted lists stay resident while their job lives)
+    size_t gram_top = 0;          // recursive_pcor = 0: doubles used in ctx->d_arena by this pool's job matrices (kept across rounds)
+    uint64_t gram_epoch = 0;      // epoch of ctx->d_arena this pool's offsets belong to (0: none yet)
     double t_launch = 0.0;
 };
 int fwi_pool_launch(fw_ctx *ctx, FwPool &pool);                                    // asynchronous
