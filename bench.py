@@ -46,6 +46,16 @@ def make_input(cfg, args):
     import flashweave_jl_amd as fw
     from flashweave_jl_amd import preprocess as pre
     from flashweave_jl_amd import synth
+    if cfg == "cfg1":
+        # BASELINE.json configs[0]: the reference's bundled OTU table (tests/golden/HMP_SRA_gut_small.tsv = test/data of the reference),
+        # FlashWeave-S, max_k 3 -- a parity case (tests/test_gpu_fz.py reproduces its golden networks), runnable here for completeness
+        path = os.path.join(ROOT, "tests", "golden", "HMP_SRA_gut_small.tsv")
+        counts = np.loadtxt(path, delimiter="\t", skiprows=1, usecols=range(1, 51)).astype(np.int64)
+        c = {"p": counts.shape[1], "n": counts.shape[0], "seed": 0, "mode": "bundled", "test_name": "fz", "max_k": 3,
+             "label": "cfg1: bundled HMP_SRA_gut_small table (%d samples x %d OTUs), fz, max_k=3, alpha=0.01" % counts.shape}
+        t1 = time.perf_counter()
+        data, _, _ = pre.normalize(counts, "fz", prec=32)
+        return c, synth.checksum(counts.astype(np.int32)), data, {"seconds": time.perf_counter() - t1, "where": "host (preprocess.py)", "generate_counts_seconds": 0.0}
     c = dict(synth.CONFIGS[cfg])
     if args.p:
         c["p"] = args.p
@@ -579,8 +589,9 @@ def main():
 
         out = {"metric": "ci_tests_per_sec", "value": main_m["value"], "unit": "tests/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": main_m["ms_per_step"], "higher_is_better": True, "scaling": "strong",
-               "vs_baseline": None, "dtype": "f64" if cfg["test_name"] in ("fz", "fz_nz") else "i32", "data": "synthetic",
-               "config": {"workload": "%s: fwsynth-v1 %d OTUs x %d samples, %s, max_k=%d, alpha=0.01" %
+               "vs_baseline": None, "dtype": "f64" if cfg["test_name"] in ("fz", "fz_nz") else "i32",
+               "data": "bundled table of the reference's tests" if cfg.get("label") else "synthetic",
+               "config": {"workload": cfg.get("label") or "%s: fwsynth-v1 %d OTUs x %d samples, %s, max_k=%d, alpha=0.01" %
                                       (args.config, p, n, cfg["test_name"], cfg["max_k"]),
                           "counts_sha256": csum, "recursive_pcor": 0 if args.stream_columns else 1, "dense_cor": 0 if args.no_cor_matrix else 1, "feed_forward": ff, "round_size": R if ff else 0,
                           "sampled_targets": args.max_targets or None,
