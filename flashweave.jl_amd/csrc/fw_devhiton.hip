@@ -2189,7 +2189,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         P.growth_busy = envu("FW_DH_GROWTH_BUSY", 4ull);
         P.busy_jobs = (unsigned int)envu("FW_DH_BUSY_JOBS", 2048ull);
         P.spec_depth = spec_depth;
-        P.spec_below = envu("FW_DH_SPEC_BELOW", c->P.max_k <= 3 ? 30000000ull : 12000000ull);  // max_k 4-5: whole enumerations of the look-ahead pools are too dear in big launches (cfg5, first 40 000 targets: 0.97 -> 1.95 s with 30 M)  // (r03, after the job-count gate of the interleaving look-ahead moved: 12 M -> 199.8 ms, 20 M 193.6, 30 M 193.4, 50 M 194.7, none 193.6; cfg3 without feed-forward 172.1 -> 168.4)
+        P.spec_below = envu("FW_DH_SPEC_BELOW", (c->P.max_k <= 3 && ntg >= 256) ? 30000000ull : 12000000ull);  // chains of few targets (a rank of 4 / 8: 98 / 49 per chain) are latency-bound and pay for it: slowest of 8 ranks 83.9 -> 91.0 ms with 30 M;  // max_k 4-5: whole enumerations of the look-ahead pools are too dear in big launches (cfg5, first 40 000 targets: 0.97 -> 1.95 s with 30 M)  // (r03, after the job-count gate of the interleaving look-ahead moved: 12 M -> 199.8 ms, 20 M 193.6, 30 M 193.4, 50 M 194.7, none 193.6; cfg3 without feed-forward 172.1 -> 168.4)
         P.spec0_depth = spec0_depth;
         P.spec0_below = envu("FW_DH_SPEC0_BELOW", 12000000ull);
         { const char *e = fw_knob("FW_DH_SPEC0_LIGHT"); P.spec0_depth_light = spec0_depth > 0 ? std::min(std::max(e ? atoi(e) : spec0_depth, spec0_depth), DH_MAX_SPEC) : 0; }
