@@ -566,7 +566,7 @@ def main():
                     "evaluated_tests_per_s_in_kernel": rcn["cond_tests_evaluated"] / max(sub_launch_s, 1e-12)}
         if args.stream_columns:
             # variant S (recursive_pcor = 0).  B_fzS = what a test that shares nothing streams.  The kernels share: the correlations of a
-            # job are computed once per job and pool round from its columns (fzs_gram_kernel) and the tests condition sub-matrices of
+            # job are computed once per job from its columns (fzs_gram_kernel) and the tests condition sub-matrices of
             # that matrix out of LDS, so `achieved` is a multiple of the HBM rate and the bound is the conditioning arithmetic
             # (FW_FZS_GRAM=0: the per-test streaming form, 1.8 x the nominal rate with X / Y in LDS and the accepted columns in L2)
             roofline["bound"] = "valu" if roofline["frac"] > 1.0 else "hbm"
