@@ -301,3 +301,27 @@ def test_closed_form_fz_thresholds_sit_inside_the_guard_band():
                 if abs(hi) < 1.0:
                     assert O.fz_pval(hi, n_r, 0) < alpha, (alpha, n_r, sgn)
                 assert not (O.fz_pval(lo, n_r, 0) < alpha), (alpha, n_r, sgn)
+
+
+def test_pcor_with_a_repeated_conditioning_variable():
+    """Feed-forward whitelists can put a variable twice into the pool of an elimination job (hiton.jl:24-26 pushes a whitelisted
+    member again).  StatsBase.partialcor then meets r(z, z) = S / sqrt(S S) = 1 exactly and divides 0 by 0: NaN, i.e. "not
+    significant" (tests.jl:1-3) -- while pcor_rec on the matrix returns a finite value for the same call (its own guards).  The two
+    variants of the reference therefore learn different feed-forward networks; the GPU paths follow each of them
+    (tests/test_gpu_fzs.py::test_feed_forward_network_without_a_correlation_matrix, tests/test_gpu_fz.py)."""
+    rng = np.random.default_rng(0)
+    d = rng.standard_normal((200, 6))
+    d[:, 2] += d[:, 0]
+    d[:, 3] += d[:, 1] + d[:, 0]
+    cm = O.cor(d, "f32")
+    data_variant = O.Oracle("fz", cor_mat=cm, n_obs=200)
+    data_variant.set_fz_data(d)
+    matrix_variant = O.Oracle("fz", cor_mat=cm, n_obs=200)
+    s1, p1, _, _ = data_variant.test(0, 1, (2,))
+    s2, p2, _, _ = matrix_variant.test(0, 1, (2,))
+    assert abs(s1 - s2) < 1e-5 and np.isfinite(p1)
+    for zs in ((2, 2), (2, 3, 2), (3, 2, 2)):
+        s, p, _, _ = data_variant.test(0, 1, zs)
+        assert np.isnan(s) and np.isnan(p), (zs, s, p)
+        s, p, _, _ = matrix_variant.test(0, 1, zs)
+        assert np.isfinite(s) and np.isfinite(p), (zs, s, p)
