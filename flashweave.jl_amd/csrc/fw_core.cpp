@@ -1006,6 +1006,8 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
                 : fwi_mi_segments(c, (int64_t)ns, dsegs, dacc, dout, pb);
     }
     if (rc) return rc;
+    if (stream && arena_floats * sizeof(double) > ((size_t)8 << 30))
+        pool.gram_epoch = 0;  // fwi_fzs_segments streamed this launch instead (matrices beyond its arena limit): nothing was cached
     if (!zc_out)
         FW_HIP(c, hipMemcpyAsync(pb.h_out.ptr, pb.d_out.ptr, ns * sizeof(FwSegOut), hipMemcpyDeviceToHost, pb.launch_stream));
     FW_HIP(c, hipEventRecord(pb.evd, pb.launch_stream));
