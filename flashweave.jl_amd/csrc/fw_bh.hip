@@ -6,7 +6,13 @@
 //   3. inclusive min-scan over the descending order = the reference's backward cumulative minimum
 //   4. scatter back, keep adj < alpha, emit both directions keyed (src << 32 | dst), sort, cut rows by binary search
 // Floating-point expressions are the host restatement's (p * m / rank, one multiplication then one division).
-#include <hipcub/hipcub.hpp>
+// The sorts and the scan are rocPRIM's device primitives called directly (ROCm's native library; r01-r03 went through the
+// hipCUB compatibility layer): LSD radix sorts are stable, which step 4 and the candidate order rely on.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 
 #include "fw_internal.h"
 
@@ -115,15 +121,14 @@ int fwi_bh_csr_device(fw_ctx *ctx, const FwL0Dev &in, int64_t m)
     hipStream_t st = ctx->stream;
     // temp storage sizes of the three library calls
     size_t tb_sort1 = 0, tb_scan = 0, tb_sort2 = 0, tb_seg = 0;
-    FW_HIP(ctx, (hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb_sort1, (const double *)nullptr, (double *)nullptr,
-                                                             (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)k, 0, 64, st)));
-    FW_HIP(ctx, (hipcub::DeviceScan::InclusiveScan(nullptr, tb_scan, (const double *)nullptr, (double *)nullptr, MinOp(), (int)k, st)));
-    FW_HIP(ctx, (hipcub::DeviceRadixSort::SortPairs(nullptr, tb_sort2, (const unsigned long long *)nullptr,
-                                                   (unsigned long long *)nullptr, (const uint32_t *)nullptr,
-                                                   (uint32_t *)nullptr, (int)(2 * k), 0, 64, st)));
-    FW_HIP(ctx, (hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tb_seg, (const double *)nullptr, (double *)nullptr,
-                                                            (const int32_t *)nullptr, (int32_t *)nullptr, (int)(2 * k), p,
-                                                            (const int *)nullptr, (const int *)nullptr, 0, 64, st)));
+    FW_HIP(ctx, (rocprim::radix_sort_pairs_desc(nullptr, tb_sort1, (const double *)nullptr, (double *)nullptr, (const uint32_t *)nullptr,
+                                                (uint32_t *)nullptr, k, 0u, 64u, st)));
+    FW_HIP(ctx, (rocprim::inclusive_scan(nullptr, tb_scan, (const double *)nullptr, (double *)nullptr, k, MinOp(), st)));
+    FW_HIP(ctx, (rocprim::radix_sort_pairs(nullptr, tb_sort2, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                           (const uint32_t *)nullptr, (uint32_t *)nullptr, 2 * k, 0u, 64u, st)));
+    FW_HIP(ctx, (rocprim::segmented_radix_sort_pairs(nullptr, tb_seg, (const double *)nullptr, (double *)nullptr, (const int32_t *)nullptr,
+                                                     (int32_t *)nullptr, (unsigned int)(2 * k), (unsigned int)p, (const int *)nullptr,
+                                                     (const int *)nullptr, 0u, 64u, st)));
     const size_t tb = std::max(std::max(tb_sort1, tb_seg), std::max(tb_scan, tb_sort2));
     // carve one scratch buffer
     size_t off = 0;
@@ -152,11 +157,10 @@ int fwi_bh_csr_device(fw_ctx *ctx, const FwL0Dev &in, int64_t m)
     if (ctx->P.fdr) {
         hipLaunchKernelGGL(bh_iota_kernel, dim3(gk), dim3(256), 0, st, iota, k);
         size_t t1 = tb;
-        FW_HIP(ctx, (hipcub::DeviceRadixSort::SortPairsDescending(B + o_tmp, t1, in.pval, p_desc, (const uint32_t *)iota, i_desc,
-                                                                 (int)k, 0, 64, st)));
+        FW_HIP(ctx, (rocprim::radix_sort_pairs_desc(B + o_tmp, t1, in.pval, p_desc, (const uint32_t *)iota, i_desc, k, 0u, 64u, st)));
         hipLaunchKernelGGL(bh_adj_kernel, dim3(gk), dim3(256), 0, st, (const double *)p_desc, adj, k, (double)m);
         size_t t2 = tb;
-        FW_HIP(ctx, (hipcub::DeviceScan::InclusiveScan(B + o_tmp, t2, (const double *)adj, adj, MinOp(), (int)k, st)));
+        FW_HIP(ctx, (rocprim::inclusive_scan(B + o_tmp, t2, (const double *)adj, adj, k, MinOp(), st)));
         hipLaunchKernelGGL(bh_scatter_kernel, dim3(gk), dim3(256), 0, st, (const double *)adj, (const uint32_t *)i_desc, padj, k);
     } else {
         FW_HIP(ctx, hipMemcpyAsync(padj, in.pval, k * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -172,8 +176,8 @@ int fwi_bh_csr_device(fw_ctx *ctx, const FwL0Dev &in, int64_t m)
     int bits = 1;
     while ((1ll << bits) < (long long)p) ++bits;
     size_t t3 = tb;
-    FW_HIP(ctx, (hipcub::DeviceRadixSort::SortPairs(B + o_tmp, t3, (const unsigned long long *)keys, keys2, (const uint32_t *)pay,
-                                                   pay2, (int)n2, 0, 32 + bits, st)));
+    FW_HIP(ctx, (rocprim::radix_sort_pairs(B + o_tmp, t3, (const unsigned long long *)keys, keys2, (const uint32_t *)pay, pay2, (size_t)n2, 0u,
+                                           (unsigned int)(32 + bits), st)));
     hipLaunchKernelGGL(bh_rows_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, (const unsigned long long *)keys2,
                        (const uint32_t *)pay2, in.stat64, in.stat32, (const double *)padj, (size_t)n2, idx, sto, pvo);
     int *off32 = (int *)(B + o_off32);
@@ -184,8 +188,8 @@ int fwi_bh_csr_device(fw_ctx *ctx, const FwL0Dev &in, int64_t m)
     // candidate order of every variable (hiton.jl:211-217): its neighbours by ascending adjusted p, ties by ascending
     // index = a STABLE sort of each row by p (radix sort is stable; rows are already in ascending partner order)
     size_t t4 = tb;
-    FW_HIP(ctx, (hipcub::DeviceSegmentedRadixSort::SortPairs(B + o_tmp, t4, (const double *)pvo, psort, (const int32_t *)idx, cand,
-                                                            (int)n2, p, (const int *)off32, (const int *)off32 + 1, 0, 64, st)));
+    FW_HIP(ctx, (rocprim::segmented_radix_sort_pairs(B + o_tmp, t4, (const double *)pvo, psort, (const int32_t *)idx, cand, (unsigned int)n2,
+                                                     (unsigned int)p, (const int *)off32, (const int *)off32 + 1, 0u, 64u, st)));
     FW_HIP(ctx, hipGetLastError());
     // only the row offsets go to the host now; partners / statistics / p-values follow on demand (fwi_nb_host_ensure):
     // the device-resident rounds never need them there (58 MB at cfg3)

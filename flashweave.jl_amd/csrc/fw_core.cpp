@@ -918,6 +918,9 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
     const bool hk = c->P.max_k > 3;  // max_k 4-5: level-2 table kernel up to FW_HK_A accepted variables (plain fz only)
     const bool split = fz && !no_tab && (!hk || (c->P.kind == FW_FZ && !stream && !no_hk));
     const size_t tab_a = hk ? (size_t)FW_HK_A : (size_t)FW_TAB_A;
+    // record of every launched job in pool.nzrecs: with `split` the records are pushed in two passes (short lists first), i.e. NOT in
+    // pool.live order -- the re-layout below must follow this map, not a running counter
+    std::vector<size_t> job_rec(pool.live.size(), (size_t)-1);
     for (int pass = 0; pass < (split ? 2 : 1); ++pass) {
         for (size_t ji = 0; ji < pool.live.size(); ++ji) {
             FwPoolJob &j = pool.live[ji];
@@ -944,6 +947,7 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
                 ++si;
             }
             if (nzs || stream) {  // per-job record: fz_nz sub-matrix / recursive_pcor = 0 job-local correlation matrix
+                job_rec[ji] = pool.nzrecs.size();
                 FwNzJob r{};
                 r.X = j.X;
                 r.Y = j.Y;
@@ -975,10 +979,10 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
         // that sit this round out are caught by the epoch)
         pool.gram_epoch = ++c->gram_epoch;
         pool.gram_top = 0;
-        size_t ri = 0;
-        for (FwPoolJob &j : pool.live) {
+        for (size_t ji = 0; ji < pool.live.size(); ++ji) {
+            FwPoolJob &j = pool.live[ji];
             if (!j.launched) continue;
-            FwNzJob &r = pool.nzrecs[ri++];
+            FwNzJob &r = pool.nzrecs[job_rec[ji]];
             j.gram_off = (int64_t)pool.gram_top;
             j.gram_epoch = pool.gram_epoch;
             r.cor_off = (long long)j.gram_off;

@@ -1283,10 +1283,9 @@ int fwi_fznz_submatrices(fw_ctx *ctx, int64_t njobs, const FwNzJob *recs_host, s
     const size_t lds = fznz_lds_bytes(m_cap, ctx->P.n);
     if (lds > 160u * 1024u - 64u)
         return fw_fail(ctx, FW_ERR_LIMIT, "fz_nz: a job with %d variables does not fit the LDS of one workgroup", m_cap);
-    static size_t lds_attr = 0;  // raise the kernel's dynamic-LDS limit once per size class (above the 64 KB default)
-    if (lds > lds_attr) {
-        (void)hipFuncSetAttribute((const void *)fznz_submat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160u * 1024u - 64u));
-        lds_attr = 160u * 1024u;
+    if (!ctx->fznz_lds_raised) {  // raise the kernel's dynamic-LDS limit (above the 64 KB default) once per context, i.e. per device
+        FW_HIP(ctx, hipFuncSetAttribute((const void *)fznz_submat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160u * 1024u - 64u)));
+        ctx->fznz_lds_raised = true;
     }
     hipLaunchKernelGGL(fznz_submat_kernel, dim3((unsigned)njobs), dim3(FZNZ_NT), lds, stream, ctx->d_data,
                        (const unsigned long long *)ctx->d_nzbits, ctx->P.n, ctx->W, (FwNzJob *)ctx->d_nzrecs.ptr, d_acc,

@@ -85,14 +85,15 @@ __global__ __launch_bounds__(256) void norm_clr_out_kernel(const int32_t *__rest
 {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= nk) return;
-    const int q = blockIdx.y;
-    const int32_t v = x[(size_t)cols[q] * n + rows[r]];
-    double o;
-    if (mode == 0)
-        o = log((v == 0 ? pseudo[r] : (double)v) / gmean[r]);
-    else
-        o = v == 0 ? 0.0 : log((double)v / gmean[r]);
-    out[(size_t)q * nk + r] = (float)o;
+    for (int q = blockIdx.y; q < pk; q += gridDim.y) {  // (grid.y is capped at NORM_GRID_Y: tables with more kept columns loop)
+        const int32_t v = x[(size_t)cols[q] * n + rows[r]];
+        double o;
+        if (mode == 0)
+            o = log((v == 0 ? pseudo[r] : (double)v) / gmean[r]);
+        else
+            o = v == 0 ? 0.0 : log((double)v / gmean[r]);
+        out[(size_t)q * nk + r] = (float)o;
+    }
 }
 
 __global__ __launch_bounds__(256) void norm_binary_out_kernel(const int32_t *__restrict__ x, int n, const int32_t *__restrict__ rows, int nk,
@@ -100,8 +101,7 @@ __global__ __launch_bounds__(256) void norm_binary_out_kernel(const int32_t *__r
 {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= nk) return;
-    const int q = blockIdx.y;
-    out[(size_t)q * nk + r] = x[(size_t)cols[q] * n + rows[r]] != 0 ? 1 : 0;
+    for (int q = blockIdx.y; q < pk; q += gridDim.y) out[(size_t)q * nk + r] = x[(size_t)cols[q] * n + rows[r]] != 0 ? 1 : 0;
 }
 
 // per kept column over the kept rows: does it hold both a zero and a non-zero?
@@ -213,13 +213,15 @@ __global__ __launch_bounds__(1024) void norm_binned_kernel(const int32_t *__rest
 }
 
 // dst column q2 = src column sel[q2] (nk entries each)
-__global__ __launch_bounds__(256) void norm_gather_cols_kernel(const int32_t *__restrict__ src, const int32_t *__restrict__ sel, int nk,
+__global__ __launch_bounds__(256) void norm_gather_cols_kernel(const int32_t *__restrict__ src, const int32_t *__restrict__ sel, int nk, int pk,
                                                                int32_t *__restrict__ dst)
 {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= nk) return;
-    dst[(size_t)blockIdx.y * nk + r] = src[(size_t)sel[blockIdx.y] * nk + r];
+    for (int q = blockIdx.y; q < pk; q += gridDim.y) dst[(size_t)q * nk + r] = src[(size_t)sel[q] * nk + r];
 }
+
+#define NORM_GRID_Y 65535  // HIP's limit on grid.y: the per-column output kernels loop beyond it
 
 #define NHIP(call)                                                                                           \
     do {                                                                                                     \
@@ -374,7 +376,7 @@ extern "C" int fw_normalize_counts(int32_t device, int32_t kind, int32_t n, int3
             }
             NHIP(hipMemcpy(d_cols, cols.data(), sizeof(int32_t) * pk, hipMemcpyHostToDevice));
             NHIP(hipMalloc((void **)&d_oi, sizeof(int32_t) * (size_t)nk * pk));
-            hipLaunchKernelGGL(norm_binary_out_kernel, dim3((nk + 255) / 256, pk), dim3(256), 0, 0, d_x, n, d_rows, nk, d_cols, pk, d_oi);
+            hipLaunchKernelGGL(norm_binary_out_kernel, dim3((nk + 255) / 256, std::min(pk, NORM_GRID_Y)), dim3(256), 0, 0, d_x, n, d_rows, nk, d_cols, pk, d_oi);
             NHIP(hipGetLastError());
             NHIP(hipMemcpy(out_i32, d_oi, sizeof(int32_t) * (size_t)nk * pk, hipMemcpyDeviceToHost));
         } else if (kind == FW_MI_NZ) {
@@ -407,7 +409,7 @@ extern "C" int fw_normalize_counts(int32_t device, int32_t kind, int32_t n, int3
             NHIP(hipMalloc((void **)&d_sel, sizeof(int32_t) * pk));
             NHIP(hipMemcpy(d_sel, sel.data(), sizeof(int32_t) * pk, hipMemcpyHostToDevice));
             NHIP(hipMalloc((void **)&d_oi, sizeof(int32_t) * (size_t)nk * pk));
-            hipLaunchKernelGGL(norm_gather_cols_kernel, dim3((nk + 255) / 256, pk), dim3(256), 0, 0, d_tmp, d_sel, nk, d_oi);
+            hipLaunchKernelGGL(norm_gather_cols_kernel, dim3((nk + 255) / 256, std::min(pk, NORM_GRID_Y)), dim3(256), 0, 0, d_tmp, d_sel, nk, pk, d_oi);
             NHIP(hipGetLastError());
             NHIP(hipMemcpy(out_i32, d_oi, sizeof(int32_t) * (size_t)nk * pk, hipMemcpyDeviceToHost));
         } else {
@@ -416,7 +418,7 @@ extern "C" int fw_normalize_counts(int32_t device, int32_t kind, int32_t n, int3
             NHIP(hipMemcpy(d_pseudo, pseudo.data(), sizeof(double) * nk, hipMemcpyHostToDevice));
             NHIP(hipMemcpy(d_g, g.data(), sizeof(double) * nk, hipMemcpyHostToDevice));
             NHIP(hipMalloc((void **)&d_of, sizeof(float) * (size_t)nk * pk));
-            hipLaunchKernelGGL(norm_clr_out_kernel, dim3((nk + 255) / 256, pk), dim3(256), 0, 0, d_x, n, d_rows, nk, d_cols, pk, d_pseudo, d_g,
+            hipLaunchKernelGGL(norm_clr_out_kernel, dim3((nk + 255) / 256, std::min(pk, NORM_GRID_Y)), dim3(256), 0, 0, d_x, n, d_rows, nk, d_cols, pk, d_pseudo, d_g,
                                kind == FW_FZ ? 0 : 1, d_of);
             NHIP(hipGetLastError());
             NHIP(hipMemcpy(out_f32, d_of, sizeof(float) * (size_t)nk * pk, hipMemcpyDeviceToHost));

@@ -1,6 +1,7 @@
 """Multi-GPU exchange step of the target-sharded conditional stage.
 
-The path shards by target variable: every rank owns every world_size-th target of a feed-forward round and holds
+The path shards by target variable: the targets of a feed-forward round are dealt to the ranks longest-estimated-work
+first (LPT on (level-0 degree)^min(max_k, 3) + 64, computed identically on every rank: fw_hiton.cpp), every rank holds
 the full (replicated) packed data / correlation matrix, so the data path needs no collective.  The one real
 exchange is the per-round all-gather of the newly found directed neighbour entries (target, neighbour, stat, p)
 that feeds the next round's whitelists (the role of the master's running graph, reference

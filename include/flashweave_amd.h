@@ -145,11 +145,12 @@ int fw_abi_version(void);
 int fw_set_data_dense_f32(fw_ctx *ctx, const float *data);
 
 /* FW_MI / FW_MI_NZ: SparseMatrixCSC{Int32,Int64} as produced by normalize_data (make_sparse = true).
- * colptr has p+1 entries; rowval is 0-based and sorted within each column; values are 1..3.
+ * colptr has p+1 entries; rowval is 0-based and sorted within each column; values are 1..2
+ * (stored zeros are not allowed; a third non-zero level is FW_ERR_LIMIT -- two bit planes per variable).
  * Also computes levels / max_vals (src/misc.jl:64-97). */
 int fw_set_data_csc_i32(fw_ctx *ctx, const int64_t *colptr, const int32_t *rowval, const int32_t *nzval);
 
-/* FW_MI / FW_MI_NZ, dense input (Matrix{Int32}, n x p column-major, values 0..3); converted on the host to
+/* FW_MI / FW_MI_NZ, dense input (Matrix{Int32}, n x p column-major, values 0..2); converted on the host to
  * the same packed device layout, i.e. evaluated with the SPARSE-path semantics (levels_z rules). */
 int fw_set_data_dense_i32(fw_ctx *ctx, const int32_t *data);
 

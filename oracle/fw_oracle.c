@@ -1551,6 +1551,43 @@ int64_t fwo_level0_sample(fwo_ctx *c, int hps, int64_t n_obs_min, int x_start, i
     return n_tests;
 }
 
+/* Level-0 pair tests of the rows X = x_start, x_start + x_stride, ... (at most max_rows of them; every Y > X) WITH their
+ * results: the pairs whose raw p-value is below alpha (after the reliability rule of tests.jl:397-398), in (X, Y) order --
+ * what fwo_level0 would hand to Benjamini-Hochberg from these rows.  For the full-size level-0 parity tests (the device run
+ * with FDR = false keeps exactly these pairs).  Returns the number of pairs written (at most cap; -1 if cap was too small);
+ * *n_tests = pair tests executed, *m = those with a non-NaN p-value. */
+int64_t fwo_level0_rows(fwo_ctx *c, double alpha, int hps, int64_t n_obs_min, int x_start, int x_stride, int max_rows, int64_t cap,
+                        int32_t *out_x, int32_t *out_y, double *out_stat, double *out_pval, int64_t *n_tests, int64_t *m)
+{
+    int64_t nf = 0, nt = 0, mm = 0;
+    int rows = 0;
+    for (int X = x_start; X < c->p - 1 && rows < max_rows; X += (x_stride > 0 ? x_stride : 1), ++rows) {
+        int x_fail = !FWO_IS_CONT(c) && c->levels[X] < 2;
+        for (int Y = X + 1; Y < c->p; ++Y) {
+            fwo_result r;
+            if (x_fail)
+                set_result(&r, 0.0, 1.0, 0, 0);
+            else
+                fwo_test(c, X, Y, NULL, 0, hps, n_obs_min, &r);
+            ++nt;
+            double stat = r.stat, pval = r.pval;
+            if (!r.suff_power) stat = pval = NAN;
+            if (!isnan(pval)) ++mm;
+            if (pval < alpha) {
+                if (nf == cap) return -1;
+                out_x[nf] = X;
+                out_y[nf] = Y;
+                out_stat[nf] = stat;
+                out_pval[nf] = pval;
+                ++nf;
+            }
+        }
+    }
+    *n_tests = nt;
+    *m = mm;
+    return nf;
+}
+
 int64_t fwo_nbrs_total(const fwo_nbrs *nb, int p) { return nb->off[p]; }
 int64_t fwo_nbrs_ntests(const fwo_nbrs *nb) { return nb->n_tests; }
 void fwo_nbrs_copy(const fwo_nbrs *nb, int p, int32_t *off, int32_t *idx, double *stat, double *pval)

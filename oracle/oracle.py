@@ -81,6 +81,9 @@ def lib():
         L.fwo_nbrs_from_csr.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int64]
         L.fwo_level0_sample.restype = C.c_int64
         L.fwo_level0_sample.argtypes = [vp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double)]
+        L.fwo_level0_rows.restype = C.c_int64
+        L.fwo_level0_rows.argtypes = [vp, C.c_double, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, vp, vp, vp, vp,
+                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.fwo_nbrs_total.restype = C.c_int64
         L.fwo_nbrs_total.argtypes = [vp, C.c_int]
         L.fwo_nbrs_ntests.restype = C.c_int64
@@ -259,6 +262,19 @@ class Oracle:
         sec = C.c_double(0)
         nt = self.L.fwo_level0_sample(self.h, hps, n_obs_min, x_start, x_stride, max_seconds, C.byref(sec))
         return int(nt), sec.value
+
+    def level0_rows(self, alpha=0.01, hps=5, n_obs_min=0, x_start=0, x_stride=1, max_rows=1 << 30, cap=1 << 22):
+        """Raw level-0 results of sampled rows (every Y > X): the pairs with raw p < alpha -> dict(X, Y, stat, pval, n_tests, m)."""
+        x = np.zeros(cap, np.int32)
+        y = np.zeros(cap, np.int32)
+        st = np.zeros(cap, np.float64)
+        pv = np.zeros(cap, np.float64)
+        nt, m = C.c_int64(0), C.c_int64(0)
+        k = self.L.fwo_level0_rows(self.h, alpha, hps, n_obs_min, x_start, x_stride, max_rows, cap, _ptr(x), _ptr(y), _ptr(st), _ptr(pv),
+                                   C.byref(nt), C.byref(m))
+        if k < 0:
+            raise ValueError("level0_rows: more than %d significant pairs in the sample" % cap)
+        return dict(X=x[:k], Y=y[:k], stat=st[:k], pval=pv[:k], n_tests=int(nt.value), m=int(m.value))
 
     def learn(self, max_k=3, alpha=0.01, hps=5, n_obs_min=-1, max_tests=10_000_000, FDR=True, feed_forward=True,
               round_size=1, max_targets=0, target_stride=1, max_seconds=0.0, target_offset=0, nbrs=None):

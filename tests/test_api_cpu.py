@@ -7,10 +7,16 @@ import flashweave_jl_amd as fw
 from flashweave_jl_amd import api
 
 
-def test_default_round_size_is_the_benchmarked_schedule():
-    # R = 1024 * ceil(p / 10240): about ten feed-forward rounds per pass (bench.py's headline schedule)
-    assert api.default_round_size(50) == 1024 and api.default_round_size(10_000) == 1024
-    assert api.default_round_size(10_241) == 2048 and api.default_round_size(50_020) == 5120 and api.default_round_size(100_000) == 10_240
+def test_default_round_size():
+    # small problems: the reference's single_il schedule (reproduces its golden networks by default)
+    assert api.default_round_size(50) == 1 and api.default_round_size(512) == 1
+    # beyond: eight to ten rounds per pass at every size (one round would silently switch feed_forward off) ...
+    for p in (513, 1000, 5000, 8000, 10_000, 30_000, 50_020, 100_000):
+        R = api.default_round_size(p)
+        assert R >= 64 and 8 <= -(-p // R) <= 10, (p, R)
+    # ... and at the benchmark sizes R = 1024 * ceil(p / 10240), bench.py's headline schedule
+    assert api.default_round_size(10_000) == 1024 and api.default_round_size(10_241) == 1281
+    assert api.default_round_size(50_020) == 5120 and api.default_round_size(100_000) == 10_240
 
 
 def test_learn_network_rejects_what_it_would_otherwise_ignore():
@@ -35,3 +41,6 @@ def test_normalize_counts_validates_before_touching_the_device():
 def test_integral_float_tables_take_the_device_front_end():
     assert api._integral(np.array([[1.0, 0.0], [3.0, 2.0]])) and api._integral(np.array([[1, 0]], dtype=np.int32))
     assert not api._integral(np.array([[0.5, 1.0]])) and not api._integral(np.array([[np.nan, 1.0]]))
+    # integer tables outside Int32 / with negative entries go to the host front-end too (they used to reach the device and raise)
+    assert not api._integral(np.array([[2 ** 40, 1]], dtype=np.int64)) and not api._integral(np.array([[-1, 1]], dtype=np.int64))
+    assert not api._integral(np.array([[2 ** 31, 1]], dtype=np.uint32)) and api._integral(np.array([[2 ** 31 - 1, 0]], dtype=np.uint32))

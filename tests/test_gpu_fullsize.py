@@ -206,14 +206,89 @@ def test_cfg5_full_size_sample_properties():
     eng.close()
 
 
+_CFG4 = {}
+
+
+def _cfg4_data():
+    """cfg4's normalised table (host front-end: two minutes of CPU), built once per test session."""
+    if "data" not in _CFG4:
+        c = synth.CONFIGS["cfg4"]
+        counts, meta = synth.generate(c["p"], c["n"], c["seed"], mode=c["mode"], habitats=c["habitats"], n_meta=c["n_meta"])
+        _CFG4["data"] = np.ascontiguousarray(pre.normalize_with_meta(counts, c["test_name"], meta.astype(np.float64), prec=32)["data"])
+    return synth.CONFIGS["cfg4"], _CFG4["data"]
+
+
+def test_cfg4_full_size_headline_schedule_equals_oracle():
+    """The schedule bench.py reports for cfg4 (feed_forward = 1, rounds of R = 5120 targets: `profiles/r0*_bench_cfg4_n1.json`) at
+    FULL size against the oracle over the WHOLE schedule -- all ten rounds, i.e. including the last one with the 3 940 heaviest
+    targets that the team-target / lock-step / board / seeded-record machinery of the persistent kernel serves, and with whitelists
+    in play from the second round on (interleaved.jl:124-183, tests.jl:281-346).  The oracle runs on the device's level-0
+    neighbour lists (a CPU level-0 over 1.25e9 pairs takes hours; the lists are compared with the oracle's pair tests on sampled
+    rows in the next test).  Directed lists exact, weights 1e-11 (summation order of the MI terms), p-values
+    1e-10, reference-order test count exact.  FW_CFG4_ORACLE_TARGETS bounds the compared prefix of the schedule (default: all)."""
+    import os
+    c, data = _cfg4_data()
+    n, p = data.shape
+    M = int(os.environ.get("FW_CFG4_ORACLE_TARGETS", "0")) or p
+    R = 5120
+    eng = fw.Engine(c["test_name"], n, p, max_k=3)
+    eng.set_data(data)
+    got = eng.lgl(feed_forward=True, round_size=R, max_targets=(M if M < p else 0), edge_dict=False)
+    cn = eng.counters()
+    nb = eng.pw_univar_neighbors_get()
+    nb["n_tests"] = p * (p - 1) // 2
+    orc = O.Oracle(c["test_name"], csc=O.dense_to_csc(data), shape=(n, p), sparse=True, max_k=3)
+    exp = orc.learn(max_k=3, feed_forward=True, round_size=R, max_targets=(M if M < p else 0), nbrs=nb)
+    assert np.array_equal(got["pc_off"], exp["pc_off"])
+    assert np.array_equal(got["pc_idx"], exp["pc_idx"])
+    assert np.allclose(got["pc_weight"], exp["pc_weight"], rtol=1e-11, atol=1e-15, equal_nan=True)  # NaN = whitelisted without a test
+    assert np.allclose(got["pc_pval"], exp["pc_pval"], rtol=1e-10, atol=0.0, equal_nan=True)
+    assert int(np.isnan(exp["pc_weight"]).sum()) > 100            # the whitelists were really in play
+    assert cn["cond_tests_ref"] == exp["n_cond_tests"] > 100_000
+    ge = dict(zip(zip(got["edge_src"].tolist(), got["edge_dst"].tolist()), got["edge_weight"].tolist()))
+    assert set(ge) == set(exp["edges"]) and len(ge) > 1000
+    assert all(abs(ge[e] - w) <= 1e-11 * abs(w) + 1e-15 for e, w in exp["edges"].items())
+    orc.close()
+    eng.close()
+
+
+def test_cfg4_full_size_level0_rows_equal_oracle():
+    """cfg4's level 0 at FULL size (1.25e9 pairs through mi_level0_kernel + the exact kernel) against the oracle's own pair tests on
+    sampled rows -- rows 0, s, 2s, ... (s = p // 64: the sample bench.py's cpu_baseline times) against every later column.  The
+    device runs with FDR = false, so its lists hold exactly the pairs with a raw p-value below alpha (tests.jl:436-532 without
+    the BH step; BH itself: test_device_bh_equals_host_bh): for every sampled row the partners beyond it, their statistics
+    (1e-12) and p-values (1e-10) must be the oracle's."""
+    c, data = _cfg4_data()
+    n, p = data.shape
+    eng = fw.Engine(c["test_name"], n, p, max_k=3, FDR=False)
+    eng.set_data(data)
+    nb = eng.pw_univar_neighbors()
+    off, idx, st, pv = nb["off"], nb["idx"], nb["stat"], nb["pval"]
+    orc = O.Oracle(c["test_name"], csc=O.dense_to_csc(data), shape=(n, p), sparse=True, max_k=3)
+    nom = orc.auto_n_obs_min(-1, 5, 3)
+    stride = p // 64
+    exp = orc.level0_rows(alpha=0.01, hps=5, n_obs_min=nom, x_start=0, x_stride=stride, max_rows=64)
+    assert exp["n_tests"] > 1_000_000 and len(exp["X"]) > 1000
+    nchk = 0
+    for X in range(0, p - 1, stride)[:64]:
+        row = slice(off[X], off[X + 1])
+        later = idx[row] > X
+        sel = exp["X"] == X
+        assert np.array_equal(idx[row][later], exp["Y"][sel]), X
+        assert np.allclose(st[row][later], exp["stat"][sel], rtol=1e-12, atol=1e-15)
+        assert np.allclose(pv[row][later], exp["pval"][sel], rtol=1e-10, atol=0.0)
+        nchk += int(sel.sum())
+    assert nchk == len(exp["X"])
+    orc.close()
+    eng.close()
+
+
 def test_cfg4_full_size_properties():
     """BASELINE configs[3] (cfg4: 50 000 OTUs x 5 000 samples + 20 meta variables, FlashWeaveHE-F, max_k = 3) at full size:
     idempotent passes, edges are level-0 pairs, and the first 4 000 targets of the schedule equal the oracle's directed
     results (the oracle runs on the device's level-0 neighbour lists: a full CPU level-0 over 1.25e9 pairs takes minutes;
     the lists themselves are checked against the oracle at 300-1000 variables in tests/test_gpu_mi.py)."""
-    c = synth.CONFIGS["cfg4"]
-    counts, meta = synth.generate(c["p"], c["n"], c["seed"], mode=c["mode"], habitats=c["habitats"], n_meta=c["n_meta"])
-    data = np.ascontiguousarray(pre.normalize_with_meta(counts, c["test_name"], meta.astype(np.float64), prec=32)["data"])
+    c, data = _cfg4_data()
     n, p = data.shape
     eng = fw.Engine(c["test_name"], n, p, max_k=3)
     eng.set_data(data)

@@ -269,13 +269,21 @@ def test_learn_network_api_reproduces_all_golden_networks(tmp_path):
     for sensitive, het, name, wtol in ((True, False, "fz", 5e-5), (True, True, "fz_nz", 2e-5),
                                        (False, False, "mi", 1e-13), (False, True, "mi_nz", 1e-13)):
         for max_k in (0, 3):
-            # round_size=1: the reference's deterministic single_il schedule the goldens were generated with (the default
-            # schedule is the device one: default_round_size(p) targets per feed-forward round)
-            net = fw.learn_network(raw, sensitive=sensitive, heterogeneous=het, max_k=max_k, round_size=1)
+            # the DEFAULT call: up to 512 variables learn_network runs the reference's deterministic single_il schedule, the one the
+            # goldens were generated with (larger tables take default_round_size(p) targets per device round)
+            net = fw.learn_network(raw, sensitive=sensitive, heterogeneous=het, max_k=max_k)
+            assert net["parameters"]["round_size"] == 1 and net["parameters"]["schedule"].startswith("single_il")
             assert net["counters"]["normalized_on_device"]
             exp = read_edgelist("%s/learning_expected/exp_%s_maxk%d.edgelist" % (GOLDEN, name, max_k))
             assert set(net["edges"]) == set(exp), (name, max_k)
             assert all(abs(net["edges"][e] - exp[e]) <= wtol for e in exp)
+    # dense_cor=False in its most natural call (recursive_pcor left at its default): runs, warns, and says what it ran
+    with pytest.warns(UserWarning, match="recursive_pcor=False"):
+        nm = fw.learn_network(raw, sensitive=True, heterogeneous=False, max_k=3, dense_cor=False)
+    assert nm["parameters"]["recursive_pcor"] is False and nm["parameters"]["dense_cor"] is False and len(nm["edges"]) > 0
+    # ... and the flag is ignored where the reference ignores it (no matrix exists for these tests anyway)
+    ni = fw.learn_network(raw, sensitive=False, heterogeneous=True, max_k=3, dense_cor=False)
+    assert ni["edges"] == net["edges"]
     out = tmp_path / "net.edgelist"
     net.save(str(out))
     back, hdr, _ = fio.read_edgelist(str(out))

@@ -155,6 +155,43 @@ def test_job_matrix_and_streamed_forms_agree(ctx, monkeypatch, max_k):
         assert abs(g["stat"] - e["stat"]) < 1e-11
 
 
+def test_job_matrix_cache_with_mixed_list_lengths_and_an_arena_regrow(monkeypatch):
+    # A launch packs the job records in two passes (lists up to 512 variables first), i.e. not in pool order; when the matrix arena
+    # has to grow -- always on the first launch of a context -- every record gets a fresh offset, and the JOB must remember the
+    # offset of ITS record (r03 paired them by a running counter: a job that took a second window then conditioned a foreign
+    # matrix).  Long and short lists interleaved, alpha near 1 so that every job runs through several windows; the cached-matrix
+    # form must agree with the streamed form (no cache at all) and with the oracle.
+    counts = synth.generate(900, 200, 77, mode="S")
+    data, _, _ = pre.normalize(counts, "fz", prec=32)
+    data = np.asfortranarray(data)
+    n, p = data.shape
+    assert p > 640
+    rng = np.random.default_rng(9)
+    T, C, A = [], [], []
+    for la in [600, 12, 530, 30, 7, 620, 45, 513, 512]:
+        v = rng.choice(p, size=la + 2, replace=False)
+        T.append(int(v[0])); C.append(int(v[1])); A.append([int(t) for t in v[2:]])
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FW_FZS_GRAM", mode)
+        eng = fw.Engine("fz", n, p, max_k=2, alpha=0.9999, recursive_pcor=False, max_tests=60_000, n_obs_min=0)
+        eng.set_data(data)
+        res[mode] = eng.test_subsets_batch(T, C, A)
+        eng.close()
+    orc = O.Oracle("fz", cor_mat=np.eye(p, dtype=np.float32), n_obs=n)
+    orc.set_fz_data(data.astype(np.float64))
+    multi = 0
+    for t, c, a, g, s in zip(T, C, A, res["1"], res["0"]):
+        assert g["status"] == s["status"] and g["num_tests"] == s["num_tests"] and g["Zs"] == s["Zs"], (t, c, len(a), g, s)
+        assert abs(g["stat"] - s["stat"]) < 1e-12
+        multi += g["num_tests"] > 5000
+        e = orc.test_subsets(t, c, a, max_k=2, alpha=0.9999, n_obs_min=0, max_tests=60_000)
+        assert g["status"] == e["status"] and g["num_tests"] == e["num_tests"] and g["Zs"] == e["Zs"], (t, c, len(a), g, e)
+        assert abs(g["stat"] - e["stat"]) < 1e-11
+    assert multi >= 4   # several windows per job: the cache was used
+    orc.close()
+
+
 @pytest.mark.parametrize("round_size", [32, 100])
 def test_feed_forward_network_without_a_correlation_matrix(ctx, round_size):
     # the reference's default schedule (feed-forward rounds with whitelists) on the recursive_pcor = 0 path
