@@ -199,7 +199,9 @@ def cpu_baseline(args, cfg, data, n, p, eng, level0_per_step):
                   "the conditional sample taken from the device run)" % (stride, stride, l0_tests, l0_secs)
     l0_rate = l0_tests / max(l0_secs, 1e-9)
     c_rate = r["n_cond_tests"] / max(r["t_cond"], 1e-9)
-    cpu = {"unit": "tests/s", "cores": 1, "kind": "port",
+    cpu = {"unit": "tests/s", "cores": 1, "kind": "port", "feed_forward": 0,
+           "schedule_note": "the CPU sample runs feed_forward = 0 (one round, no whitelists); the GPU headline runs the schedule in "
+                            "config.feed_forward / config.round_size -- rates per test are comparable, the conditioning pools differ",
            "sample": "oracle/fw_oracle.c (C restatement; the Julia reference cannot run here): %s + conditional stage of "
                      "every %d-th target of the schedule (%d targets, %d tests, %.2fs), feed_forward=0" %
                      (l0_note, tstride, r["n_targets"], r["n_cond_tests"], r["t_cond"]),
@@ -523,7 +525,7 @@ def main():
         # counters of the same kernel on the same workload from separate rocprofv3 --pmc passes (they cannot be read from inside
         # this process): HBM-side traffic per launch, VALU instructions per test, VALU-busy share.  profiles/README.md
         pmc, pmc_src = None, None
-        for cand in ("r03_%s_pmc_summary.json" % args.config, "r02_%s_pmc_summary.json" % args.config):
+        for cand in ("r04_%s_pmc_summary.json" % args.config, "r03_%s_pmc_summary.json" % args.config, "r02_%s_pmc_summary.json" % args.config):
             pmc_path = os.path.join(ROOT, "profiles", cand)
             if not args.p and not args.n and os.path.exists(pmc_path):
                 js = json.load(open(pmc_path))
@@ -545,7 +547,12 @@ def main():
                     "note": "busy_frac = SQ_ACTIVE_INST_VALU x waves per SIMD / SQ_WAVE_CYCLES from the tracked PMC pass: the share of "
                             "cycles in which the SIMD's vector ALU is executing; Float64 and transcendental instructions hold it 4-16 "
                             "cycles, so the issue fraction computed at the 32-bit rate understates it", "source": pmc_src}
-        bound = "valu" if (valu and valu["busy_frac"] >= 0.6 and (traffic or 0) < 0.5 * rcn["alg_bytes_subsets"] / n_sub_launches) else "hbm"
+        # what the counters of the tracked PMC pass name as the limiter.  Fabric traffic well below the algorithmic bytes means the
+        # operands are cache-resident and HBM is NOT the bound: then "valu" when the vector ALUs are busy >= 60 % of the cycles,
+        # else "latency" (dependent chains / issue of a few resident wavefronts: the discrete persistent kernel).  "hbm" only when
+        # the traffic is there, or when no PMC summary of this configuration is tracked (the nominal label of SURVEY 8d)
+        low_traffic = pmc is not None and (traffic or 0) < 0.5 * rcn["alg_bytes_subsets"] / n_sub_launches
+        bound = ("valu" if valu and valu["busy_frac"] >= 0.6 else "latency") if low_traffic else "hbm"
         roofline = {"bound": bound, "kernel": kname,
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": (pmc_src + " (FETCH_SIZE + WRITE_SIZE per launch)") if traffic else None,
@@ -569,9 +576,23 @@ def main():
             # job are computed once per job from its columns (fzs_gram_kernel) and the tests condition sub-matrices of
             # that matrix out of LDS, so `achieved` is a multiple of the HBM rate and the bound is the conditioning arithmetic
             # (FW_FZS_GRAM=0: the per-test streaming form, 1.8 x the nominal rate with X / Y in LDS and the accepted columns in L2)
-            roofline["bound"] = "valu" if roofline["frac"] > 1.0 else "hbm"
             roofline["served_by"] = ("job-local Float64 correlation matrices in LDS (fw_fzs.hip: fzs_gram_kernel + fzs_subsets_seg_kernel<.., GRAM>); "
                                      "profiles/r03_fzs_micro*.json")
+            if rcn.get("gram_jobs", 0) > 0:
+                # the job-matrix form has its own algorithmic unit (fw_counters.gram_*): what must cross HBM is a job's columns ONCE
+                # ((a + 2) n 4 bytes) plus 32 bytes per test record, and the contraction is 2 n C(a + 2, 2) flops per job; B_fzS (columns
+                # per test) described a form that shares nothing and gave "fractions" of 5.8 (r03 review)
+                jb = rcn["gram_alg_bytes"] + 32.0 * rcn["cond_tests_evaluated"]
+                roofline.update({"bound": "valu", "unit": "GB/s", "achieved": jb / max(sub_launch_s, 1e-12) / 1e9,
+                                 "frac": jb / max(sub_launch_s, 1e-12) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": jb / n_sub_launches,
+                                 "job_matrices": {"jobs": rcn["gram_jobs"], "column_bytes": rcn["gram_alg_bytes"], "gram_flops": rcn["gram_alg_flops"],
+                                                  "gram_tflops_over_kernel_time": rcn["gram_alg_flops"] / max(sub_launch_s, 1e-12) / 1e12,
+                                                  "per_test_streaming_unit_bytes": rcn["alg_bytes_subsets"],
+                                                  "note": "achieved / frac: (columns of every job once + 32 B per evaluated test) over the HIP-event time of the "
+                                                          "variant's kernels; the limiter is the Float64 conditioning arithmetic of the tests on the LDS-resident "
+                                                          "matrix (bound = valu), not HBM"}})
+            else:
+                roofline["bound"] = "valu" if roofline["frac"] > 1.0 else "hbm"
         sub_launch_s = cn["t_dev_subsets_s"]  # the stage table below reports the headline pass
         cpu, cpu_skipped = None, None
         if world > 1:

@@ -242,6 +242,18 @@ int fw_set_cor_mat(fw_ctx *c, const float *cor)
         if (std::fabs(cor[t]) > 1.0f)
             return fw_fail(c, FW_ERR_ARG, "fw_set_cor_mat: entry %zu = %g is outside [-1, 1]: not a correlation matrix", t,
                            (double)cor[t]);
+    // ... and on its exact symmetry (what cor() returns: the kernels read whichever of cor[u][v] / cor[v][u] lies in the row the
+    // neighbouring lanes read, fw_fz_core.h CORT)
+    {
+        const size_t pp = (size_t)c->P.p;
+        for (size_t u = 0; u < pp; ++u)
+            for (size_t v = u + 1; v < pp; ++v) {
+                const float a = cor[u * pp + v], b = cor[v * pp + u];
+                if (!(a == b || (a != a && b != b)))
+                    return fw_fail(c, FW_ERR_ARG, "fw_set_cor_mat: entries (%zu, %zu) = %g and (%zu, %zu) = %g differ: not a symmetric matrix", u, v,
+                                   (double)a, v, u, (double)b);
+            }
+    }
     if (!c->d_cor) FW_HIP(c, hipMalloc(&c->d_cor, bytes));
     FW_HIP(c, hipMemcpy(c->d_cor, cor, bytes, hipMemcpyHostToDevice));
     c->have_cor = true;
@@ -962,6 +974,9 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
                         j.gram_epoch = pool.gram_epoch;
                         pool.gram_top += (size_t)r.m * r.m;
                         r.nR = 1;  // to be computed in this launch
+                        c->cnt.gram_jobs += 1;  // (the job-matrix form's own algorithmic unit, fw_counters)
+                        c->cnt.gram_alg_bytes += (double)r.m * (double)c->P.n * 4.0;
+                        c->cnt.gram_alg_flops += 2.0 * (double)c->P.n * 0.5 * (double)r.m * (double)(r.m - 1);
                     }
                     r.cor_off = (long long)j.gram_off;
                     arena_floats = pool.gram_top;
@@ -1249,6 +1264,19 @@ int fw_get_counters(const fw_ctx *c, fw_counters *out)
     if (!out) return fw_fail(c, FW_ERR_ARG, "fw_get_counters: NULL output");
     *out = c->cnt;
     return FW_OK;
+}
+
+int fw_selftest(fw_ctx *c, int which, uint64_t cases, uint64_t seed, uint64_t *mismatches)
+{
+    if (!c || !mismatches) return fw_fail(c, FW_ERR_ARG, "fw_selftest: NULL argument");
+    *mismatches = 0;
+    if (which == FW_SELFTEST_DIV) {
+        unsigned long long bad = 0;
+        const int rc = fwi_selftest_div(c, (unsigned long long)cases, (unsigned long long)seed, &bad);
+        *mismatches = (uint64_t)bad;
+        return rc;
+    }
+    return fw_fail(c, FW_ERR_ARG, "fw_selftest: unknown test %d", which);
 }
 
 int fw_reset_counters(fw_ctx *c)

@@ -147,6 +147,38 @@ __device__ __forceinline__ double dh_alg_bytes(int a, unsigned long long evaluat
     return bytes;
 }
 
+// number of subsets of sizes max_k .. 1 of a accepted variables, capped by max_tests (tests.jl:300-311): 32-bit binomials (no
+// 64-bit division, no Float64 estimate) where every term fits -- all of cfg2 / cfg4; the persistent discrete kernel paid for
+// three fw_binom_u64 per job
+__device__ __forceinline__ unsigned long long dh_enum_size(int a, int max_k, long long max_tests)
+{
+    unsigned long long N = 0ull;
+    if (max_k <= 3 && a <= FW_UNRANK32_A) {
+        for (int s = max_k; s >= 1; --s) N += (unsigned long long)fw_binom32(a, s);
+    } else {
+        for (int s = max_k; s >= 1; --s) {
+            N += fw_binom_u64(a, s);
+            if (N > (1ull << 62)) N = 1ull << 62;
+        }
+    }
+    if (max_tests > 0 && (unsigned long long)max_tests < N) N = (unsigned long long)max_tests;
+    return N;
+}
+
+// dh_alg_bytes for the discrete kinds with max_k <= 3 and short lists: the same sum in integers (bytes per test of size s are
+// (s + 2) * bytes_per_col + 32, a multiple of 1/8 at most -> exact in Float64 either way)
+__device__ __forceinline__ double dh_alg_bytes_disc32(int a, unsigned long long evaluated, int max_k, double disc_bytes_per_col)
+{
+    double bytes = 0.0;
+    unsigned long long left = evaluated;
+    for (int s = max_k; s >= 1 && left > 0ull; --s) {
+        const unsigned long long b = (unsigned long long)fw_binom32(a, s), cnt = left < b ? left : b;
+        bytes += (double)cnt * ((double)(s + 2) * disc_bytes_per_col + 32.0);
+        left -= cnt;
+    }
+    return bytes;
+}
+
 // Advance a target until it needs a device test (returns true; the job is (T, cands[pos], acc[0..na))) or finishes.
 // Executed by the whole wavefront of the target: every lane holds the same copy of x and takes the same branches
 // (stores of one lane are made visible to the others by workgroup-scope fences: one L1 per CU, no cache maintenance);
@@ -394,8 +426,21 @@ __shared__ unsigned short dh_mi_tab[4][MI_TAB16];
 __shared__ int32_t dh_mi_acc[4][1024];  // a helper's copy of the accepted list of the board it works on (MI_ACC_LDS)
 __shared__ DhTgt dh_mi_x[4];            // the state of the target each wavefront of dh_mi_target_kernel is working on
 __shared__ MiBest dh_mi_seed[4];        // the seed a wavefront hands to the test routine (mi_run_ranks)
+// Everything the out-of-line routines of the persistent kernel need about the launch -- device arrays, data description, parameters --
+// sits in LDS, written once by the kernel, and the test routine leaves its record in its wavefront's LDS slot.  r02 / r03 passed
+// MiDev by value and DhArrays / DhParams by reference and returned FwSegOut by value: by-value structs cross a call through
+// private memory (100 + 72 bytes PER LANE written and read back per call, 1 M calls per cfg4 pass), and a by-reference kernel
+// argument forces the kernel to keep a stack copy that every use in the callee loads from -- the r03 counters showed twice as many
+// bytes written as read by this kernel, and the r04 tick profile 9 us per call outside the tests (profiles/r04_cfg4_attribution.json).
+struct DhMiCtx {
+    DhArrays A;
+    MiDev M;
+    DhParams P;
+};
+__shared__ DhMiCtx dh_mi_ctx;
+__shared__ FwSegOut dh_mi_out[4];  // the record of the last mi_run_ranks / mi_run_ranks4 call of each wavefront
 #ifdef FW_MI_TICKS
-__shared__ unsigned long long dh_mi_ticks[4][6];  // per wavefront: calls, tests, ticks in the prologue / the test core / the accounting (Q) / sizes
+__shared__ unsigned long long dh_mi_ticks[4][12];  // per wavefront: calls, tests, ticks in the prologue / the test core / the accounting (Q) / sizes; [6..11]: ticks in dh_advance, job set-up (enumeration size, tail look), commit + counters, publish, wait for own board (idle), merge
 #endif
 
 // Everything two wavefronts share travels as write-through messages: the producer stores with sc1 (relaxed agent-scope atomic
@@ -420,7 +465,7 @@ struct MiQueue {
     unsigned int next_target, targets_done, n_boards, hint, res_top, bacc_top, pad[1], next_team;  // pad[0]: watchdog code
     unsigned long long t_body, t_ctl, t_sleep, n_seg;  // dh_mi_target_kernel: 100 MHz ticks summed over wavefronts (FW_TRACE_HOST; see the end of the kernel)
     unsigned long long t_total;  // dh_mi_target_kernel: ticks until the wavefront ran out of targets (the fields above: see its end)
-    unsigned long long tick[6];  // FW_MI_TICKS builds: calls of the test routine, tests, ticks before / in the test core / in the accounting, sum of set sizes
+    unsigned long long tick[12];  // FW_MI_TICKS builds: calls of the test routine, tests, ticks before / in the test core / in the accounting, sum of set sizes; [6..11] see dh_mi_ticks
     unsigned long long tm_run, tm_wait, tm_steps, tm_tests;  // dh_mi_team: ticks inside the test routine / at the barrier behind it, lock-step rounds, tests in them (all wavefronts)
 };
 
@@ -467,12 +512,12 @@ __device__ __forceinline__ unsigned long long mi_rfl_lane64(unsigned long long v
 // Called, not inlined: the kernel reaches it from four places (own jobs, own board, other boards while waiting / between
 // jobs / at the end) and four copies of the test made 168 KB of code -- against a 64 KB instruction cache.
 template <int L, int NXY, bool PRE>
-__device__ __noinline__ FwSegOut mi_run_ranks(const MiDev M_in, int T, int cand, const int32_t *__restrict__ acc_in, int a, int max_k,
-                                              long long max_tests, unsigned long long r0, unsigned long long r1,
-                                              const unsigned long long *stop_min_in, int remote_acc, const MiBest *seed_in)
+__device__ __noinline__ void mi_run_ranks(int T, int cand, const int32_t *__restrict__ acc_in, int a, int max_k,
+                                          long long max_tests, unsigned long long r0, unsigned long long r1,
+                                          const unsigned long long *stop_min_in, int remote_acc, const MiBest *seed_in)
 {
     unsigned short *tab = dh_mi_tab[threadIdx.x >> 6];
-    const MiDev M = mi_uniform(M_in);
+    const MiDev M = mi_uniform(dh_mi_ctx.M);
     T = __builtin_amdgcn_readfirstlane(T);
     cand = __builtin_amdgcn_readfirstlane(cand);
     a = __builtin_amdgcn_readfirstlane(a);
@@ -586,7 +631,9 @@ __device__ __noinline__ FwSegOut mi_run_ranks(const MiDev M_in, int T, int cand,
             for (int j = i + 1; j < s; ++j) pos[j] = pos[j - 1] + 1;
         }
     }
-    return o;
+    if ((threadIdx.x & 63) == 0) dh_mi_out[threadIdx.x >> 6] = o;  // (every lane holds the same record)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // The same enumeration, four subsets per step (mi_test_core4: one DPP row of 16 lanes per test; n <= MI4_N, max_k <= 3, 2 x 2 cells
@@ -594,12 +641,12 @@ __device__ __noinline__ FwSegOut mi_run_ranks(const MiDev M_in, int T, int cand,
 // sequential loop would (first stop wins, `>=` maximum before it), so the tests behind a stop inside a step are the only
 // speculation (counted in `evaluated`).
 template <int L>
-__device__ __noinline__ FwSegOut mi_run_ranks4(const MiDev M_in, int T, int cand, const int32_t *__restrict__ acc_in, int a, int max_k,
-                                               long long max_tests, unsigned long long r0, unsigned long long r1,
-                                               const unsigned long long *stop_min_in, int remote_acc, const MiBest *seed_in)
+__device__ __noinline__ void mi_run_ranks4(int T, int cand, const int32_t *__restrict__ acc_in, int a, int max_k,
+                                           long long max_tests, unsigned long long r0, unsigned long long r1,
+                                           const unsigned long long *stop_min_in, int remote_acc, const MiBest *seed_in)
 {
     unsigned short *tab = dh_mi_tab[threadIdx.x >> 6];
-    const MiDev M = mi_uniform(M_in);
+    const MiDev M = mi_uniform(dh_mi_ctx.M);
     T = __builtin_amdgcn_readfirstlane(T);
     cand = __builtin_amdgcn_readfirstlane(cand);
     a = __builtin_amdgcn_readfirstlane(a);
@@ -744,7 +791,9 @@ __device__ __noinline__ FwSegOut mi_run_ranks4(const MiDev M_in, int T, int cand
         if (stopped) break;
         r += (unsigned long long)nb;
     }
-    return o;
+    if ((threadIdx.x & 63) == 0) dh_mi_out[threadIdx.x >> 6] = o;  // (every lane holds the same record)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // ---- first tests of four candidates at once (R4 kernels) ------------------------------------------------------------------------
@@ -762,12 +811,12 @@ struct MiAhead {
 __shared__ MiAhead dh_mi_ahead[4];
 
 template <int L>
-__device__ __noinline__ void mi_first4(const MiDev M_in, int T, int pos0, const int32_t *__restrict__ cands_in, int nb, const int32_t *__restrict__ acc_in,
+__device__ __noinline__ void mi_first4(int T, int pos0, const int32_t *__restrict__ cands_in, int nb, const int32_t *__restrict__ acc_in,
                                        int a, int max_k, long long max_tests)
 {
     unsigned short *tab = dh_mi_tab[threadIdx.x >> 6];
     MiAhead &H = dh_mi_ahead[threadIdx.x >> 6];
-    const MiDev M = mi_uniform(M_in);
+    const MiDev M = mi_uniform(dh_mi_ctx.M);
     T = __builtin_amdgcn_readfirstlane(T);
     pos0 = __builtin_amdgcn_readfirstlane(pos0);
     nb = __builtin_amdgcn_readfirstlane(nb);
@@ -827,14 +876,15 @@ __device__ __noinline__ void mi_first4(const MiDev M_in, int T, int pos0, const 
 
 // R4: the four-subsets-per-step form (host: n <= MI4_N, max_k <= 3, 2 x 2 cells); one of the two routines per instantiation
 template <int L, int NXY, bool PRE, bool R4>
-__device__ __forceinline__ FwSegOut mi_run_ranks_sel(const MiDev &M, int T, int cand, const int32_t *__restrict__ acc, int a, int max_k,
+__device__ __forceinline__ FwSegOut mi_run_ranks_sel(int T, int cand, const int32_t *__restrict__ acc, int a, int max_k,
                                                      long long max_tests, unsigned long long r0, unsigned long long r1,
                                                      const unsigned long long *stop_min, int remote_acc, const MiBest *seed)
 {
     if constexpr (R4)
-        return mi_run_ranks4<L>(M, T, cand, acc, a, max_k, max_tests, r0, r1, stop_min, remote_acc, seed);
+        mi_run_ranks4<L>(T, cand, acc, a, max_k, max_tests, r0, r1, stop_min, remote_acc, seed);
     else
-        return mi_run_ranks<L, NXY, PRE>(M, T, cand, acc, a, max_k, max_tests, r0, r1, stop_min, remote_acc, seed);
+        mi_run_ranks<L, NXY, PRE>(T, cand, acc, a, max_k, max_tests, r0, r1, stop_min, remote_acc, seed);
+    return dh_mi_out[threadIdx.x >> 6];  // (inlined: the record comes back through LDS, not through a by-value return)
 }
 
 // one record = 9 64-bit words (FwSegOut), written through / read back word by word
@@ -928,8 +978,9 @@ __device__ __forceinline__ DhMerge mi_merge(const FwSegOut *__restrict__ so, lon
 // staged from the board's write-through copy.
 template <int L, int NXY, bool PRE, bool R4>
 __device__ __forceinline__ bool mi_board_work(MiBoard *__restrict__ b, FwSegOut *__restrict__ res, const int32_t *__restrict__ bacc,
-                                              const int32_t *acc_own, const MiDev &M, const DhParams &P, int lane)
+                                              const int32_t *acc_own, int lane)
 {
+    const DhParams &P = dh_mi_ctx.P;
     const unsigned long long nr = mi_ld_u64(&b->nr);
     const unsigned int nch = (unsigned int)nr, res_off = (unsigned int)(nr >> 32);
     if (mi_ld_u32(&b->next_chunk) >= nch) return false;
@@ -978,7 +1029,7 @@ __device__ __forceinline__ bool mi_board_work(MiBoard *__restrict__ b, FwSegOut 
             __builtin_amdgcn_wave_barrier();
             seed = &sd;
         }
-        o = mi_run_ranks_sel<L, NXY, PRE, R4>(M, (int)(unsigned int)tc, (int)(unsigned int)(tc >> 32), acc, a, P.max_k, P.max_tests, r0, r1,
+        o = mi_run_ranks_sel<L, NXY, PRE, R4>((int)(unsigned int)tc, (int)(unsigned int)(tc >> 32), acc, a, P.max_k, P.max_tests, r0, r1,
                                       &b->stop_min, remote, seed);
         if (o.stop_rank != FW_RANK_NONE && lane == 0) atomicMin(&b->stop_min, o.stop_rank);
     }
@@ -995,7 +1046,7 @@ __device__ __forceinline__ bool mi_board_work(MiBoard *__restrict__ b, FwSegOut 
 // a thousand wavefronts polling and swapping the same two words.)
 template <int L, int NXY, bool PRE, bool R4>
 __device__ __noinline__ bool mi_help(MiQueue *__restrict__ Q, MiBoard *__restrict__ boards, FwSegOut *__restrict__ res,
-                                     const int32_t *__restrict__ bacc, const MiDev &M, const DhParams &P, int lane)
+                                     const int32_t *__restrict__ bacc, int lane)
 {
     unsigned int nb = mi_ld_u32(&Q->n_boards);
     if (nb > MI_BOARD_CAP) nb = MI_BOARD_CAP;
@@ -1004,7 +1055,7 @@ __device__ __noinline__ bool mi_help(MiQueue *__restrict__ Q, MiBoard *__restric
         MiBoard *b = boards + i;
         if (mi_ld_u32(&b->ready) == 0u) return false;  // reserved, not yet filled
         if (mi_ld_u32(&b->next_chunk) < (unsigned int)mi_ld_u64(&b->nr)) {
-            if (mi_board_work<L, NXY, PRE, R4>(b, res, bacc, nullptr, M, P, lane)) return true;
+            if (mi_board_work<L, NXY, PRE, R4>(b, res, bacc, nullptr, lane)) return true;
         } else if (i == mi_ld_u32(&Q->hint) && lane == 0) {
             atomicMax(&Q->hint, i + 1u);  // every record of this board is taken: later scans start behind it
         }
@@ -1073,9 +1124,11 @@ __device__ __forceinline__ bool mi_publish(MiQueue *__restrict__ Q, MiBoard *__r
 // the whole HITON-PC of target t on the four wavefronts of this workgroup (every wavefront calls it; uniform control flow
 // between the barriers: every decision is taken from LDS values all four read)
 template <int L, int NXY, bool PRE, bool R4>
-__device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, const DhArrays &A, const MiDev &M, const DhParams &P, MiQueue *__restrict__ Q,
+__device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, MiQueue *__restrict__ Q,
                                         MiBoard *__restrict__ boards, FwSegOut *__restrict__ res, int32_t *__restrict__ bacc)
 {
+    const DhArrays &A = dh_mi_ctx.A;
+    const DhParams &P = dh_mi_ctx.P;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     DhTgt &x = dh_mi_x[0];
     MiTeamJob &J = dh_mi_tj;
@@ -1095,13 +1148,7 @@ __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, 
                     J.cand = cands[x.pos];
                     J.acc_off = DH_ACC_OFF(x, x.cur, 1);
                     J.a = x.na;
-                    unsigned long long N = 0ull;
-                    for (int s = P.max_k; s >= 1; --s) {
-                        N += fw_binom_u64(x.na, s);
-                        if (N > (1ull << 62)) N = 1ull << 62;
-                    }
-                    if (P.max_tests > 0 && (unsigned long long)P.max_tests < N) N = (unsigned long long)P.max_tests;
-                    J.N = N;
+                    J.N = dh_enum_size(x.na, P.max_k, P.max_tests);
                     J.tail = (P.mi_team_tail || (mi_ld_u32(&Q->next_target) + P.mi_team >= (unsigned int)ntg &&
                                                  ((unsigned int)ntg - mi_ld_u32(&Q->targets_done)) * 8u <= gridDim.x * 4u)) ? 1 : 0;
                 }
@@ -1144,7 +1191,7 @@ __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, 
                     __builtin_amdgcn_wave_barrier();
                     seed = &sd;
                 }
-                o = mi_run_ranks_sel<L, NXY, PRE, R4>(M, T, cand, acc, a, P.max_k, P.max_tests, r0, r1, nullptr, 0, seed);
+                o = mi_run_ranks_sel<L, NXY, PRE, R4>(T, cand, acc, a, P.max_k, P.max_tests, r0, r1, nullptr, 0, seed);
             } else {
                 o.stop_rank = FW_RANK_NONE;
                 o.stop_stat = o.stop_pval = 0.0;
@@ -1206,7 +1253,7 @@ __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, 
                 unsigned int bi, ro;
                 const bool ok = mi_publish(Q, boards, bacc, bacc_off, acc, a, T, cand, next, W, chunk, nch, lane, bi, ro, best_p, best_g, best_df);
                 if (!ok) {  // out of board space (never at the benchmark sizes): the leader carries on alone
-                    const FwSegOut q = mi_run_ranks_sel<L, NXY, PRE, R4>(M, T, cand, acc, a, P.max_k, P.max_tests, next, next + W, nullptr, 0, nullptr);
+                    const FwSegOut q = mi_run_ranks_sel<L, NXY, PRE, R4>(T, cand, acc, a, P.max_k, P.max_tests, next, next + W, nullptr, 0, nullptr);
                     if (lane == 0) {
                         J.mg.g = q.stop_stat;
                         J.mg.df = q.best_df;
@@ -1224,7 +1271,7 @@ __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, 
             const unsigned int bi = J.board;
             if (bi < MI_BOARD_CAP) {
                 MiBoard *b = boards + bi;
-                while (mi_board_work<L, NXY, PRE, R4>(b, res, bacc, acc, M, P, lane)) {
+                while (mi_board_work<L, NXY, PRE, R4>(b, res, bacc, acc, lane)) {
                 }
                 if (wave == 0) {
                     unsigned int spins = 0u;
@@ -1274,7 +1321,8 @@ __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, 
             x.c_ref += nt;
             x.c_calls += 1ull;
             x.c_eval += ev;
-            x.c_alg += dh_alg_bytes(a, ev, P.max_k, P.disc_bytes_per_col);
+            x.c_alg += (P.max_k <= 3 && a <= FW_UNRANK32_A) ? dh_alg_bytes_disc32(a, ev, P.max_k, P.disc_bytes_per_col)
+                                                            : dh_alg_bytes(a, ev, P.max_k, P.disc_bytes_per_col);
             dh_commit(x, A, lane, 1, r_stat, r_p, r_pow, P.alpha);
         }
         __syncthreads();  // (the next job's descriptor is written behind this)
@@ -1287,6 +1335,11 @@ __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, 
     __syncthreads();
 }
 
+#ifdef FW_MI_TICKS
+#define MI_TICK(slot, t0) do { if ((threadIdx.x & 63) == 0) dh_mi_ticks[threadIdx.x >> 6][slot] += wall_clock64() - (t0); } while (0)
+#else
+#define MI_TICK(slot, t0) do { (void)(t0); } while (0)
+#endif
 #ifndef DH_MI_OCC
 #define DH_MI_OCC 1  // workgroups per CU the register budget is sized for
 #endif
@@ -1301,11 +1354,17 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
     // phases (own records + waiting / helping), helping before jobs, the tail after the last target
     unsigned long long tk_seq = 0ull, tk_board = 0ull, tk_help = 0ull, tk_tail = 0ull;
 #ifdef FW_MI_TICKS
-    if (lane < 6) dh_mi_ticks[threadIdx.x >> 6][lane] = 0ull;
+    if (lane < 12) dh_mi_ticks[threadIdx.x >> 6][lane] = 0ull;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #endif
     if (lane == 0) dh_mi_ahead[threadIdx.x >> 6].n = 0;  // (no look-ahead results yet)
+    if (threadIdx.x == 0) {  // the launch context of the out-of-line routines (see DhMiCtx)
+        dh_mi_ctx.A = A;
+        dh_mi_ctx.M = M;
+        dh_mi_ctx.P = P;
+    }
+    __syncthreads();
     const unsigned long long tk_begin = wall_clock64();
     // the heaviest targets (the first mi_team of the list): a workgroup each, all four wavefronts on it (dh_mi_team), taken in list
     // order by whichever workgroup is free; the list proper starts behind them
@@ -1315,7 +1374,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
         const unsigned int ts = (unsigned int)dh_mi_tj.go;
         __syncthreads();  // (dh_mi_team rewrites the descriptor)
         if (ts >= P.mi_team) break;
-        dh_mi_team<L, NXY, PRE, R4>(tg, ntg, order[ts], A, M, P, Q, boards, res, bacc);
+        dh_mi_team<L, NXY, PRE, R4>(tg, ntg, order[ts], Q, boards, res, bacc);
     }
     unsigned int jobctr = 0u;
     bool tail_seen = false;
@@ -1332,7 +1391,11 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        while (dh_advance(x, A, lane, 1)) {
+        for (;;) {
+            const unsigned long long tka0 = wall_clock64();
+            const bool more_jobs = dh_advance(x, A, lane, 1);
+            MI_TICK(6, tka0);
+            if (!more_jobs) break;
             // other targets' big enumerations first: they are the critical path of the pass
             const unsigned long long tk0 = wall_clock64();
             // ... unless this target is one of the heavy ones: its own chain of jobs IS the critical path (cfg2 / cfg4: the
@@ -1343,7 +1406,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
             // them than for its tests (cfg2 trace: 18.8 us per job against a 12 us test)
             const bool poll = (jobctr++ & 3u) == 0u;
             if (P.mi_help_jobs && !heavy && poll)
-                while (mi_ld_u32(&Q->n_boards) > mi_ld_u32(&Q->hint) && mi_help<L, NXY, PRE, R4>(Q, boards, res, bacc, M, P, lane)) {
+                while (mi_ld_u32(&Q->n_boards) > mi_ld_u32(&Q->hint) && mi_help<L, NXY, PRE, R4>(Q, boards, res, bacc, lane)) {
                 }
             const unsigned long long tk1 = wall_clock64();
             tk_help += tk1 - tk0;
@@ -1351,12 +1414,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
             const int32_t cand = cands[x.pos];
             const long long acc_off = DH_ACC_OFF(x, x.cur, 1);
             const int a = x.na;
-            unsigned long long N = 0ull;
-            for (int s = P.max_k; s >= 1; --s) {
-                N += fw_binom_u64(a, s);
-                if (N > (1ull << 62)) N = 1ull << 62;
-            }
-            if (P.max_tests > 0 && (unsigned long long)P.max_tests < N) N = (unsigned long long)P.max_tests;
+            const unsigned long long N = dh_enum_size(a, P.max_k, P.max_tests);
             // the first tests: alone.  Elimination-phase jobs nearly always run to the end (the member passed every test against
             // almost this pool a moment ago): a big one goes to a board at once, whole enumeration in one window
             const bool elim_full = x.phase == 1 && P.mi_elim_min > 0u && N > (unsigned long long)P.mi_elim_min;
@@ -1372,6 +1430,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
             const bool tail = tail_seen;
             const unsigned long long seq = tail ? P.mi_seq_tail : (heavy ? P.mi_seq_heavy : P.mi_seq);
             unsigned long long next = elim_full ? 0ull : (N < seq ? N : seq);
+            MI_TICK(7, tk1);
             FwSegOut o;
             bool first_known = false;
             if constexpr (R4) {
@@ -1381,7 +1440,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
                     unsigned long long computed = 0ull;
                     if (!hit && x.nc - x.pos >= 2) {
                         const int nb = x.nc - x.pos < 4 ? x.nc - x.pos : 4;
-                        mi_first4<L>(M, x.T, x.pos, cands + x.pos, nb, A.acc + acc_off, a, P.max_k, P.max_tests);
+                        mi_first4<L>(x.T, x.pos, cands + x.pos, nb, A.acc + acc_off, a, P.max_k, P.max_tests);
                         computed = (unsigned long long)H.n;
                         hit = true;
                     }
@@ -1412,7 +1471,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
                                 }
                                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                                 __builtin_amdgcn_wave_barrier();
-                                o = mi_run_ranks_sel<L, NXY, PRE, R4>(M, x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, 1ull, next, nullptr, 0,
+                                o = mi_run_ranks_sel<L, NXY, PRE, R4>(x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, 1ull, next, nullptr, 0,
                                                                       H.pval[t] > 1e-290 ? &sd : nullptr);
                             }
                             if (o.stop_rank == FW_RANK_NONE && !(o.best_pval >= H.pval[t])) {  // the first test is still the maximum
@@ -1427,7 +1486,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
                 }
             }
             if (!first_known)
-                o = mi_run_ranks_sel<L, NXY, PRE, R4>(M, x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, 0ull, next, nullptr, 0, nullptr);
+                o = mi_run_ranks_sel<L, NXY, PRE, R4>(x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, 0ull, next, nullptr, 0, nullptr);
             unsigned long long ev = o.evaluated, nt = 0ull;
             bool stopped = o.stop_rank != FW_RANK_NONE;
             double r_stat = stopped ? o.stop_stat : 0.0, r_p = stopped ? o.stop_pval : 0.0;
@@ -1448,11 +1507,13 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
                 chunk = chunk < chunk_min ? chunk_min : (chunk > P.mi_chunk_max ? P.mi_chunk_max : chunk);
                 const unsigned int nch = (unsigned int)((W + chunk - 1ull) / chunk);
                 unsigned int bi, ro;
+                const unsigned long long tkp0 = wall_clock64();
                 const bool published = mi_publish(Q, boards, bacc, bacc_off, A.acc + acc_off, a, x.T, cand, next, W, chunk, nch, lane, bi, ro,
                                                   best_p, best_g, best_df);
+                MI_TICK(9, tkp0);
                 DhMerge mg;
                 if (!published) {  // out of board space (never at the benchmark sizes): the owner carries on alone
-                    const FwSegOut q = mi_run_ranks_sel<L, NXY, PRE, R4>(M, x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, next, next + W, nullptr, 0, nullptr);
+                    const FwSegOut q = mi_run_ranks_sel<L, NXY, PRE, R4>(x.T, cand, A.acc + acc_off, a, P.max_k, P.max_tests, next, next + W, nullptr, 0, nullptr);
                     mg.stop = q.stop_rank != FW_RANK_NONE;
                     mg.stat = mg.stop ? q.stop_stat : q.best_stat;
                     mg.p = mg.stop ? q.stop_pval : (q.best_pval < 0.0 ? -2.0 : q.best_pval);
@@ -1463,19 +1524,23 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
                     mg.df = q.best_df;
                 } else {
                     MiBoard *b = boards + bi;
-                    while (mi_board_work<L, NXY, PRE, R4>(b, res, bacc, A.acc + acc_off, M, P, lane)) {
+                    while (mi_board_work<L, NXY, PRE, R4>(b, res, bacc, A.acc + acc_off, lane)) {
                     }
                     unsigned int spins = 0u;
                     while (mi_ld_u32(&b->done) < nch) {  // records claimed by other wavefronts: they are running
-                        if (heavy || !mi_help<L, NXY, PRE, R4>(Q, boards, res, bacc, M, P, lane)) {
+                        if (heavy || !mi_help<L, NXY, PRE, R4>(Q, boards, res, bacc, lane)) {
+                            const unsigned long long tkw0 = wall_clock64();
                             mi_nap_wait();
+                            MI_TICK(10, tkw0);
                             if (++spins > (1u << 27)) {  // ~30 s: a logic error, not a workload -- report instead of hanging the GPU
                                 if (lane == 0) atomicExch(&Q->pad[0], 1u);
                                 break;
                             }
                         }
                     }
+                    const unsigned long long tkm0 = wall_clock64();
                     mg = mi_merge(res, (long long)ro, (int)nch, lane);
+                    MI_TICK(11, tkm0);
                 }
                 ev += mg.ev;
                 if (mg.stop) {
@@ -1507,11 +1572,14 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
                 r_pow = 1;
                 nt = N;
             }
+            const unsigned long long tkc0 = wall_clock64();
             x.c_ref += nt;
             x.c_calls += 1ull;
             x.c_eval += ev;
-            x.c_alg += dh_alg_bytes(a, ev, P.max_k, P.disc_bytes_per_col);
+            x.c_alg += (P.max_k <= 3 && a <= FW_UNRANK32_A) ? dh_alg_bytes_disc32(a, ev, P.max_k, P.disc_bytes_per_col)
+                                                            : dh_alg_bytes(a, ev, P.max_k, P.disc_bytes_per_col);
             dh_commit(x, A, lane, 1, r_stat, r_p, r_pow, P.alpha);
+            MI_TICK(8, tkc0);
         }
         if (lane == 0) {
             x.r_more0 = (unsigned int)wall_clock64();
@@ -1523,7 +1591,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
     const unsigned long long tk_t0 = wall_clock64();
     unsigned int spins = 0u;
     while (mi_ld_u32(&Q->targets_done) < (unsigned int)ntg && mi_ld_u32(&Q->pad[0]) == 0u) {
-        if (!mi_help<L, NXY, PRE, R4>(Q, boards, res, bacc, M, P, lane)) {
+        if (!mi_help<L, NXY, PRE, R4>(Q, boards, res, bacc, lane)) {
             mi_nap_tail();
             if (++spins > (1u << 27)) {
                 if (lane == 0) atomicExch(&Q->pad[0], 2u);
@@ -1539,7 +1607,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
         atomicAdd(&Q->n_seg, tk_tail);
         atomicAdd(&Q->t_total, tk_t0 - tk_begin);
 #ifdef FW_MI_TICKS
-        for (int q = 0; q < 6; ++q) atomicAdd(&Q->tick[q], dh_mi_ticks[threadIdx.x >> 6][q]);
+        for (int q = 0; q < 12; ++q) atomicAdd(&Q->tick[q], dh_mi_ticks[threadIdx.x >> 6][q]);
 #endif
     }
 }
@@ -2356,6 +2424,11 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
                 fprintf(stderr, "[fw] test routine: %llu calls, %llu tests (mean set size %.2f); per test %.2f us before the core (unranking, list), %.2f us in the core, %.2f us in the accounting (Q)\n",
                         hq.tick[0], hq.tick[1], (double)hq.tick[5] / (double)hq.tick[1], 1e-2 * hq.tick[2] / (double)hq.tick[1],
                         1e-2 * hq.tick[3] / (double)hq.tick[1], 1e-2 * hq.tick[4] / (double)hq.tick[1]);
+            if (hq.tick[1])
+                fprintf(stderr, "[fw] state machine, ms per wavefront: dh_advance %.3f, job set-up %.3f, commit + counters %.3f, publish %.3f, idle wait for own board %.3f, merge %.3f; "
+                                "test routine: before the core %.3f, core %.3f, accounting %.3f\n",
+                        ms * hq.tick[6] / nw, ms * hq.tick[7] / nw, ms * hq.tick[8] / nw, ms * hq.tick[9] / nw, ms * hq.tick[10] / nw, ms * hq.tick[11] / nw,
+                        ms * hq.tick[2] / nw, ms * hq.tick[3] / nw, ms * hq.tick[4] / nw);
             if (hq.tm_steps)
                 fprintf(stderr, "[fw] team rounds: %llu wavefront-rounds, %llu tests in them; per wavefront-round %.2f us in the test routine, %.2f us at the barrier\n",
                         hq.tm_steps, hq.tm_tests, 1e-2 * hq.tm_run / (double)hq.tm_steps, 1e-2 * hq.tm_wait / (double)hq.tm_steps);

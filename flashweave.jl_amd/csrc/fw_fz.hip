@@ -284,6 +284,11 @@ __global__ void fz_thresholds_kernel(double alpha, double zscale, double *thr)
     fz_thresholds_dev(alpha, zscale, thr);
     // thr[4]: |r| below which x = |z|/sqrt2 < FZ_X_SUB for sure (see fz_seg_body); once here instead of once per thread
     thr[4] = zscale > 0.0 ? tanh(FZ_X_SUB * 0.7071067811865476 / zscale) * (1.0 - 1e-9) : 2.0;
+    // thr[5..7]: the squared thresholds of the screened size-3 test (fz_seg_body: h2_pos, h2_neg, s2), once here so that the segment
+    // kernel holds them in scalar registers
+    thr[5] = thr[1] * thr[1] * (1.0 + 1e-12);
+    thr[6] = thr[3] * thr[3] * (1.0 + 1e-12);
+    thr[7] = (thr[4] < 1.0 ? thr[4] * thr[4] : 1.0) * (1.0 - 1e-12);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1353,5 +1358,66 @@ int fwi_fznz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t 
     FW_HIP(ctx, hipMemcpyAsync(out, ctx->d_out.ptr, (size_t)m * sizeof(fw_test_result), hipMemcpyDeviceToHost, ctx->stream));
     FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cnt.kernel_launches += 1;
+    return FW_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// device self-test of the hand-written arithmetic sequences (fw_selftest, include/flashweave_amd.h)
+// ------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ unsigned long long st_mix(unsigned long long x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+// FW_SELFTEST_DIV: fz_div_nn(n, d) against the compiler's IEEE division, bit for bit, on the operand ranges of the NaN-free
+// partial-correlation path: numerators = round5 values (|k| <= 200 000 multiples of 1e-5 as Float32-converted and as Float64
+// values, zero and -0 included), denominators = products of square roots of 1 - v^2 (Float32 roots converted, Float64 roots;
+// log-uniform in [2^-54, 1], the end points and powers of two included)
+__global__ void fz_selftest_div_kernel(unsigned long long cases, unsigned long long seed, unsigned long long *mismatches)
+{
+    unsigned long long bad = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < cases;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long h = st_mix(seed + i), h2 = st_mix(h);
+        const int k = (int)(h % 400001ull) - 200000;
+        double n;
+        if ((h >> 32) & 1ull)
+            n = (double)round5_f32_nn((float)k * 1e-5f);
+        else
+            n = round5_f64_nn((double)k * 1e-5);
+        if (((h >> 33) & 1023ull) == 0ull) n = -0.0;
+        // two factors in (0, 1]: mantissa from the hash, exponent log-uniform
+        const double m1 = 1.0 + (double)(h2 & 0xFFFFFFFFFFFFFull) * 2.220446049250313e-16;         // [1, 2)
+        const double m2 = 1.0 + (double)((h2 >> 11) & 0xFFFFFull) * 9.5367431640625e-07;            // coarse mantissa (Float32-like roots)
+        const int e1 = -(int)((h >> 43) % 28ull), e2 = -(int)((h >> 48) % 28ull);
+        double f1 = ldexp(m1, e1 - 1), f2 = (double)(float)ldexp(m2, e2 - 1);
+        const unsigned sel = (unsigned)((h >> 53) & 63ull);
+        if (sel == 0u) f1 = 1.0;
+        if (sel == 1u) f2 = 1.0;
+        if (sel == 2u) f1 = ldexp(1.0, e1);
+        if (sel == 3u) f2 = fz_sqrt_unit_raw(1.0 - (1.0 - ldexp(1.0, -52)) * (1.0 - ldexp(1.0, -52)));  // the smallest root of 1 - v^2, |v| < 1
+        const double d = f1 * f2;
+        const double a = fz_div_nn(n, d), b = n / d;
+        bad += __double_as_longlong(a) != __double_as_longlong(b);
+    }
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(mismatches, bad);
+}
+}  // namespace
+
+int fwi_selftest_div(fw_ctx *ctx, unsigned long long cases, unsigned long long seed, unsigned long long *mismatches)
+{
+    unsigned long long *d = nullptr;
+    FW_HIP(ctx, hipMalloc((void **)&d, 8));
+    FW_HIP(ctx, hipMemsetAsync(d, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(fz_selftest_div_kernel, dim3(4096), dim3(256), 0, ctx->stream, cases, seed, d);
+    FW_HIP(ctx, hipGetLastError());
+    FW_HIP(ctx, hipMemcpyAsync(mismatches, d, 8, hipMemcpyDeviceToHost, ctx->stream));
+    FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d);
     return FW_OK;
 }

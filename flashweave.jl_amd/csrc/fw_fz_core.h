@@ -378,12 +378,31 @@ __device__ __forceinline__ float pc_l1_rf(float xy, float xz, float yz, float rx
     return q;
 }
 
+// n / d, correctly rounded, for the operands of the NaN-free path: |n| <= 2 a multiple of 1e-5 (or zero), d in [2^-60, 1] -- far from
+// every range in which v_div_scale_f64 rescales (operands with extreme exponents, quotients near the ends of the exponent range),
+// so the compiler's IEEE sequence (2 x v_div_scale, v_rcp_f64, two Newton steps, quotient + residual, v_div_fmas, v_div_fixup)
+// degenerates to the same instructions on the same values without the two scalings and with a plain fma for v_div_fmas:
+// same bits, two instructions and a VCC dependency less per division.  v_div_fixup stays: it gives 0 / d the sign of the
+// numerator (the residual step turns -0 into +0) and d = 0 its inf / NaN (selected away by the callers).
+// fw_selftest(FW_SELFTEST_DIV) compares it with the compiler's division on the device over these operand ranges.
+__device__ __forceinline__ double fz_div_nn(double n, double d)
+{
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    const double q = n * y;
+    const double r = __builtin_fma(-d, q, n);
+    return __builtin_amdgcn_div_fixup(__builtin_fma(r, y, q), d, n);
+}
+
 __device__ __forceinline__ double pc_l2_all32_d1_nn(float a, float b, float c, double d1, double d2c)
 {
     const float prod = b * c;
     const double ev = (double)round5_f32_nn(a - prod);
     const double denom = d1 * d2c;
-    const double v = (denom == 0.0) ? 0.0 : ev / denom;
+    const double v = (denom == 0.0) ? 0.0 : fz_div_nn(ev, denom);
     return fz_clamp_unit_nn(v);
 }
 
@@ -394,7 +413,19 @@ __device__ __forceinline__ double pc_l3_nn(double a, double b, double c)
     const double ev = round5_f64_nn(a - b * c);
     const double xb = 1.0 - b * b, xc = 1.0 - c * c;
     const double denom = fz_sqrt_unit_raw(xb) * fz_sqrt_unit_raw(xc);
-    const double v = (xb == 0.0 || xc == 0.0) ? 0.0 : ev / denom;
+    const double v = (xb == 0.0 || xc == 0.0) ? 0.0 : fz_div_nn(ev, denom);
+    return fz_clamp_unit_nn(v);
+}
+
+// pc_l3_nn in two halves for the screened size-3 test of the table kernel: the test first looks at ev = round5(a - b c) and the two
+// radicands xb = 1 - b^2, xc = 1 - c^2 (fz_seg_body: ev^2 against thr^2 xb xc decides "significant for sure" and "clearly not the
+// lane's maximum-p test" without the two square roots and the division); the quotient itself -- the SAME operations on the same
+// values as pc_l3_nn, hence the same bits -- is only taken where its value is needed: a stopping test, a test inside a guard band,
+// the lane's maximum-p candidate once per run.  Out of line: rare, and the hot loop should not carry its registers.
+static __device__ __noinline__ double fz_l3_finish(double ev, double xb, double xc)
+{
+    const double denom = fz_sqrt_unit_raw(xb) * fz_sqrt_unit_raw(xc);
+    const double v = (xb == 0.0 || xc == 0.0) ? 0.0 : fz_div_nn(ev, denom);
     return fz_clamp_unit_nn(v);
 }
 
@@ -504,7 +535,7 @@ __device__ __forceinline__ double pc_l3s_nn(double a, double b, double c, double
 {
     const double ev = round5_f64_nn(a - b * c);
     const double denom = sb * sc;
-    const double v = (denom == 0.0) ? 0.0 : ev / denom;
+    const double v = (denom == 0.0) ? 0.0 : fz_div_nn(ev, denom);
     return fz_clamp_unit_nn(v);
 }
 __device__ __forceinline__ double fz_sq1(double v) { return fz_sqrt_unit(1.0 - v * v); }
@@ -586,7 +617,8 @@ __device__ __forceinline__ double fz_l1t_stat(const float *__restrict__ cor, int
     for (int t = 0; t < K - 1; ++t)
 #pragma unroll
         for (int u = t + 1; u < K - 1; ++u) {
-            const TV v = pc_l1_r(cor[(size_t)zid[t] * p + zid[u]], c[t], c[u], r[t], r[u]);
+            // (transposed read of the symmetric matrix: zid[u] belongs to the slower-moving position -> one row per wavefront, see CORT)
+            const TV v = pc_l1_r(cor[(size_t)zid[u] * p + zid[t]], c[t], c[u], r[t], r[u]);
             R[2 + t][2 + u] = v.v;
             is32[2 + t][2 + u] = v.f32;
             clean = clean && v.v == v.v;
@@ -723,9 +755,21 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     const double rlo_pos = thr[0], rhi_pos = thr[1], rlo_neg = thr[2], rhi_neg = thr[3];
     // |r| below which x = |z|/sqrt2 < FZ_X_SUB for sure: x = zscale * log((1+r)/(1-r)) / sqrt2  <=>  r = tanh(x / (sqrt2 zscale))
     const double rsub_lo = !LOCAL ? thr[4] : (zscale > 0.0 ? tanh(FZ_X_SUB * 0.7071067811865476 / zscale) * (1.0 - 1e-9) : 2.0);
+    // screened size-3 test (TAB3, see fz_l3_finish): with |stat| = |ev| / (sqrt(xb) sqrt(xc)) up to 1e-15 relative,
+    //   ev^2 > h2 xb xc  =>  |stat| > rhi (significant for sure: rhi already sits 1e-9 above the true threshold),
+    //   ev^2 < s2 xb xc  =>  |stat| < min(rsub_lo, 1): not clamped, p in the normal range (maximum-p tracking by |stat| alone)
+    // (the context-wide thresholds carry them ready-made in thr[5..7]: fz_thresholds_kernel; per-job thresholds of fz_nz: computed here)
+    const double h2_pos = !LOCAL ? thr[5] : rhi_pos * rhi_pos * (1.0 + 1e-12), h2_neg = !LOCAL ? thr[6] : rhi_neg * rhi_neg * (1.0 + 1e-12);
+    const double s2 = !LOCAL ? thr[7] : (rsub_lo < 1.0 ? rsub_lo * rsub_lo : 1.0) * (1.0 - 1e-12);
     __syncthreads();
 #define ACCV(i) (LOCAL ? ((i) + 2) : (in_lds ? s_acc[(i)] : gacc[(i)]))
 #define CORV(u, v) cor[(size_t)(u) * p + (v)]
+// Transposed read: the resident Pearson matrix is EXACTLY symmetric (mirrored stores of the GEMM epilogue; fw_set_cor_mat rejects
+// anything else), so cor[v][u] is the same bits as cor[u][v] -- and where u is the index that moves from lane to lane (the last
+// position of a subset, the later position of a table entry) while v stays, the 64 gathers of a wavefront fall into ONE 4 p-byte row
+// instead of 64 rows 4 p bytes apart (64 DRAM pages and 64 translations per wavefront instruction).  Job-local matrices (fz_nz)
+// keep the plain order.
+#define CORT(u, v) (LOCAL ? CORV(u, v) : CORV(v, u))
 
     const int X = LOCAL ? 0 : seg.X, Y = LOCAL ? 1 : seg.Y;
     const float cXY = CORV(X, Y);
@@ -859,7 +903,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                     const float cXz1 = CORV(X, z1), cYz1 = CORV(Y, z1);
                     for (int v = i0 + 1 + tid; v < a; v += 256) {
                         const int zv = ACCV(v);
-                        const float cvz1 = CORV(zv, z1);
+                        const float cvz1 = CORT(zv, z1);
                         const TV LX = pc_l1(CORV(X, zv), cXz1, cvz1);
                         const TV LY = pc_l1(CORV(Y, zv), cYz1, cvz1);
                         s_l1[v] = make_float4((float)LX.v, (float)LY.v, cvz1, sqrtf(1.0f - cvz1 * cvz1));
@@ -971,8 +1015,8 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                             const TV LXw{(double)ew.x, (fw_ & 1) != 0}, LYw{(double)ew.y, (fw_ & 2) != 0};
                             const TV LXz2{(double)e2.x, (f2 & 1) != 0}, LYz2{(double)e2.y, (f2 & 2) != 0};
                             const TV P2z3{(double)s3_bp2[d], s3_bfl[d] != 0};
-                            const TV P2w = pc_l1_r(CORV(zw, z2), ew.z, e2.z, ew.w, e2.w);  // rho(w,z2|z1)
-                            const TV P3w = pc_l1_r(CORV(zw, z3), ew.z, e3.z, ew.w, e3.w);  // rho(w,z3|z1)
+                            const TV P2w = pc_l1_r(CORT(zw, z2), ew.z, e2.z, ew.w, e2.w);  // rho(w,z2|z1)
+                            const TV P3w = pc_l1_r(CORT(zw, z3), ew.z, e3.z, ew.w, e3.w);  // rho(w,z3|z1)
                             const double dw = fz_sq1(P2w.v);
                             const double Q3 = pc_l2_d2(P3w, P2w, P2z3, s3_bd2c[d]);  // rho(w,z3|z1,z2): w is the first of the pair
                             const double X2w = pc_l2_d2(LXw, LXz2, P2w, dw);        // rho(X,w|z1,z2)
@@ -1042,7 +1086,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                             ++i;
                         }
                         const int z1 = ACCV(i), zv = ACCV(i + 1 + rem);
-                        const float cXz1 = CORV(X, z1), cYz1 = CORV(Y, z1), cvz1 = CORV(zv, z1);
+                        const float cXz1 = CORV(X, z1), cYz1 = CORV(Y, z1), cvz1 = CORT(zv, z1);
                         const TV A1 = pc_l1(cXY, cXz1, cYz1);
                         const TV LX = pc_l1(CORV(X, zv), cXz1, cvz1);
                         const TV LY = pc_l1(CORV(Y, zv), cYz1, cvz1);
@@ -1068,6 +1112,9 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
         // lane best: ordered by x = |z|/sqrt2 ascending (= p descending); in the underflow regime (x > FZ_X_SUB, where
         // different x can give the same subnormal/zero p) by the exact p instead; later rank wins ties (tests.jl:338)
         double my_bx = FZ_X_NONE, my_bps = 0.0, my_ba = 0.0;
+        // TAB3: the lane best as (numerator, radicands) -- |stat|^2 = my_bev^2 / (my_bxb my_bxc); its statistic is
+        // fz_l3_finish(my_bev, my_bxb, my_bxc), or my_bev itself when my_bxb = my_bxc = 1 (tests whose quotient was taken)
+        double my_bev = 0.0, my_bxb = 1.0, my_bxc = 1.0;
         unsigned int my_done = 0;  // tests this lane executes in this chunk (it leaves its run at its first stop)
         if (any) {
             // unrank the first rank of the run
@@ -1105,6 +1152,8 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
             double d2cl = 0.0, q3l = 0.0, sq3l = 0.0, x3l = 0.0, sx3l = 0.0, y3l = 0.0, sy3l = 0.0, a4l = 0.0;
             for (unsigned long long r = r0; r < r1; r += rstep) {
                 double stat;
+                double l3_ev = 0.0, l3_xb = 1.0, l3_xc = 1.0;
+                bool screened = false;  // TAB3 fast path: stat is still (l3_ev, l3_xb, l3_xc)
                 ++my_done;
                 if (HK && s >= 4) {  // (every chunk of this variant that holds subsets of 4 or 5 variables has its tables)
                     if (!hk_ok || s != hk_s) __builtin_trap();  // would be a chunking bug: fail loudly
@@ -1131,7 +1180,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                     const float4 tk = s_tab[ek];
                     const float rk1 = s_tab_r1[ek];
                     const int fj = __float_as_int(tj.w), fk = __float_as_int(tk.w);
-                    const float c32 = CORV(fk & FZ_TAB_ZMASK, fj & FZ_TAB_ZMASK);
+                    const float c32 = CORT(fk & FZ_TAB_ZMASK, fj & FZ_TAB_ZMASK);
                     bool f1ok;
                     const float F1f = pc_l1_rf(c32, tk.z, tj.z, rk1, rj1, f1ok);
                     const double F1v = (double)F1f;
@@ -1140,7 +1189,12 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                     if (__all((((fj & fk) >> 28) & 7) == 7 && f1ok)) {
                         const double D2 = pc_l2_all32_d1_nn(tk.x, tj.x, F1f, (double)rj2.x, dF);
                         const double E2 = pc_l2_all32_d1_nn(tk.y, tj.y, F1f, (double)rj2.y, dF);
-                        stat = pc_l3_nn(A2j, D2, E2);
+                        // pc_l3_nn(A2j, D2, E2), first half: numerator and radicands (the quotient follows where it is needed)
+                        l3_ev = round5_f64_nn(A2j - D2 * E2);
+                        l3_xb = 1.0 - D2 * D2;
+                        l3_xc = 1.0 - E2 * E2;
+                        screened = true;
+                        stat = 0.0;
                     } else {
                         const TV F1 = pc_l1_r(c32, tk.z, tj.z, rk1, rj1);
                         const TV D1{(double)tk.x, ((fk >> 30) & 1) != 0}, Bj{(double)tj.x, ((fj >> 30) & 1) != 0};
@@ -1166,7 +1220,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                         A2 = pc_l2(A1, B1, C1);
                     }
                     const int z3 = ACCV(pos[2]);
-                    const float cXz3 = CORV(X, z3), cYz3 = CORV(Y, z3), cz3z1 = CORV(z3, z1), cz3z2 = CORV(z3, z2);
+                    const float cXz3 = CORV(X, z3), cYz3 = CORV(Y, z3), cz3z1 = CORT(z3, z1), cz3z2 = CORT(z3, z2);
                     const TV D1 = pc_l1(cXz3, cXz1, cz3z1);
                     const TV E1 = pc_l1(cYz3, cYz1, cz3z1);
                     const TV F1 = pc_l1(cz3z2, cz3z1, cz2z1);
@@ -1223,7 +1277,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                         }
                         const int pm = pos[4], em = l3_base + pm;
                         const float4 t1m = s_l1[pm];
-                        const float c45 = CORV(s_acc[pm], zl);
+                        const float c45 = CORT(s_acc[pm], zl);
                         bool f1ok;
                         const float R1f = pc_l1_rf(c45, t1m.z, t1l.z, t1m.w, t1l.w, f1ok);     // rho(v,z4|z1)
                         if (__all(l3_nn && f1ok)) {
@@ -1257,21 +1311,38 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 } else {
                     stat = 0.0;
                 }
+                // |stat|^2 = e2 / m2 (TAB3); `sure`: significant, in the normal range of p, not the last test of a capped job -- decided
+                // on the squares, no quotient taken (fz_l3_finish)
+                double e2 = 0.0, m2 = 1.0;
+                bool sure = false;
+                if (TAB3) {
+                    if (screened) {
+                        m2 = l3_xb * l3_xc;
+                        e2 = l3_ev * l3_ev;
+                        sure = e2 > (l3_ev < 0.0 ? h2_neg : h2_pos) * m2 && e2 < s2 * m2 &&
+                               !(max_tests > 0 && r + 1 >= (unsigned long long)max_tests);
+                        if (!sure) stat = fz_l3_finish(l3_ev, l3_xb, l3_xc);
+                    } else {
+                        e2 = stat * stat;
+                    }
+                }
                 const double av = fabs(stat);
-                const bool negr = stat < 0.0;
-                bool sig;
-                if (av > (negr ? rhi_neg : rhi_pos))
-                    sig = true;
-                else if (av < (negr ? rlo_neg : rlo_pos))
-                    sig = false;
-                else
-                    sig = fz_pval_slow(stat, zscale) < alpha;  // inside the guard band (or NaN): exact
-                if (!sig || (max_tests > 0 && r + 1 >= (unsigned long long)max_tests)) {
-                    my_stop = r;
-                    stop_stat = stat;
-                    stop_p = fz_pval_slow(stat, zscale);
-                    (void)__hip_atomic_fetch_min(&s_cstop, (unsigned int)(r - cbase), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    break;
+                if (!sure) {
+                    const bool negr = stat < 0.0;
+                    bool sig;
+                    if (av > (negr ? rhi_neg : rhi_pos))
+                        sig = true;
+                    else if (av < (negr ? rlo_neg : rlo_pos))
+                        sig = false;
+                    else
+                        sig = fz_pval_slow(stat, zscale) < alpha;  // inside the guard band (or NaN): exact
+                    if (!sig || (max_tests > 0 && r + 1 >= (unsigned long long)max_tests)) {
+                        my_stop = r;
+                        stop_stat = stat;
+                        stop_p = fz_pval_slow(stat, zscale);
+                        (void)__hip_atomic_fetch_min(&s_cstop, (unsigned int)(r - cbase), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        break;
+                    }
                 }
                 // a lane of this workgroup has stopped at an earlier rank of the chunk: nothing behind it matters any more
                 // (the merge takes the first stop) -- r01/r02 profile: lanes running on behind the stop were the 18 % of
@@ -1283,41 +1354,92 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 // "lazily" (x is computed once per run, below), a clearly larger one is skipped, and only near-ties and
                 // the underflow regime take the exact path.
                 bool exact = false, lazy_take = false;
-                if (av < rsub_lo) {
-                    if (my_bx == FZ_X_NONE || my_bx > FZ_X_SUB)
-                        lazy_take = true;  // nothing yet, or the best so far sits in the underflow regime (smaller p)
-                    else if (av < my_ba * (1.0 - 1e-12))
-                        lazy_take = true;
-                    else
-                        exact = av <= my_ba * (1.0 + 1e-12);
-                } else {
-                    exact = true;
-                }
-                if (lazy_take) {
-                    my_bx = FZ_X_LAZY;
-                    my_bps = 0.0;
-                    my_ba = av;
-                    my_br = r;
-                    my_bstat = stat;
-                }
-                if (exact) {
-                    if (my_bx == FZ_X_LAZY)
-                        my_bx = fz_xkey_slow(my_bstat, zscale);
-                    const double xz = fz_xkey_slow(stat, zscale);
-                    bool take;
-                    double ps = 0.0;
-                    if (xz > FZ_X_SUB) {
-                        ps = fz_pval_slow(stat, zscale);  // exact (possibly subnormal / zero) p
-                        take = (my_bx == FZ_X_NONE) || (my_bx > FZ_X_SUB && ps >= my_bps);
+                if (TAB3) {
+                    // the same three-way decision on the squares e2 / m2 against my_bev^2 / (my_bxb my_bxc), cross-multiplied (no division)
+                    if (sure || av < rsub_lo) {
+                        if (my_bx == FZ_X_NONE || my_bx > FZ_X_SUB) {
+                            lazy_take = true;
+                        } else {
+                            const double lhs = e2 * (my_bxb * my_bxc), rhs = (my_bev * my_bev) * m2;
+                            if (lhs < rhs * (1.0 - 1e-11))
+                                lazy_take = true;
+                            else
+                                exact = lhs <= rhs * (1.0 + 1e-11);
+                        }
                     } else {
-                        take = (my_bx == FZ_X_NONE) || (my_bx > FZ_X_SUB) || (xz <= my_bx);
+                        exact = true;
                     }
-                    if (take) {
-                        my_bx = xz;
-                        my_bps = ps;
+                    if (lazy_take) {
+                        my_bx = FZ_X_LAZY;
+                        my_bps = 0.0;
+                        my_br = r;
+                        my_bev = sure ? l3_ev : stat;
+                        my_bxb = sure ? l3_xb : 1.0;
+                        my_bxc = sure ? l3_xc : 1.0;
+                    }
+                    if (exact) {
+                        if (sure) stat = fz_l3_finish(l3_ev, l3_xb, l3_xc);
+                        if (my_bx == FZ_X_LAZY) {
+                            if (my_bxb != 1.0 || my_bxc != 1.0) {
+                                my_bev = fz_l3_finish(my_bev, my_bxb, my_bxc);
+                                my_bxb = my_bxc = 1.0;
+                            }
+                            my_bx = fz_xkey_slow(my_bev, zscale);
+                        }
+                        const double xz = fz_xkey_slow(stat, zscale);
+                        bool take;
+                        double ps = 0.0;
+                        if (xz > FZ_X_SUB) {
+                            ps = fz_pval_slow(stat, zscale);  // exact (possibly subnormal / zero) p
+                            take = (my_bx == FZ_X_NONE) || (my_bx > FZ_X_SUB && ps >= my_bps);
+                        } else {
+                            take = (my_bx == FZ_X_NONE) || (my_bx > FZ_X_SUB) || (xz <= my_bx);
+                        }
+                        if (take) {
+                            my_bx = xz;
+                            my_bps = ps;
+                            my_br = r;
+                            my_bev = stat;
+                            my_bxb = my_bxc = 1.0;
+                        }
+                    }
+                } else {
+                    if (av < rsub_lo) {
+                        if (my_bx == FZ_X_NONE || my_bx > FZ_X_SUB)
+                            lazy_take = true;  // nothing yet, or the best so far sits in the underflow regime (smaller p)
+                        else if (av < my_ba * (1.0 - 1e-12))
+                            lazy_take = true;
+                        else
+                            exact = av <= my_ba * (1.0 + 1e-12);
+                    } else {
+                        exact = true;
+                    }
+                    if (lazy_take) {
+                        my_bx = FZ_X_LAZY;
+                        my_bps = 0.0;
                         my_ba = av;
                         my_br = r;
                         my_bstat = stat;
+                    }
+                    if (exact) {
+                        if (my_bx == FZ_X_LAZY)
+                            my_bx = fz_xkey_slow(my_bstat, zscale);
+                        const double xz = fz_xkey_slow(stat, zscale);
+                        bool take;
+                        double ps = 0.0;
+                        if (xz > FZ_X_SUB) {
+                            ps = fz_pval_slow(stat, zscale);  // exact (possibly subnormal / zero) p
+                            take = (my_bx == FZ_X_NONE) || (my_bx > FZ_X_SUB && ps >= my_bps);
+                        } else {
+                            take = (my_bx == FZ_X_NONE) || (my_bx > FZ_X_SUB) || (xz <= my_bx);
+                        }
+                        if (take) {
+                            my_bx = xz;
+                            my_bps = ps;
+                            my_ba = av;
+                            my_br = r;
+                            my_bstat = stat;
+                        }
                     }
                 }
                 // next combination in lexicographic order (sizes descend when one is exhausted)
@@ -1370,6 +1492,10 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                     chg = i;
                 }
             }
+        }
+        if (TAB3) {  // the lane best's statistic (its quotient, if it has not been taken yet)
+            if (my_bx != FZ_X_NONE && (my_bxb != 1.0 || my_bxc != 1.0)) my_bev = fz_l3_finish(my_bev, my_bxb, my_bxc);
+            my_bstat = my_bev;
         }
         if (my_bx == FZ_X_LAZY)  // resolve the lazily kept lane best: its x-key
             my_bx = fz_xkey_slow(my_bstat, zscale);
@@ -1447,6 +1573,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     }
 #undef ACCV
 #undef CORV
+#undef CORT
     if (tid == 0) {
         FwSegOut o;
         o.stop_rank = NONE;

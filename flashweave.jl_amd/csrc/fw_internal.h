@@ -288,6 +288,7 @@ int fwi_pool_round(fw_ctx *ctx, FwPool &pool, std::vector<FwPoolJob> &finished);
 int fwi_bh_csr_device(fw_ctx *ctx, const FwL0Dev &in, int64_t m_reliable);
 // device-resident all-gather of the ranks' significant level-0 pairs (fw_xchg.hip)
 int fwi_l0_exchange_dev(fw_ctx *c, const fw_dev_exchange *x, int world, const FwL0Dev &local, int64_t m_local, FwL0Dev *merged, int64_t *m_sum);
+int fwi_selftest_div(fw_ctx *ctx, unsigned long long cases, unsigned long long seed, unsigned long long *mismatches);  // fw_fz.hip
 int fwi_nb_host_ensure(fw_ctx *ctx);  // download partners / statistics / adjusted p if only the device holds them
 
 // ---- device-resident HITON rounds (fw_devhiton.hip, FW_FZ) ----

@@ -43,7 +43,7 @@ class _Counters(C.Structure):
                 ("subsets_calls", C.c_int64), ("kernel_launches", C.c_int64), ("subsets_launches", C.c_int64), ("t_level0_s", C.c_double), ("t_level0_host_s", C.c_double),
                 ("t_cond_s", C.c_double), ("t_dev_subsets_s", C.c_double), ("t_host_advance_s", C.c_double),
                 ("t_host_build_s", C.c_double), ("t_host_launch_s", C.c_double), ("t_host_wait_s", C.c_double), ("t_host_merge_s", C.c_double),
-                ("alg_bytes_subsets", C.c_double)]
+                ("alg_bytes_subsets", C.c_double), ("gram_jobs", C.c_int64), ("gram_alg_bytes", C.c_double), ("gram_alg_flops", C.c_double)]
 
 
 class _LearnOpts(C.Structure):
@@ -69,7 +69,9 @@ _LIB = None
 
 
 def lib_path():
-    return os.path.join(_HERE, "libflashweave_amd.so")
+    # profiling builds of the same sources (e.g. -DFW_MI_TICKS, profiles/tools): honoured only under FW_KNOBS=1, like every FW_* knob
+    alt = os.environ.get("FW_LIB_PATH") if os.environ.get("FW_KNOBS") == "1" else None
+    return alt if alt else os.path.join(_HERE, "libflashweave_amd.so")
 
 
 def load_library():
@@ -119,6 +121,8 @@ def load_library():
     L.fw_network_get_directed.argtypes = [vp, vp, vp, vp, vp]
     L.fw_get_counters.argtypes = [vp, C.POINTER(_Counters)]
     L.fw_reset_counters.argtypes = [vp]
+    if hasattr(L, "fw_selftest"):  # (absent from older builds loaded through FW_LIB_PATH for A/B profiling)
+        L.fw_selftest.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
     L.fw_effective_n_obs_min.restype = C.c_int64
     L.fw_effective_n_obs_min.argtypes = [vp]
     _LIB = L
@@ -330,6 +334,12 @@ class Engine:
 
     def test_subsets(self, T, cand, accepted):
         return self.test_subsets_batch([T], [cand], [list(accepted)])[0]
+
+    def selftest(self, which=1, cases=1 << 28, seed=1):
+        """fw_selftest: device-side bit comparison of a hand-written arithmetic sequence with the compiler's (1 = Float64 division)."""
+        bad = C.c_uint64(0)
+        self._ck(self.L.fw_selftest(self.h, which, cases, seed, C.byref(bad)))
+        return int(bad.value)
 
     # -- LGL -----------------------------------------------------------------------------------------
     def lgl(self, feed_forward=True, round_size=1, rank=0, world_size=1, max_targets=0, allgather=None, edge_dict=True, dev_exchange=None):

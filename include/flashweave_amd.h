@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 4 /* 2: fw_params.recursive_pcor, fw_level0_sharded; 3: device-resident exchange (fw_dev_exchange), sharded cor; 4: fw_params.no_cor_mat */
+#define FW_ABI_VERSION 5 /* 2: fw_params.recursive_pcor, fw_level0_sharded; 3: device-resident exchange (fw_dev_exchange), sharded cor; 4: fw_params.no_cor_mat; 5: fw_selftest, fw_counters.gram_* */
 
 /* test kinds: src/types.jl:61-72 (test_name "mi" / "mi_nz" / "fz") */
 #define FW_MI 0
@@ -123,6 +123,13 @@ typedef struct fw_counters {
     double t_host_merge_s;       /* host: in-order merge of segment outputs */
     double alg_bytes_subsets;    /* algorithmic bytes of the evaluated conditional tests:
                                     fz: 4*C(k+2,2)+32 per test of order k; discrete: (k+2)*n*b/8+32, b = 1 (mi) / 2 (mi_nz) */
+    /* ABI 5 -- recursive_pcor = 0 with job-local correlation matrices (the default form of that variant): its own algorithmic unit.
+     * A (T, candidate | subsets of a accepted variables) job computes ONE (a+2) x (a+2) matrix from its columns and every test
+     * conditions a sub-matrix of it, so what must cross HBM is the job's columns once, and the contraction is 2 n C(a+2, 2) flops;
+     * alg_bytes_subsets (columns per TEST) stays the unit of the streamed form (FW_FZS_GRAM=0, explicit test batches). */
+    int64_t gram_jobs;           /* job matrices computed */
+    double gram_alg_bytes;       /* sum over them of (a + 2) * n * 4 */
+    double gram_alg_flops;       /* sum over them of 2 * n * C(a + 2, 2) */
 } fw_counters;
 
 /* ---- lifecycle -------------------------------------------------------------------------------- */
@@ -273,6 +280,12 @@ int fw_network_get_directed(const fw_ctx *ctx, int64_t *off, int32_t *idx, doubl
  * (one-hot, discretisation: preprocess.py) and appended. */
 int fw_normalize_counts(int32_t device, int32_t kind, int32_t n, int32_t p, const int32_t *counts, float *out_f32, int32_t *out_i32,
                         uint8_t *row_mask, uint8_t *col_mask, int32_t *n_out, int32_t *p_out);
+
+/* Device self-test of hand-written arithmetic sequences that replace a compiler-generated IEEE sequence and must return the
+ * same bits.  which = FW_SELFTEST_DIV: the unscaled Float64 division of the NaN-free partial-correlation path (statfuns.jl:44-62
+ * `/`) against the compiler's division on `cases` hashed operand pairs of that path's ranges; *mismatches = pairs that differ. */
+#define FW_SELFTEST_DIV 1
+int fw_selftest(fw_ctx *ctx, int which, uint64_t cases, uint64_t seed, uint64_t *mismatches);
 
 int fw_get_counters(const fw_ctx *ctx, fw_counters *out);
 int fw_reset_counters(fw_ctx *ctx);

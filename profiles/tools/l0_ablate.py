@@ -24,5 +24,5 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             pass
     print(os.environ.get("FW_L0_DBG", "0"), (time.perf_counter() - t0) / 3)
 else:
-    for d in ("0", "1", "2", "4", "3", "5", "7"):
+    for d in (os.environ.get("L0_ABLATE_SET", "0 1 2 4 3 5 7").split()):
         subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, FW_L0_DBG=d))

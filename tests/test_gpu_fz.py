@@ -262,6 +262,16 @@ def test_full_size_properties():
     eng.close()
 
 
+def test_unscaled_division_equals_the_compilers_division():
+    # fz_div_nn (fw_fz_core.h): the IEEE division sequence without v_div_scale / v_div_fmas for the operand ranges of the NaN-free
+    # partial-correlation path (numerators: round5 values, denominators: products of roots of 1 - v^2).  v_rcp_f64 is a hardware
+    # approximation, so the comparison runs on the device: 2^31 hashed operand pairs against the compiler's `n / d`, bit for bit.
+    eng = fw.Engine("fz", 64, 8, max_k=3)
+    for seed in (1, 2):
+        assert eng.selftest(which=1, cases=1 << 30, seed=seed) == 0
+    eng.close()
+
+
 def test_learn_network_api_reproduces_all_golden_networks(tmp_path):
     # the reference's entry point on the bundled table (BASELINE config 1): all four modes x max_k in {0, 3}
     from flashweave_jl_amd import io as fio
