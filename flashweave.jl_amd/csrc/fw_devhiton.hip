@@ -59,6 +59,7 @@ struct DhGlobal {
                                     // the coming launch holds a segment with |accepted| > FW_TAB_A (set by dh_fill_kernel): the
                                     // in-lane variant of the fz segment kernel leaves at once when it does not
     unsigned int ns_ring[64];  // segments of the last 64 planned launches (the host reads the record once per batch)
+    unsigned int step_ticket, pad_t;  // fused round: workgroups of dh_round_kernel that have finished their targets
 };
 
 // accepted-list buffer b of a target: (spec_depth + 1) buffers of 2 * cap entries each
@@ -1622,10 +1623,10 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
 // L_{j+1} = (L_j + [c_j]) \ {c_{j+1}} (hiton.jl:134-149: a kept member re-enters the pool at its end), each in its own
 // accepted-list buffer.  The step kernel commits them in order; the first dropped member ends the chain (the later
 // look-ahead jobs saw a pool that still held it: their results are discarded and they run again).
-__global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, int ntg, DhGlobal *__restrict__ g, DhArrays A,
-                                                      const FwSegOut *__restrict__ so, const long long *__restrict__ seg0,
-                                                      unsigned long long *__restrict__ win, unsigned int *__restrict__ sp,
-                                                      unsigned long long *__restrict__ win2, const int32_t *__restrict__ act, DhParams P)
+__device__ __forceinline__ void dh_step_dev(DhTgt *__restrict__ tg, int ntg, DhGlobal *__restrict__ g, const DhArrays &A,
+                                            const FwSegOut *__restrict__ so, const long long *__restrict__ seg0,
+                                            unsigned long long *__restrict__ win, unsigned int *__restrict__ sp,
+                                            unsigned long long *__restrict__ win2, const int32_t *__restrict__ act, const DhParams &P)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ci = blockIdx.x * 4 + wave;  // position in the list of unfinished targets (seg0 is indexed by it)
@@ -1872,23 +1873,40 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
     }
 }
 
+__global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, int ntg, DhGlobal *__restrict__ g, DhArrays A,
+                                                      const FwSegOut *__restrict__ so, const long long *__restrict__ seg0,
+                                                      unsigned long long *__restrict__ win, unsigned int *__restrict__ sp,
+                                                      unsigned long long *__restrict__ win2, const int32_t *__restrict__ act, DhParams P)
+{
+    dh_step_dev(tg, ntg, g, A, so, seg0, win, sp, win2, act, P);
+}
+
 // one workgroup: totals of the coming launch, its segment length, per-target segment counts and their exclusive scan.
 // The segment length has no upper cap here, so the launch never holds more than seg_target + (live jobs) segments:
 // the fixed grid (seg_target + targets) always covers it.
 #define DH_PER 16  // targets per planning thread held in registers (more targets: extra passes over global memory)
-__global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__restrict__ g, const unsigned long long *__restrict__ win,
-                                                       const unsigned int *__restrict__ sp, const unsigned long long *__restrict__ win2,
-                                                       const int32_t *__restrict__ act_all,
-                                                       long long *__restrict__ seg0, unsigned int seg_target, unsigned int seg_q,
-                                                       unsigned int seg_min, ulonglong2 *__restrict__ log, unsigned int log_cap,
-                                                       unsigned long long seg_a, unsigned long long seg_b)
+struct DhPlanArgs {
+    unsigned int seg_target, seg_q, seg_min, log_cap;
+    ulonglong2 *log;
+    unsigned long long seg_a, seg_b;
+};
+// NT = threads of the one workgroup that plans: 1024 as a kernel of its own (dh_plan_kernel), 256 as the tail of the fused round
+// (the last workgroup of dh_step_kernel)
+template <int NT>
+__device__ __forceinline__ void dh_plan_dev(int ntg, DhGlobal *__restrict__ g, const unsigned long long *__restrict__ win,
+                                            const unsigned int *__restrict__ sp, const unsigned long long *__restrict__ win2,
+                                            const int32_t *__restrict__ act_all, long long *__restrict__ seg0, const DhPlanArgs PA)
 {
+    constexpr int NW = NT / 64;
+    const unsigned int seg_target = PA.seg_target, seg_q = PA.seg_q, seg_min = PA.seg_min, log_cap = PA.log_cap;
+    ulonglong2 *__restrict__ log = PA.log;
+    const unsigned long long seg_a = PA.seg_a, seg_b = PA.seg_b;
     __shared__ unsigned long long s_tot[16];
     __shared__ unsigned int s_live[16], s_wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int na = (int)g->n_act;  // unfinished targets; everything below is indexed by the position in that list
     const int32_t *act = act_all + (size_t)g->act_sel * ntg;
-    const int per = (na + 1023) / 1024;
+    const int per = (na + NT - 1) / NT;
     const int b = tid * per, e = (b + per) < na ? (b + per) : na;
     unsigned long long tot = 0ull;
     unsigned int live = 0u;
@@ -1926,7 +1944,7 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
     unsigned long long total = 0ull;
     unsigned int n_live = 0u;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) {
+    for (int w = 0; w < NW; ++w) {
         total += s_tot[w];
         n_live += s_live[w];
     }
@@ -1955,7 +1973,7 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
     __syncthreads();
     unsigned int wbase = 0u, ns = 0u;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) {
+    for (int w = 0; w < NW; ++w) {
         if (w < wave) wbase += s_wsum[w];
         ns += s_wsum[w];
     }
@@ -1985,12 +2003,18 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
     }
 }
 
-__global__ __launch_bounds__(256) void dh_fill_kernel(const DhTgt *__restrict__ tg, int ntg, DhGlobal *__restrict__ g,
-                                                      const long long *__restrict__ seg0, const DhArrays A,
-                                                      FwSeg *__restrict__ segs, int d1, const int32_t *__restrict__ act)
+__global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__restrict__ g, const unsigned long long *__restrict__ win,
+                                                       const unsigned int *__restrict__ sp, const unsigned long long *__restrict__ win2,
+                                                       const int32_t *__restrict__ act_all, long long *__restrict__ seg0, DhPlanArgs PA)
 {
-    const unsigned int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= g->ns) return;
+    dh_plan_dev<1024>(ntg, g, win, sp, win2, act_all, seg0, PA);
+}
+
+// segment record s of the coming launch (one thread)
+__device__ __forceinline__ void dh_fill_one(const unsigned int s, const DhTgt *__restrict__ tg, int ntg, DhGlobal *__restrict__ g,
+                                            const long long *__restrict__ seg0, const DhArrays &A, FwSeg *__restrict__ segs, int d1,
+                                            const int32_t *__restrict__ act)
+{
     int lo = 0, hi = (int)g->n_act;  // first list position with seg0 > s; the job owning slot s is the one before it
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
@@ -2026,6 +2050,45 @@ __global__ __launch_bounds__(256) void dh_fill_kernel(const DhTgt *__restrict__ 
     const unsigned long long hi_r = lo_r + (slot > 0u ? x.jwin2 : x.jwin);
     sg.end = sg.start + seglen < hi_r ? sg.start + seglen : hi_r;
     segs[s] = sg;
+}
+__global__ __launch_bounds__(256) void dh_fill_kernel(const DhTgt *__restrict__ tg, int ntg, DhGlobal *__restrict__ g,
+                                                      const long long *__restrict__ seg0, const DhArrays A,
+                                                      FwSeg *__restrict__ segs, int d1, const int32_t *__restrict__ act)
+{
+    const unsigned int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= g->ns) return;
+    dh_fill_one(s, tg, ntg, g, seg0, A, segs, d1, act);
+}
+
+// The fused round (r04): step for every target, then the LAST workgroup to finish plans the coming launch and fills its segment
+// records -- one launch between two segment kernels instead of three.  r03's one-chain trace of cfg3: 21.5 + 7.5 + 5.6 us of
+// step / plan / fill and ~22 us of launch gaps per round, 1 100 dependent rounds per chain; the plan is one workgroup and the
+// fill a few thousand records, so the workgroup that takes the last ticket (one atomic per workgroup: a few hundred per round,
+// not the thousands of r01) does both in place of two more launches and their gaps.  Ordering: every workgroup makes its
+// stores (target states, windows, accepted lists) visible device-wide before it takes its ticket (release fence: the L2 of an
+// XCD is written back), the last one acquires after it (its L2 is invalidated -- as a kernel boundary would do anyway).
+// Rounds that compact the list of unfinished targets (one in sixteen) keep the three launches.
+__global__ __launch_bounds__(256) void dh_round_kernel(DhTgt *__restrict__ tg, int ntg, DhGlobal *__restrict__ g, DhArrays A,
+                                                       const FwSegOut *__restrict__ so, long long *__restrict__ seg0,
+                                                       unsigned long long *__restrict__ win, unsigned int *__restrict__ sp,
+                                                       unsigned long long *__restrict__ win2, const int32_t *__restrict__ act, DhParams P,
+                                                       DhPlanArgs PA, FwSeg *__restrict__ segs, int d1, int fill_here)
+{
+    __shared__ int s_last;
+    dh_step_dev(tg, ntg, g, A, so, seg0, win, sp, win2, act, P);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&g->step_ticket, 1u) == gridDim.x - 1u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x == 0) g->step_ticket = 0u;
+    dh_plan_dev<256>(ntg, g, win, sp, win2, act, seg0, PA);
+    if (!fill_here) return;  // (FW_DH_FUSE=1: the fill keeps its own launch -- a few thousand records are one pass of a grid)
+    __threadfence();
+    __syncthreads();
+    const unsigned int ns = g->ns;
+    for (unsigned int s = threadIdx.x; s < ns; s += 256u) dh_fill_one(s, tg, ntg, g, seg0, A, segs, d1, act);
 }
 
 // One workgroup, once per batch of rounds (between dh_step_kernel and dh_plan_kernel): drops the finished targets from
@@ -2341,14 +2404,37 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     if (!evh.ok) return fw_fail(c, FW_ERR_DEVICE, "device HITON: hipEventCreate failed");
     auto &ev = evh.ev;
     auto &ev_end = evh.ev_end;
+    DhPlanArgs PA{};
+    PA.seg_target = seg_target;
+    PA.seg_q = P.seg_q;
+    PA.seg_min = P.seg_min;
+    PA.log_cap = LOG_CAP;
+    PA.log = d_log;
+    PA.seg_a = seg_a;
+    PA.seg_b = seg_b;
+    // FW_DH_FUSE: 0 (default) = step, plan and fill as three launches, 1 = the last workgroup of the step kernel plans, 2 = ... and
+    // fills (dh_round_kernel); rounds that compact the list keep the three launches.  Built and measured in r04, NOT kept as the
+    // default: cfg3 headline 189.9 / 188.4 / 203.0 ms and one-chain pass 237.4 / 245.5 / 270.7 ms with 0 / 1 / 2
+    // (profiles/r04_fused_round.json) -- one 256-thread workgroup behind two device-wide fences plans slower than a 1 024-thread
+    // launch (+7 us per round against the ~5 us gap it saves), and filling a few thousand records from ONE workgroup costs ~25 us
+    // where a grid does it in 6.  What would pay is a round without any single-workgroup phase.
+    static const int fuse_env = [] { const char *e = fw_knob("FW_DH_FUSE"); return e ? atoi(e) : 0; }();
+    const int fuse = c->P.kind == FW_FZ ? fuse_env : 0;
     auto planfill = [&](bool compact) {
+        if (fuse > 0 && !compact) {
+            hipLaunchKernelGGL(dh_round_kernel, dim3((n_act_bound + 3u) / 4u), dim3(256), 0, st, d_tg, ntg, d_g, A, (const FwSegOut *)d_so, d_seg0,
+                               d_win, d_sp, d_win2, (const int32_t *)d_act, P, PA, d_segs, d1, fuse >= 2 ? 1 : 0);
+            if (fuse < 2)
+                hipLaunchKernelGGL(dh_fill_kernel, dim3(g_fill), dim3(256), 0, st, (const DhTgt *)d_tg, ntg, d_g, (const long long *)d_seg0, A,
+                                   d_segs, d1, (const int32_t *)d_act);
+            return;
+        }
         hipLaunchKernelGGL(dh_step_kernel, dim3((n_act_bound + 3u) / 4u), dim3(256), 0, st, d_tg, ntg, d_g, A,
                            (const FwSegOut *)d_so, (const long long *)d_seg0, d_win, d_sp, d_win2, (const int32_t *)d_act, P);
         if (compact)  // between step and plan: seg0 of the coming launch is built on the new list
             hipLaunchKernelGGL(dh_compact_kernel, dim3(1), dim3(1024), 0, st, (const DhTgt *)d_tg, ntg, d_g, d_act);
         hipLaunchKernelGGL(dh_plan_kernel, dim3(1), dim3(1024), 0, st, ntg, d_g, (const unsigned long long *)d_win,
-                           (const unsigned int *)d_sp, (const unsigned long long *)d_win2, (const int32_t *)d_act, d_seg0, seg_target, P.seg_q, P.seg_min, d_log,
-                           LOG_CAP, seg_a, seg_b);
+                           (const unsigned int *)d_sp, (const unsigned long long *)d_win2, (const int32_t *)d_act, d_seg0, PA);
         hipLaunchKernelGGL(dh_fill_kernel, dim3(g_fill), dim3(256), 0, st, (const DhTgt *)d_tg, ntg, d_g,
                            (const long long *)d_seg0, A, d_segs, d1, (const int32_t *)d_act);
     };

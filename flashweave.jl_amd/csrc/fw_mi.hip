@@ -496,20 +496,45 @@ __global__ __launch_bounds__(256) void mi_level0_kernel(MiDev P, int p, int T, c
     for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int v = 0; v < 4; ++v) A[u][v] = B[u][v] = C[u][v] = D[u][v] = 0;
-    for (int w0 = 0; w0 < P.W; w0 += L0_WC) {
-        __syncthreads();
-        for (int e = tid; e < L0_T * L0_WC; e += 256) {
+    // Staging is software-pipelined (r04): the words of chunk c + 1 are requested into registers (two elements per thread and
+    // plane: 16 VGPRs) BEFORE the popcount loop of chunk c runs and written to LDS after it, so the L2 round trip of a chunk
+    // hides behind ~2 000 VALU instructions instead of standing between two barriers.  (r03 ablation: staging alone 12.6 ms,
+    // popcount loop ~35 ms, and the kernel took their SUM -- three workgroups per CU did not overlap them.)
+    constexpr int L0_EPT = L0_T * L0_WC / 256;  // elements per thread and array
+    unsigned long long rXn[L0_EPT], rYn[L0_EPT], rXh[L0_EPT], rYh[L0_EPT];
+    auto l0_fetch = [&](int w0) {
+#pragma unroll
+        for (int q = 0; q < L0_EPT; ++q) {
+            const int e = tid + 256 * q;
             const int col = e / L0_WC, w = e % L0_WC;
             const int gx = bi * L0_T + col, gy = bj * L0_T + col;
             const bool wv = w0 + w < P.W && !(dbg & 2);
-            sXn[w][col] = (gx < p && wv) ? P.nz[(size_t)gx * P.W + w0 + w] : 0ull;
-            sYn[w][col] = (gy < p && wv) ? P.nz[(size_t)gy * P.W + w0 + w] : 0ull;
+            rXn[q] = (gx < p && wv) ? P.nz[(size_t)gx * P.W + w0 + w] : 0ull;
+            rYn[q] = (gy < p && wv) ? P.nz[(size_t)gy * P.W + w0 + w] : 0ull;
             if (HAS_HI) {
-                sXh[w][col] = (gx < p && wv) ? P.hi[(size_t)gx * P.W + w0 + w] : 0ull;
-                sYh[w][col] = (gy < p && wv) ? P.hi[(size_t)gy * P.W + w0 + w] : 0ull;
+                rXh[q] = (gx < p && wv) ? P.hi[(size_t)gx * P.W + w0 + w] : 0ull;
+                rYh[q] = (gy < p && wv) ? P.hi[(size_t)gy * P.W + w0 + w] : 0ull;
+            } else {
+                rXh[q] = rYh[q] = 0ull;
+            }
+        }
+    };
+    l0_fetch(0);
+    for (int w0 = 0; w0 < P.W; w0 += L0_WC) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < L0_EPT; ++q) {
+            const int e = tid + 256 * q;
+            const int col = e / L0_WC, w = e % L0_WC;
+            sXn[w][col] = rXn[q];
+            sYn[w][col] = rYn[q];
+            if (HAS_HI) {
+                sXh[w][col] = rXh[q];
+                sYh[w][col] = rYh[q];
             }
         }
         __syncthreads();
+        if (w0 + L0_WC < P.W) l0_fetch(w0 + L0_WC);  // in flight while this chunk is counted
 #pragma unroll 1  // unrolling this loop made the compiler hoist all 8 x 16 LDS reads: 256 VGPRs + scratch (r01 ISA)
         for (int w = 0; w < ((dbg & 4) ? 0 : L0_WC); ++w) {
             unsigned long long xn[4], yn[4], xh[4], yh[4];
