@@ -96,6 +96,10 @@ def parse_args(argv=None):
                          "significant pairs all-gathered in device memory (fw_level0_sharded_dev)")
     ap.add_argument("--host-exchange", action="store_true",
                     help="N > 1: per-round exchange through the host callback (numpy packing, r02 form) instead of fw_learn_network_dev")
+    ap.add_argument("--library-rccl", action="store_true",
+                    help="N > 1 (or --force-dist): the exchanges are issued by the LIBRARY on its own RCCL communicator (fw_comm_init, "
+                         "fw_level0_comm, fw_cor_mat_allgather_comm, fw_learn_network_comm); torch.distributed only carries the 128-byte "
+                         "rendezvous id.  Default: torch.distributed collectives on device buffers the library packs (fw_dev_exchange)")
     ap.add_argument("--shard-cor", action="store_true",
                     help="N > 1, fz: row-block sharding of the Pearson GEMM with an in-place all-gather (default from p = 30 000 on)")
     ap.add_argument("--max-targets", type=int, default=0,
@@ -387,7 +391,37 @@ def main():
                 eng.level0_dev(r, NW, (l0_prepare, l0_exchange))
             l0sim["mode"] = "replay"
 
+    lib_comm = bool(use_dist and args.library_rccl)
+    if lib_comm:
+        if dist.get_backend() != "nccl":
+            raise SystemExit("bench.py --library-rccl needs the nccl (RCCL) backend: one rank per GPU")
+        box = [fw.Engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        eng.comm_init(box[0], rank, world)
+
+    def step_lib(ff, R):
+        # every exchange inside the library (fw_rccl.cpp)
+        if cfg["test_name"] == "fz" and not args.no_cor_matrix:
+            if shard_cor:
+                T_ = (p + 127) // 128
+                rpr = 128 * ((T_ + world - 1) // world)
+                if sim.get("corbuf") is None or sim["corbuf"].numel() < world * rpr * p:
+                    sim["corbuf"] = torch.empty(world * rpr * p, dtype=torch.float32, device=dev)
+                eng.use_cor_buffer(sim["corbuf"].data_ptr(), sim["corbuf"].numel())
+                eng.compute_cor_rows(rank, world)
+                eng.cor_allgather_comm(rpr)
+                eng.cor_ready()
+            else:
+                eng.compute_cor()
+        if shard_l0:
+            eng.level0_comm()
+        else:
+            eng.level0()
+        return eng.lgl_comm(feed_forward=bool(ff), round_size=R, max_targets=args.max_targets, edge_dict=False)
+
     def step(ff, R):
+        if lib_comm:
+            return step_lib(ff, R)
         if cfg["test_name"] == "fz" and not args.no_cor_matrix:
             if use_dist and shard_cor:
                 from flashweave_jl_amd.dist import sharded_cor
@@ -419,6 +453,7 @@ def main():
             step(ff, R)
         eng.reset_counters()
         xstats.clear()
+        cs0 = eng.comm_stats() if lib_comm else None
         barrier()
         t0 = time.perf_counter()
         net = None
@@ -426,6 +461,10 @@ def main():
             net = step(ff, R)
         barrier()
         dt = time.perf_counter() - t0
+        if lib_comm:  # the library's own exchange counters (fw_comm_stats), same keys as the Python callbacks keep
+            cs1 = eng.comm_stats()
+            xstats.update({k: cs1[k] - cs0[k] for k in ("calls", "collectives", "entries", "seconds")})
+            xstats["issued_by"] = "library (fw_rccl.cpp: ncclAllGather on the engine's stream)"
         cn = eng.counters()
         cond_ref, cond_eval = cn["cond_tests_ref"], cn["cond_tests_evaluated"]
         if use_dist:
@@ -443,7 +482,8 @@ def main():
                 "exchange": {"calls_per_step": xstats.get("calls", 0) / s, "collectives_per_step": xstats.get("collectives", 0) / s,
                              "entries_per_step": xstats.get("entries", 0) / s,
                              "seconds_per_step_rank0": xstats.get("seconds", 0.0) / s,
-                             "us_per_round_rank0": 1e6 * xstats.get("seconds", 0.0) / max(xstats.get("calls", 0), 1)}
+                             "us_per_round_rank0": 1e6 * xstats.get("seconds", 0.0) / max(xstats.get("calls", 0), 1),
+                             "issued_by": xstats.get("issued_by", "host language (torch.distributed on buffers the library packs)")}
                 if use_dist else None}
 
     auto_R = DEFAULT_ROUND * ((p + 10 * DEFAULT_ROUND - 1) // (10 * DEFAULT_ROUND))

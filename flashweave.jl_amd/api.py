@@ -82,8 +82,6 @@ def learn_network(data, sensitive=True, heterogeneous=False, max_k=3, alpha=0.01
                          "`data` yourself (preprocess.normalize_with_meta) or pass normalize=True")
     t_norm0 = time.perf_counter()
     on_device = bool(normalize and device_normalize and prec == 32 and _integral(data))
-    if on_device and test_name == "mi_nz" and data.shape[0] > 16384:
-        on_device = False  # binned_nz_clr sorts a column's non-zeros in LDS (fw_norm.hip: at most 16 384 samples): host front-end
     dev_norm = (lambda c, t: normalize_counts(c, t, device=device)) if on_device else None
     if normalize and meta_data is not None:
         r = pre.normalize_with_meta(data, test_name, meta_data, prec=prec, header=header, meta_header=meta_header,

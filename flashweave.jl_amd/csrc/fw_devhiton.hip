@@ -97,6 +97,7 @@ struct DhParams {
     unsigned int mi_team;      // the first mi_team targets of the (heaviest-first) list are run by a whole workgroup each (dh_mi_team)
     unsigned int mi_team_tail;   // team targets publish tail-mode boards (short records, wide first window) from the start
     unsigned int mi_team_steps;  // lock-step rounds of a team job (4 wavefronts x 1 or 4 ranks each) before its enumeration goes to a board
+    unsigned int mi_trace;       // take the per-job / per-target clock reads (FW_TRACE_HOST, FW_MI_TICKS builds)
     int spec0_depth;                // interleaving-phase look-ahead (first windows of the next candidates)
     unsigned long long spec0_below;
     unsigned int spec0_jobs;  // ... and fewer live jobs than this
@@ -422,7 +423,7 @@ __device__ __forceinline__ bool dh_commit(DhTgt &x, const DhArrays &A, int lane,
 #define MI_REC_CAP (1u << 20)
 
 // one LDS table [stratum][cell] per wavefront (fw_mi_core.h); module scope so that the called test routine addresses it as LDS
-__shared__ unsigned short dh_mi_tab[4][MI_TAB16];
+__shared__ unsigned short dh_mi_tab[4][2 * MI_TAB16];  // (twice the 16-bit table: the 32-bit form of more than 65 535 samples)
 
 __shared__ int32_t dh_mi_acc[4][1024];  // a helper's copy of the accepted list of the board it works on (MI_ACC_LDS)
 __shared__ DhTgt dh_mi_x[4];            // the state of the target each wavefront of dh_mi_target_kernel is working on
@@ -462,7 +463,7 @@ struct MiBoard {
     double seed_p, seed_g;        // the job's maximum-p test so far (seed_p < 0: none): records skip the Q(a, x) of tests it dominates
 };
 
-struct MiQueue {
+struct alignas(16) MiQueue {
     unsigned int next_target, targets_done, n_boards, hint, res_top, bacc_top, pad[1], next_team;  // pad[0]: watchdog code
     unsigned long long t_body, t_ctl, t_sleep, n_seg;  // dh_mi_target_kernel: 100 MHz ticks summed over wavefronts (FW_TRACE_HOST; see the end of the kernel)
     unsigned long long t_total;  // dh_mi_target_kernel: ticks until the wavefront ran out of targets (the fields above: see its end)
@@ -478,6 +479,15 @@ __device__ __forceinline__ unsigned long long mi_ld_u64(const unsigned long long
 __device__ __forceinline__ void mi_st_u64(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void mi_st_u32(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void mi_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// the four hot words of MiQueue (next_target, targets_done, n_boards, hint: its first 16 bytes) in ONE sc1 round trip -- the owner
+// of a target looks at them before every fourth job, and four dependent relaxed loads were four round trips of ~2 us
+typedef unsigned int mi_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mi_u32x4 mi_ld_u128(const void *p)
+{
+    mi_u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
 #ifndef MI_NAP_WAIT
 #define MI_NAP_WAIT 2  // x 128 cycles between two looks at a board the wavefront waits for
 #endif
@@ -512,7 +522,7 @@ __device__ __forceinline__ unsigned long long mi_rfl_lane64(unsigned long long v
 // ranks [r0, r1) of the job (T, cand | subsets of acc[0..a)) in enumeration order, one test after the other (whole wavefront).
 // Called, not inlined: the kernel reaches it from four places (own jobs, own board, other boards while waiting / between
 // jobs / at the end) and four copies of the test made 168 KB of code -- against a 64 KB instruction cache.
-template <int L, int NXY, bool PRE>
+template <int L, int NXY, int PRE>
 __device__ __noinline__ void mi_run_ranks(int T, int cand, const int32_t *__restrict__ acc_in, int a, int max_k,
                                           long long max_tests, unsigned long long r0, unsigned long long r1,
                                           const unsigned long long *stop_min_in, int remote_acc, const MiBest *seed_in)
@@ -586,7 +596,7 @@ __device__ __noinline__ void mi_run_ranks(int T, int cand, const int32_t *__rest
 #ifdef FW_MI_TICKS
         const unsigned long long tkb = wall_clock64();
 #endif
-        MiRes t = mi_test_core<L, NXY, PRE>(M, T, cand, zs, s, tab);
+        MiRes t = mi_test_core<L, NXY, PRE == 1, PRE == 2>(M, T, cand, zs, s, tab);  // PRE: 0 words loaded per batch, 1 register-resident (n <= 6144), 2 32-bit counts (n > 65 535)
         ++o.evaluated;
 #ifdef FW_MI_TICKS
         const unsigned long long tkc = wall_clock64();
@@ -876,7 +886,7 @@ __device__ __noinline__ void mi_first4(int T, int pos0, const int32_t *__restric
 }
 
 // R4: the four-subsets-per-step form (host: n <= MI4_N, max_k <= 3, 2 x 2 cells); one of the two routines per instantiation
-template <int L, int NXY, bool PRE, bool R4>
+template <int L, int NXY, int PRE, bool R4>
 __device__ __forceinline__ FwSegOut mi_run_ranks_sel(int T, int cand, const int32_t *__restrict__ acc, int a, int max_k,
                                                      long long max_tests, unsigned long long r0, unsigned long long r1,
                                                      const unsigned long long *stop_min, int remote_acc, const MiBest *seed)
@@ -977,7 +987,7 @@ __device__ __forceinline__ DhMerge mi_merge(const FwSegOut *__restrict__ so, lon
 
 // claim and evaluate one record of board b (if any is left); true if a record was processed.  acc_own: the caller published the board (its accepted list is at hand); otherwise the list is
 // staged from the board's write-through copy.
-template <int L, int NXY, bool PRE, bool R4>
+template <int L, int NXY, int PRE, bool R4>
 __device__ __forceinline__ bool mi_board_work(MiBoard *__restrict__ b, FwSegOut *__restrict__ res, const int32_t *__restrict__ bacc,
                                               const int32_t *acc_own, int lane)
 {
@@ -1045,7 +1055,7 @@ __device__ __forceinline__ bool mi_board_work(MiBoard *__restrict__ b, FwSegOut 
 // look for an open board (from the first one that still has unclaimed records) and work on one record of it; true if
 // something was done.  (A global FIFO of records with a compare-and-swap head was tried instead of the scan: 10x slower --
 // a thousand wavefronts polling and swapping the same two words.)
-template <int L, int NXY, bool PRE, bool R4>
+template <int L, int NXY, int PRE, bool R4>
 __device__ __noinline__ bool mi_help(MiQueue *__restrict__ Q, MiBoard *__restrict__ boards, FwSegOut *__restrict__ res,
                                      const int32_t *__restrict__ bacc, int lane)
 {
@@ -1124,7 +1134,10 @@ __device__ __forceinline__ bool mi_publish(MiQueue *__restrict__ Q, MiBoard *__r
 
 // the whole HITON-PC of target t on the four wavefronts of this workgroup (every wavefront calls it; uniform control flow
 // between the barriers: every decision is taken from LDS values all four read)
-template <int L, int NXY, bool PRE, bool R4>
+// the persistent kernel's own clock reads (per job: phase times for FW_TRACE_HOST): a wall_clock64() is a scalar memory round trip,
+// four of them per job were ~5 % of a light job -- taken only when the host asks for the trace (DhParams::mi_trace)
+#define MI_CLK() (P.mi_trace ? wall_clock64() : 0ull)
+template <int L, int NXY, int PRE, bool R4>
 __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, MiQueue *__restrict__ Q,
                                         MiBoard *__restrict__ boards, FwSegOut *__restrict__ res, int32_t *__restrict__ bacc)
 {
@@ -1135,7 +1148,7 @@ __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, 
     MiTeamJob &J = dh_mi_tj;
     if (wave == 0 && lane == 0) {
         x = tg[t];
-        x.r_first0 = (unsigned int)wall_clock64();
+        x.r_first0 = (unsigned int)MI_CLK();
     }
     __syncthreads();
     const unsigned long long per = R4 ? 4ull : 1ull;  // ranks per wavefront and lock-step round
@@ -1166,7 +1179,7 @@ __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, 
         const int cand = J.cand, a = J.a, T = x.T;
         const int32_t *acc = a <= MI_ACC_LDS ? (const int32_t *)dh_mi_acc[0] : A.acc + J.acc_off;
         const unsigned long long N = J.N;
-        const unsigned long long tk1 = wall_clock64();
+        const unsigned long long tk1 = MI_CLK();
         // lock-step rounds: wavefront w takes ranks next + w * per ...
         unsigned long long next = 0ull, ev = 0ull, nt = 0ull;
         bool stopped = false;
@@ -1179,7 +1192,7 @@ __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, 
             unsigned long long r1 = r0 + per;
             if (r1 > N) r1 = N;
             FwSegOut o;
-            const unsigned long long tq0 = wall_clock64();
+            const unsigned long long tq0 = MI_CLK();
             if (r0 < N) {
                 const MiBest *seed = nullptr;
                 if (best_p > 1e-290) {  // what the earlier rounds found: the tests it dominates skip their Q(a, x)
@@ -1203,12 +1216,12 @@ __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, 
                 o.evaluated = 0ull;
             }
             if (lane == 0) dh_mi_trec[step & 1u][wave] = o;
-            const unsigned long long tq1 = wall_clock64();
+            const unsigned long long tq1 = MI_CLK();
             __syncthreads();  // (two buffers: the records of round s are rewritten in round s + 2, behind the barrier of round s + 1)
 #ifdef FW_MI_TICKS
             if (lane == 0) {
                 atomicAdd(&Q->tm_run, tq1 - tq0);
-                atomicAdd(&Q->tm_wait, wall_clock64() - tq1);
+                atomicAdd(&Q->tm_wait, MI_CLK() - tq1);
                 atomicAdd(&Q->tm_steps, 1ull);
                 atomicAdd(&Q->tm_tests, o.evaluated);
             }
@@ -1237,7 +1250,7 @@ __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, 
             next += 4ull * per;
             if (next > N) next = N;
         }
-        const unsigned long long tk2 = wall_clock64();
+        const unsigned long long tk2 = MI_CLK();
         // ... the rest of a long enumeration: boards (the leader publishes and merges, all four work on the records)
         const bool tail = J.tail != 0;
         unsigned long long width = (unsigned long long)(tail ? P.mi_win0_tail : P.mi_win0);
@@ -1312,7 +1325,7 @@ __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, 
             nt = N;
         }
         if (wave == 0) {
-            const unsigned long long tk3 = wall_clock64();
+            const unsigned long long tk3 = MI_CLK();
             if (lane == 0) {
                 x.r_first1 += (unsigned int)(tk2 - tk1);
                 x.r_more1 += (unsigned int)(tk3 - tk2);
@@ -1329,7 +1342,7 @@ __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, 
         __syncthreads();  // (the next job's descriptor is written behind this)
     }
     if (wave == 0 && lane == 0) {
-        x.r_more0 = (unsigned int)wall_clock64();
+        x.r_more0 = (unsigned int)MI_CLK();
         tg[t] = x;
         atomicAdd(&Q->targets_done, 1u);
     }
@@ -1344,7 +1357,7 @@ __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, 
 #ifndef DH_MI_OCC
 #define DH_MI_OCC 1  // workgroups per CU the register budget is sized for
 #endif
-template <int L, int NXY, bool PRE, bool R4>
+template <int L, int NXY, int PRE, bool R4>
 __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__restrict__ tg, int ntg, const int32_t *__restrict__ order,
                                                            DhArrays A, MiDev M, DhParams P, MiQueue *__restrict__ Q,
                                                            MiBoard *__restrict__ boards, FwSegOut *__restrict__ res,
@@ -1366,7 +1379,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
         dh_mi_ctx.P = P;
     }
     __syncthreads();
-    const unsigned long long tk_begin = wall_clock64();
+    const unsigned long long tk_begin = MI_CLK();
     // the heaviest targets (the first mi_team of the list): a workgroup each, all four wavefronts on it (dh_mi_team), taken in list
     // order by whichever workgroup is free; the list proper starts behind them
     for (;;) {
@@ -1388,17 +1401,17 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
         DhTgt &x = dh_mi_x[threadIdx.x >> 6];
         if (lane == 0) {
             x = tg[t];
-            x.r_first0 = (unsigned int)wall_clock64();  // FW_TRACE_HOST: when the target was taken / finished (100 MHz ticks, low word)
+            x.r_first0 = (unsigned int)MI_CLK();  // FW_TRACE_HOST: when the target was taken / finished (100 MHz ticks, low word)
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         for (;;) {
-            const unsigned long long tka0 = wall_clock64();
+            const unsigned long long tka0 = MI_CLK();
             const bool more_jobs = dh_advance(x, A, lane, 1);
             MI_TICK(6, tka0);
             if (!more_jobs) break;
             // other targets' big enumerations first: they are the critical path of the pass
-            const unsigned long long tk0 = wall_clock64();
+            const unsigned long long tk0 = MI_CLK();
             // ... unless this target is one of the heavy ones: its own chain of jobs IS the critical path (cfg2 / cfg4: the
             // launch ended when the heaviest target did, 13 ms after the average wavefront had run out of targets)
             const bool heavy = P.mi_heavy > 0u && (unsigned int)x.nc >= P.mi_heavy;
@@ -1406,10 +1419,12 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
             // trips of ~2 us, and a chain of jobs that end with their first test (or cost nothing at all: mi_first4) paid more for
             // them than for its tests (cfg2 trace: 18.8 us per job against a 12 us test)
             const bool poll = (jobctr++ & 3u) == 0u;
-            if (P.mi_help_jobs && !heavy && poll)
-                while (mi_ld_u32(&Q->n_boards) > mi_ld_u32(&Q->hint) && mi_help<L, NXY, PRE, R4>(Q, boards, res, bacc, lane)) {
+            mi_u32x4 q4 = {0u, 0u, 0u, 0u};  // {next_target, targets_done, n_boards, hint}
+            if (poll) q4 = mi_ld_u128(Q);
+            if (P.mi_help_jobs && !heavy && poll && q4.z > q4.w)
+                while (mi_help<L, NXY, PRE, R4>(Q, boards, res, bacc, lane) && mi_ld_u32(&Q->n_boards) > mi_ld_u32(&Q->hint)) {
                 }
-            const unsigned long long tk1 = wall_clock64();
+            const unsigned long long tk1 = MI_CLK();
             tk_help += tk1 - tk0;
             const int32_t *cands = x.phase == 0 ? A.cand0 + x.cand_off : A.tpc_key + x.co;
             const int32_t cand = cands[x.pos];
@@ -1425,9 +1440,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
             // tests (one rank of eight, cfg4: 46.9 -> 37.2 ms of conditional stage)
             // (tail: no target left to claim AND fewer than one wavefront in eight still owns one -- cfg2 has as many targets as
             // the launch has wavefronts: "list exhausted" alone switched every job of the pass to the short prefix, 15 -> 22 ms)
-            if (poll)
-                tail_seen = mi_ld_u32(&Q->next_target) + P.mi_team >= (unsigned int)ntg &&
-                            ((unsigned int)ntg - mi_ld_u32(&Q->targets_done)) * 8u <= gridDim.x * 4u;
+            if (poll) tail_seen = q4.x + P.mi_team >= (unsigned int)ntg && ((unsigned int)ntg - q4.y) * 8u <= gridDim.x * 4u;
             const bool tail = tail_seen;
             const unsigned long long seq = tail ? P.mi_seq_tail : (heavy ? P.mi_seq_heavy : P.mi_seq);
             unsigned long long next = elim_full ? 0ull : (N < seq ? N : seq);
@@ -1499,7 +1512,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
             unsigned long long width = elim_full ? N : (unsigned long long)(tail ? P.mi_win0_tail : P.mi_win0);
             const unsigned long long chunk_min = tail ? P.mi_chunk_tail : P.mi_chunk_min;
             unsigned int bacc_off = MI_BACC_CAP;  // this job's write-through copy of its accepted list (made with its first board)
-            const unsigned long long tk2 = wall_clock64();
+            const unsigned long long tk2 = MI_CLK();
             tk_seq += tk2 - tk1;
             if (lane == 0) x.r_first1 += (unsigned int)(tk2 - tk1);  // FW_TRACE_HOST: this target's ticks in sequential prefixes / board phases
             while (!stopped && next < N) {
@@ -1508,7 +1521,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
                 chunk = chunk < chunk_min ? chunk_min : (chunk > P.mi_chunk_max ? P.mi_chunk_max : chunk);
                 const unsigned int nch = (unsigned int)((W + chunk - 1ull) / chunk);
                 unsigned int bi, ro;
-                const unsigned long long tkp0 = wall_clock64();
+                const unsigned long long tkp0 = MI_CLK();
                 const bool published = mi_publish(Q, boards, bacc, bacc_off, A.acc + acc_off, a, x.T, cand, next, W, chunk, nch, lane, bi, ro,
                                                   best_p, best_g, best_df);
                 MI_TICK(9, tkp0);
@@ -1530,7 +1543,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
                     unsigned int spins = 0u;
                     while (mi_ld_u32(&b->done) < nch) {  // records claimed by other wavefronts: they are running
                         if (heavy || !mi_help<L, NXY, PRE, R4>(Q, boards, res, bacc, lane)) {
-                            const unsigned long long tkw0 = wall_clock64();
+                            const unsigned long long tkw0 = MI_CLK();
                             mi_nap_wait();
                             MI_TICK(10, tkw0);
                             if (++spins > (1u << 27)) {  // ~30 s: a logic error, not a workload -- report instead of hanging the GPU
@@ -1539,7 +1552,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
                             }
                         }
                     }
-                    const unsigned long long tkm0 = wall_clock64();
+                    const unsigned long long tkm0 = MI_CLK();
                     mg = mi_merge(res, (long long)ro, (int)nch, lane);
                     MI_TICK(11, tkm0);
                 }
@@ -1560,7 +1573,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
                 width *= 8ull;
             }
             {
-                const unsigned long long tk3 = wall_clock64();
+                const unsigned long long tk3 = MI_CLK();
                 tk_board += tk3 - tk2;
                 if (lane == 0) {
                     x.r_more1 += (unsigned int)(tk3 - tk2);
@@ -1573,7 +1586,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
                 r_pow = 1;
                 nt = N;
             }
-            const unsigned long long tkc0 = wall_clock64();
+            const unsigned long long tkc0 = MI_CLK();
             x.c_ref += nt;
             x.c_calls += 1ull;
             x.c_eval += ev;
@@ -1583,13 +1596,13 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
             MI_TICK(8, tkc0);
         }
         if (lane == 0) {
-            x.r_more0 = (unsigned int)wall_clock64();
+            x.r_more0 = (unsigned int)MI_CLK();
             tg[t] = x;
             atomicAdd(&Q->targets_done, 1u);  // (a termination count, not a hand-off: the host reads tg after the kernel)
         }
     }
     // no targets left to start: work on boards until every target has finished
-    const unsigned long long tk_t0 = wall_clock64();
+    const unsigned long long tk_t0 = MI_CLK();
     unsigned int spins = 0u;
     while (mi_ld_u32(&Q->targets_done) < (unsigned int)ntg && mi_ld_u32(&Q->pad[0]) == 0u) {
         if (!mi_help<L, NXY, PRE, R4>(Q, boards, res, bacc, lane)) {
@@ -1600,7 +1613,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
             }
         }
     }
-    tk_tail = wall_clock64() - tk_t0;
+    tk_tail = MI_CLK() - tk_t0;
     if (lane == 0) {  // t_body: first tests of own jobs, t_ctl: board phases, t_sleep: helping before jobs, n_seg: tail; total in pad[1] units of 2^10 ticks
         atomicAdd(&Q->t_body, tk_seq);
         atomicAdd(&Q->t_ctl, tk_board);
@@ -2199,7 +2212,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     // persistent-workgroup variant was built in r02, lost 140 vs 58 ms on the heavy rounds, and was removed in r03).
     static const bool mi_rounds = [] { const char *e = fw_knob("FW_MI_ROUNDS"); return e && atoi(e) != 0; }();
     // (more than 65 535 samples: 32-bit cell counts -- only the segment kernels have that form, so such data takes the rounds)
-    const bool per_target = c->P.kind != FW_FZ && !mi_rounds && c->P.n <= 65535;
+    const bool per_target = c->P.kind != FW_FZ && !mi_rounds;  // (r04: the persistent kernel has a 32-bit-count form too, PRE = 2)
     const int spec_depth = c->P.kind == FW_FZ ? std::min(std::max(spec_env, 0), DH_MAX_SPEC) : 0;
     const int d1 = spec_depth + 1;
     // interleaving-phase look-ahead (first windows of the next candidates, same accepted list): FW_DH_SPEC0 candidates,
@@ -2475,6 +2488,11 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
                         tg[order[0]].nc, ntg > 63 ? tg[order[63]].nc : -1, ntg > 255 ? tg[order[255]].nc : -1);
             }
         }
+#ifdef FW_MI_TICKS
+        P.mi_trace = 1u;
+#else
+        P.mi_trace = trace_host ? 1u : 0u;
+#endif
         FW_HIP(c, hipMemsetAsync(d_mq, 0, sizeof(MiQueue), st));
         FW_HIP(c, hipMemsetAsync(d_boards, 0, sizeof(MiBoard) * MI_BOARD_CAP, st));  // ready flags, claimed / finished counts
         FW_HIP(c, hipEventRecord(ev[0][0], st));
@@ -2490,12 +2508,13 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         // GPU, 35.3 vs 39.2 ms for one rank of eight -- FW_MI_ROW4=2 forces it on up to MI4_N for such experiments
         static const bool row4_force = [] { const char *e = fw_knob("FW_MI_ROW4"); return e && atoi(e) == 2; }();
         const bool r4 = row4_env && pre && c->P.n <= (row4_force ? MI4_N : 2048) && (c->L == 2 || c->mi_nxy == 2);
+        const bool wide = c->P.n > 65535;  // cell counts beyond 16 bits: one count per register, 32-bit tables (mi_test_core<.., WIDE>)
         if (c->L == 2) {
-            if (r4) DH_MI_LAUNCH(2, 2, true, true); else if (pre) DH_MI_LAUNCH(2, 2, true, false); else DH_MI_LAUNCH(2, 2, false, false);
+            if (wide) DH_MI_LAUNCH(2, 2, 2, false); else if (r4) DH_MI_LAUNCH(2, 2, 1, true); else if (pre) DH_MI_LAUNCH(2, 2, 1, false); else DH_MI_LAUNCH(2, 2, 0, false);
         } else if (c->mi_nxy == 2) {
-            if (r4) DH_MI_LAUNCH(3, 2, true, true); else if (pre) DH_MI_LAUNCH(3, 2, true, false); else DH_MI_LAUNCH(3, 2, false, false);
+            if (wide) DH_MI_LAUNCH(3, 2, 2, false); else if (r4) DH_MI_LAUNCH(3, 2, 1, true); else if (pre) DH_MI_LAUNCH(3, 2, 1, false); else DH_MI_LAUNCH(3, 2, 0, false);
         } else {
-            if (pre) DH_MI_LAUNCH(3, 3, true, false); else DH_MI_LAUNCH(3, 3, false, false);
+            if (wide) DH_MI_LAUNCH(3, 3, 2, false); else if (pre) DH_MI_LAUNCH(3, 3, 1, false); else DH_MI_LAUNCH(3, 3, 0, false);
         }
 #undef DH_MI_LAUNCH
         FW_HIP(c, hipGetLastError());

@@ -113,8 +113,11 @@ struct FwPoolBuf {
     FwDevBuf d_acc;  // arena of the live jobs' accepted lists (uploaded once per job, not once per round)
 };
 
+struct FwComm;  // library-side RCCL communicator state (fw_rccl.cpp)
+
 struct fw_ctx {
     fw_params P{};
+    FwComm *comm = nullptr;  // fw_comm_init: the library's own communicator for target-sharded runs
     int64_t n_obs_min_eff = 0;
     mutable std::string err;
     hipStream_t stream = nullptr;
@@ -289,6 +292,7 @@ int fwi_bh_csr_device(fw_ctx *ctx, const FwL0Dev &in, int64_t m_reliable);
 // device-resident all-gather of the ranks' significant level-0 pairs (fw_xchg.hip)
 int fwi_l0_exchange_dev(fw_ctx *c, const fw_dev_exchange *x, int world, const FwL0Dev &local, int64_t m_local, FwL0Dev *merged, int64_t *m_sum);
 int fwi_selftest_div(fw_ctx *ctx, unsigned long long cases, unsigned long long seed, unsigned long long *mismatches);  // fw_fz.hip
+void fwi_comm_free(fw_ctx *ctx);  // fw_rccl.cpp
 int fwi_nb_host_ensure(fw_ctx *ctx);  // download partners / statistics / adjusted p if only the device holds them
 
 // ---- device-resident HITON rounds (fw_devhiton.hip, FW_FZ) ----

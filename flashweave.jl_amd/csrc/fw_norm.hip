@@ -128,16 +128,22 @@ __global__ __launch_bounds__(256) void norm_col_levels_kernel(const int32_t *__r
 // to LDS and are sorted there (bitonic, +inf padding); an entry's tied rank is then (#smaller) + (#equal + 1) / 2 from two binary
 // searches, the largest rank m - (e_max - 1) / 2, and bin = floor((rank / max rank) / (1/2 + 1e-5)) + 1 exactly as discretize()
 // computes it in Float64 (preprocessing.jl:238-265 with n_bins - 1 = 2 for the non-zeros, :267-291).  two[q] = the non-zeros show
-// both bins.  LDS: 8 bytes per padded entry (n <= 16 384 kept rows).
+// both bins.  The keys live in LDS, 8 bytes per padded entry, up to 16 384 kept rows; beyond (r04: preprocessing.jl:217-291 has no
+// bound) in a slice of device memory per workgroup (gkeys, M doubles each: the same bitonic network, its passes through L2
+// instead of LDS -- the stores of a pass are visible to the workgroup's other wavefronts behind the barrier, one L1 per CU), the
+// workgroups striding over the columns so that the scratch stays at gridDim.x * M doubles.
 #define NORM_BIN_MAX 16384
 __global__ __launch_bounds__(1024) void norm_binned_kernel(const int32_t *__restrict__ x, int n, const int32_t *__restrict__ rows, int nk,
-                                                           const int32_t *__restrict__ cols, const double *__restrict__ gmean,
-                                                           int32_t *__restrict__ out, int32_t *__restrict__ two, int M)
+                                                           const int32_t *__restrict__ cols, int pk, const double *__restrict__ gmean,
+                                                           int32_t *__restrict__ out, int32_t *__restrict__ two, int M, double *gkeys)
 {
-    extern __shared__ double s_key[];
+    extern __shared__ double s_key_lds[];
     __shared__ int s_cnt, s_b1, s_b2;
-    const int q = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    double *s_key = gkeys ? gkeys + (size_t)blockIdx.x * (size_t)M : s_key_lds;
+  for (int q = blockIdx.x; q < pk; q += gridDim.x) {
     const int32_t *col = x + (size_t)cols[q] * n;
+    __syncthreads();  // (the previous column's last readers of s_key / s_b1 / s_b2)
     if (tid == 0) s_cnt = s_b1 = s_b2 = 0;
     __syncthreads();
     for (int r = tid; r < nk; r += 1024) {
@@ -210,6 +216,7 @@ __global__ __launch_bounds__(1024) void norm_binned_kernel(const int32_t *__rest
     if (b2) s_b2 = 1;
     __syncthreads();
     if (tid == 0) two[q] = s_b1 && s_b2;
+  }
 }
 
 // dst column q2 = src column sel[q2] (nk entries each)
@@ -246,7 +253,7 @@ extern "C" int fw_normalize_counts(int32_t device, int32_t kind, int32_t n, int3
     int rc = FW_OK;
     int32_t *d_x = nullptr, *d_cmin = nullptr, *d_cmax = nullptr, *d_cols = nullptr, *d_rows = nullptr, *d_rzero = nullptr, *d_rmin = nullptr,
             *d_two = nullptr, *d_oi = nullptr, *d_tmp = nullptr, *d_sel = nullptr;
-    double *d_rsum = nullptr, *d_rlog = nullptr, *d_pseudo = nullptr, *d_g = nullptr;
+    double *d_rsum = nullptr, *d_rlog = nullptr, *d_pseudo = nullptr, *d_g = nullptr, *d_keys = nullptr;
     float *d_of = nullptr;
     std::vector<int32_t> cmin((size_t)p), cmax((size_t)p), cols, rows, rzero, rmin;
     std::vector<double> rsum, rlog;
@@ -380,18 +387,18 @@ extern "C" int fw_normalize_counts(int32_t device, int32_t kind, int32_t n, int3
             NHIP(hipGetLastError());
             NHIP(hipMemcpy(out_i32, d_oi, sizeof(int32_t) * (size_t)nk * pk, hipMemcpyDeviceToHost));
         } else if (kind == FW_MI_NZ) {
-            if (nk > NORM_BIN_MAX) {
-                rc = fw_fail(nullptr, FW_ERR_LIMIT, "fw_normalize_counts: binned_nz_clr sorts a column's non-zeros in LDS (at most %d samples, got %d)", NORM_BIN_MAX, nk);
-                goto done;
-            }
             int M = 2;
             while (M < nk) M <<= 1;
+            const bool keys_in_lds = M <= NORM_BIN_MAX;  // beyond: one slice of device memory per workgroup
+            const int bgrid = keys_in_lds ? pk : std::min(pk, 1024);
+            if (!keys_in_lds) NHIP(hipMalloc((void **)&d_keys, sizeof(double) * (size_t)M * (size_t)bgrid));
             NHIP(hipMalloc((void **)&d_g, sizeof(double) * nk));
             NHIP(hipMemcpy(d_g, g.data(), sizeof(double) * nk, hipMemcpyHostToDevice));
             NHIP(hipMalloc((void **)&d_two, sizeof(int32_t) * pk));
             NHIP(hipMalloc((void **)&d_tmp, sizeof(int32_t) * (size_t)nk * pk));
             NHIP(hipFuncSetAttribute((const void *)norm_binned_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * NORM_BIN_MAX)));
-            hipLaunchKernelGGL(norm_binned_kernel, dim3(pk), dim3(1024), sizeof(double) * (size_t)M, 0, d_x, n, d_rows, nk, d_cols, d_g, d_tmp, d_two, M);
+            hipLaunchKernelGGL(norm_binned_kernel, dim3(bgrid), dim3(1024), keys_in_lds ? sizeof(double) * (size_t)M : 0, 0, d_x, n, d_rows, nk, d_cols, pk,
+                               d_g, d_tmp, d_two, M, d_keys);
             NHIP(hipGetLastError());
             std::vector<int32_t> two((size_t)pk), sel;
             NHIP(hipMemcpy(two.data(), d_two, sizeof(int32_t) * pk, hipMemcpyDeviceToHost));
@@ -427,7 +434,7 @@ extern "C" int fw_normalize_counts(int32_t device, int32_t kind, int32_t n, int3
         *p_out = pk;
     }
 done:
-    void *ptrs[] = {d_x, d_cmin, d_cmax, d_cols, d_rows, d_rzero, d_rmin, d_two, d_oi, d_tmp, d_sel, d_rsum, d_rlog, d_pseudo, d_g, d_of};
+    void *ptrs[] = {d_x, d_cmin, d_cmax, d_cols, d_rows, d_rzero, d_rmin, d_two, d_oi, d_tmp, d_sel, d_rsum, d_rlog, d_pseudo, d_g, d_of, d_keys};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     return rc;

@@ -121,6 +121,14 @@ def load_library():
     L.fw_network_get_directed.argtypes = [vp, vp, vp, vp, vp]
     L.fw_get_counters.argtypes = [vp, C.POINTER(_Counters)]
     L.fw_reset_counters.argtypes = [vp]
+    if hasattr(L, "fw_comm_init"):
+        L.fw_comm_unique_id.argtypes = [vp]
+        L.fw_comm_init.argtypes = [vp, vp, C.c_int32, C.c_int32]
+        L.fw_comm_destroy.argtypes = [vp]
+        L.fw_comm_stats.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.fw_level0_comm.argtypes = [vp, vp]
+        L.fw_cor_mat_allgather_comm.argtypes = [vp, C.c_int64]
+        L.fw_learn_network_comm.argtypes = [vp, vp, vp]
     if hasattr(L, "fw_selftest"):  # (absent from older builds loaded through FW_LIB_PATH for A/B profiling)
         L.fw_selftest.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
     L.fw_effective_n_obs_min.restype = C.c_int64
@@ -273,6 +281,47 @@ class Engine:
         self._ck(self.L.fw_level0_sharded_dev(self.h, rank, world_size, C.byref(x), C.byref(nnz)))
         return nnz.value
 
+    # -- library-side collectives (fw_comm_*: RCCL on a communicator the library owns) -------------------
+    @staticmethod
+    def comm_unique_id():
+        """Rank 0: the 128-byte rendezvous id (ncclGetUniqueId); ship it to every rank, then comm_init everywhere."""
+        L = load_library()
+        buf = (C.c_uint8 * 128)()
+        rc = L.fw_comm_unique_id(buf)
+        if rc:
+            raise FlashWeaveError(rc, (L.fw_last_error(None) or b"").decode())
+        return bytes(buf)
+
+    def comm_init(self, id128, rank, world_size):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(id128))
+        self._ck(self.L.fw_comm_init(self.h, buf, int(rank), int(world_size)))
+
+    def comm_destroy(self):
+        self._ck(self.L.fw_comm_destroy(self.h))
+
+    def comm_stats(self):
+        a, b, c_, d = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        s_ = C.c_double(0)
+        self._ck(self.L.fw_comm_stats(self.h, C.byref(a), C.byref(b), C.byref(c_), C.byref(d), C.byref(s_)))
+        return dict(calls=a.value, collectives=b.value, entries=c_.value, bytes=d.value, seconds=s_.value)
+
+    def level0_comm(self):
+        """fw_level0_comm: level 0 with this rank's share of the pair tiles (discrete kinds), significant pairs all-gathered by the library."""
+        nnz = C.c_int64(0)
+        self._ck(self.L.fw_level0_comm(self.h, C.byref(nnz)))
+        return nnz.value
+
+    def cor_allgather_comm(self, rows_per_rank):
+        self._ck(self.L.fw_cor_mat_allgather_comm(self.h, int(rows_per_rank)))
+
+    def lgl_comm(self, feed_forward=True, round_size=1, max_targets=0, edge_dict=True):
+        """fw_learn_network_comm: LGL of a target-sharded run, the per-round exchange issued by the library (rank / world_size are the
+        communicator's)."""
+        opts = _LearnOpts(int(feed_forward), int(round_size), 0, 1, int(max_targets), 0)
+        ne = C.c_int64(0)
+        self._ck(self.L.fw_learn_network_comm(self.h, C.byref(opts), C.byref(ne)))
+        return self._network(ne.value, edge_dict)
+
     # -- row-block sharding of cor() ------------------------------------------------------------------
     def use_cor_buffer(self, device_ptr, capacity_floats):
         """Keep the p x p matrix in caller-owned device memory (a torch tensor's data_ptr()): fw_use_cor_buffer."""
@@ -358,6 +407,10 @@ class Engine:
             self._ck(self.L.fw_learn_network_dev(self.h, C.byref(opts), C.byref(x), C.byref(ne)))
         else:
             self._ck(self.L.fw_learn_network(self.h, C.byref(opts), C.cast(cb, C.c_void_p) if cb else None, None, C.byref(ne)))
+        return self._network(ne.value, edge_dict)
+
+    def _network(self, n_edges, edge_dict):
+        ne = C.c_int64(n_edges)
         k = max(ne.value, 1)
         src, dst, w = np.zeros(k, np.int32), np.zeros(k, np.int32), np.zeros(k, np.float64)
         self._ck(self.L.fw_network_get(self.h, _ptr(src), _ptr(dst), _ptr(w)))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 5 /* 2: fw_params.recursive_pcor, fw_level0_sharded; 3: device-resident exchange (fw_dev_exchange), sharded cor; 4: fw_params.no_cor_mat; 5: fw_selftest, fw_counters.gram_* */
+#define FW_ABI_VERSION 5 /* 2: fw_params.recursive_pcor, fw_level0_sharded; 3: device-resident exchange (fw_dev_exchange), sharded cor; 4: fw_params.no_cor_mat; 5: fw_selftest, fw_counters.gram_*, fw_comm_* (library-side RCCL) */
 
 /* test kinds: src/types.jl:61-72 (test_name "mi" / "mi_nz" / "fz") */
 #define FW_MI 0
@@ -265,6 +265,26 @@ int fw_learn_network(fw_ctx *ctx, const fw_learn_opts *opts, fw_allgather_fn all
  * send buffer, all-gathered by the caller's collective and unpacked from the gathered buffer -- the host language only runs the
  * collective (r02's callback packed and unpacked in numpy: ~0.9 ms per round of a cfg3 pass). */
 int fw_learn_network_dev(fw_ctx *ctx, const fw_learn_opts *opts, const fw_dev_exchange *exchange, int64_t *n_edges_out);
+/* ---- library-side collectives (ABI 5): the same exchanges on a communicator the LIBRARY owns ------------------------------------
+ * replaces: the master <-> worker message loop of src/interleaved.jl:112-183 for one process per GPU.  RCCL (librccl.so.1, reached
+ * through dlopen: single-GPU users never load it) on the context's stream; the host language only carries the 128-byte rendezvous
+ * id from rank 0 to the others (torch.distributed / MPI / Distributed.jl) and never sees a payload.
+ *   fw_comm_unique_id   rank 0: ncclGetUniqueId
+ *   fw_comm_init        every rank, after fw_ctx_create on ITS device: ncclCommInitRank (one rank per device)
+ *   fw_level0_comm      = fw_level0_sharded_dev with the library's all-gather (discrete kinds; Fisher-z kinds: plain fw_level0)
+ *   fw_cor_mat_allgather_comm  the in-place all-gather of the row blocks of fw_compute_cor_mat_rows (then fw_cor_mat_ready)
+ *   fw_learn_network_comm      = fw_learn_network_dev with the library's all-gather per feed-forward round; opts->rank /
+ *                              world_size are taken from the communicator
+ *   fw_comm_stats       exchanges so far: calls, collectives, directed entries, gathered bytes, seconds inside them */
+#define FW_COMM_ID_BYTES 128
+int fw_comm_unique_id(uint8_t *id128);
+int fw_comm_init(fw_ctx *ctx, const uint8_t *id128, int32_t rank, int32_t world_size);
+int fw_comm_destroy(fw_ctx *ctx);
+int fw_comm_stats(const fw_ctx *ctx, int64_t *calls, int64_t *collectives, int64_t *entries, int64_t *bytes, double *seconds);
+int fw_level0_comm(fw_ctx *ctx, int64_t *nnz_out);
+int fw_cor_mat_allgather_comm(fw_ctx *ctx, int64_t rows_per_rank);
+int fw_learn_network_comm(fw_ctx *ctx, const fw_learn_opts *opts, int64_t *n_edges_out);
+
 int fw_network_get(const fw_ctx *ctx, int32_t *src, int32_t *dst, double *weight); /* src < dst */
 /* directed per-target results (state_results of every HitonState): CSR over targets */
 int fw_network_get_directed(const fw_ctx *ctx, int64_t *off, int32_t *idx, double *weight, double *pval);
@@ -273,8 +293,8 @@ int fw_network_get_directed(const fw_ctx *ctx, int64_t *off, int32_t *idx, doubl
 
 /* replaces: normalize_data / preprocess_data (src/preprocessing.jl:412-563) for a count table without meta variables:
  * filter_by_variance (:367-409), then by kind  FW_FZ: clr_adapt (:133-214)   FW_FZ_NZ: clr_nz (:192-207)   FW_MI: binary (:475-490)
- * FW_MI_NZ: binned_nz_clr (clr_nz, then per column the tied ranks of the non-zero entries in two bins, :217-291,492-521; at most
- * 16 384 samples).  counts: n x p column-major Int32.  Outputs (host buffers sized for n x p): out_f32 (FW_FZ / FW_FZ_NZ) or
+ * FW_MI_NZ: binned_nz_clr (clr_nz, then per column the tied ranks of the non-zero entries in two bins, :217-291,492-521; the
+ * column sort runs in LDS up to 16 384 samples and through device memory beyond).  counts: n x p column-major Int32.  Outputs (host buffers sized for n x p): out_f32 (FW_FZ / FW_FZ_NZ) or
  * out_i32 (FW_MI / FW_MI_NZ), column-major *n_out x *p_out; row_mask[n] / col_mask[p] = kept samples / variables.  No context
  * needed: create one with the resulting shape afterwards.  Meta variables (a handful of columns) are prepared by the caller
  * (one-hot, discretisation: preprocess.py) and appended. */

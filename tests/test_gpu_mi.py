@@ -474,3 +474,18 @@ def test_more_than_65535_samples(kind, rows):
         assert _close(net["edges"][e_], w, STOL)
     assert eng.counters()["cond_tests_ref"] == exp["n_cond_tests"]
     eng.close()
+    # ... and through the persistent per-target kernel in its 32-bit-count form (r04: dh_mi_target_kernel<.., PRE = 2>; the knob only
+    # lifts the "at least 256 targets" rule so that ten variables reach it)
+    import os
+    os.environ["FW_DEV_MIN_TARGETS"] = "1"
+    try:
+        eng = fw.Engine(kind, n, p, max_k=2)
+        eng.set_data(data)
+        net2 = eng.lgl(feed_forward=False, round_size=0)
+        assert set(net2["edges"]) == set(exp["edges"])
+        for e_, w in exp["edges"].items():
+            assert _close(net2["edges"][e_], w, STOL)
+        assert eng.counters()["cond_tests_ref"] == exp["n_cond_tests"]
+        eng.close()
+    finally:
+        del os.environ["FW_DEV_MIN_TARGETS"]

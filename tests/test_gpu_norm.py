@@ -65,6 +65,18 @@ def test_binned_nz_clr_ties_and_duplicated_samples():
     assert (rm == erm).all() and (cm == ecm).all() and np.array_equal(got, exp)
 
 
+def test_binned_nz_clr_beyond_16384_samples():
+    # the column sort of binned_nz_clr leaves LDS above 16 384 samples (keys in device memory, workgroups striding over the columns):
+    # 20 000 samples incl. duplicated ones (ties) against the host front-end (preprocessing.jl:217-291 has no bound on n)
+    rng = np.random.default_rng(11)
+    base = rng.poisson(2.0, size=(12_000, 40)) * (rng.random((12_000, 40)) < 0.5)
+    counts = np.concatenate([base, base[:8_000]], axis=0)
+    exp, erm, ecm = pre.normalize(counts, "mi_nz")
+    got, rm, cm = fw.normalize_counts(counts, "mi_nz")
+    assert exp.shape[0] > 16384
+    assert (rm == erm).all() and (cm == ecm).all() and np.array_equal(got, exp)
+
+
 def test_learn_network_uses_the_device_front_end():
     # learn_network(normalize=True) on a count table: the default path normalises on the device (no host pre.normalize) and
     # gives the network of the host front-end + engine composition
