@@ -141,6 +141,23 @@ __global__ __launch_bounds__(1024) void norm_binned_kernel(const int32_t *__rest
     __shared__ int s_cnt, s_b1, s_b2;
     const int tid = threadIdx.x;
     double *s_key = gkeys ? gkeys + (size_t)blockIdx.x * (size_t)M : s_key_lds;
+    // keys in device memory: relaxed agent-scope accesses (they bypass the per-CU vector cache, whose lines another wavefront's
+    // store does not refresh) and a device-scope fence in front of every barrier; in LDS plain accesses
+    const bool glob = gkeys != nullptr;
+    auto KLD = [&](int i) -> double {
+        return glob ? __longlong_as_double(__hip_atomic_load((const long long *)&s_key[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : s_key[i];
+    };
+    auto KST = [&](int i, double v) {
+        if (glob)
+            __hip_atomic_store((long long *)&s_key[i], __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+            s_key[i] = v;
+    };
+#define NB_SYNC()                 \
+    {                             \
+        if (glob) __threadfence(); \
+        __syncthreads();          \
+    }
   for (int q = blockIdx.x; q < pk; q += gridDim.x) {
     const int32_t *col = x + (size_t)cols[q] * n;
     __syncthreads();  // (the previous column's last readers of s_key / s_b1 / s_b2)
@@ -148,34 +165,34 @@ __global__ __launch_bounds__(1024) void norm_binned_kernel(const int32_t *__rest
     __syncthreads();
     for (int r = tid; r < nk; r += 1024) {
         const int32_t v = col[rows[r]];
-        if (v != 0) s_key[atomicAdd(&s_cnt, 1)] = log((double)v / gmean[r]);  // order does not matter: sorted below
+        if (v != 0) KST(atomicAdd(&s_cnt, 1), log((double)v / gmean[r]));  // order does not matter: sorted below
     }
-    __syncthreads();
+    NB_SYNC()
     const int m = s_cnt;
-    for (int i = m + tid; i < M; i += 1024) s_key[i] = INFINITY;
-    __syncthreads();
+    for (int i = m + tid; i < M; i += 1024) KST(i, INFINITY);
+    NB_SYNC()
     for (int k = 2; k <= M; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < M; i += 1024) {
                 const int l = i ^ j;
                 if (l > i) {
-                    const double a = s_key[i], b = s_key[l];
+                    const double a = KLD(i), b = KLD(l);
                     const bool up = (i & k) == 0;
                     if (up ? (a > b) : (a < b)) {
-                        s_key[i] = b;
-                        s_key[l] = a;
+                        KST(i, b);
+                        KST(l, a);
                     }
                 }
             }
-            __syncthreads();
+            NB_SYNC()
         }
     double rmax = 1.0;
     if (m > 0) {
-        const double top = s_key[m - 1];
+        const double top = KLD(m - 1);
         int lo = 0, hi = m;  // first index with key >= top
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            if (s_key[mid] < top)
+            if (KLD(mid) < top)
                 lo = mid + 1;
             else
                 hi = mid;
@@ -192,7 +209,7 @@ __global__ __launch_bounds__(1024) void norm_binned_kernel(const int32_t *__rest
             int lo = 0, hi = m;
             while (lo < hi) {  // #smaller
                 const int mid = (lo + hi) >> 1;
-                if (s_key[mid] < c)
+                if (KLD(mid) < c)
                     lo = mid + 1;
                 else
                     hi = mid;
@@ -200,7 +217,7 @@ __global__ __launch_bounds__(1024) void norm_binned_kernel(const int32_t *__rest
             int lo2 = lo, hi2 = m;
             while (lo2 < hi2) {  // first index with key > c
                 const int mid = (lo2 + hi2) >> 1;
-                if (s_key[mid] <= c)
+                if (KLD(mid) <= c)
                     lo2 = mid + 1;
                 else
                     hi2 = mid;
@@ -217,6 +234,7 @@ __global__ __launch_bounds__(1024) void norm_binned_kernel(const int32_t *__rest
     __syncthreads();
     if (tid == 0) two[q] = s_b1 && s_b2;
   }
+#undef NB_SYNC
 }
 
 // dst column q2 = src column sel[q2] (nk entries each)

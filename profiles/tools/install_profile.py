@@ -3,7 +3,7 @@ python profiles/tools/install_profile.py <cfg> <kernel-name-substring> [round, d
 import csv, json, shutil, sys
 
 cfg, kname = sys.argv[1], sys.argv[2]
-RND = sys.argv[3] if len(sys.argv) > 3 else "r03"
+RND = sys.argv[3] if len(sys.argv) > 3 else "r04"
 P = "gpurun_out/prof_%s_%s/" % (RND, cfg)
 sq, f, w = (json.load(open(P + n)) for n in ("pmc_sq.json", "pmc_f.json", "pmc_w.json"))
 bench = json.loads([l for l in open(P + "bench_under_rocprof.json") if l.startswith("{")][-1])
