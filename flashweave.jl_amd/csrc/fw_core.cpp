@@ -243,18 +243,6 @@ int fw_set_cor_mat(fw_ctx *c, const float *cor)
         if (std::fabs(cor[t]) > 1.0f)
             return fw_fail(c, FW_ERR_ARG, "fw_set_cor_mat: entry %zu = %g is outside [-1, 1]: not a correlation matrix", t,
                            (double)cor[t]);
-    // ... and on its exact symmetry (what cor() returns: the kernels read whichever of cor[u][v] / cor[v][u] lies in the row the
-    // neighbouring lanes read, fw_fz_core.h CORT)
-    {
-        const size_t pp = (size_t)c->P.p;
-        for (size_t u = 0; u < pp; ++u)
-            for (size_t v = u + 1; v < pp; ++v) {
-                const float a = cor[u * pp + v], b = cor[v * pp + u];
-                if (!(a == b || (a != a && b != b)))
-                    return fw_fail(c, FW_ERR_ARG, "fw_set_cor_mat: entries (%zu, %zu) = %g and (%zu, %zu) = %g differ: not a symmetric matrix", u, v,
-                                   (double)a, v, u, (double)b);
-            }
-    }
     if (!c->d_cor) FW_HIP(c, hipMalloc(&c->d_cor, bytes));
     FW_HIP(c, hipMemcpy(c->d_cor, cor, bytes, hipMemcpyHostToDevice));
     c->have_cor = true;

@@ -617,8 +617,11 @@ __device__ __forceinline__ double fz_l1t_stat(const float *__restrict__ cor, int
     for (int t = 0; t < K - 1; ++t)
 #pragma unroll
         for (int u = t + 1; u < K - 1; ++u) {
-            // (transposed read of the symmetric matrix: zid[u] belongs to the slower-moving position -> one row per wavefront, see CORT)
+#ifdef FW_CORT_TRANSPOSED
             const TV v = pc_l1_r(cor[(size_t)zid[u] * p + zid[t]], c[t], c[u], r[t], r[u]);
+#else
+            const TV v = pc_l1_r(cor[(size_t)zid[t] * p + zid[u]], c[t], c[u], r[t], r[u]);
+#endif
             R[2 + t][2 + u] = v.v;
             is32[2 + t][2 + u] = v.f32;
             clean = clean && v.v == v.v;
@@ -764,12 +767,16 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     __syncthreads();
 #define ACCV(i) (LOCAL ? ((i) + 2) : (in_lds ? s_acc[(i)] : gacc[(i)]))
 #define CORV(u, v) cor[(size_t)(u) * p + (v)]
-// Transposed read: the resident Pearson matrix is EXACTLY symmetric (mirrored stores of the GEMM epilogue; fw_set_cor_mat rejects
-// anything else), so cor[v][u] is the same bits as cor[u][v] -- and where u is the index that moves from lane to lane (the last
-// position of a subset, the later position of a table entry) while v stays, the 64 gathers of a wavefront fall into ONE 4 p-byte row
-// instead of 64 rows 4 p bytes apart (64 DRAM pages and 64 translations per wavefront instruction).  Job-local matrices (fz_nz)
-// keep the plain order.
+// CORT(u, v): the entry a lane gathers where u is the index that moves from lane to lane.  r04 measured the transposed read
+// cor[v][u] here (the matrix is exactly symmetric, and the 64 gathers of a wavefront then fall into one row instead of 64 rows):
+// neutral at cfg3 (193.2 against 191.8 ms), 3.7 % SLOWER at cfg5 (65.3 against 63.0 s on the same box, p = 100 000: a row is 400 KB,
+// the lines of 64 scattered columns of one row conflict in the L2 sets where 64 rows at one column do not) -- kept off.
+// -DFW_CORT_TRANSPOSED builds it.
+#ifdef FW_CORT_TRANSPOSED
 #define CORT(u, v) (LOCAL ? CORV(u, v) : CORV(v, u))
+#else
+#define CORT(u, v) CORV(u, v)
+#endif
 
     const int X = LOCAL ? 0 : seg.X, Y = LOCAL ? 1 : seg.Y;
     const float cXY = CORV(X, Y);
