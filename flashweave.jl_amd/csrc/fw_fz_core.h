@@ -753,7 +753,8 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     }
     unsigned long long cnt[FW_MAX_K + 1];
 #pragma unroll
-    for (int s = FW_MAX_K; s >= 1; --s) cnt[s] = (s <= max_k) ? binom_u64(a, s) : 0ull;
+    for (int s = FW_MAX_K; s >= 1; --s)  // (size-3 table variant: |accepted| <= 512, sizes <= 3 -- 32-bit binomials, no 64-bit division in every workgroup's prologue)
+        cnt[s] = (s <= max_k) ? (TAB3 ? (unsigned long long)fw_binom32(a, s) : binom_u64(a, s)) : 0ull;
     // significance thresholds on |r| (see fz_thresholds_kernel): outside [lo, hi] the verdict of p < alpha is certain
     const double rlo_pos = thr[0], rhi_pos = thr[1], rlo_neg = thr[2], rhi_neg = thr[3];
     // |r| below which x = |z|/sqrt2 < FZ_X_SUB for sure: x = zscale * log((1+r)/(1-r)) / sqrt2  <=>  r = tanh(x / (sqrt2 zscale))

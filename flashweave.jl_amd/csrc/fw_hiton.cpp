@@ -304,7 +304,8 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
             const char *mt = fw_knob("FW_DEV_MIN_TARGETS");  // test knob
             const size_t min_targets = mt ? (size_t)atol(mt) : (c->P.kind == FW_FZ ? 64 : 256);  // cfg2 (1000 targets): 19 ms on the device, 28 ms through the host pool
             const bool stream = c->P.kind == FW_FZ && !c->P.recursive_pcor;  // streamed-column tests: host pool over fw_fzs.hip
-            const bool use_dev = !host_only && c->P.kind != FW_FZ_NZ && !stream && !no_power && n_my >= min_targets;
+            // (discrete data with more than three levels -- the generic form of fw_mi_core.h -- runs through the host job pool as well)
+            const bool use_dev = !host_only && c->P.kind != FW_FZ_NZ && !stream && !no_power && !c->mi_generic && n_my >= min_targets;
             const bool dev_cands = use_dev && c->d_cand != nullptr;  // candidate order already built on the device (fw_bh.hip)
             if (!dev_cands)
                 if (int rc = fwi_nb_host_ensure(c)) return rc;

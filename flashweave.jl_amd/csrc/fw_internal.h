@@ -149,6 +149,8 @@ struct fw_ctx {
     uint64_t *d_nzbits = nullptr;  // [p][W] bit i of word w: sample 64w+i has value != 0
     uint64_t *d_hibits = nullptr;  // [p][W] value == 2 (second non-zero level); NULL when L == 2
     int32_t *d_levels = nullptr, *d_maxvals = nullptr;
+    unsigned char *d_vals = nullptr;  // generic discrete form (a value above 2): one byte per (variable, sample), [p][n]; null otherwise
+    bool mi_generic = false;
     bool fznz_lds_raised = false;  // fznz_submat_kernel's dynamic-LDS limit was raised on this context's device (a property of (function, device): one flag per context, set under the context's own launches)
     float *d_xlnx = nullptr;       // [x ln x | ln x] for x = 0..n (Float32 tables of the discrete level-0 screen)
     int32_t *d_firstnz = nullptr;  // per column: index of the first non-zero sample (n if none)

@@ -24,6 +24,17 @@
 static MiDev mi_dev(const fw_ctx *ctx);
 static double host_igamc(double a, double x);
 
+// L = 0 selects the generic form (values above 2: mi_test_core_gen, one byte per value, 32-bit LDS table) in the kernels below
+template <int L, int NXY, bool PRE, bool WIDE>
+static __device__ __forceinline__ MiRes mi_test_any(const MiDev &P, int X, int Y, const MiZs &zs, int k, unsigned short *tab)
+{
+    if constexpr (L == 0)
+        return mi_test_core_gen(P, X, Y, zs, k, (unsigned *)tab);
+    else
+        return mi_test_core<L, NXY, PRE, WIDE>(P, X, Y, zs, k, tab);
+}
+#define MI_TAB_U16(L, WIDE) ((L) == 0 ? 2 * MIG_TAB32 : ((WIDE) ? 2 * MI_TAB16 : MI_TAB16))
+
 // ------------------------------------------------------------------------------------------------
 // batch of single tests: one wave per test
 // ------------------------------------------------------------------------------------------------
@@ -34,7 +45,7 @@ __global__ __launch_bounds__(256) void mi_test_batch_kernel(MiDev P, long long m
                                                             const int32_t *__restrict__ zflat,
                                                             fw_test_result *__restrict__ out)
 {
-    __shared__ unsigned short s_tab[4][WIDE ? 2 * MI_TAB16 : MI_TAB16];
+    __shared__ unsigned short s_tab[4][MI_TAB_U16(L, WIDE)];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long t = (long long)blockIdx.x * 4 + wave;
     if (t >= m) return;
@@ -43,7 +54,7 @@ __global__ __launch_bounds__(256) void mi_test_batch_kernel(MiDev P, long long m
 #pragma unroll
     for (int q = 0; q < MI_MAX_K; ++q) zs.v[q] = (q < k) ? zflat[zoff[t] + q] : 0;
     if (P.prof) P.prof += 8 * t;  // one record per test
-    MiRes r = mi_test_core<L, NXY, PRE, WIDE>(P, X[t], Y[t], zs, k, s_tab[wave]);
+    MiRes r = mi_test_any<L, NXY, PRE, WIDE>(P, X[t], Y[t], zs, k, s_tab[wave]);
     const unsigned long long pt = P.prof ? __builtin_readcyclecounter() : 0ull;
     (void)mi_res_pval(r);
     if (P.prof && lane == 0) P.prof[3] = __builtin_readcyclecounter() - pt;
@@ -67,7 +78,7 @@ __device__ __forceinline__ void mi_seg_body(const MiDev &P, const FwSeg *__restr
                                             FwSegOut *__restrict__ out, int max_k, double alpha, long long max_tests,
                                             const unsigned sidx /* segment this workgroup evaluates */, int need_p)
 {
-    __shared__ unsigned short s_tab[4][WIDE ? 2 * MI_TAB16 : MI_TAB16];
+    __shared__ unsigned short s_tab[4][MI_TAB_U16(L, WIDE)];
     __shared__ unsigned long long s_stop[4], s_br[4];
     __shared__ double s_sstat[4], s_sp[4], s_bp[4], s_bstat[4];
     __shared__ int s_sdf[4], s_spow[4], s_bdf[4];
@@ -113,7 +124,7 @@ __device__ __forceinline__ void mi_seg_body(const MiDev &P, const FwSeg *__restr
                 MiZs zs;
 #pragma unroll
                 for (int q = 0; q < MI_MAX_K; ++q) zs.v[q] = (q < s) ? gacc[pos[q]] : 0;
-                MiRes t = mi_test_core<L, NXY, PRE, WIDE>(P, seg.X, seg.Y, zs, s, s_tab[wave]);
+                MiRes t = mi_test_any<L, NXY, PRE, WIDE>(P, seg.X, seg.Y, zs, s, s_tab[wave]);
                 ++my_done;
                 const int ev = mi_account(P, t, max_tests > 0 && r + 1 >= (unsigned long long)max_tests, mb, need_p != 0);
                 if (ev == 1) {
@@ -652,7 +663,186 @@ static MiDev mi_dev(const fw_ctx *ctx)
     P.alpha = ctx->P.alpha;
     P.prof = nullptr;
     P.view = 0;
+    P.vals = ctx->mi_generic ? ctx->d_vals : nullptr;
     return P;
+}
+
+// ---- generic form: a value above 2 somewhere (mi_test_core_gen) -------------------------------------------------------------
+// One byte per (variable, sample); levels / max_vals as misc.jl:64-97 computes them (distinct values of the column, the implicit
+// zero included); L = maximum(max_vals) + 1 for every table of the context (types.jl:89,110).  The conditional tests run through the
+// same batch / segment kernels as the bit-plane forms (template value L = 0), HITON-PC through the host job pool, level 0 through
+// mig_level0_kernel (one wavefront per pair).  Limits: values <= 7, L^max_k (L^2 + 1) <= MIG_TAB32 words of LDS per wavefront.
+static double host_igamc(double a, double x);
+static int mig_upload(fw_ctx *ctx, const int64_t *colptr, const int32_t *rowval, const int32_t *nzval)
+{
+    const int n = ctx->P.n, p = ctx->P.p;
+    std::vector<unsigned char> vals((size_t)p * n, 0);
+    int maxv_all = 0;
+    for (int v = 0; v < p; ++v) {
+        bool seen[MIG_MAX_L] = {false};
+        int mx = 0;
+        for (int64_t j = colptr[v]; j < colptr[v + 1]; ++j) {
+            const int32_t x = nzval[j];
+            vals[(size_t)v * n + rowval[j]] = (unsigned char)x;
+            seen[x] = true;
+            mx = std::max(mx, (int)x);
+        }
+        int lev = n > colptr[v + 1] - colptr[v] ? 1 : 0;
+        for (int q = 1; q < MIG_MAX_L; ++q) lev += seen[q] ? 1 : 0;
+        ctx->levels[v] = lev;
+        ctx->max_vals[v] = mx;
+        maxv_all = std::max(maxv_all, mx);
+    }
+    ctx->L = maxv_all + 1;
+    ctx->mi_nxy = ctx->L;
+    ctx->W = (n + 63) / 64;
+    long long strata = 1;
+    for (int j = 0; j < ctx->P.max_k; ++j) strata *= ctx->L;
+    if (strata * ((long long)ctx->L * ctx->L + 1) > MIG_TAB32)
+        return fw_fail(ctx, FW_ERR_LIMIT, "discrete data with %d levels and max_k = %d needs %lld table words per test (limit %d): lower max_k or merge levels", ctx->L,
+                       ctx->P.max_k, strata * ((long long)ctx->L * ctx->L + 1), MIG_TAB32);
+    void **ptrs[] = {(void **)&ctx->d_nzbits, (void **)&ctx->d_hibits, (void **)&ctx->d_levels, (void **)&ctx->d_maxvals, (void **)&ctx->d_firstnz, (void **)&ctx->d_vals,
+                     (void **)&ctx->d_gthr};
+    for (void **q : ptrs)
+        if (*q) {
+            (void)hipFree(*q);
+            *q = nullptr;
+        }
+    FW_HIP(ctx, hipMalloc((void **)&ctx->d_vals, vals.size()));
+    FW_HIP(ctx, hipMemcpy(ctx->d_vals, vals.data(), vals.size(), hipMemcpyHostToDevice));
+    FW_HIP(ctx, hipMalloc((void **)&ctx->d_levels, sizeof(int32_t) * p));
+    FW_HIP(ctx, hipMalloc((void **)&ctx->d_maxvals, sizeof(int32_t) * p));
+    FW_HIP(ctx, hipMemcpy(ctx->d_levels, ctx->levels.data(), sizeof(int32_t) * p, hipMemcpyHostToDevice));
+    FW_HIP(ctx, hipMemcpy(ctx->d_maxvals, ctx->max_vals.data(), sizeof(int32_t) * p, hipMemcpyHostToDevice));
+    {  // alpha quantiles of G^2 per df: df <= (L - 1)^2 per stratum
+        const int ndf = (int)std::min<long long>((long long)(ctx->L - 1) * (ctx->L - 1) * strata + 1, 4096);
+        std::vector<double> q((size_t)ndf, 1e300);
+        for (int df = 1; df < ndf; ++df) {
+            double lo = 0.0, hi = 16.0 + 4.0 * df;
+            while (host_igamc(0.5 * df, 0.5 * hi) >= ctx->P.alpha) hi *= 2.0;
+            for (int it = 0; it < 64; ++it) {
+                const double mid = 0.5 * (lo + hi);
+                if (host_igamc(0.5 * df, 0.5 * mid) < ctx->P.alpha)
+                    hi = mid;
+                else
+                    lo = mid;
+            }
+            q[df] = 0.5 * (lo + hi);
+        }
+        FW_HIP(ctx, hipMalloc((void **)&ctx->d_gthr, sizeof(double) * (size_t)ndf));
+        FW_HIP(ctx, hipMemcpy(ctx->d_gthr, q.data(), sizeof(double) * (size_t)ndf, hipMemcpyHostToDevice));
+        ctx->gthr_n = ndf;
+    }
+    ctx->mi_generic = true;
+    return FW_OK;
+}
+
+// level 0 of the generic form: wavefront w of the launch tests pair q0 + w (pairs linearised row by row over the upper triangle);
+// tests.jl:80-92 (everything fails if levels[X] < 2) + the scalar test, kept if reliable and p < alpha
+__global__ __launch_bounds__(256) void mig_level0_kernel(MiDev P, int p, long long q0, long long q1, double alpha, MiL0Counters *cnt,
+                                                         unsigned long long cap, int32_t *out_i, int32_t *out_j, double *out_s, double *out_p)
+{
+    __shared__ unsigned short s_tab[4][2 * MIG_TAB32];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long q = q0 + (long long)blockIdx.x * 4 + wave;
+    if (q >= q1) return;
+    // q -> (i, j), i < j: row i starts at offset i p - i (i + 1) / 2
+    const double pd = (double)p - 0.5;
+    long long i = (long long)(pd - sqrt(pd * pd - 2.0 * (double)q));
+    if (i < 0) i = 0;
+    while (i > 0 && i * (long long)p - i * (i + 1) / 2 > q) --i;
+    while ((i + 1) * (long long)p - (i + 1) * (i + 2) / 2 <= q) ++i;
+    const long long j = q - (i * (long long)p - i * (i + 1) / 2) + i + 1;
+    MiRes r;
+    r.stat = 0.0;
+    r.pval = 1.0;
+    r.df = 0;
+    r.power = 0;
+    r.g = 0.0;
+    r.n_obs = 0;
+    if (P.levels[(int)i] >= 2) {
+        MiZs zs;
+#pragma unroll
+        for (int t = 0; t < MI_MAX_K; ++t) zs.v[t] = 0;
+        r = mi_test_core_gen(P, (int)i, (int)j, zs, 0, (unsigned *)s_tab[wave]);
+    }
+    double pv = 1.0;
+    if (r.power) pv = mi_res_pval(r);
+    if (lane == 0) {
+        if (!r.power) {
+            atomicAdd(&cnt->n_unreliable, 1ull);
+        } else if (pv < alpha) {
+            const unsigned long long slot = atomicAdd(&cnt->n_sig, 1ull);
+            if (slot < cap) {
+                out_i[slot] = (int32_t)i;
+                out_j[slot] = (int32_t)j;
+                out_s[slot] = r.stat;
+                out_p[slot] = pv;
+            }
+        }
+    }
+}
+
+static int mig_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &pj, std::vector<double> &stat, std::vector<double> &pval,
+                      int64_t *m_reliable, FwL0Dev *dev)
+{
+    const int p = ctx->P.p;
+    const long long npairs = (long long)p * (p - 1) / 2;
+    const long long q0 = npairs * ctx->l0_rank / ctx->l0_world, q1 = npairs * (ctx->l0_rank + 1) / ctx->l0_world;
+    const MiDev P = mi_dev(ctx);
+    unsigned long long cap = (unsigned long long)std::max<long long>(std::min<long long>(q1 - q0, 1ll << 22), 1);
+    if (cap < ctx->l0_cap_hint) cap = ctx->l0_cap_hint;
+    MiL0Counters h{};
+    int rc;
+    int32_t *oi = nullptr, *oj = nullptr;
+    double *os = nullptr, *op = nullptr;
+    for (int attempt = 0;; ++attempt) {
+        if ((rc = fw_dev_reserve(ctx, ctx->d_tmp0, sizeof(MiL0Counters)))) return rc;
+        if ((rc = fw_dev_reserve(ctx, ctx->d_tmp1, cap * 2 * sizeof(int32_t)))) return rc;
+        if ((rc = fw_dev_reserve(ctx, ctx->d_tmp2, cap * 2 * sizeof(double)))) return rc;
+        oi = (int32_t *)ctx->d_tmp1.ptr;
+        oj = oi + cap;
+        os = (double *)ctx->d_tmp2.ptr;
+        op = os + cap;
+        FW_HIP(ctx, hipMemsetAsync(ctx->d_tmp0.ptr, 0, sizeof(MiL0Counters), ctx->stream));
+        if (q1 > q0)
+            hipLaunchKernelGGL(mig_level0_kernel, dim3((unsigned)((q1 - q0 + 3) / 4)), dim3(256), 0, ctx->stream, P, p, q0, q1, ctx->P.alpha,
+                               (MiL0Counters *)ctx->d_tmp0.ptr, cap, oi, oj, os, op);
+        FW_HIP(ctx, hipGetLastError());
+        FW_HIP(ctx, hipMemcpyAsync(&h, ctx->d_tmp0.ptr, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->cnt.kernel_launches += 1;
+        if (h.n_sig > ctx->l0_cap_hint) ctx->l0_cap_hint = h.n_sig;
+        if (h.n_sig <= cap) break;
+        if (attempt == 1) return fw_fail(ctx, FW_ERR_DEVICE, "discrete level-0 (generic form): result buffer overflow twice");
+        cap = h.n_sig;
+    }
+    *m_reliable = npairs - (long long)h.n_unreliable;  // (sharded runs: this rank's share; fw_level0_sharded adds the ranks' counts up)
+    const size_t k = (size_t)h.n_sig;
+    pi.clear();
+    pj.clear();
+    stat.clear();
+    pval.clear();
+    if (dev) {
+        *dev = FwL0Dev{};
+        dev->i = oi;
+        dev->j = oj;
+        dev->stat64 = os;
+        dev->pval = op;
+        dev->k = k;
+        return FW_OK;
+    }
+    pi.resize(k);
+    pj.resize(k);
+    stat.resize(k);
+    pval.resize(k);
+    if (k) {
+        FW_HIP(ctx, hipMemcpy(pi.data(), oi, k * sizeof(int32_t), hipMemcpyDeviceToHost));
+        FW_HIP(ctx, hipMemcpy(pj.data(), oj, k * sizeof(int32_t), hipMemcpyDeviceToHost));
+        FW_HIP(ctx, hipMemcpy(stat.data(), os, k * sizeof(double), hipMemcpyDeviceToHost));
+        FW_HIP(ctx, hipMemcpy(pval.data(), op, k * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return FW_OK;
 }
 
 int fwi_mi_upload(fw_ctx *ctx, const int64_t *colptr, const int32_t *rowval, const int32_t *nzval)
@@ -665,6 +855,8 @@ int fwi_mi_upload(fw_ctx *ctx, const int64_t *colptr, const int32_t *rowval, con
     ctx->levels.assign(p, 0);
     ctx->max_vals.assign(p, 0);
     int maxv_all = 0;
+    bool generic = false;
+    ctx->mi_generic = false;
     for (int v = 0; v < p; ++v) {
         if (colptr[v + 1] < colptr[v]) return fw_fail(ctx, FW_ERR_ARG, "colptr not monotone at column %d", v);
         bool seen[4] = {false, false, false, false};
@@ -674,8 +866,12 @@ int fwi_mi_upload(fw_ctx *ctx, const int64_t *colptr, const int32_t *rowval, con
             const int32_t r = rowval[j], x = nzval[j];
             if (r < 0 || r >= n || r <= prev_row) return fw_fail(ctx, FW_ERR_ARG, "row indices of column %d are not sorted / in range", v);
             prev_row = r;
-            if (x < 1 || x > 2)
-                return fw_fail(ctx, FW_ERR_LIMIT, "discrete values must be 0, 1 or 2 (column %d holds %d); stored zeros are not allowed", v, x);
+            if (x < 1 || x >= MIG_MAX_L)
+                return fw_fail(ctx, FW_ERR_LIMIT, "discrete values must be 0 .. %d (column %d holds %d); stored zeros are not allowed", MIG_MAX_L - 1, v, x);
+            if (x > 2) {  // more than three levels somewhere: the generic form below
+                generic = true;
+                continue;
+            }
             seen[x] = true;
             mx = std::max(mx, x);
             nzb[(size_t)v * W + (r >> 6)] |= 1ull << (r & 63);
@@ -691,6 +887,7 @@ int fwi_mi_upload(fw_ctx *ctx, const int64_t *colptr, const int32_t *rowval, con
         ctx->max_vals[v] = mx;
         maxv_all = std::max(maxv_all, (int)mx);
     }
+    if (generic) return mig_upload(ctx, colptr, rowval, nzval);
     ctx->L = maxv_all + 1;  // types.jl:89,110
     if (ctx->L < 2) ctx->L = 2;
     // 9-cell tables only where X / Y can take three values inside the sub-table: "mi" on data that holds the value 2
@@ -801,6 +998,7 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
                   std::vector<double> &pval, int64_t *m_reliable, FwL0Dev *dev)
 {
     if (dev) *dev = FwL0Dev{};
+    if (ctx->mi_generic) return mig_level0(ctx, pi, pj, stat, pval, m_reliable, dev);
     const int p = ctx->P.p;
     const long long npairs = (long long)p * (p - 1) / 2;
     // G thresholds per df (df <= 4 at level 0): 0.999 * the alpha quantile -> everything below has p > alpha
@@ -911,7 +1109,9 @@ int fwi_mi_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const i
                        ctx->P.max_k, ctx->P.alpha, (long long)ctx->P.max_tests, d_ns, 0 /* HITON-PC never reads a rejected test's p */)
     const bool pre = ctx->P.n <= MI_PRE_N && ctx->P.max_k <= MI_PRE_K;
     const bool wide = ctx->P.n > 65535;  // 32-bit cell counts and tables (fw_mi_core.h)
-    if (ctx->L == 2) {
+    if (ctx->mi_generic) {
+        MI_SEG_LAUNCH(0, 2, false, false);
+    } else if (ctx->L == 2) {
         if (wide) MI_SEG_LAUNCH(2, 2, false, true); else if (pre) MI_SEG_LAUNCH(2, 2, true, false); else MI_SEG_LAUNCH(2, 2, false, false);
     } else if (ctx->mi_nxy == 2) {
         if (wide) MI_SEG_LAUNCH(3, 2, false, true); else if (pre) MI_SEG_LAUNCH(3, 2, true, false); else MI_SEG_LAUNCH(3, 2, false, false);
@@ -956,7 +1156,9 @@ int fwi_mi_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y
                        (long long)m, dX, dY, dz, (const int32_t *)ctx->d_acc.ptr, (fw_test_result *)ctx->d_out.ptr)
     const bool pre = ctx->P.n <= MI_PRE_N && kmax <= MI_PRE_K;  // the batch's own largest conditioning set decides here
     const bool wide = ctx->P.n > 65535;
-    if (ctx->L == 2) {
+    if (ctx->mi_generic) {
+        MI_TB_LAUNCH(0, 2, false, false);
+    } else if (ctx->L == 2) {
         if (wide) MI_TB_LAUNCH(2, 2, false, true); else if (pre) MI_TB_LAUNCH(2, 2, true, false); else MI_TB_LAUNCH(2, 2, false, false);
     } else if (ctx->mi_nxy == 2) {
         if (wide) MI_TB_LAUNCH(3, 2, false, true); else if (pre) MI_TB_LAUNCH(3, 2, true, false); else MI_TB_LAUNCH(3, 2, false, false);
@@ -990,7 +1192,9 @@ int fwi_mi_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_
                        d_acc, d_out, ctx->P.max_k, ctx->P.alpha, (long long)ctx->P.max_tests, (const unsigned *)nullptr, 1)
     const bool pre = ctx->P.n <= MI_PRE_N && ctx->P.max_k <= MI_PRE_K;
     const bool wide = ctx->P.n > 65535;  // 32-bit cell counts and tables (fw_mi_core.h)
-    if (ctx->L == 2) {
+    if (ctx->mi_generic) {
+        MI_SEG_LAUNCH(0, 2, false, false);
+    } else if (ctx->L == 2) {
         if (wide) MI_SEG_LAUNCH(2, 2, false, true); else if (pre) MI_SEG_LAUNCH(2, 2, true, false); else MI_SEG_LAUNCH(2, 2, false, false);
     } else if (ctx->mi_nxy == 2) {
         if (wide) MI_SEG_LAUNCH(3, 2, false, true); else if (pre) MI_SEG_LAUNCH(3, 2, true, false); else MI_SEG_LAUNCH(3, 2, false, false);

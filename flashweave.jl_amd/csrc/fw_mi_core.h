@@ -37,6 +37,7 @@ struct MiDev {
     int gthr_n;
     double alpha;
     unsigned long long *prof;  // profiling only (FW_MI_PROF=1, fw_test_batch): shader-clock cycles per phase, summed over tests
+    const unsigned char *vals;  // generic form (data with a value above 2, r04): one byte per (variable, sample), [p][n]; else null
 };
 
 struct MiRes {
@@ -530,6 +531,189 @@ static __device__ __forceinline__ MiRes mi_test_core(const MiDev &P, const int X
 }
 
 // ------------------------------------------------------------------------------------------------
+// GENERIC form (r04): discrete variables with MORE THAN THREE LEVELS (values 0 .. L - 1, L <= 8; the reference sizes its tables
+// L x L x L^max_k for any L, types.jl:98-117, misc.jl:64-97; reachable with make_onehot = false meta data, preprocessing.jl:42-117).
+// The bit-plane forms above hold two planes per variable; here the data is one byte per value and the wavefront bins row by row:
+// lane l takes rows l, l + 64, ... and adds 1 to cell [key][x][y] of a 32-bit LDS table (ds_add_u32; key = sum_j z_j L^j).  Everything
+// after the counting -- stratum occupancy, levels_z, power, mutual information, adjust_df -- is the same rule set as
+// mi_test_core, written with run-time loop bounds (sub-table = levels sx.. of X, sy.. of Y).  A slow path by design (meta-variable
+// scale problems): ~n / 64 LDS atomics per lane and test instead of a handful of popcounts.  tab: MIG_TAB32 32-bit words.
+// ------------------------------------------------------------------------------------------------
+#define MIG_MAX_L 8
+#define MIG_TAB32 3840  // words of one wavefront's table: L^k strata x (L^2 cells + the stratum total) must fit (host check)
+static __device__ __forceinline__ MiRes mi_test_core_gen(const MiDev &P, const int X_in, const int Y_in, const MiZs &zs_in, const int k_in,
+                                                         unsigned *tab)
+{
+    const int X = __builtin_amdgcn_readfirstlane(X_in), Y = __builtin_amdgcn_readfirstlane(Y_in);
+    const int k = __builtin_amdgcn_readfirstlane(k_in);
+    int zv[MI_MAX_K];
+#pragma unroll
+    for (int q = 0; q < MI_MAX_K; ++q) zv[q] = __builtin_amdgcn_readfirstlane(zs_in.v[q]);
+    const int lane = threadIdx.x & 63;
+    const int L = P.L, LL = L * L, NCT = LL + 1;
+    const bool flagX = P.nzmode && P.maxv[X] > 1, flagY = P.nzmode && P.maxv[Y] > 1;
+    const bool any_flag = flagX || flagY;
+    const bool special_k1 = (k == 1) && any_flag && !P.dense;  // contingency.jl:250-253 (sparse dispatch only)
+    const int sx = flagX ? 1 : 0, sy = flagY ? 1 : 0;
+    int lx, ly;
+    if (P.nzmode) {  // tests.jl:200-203
+        lx = L - sx;
+        ly = L - sy;
+    } else {
+        lx = P.levels[X];
+        ly = P.levels[Y];
+    }
+    MiRes res;
+    res.stat = 0.0;
+    res.pval = 1.0;
+    res.df = 0;
+    res.power = 0;
+    res.g = 0.0;
+    res.n_obs = 0;
+    if (k == 0) {  // tests.jl:36 sufficient_power(X, Y, data, ...) pre-check (tests.jl:9-20)
+        bool ok = (long long)P.n >= P.n_obs_min;
+        if (ok) {
+            const long long vx = P.levels[X], vy = P.levels[Y];
+            const long long ox = vx > 1 ? 2 : 1, oy = vy > 1 ? 2 : 1;
+            ok = ((double)P.n / (double)((vx - ox) * (vy - oy))) > (double)P.hps;
+        }
+        if (!ok) return res;
+    }
+    int S = 1;
+    for (int j = 0; j < k; ++j) S *= L;
+    const bool tot_sep = P.dense && any_flag;
+    const bool viewX = P.dense && P.view && P.nzmode && P.levels[X] > 2, viewY = P.dense && P.view && P.nzmode && P.levels[Y] > 2;
+    // ---- counting ----
+    for (int i = lane; i < S * NCT; i += 64) tab[i] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const size_t n = (size_t)P.n;
+    const unsigned char *cx = P.vals + (size_t)X * n, *cy = P.vals + (size_t)Y * n;
+    for (int r = lane; r < P.n; r += 64) {
+        const int x = cx[r], y = cy[r];
+        int key = 0, mul = 1;
+#pragma unroll
+        for (int j = 0; j < MI_MAX_K; ++j)
+            if (j < k) {
+                key += (int)P.vals[(size_t)zv[j] * n + r] * mul;
+                mul *= L;
+            }
+        const bool in_sub = (!flagX || x != 0) && (!flagY || y != 0);
+        const bool in_tab = P.dense ? ((!viewX || x != 0) && (!viewY || y != 0)) : in_sub;
+        if (in_sub) atomicAdd(&tab[key * NCT + x + L * y], 1u);
+        if (tot_sep && in_tab) atomicAdd(&tab[key * NCT + LL], 1u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- lanes <-> strata: occupancy, n_obs ----
+    int n_nonempty = 0, zmax = -1, key0_seen = 0;
+    long long n_obs = 0, n_counted = 0;
+    for (int base = 0; base < S; base += 64) {
+        const int key = base + lane;
+        if (key < S) {
+            const unsigned *t = tab + key * NCT;
+            int sub = 0;
+            for (int yy = sy; yy < L; ++yy)
+                for (int xx = sx; xx < L; ++xx) sub += (int)t[xx + L * yy];
+            const int tot = tot_sep ? (int)t[LL] : sub;
+            if (tot > 0) {
+                ++n_nonempty;
+                zmax = key;
+                if (key == 0) key0_seen = 1;
+            }
+            n_obs += sub;
+            n_counted += tot;
+        }
+    }
+    n_nonempty = wave_sum_i(n_nonempty);
+    key0_seen = __builtin_amdgcn_readlane(key0_seen, 0);
+    n_obs = wave_sum_ll(n_obs);
+    int levels_z;
+    if (k == 0) {
+        levels_z = 1;
+    } else if (special_k1) {
+        const int zm = wave_max_i(zmax);
+        levels_z = zm < 0 ? 1 : zm + 1;
+    } else if (any_flag && !P.dense) {
+        n_counted = wave_sum_ll(n_counted);
+        levels_z = n_nonempty + ((P.n - n_counted > 0 && !key0_seen) ? 1 : 0);
+    } else {
+        levels_z = n_nonempty;
+    }
+    bool power;
+    if (k == 0)
+        power = (n_obs >= P.n_obs_min) && (((double)n_obs / (double)((long long)lx * ly)) > (double)P.hps);
+    else
+        power = ((double)n_obs / (double)((long long)lx * ly * levels_z)) > (double)P.hps;
+    if (!power) return res;
+    // ---- mutual information: lanes <-> (stratum, cell) pairs; cell (i, j) = sub-table indices, table entry (sx + i, sy + j) ----
+    double pos = 0.0, neg = 0.0;
+    long long npos = 0, nneg = 0;
+    int df_part = 0;
+    const int npairs = S * LL;
+#define MIG_V(ii, jj) (((ii) < lx && (jj) < ly && sx + (ii) < L && sy + (jj) < L) ? (long long)t[(sx + (ii)) + L * (sy + (jj))] : 0ll)
+    for (int base = 0; base < npairs; base += 64) {
+        const int q = base + lane;
+        if (q < npairs) {
+            const int key = q / LL, c = q - key * LL;
+            const int i = c % L, j = c / L;
+            const unsigned *t = tab + key * NCT;
+            const long long mine = MIG_V(i, j);
+            if (mine != 0 || c == 0) {
+                long long my_mi = 0, my_mj = 0, mk = 0;
+                for (int u = 0; u < L; ++u) {
+                    my_mi += MIG_V(i, u);
+                    my_mj += MIG_V(u, j);
+                }
+                int alx = 0, aly = 0;
+                for (int u = 0; u < L; ++u) {
+                    long long ri = 0, cj = 0;
+                    for (int w = 0; w < L; ++w) {
+                        ri += MIG_V(u, w);
+                        cj += MIG_V(w, u);
+                    }
+                    mk += ri;
+                    alx += ri > 0;
+                    aly += cj > 0;
+                }
+                if (mine != 0 && my_mi != 0 && my_mj != 0) {
+                    const double denom_k = (k == 0) ? (double)n_obs : (double)mk;
+                    const double term = log((denom_k * (double)mine) / (double)(my_mi * my_mj)) * (double)mine;
+                    if (i == j) {
+                        pos += term;
+                        npos += mine;
+                    } else {
+                        neg += term;
+                        nneg += mine;
+                    }
+                }
+                if (c == 0) {  // adjust_df (statfuns.jl:281-297), once per stratum
+                    alx = alx < 1 ? 1 : alx;
+                    aly = aly < 1 ? 1 : aly;
+                    df_part += (alx - 1) * (aly - 1);
+                }
+            }
+        }
+    }
+#undef MIG_V
+    pos = wave_sum_d(pos);
+    neg = wave_sum_d(neg);
+    npos = wave_sum_ll(npos);
+    nneg = wave_sum_ll(nneg);
+    const int df = wave_sum_i(df_part);
+    const double nd_ = (k == 0) ? (double)n_obs : (double)(npos + nneg);
+    double mi = (pos + neg) / nd_;
+    if (neg * ((double)nneg / nd_) > pos * ((double)npos / nd_)) mi *= -1.0;
+    res.stat = mi;
+    res.pval = NAN;
+    res.df = df;
+    res.power = 1;
+    res.g = 2.0 * fabs(mi) * (double)n_obs;
+    res.n_obs = n_obs;
+    return res;
+}
+
+// ------------------------------------------------------------------------------------------------
 // FOUR tests per wavefront (r03): row r of 16 lanes (one DPP row) evaluates (X, Y | Zs_r) -- four consecutive subsets of one
 // test_subsets job, same X, Y and k.  n <= 5120 (lane i of a row owns the 32-row words i, i + 16, ..., i + 144 of every plane),
 // k <= 3, NXY = 2.  Why: at n = 5000 a lane of the one-test form holds 2.45 words per plane, and the wavefront spends more
@@ -861,6 +1045,7 @@ static __device__ __forceinline__ MiDev mi_uniform(const MiDev &P)
     U.gthr_n = __builtin_amdgcn_readfirstlane(P.gthr_n);
     U.alpha = __longlong_as_double((long long)mi_rfl64((unsigned long long)__double_as_longlong(P.alpha)));
     U.prof = (unsigned long long *)mi_rfl64((unsigned long long)P.prof);
+    U.vals = (const unsigned char *)mi_rfl64((unsigned long long)P.vals);
     return U;
 }
 

@@ -489,3 +489,85 @@ def test_more_than_65535_samples(kind, rows):
         eng.close()
     finally:
         del os.environ["FW_DEV_MIN_TARGETS"]
+
+
+def _multi_level_data(n, p, levels, seed, zero_frac=0.3):
+    rng = np.random.default_rng(seed)
+    lat = rng.standard_normal((n, 4))
+    x = lat @ rng.standard_normal((4, p)) + rng.standard_normal((n, p))
+    cuts = np.quantile(x, np.linspace(0, 1, levels + 1)[1:-1])
+    data = np.digitize(x, cuts).astype(np.int32)            # 0 .. levels - 1
+    data[rng.random((n, p)) < zero_frac] = 0
+    data[:, 0] = (data[:, 0] > 0).astype(np.int32)          # one binary and one three-level variable among them
+    data[:, 1] = np.minimum(data[:, 1], 2)
+    return np.ascontiguousarray(data)
+
+
+@pytest.mark.parametrize("kind", ["mi", "mi_nz"])
+@pytest.mark.parametrize("levels", [4, 5])
+def test_more_than_three_levels(kind, levels):
+    """Discrete variables with more than three levels (r04: the generic form -- one byte per value, 32-bit LDS tables of L x L x L^k
+    cells; the reference sizes its tables for any L, types.jl:98-117, misc.jl:64-97, reachable with make_onehot = false meta data,
+    preprocessing.jl:42-117).  Levels / max_vals, single tests of every conditioning-set size, test_subsets jobs, level 0 and the
+    network against the oracle (whose table code is the reference's for any L): integers exact, MI 1e-12, p 1e-10."""
+    n, p = 700, 40
+    data = _multi_level_data(n, p, levels, 100 + levels)
+    max_k = 3 if levels == 4 else 2                          # the table of a test must fit a wavefront's LDS slot: L^k (L^2 + 1) <= 3840
+    eng = fw.Engine(kind, n, p, max_k=max_k)
+    eng.set_data(data)
+    orc = O.Oracle(kind, data, sparse=True, max_k=max_k)
+    lev, mxv = eng.levels()
+    olev, omxv = orc.levels()
+    assert list(lev) == list(olev) and list(mxv) == list(omxv) and max(mxv) == levels - 1
+    nom = eng.n_obs_min
+    rng = np.random.default_rng(7)
+    X, Y, Zs = [], [], []
+    for _ in range(400):
+        k = int(rng.integers(0, max_k + 1))
+        v = rng.choice(p, size=k + 2, replace=False)
+        X.append(int(v[0])); Y.append(int(v[1])); Zs.append(tuple(int(t) for t in v[2:]))
+    got = eng.test_batch(X, Y, Zs)
+    npow = 0
+    for x, y, z, g in zip(X, Y, Zs, got):
+        s, pv, df, pw = orc.test(x, y, z, hps=5, n_obs_min=nom)
+        assert (g.df, g.suff_power) == (df, pw), (x, y, z, g, (s, pv, df, pw))
+        assert _close(g.stat, s, STOL) and _close(g.pval, pv, PTOL), (x, y, z, g, (s, pv, df, pw))
+        npow += pw
+    assert npow > 50
+    # test_subsets jobs
+    T, C, A = [], [], []
+    for _ in range(60):
+        v = rng.choice(p, size=int(rng.integers(3, 9)), replace=False)
+        T.append(int(v[0])); C.append(int(v[1])); A.append([int(t) for t in v[2:]])
+    res = eng.test_subsets_batch(T, C, A)
+    for t, c, a, g in zip(T, C, A, res):
+        e = orc.test_subsets(t, c, a, max_k=max_k, alpha=0.01, hps=5, n_obs_min=nom)
+        assert g["status"] == e["status"] and g["num_tests"] == e["num_tests"] and g["df"] == e["df"], (t, c, a, g, e)
+        assert _close(g["stat"], e["stat"], STOL) and _close(g["pval"], e["pval"], PTOL)
+    # level 0 and the network (host job pool: the persistent kernel holds two bit planes per variable)
+    got0 = eng.pw_univar_neighbors()
+    exp0 = orc.level0(alpha=0.01, hps=5, n_obs_min=nom)
+    assert (got0["off"] == exp0["off"]).all() and (got0["idx"] == exp0["idx"]).all() and len(exp0["idx"]) > 10
+    assert np.allclose(got0["stat"], exp0["stat"], rtol=1e-12, atol=1e-15) and np.allclose(got0["pval"], exp0["pval"], rtol=1e-10, atol=0.0)
+    for ff, R in ((False, 0), (True, 8)):
+        net = eng.lgl(feed_forward=ff, round_size=R)
+        exp = orc.learn(max_k=max_k, feed_forward=ff, round_size=R)
+        assert set(net["edges"]) == set(exp["edges"]) and len(exp["edges"]) > 3, (ff, len(net["edges"]), len(exp["edges"]))
+        for e_, w in exp["edges"].items():
+            assert _close(net["edges"][e_], w, STOL)
+        assert np.array_equal(net["pc_off"], exp["pc_off"]) and np.array_equal(net["pc_idx"], exp["pc_idx"])
+    eng.close()
+
+
+def test_more_than_three_levels_table_limit():
+    # L^max_k (L^2 + 1) words must fit the wavefront's LDS slot: six levels with max_k = 3 do not -> FW_ERR_LIMIT, loudly
+    data = _multi_level_data(200, 10, 6, 3)
+    eng = fw.Engine("mi", 200, 10, max_k=3)
+    with pytest.raises(fw.FlashWeaveError) as ei:
+        eng.set_data(data)
+    assert ei.value.code == -5  # FW_ERR_LIMIT
+    eng.close()
+    eng = fw.Engine("mi", 200, 10, max_k=2)
+    eng.set_data(data)                                       # 36 strata x 37 words: fits
+    assert eng.levels()[1].max() == 5
+    eng.close()
