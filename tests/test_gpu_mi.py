@@ -184,7 +184,7 @@ def test_csc_input_equals_dense_input(ctx):
 
 def test_rejects_unsupported_values():
     bad = np.zeros((50, 4), dtype=np.int32)
-    bad[:, 1] = 3
+    bad[:, 1] = 8  # 0..7 are served (values above 2: the generic form); 8 and negative values are not
     eng = fw.Engine("mi_nz", 50, 4)
     with pytest.raises(fw.FlashWeaveError) as ei:
         eng.set_data(bad)
