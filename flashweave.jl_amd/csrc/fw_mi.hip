@@ -367,10 +367,28 @@ struct MiCand {
 // G / 2 = sum_c c ln(c n / (m_i m_j)) = sum_c T[c] + S ln(n_obs) - sum_i T[m_i] - sum_j T[m_j] with T[x] = x ln x and
 // S = sum of the cells inside the level ranges: 15 lookups in a Float32 table of T plus one of ln instead of nine
 // logarithms (the power rules n / d > hps are evaluated as the equivalent integer comparison n > hps * d).
+// The integer / Float32 part of mi_pair_screen for the pair every HE table is made of (see the comment inside it), as its own function
+// for callers that screen in two passes (mi_level0_mfma_kernel): 1 = unreliable, 0 = cannot be significant, -1 = needs the full screen.
+__device__ __forceinline__ int mi_pair_prescreen(const MiDev &P, const int4 mX, const int4 mY, int A, int B, int C, int D, const double *gthr)
+{
+    const bool flagX = P.nzmode && mX.w > 1, flagY = P.nzmode && mY.w > 1;
+    if (!(flagX && flagY && P.L == 3)) return -1;
+    const int vx = mX.z, vy = mY.z;
+    const int ox = vx > 1 ? 2 : 1, oy = vy > 1 ? 2 : 1;
+    bool reliable = vx >= 2 && (long long)P.n >= P.n_obs_min && (long long)P.n > (long long)P.hps * (vx - ox) * (vy - oy);
+    reliable = reliable && (long long)A >= P.n_obs_min && (long long)A > (long long)P.hps * 4;
+    if (!reliable) return 1;
+    const int r1 = A - B, c1 = A - C;
+    if (r1 == 0 || B == 0 || c1 == 0 || C == 0) return 0;
+    const float det = (float)((long long)A * D - (long long)B * C);
+    const float lhs = 2.0f * (float)A * det * det, rhs = ((float)r1 * (float)B) * ((float)c1 * (float)C);
+    return (lhs < 0.98f * (float)gthr[1] * rhs) ? 0 : -1;
+}
+
 __device__ __forceinline__ int mi_pair_screen(const MiDev &P, const int4 mX, const int4 mY, int X, int Y, int A, int B, int C, int D,
                                               const float *__restrict__ xlnx, const float *__restrict__ lnx, const double *gthr,
                                               MiL0Counters *cnt, unsigned long long cap_c, MiCand *__restrict__ cands,
-                                              MiCand *s_q, int *s_qn)
+                                              MiCand *s_q, int *s_qn, int qcap = L0_QCAP)
 {
     const int L = P.L;
     const int nzX = mX.x, nzY = mY.x, hiX = mX.y, hiY = mY.y;
@@ -434,16 +452,37 @@ __device__ __forceinline__ int mi_pair_screen(const MiDev &P, const int4 mX, con
     aly = aly < 1 ? 1 : aly;
     const int df = (alx - 1) * (aly - 1);
     if (df == 0) return 0;  // p = 1
-    float g = 0.0f;
+    double g32;
+    if (xlnx) {
+        float g = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) g += xlnx[tv[i][j]];
-    g += (float)S * lnx[n_obs];
-    g -= (xlnx[mi_[0]] + xlnx[mi_[1]] + xlnx[mi_[2]]) + (xlnx[mj_[0]] + xlnx[mj_[1]] + xlnx[mj_[2]]);
-    // |g - G/2| <= 16 table roundings of <= 0.003 each at n <= 65536: far inside the margin below
-    const double g32 = 2.0 * fabs((double)g);
-    if (g32 < 0.99 * gthr[df] - (0.5 + 1e-4 * (double)P.n)) return 0;  // cannot reach the alpha quantile
+            for (int j = 0; j < 3; ++j) g += xlnx[tv[i][j]];
+        g += (float)S * lnx[n_obs];
+        g -= (xlnx[mi_[0]] + xlnx[mi_[1]] + xlnx[mi_[2]]) + (xlnx[mj_[0]] + xlnx[mj_[1]] + xlnx[mj_[2]]);
+        // |g - G/2| <= 16 table roundings of <= 0.003 each at n <= 65536: far inside the margin below
+        g32 = 2.0 * fabs((double)g);
+    } else {
+        // no tables (mi_level0_mfma_kernel: one wavefront per SIMD, where 16 look-ups in global memory are 16 exposed round trips):
+        // x log2 x from the hardware logarithm (v_log_f32, 1 ulp), summed in Float64, times ln 2 at the end.  A term is at most
+        // n log2 n with a relative error below 2^-22: 0.03 at n = 5 000, 0.5 at n = 65 535 -- 16 of them stay inside the margin below
+        // (1.0 resp. 7.0 in G).
+        auto T2 = [](int x) -> double { return x > 0 ? (double)((float)x * __log2f((float)x)) : 0.0; };
+        double g2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) g2 += T2(tv[i][j]);
+        g2 += (double)((float)S * __log2f((float)n_obs));
+        g2 -= (T2(mi_[0]) + T2(mi_[1]) + T2(mi_[2])) + (T2(mj_[0]) + T2(mj_[1]) + T2(mj_[2]));
+        g32 = 2.0 * 0.6931471805599453 * fabs(g2);
+        // tighter margin than the table form's: |g32 - G| <= 2 ln 2 x 16 terms x n log2 n x 2^-22 (0.33 at n = 5 000, 5.6 at 65 535)
+        const double fn = (double)P.n;
+        const double err = 2.0 * 0.6931471805599453 * 16.0 * fn * (double)__log2f((float)P.n) * 2.384185791015625e-07;
+        if (g32 < 0.99 * gthr[df] - (0.05 + 1.5 * err)) return 0;
+    }
+    if (xlnx && g32 < 0.99 * gthr[df] - (0.5 + 1e-4 * (double)P.n)) return 0;  // cannot reach the alpha quantile
     // candidates are queued per workgroup in LDS and appended to the global list with ONE atomic per workgroup (millions
     // of atomics on the one counter serialised the kernel: 46 of 66 ms at cfg4); overflow falls back to the direct append
     MiCand cd;
@@ -454,7 +493,7 @@ __device__ __forceinline__ int mi_pair_screen(const MiDev &P, const int4 mX, con
     cd.C = C;
     cd.D = D;
     const int qs = atomicAdd(s_qn, 1);
-    if (qs < L0_QCAP) {
+    if (qs < qcap) {
         s_q[qs] = cd;
     } else {
         const unsigned long long slot = atomicAdd(&cnt->n_sig, 1ull);  // n_sig doubles as the candidate counter in kernel 1
@@ -619,6 +658,272 @@ __global__ __launch_bounds__(256) void mi_level0_kernel(MiDev P, int p, int T, c
         if (s_qbase + (unsigned long long)q < cap_c) cands[s_qbase + q] = s_q[q];
 }
 
+// ------------------------------------------------------------------------------------------------
+// kernel 1, matrix-core form (r04; three-valued data, n <= 65 535).  The four counts of a pair are four entries of the Gram matrix
+// of the 2p bit planes over the n samples: A = <nzX, nzY>, B = <hiX, nzY>, C = <nzX, hiY>, D = <hiX, hiY> -- a binary GEMM that
+// the popcount form above runs at the integer-VALU peak (16 instructions per pair and 64-sample word: ~40 ms at cfg4 whatever the
+// tiling).  v_mfma_i32_32x32x32_i8 does 32 768 multiply-adds per ~32 cycles and SIMD, four times the popcount rate, and an int32
+// accumulator holds a count exactly.  Workgroup tile 128 x 128 variables, four wavefronts with 64 x 64 variables each = 2 x 2
+// blocks of 32 x 32 variables x 4 plane pairs = 16 accumulator tiles (256 registers: one wavefront per SIMD, the unified 512-
+// register file).  The bit planes are staged in LDS as 64-sample words (4 KB per word and tile side, double-buffered through
+// registers like the popcount form); every lane reads the 32-bit half-word of its operand row (lane & 31: the row, lane >> 5: which
+// half) and expands 16 bits to the 16 bytes of an operand register quadruple with v_bfe / v_mul_u32_u24 / v_and (bit i of a nibble
+// times 0x204081 lands on bit 8 i).  Any assignment of samples to the K index of the instruction is right as long as both operands
+// use the same one -- the sum over samples does not depend on their order -- so no layout table is involved beyond "row = lane & 31,
+// K group = lane >> 5" for both operands and the documented C layout (col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)).
+// The epilogue is the screen of the popcount form (mi_pair_screen) on counters parked in LDS, conflict-free ([entry][thread]).
+typedef int l0m_v4i __attribute__((ext_vector_type(4)));
+typedef int l0m_v16i __attribute__((ext_vector_type(16)));
+#define L0M_T 128
+#define L0M_WC 8      // 64-sample words per stage
+static_assert(L0M_T == 128 && L0M_WC == 8, "the staging map of mi_level0_mfma_kernel is written for 128-variable tiles and 8-word stages");
+#define L0M_S 8       // tiles per side of a super-tile (the unit of the XCD-aware order and of the sharded forms)
+#define L0M_QCAP 1024 // per-workgroup candidate queue
+#define L0M_SCAP 2048 // pairs per tile that pass the integer / Float32 verdicts and take the table look-ups (more: screened in place)
+
+__device__ __forceinline__ l0m_v4i l0m_expand16(unsigned w, int sh)
+{
+    l0m_v4i r;
+    r[0] = (int)(__umul24(__builtin_amdgcn_ubfe(w, sh, 4), 0x204081u) & 0x01010101u);
+    r[1] = (int)(__umul24(__builtin_amdgcn_ubfe(w, sh + 4, 4), 0x204081u) & 0x01010101u);
+    r[2] = (int)(__umul24(__builtin_amdgcn_ubfe(w, sh + 8, 4), 0x204081u) & 0x01010101u);
+    r[3] = (int)(__umul24(__builtin_amdgcn_ubfe(w, sh + 12, 4), 0x204081u) & 0x01010101u);
+    return r;
+}
+
+__global__ __launch_bounds__(256, 1) void mi_level0_mfma_kernel(MiDev P, int p, int T, const int32_t *__restrict__ cnt_nz,
+                                                               const int32_t *__restrict__ cnt_hi, const double *gthr,
+                                                               MiL0Counters *cnt, unsigned long long cap_c, MiCand *__restrict__ cands,
+                                                               const float *__restrict__ xlnx, const float *__restrict__ lnx, int dbg,
+                                                               int st_off, int st_end /* this launch's super-tiles */)
+{
+    // staging words [side][plane][var][L0M_WC + 1] (36 KB; the pad word makes the operand reads of 32 consecutive variables conflict-
+    // free) -- the same bytes hold the parked counters of the epilogue's overflow path ([32][256] ints = 32 KB)
+    __shared__ unsigned long long s_raw[2 * 2 * L0M_T * (L0M_WC + 1)];
+    __shared__ double s_gthr[8];
+    __shared__ int4 s_meta[2 * L0M_T];
+    __shared__ MiCand s_q[L0M_QCAP];
+    __shared__ int s_qn, s_nsw[4];
+    __shared__ unsigned char s_std[2 * L0M_T];
+    __shared__ unsigned long long s_qbase;
+    __shared__ uint4 s_surv[L0M_SCAP];  // {local X | local Y << 8, A | B << 16, C | D << 16, -}
+    unsigned long long(*sXY)[2][L0M_T][L0M_WC + 1] = (unsigned long long(*)[2][L0M_T][L0M_WC + 1])s_raw;  // [side]
+    // XCD-aware tile order: consecutive workgroups go round-robin to the eight XCDs, each with its own 4 MB L2.  The tile list is cut
+    // into SUPER-TILES of L0M_S x L0M_S tiles (16 x 128 variables x 2 planes x n / 8 bytes = 2.6 MB at n = 5 000: L2-resident) and the
+    // workgroups of one XCD (blockIdx & 7) work through the tiles of one super-tile after the other, so a column of bit planes crosses
+    // the fabric once per super-tile instead of once per tile (r04: the staging alone moved 25 GB at 2 TB/s, 12 of the kernel's 31 ms).
+    const int st = st_off + (int)(blockIdx.x >> 3) / (L0M_S * L0M_S) * 8 + (int)(blockIdx.x & 7);
+    if (st >= st_end) return;
+    const int TS = (T + L0M_S - 1) / L0M_S;
+    int sj = st, si = 0;
+    while (sj >= TS - si) {
+        sj -= TS - si;
+        ++si;
+    }
+    sj += si;
+    const int tin = (int)(blockIdx.x >> 3) % (L0M_S * L0M_S);
+    const int bi = si * L0M_S + tin / L0M_S, bj = sj * L0M_S + tin % L0M_S;
+    if (bi >= T || bj >= T || bi > bj) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wx = wave >> 1, wy = wave & 1;
+    if (tid < 8) s_gthr[tid] = gthr[tid];
+    if (tid == 0) s_qn = 0;
+    {
+        const int g = (tid < L0M_T ? bi : bj) * L0M_T + (tid & (L0M_T - 1));
+        s_meta[tid] = g < p ? make_int4(cnt_nz[g], cnt_hi[g], P.levels[g], P.maxv[g]) : make_int4(0, 0, 0, 0);
+    }
+    l0m_v16i acc[2][2][2][2];  // [X block][Y block][X plane][Y plane]
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q >> 3][(q >> 2) & 1][(q >> 1) & 1][q & 1][r] = 0;
+    // staging: a stage is 2 sides x 128 variables x 2 planes x L0M_WC words = 4 096 words, 16 per thread; element e = q * 256 + tid
+    // is (side q >> 3, variable (e & 2047) >> 4, plane (e >> 3) & 1, word e & 7): eight consecutive lanes read the 64 contiguous bytes
+    // of one (variable, plane) -- a wavefront's load touches 8 runs instead of 64 scattered words.  Addresses are clamped and the value
+    // zeroed by a select, so the 16 loads are unconditional.
+    unsigned long long rr[16];
+    auto fetch = [&](int w0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = (q & 7) * 256 + tid, side = q >> 3;
+            const int var = e >> 4, pl = (e >> 3) & 1, w = e & 7;
+            const int g = (side ? bj : bi) * L0M_T + var;
+            const bool ok = g < p && w0 + w < P.W && !(dbg & 2);
+            const unsigned long long *src = pl ? P.hi : P.nz;
+            const unsigned long long v = src[(size_t)(g < p ? g : p - 1) * P.W + (w0 + w < P.W ? w0 + w : P.W - 1)];
+            rr[q] = ok ? v : 0ull;
+        }
+    };
+    fetch(0);
+    const int rowX = wx * 64 + (lane & 31), rowY = wy * 64 + (lane & 31), half = lane >> 5;
+    // The expansion of the NEXT K step (96 VALU instructions) is issued between the 16 matrix instructions of the current one
+    // (sched_group_barrier: one MFMA, then six VALU): with one wavefront per SIMD nothing else would fill the matrix pipe's 32 cycles
+    // per instruction, and expansion + MFMA back to back was 1 800 cycles per 64-sample word instead of ~1 050.
+#define L0M_WORDS(dst, w)                                                                  \
+    {                                                                                      \
+        _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_) _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_) \
+        {                                                                                  \
+            dst[0][a_][pl_] = ((const unsigned *)&sXY[0][pl_][rowX + 32 * a_][w])[half];   \
+            dst[1][a_][pl_] = ((const unsigned *)&sXY[1][pl_][rowY + 32 * a_][w])[half];   \
+        }                                                                                  \
+    }
+#define L0M_EXPAND(fa_, fb_, src, sh)                                                      \
+    {                                                                                      \
+        _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_) _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_) \
+        {                                                                                  \
+            fa_[a_][pl_] = l0m_expand16(src[0][a_][pl_], sh);                              \
+            fb_[a_][pl_] = l0m_expand16(src[1][a_][pl_], sh);                              \
+        }                                                                                  \
+    }
+#define L0M_MFMA16(fa_, fb_)                                                               \
+    {                                                                                      \
+        _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_) _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_) \
+            _Pragma("unroll") for (int px_ = 0; px_ < 2; ++px_) _Pragma("unroll") for (int py_ = 0; py_ < 2; ++py_) \
+                acc[a_][b_][px_][py_] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa_[a_][px_], fb_[b_][py_], acc[a_][b_][px_][py_], 0, 0, 0); \
+    }
+    for (int w0 = 0; w0 < P.W; w0 += L0M_WC) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = (q & 7) * 256 + tid;
+            sXY[q >> 3][(e >> 3) & 1][e >> 4][e & 7] = rr[q];
+        }
+        __syncthreads();
+        if (w0 + L0M_WC < P.W) fetch(w0 + L0M_WC);
+        if (dbg & 4) continue;
+        unsigned cur[2][2][2], nxt[2][2][2];  // [side][block][plane]: this lane's 32 samples of its operand rows
+        l0m_v4i f0a[2][2], f0b[2][2], f1a[2][2], f1b[2][2];
+        L0M_WORDS(cur, 0);
+        L0M_EXPAND(f0a, f0b, cur, 0);
+#pragma unroll 1
+        for (int w = 0; w < L0M_WC; ++w) {
+            const int wn = w + 1 < L0M_WC ? w + 1 : w;  // the last step expands a word again instead of branching
+            L0M_WORDS(nxt, wn);
+            L0M_EXPAND(f1a, f1b, cur, 16);
+            L0M_MFMA16(f0a, f0b);
+            L0M_EXPAND(f0a, f0b, nxt, 0);
+            L0M_MFMA16(f1a, f1b);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cur[q >> 2][(q >> 1) & 1][q & 1] = nxt[q >> 2][(q >> 1) & 1][q & 1];
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            }
+        }
+    }
+#undef L0M_WORDS
+#undef L0M_EXPAND
+#undef L0M_MFMA16
+    __syncthreads();
+    if (dbg & 1) {
+        if (acc[0][0][0][0][0] + acc[1][1][1][1][15] == -12345) cnt->n_sig = 1;
+        return;
+    }
+    // Epilogue in two passes.  Pass 1 decides the pair every HE table is made of -- both variables nz-adjusted with three levels
+    // ("standard", one flag per variable) -- on integers and one Float32 inequality, BRANCH-FREE (the rules of mi_pair_prescreen as
+    // selects: with one wavefront per SIMD every divergent early return was a pipeline drain, 64 times per lane), reading the
+    // accumulators in place (fully unrolled).  Pairs that need the table look-ups -- and every pair with a non-standard variable --
+    // go to a survivor list in LDS: each wavefront fills its own quarter (ballot + lane rank: no atomics, no waits).  Pass 2 walks the
+    // lists densely with the full screen.  (One pass, pair by pair: every wavefront waited for the global-memory look-ups of its slowest
+    // lane in each of its 64 steps -- 31 ms at cfg4.)
+    int *s_cnt = (int *)s_raw;
+    int n_unrel = 0;
+    {
+        const int g = (tid < L0M_T ? bi : bj) * L0M_T + (tid & (L0M_T - 1));
+        const int4 m = s_meta[tid];
+        s_std[tid] = (g < p && P.nzmode && P.L == 3 && m.w > 1 && m.z == 3) ? 1 : 0;
+    }
+    __syncthreads();
+    const bool pre_ok = (long long)P.n >= P.n_obs_min && (long long)P.n > (long long)P.hps;  // tests.jl:9-20 for two three-level variables
+    const long long thrA64 = P.n_obs_min > (long long)P.hps * 4 + 1 ? P.n_obs_min : (long long)P.hps * 4 + 1;
+    const int thrA = thrA64 > 0x7fffffffll ? 0x7fffffff : (int)thrA64;  // reliable <=> A >= thrA
+    const float kthr = 0.98f * (float)s_gthr[1];
+    int my_ns = 0;  // survivors of this wavefront so far (wave-uniform)
+    const int seg0 = wave * (L0M_SCAP / 4);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        unsigned stdX = 0u;  // bit r: the X variable of accumulator register r is standard
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stdX |= (unsigned)s_std[wx * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half] << r;
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            const int lY = wy * 64 + 32 * bb + (lane & 31);
+            const int Y = bj * L0M_T + lY;
+            const bool stdY = s_std[L0M_T + lY] != 0;
+            unsigned ovf = 0u;  // pairs that found the survivor list full
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lX = wx * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int X = bi * L0M_T + lX;
+                const int cA = acc[a][bb][0][0][r], cB = acc[a][bb][1][0][r], cC = acc[a][bb][0][1][r], cD = acc[a][bb][1][1][r];
+                const bool valid = X < Y && Y < p;
+                const bool stdp = stdY && ((stdX >> r) & 1u);
+                const bool rel = pre_ok && cA >= thrA;
+                const int r1 = cA - cB, c1 = cA - cC;
+                const bool empty = r1 == 0 || cB == 0 || c1 == 0 || cC == 0;
+                // |A D - B C| from one fused multiply-add: A D enters exactly, B C rounded to 24 bits -- the bound below adds that
+                // rounding (<= 2^-24 B C) and the result's own (2^-24 |det|), so a pair is only dropped if its exact 2 X^2 is below
+                // the threshold (counts <= 65 535 are exact Float32 values)
+                const float fA = (float)cA, fB = (float)cB, fC = (float)cC, fD = (float)cD;
+                const float bc = fB * fC;
+                const float det = fabsf(__builtin_fmaf(fA, fD, -bc)) * 1.0000003f + 6.0e-8f * bc;
+                const float lhs = 2.0f * fA * det * det, rhs = ((float)r1 * fB) * ((float)c1 * fC);
+                const bool pass = !(lhs < kthr * rhs);
+                const bool surv = valid && (!stdp || (rel && !empty && pass));
+                n_unrel += (valid && stdp && !rel) ? 1 : 0;
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(surv);
+                if (bal) {
+                    const int slot = my_ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    if (surv) {
+                        if (slot < L0M_SCAP / 4)
+                            s_surv[seg0 + slot] = make_uint4((unsigned)lX | ((unsigned)lY << 8), (unsigned)cA | ((unsigned)cB << 16), (unsigned)cC | ((unsigned)cD << 16), 0u);
+                        else
+                            ovf |= 1u << r;
+                    }
+                    my_ns += __builtin_popcountll(bal);
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(ovf != 0u)) {  // rare (a wavefront with more than L0M_SCAP / 4 pairs for the tables): screened in place
+                const int4 mY = s_meta[L0M_T + lY];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s_cnt[(2 * r) * 256 + tid] = acc[a][bb][0][0][r] | (acc[a][bb][1][0][r] << 16);
+                    s_cnt[(2 * r + 1) * 256 + tid] = acc[a][bb][0][1][r] | (acc[a][bb][1][1][r] << 16);
+                }
+#pragma unroll 1
+                for (int r = 0; r < 16; ++r)
+                    if ((ovf >> r) & 1u) {
+                        const int lX = wx * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const unsigned ab = (unsigned)s_cnt[(2 * r) * 256 + tid], cd = (unsigned)s_cnt[(2 * r + 1) * 256 + tid];
+                        n_unrel += mi_pair_screen(P, s_meta[lX], mY, bi * L0M_T + lX, Y, (int)(ab & 0xffffu), (int)(ab >> 16), (int)(cd & 0xffffu), (int)(cd >> 16),
+                                                  (const float *)nullptr, (const float *)nullptr, s_gthr, cnt, cap_c, cands, s_q, &s_qn, L0M_QCAP);
+                    }
+            }
+        }
+    }
+    if (lane == 0) s_nsw[wave] = my_ns < L0M_SCAP / 4 ? my_ns : L0M_SCAP / 4;
+    __syncthreads();
+#pragma unroll 1
+    for (int sg = 0; sg < ((dbg & 8) ? 0 : 4); ++sg) {
+        const int ns = s_nsw[sg];
+        for (int q = tid; q < ns; q += 256) {
+            const uint4 e = s_surv[sg * (L0M_SCAP / 4) + q];
+            const int lX = (int)(e.x & 0xffu), lY = (int)(e.x >> 8);
+            n_unrel += mi_pair_screen(P, s_meta[lX], s_meta[L0M_T + lY], bi * L0M_T + lX, bj * L0M_T + lY, (int)(e.y & 0xffffu), (int)(e.y >> 16),
+                                      (int)(e.z & 0xffffu), (int)(e.z >> 16), (const float *)nullptr, (const float *)nullptr, s_gthr, cnt, cap_c, cands, s_q, &s_qn, L0M_QCAP);
+        }
+    }
+    n_unrel = wave_sum_i(n_unrel);
+    if (lane == 0 && n_unrel) atomicAdd(&cnt->n_unreliable, (unsigned long long)n_unrel);
+    __syncthreads();
+    const int nq = s_qn < L0M_QCAP ? s_qn : L0M_QCAP;
+    if (tid == 0 && nq > 0) s_qbase = atomicAdd(&cnt->n_sig, (unsigned long long)nq);
+    __syncthreads();
+    for (int q = tid; q < nq; q += 256)
+        if (s_qbase + (unsigned long long)q < cap_c) cands[s_qbase + q] = s_q[q];
+}
+
 __global__ __launch_bounds__(256) void mi_level0_exact_kernel(MiDev P, const MiCand *__restrict__ cands, unsigned long long ncand,
                                                               const int32_t *__restrict__ cnt_nz, const int32_t *__restrict__ cnt_hi,
                                                               double alpha, const double *gthr, MiL0Counters *cnt,
@@ -664,6 +969,8 @@ static MiDev mi_dev(const fw_ctx *ctx)
     P.prof = nullptr;
     P.view = 0;
     P.vals = ctx->mi_generic ? ctx->d_vals : nullptr;
+    static const int rowk = fw_knob("FW_MI_ROWK") ? atoi(fw_knob("FW_MI_ROWK")) : 2;  // 99: popcount form only (A/B)
+    P.rowk = rowk;
     return P;
 }
 
@@ -1019,8 +1326,17 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
         gthr[df] = 0.999 * lo;
     }
     int rc;
-    const int T = (p + L0_T - 1) / L0_T;
-    const int nblk_all = T * (T + 1) / 2;
+    // matrix-core form of kernel 1: three-valued data whose counts fit 16 bits (FW_L0_MFMA=0: the popcount form, for A/B runs)
+    // Default: the nz-adjusted kind (its pairs are decided by the branch-free first pass of the epilogue) from 1 024 variables on.
+    // FW_L0_MFMA=2 forces it wherever it is defined (tests: small tables, the plain three-valued kind through the overflow path).
+    const int l0_mfma_knob = fw_knob("FW_L0_MFMA") ? atoi(fw_knob("FW_L0_MFMA")) : 1;
+    const bool l0_mfma = l0_mfma_knob != 0 && ctx->d_hibits && ctx->P.n <= 65535 &&
+                         (l0_mfma_knob == 2 || (ctx->P.kind == FW_MI_NZ && p >= 1024));
+    const int l0_tile = l0_mfma ? L0M_T : L0_T;
+    const int T = (p + l0_tile - 1) / l0_tile;
+    // (matrix-core form: the unit a rank's share is counted in is the super-tile of L0M_S x L0M_S tiles)
+    const int TS = (T + L0M_S - 1) / L0M_S;
+    const int nblk_all = l0_mfma ? TS * (TS + 1) / 2 : (int)((long long)T * (T + 1) / 2);
     // target-sharded runs: every rank screens a contiguous range of the linearised upper-triangular tile list (tiles cost
     // the same: the list is balanced) and the significant pairs are all-gathered afterwards (fw_level0_sharded)
     const int b_off = (int)((long long)nblk_all * ctx->l0_rank / ctx->l0_world);
@@ -1041,6 +1357,9 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
         FW_HIP(ctx, hipMemcpyAsync(d_gthr, gthr, sizeof(gthr), hipMemcpyHostToDevice, ctx->stream));
         if (nblk == 0)
             ;  // more ranks than tiles: nothing to screen here
+        else if (l0_mfma)
+            hipLaunchKernelGGL(mi_level0_mfma_kernel, dim3((unsigned)(8 * ((nblk + 7) / 8) * L0M_S * L0M_S)), dim3(256), 0, ctx->stream, P, p, T, ctx->d_firstnz,
+                               ctx->d_firstnz + p, d_gthr, (MiL0Counters *)ctx->d_tmp0.ptr, cap_c, (MiCand *)ctx->d_jobs.ptr, ctx->d_xlnx, ctx->d_xlnx + (ctx->P.n + 1), l0_dbg, b_off, b_off + nblk);
         else if (ctx->d_hibits)
             hipLaunchKernelGGL(mi_level0_kernel<true>, dim3(nblk), dim3(256), 0, ctx->stream, P, p, T, ctx->d_firstnz,
                                ctx->d_firstnz + p, d_gthr, (MiL0Counters *)ctx->d_tmp0.ptr, cap_c, (MiCand *)ctx->d_jobs.ptr, ctx->d_xlnx, ctx->d_xlnx + (ctx->P.n + 1), l0_dbg, b_off);

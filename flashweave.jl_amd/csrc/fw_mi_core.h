@@ -38,6 +38,7 @@ struct MiDev {
     double alpha;
     unsigned long long *prof;  // profiling only (FW_MI_PROF=1, fw_test_batch): shader-clock cycles per phase, summed over tests
     const unsigned char *vals;  // generic form (data with a value above 2, r04): one byte per (variable, sample), [p][n]; else null
+    int rowk;  // smallest conditioning-set size for which the ROW form of the counting phase is considered (mi_bin_rows; 99: never)
 };
 
 struct MiRes {
@@ -144,6 +145,7 @@ static __device__ __forceinline__ int wave_max_i(int v)
 #undef MI_DPP_MAX
     return __builtin_amdgcn_readlane(v, 63);
 }
+static __device__ __forceinline__ unsigned mi_wave_max_u(unsigned v) { return (unsigned)wave_max_i((int)v); }
 static __device__ __forceinline__ double wave_sum_d(double v)
 {
 #define MI_DPP_ADDD(ctrl, rmask)                                                                               \
@@ -262,6 +264,54 @@ static __device__ __forceinline__ void mi_count_words(const MiWords<KM> &w, unsi
         }
 }
 
+// ROW form of the counting phase (r04).  The popcount form above costs strata x cells x words whatever the data holds: 27 x 4 x 3
+// AND + popcount pairs and 54 six-step DPP reductions for a k = 3 test at n = 5000 (~2 100 of its ~2 900 VALU instructions).  A lane
+// can instead walk the SET BITS of its own sub-table row mask -- in the nz-adjusted kinds only the rows where X and Y are both
+// non-zero (cfg4: a few hundred of 5 000) -- extract the k + 2 values of each row from the words it already holds and add 1 to the
+// [stratum][cell] entry of the wavefront's LDS table (ds_add_u32; two 16-bit counts per word unless WIDE).  Cost: ~26 instructions
+// per step, steps = the largest popcount of a lane's word.  Same table, same integers: everything after the counting is unchanged.
+template <int L, int NXY, int KM, bool WIDE>
+static __device__ __forceinline__ void mi_bin_rows(const MiWords<KM> &w, unsigned *tab32, int k, bool flagX, bool flagY)
+{
+    constexpr int NC = NXY * NXY;
+    constexpr int NCT16 = (NC + 2) & ~1;
+    unsigned m = w.vm;
+    if (flagX) m &= w.xn;
+    if (flagY) m &= w.yn;
+    const unsigned xu = flagX ? w.xh : w.xn, yu = flagY ? w.yh : w.yn;  // NXY == 2: the bit that tells the sub-table's two values apart
+    while (m) {
+        const int b = __builtin_ctz(m);
+        m &= m - 1u;
+        unsigned c;
+        if (NXY == 2)
+            c = ((xu >> b) & 1u) + 2u * ((yu >> b) & 1u);
+        else
+            c = ((w.xn >> b) & 1u) + ((w.xh >> b) & 1u) + 3u * (((w.yn >> b) & 1u) + ((w.yh >> b) & 1u));
+        unsigned key = 0u, mul = 1u;
+#pragma unroll
+        for (int j = 0; j < KM; ++j)
+            if (j < k) {
+                unsigned d = (w.zn[j] >> b) & 1u;
+                if (L == 3) d += (w.zh[j] >> b) & 1u;
+                key += d * mul;
+                mul *= (unsigned)L;
+            }
+        const unsigned idx = key * (unsigned)NCT16 + c;
+        if (WIDE)
+            __hip_atomic_fetch_add(tab32 + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        else
+            __hip_atomic_fetch_add(tab32 + (idx >> 1), 1u << ((idx & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+}
+template <int KM>
+static __device__ __forceinline__ int mi_row_steps(const MiWords<KM> &w, bool flagX, bool flagY)
+{
+    unsigned m = w.vm;
+    if (flagX) m &= w.xn;
+    if (flagY) m &= w.yn;
+    return (int)mi_wave_max_u((unsigned)__builtin_popcount(m));
+}
+
 // ------------------------------------------------------------------------------------------------
 // L = number of levels of the context (2 or 3); NXY = 2: X and Y take two values inside the sub-table (presence /
 // absence, or the two non-zero bins of an nz-adjusted variable) -> 4 cells per stratum; NXY = 3: 9 cells (mi on 3-valued data).
@@ -346,7 +396,41 @@ static __device__ __forceinline__ MiRes mi_test_core(const MiDev &P, const int X
 #pragma unroll
         for (int it = 0; it < NIT; ++it) mi_load_words<L, KM>(wd[it], pn, ph, xn, xh, yn, yh, W2, zs, k, it * 64 + lane, nd, P.n);
     }
-    for (int b = 0; b < nbatch; ++b) {
+    // row form or popcount form?  Both fill the same table; an estimate of their instruction counts decides (wave-uniform).
+    bool rowform = false;
+    if (!tot_sep && k >= P.rowk) {
+        const int nslot = (nd + 63) >> 6;
+        int steps;
+        if (PRE) {
+            steps = 0;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                if (it * 64 < nd) steps += mi_row_steps<KM>(wd[it], flagX, flagY);
+        } else {
+            mi_load_words<L, KM>(wd[0], pn, ph, xn, xh, yn, yh, W2, zs, 0, lane, nd, P.n);  // X and Y only: the first 2 048 rows stand for the rest
+            steps = mi_row_steps<KM>(wd[0], flagX, flagY) * nslot;
+        }
+        const int cost_rows = 40 + steps * (14 + 4 * k);
+        const int cost_pop = nbatch * (nslot * (SB * NC * 2 + 20) + SB * ((NC + 1) / 2) * 7);
+        rowform = cost_rows < cost_pop;
+    }
+    if (rowform) {
+        const int nw = (S * NCT16 * (int)sizeof(TabT)) >> 2;
+        for (int q = lane; q < nw; q += 64) tab32[q] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (PRE) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                if (it * 64 < nd) mi_bin_rows<L, NXY, KM, WIDE>(wd[it], tab32, k, flagX, flagY);
+        } else {
+            for (int d0 = 0; d0 < nd; d0 += 64) {
+                mi_load_words<L, KM>(wd[0], pn, ph, xn, xh, yn, yh, W2, zs, k, d0 + lane, nd, P.n);
+                mi_bin_rows<L, NXY, KM, WIDE>(wd[0], tab32, k, flagX, flagY);
+            }
+        }
+    }
+    for (int b = 0; b < (rowform ? 0 : nbatch); ++b) {
         unsigned acc[SBMAX][NCT];
 #pragma unroll
         for (int s = 0; s < SBMAX; ++s)
@@ -1046,6 +1130,7 @@ static __device__ __forceinline__ MiDev mi_uniform(const MiDev &P)
     U.alpha = __longlong_as_double((long long)mi_rfl64((unsigned long long)__double_as_longlong(P.alpha)));
     U.prof = (unsigned long long *)mi_rfl64((unsigned long long)P.prof);
     U.vals = (const unsigned char *)mi_rfl64((unsigned long long)P.vals);
+    U.rowk = __builtin_amdgcn_readfirstlane(P.rowk);
     return U;
 }
 

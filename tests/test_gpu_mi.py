@@ -140,6 +140,32 @@ def test_level0(ctx):
     assert len(exp["idx"]) > 0
 
 
+@pytest.mark.parametrize("kind", ["mi_nz", "mi"])
+def test_level0_matrix_core_form_equals_oracle(kind, monkeypatch):
+    """mi_level0_mfma_kernel (r04: the pair counts as an int8 matrix-core Gram product, 128 x 128 tiles; default for mi_nz from 1 024
+    variables on) forced on a small table: several tiles incl. diagonal ones and a ragged last tile, binary meta variables (pairs the
+    branch-free first pass hands to the full screen), and for the plain three-valued kind EVERY pair through the survivor-list overflow
+    path.  Lists, statistics and p-values against the oracle, and the same bytes as the popcount form."""
+    data = _synth(kind, 300, 400, 29)
+    n, p = data.shape
+    res = {}
+    for knob in ("2", "0"):
+        monkeypatch.setenv("FW_L0_MFMA", knob)
+        eng = fw.Engine(kind, n, p, max_k=3)
+        eng.set_data(data)
+        res[knob] = eng.pw_univar_neighbors()
+        res[knob + "m"] = eng.counters()["level0_tests"]
+        nom = eng.n_obs_min
+        eng.close()
+    exp = O.Oracle(kind, data, sparse=True, max_k=3).level0(alpha=0.01, hps=5, n_obs_min=nom)
+    got = res["2"]
+    assert (got["off"] == exp["off"]).all() and (got["idx"] == exp["idx"]).all() and len(exp["idx"]) > 100
+    assert np.allclose(got["stat"], exp["stat"], rtol=STOL, atol=0) and np.allclose(got["pval"], exp["pval"], rtol=PTOL, atol=0)
+    for f in ("off", "idx", "stat", "pval"):
+        assert np.array_equal(got[f], res["0"][f]), f
+    assert res["2m"] == res["0m"] == p * (p - 1) // 2
+
+
 @pytest.mark.parametrize("ff,R", [(False, 0), (True, 1), (True, 16)])
 def test_network_matches_oracle(ctx, ff, R):
     kind, data, n, p, orc = ctx["kind"], ctx["data"], ctx["n"], ctx["p"], ctx["orc"]
