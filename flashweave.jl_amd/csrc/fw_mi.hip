@@ -331,11 +331,16 @@ __device__ __forceinline__ void mi_pair_epilogue(const MiDev &P, int X, int Y, i
                 pval = 1.0;  // any value >= alpha: never looked at again
         }
     }
-    // (unreliable pairs were already counted by the screening kernel)
+    // Unreliable pairs are counted by the screening kernel -- except those it hands over UNSCREENED (mi_level0_mfma_kernel when a
+    // survivor list is full): a screened candidate is reliable by construction, so whatever is unreliable here has not been counted.
+    const int lane = threadIdx.x & 63;
+    {
+        const unsigned long long um = __ballot(unreliable);
+        if (um != 0ull && lane == __ffsll((long long)um) - 1) atomicAdd(&cnt->n_unreliable, (unsigned long long)__popcll(um));
+    }
     const bool keep = !unreliable && pval < alpha;
     const unsigned long long km = __ballot(keep);  // one atomic per wavefront
     unsigned long long base = 0;
-    const int lane = threadIdx.x & 63;
     if (km != 0ull) {
         const int leader = __ffsll((long long)km) - 1;
         if (lane == leader) base = atomicAdd(&cnt->n_sig, (unsigned long long)__popcll(km));
@@ -681,21 +686,26 @@ static_assert(L0M_T == 128 && L0M_WC == 8, "the staging map of mi_level0_mfma_ke
 #define L0M_QCAP 1024 // per-workgroup candidate queue
 #define L0M_SCAP 2048 // pairs per tile that pass the integer / Float32 verdicts and take the table look-ups (more: screened in place)
 
-__device__ __forceinline__ l0m_v4i l0m_expand16(unsigned w, int sh)
+// Four operand registers (16 bytes of 0 / 1) from this lane's 32 samples, K step ks (0 / 1): register q holds bit 4 ks + q of
+// each of the four bytes of the word -- (w >> (4 ks + q)) & 0x01010101, two instructions.  Which sample lands on which K index
+// is immaterial as long as both operands use the same map (the sum over samples does not depend on their order); over the two K
+// steps and four registers every bit of the word is used exactly once.
+__device__ __forceinline__ l0m_v4i l0m_expand16(unsigned w, int ks)
 {
     l0m_v4i r;
-    r[0] = (int)(__umul24(__builtin_amdgcn_ubfe(w, sh, 4), 0x204081u) & 0x01010101u);
-    r[1] = (int)(__umul24(__builtin_amdgcn_ubfe(w, sh + 4, 4), 0x204081u) & 0x01010101u);
-    r[2] = (int)(__umul24(__builtin_amdgcn_ubfe(w, sh + 8, 4), 0x204081u) & 0x01010101u);
-    r[3] = (int)(__umul24(__builtin_amdgcn_ubfe(w, sh + 12, 4), 0x204081u) & 0x01010101u);
+    r[0] = (int)((w >> (4 * ks)) & 0x01010101u);
+    r[1] = (int)((w >> (4 * ks + 1)) & 0x01010101u);
+    r[2] = (int)((w >> (4 * ks + 2)) & 0x01010101u);
+    r[3] = (int)((w >> (4 * ks + 3)) & 0x01010101u);
     return r;
 }
 
 __global__ __launch_bounds__(256, 1) void mi_level0_mfma_kernel(MiDev P, int p, int T, const int32_t *__restrict__ cnt_nz,
                                                                const int32_t *__restrict__ cnt_hi, const double *gthr,
                                                                MiL0Counters *cnt, unsigned long long cap_c, MiCand *__restrict__ cands,
-                                                               const float *__restrict__ xlnx, const float *__restrict__ lnx, int dbg,
-                                                               int st_off, int st_end /* this launch's super-tiles */)
+                                                               int dbg,
+                                                               int st_off, int st_end /* this launch's super-tiles */,
+                                                               unsigned long long *prof /* FW_L0_VERBOSE: shader cycles per phase, else null */)
 {
     // staging words [side][plane][var][L0M_WC + 1] (36 KB; the pad word makes the operand reads of 32 consecutive variables conflict-
     // free) -- the same bytes hold the parked counters of the epilogue's overflow path ([32][256] ints = 32 KB)
@@ -725,6 +735,7 @@ __global__ __launch_bounds__(256, 1) void mi_level0_mfma_kernel(MiDev P, int p, 
     const int bi = si * L0M_S + tin / L0M_S, bj = sj * L0M_S + tin % L0M_S;
     if (bi >= T || bj >= T || bi > bj) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wx = wave >> 1, wy = wave & 1;
+    const unsigned long long pt0 = prof ? __builtin_readcyclecounter() : 0ull;
     if (tid < 8) s_gthr[tid] = gthr[tid];
     if (tid == 0) s_qn = 0;
     {
@@ -798,7 +809,7 @@ __global__ __launch_bounds__(256, 1) void mi_level0_mfma_kernel(MiDev P, int p, 
         for (int w = 0; w < L0M_WC; ++w) {
             const int wn = w + 1 < L0M_WC ? w + 1 : w;  // the last step expands a word again instead of branching
             L0M_WORDS(nxt, wn);
-            L0M_EXPAND(f1a, f1b, cur, 16);
+            L0M_EXPAND(f1a, f1b, cur, 1);
             L0M_MFMA16(f0a, f0b);
             L0M_EXPAND(f0a, f0b, nxt, 0);
             L0M_MFMA16(f1a, f1b);
@@ -808,7 +819,7 @@ __global__ __launch_bounds__(256, 1) void mi_level0_mfma_kernel(MiDev P, int p, 
 #pragma unroll
             for (int q = 0; q < 32; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
             }
         }
     }
@@ -816,6 +827,7 @@ __global__ __launch_bounds__(256, 1) void mi_level0_mfma_kernel(MiDev P, int p, 
 #undef L0M_EXPAND
 #undef L0M_MFMA16
     __syncthreads();
+    const unsigned long long pt1 = prof ? __builtin_readcyclecounter() : 0ull;
     if (dbg & 1) {
         if (acc[0][0][0][0][0] + acc[1][1][1][1][15] == -12345) cnt->n_sig = 1;
         return;
@@ -841,68 +853,82 @@ __global__ __launch_bounds__(256, 1) void mi_level0_mfma_kernel(MiDev P, int p, 
     const float kthr = 0.98f * (float)s_gthr[1];
     int my_ns = 0;  // survivors of this wavefront so far (wave-uniform)
     const int seg0 = wave * (L0M_SCAP / 4);
+    int n_unrel_w = 0;  // wave-uniform count of unreliable pairs (popcounts of lane masks: no vector adds)
+    // FAST tiles -- off the diagonal, inside the table, every variable standard: all but the last tile row / column and the
+    // diagonal -- need neither the index tests nor the flags: ~25 vector instructions per pair instead of ~80.
+    const bool fast_tile = bi < bj && (bj + 1) * L0M_T <= p && __syncthreads_and(s_std[tid] != 0);
+    auto pass1 = [&](auto fast_c) {
+        constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        unsigned stdX = 0u;  // bit r: the X variable of accumulator register r is standard
+        for (int a = 0; a < 2; ++a) {
+            unsigned stdX = 0u;  // bit r: the X variable of accumulator register r is standard
+            if (!FAST) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) stdX |= (unsigned)s_std[wx * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half] << r;
-#pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
-            const int lY = wy * 64 + 32 * bb + (lane & 31);
-            const int Y = bj * L0M_T + lY;
-            const bool stdY = s_std[L0M_T + lY] != 0;
-            unsigned ovf = 0u;  // pairs that found the survivor list full
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lX = wx * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int X = bi * L0M_T + lX;
-                const int cA = acc[a][bb][0][0][r], cB = acc[a][bb][1][0][r], cC = acc[a][bb][0][1][r], cD = acc[a][bb][1][1][r];
-                const bool valid = X < Y && Y < p;
-                const bool stdp = stdY && ((stdX >> r) & 1u);
-                const bool rel = pre_ok && cA >= thrA;
-                const int r1 = cA - cB, c1 = cA - cC;
-                const bool empty = r1 == 0 || cB == 0 || c1 == 0 || cC == 0;
-                // |A D - B C| from one fused multiply-add: A D enters exactly, B C rounded to 24 bits -- the bound below adds that
-                // rounding (<= 2^-24 B C) and the result's own (2^-24 |det|), so a pair is only dropped if its exact 2 X^2 is below
-                // the threshold (counts <= 65 535 are exact Float32 values)
-                const float fA = (float)cA, fB = (float)cB, fC = (float)cC, fD = (float)cD;
-                const float bc = fB * fC;
-                const float det = fabsf(__builtin_fmaf(fA, fD, -bc)) * 1.0000003f + 6.0e-8f * bc;
-                const float lhs = 2.0f * fA * det * det, rhs = ((float)r1 * fB) * ((float)c1 * fC);
-                const bool pass = !(lhs < kthr * rhs);
-                const bool surv = valid && (!stdp || (rel && !empty && pass));
-                n_unrel += (valid && stdp && !rel) ? 1 : 0;
-                const unsigned long long bal = __builtin_amdgcn_ballot_w64(surv);
-                if (bal) {
-                    const int slot = my_ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                    if (surv) {
-                        if (slot < L0M_SCAP / 4)
-                            s_surv[seg0 + slot] = make_uint4((unsigned)lX | ((unsigned)lY << 8), (unsigned)cA | ((unsigned)cB << 16), (unsigned)cC | ((unsigned)cD << 16), 0u);
-                        else
-                            ovf |= 1u << r;
-                    }
-                    my_ns += __builtin_popcountll(bal);
-                }
+                for (int r = 0; r < 16; ++r) stdX |= (unsigned)s_std[wx * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half] << r;
             }
-            if (__builtin_amdgcn_ballot_w64(ovf != 0u)) {  // rare (a wavefront with more than L0M_SCAP / 4 pairs for the tables): screened in place
-                const int4 mY = s_meta[L0M_T + lY];
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int lY = wy * 64 + 32 * bb + (lane & 31);
+                const int Y = bj * L0M_T + lY;
+                const bool stdY = FAST || s_std[L0M_T + lY] != 0;
+                unsigned ovf = 0u;  // pairs that found the survivor list full
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    s_cnt[(2 * r) * 256 + tid] = acc[a][bb][0][0][r] | (acc[a][bb][1][0][r] << 16);
-                    s_cnt[(2 * r + 1) * 256 + tid] = acc[a][bb][0][1][r] | (acc[a][bb][1][1][r] << 16);
-                }
-#pragma unroll 1
-                for (int r = 0; r < 16; ++r)
-                    if ((ovf >> r) & 1u) {
-                        const int lX = wx * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        const unsigned ab = (unsigned)s_cnt[(2 * r) * 256 + tid], cd = (unsigned)s_cnt[(2 * r + 1) * 256 + tid];
-                        n_unrel += mi_pair_screen(P, s_meta[lX], mY, bi * L0M_T + lX, Y, (int)(ab & 0xffffu), (int)(ab >> 16), (int)(cd & 0xffffu), (int)(cd >> 16),
-                                                  (const float *)nullptr, (const float *)nullptr, s_gthr, cnt, cap_c, cands, s_q, &s_qn, L0M_QCAP);
+                    const int lX = wx * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int X = bi * L0M_T + lX;
+                    const int cA = acc[a][bb][0][0][r], cB = acc[a][bb][1][0][r], cC = acc[a][bb][0][1][r], cD = acc[a][bb][1][1][r];
+                    const bool valid = FAST || (X < Y && Y < p);
+                    const bool stdp = FAST || (stdY && ((stdX >> r) & 1u));
+                    const bool rel = pre_ok && cA >= thrA;
+                    // |A D - B C| from one fused multiply-add: A D enters exactly, B C rounded to 24 bits -- the bound adds that
+                    // rounding (<= 2^-24 B C) and the result's own (2^-24 |det|), so a pair is only dropped if its exact 2 X^2 is
+                    // below the threshold (counts <= 65 535 are exact Float32 values).  An empty marginal (df = 0, p = 1) makes the
+                    // right-hand side zero.
+                    const float fA = (float)cA, fB = (float)cB, fC = (float)cC, fD = (float)cD;
+                    const float bc = fB * fC;
+                    const float det = fabsf(__builtin_fmaf(fA, fD, -bc)) * 1.0000003f + 6.0e-8f * bc;
+                    const float lhs = 2.0f * fA * det * det, rhs = ((fA - fB) * fB) * ((fA - fC) * fC);
+                    const bool pass = rhs > 0.0f && !(lhs < kthr * rhs);
+                    const bool surv = valid && (!stdp || (rel && pass));
+                    n_unrel_w += __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid && stdp && !rel));
+                    const unsigned long long bal = __builtin_amdgcn_ballot_w64(surv);
+                    if (bal) {
+                        const int slot = my_ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                        if (surv) {
+                            if (slot < L0M_SCAP / 4)
+                                s_surv[seg0 + slot] = make_uint4((unsigned)lX | ((unsigned)lY << 8), (unsigned)cA | ((unsigned)cB << 16), (unsigned)cC | ((unsigned)cD << 16), 0u);
+                            else
+                                ovf |= 1u << r;
+                        }
+                        my_ns += __builtin_popcountll(bal);
                     }
+                }
+                if (__builtin_amdgcn_ballot_w64(ovf != 0u)) {  // rare (a wavefront with more than L0M_SCAP / 4 pairs for the tables): screened in place
+                    const int4 mY = s_meta[L0M_T + lY];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        s_cnt[(2 * r) * 256 + tid] = acc[a][bb][0][0][r] | (acc[a][bb][1][0][r] << 16);
+                        s_cnt[(2 * r + 1) * 256 + tid] = acc[a][bb][0][1][r] | (acc[a][bb][1][1][r] << 16);
+                    }
+#pragma unroll 1
+                    for (int r = 0; r < 16; ++r)
+                        if ((ovf >> r) & 1u) {
+                            const int lX = wx * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            const unsigned ab = (unsigned)s_cnt[(2 * r) * 256 + tid], cd = (unsigned)s_cnt[(2 * r + 1) * 256 + tid];
+                            n_unrel += mi_pair_screen(P, s_meta[lX], mY, bi * L0M_T + lX, Y, (int)(ab & 0xffffu), (int)(ab >> 16), (int)(cd & 0xffffu), (int)(cd >> 16),
+                                                      (const float *)nullptr, (const float *)nullptr, s_gthr, cnt, cap_c, cands, s_q, &s_qn, L0M_QCAP);
+                        }
+                }
             }
         }
-    }
+    };
+    if (fast_tile)
+        pass1(std::true_type{});
+    else
+        pass1(std::false_type{});
+    if (lane == 0) n_unrel += n_unrel_w;
     if (lane == 0) s_nsw[wave] = my_ns < L0M_SCAP / 4 ? my_ns : L0M_SCAP / 4;
+    const unsigned long long pt2 = prof ? __builtin_readcyclecounter() : 0ull;
     __syncthreads();
 #pragma unroll 1
     for (int sg = 0; sg < ((dbg & 8) ? 0 : 4); ++sg) {
@@ -914,6 +940,7 @@ __global__ __launch_bounds__(256, 1) void mi_level0_mfma_kernel(MiDev P, int p, 
                                       (int)(e.z & 0xffffu), (int)(e.z >> 16), (const float *)nullptr, (const float *)nullptr, s_gthr, cnt, cap_c, cands, s_q, &s_qn, L0M_QCAP);
         }
     }
+    const unsigned long long pt3 = prof ? __builtin_readcyclecounter() : 0ull;
     n_unrel = wave_sum_i(n_unrel);
     if (lane == 0 && n_unrel) atomicAdd(&cnt->n_unreliable, (unsigned long long)n_unrel);
     __syncthreads();
@@ -922,6 +949,14 @@ __global__ __launch_bounds__(256, 1) void mi_level0_mfma_kernel(MiDev P, int p, 
     __syncthreads();
     for (int q = tid; q < nq; q += 256)
         if (s_qbase + (unsigned long long)q < cap_c) cands[s_qbase + q] = s_q[q];
+    if (prof && tid == 0) {
+        atomicAdd(prof + 0, pt1 - pt0);
+        atomicAdd(prof + 1, pt2 - pt1);
+        atomicAdd(prof + 2, pt3 - pt2);
+        atomicAdd(prof + 3, __builtin_readcyclecounter() - pt3);
+        atomicAdd(prof + 4, 1ull);
+        atomicAdd(prof + 5, (unsigned long long)(s_nsw[0] + s_nsw[1] + s_nsw[2] + s_nsw[3]));
+    }
 }
 
 __global__ __launch_bounds__(256) void mi_level0_exact_kernel(MiDev P, const MiCand *__restrict__ cands, unsigned long long ncand,
@@ -1350,16 +1385,19 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
     MiL0Counters h1{};
     double *d_gthr = nullptr;
     for (int attempt = 0;; ++attempt) {
-        if ((rc = fw_dev_reserve(ctx, ctx->d_tmp0, 2 * sizeof(MiL0Counters) + 8 * sizeof(double)))) return rc;
+        if ((rc = fw_dev_reserve(ctx, ctx->d_tmp0, 2 * sizeof(MiL0Counters) + 8 * sizeof(double) + 8 * sizeof(unsigned long long)))) return rc;
         if ((rc = fw_dev_reserve(ctx, ctx->d_jobs, cap_c * sizeof(MiCand)))) return rc;
         FW_HIP(ctx, hipMemsetAsync(ctx->d_tmp0.ptr, 0, 2 * sizeof(MiL0Counters), ctx->stream));
         d_gthr = (double *)((char *)ctx->d_tmp0.ptr + 2 * sizeof(MiL0Counters));
+        unsigned long long *d_prof = (unsigned long long *)(d_gthr + 8);
+        const bool l0_prof = l0_mfma && fw_knob("FW_L0_VERBOSE");
+        if (l0_prof) FW_HIP(ctx, hipMemsetAsync(d_prof, 0, 8 * sizeof(unsigned long long), ctx->stream));
         FW_HIP(ctx, hipMemcpyAsync(d_gthr, gthr, sizeof(gthr), hipMemcpyHostToDevice, ctx->stream));
         if (nblk == 0)
             ;  // more ranks than tiles: nothing to screen here
         else if (l0_mfma)
             hipLaunchKernelGGL(mi_level0_mfma_kernel, dim3((unsigned)(8 * ((nblk + 7) / 8) * L0M_S * L0M_S)), dim3(256), 0, ctx->stream, P, p, T, ctx->d_firstnz,
-                               ctx->d_firstnz + p, d_gthr, (MiL0Counters *)ctx->d_tmp0.ptr, cap_c, (MiCand *)ctx->d_jobs.ptr, ctx->d_xlnx, ctx->d_xlnx + (ctx->P.n + 1), l0_dbg, b_off, b_off + nblk);
+                               ctx->d_firstnz + p, d_gthr, (MiL0Counters *)ctx->d_tmp0.ptr, cap_c, (MiCand *)ctx->d_jobs.ptr, l0_dbg, b_off, b_off + nblk, l0_prof ? d_prof : nullptr);
         else if (ctx->d_hibits)
             hipLaunchKernelGGL(mi_level0_kernel<true>, dim3(nblk), dim3(256), 0, ctx->stream, P, p, T, ctx->d_firstnz,
                                ctx->d_firstnz + p, d_gthr, (MiL0Counters *)ctx->d_tmp0.ptr, cap_c, (MiCand *)ctx->d_jobs.ptr, ctx->d_xlnx, ctx->d_xlnx + (ctx->P.n + 1), l0_dbg, b_off);
@@ -1370,6 +1408,13 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
         FW_HIP(ctx, hipMemcpyAsync(&h1, ctx->d_tmp0.ptr, sizeof(h1), hipMemcpyDeviceToHost, ctx->stream));
         FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->cnt.kernel_launches += 1;
+        if (l0_prof) {
+            unsigned long long hp[8];
+            FW_HIP(ctx, hipMemcpy(hp, d_prof, sizeof(hp), hipMemcpyDeviceToHost));
+            const double nt = (double)std::max<unsigned long long>(hp[4], 1);
+            fprintf(stderr, "[fw] mi_level0_mfma_kernel, shader cycles per tile (%llu tiles): staging + matrix loop %.0f, first pass %.0f, second pass %.0f, queue %.0f; pairs for the second pass per tile %.0f\n",
+                    hp[4], hp[0] / nt, hp[1] / nt, hp[2] / nt, hp[3] / nt, hp[5] / nt);
+        }
         if (h1.n_sig > ctx->l0_cap_hint) ctx->l0_cap_hint = h1.n_sig;
         if (h1.n_sig <= cap_c) break;
         if (attempt == 1) return fw_fail(ctx, FW_ERR_DEVICE, "discrete level-0: candidate buffer overflow twice");
@@ -1397,6 +1442,7 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
     FW_HIP(ctx, hipMemcpyAsync(&h2, d_cnt2, sizeof(h2), hipMemcpyDeviceToHost, ctx->stream));
     FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cnt.kernel_launches += 1;
+    *m_reliable -= (long long)h2.n_unreliable;  // pairs the screening kernel handed over unscreened (mi_pair_epilogue)
     const size_t k = (size_t)h2.n_sig;
     if (dev) {  // results stay on the device for fwi_bh_csr_device
         dev->i = oi;

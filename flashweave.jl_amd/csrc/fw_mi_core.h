@@ -398,7 +398,7 @@ static __device__ __forceinline__ MiRes mi_test_core(const MiDev &P, const int X
     }
     // row form or popcount form?  Both fill the same table; an estimate of their instruction counts decides (wave-uniform).
     bool rowform = false;
-    if (!tot_sep && k >= P.rowk) {
+    if (!tot_sep && any_flag && k >= P.rowk) {  // (sub-tables of the nz-adjusted kinds: few rows; a dense sub-table walks 32 bits per word)
         const int nslot = (nd + 63) >> 6;
         int steps;
         if (PRE) {
