@@ -700,23 +700,21 @@ __device__ __forceinline__ l0m_v4i l0m_expand16(unsigned w, int ks)
     return r;
 }
 
-__global__ __launch_bounds__(256, 1) void mi_level0_mfma_kernel(MiDev P, int p, int T, const int32_t *__restrict__ cnt_nz,
-                                                               const int32_t *__restrict__ cnt_hi, const double *gthr,
-                                                               MiL0Counters *cnt, unsigned long long cap_c, MiCand *__restrict__ cands,
-                                                               int dbg,
-                                                               int st_off, int st_end /* this launch's super-tiles */,
-                                                               unsigned long long *prof /* FW_L0_VERBOSE: shader cycles per phase, else null */)
+__global__ __launch_bounds__(512) void mi_level0_mfma_kernel(MiDev P, int p, int T, const int32_t *__restrict__ cnt_nz,
+                                                            const int32_t *__restrict__ cnt_hi, const double *gthr,
+                                                            MiL0Counters *cnt, unsigned long long cap_c, MiCand *__restrict__ cands,
+                                                            int dbg, int st_off, int st_end /* this launch's super-tiles */,
+                                                            unsigned long long *prof /* FW_L0_VERBOSE: shader cycles per phase, else null */)
 {
-    // staging words [side][plane][var][L0M_WC + 1] (36 KB; the pad word makes the operand reads of 32 consecutive variables conflict-
-    // free) -- the same bytes hold the parked counters of the epilogue's overflow path ([32][256] ints = 32 KB)
+    // staging words [side][plane][var][L0M_WC + 1] (36 KB; the pad word makes the operand reads of 32 consecutive variables conflict-free)
     __shared__ unsigned long long s_raw[2 * 2 * L0M_T * (L0M_WC + 1)];
     __shared__ double s_gthr[8];
     __shared__ int4 s_meta[2 * L0M_T];
     __shared__ MiCand s_q[L0M_QCAP];
-    __shared__ int s_qn, s_nsw[4];
+    __shared__ int s_qn, s_nsw[8], s_nun[8];
     __shared__ unsigned char s_std[2 * L0M_T];
     __shared__ unsigned long long s_qbase;
-    __shared__ uint4 s_surv[L0M_SCAP];  // {local X | local Y << 8, A | B << 16, C | D << 16, -}
+    __shared__ uint4 s_surv[L0M_SCAP];  // {local X | local Y << 8, A | B << 16, C | D << 16, -}: one eighth per wavefront
     unsigned long long(*sXY)[2][L0M_T][L0M_WC + 1] = (unsigned long long(*)[2][L0M_T][L0M_WC + 1])s_raw;  // [side]
     // XCD-aware tile order: consecutive workgroups go round-robin to the eight XCDs, each with its own 4 MB L2.  The tile list is cut
     // into SUPER-TILES of L0M_S x L0M_S tiles (16 x 128 variables x 2 planes x n / 8 bytes = 2.6 MB at n = 5 000: L2-resident) and the
@@ -734,29 +732,32 @@ __global__ __launch_bounds__(256, 1) void mi_level0_mfma_kernel(MiDev P, int p, 
     const int tin = (int)(blockIdx.x >> 3) % (L0M_S * L0M_S);
     const int bi = si * L0M_S + tin / L0M_S, bj = sj * L0M_S + tin % L0M_S;
     if (bi >= T || bj >= T || bi > bj) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wx = wave >> 1, wy = wave & 1;
+    // eight wavefronts, two per SIMD: wavefront (wx, wy) owns X variables [64 wx, +64) x Y variables [32 wy, +32)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wx = wave >> 2, wy = wave & 3;
     const unsigned long long pt0 = prof ? __builtin_readcyclecounter() : 0ull;
     if (tid < 8) s_gthr[tid] = gthr[tid];
     if (tid == 0) s_qn = 0;
-    {
+    if (tid < 2 * L0M_T) {
         const int g = (tid < L0M_T ? bi : bj) * L0M_T + (tid & (L0M_T - 1));
-        s_meta[tid] = g < p ? make_int4(cnt_nz[g], cnt_hi[g], P.levels[g], P.maxv[g]) : make_int4(0, 0, 0, 0);
+        const int4 m = g < p ? make_int4(cnt_nz[g], cnt_hi[g], P.levels[g], P.maxv[g]) : make_int4(0, 0, 0, 0);
+        s_meta[tid] = m;
+        s_std[tid] = (g < p && P.nzmode && P.L == 3 && m.w > 1 && m.z == 3) ? 1 : 0;  // nz-adjusted, three levels: see the epilogue
     }
-    l0m_v16i acc[2][2][2][2];  // [X block][Y block][X plane][Y plane]
+    l0m_v16i acc[2][2][2];  // [X block][X plane][Y plane]
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
+    for (int q = 0; q < 8; ++q)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q >> 3][(q >> 2) & 1][(q >> 1) & 1][q & 1][r] = 0;
-    // staging: a stage is 2 sides x 128 variables x 2 planes x L0M_WC words = 4 096 words, 16 per thread; element e = q * 256 + tid
-    // is (side q >> 3, variable (e & 2047) >> 4, plane (e >> 3) & 1, word e & 7): eight consecutive lanes read the 64 contiguous bytes
+        for (int r = 0; r < 16; ++r) acc[q >> 2][(q >> 1) & 1][q & 1][r] = 0;
+    // staging: a stage is 2 sides x 128 variables x 2 planes x L0M_WC words = 4 096 words, 8 per thread; element e = q * 512 + tid
+    // is (side e >> 11, variable (e & 2047) >> 4, plane (e >> 3) & 1, word e & 7): eight consecutive lanes read the 64 contiguous bytes
     // of one (variable, plane) -- a wavefront's load touches 8 runs instead of 64 scattered words.  Addresses are clamped and the value
-    // zeroed by a select, so the 16 loads are unconditional.
-    unsigned long long rr[16];
+    // zeroed by a select, so the loads are unconditional.
+    unsigned long long rr[8];
     auto fetch = [&](int w0) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int e = (q & 7) * 256 + tid, side = q >> 3;
-            const int var = e >> 4, pl = (e >> 3) & 1, w = e & 7;
+        for (int q = 0; q < 8; ++q) {
+            const int e = q * 512 + tid, side = e >> 11;
+            const int var = (e & 2047) >> 4, pl = (e >> 3) & 1, w = e & 7;
             const int g = (side ? bj : bi) * L0M_T + var;
             const bool ok = g < p && w0 + w < P.W && !(dbg & 2);
             const unsigned long long *src = pl ? P.hi : P.nz;
@@ -765,100 +766,96 @@ __global__ __launch_bounds__(256, 1) void mi_level0_mfma_kernel(MiDev P, int p, 
         }
     };
     fetch(0);
-    const int rowX = wx * 64 + (lane & 31), rowY = wy * 64 + (lane & 31), half = lane >> 5;
-    // The expansion of the NEXT K step (96 VALU instructions) is issued between the 16 matrix instructions of the current one
-    // (sched_group_barrier: one MFMA, then six VALU): with one wavefront per SIMD nothing else would fill the matrix pipe's 32 cycles
-    // per instruction, and expansion + MFMA back to back was 1 800 cycles per 64-sample word instead of ~1 050.
+    const int rowX = wx * 64 + (lane & 31), rowY = wy * 32 + (lane & 31), half = lane >> 5;
+    // The expansion of the NEXT K step (45 VALU instructions) is issued between the 8 matrix instructions of the current one
+    // (sched_group_barrier: one MFMA, then six VALU).  Two wavefronts share a SIMD: a lone wavefront issues one instruction per ~5.5
+    // cycles whatever it executes (the 256-thread form of this kernel: 1 290 cycles per 64-sample word for 235 instructions, with the
+    // matrix pipe busy 1 024 of them).
 #define L0M_WORDS(dst, w)                                                                  \
     {                                                                                      \
-        _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_) _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_) \
+        _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_)                                \
         {                                                                                  \
-            dst[0][a_][pl_] = ((const unsigned *)&sXY[0][pl_][rowX + 32 * a_][w])[half];   \
-            dst[1][a_][pl_] = ((const unsigned *)&sXY[1][pl_][rowY + 32 * a_][w])[half];   \
+            dst[0][pl_] = ((const unsigned *)&sXY[0][pl_][rowX][w])[half];                 \
+            dst[1][pl_] = ((const unsigned *)&sXY[0][pl_][rowX + 32][w])[half];            \
+            dst[2][pl_] = ((const unsigned *)&sXY[1][pl_][rowY][w])[half];                 \
         }                                                                                  \
     }
-#define L0M_EXPAND(fa_, fb_, src, sh)                                                      \
+#define L0M_EXPAND(f_, src, sh)                                                            \
     {                                                                                      \
-        _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_) _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_) \
-        {                                                                                  \
-            fa_[a_][pl_] = l0m_expand16(src[0][a_][pl_], sh);                              \
-            fb_[a_][pl_] = l0m_expand16(src[1][a_][pl_], sh);                              \
-        }                                                                                  \
+        _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_) \
+            f_[q_][pl_] = l0m_expand16(src[q_][pl_], sh);                                  \
     }
-#define L0M_MFMA16(fa_, fb_)                                                               \
+#define L0M_MFMA8(f_)                                                                      \
     {                                                                                      \
-        _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_) _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_) \
-            _Pragma("unroll") for (int px_ = 0; px_ < 2; ++px_) _Pragma("unroll") for (int py_ = 0; py_ < 2; ++py_) \
-                acc[a_][b_][px_][py_] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa_[a_][px_], fb_[b_][py_], acc[a_][b_][px_][py_], 0, 0, 0); \
+        _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_) _Pragma("unroll") for (int px_ = 0; px_ < 2; ++px_) \
+            _Pragma("unroll") for (int py_ = 0; py_ < 2; ++py_)                            \
+                acc[a_][px_][py_] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f_[a_][px_], f_[2][py_], acc[a_][px_][py_], 0, 0, 0); \
     }
     for (int w0 = 0; w0 < P.W; w0 += L0M_WC) {
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int e = (q & 7) * 256 + tid;
-            sXY[q >> 3][(e >> 3) & 1][e >> 4][e & 7] = rr[q];
+        for (int q = 0; q < 8; ++q) {
+            const int e = q * 512 + tid;
+            sXY[e >> 11][(e >> 3) & 1][(e & 2047) >> 4][e & 7] = rr[q];
         }
         __syncthreads();
         if (w0 + L0M_WC < P.W) fetch(w0 + L0M_WC);
         if (dbg & 4) continue;
-        unsigned cur[2][2][2], nxt[2][2][2];  // [side][block][plane]: this lane's 32 samples of its operand rows
-        l0m_v4i f0a[2][2], f0b[2][2], f1a[2][2], f1b[2][2];
+        unsigned cur[3][2], nxt[3][2];  // [X block 0, X block 1, Y block][plane]: this lane's 32 samples of its operand rows
+        l0m_v4i f0[3][2], f1[3][2];
         L0M_WORDS(cur, 0);
-        L0M_EXPAND(f0a, f0b, cur, 0);
+        L0M_EXPAND(f0, cur, 0);
 #pragma unroll 1
         for (int w = 0; w < L0M_WC; ++w) {
             const int wn = w + 1 < L0M_WC ? w + 1 : w;  // the last step expands a word again instead of branching
             L0M_WORDS(nxt, wn);
-            L0M_EXPAND(f1a, f1b, cur, 1);
-            L0M_MFMA16(f0a, f0b);
-            L0M_EXPAND(f0a, f0b, nxt, 0);
-            L0M_MFMA16(f1a, f1b);
+            L0M_EXPAND(f1, cur, 1);
+            L0M_MFMA8(f0);
+            L0M_EXPAND(f0, nxt, 0);
+            L0M_MFMA8(f1);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) cur[q >> 2][(q >> 1) & 1][q & 1] = nxt[q >> 2][(q >> 1) & 1][q & 1];
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            for (int q = 0; q < 6; ++q) cur[q >> 1][q & 1] = nxt[q >> 1][q & 1];
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
 #pragma unroll
-            for (int q = 0; q < 32; ++q) {
+            for (int q = 0; q < 16; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
             }
         }
     }
 #undef L0M_WORDS
 #undef L0M_EXPAND
-#undef L0M_MFMA16
+#undef L0M_MFMA8
     __syncthreads();
     const unsigned long long pt1 = prof ? __builtin_readcyclecounter() : 0ull;
     if (dbg & 1) {
-        if (acc[0][0][0][0][0] + acc[1][1][1][1][15] == -12345) cnt->n_sig = 1;
+        if (acc[0][0][0][0] + acc[1][1][1][15] == -12345) cnt->n_sig = 1;
         return;
     }
     // Epilogue in two passes.  Pass 1 decides the pair every HE table is made of -- both variables nz-adjusted with three levels
     // ("standard", one flag per variable) -- on integers and one Float32 inequality, BRANCH-FREE (the rules of mi_pair_prescreen as
-    // selects: with one wavefront per SIMD every divergent early return was a pipeline drain, 64 times per lane), reading the
-    // accumulators in place (fully unrolled).  Pairs that need the table look-ups -- and every pair with a non-standard variable --
-    // go to a survivor list in LDS: each wavefront fills its own quarter (ballot + lane rank: no atomics, no waits).  Pass 2 walks the
-    // lists densely with the full screen.  (One pass, pair by pair: every wavefront waited for the global-memory look-ups of its slowest
-    // lane in each of its 64 steps -- 31 ms at cfg4.)
-    int *s_cnt = (int *)s_raw;
+    // selects), reading the accumulators in place (fully unrolled).  Pairs that need the full screen -- and every pair with a
+    // non-standard variable -- go to a survivor list in LDS: each wavefront fills its own eighth (ballot + lane rank: no atomics, no
+    // waits).  Pass 2 walks the lists densely with the full screen (hardware logarithms instead of table look-ups).  A pair that finds
+    // its wavefront's list full goes to the exact kernel unscreened (that kernel counts unreliable pairs among its input itself).
+    // (One pass, pair by pair: every wavefront waited for the global-memory look-ups of its slowest lane in each of its steps --
+    // 31 ms at cfg4.)
     int n_unrel = 0;
-    {
-        const int g = (tid < L0M_T ? bi : bj) * L0M_T + (tid & (L0M_T - 1));
-        const int4 m = s_meta[tid];
-        s_std[tid] = (g < p && P.nzmode && P.L == 3 && m.w > 1 && m.z == 3) ? 1 : 0;
-    }
-    __syncthreads();
     const bool pre_ok = (long long)P.n >= P.n_obs_min && (long long)P.n > (long long)P.hps;  // tests.jl:9-20 for two three-level variables
     const long long thrA64 = P.n_obs_min > (long long)P.hps * 4 + 1 ? P.n_obs_min : (long long)P.hps * 4 + 1;
     const int thrA = thrA64 > 0x7fffffffll ? 0x7fffffff : (int)thrA64;  // reliable <=> A >= thrA
     const float kthr = 0.98f * (float)s_gthr[1];
     int my_ns = 0;  // survivors of this wavefront so far (wave-uniform)
-    const int seg0 = wave * (L0M_SCAP / 4);
+    const int seg0 = wave * (L0M_SCAP / 8);
     int n_unrel_w = 0;  // wave-uniform count of unreliable pairs (popcounts of lane masks: no vector adds)
     // FAST tiles -- off the diagonal, inside the table, every variable standard: all but the last tile row / column and the
-    // diagonal -- need neither the index tests nor the flags: ~25 vector instructions per pair instead of ~80.
-    const bool fast_tile = bi < bj && (bj + 1) * L0M_T <= p && __syncthreads_and(s_std[tid] != 0);
+    // diagonal -- need neither the index tests nor the flags.
+    const bool fast_tile = __syncthreads_and(tid >= 2 * L0M_T || s_std[tid & (2 * L0M_T - 1)] != 0) && bi < bj && (bj + 1) * L0M_T <= p;
+    const int lY = wy * 32 + (lane & 31);
+    const int Y = bj * L0M_T + lY;
     auto pass1 = [&](auto fast_c) {
         constexpr bool FAST = decltype(fast_c)::value;
+        const bool stdY = FAST || s_std[L0M_T + lY] != 0;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             unsigned stdX = 0u;  // bit r: the X variable of accumulator register r is standard
@@ -867,57 +864,43 @@ __global__ __launch_bounds__(256, 1) void mi_level0_mfma_kernel(MiDev P, int p, 
                 for (int r = 0; r < 16; ++r) stdX |= (unsigned)s_std[wx * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half] << r;
             }
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
-                const int lY = wy * 64 + 32 * bb + (lane & 31);
-                const int Y = bj * L0M_T + lY;
-                const bool stdY = FAST || s_std[L0M_T + lY] != 0;
-                unsigned ovf = 0u;  // pairs that found the survivor list full
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int lX = wx * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const int X = bi * L0M_T + lX;
-                    const int cA = acc[a][bb][0][0][r], cB = acc[a][bb][1][0][r], cC = acc[a][bb][0][1][r], cD = acc[a][bb][1][1][r];
-                    const bool valid = FAST || (X < Y && Y < p);
-                    const bool stdp = FAST || (stdY && ((stdX >> r) & 1u));
-                    const bool rel = pre_ok && cA >= thrA;
-                    // |A D - B C| from one fused multiply-add: A D enters exactly, B C rounded to 24 bits -- the bound adds that
-                    // rounding (<= 2^-24 B C) and the result's own (2^-24 |det|), so a pair is only dropped if its exact 2 X^2 is
-                    // below the threshold (counts <= 65 535 are exact Float32 values).  An empty marginal (df = 0, p = 1) makes the
-                    // right-hand side zero.
-                    const float fA = (float)cA, fB = (float)cB, fC = (float)cC, fD = (float)cD;
-                    const float bc = fB * fC;
-                    const float det = fabsf(__builtin_fmaf(fA, fD, -bc)) * 1.0000003f + 6.0e-8f * bc;
-                    const float lhs = 2.0f * fA * det * det, rhs = ((fA - fB) * fB) * ((fA - fC) * fC);
-                    const bool pass = rhs > 0.0f && !(lhs < kthr * rhs);
-                    const bool surv = valid && (!stdp || (rel && pass));
-                    n_unrel_w += __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid && stdp && !rel));
-                    const unsigned long long bal = __builtin_amdgcn_ballot_w64(surv);
-                    if (bal) {
-                        const int slot = my_ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                        if (surv) {
-                            if (slot < L0M_SCAP / 4)
-                                s_surv[seg0 + slot] = make_uint4((unsigned)lX | ((unsigned)lY << 8), (unsigned)cA | ((unsigned)cB << 16), (unsigned)cC | ((unsigned)cD << 16), 0u);
-                            else
-                                ovf |= 1u << r;
+            for (int r = 0; r < 16; ++r) {
+                const int lX = wx * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int X = bi * L0M_T + lX;
+                const int cA = acc[a][0][0][r], cB = acc[a][1][0][r], cC = acc[a][0][1][r], cD = acc[a][1][1][r];  // A = <nzX, nzY>, B = <hiX, nzY>, C = <nzX, hiY>, D = <hiX, hiY>
+                const bool valid = FAST || (X < Y && Y < p);
+                const bool stdp = FAST || (stdY && ((stdX >> r) & 1u));
+                const bool rel = pre_ok && cA >= thrA;
+                // |A D - B C| from one fused multiply-add: A D enters exactly, B C rounded to 24 bits -- the bound adds that
+                // rounding (<= 2^-24 B C) and the result's own (2^-24 |det|), so a pair is only dropped if its exact 2 X^2 is
+                // below the threshold (counts <= 65 535 are exact Float32 values).  An empty marginal (df = 0, p = 1) makes the
+                // right-hand side zero.
+                const float fA = (float)cA, fB = (float)cB, fC = (float)cC, fD = (float)cD;
+                const float bc = fB * fC;
+                const float det = fabsf(__builtin_fmaf(fA, fD, -bc)) * 1.0000003f + 6.0e-8f * bc;
+                const float lhs = 2.0f * fA * det * det, rhs = ((fA - fB) * fB) * ((fA - fC) * fC);
+                const bool pass = rhs > 0.0f && !(lhs < kthr * rhs);
+                const bool surv = valid && (!stdp || (rel && pass));
+                n_unrel_w += __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid && stdp && !rel));
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(surv);
+                if (bal) {
+                    const int slot = my_ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    if (surv) {
+                        if (slot < L0M_SCAP / 8) {
+                            s_surv[seg0 + slot] = make_uint4((unsigned)lX | ((unsigned)lY << 8), (unsigned)cA | ((unsigned)cB << 16), (unsigned)cC | ((unsigned)cD << 16), 0u);
+                        } else {  // list full (rare): unscreened to the exact kernel
+                            MiCand cd;
+                            cd.X = X, cd.Y = Y, cd.A = cA, cd.B = cB, cd.C = cC, cd.D = cD;
+                            const int qs = atomicAdd(&s_qn, 1);
+                            if (qs < L0M_QCAP) {
+                                s_q[qs] = cd;
+                            } else {
+                                const unsigned long long gs = atomicAdd(&cnt->n_sig, 1ull);
+                                if (gs < cap_c) cands[gs] = cd;
+                            }
                         }
-                        my_ns += __builtin_popcountll(bal);
                     }
-                }
-                if (__builtin_amdgcn_ballot_w64(ovf != 0u)) {  // rare (a wavefront with more than L0M_SCAP / 4 pairs for the tables): screened in place
-                    const int4 mY = s_meta[L0M_T + lY];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        s_cnt[(2 * r) * 256 + tid] = acc[a][bb][0][0][r] | (acc[a][bb][1][0][r] << 16);
-                        s_cnt[(2 * r + 1) * 256 + tid] = acc[a][bb][0][1][r] | (acc[a][bb][1][1][r] << 16);
-                    }
-#pragma unroll 1
-                    for (int r = 0; r < 16; ++r)
-                        if ((ovf >> r) & 1u) {
-                            const int lX = wx * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
-                            const unsigned ab = (unsigned)s_cnt[(2 * r) * 256 + tid], cd = (unsigned)s_cnt[(2 * r + 1) * 256 + tid];
-                            n_unrel += mi_pair_screen(P, s_meta[lX], mY, bi * L0M_T + lX, Y, (int)(ab & 0xffffu), (int)(ab >> 16), (int)(cd & 0xffffu), (int)(cd >> 16),
-                                                      (const float *)nullptr, (const float *)nullptr, s_gthr, cnt, cap_c, cands, s_q, &s_qn, L0M_QCAP);
-                        }
+                    my_ns += __builtin_popcountll(bal);
                 }
             }
         }
@@ -927,27 +910,42 @@ __global__ __launch_bounds__(256, 1) void mi_level0_mfma_kernel(MiDev P, int p, 
     else
         pass1(std::false_type{});
     if (lane == 0) n_unrel += n_unrel_w;
-    if (lane == 0) s_nsw[wave] = my_ns < L0M_SCAP / 4 ? my_ns : L0M_SCAP / 4;
+    if (lane == 0) s_nsw[wave] = my_ns < L0M_SCAP / 8 ? my_ns : L0M_SCAP / 8;
     const unsigned long long pt2 = prof ? __builtin_readcyclecounter() : 0ull;
     __syncthreads();
-#pragma unroll 1
-    for (int sg = 0; sg < ((dbg & 8) ? 0 : 4); ++sg) {
-        const int ns = s_nsw[sg];
-        for (int q = tid; q < ns; q += 256) {
-            const uint4 e = s_surv[sg * (L0M_SCAP / 4) + q];
-            const int lX = (int)(e.x & 0xffu), lY = (int)(e.x >> 8);
-            n_unrel += mi_pair_screen(P, s_meta[lX], s_meta[L0M_T + lY], bi * L0M_T + lX, bj * L0M_T + lY, (int)(e.y & 0xffffu), (int)(e.y >> 16),
-                                      (int)(e.z & 0xffffu), (int)(e.z >> 16), (const float *)nullptr, (const float *)nullptr, s_gthr, cnt, cap_c, cands, s_q, &s_qn, L0M_QCAP);
+    {   // the eight lists as one: thread t takes entries t, t + 512, ... of their concatenation
+        int cum[9];
+        cum[0] = 0;
+#pragma unroll
+        for (int sg = 0; sg < 8; ++sg) cum[sg + 1] = cum[sg] + s_nsw[sg];
+        const int tot = (dbg & 8) ? 0 : cum[8];
+        for (int g = tid; g < tot; g += 512) {
+            int sg = 0;
+#pragma unroll
+            for (int q = 1; q < 8; ++q) sg += g >= cum[q];
+            int base = 0;
+#pragma unroll
+            for (int q = 1; q < 8; ++q) base = (q == sg) ? cum[q] : base;
+            const uint4 e = s_surv[sg * (L0M_SCAP / 8) + (g - base)];
+            const int lX = (int)(e.x & 0xffu), lYq = (int)(e.x >> 8);
+            n_unrel += mi_pair_screen(P, s_meta[lX], s_meta[L0M_T + lYq], bi * L0M_T + lX, bj * L0M_T + lYq, (int)(e.y & 0xffffu), (int)(e.y >> 16),
+                                      (int)(e.z & 0xffffu), (int)(e.z >> 16), (const float *)nullptr, (const float *)nullptr, s_gthr, cnt, cap_c, cands,
+                                      s_q, &s_qn, L0M_QCAP);
         }
     }
     const unsigned long long pt3 = prof ? __builtin_readcyclecounter() : 0ull;
     n_unrel = wave_sum_i(n_unrel);
-    if (lane == 0 && n_unrel) atomicAdd(&cnt->n_unreliable, (unsigned long long)n_unrel);
+    if (lane == 0) s_nun[wave] = n_unrel;
     __syncthreads();
     const int nq = s_qn < L0M_QCAP ? s_qn : L0M_QCAP;
-    if (tid == 0 && nq > 0) s_qbase = atomicAdd(&cnt->n_sig, (unsigned long long)nq);
+    if (tid == 0) {  // one atomic per tile and counter (eight wavefronts x 76 000 tiles on one address queued up behind each other)
+        int nu = 0;
+        for (int q = 0; q < 8; ++q) nu += s_nun[q];
+        if (nu) atomicAdd(&cnt->n_unreliable, (unsigned long long)nu);
+        if (nq > 0) s_qbase = atomicAdd(&cnt->n_sig, (unsigned long long)nq);
+    }
     __syncthreads();
-    for (int q = tid; q < nq; q += 256)
+    for (int q = tid; q < nq; q += 512)
         if (s_qbase + (unsigned long long)q < cap_c) cands[s_qbase + q] = s_q[q];
     if (prof && tid == 0) {
         atomicAdd(prof + 0, pt1 - pt0);
@@ -955,7 +953,9 @@ __global__ __launch_bounds__(256, 1) void mi_level0_mfma_kernel(MiDev P, int p, 
         atomicAdd(prof + 2, pt3 - pt2);
         atomicAdd(prof + 3, __builtin_readcyclecounter() - pt3);
         atomicAdd(prof + 4, 1ull);
-        atomicAdd(prof + 5, (unsigned long long)(s_nsw[0] + s_nsw[1] + s_nsw[2] + s_nsw[3]));
+        int nsv = 0;
+        for (int q = 0; q < 8; ++q) nsv += s_nsw[q];
+        atomicAdd(prof + 5, (unsigned long long)nsv);
     }
 }
 
@@ -1396,7 +1396,7 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
         if (nblk == 0)
             ;  // more ranks than tiles: nothing to screen here
         else if (l0_mfma)
-            hipLaunchKernelGGL(mi_level0_mfma_kernel, dim3((unsigned)(8 * ((nblk + 7) / 8) * L0M_S * L0M_S)), dim3(256), 0, ctx->stream, P, p, T, ctx->d_firstnz,
+            hipLaunchKernelGGL(mi_level0_mfma_kernel, dim3((unsigned)(8 * ((nblk + 7) / 8) * L0M_S * L0M_S)), dim3(512), 0, ctx->stream, P, p, T, ctx->d_firstnz,
                                ctx->d_firstnz + p, d_gthr, (MiL0Counters *)ctx->d_tmp0.ptr, cap_c, (MiCand *)ctx->d_jobs.ptr, l0_dbg, b_off, b_off + nblk, l0_prof ? d_prof : nullptr);
         else if (ctx->d_hibits)
             hipLaunchKernelGGL(mi_level0_kernel<true>, dim3(nblk), dim3(256), 0, ctx->stream, P, p, T, ctx->d_firstnz,
