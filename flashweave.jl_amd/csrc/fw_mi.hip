@@ -700,10 +700,29 @@ __device__ __forceinline__ l0m_v4i l0m_expand16(unsigned w, int ks)
     return r;
 }
 
+#ifndef L0M_FP4
+#define L0M_FP4 1  // 1: MX-fp4 matrix instruction (v_mfma_scale_f32_32x32x64_f8f6f4, 64 samples per instruction); 0: int8 (32x32x32)
+#endif
+typedef int l0m_v8i __attribute__((ext_vector_type(8)));
+typedef float l0m_v16f __attribute__((ext_vector_type(16)));
+// MX-fp4 operand of this lane's 32 samples: 32 E2M1 nibbles in four registers, register q = bit q of each nibble of the word, as the
+// code 0b0010 = 1.0 (block scale 2^0): 0 and 1 are exact E2M1 values, a product is 0 or 1, the Float32 accumulator holds a count
+// (<= 65 535 here) exactly.  Seven instructions for 32 samples (int8: fifteen), and the instruction does twice the multiply-adds.
+__device__ __forceinline__ l0m_v8i l0m_expand_fp4(unsigned w)
+{
+    l0m_v8i r;
+    r[0] = (int)((w << 1) & 0x22222222u);
+    r[1] = (int)(w & 0x22222222u);
+    r[2] = (int)((w >> 1) & 0x22222222u);
+    r[3] = (int)((w >> 2) & 0x22222222u);
+    r[4] = r[5] = r[6] = r[7] = 0;
+    return r;
+}
+
 __global__ __launch_bounds__(512) void mi_level0_mfma_kernel(MiDev P, int p, int T, const int32_t *__restrict__ cnt_nz,
                                                             const int32_t *__restrict__ cnt_hi, const double *gthr,
                                                             MiL0Counters *cnt, unsigned long long cap_c, MiCand *__restrict__ cands,
-                                                            int dbg, int st_off, int st_end /* this launch's super-tiles */,
+                                                            int dbg, int slot_off, int slot_end /* this launch's share of the tile list, see below */,
                                                             unsigned long long *prof /* FW_L0_VERBOSE: shader cycles per phase, else null */)
 {
     // staging words [side][plane][var][L0M_WC + 1] (36 KB; the pad word makes the operand reads of 32 consecutive variables conflict-free)
@@ -720,8 +739,11 @@ __global__ __launch_bounds__(512) void mi_level0_mfma_kernel(MiDev P, int p, int
     // into SUPER-TILES of L0M_S x L0M_S tiles (16 x 128 variables x 2 planes x n / 8 bytes = 2.6 MB at n = 5 000: L2-resident) and the
     // workgroups of one XCD (blockIdx & 7) work through the tiles of one super-tile after the other, so a column of bit planes crosses
     // the fabric once per super-tile instead of once per tile (r04: the staging alone moved 25 GB at 2 TB/s, 12 of the kernel's 31 ms).
-    const int st = st_off + (int)(blockIdx.x >> 3) / (L0M_S * L0M_S) * 8 + (int)(blockIdx.x & 7);
-    if (st >= st_end) return;
+    // A launch covers the SLOTS [slot_off, slot_end) of the list (slot = super-tile x 64 + tile inside it, row-major; a rank of a
+    // sharded run gets a contiguous slot range holding its share of the real tiles).
+    const int st = slot_off / (L0M_S * L0M_S) + (int)(blockIdx.x >> 3) / (L0M_S * L0M_S) * 8 + (int)(blockIdx.x & 7);
+    const int slot = st * (L0M_S * L0M_S) + (int)(blockIdx.x >> 3) % (L0M_S * L0M_S);
+    if (slot < slot_off || slot >= slot_end) return;
     const int TS = (T + L0M_S - 1) / L0M_S;
     int sj = st, si = 0;
     while (sj >= TS - si) {
@@ -743,7 +765,11 @@ __global__ __launch_bounds__(512) void mi_level0_mfma_kernel(MiDev P, int p, int
         s_meta[tid] = m;
         s_std[tid] = (g < p && P.nzmode && P.L == 3 && m.w > 1 && m.z == 3) ? 1 : 0;  // nz-adjusted, three levels: see the epilogue
     }
+#if L0M_FP4
+    l0m_v16f acc[2][2][2];  // [X block][X plane][Y plane]: counts as Float32 (exact)
+#else
     l0m_v16i acc[2][2][2];  // [X block][X plane][Y plane]
+#endif
 #pragma unroll
     for (int q = 0; q < 8; ++q)
 #pragma unroll
@@ -771,6 +797,61 @@ __global__ __launch_bounds__(512) void mi_level0_mfma_kernel(MiDev P, int p, int
     // (sched_group_barrier: one MFMA, then six VALU).  Two wavefronts share a SIMD: a lone wavefront issues one instruction per ~5.5
     // cycles whatever it executes (the 256-thread form of this kernel: 1 290 cycles per 64-sample word for 235 instructions, with the
     // matrix pipe busy 1 024 of them).
+#if L0M_FP4
+#define L0M_WORDS(dst, w)                                                                  \
+    {                                                                                      \
+        _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_)                                \
+        {                                                                                  \
+            dst[0][pl_] = ((const unsigned *)&sXY[0][pl_][rowX][w])[half];                 \
+            dst[1][pl_] = ((const unsigned *)&sXY[0][pl_][rowX + 32][w])[half];            \
+            dst[2][pl_] = ((const unsigned *)&sXY[1][pl_][rowY][w])[half];                 \
+        }                                                                                  \
+    }
+#define L0M_EXPAND4(f_, src)                                                               \
+    {                                                                                      \
+        _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_) \
+            f_[q_][pl_] = l0m_expand_fp4(src[q_][pl_]);                                    \
+    }
+#define L0M_MFMA8F(f_)                                                                     \
+    {                                                                                      \
+        _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_) _Pragma("unroll") for (int px_ = 0; px_ < 2; ++px_) \
+            _Pragma("unroll") for (int py_ = 0; py_ < 2; ++py_)                            \
+                acc[a_][px_][py_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(f_[a_][px_], f_[2][py_], acc[a_][px_][py_], 4, 4, 0, 127, 0, 127); \
+    }
+    for (int w0 = 0; w0 < P.W; w0 += L0M_WC) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = q * 512 + tid;
+            sXY[e >> 11][(e >> 3) & 1][(e & 2047) >> 4][e & 7] = rr[q];
+        }
+        __syncthreads();
+        if (w0 + L0M_WC < P.W) fetch(w0 + L0M_WC);
+        if (dbg & 4) continue;
+        unsigned wa[3][2], wb[3][2];  // [X block 0, X block 1, Y block][plane]: this lane's 32 samples of its operand rows
+        l0m_v8i f0[3][2], f1[3][2];
+        L0M_WORDS(wa, 0);
+        L0M_EXPAND4(f0, wa);
+#pragma unroll 1
+        for (int w = 0; w < L0M_WC; w += 2) {  // two words per trip: the operand buffers alternate without register copies
+            L0M_WORDS(wb, w + 1);
+            const int wn = w + 2 < L0M_WC ? w + 2 : w + 1;  // the last trip expands a word again instead of branching
+            L0M_WORDS(wa, wn);
+            L0M_EXPAND4(f1, wb);
+            L0M_MFMA8F(f0);
+            L0M_EXPAND4(f0, wa);
+            L0M_MFMA8F(f1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            }
+        }
+    }
+#undef L0M_EXPAND4
+#undef L0M_MFMA8F
+#else
 #define L0M_WORDS(dst, w)                                                                  \
     {                                                                                      \
         _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_)                                \
@@ -823,13 +904,14 @@ __global__ __launch_bounds__(512) void mi_level0_mfma_kernel(MiDev P, int p, int
             }
         }
     }
-#undef L0M_WORDS
 #undef L0M_EXPAND
 #undef L0M_MFMA8
+#endif
+#undef L0M_WORDS
     __syncthreads();
     const unsigned long long pt1 = prof ? __builtin_readcyclecounter() : 0ull;
     if (dbg & 1) {
-        if (acc[0][0][0][0] + acc[1][1][1][15] == -12345) cnt->n_sig = 1;
+        if ((int)acc[0][0][0][0] + (int)acc[1][1][1][15] == -12345) cnt->n_sig = 1;
         return;
     }
     // Epilogue in two passes.  Pass 1 decides the pair every HE table is made of -- both variables nz-adjusted with three levels
@@ -867,7 +949,7 @@ __global__ __launch_bounds__(512) void mi_level0_mfma_kernel(MiDev P, int p, int
             for (int r = 0; r < 16; ++r) {
                 const int lX = wx * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int X = bi * L0M_T + lX;
-                const int cA = acc[a][0][0][r], cB = acc[a][1][0][r], cC = acc[a][0][1][r], cD = acc[a][1][1][r];  // A = <nzX, nzY>, B = <hiX, nzY>, C = <nzX, hiY>, D = <hiX, hiY>
+                const int cA = (int)acc[a][0][0][r], cB = (int)acc[a][1][0][r], cC = (int)acc[a][0][1][r], cD = (int)acc[a][1][1][r];  // A = <nzX, nzY>, B = <hiX, nzY>, C = <nzX, hiY>, D = <hiX, hiY>
                 const bool valid = FAST || (X < Y && Y < p);
                 const bool stdp = FAST || (stdY && ((stdX >> r) & 1u));
                 const bool rel = pre_ok && cA >= thrA;
@@ -1369,13 +1451,36 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
                          (l0_mfma_knob == 2 || (ctx->P.kind == FW_MI_NZ && p >= 1024));
     const int l0_tile = l0_mfma ? L0M_T : L0_T;
     const int T = (p + l0_tile - 1) / l0_tile;
-    // (matrix-core form: the unit a rank's share is counted in is the super-tile of L0M_S x L0M_S tiles)
     const int TS = (T + L0M_S - 1) / L0M_S;
-    const int nblk_all = l0_mfma ? TS * (TS + 1) / 2 : (int)((long long)T * (T + 1) / 2);
+    const int nblk_all = (int)((long long)T * (T + 1) / 2);
     // target-sharded runs: every rank screens a contiguous range of the linearised upper-triangular tile list (tiles cost
     // the same: the list is balanced) and the significant pairs are all-gathered afterwards (fw_level0_sharded)
     const int b_off = (int)((long long)nblk_all * ctx->l0_rank / ctx->l0_world);
     const int nblk = (int)((long long)nblk_all * (ctx->l0_rank + 1) / ctx->l0_world) - b_off;
+    // matrix-core form: the list is walked super-tile by super-tile (slot = super-tile x 64 + tile inside it; slots below the diagonal
+    // or beyond the table are empty).  This rank's slots: the contiguous range that holds the real tiles b_off .. b_off + nblk - 1.
+    int slot_off = 0, slot_end = 0;
+    if (l0_mfma) {
+        long long seen = 0;
+        bool open = false;
+        slot_off = slot_end = (int)((long long)TS * (TS + 1) / 2 * L0M_S * L0M_S);
+        for (int si = 0, st = 0; si < TS && !(open && seen >= (long long)b_off + nblk); ++si)
+            for (int sj = si; sj < TS && !(open && seen >= (long long)b_off + nblk); ++sj, ++st)
+                for (int tin = 0; tin < L0M_S * L0M_S; ++tin) {
+                    const int bi_ = si * L0M_S + tin / L0M_S, bj_ = sj * L0M_S + tin % L0M_S;
+                    const bool real = bi_ < T && bj_ < T && bi_ <= bj_;
+                    if (real && !open && seen == b_off && nblk > 0) {
+                        slot_off = st * L0M_S * L0M_S + tin;
+                        open = true;
+                    }
+                    if (real) ++seen;
+                    if (open && seen >= (long long)b_off + nblk) {
+                        slot_end = st * L0M_S * L0M_S + tin + 1;
+                        break;
+                    }
+                }
+        if (!open) slot_off = slot_end = 0;
+    }
     const MiDev P = mi_dev(ctx);
     // ---- kernel 1: popcounts + exact reliability/df + Float32 screen -> candidate records ----
     static const int l0_dbg = fw_knob("FW_L0_DBG") ? atoi(fw_knob("FW_L0_DBG")) : 0;  // profiling only (invalid results)
@@ -1396,8 +1501,10 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
         if (nblk == 0)
             ;  // more ranks than tiles: nothing to screen here
         else if (l0_mfma)
-            hipLaunchKernelGGL(mi_level0_mfma_kernel, dim3((unsigned)(8 * ((nblk + 7) / 8) * L0M_S * L0M_S)), dim3(512), 0, ctx->stream, P, p, T, ctx->d_firstnz,
-                               ctx->d_firstnz + p, d_gthr, (MiL0Counters *)ctx->d_tmp0.ptr, cap_c, (MiCand *)ctx->d_jobs.ptr, l0_dbg, b_off, b_off + nblk, l0_prof ? d_prof : nullptr);
+            hipLaunchKernelGGL(mi_level0_mfma_kernel,
+                               dim3((unsigned)(8 * (((slot_end - 1) / (L0M_S * L0M_S) - slot_off / (L0M_S * L0M_S) + 1 + 7) / 8) * L0M_S * L0M_S)), dim3(512), 0,
+                               ctx->stream, P, p, T, ctx->d_firstnz, ctx->d_firstnz + p, d_gthr, (MiL0Counters *)ctx->d_tmp0.ptr, cap_c,
+                               (MiCand *)ctx->d_jobs.ptr, l0_dbg, slot_off, slot_end, l0_prof ? d_prof : nullptr);
         else if (ctx->d_hibits)
             hipLaunchKernelGGL(mi_level0_kernel<true>, dim3(nblk), dim3(256), 0, ctx->stream, P, p, T, ctx->d_firstnz,
                                ctx->d_firstnz + p, d_gthr, (MiL0Counters *)ctx->d_tmp0.ptr, cap_c, (MiCand *)ctx->d_jobs.ptr, ctx->d_xlnx, ctx->d_xlnx + (ctx->P.n + 1), l0_dbg, b_off);

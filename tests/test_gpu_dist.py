@@ -12,7 +12,12 @@ from tests.test_dist_cpu import _launch
 pytestmark = pytest.mark.gpu
 
 
-def test_sharded_equals_single():
+@pytest.mark.parametrize("l0_mfma", ["1", "2"])
+def test_sharded_equals_single(l0_mfma, monkeypatch):
+    # l0_mfma = "2": the discrete level 0 through the matrix-core kernel whatever the size (its tile list is dealt in super-tile
+    # order: mi_level0_mfma_kernel); "1": the default choice (popcount form at this size)
+    monkeypatch.setenv("FW_KNOBS", "1")
+    monkeypatch.setenv("FW_L0_MFMA", l0_mfma)
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "res")
         assert _launch("sharded", (out,)) == [0, 0]
