@@ -1005,9 +1005,16 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
     const FwSeg *dsegs = (const FwSeg *)pb.d_in.ptr;
     const int32_t *dacc = (const int32_t *)pb.d_acc.ptr;
     if (nzs) {
-        rc = fwi_fznz_submatrices(c, (int64_t)pool.nzrecs.size(), pool.nzrecs.data(), arena_floats, dacc, pb.launch_stream);
+        const bool f64 = !c->P.recursive_pcor;  // fz_nz without a matrix: Float64 view correlations, conditioned as StatsBase.partialcor does
+        rc = fwi_fznz_submatrices(c, (int64_t)pool.nzrecs.size(), pool.nzrecs.data(), arena_floats, dacc, pb.launch_stream, f64);
         if (rc) return rc;
-        rc = fwi_fznz_segments(c, (int64_t)ns, (int64_t)ns_tab, dsegs, dacc, dout, pb);
+        if (f64) {
+            int m_max = 2;
+            for (const FwNzJob &r : pool.nzrecs) m_max = std::max(m_max, (int)r.m);
+            rc = fwi_fzs_segments_nz(c, (int64_t)ns, dsegs, dacc, dout, pb, m_max);
+        } else {
+            rc = fwi_fznz_segments(c, (int64_t)ns, (int64_t)ns_tab, dsegs, dacc, dout, pb);
+        }
     } else {
         rc = stream ? fwi_fzs_segments(c, (int64_t)ns, dsegs, dacc, dout, pb, pool.nzrecs.data(), (int64_t)pool.nzrecs.size(), arena_floats)
              : fz   ? fwi_fz_segments(c, (int64_t)ns, (int64_t)ns_tab, dsegs, dacc, dout, pb)

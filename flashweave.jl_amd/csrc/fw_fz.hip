@@ -925,7 +925,11 @@ static inline size_t fznz_lds_bytes(int m_cap, int n)
 __global__ __launch_bounds__(FZNZ_NT) void fznz_submat_kernel(const float *__restrict__ data, const unsigned long long *__restrict__ nz,
                                                               int n, int W, FwNzJob *__restrict__ recs,
                                                               const int32_t *__restrict__ accflat, float *__restrict__ arena,
-                                                              double alpha, int m_cap, double xcrit)
+                                                              double alpha, int m_cap, double xcrit,
+                                                              double *__restrict__ arena64 /* recursive_pcor = 0: the UNROUNDED Float64
+                                                              correlations go here (same element offsets) instead of the Float32 matrix:
+                                                              no clamp, no NaN -> 0 (that is cor_subset!'s), a variable listed twice
+                                                              correlates with itself exactly 1 (StatsBase sums the same numbers) */)
 {
     extern __shared__ double s_dyn[];
     __shared__ double s_ss01[2];
@@ -942,6 +946,7 @@ __global__ __launch_bounds__(FZNZ_NT) void fznz_submat_kernel(const float *__res
     long long nR = 0;
     for (int w = 0; w < W; ++w) nR += __popcll(mx[w] & my[w]);
     float *local = arena + rec->cor_off;
+    double *local64 = arena64 ? arena64 + rec->cor_off : nullptr;
     const long long npairs = (long long)m * (m - 1) / 2;
     const bool tree = rec->acc_len > 0 && n <= FZNZ_ROWS_LDS && W <= 256;  // wave-uniform (workgroup-uniform)
     if (tree) {
@@ -1050,7 +1055,11 @@ __global__ __launch_bounds__(FZNZ_NT) void fznz_submat_kernel(const float *__res
                 __builtin_amdgcn_wave_barrier();
                 const int k16 = 8 * h + c;
                 const int a = 4 * A + (k16 >> 2), b = 4 * B + (k16 & 3);
-                if (g == 0 && a < b && b < m) {
+                if (g == 0 && a < b && b < m && local64) {
+                    const double r64 = s_var[a] == s_var[b] ? 1.0 : tot / (s_sd[a] * s_sd[b]);
+                    local64[(size_t)a * m + b] = r64;
+                    local64[(size_t)b * m + a] = r64;
+                } else if (g == 0 && a < b && b < m) {
                     double r = tot / (s_sd[a] * s_sd[b]);
                     if (r > 1.0) r = 1.0;
                     if (r < -1.0) r = -1.0;
@@ -1061,7 +1070,12 @@ __global__ __launch_bounds__(FZNZ_NT) void fznz_submat_kernel(const float *__res
                 }
             }
         }
-        for (int t = tid; t < m; t += FZNZ_NT) local[(size_t)t * m + t] = 1.0f;
+        for (int t = tid; t < m; t += FZNZ_NT) {
+            if (local64)
+                local64[(size_t)t * m + t] = 1.0;
+            else
+                local[(size_t)t * m + t] = 1.0f;
+        }
         if (tid == 0) {
             rec->rxy = 0.0;  // (only univariate jobs read it: they take the sequential form below)
             rec->nR = (int32_t)nR;
@@ -1126,6 +1140,12 @@ __global__ __launch_bounds__(FZNZ_NT) void fznz_submat_kernel(const float *__res
                 pc = -1.0;
             rec->rxy = nR > 0 ? pc : 0.0;
         }
+        if (local64) {
+            const double r64 = s_var[a] == s_var[b] ? 1.0 : sacc / (s_sd[a] * s_sd[b]);
+            local64[(size_t)a * m + b] = r64;
+            local64[(size_t)b * m + a] = r64;
+            continue;
+        }
         double r = sacc / (s_sd[a] * s_sd[b]);
         if (r > 1.0) r = 1.0;
         if (r < -1.0) r = -1.0;
@@ -1134,7 +1154,12 @@ __global__ __launch_bounds__(FZNZ_NT) void fznz_submat_kernel(const float *__res
         local[(size_t)a * m + b] = rf;
         local[(size_t)b * m + a] = rf;
     }
-    for (int t = tid; t < m; t += FZNZ_NT) local[(size_t)t * m + t] = 1.0f;
+    for (int t = tid; t < m; t += FZNZ_NT) {
+        if (local64)
+            local64[(size_t)t * m + t] = 1.0;
+        else
+            local[(size_t)t * m + t] = 1.0f;
+    }
     if (tid == 0) {
         rec->nR = (int32_t)nR;
         const long long sf = nR - 3;
@@ -1144,9 +1169,28 @@ __global__ __launch_bounds__(FZNZ_NT) void fznz_submat_kernel(const float *__res
 }
 
 // ---- explicit single tests (fw_test_batch): one thread per test on the job's local matrix ----
+// StatsBase.partialcor on a job's Float64 correlation matrix (statfuns.jl:19-21): condition on Z_k, ..., Z_1 in turn, clamp at the end
+// (the recursion of fw_fzs.hip / the oracle's fwo_pcor, one thread, m <= FW_MAX_K + 2)
+__device__ double fznz_partialcor64(const double *__restrict__ C, int m)
+{
+    double R[FW_MAX_K + 2][FW_MAX_K + 2];
+    for (int a = 0; a < m; ++a)
+        for (int b = 0; b < m; ++b) R[a][b] = C[a * m + b];
+    for (int t = m - 1; t >= 2; --t)
+        for (int a = 0; a < t; ++a)
+            for (int b = a + 1; b < t; ++b) {
+                const double r = (R[a][b] - R[a][t] * R[b][t]) / (sqrt(1.0 - R[a][t] * R[a][t]) * sqrt(1.0 - R[b][t] * R[b][t]));
+                R[a][b] = R[b][a] = r;
+            }
+    double r = R[0][1];
+    if (r < -1.0) r = -1.0;
+    if (r > 1.0) r = 1.0;
+    return r;
+}
+
 __global__ __launch_bounds__(64) void fznz_single_kernel(const FwNzJob *__restrict__ recs, const float *__restrict__ arena,
                                                          long long m_tests, long long n_obs_min,
-                                                         fw_test_result *__restrict__ out)
+                                                         fw_test_result *__restrict__ out, const double *__restrict__ arena64)
 {
     const long long t = (long long)blockIdx.x * 64 + threadIdx.x;
     if (t >= m_tests) return;
@@ -1166,7 +1210,7 @@ __global__ __launch_bounds__(64) void fznz_single_kernel(const FwNzJob *__restri
     } else {
         int z[FW_MAX_K];
         for (int q = 0; q < FW_MAX_K; ++q) z[q] = 2 + q;
-        const double r = fz_pcor_any(arena + rec.cor_off, rec.m, 0, 1, z, rec.acc_len);
+        const double r = arena64 ? fznz_partialcor64(arena64 + rec.cor_off, rec.m) : fz_pcor_any(arena + rec.cor_off, rec.m, 0, 1, z, rec.acc_len);
         o.stat = r;
         o.pval = fz_pval_dev(r, rec.zscale);
         o.df = 0;
@@ -1266,7 +1310,7 @@ static double fznz_xcrit(double alpha)
 
 // recs_host: one record per job of this launch (X, Y, acc_off, acc_len, m, cor_off filled); d_acc: flat accepted ints
 int fwi_fznz_submatrices(fw_ctx *ctx, int64_t njobs, const FwNzJob *recs_host, size_t arena_floats, const int32_t *d_acc,
-                         hipStream_t stream)
+                         hipStream_t stream, bool f64)
 {
     int rc;
     static const bool nz_trace = fw_knob("FW_NZ_TRACE") != nullptr;  // profiling: shape of every sub-matrix launch
@@ -1280,7 +1324,7 @@ int fwi_fznz_submatrices(fw_ctx *ctx, int64_t njobs, const FwNzJob *recs_host, s
         fprintf(stderr, "[fw] fz_nz sub-matrices: %lld jobs (%lld univariate), largest m %lld, %lld pairs\n", (long long)njobs, uni, mmax, pairs);
     }
     if ((rc = fw_dev_reserve(ctx, ctx->d_nzrecs, (size_t)njobs * sizeof(FwNzJob)))) return rc;
-    if ((rc = fw_dev_reserve(ctx, ctx->d_arena, std::max<size_t>(arena_floats, 1) * sizeof(float)))) return rc;
+    if ((rc = fw_dev_reserve(ctx, ctx->d_arena, std::max<size_t>(arena_floats, 1) * (f64 ? sizeof(double) : sizeof(float))))) return rc;
     FW_HIP(ctx, hipMemcpyAsync(ctx->d_nzrecs.ptr, recs_host, (size_t)njobs * sizeof(FwNzJob), hipMemcpyHostToDevice, stream));
     int m_cap = 4;
     for (int64_t j = 0; j < njobs; ++j) m_cap = std::max(m_cap, (int)recs_host[j].m);
@@ -1294,7 +1338,7 @@ int fwi_fznz_submatrices(fw_ctx *ctx, int64_t njobs, const FwNzJob *recs_host, s
     }
     hipLaunchKernelGGL(fznz_submat_kernel, dim3((unsigned)njobs), dim3(FZNZ_NT), lds, stream, ctx->d_data,
                        (const unsigned long long *)ctx->d_nzbits, ctx->P.n, ctx->W, (FwNzJob *)ctx->d_nzrecs.ptr, d_acc,
-                       (float *)ctx->d_arena.ptr, ctx->P.alpha, m_cap, fznz_xcrit(ctx->P.alpha));
+                       (float *)ctx->d_arena.ptr, ctx->P.alpha, m_cap, fznz_xcrit(ctx->P.alpha), f64 ? (double *)ctx->d_arena.ptr : (double *)nullptr);
     FW_HIP(ctx, hipGetLastError());
     ctx->cnt.kernel_launches += 1;
     return FW_OK;
@@ -1350,10 +1394,11 @@ int fwi_fznz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t 
     if ((rc = fw_dev_reserve(ctx, ctx->d_out, (size_t)m * sizeof(fw_test_result)))) return rc;
     if (nz > 0)
         FW_HIP(ctx, hipMemcpyAsync(ctx->d_acc.ptr, zflat, (size_t)nz * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = fwi_fznz_submatrices(ctx, m, recs.data(), arena, (const int32_t *)ctx->d_acc.ptr, ctx->stream))) return rc;
+    const bool f64 = !ctx->P.recursive_pcor;  // no cor_mat: StatsBase.partialcor on the view (tests.jl:253)
+    if ((rc = fwi_fznz_submatrices(ctx, m, recs.data(), arena, (const int32_t *)ctx->d_acc.ptr, ctx->stream, f64))) return rc;
     hipLaunchKernelGGL(fznz_single_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, ctx->stream,
                        (const FwNzJob *)ctx->d_nzrecs.ptr, (const float *)ctx->d_arena.ptr, (long long)m,
-                       (long long)ctx->n_obs_min_eff, (fw_test_result *)ctx->d_out.ptr);
+                       (long long)ctx->n_obs_min_eff, (fw_test_result *)ctx->d_out.ptr, f64 ? (const double *)ctx->d_arena.ptr : (const double *)nullptr);
     FW_HIP(ctx, hipGetLastError());
     FW_HIP(ctx, hipMemcpyAsync(out, ctx->d_out.ptr, (size_t)m * sizeof(fw_test_result), hipMemcpyDeviceToHost, ctx->stream));
     FW_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -34,6 +34,8 @@ struct FzsDev {
     int n, p;
     double zscale;      // sqrt(n - 3) / 2, 0 if n <= 3
     long long n_obs_min;
+    int nzjobs;         // fz_nz without a matrix (r04): a job's matrix is the correlation of its ROW VIEW (fznz_submat_kernel, Float64), its
+                        // sample size and z scale come from its record (GRAM kernels only)
 };
 
 __device__ __forceinline__ double fzs_pval(double r, double zscale)
@@ -401,8 +403,32 @@ __global__ __launch_bounds__(256, FZS_SEG_OCC) void fzs_subsets_seg_kernel(FzsDe
     __shared__ int s_idx[GRAM ? 4 : 1][GRAM ? FZS_GMAX : 1][GRAM ? K + 2 : 1];
     const double *cjob = nullptr;
     int mjob = 0;
+    double zs_job = P.zscale;
+    bool power = (long long)P.n >= P.n_obs_min;  // sufficient_power(X, Y, data, test_obj, n_obs_min), tests.jl:9-12,252
     if (GRAM) {
         const FwNzJob rec = recs[seg.pad];
+        if (P.nzjobs) {  // the data of the job is its row view: size(data, 1) = rec.nR (tests.jl:293-296, 252-256)
+            if ((long long)rec.nR < P.n_obs_min) {  // (0, 1, 0, false) with zero tests
+                if (threadIdx.x == 0) {
+                    FwSegOut o;
+                    o.stop_rank = 0;
+                    o.stop_stat = 0.0;
+                    o.stop_pval = 1.0;
+                    o.best_rank = 0;
+                    o.best_stat = 0.0;
+                    o.best_pval = -1.0;
+                    o.stop_df = -2;  // marker: no test was executed (fwi_pool_collect)
+                    o.stop_power = 0;
+                    o.best_df = 0;
+                    o.pad = 0;
+                    o.evaluated = 0;
+                    out[blockIdx.x] = o;
+                }
+                return;
+            }
+            zs_job = rec.zscale;
+            power = true;
+        }
         mjob = rec.m;
         cjob = arena + rec.cor_off;
         if (mjob <= lds_m) {
@@ -411,7 +437,6 @@ __global__ __launch_bounds__(256, FZS_SEG_OCC) void fzs_subsets_seg_kernel(FzsDe
             cjob = s_cjob;
         }
     }
-    const bool power = (long long)P.n >= P.n_obs_min;  // sufficient_power(X, Y, data, test_obj, n_obs_min), tests.jl:9-12,252
     if (T > 0) {
         const int n4 = P.n >> 2;
         const float4 *gx = (const float4 *)(P.data + (size_t)seg.X * P.n), *gy = (const float4 *)(P.data + (size_t)seg.Y * P.n);
@@ -482,7 +507,7 @@ __global__ __launch_bounds__(256, FZS_SEG_OCC) void fzs_subsets_seg_kernel(FzsDe
                 }
                 if (power) {
                     FZS_WAVE_SYNC()
-                    fzs_finish<K, GRAM>(s_q[wave], s_m[wave], ng, P.zscale, cjob, mjob, GRAM ? &s_idx[wave][0][0] : nullptr);
+                    fzs_finish<K, GRAM>(s_q[wave], s_m[wave], ng, zs_job, cjob, mjob, GRAM ? &s_idx[wave][0][0] : nullptr);
                 }
                 my_done += (unsigned int)ng;
                 bool stopped = false;
@@ -707,6 +732,7 @@ FzsDev fzs_dev(const fw_ctx *ctx)
     P.n = ctx->P.n;
     P.p = ctx->P.p;
     P.zscale = ctx->P.n > 3 ? std::sqrt((double)(ctx->P.n - 3)) / 2.0 : 0.0;
+    P.nzjobs = 0;
     P.n_obs_min = ctx->n_obs_min_eff;
     return P;
 }
@@ -805,6 +831,37 @@ int fwi_fzs_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32
         if (ctx->P.max_k <= 3) FZS_SEG(3, 0, false); else FZS_SEG(FW_MAX_K, 0, false);
     }
 #undef FZS_SEG
+    FW_HIP(ctx, hipGetLastError());
+    FW_HIP(ctx, hipEventRecord(pb.ev1, pb.launch_stream));
+    return FW_OK;
+}
+
+// fz_nz without a matrix (fw_params.recursive_pcor = 0 with FW_FZ_NZ; the reference's FzTestCond with an empty cor_mat on the row views
+// of hiton.jl:85, tests.jl:253 -> statfuns.jl:19-21): the job records and their Float64 view matrices are already on the device
+// (fwi_fznz_submatrices with f64 = true wrote them into ctx->d_arena); the GRAM segment kernel conditions them as StatsBase.partialcor
+// does, with each job's own sample size.
+int fwi_fzs_segments_nz(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb, int m_max)
+{
+    if (nseg == 0) return FW_OK;
+    FW_HIP(ctx, hipEventRecord(pb.ev0, pb.launch_stream));
+    FzsDev P;
+    P.data = (const float *)ctx->d_data;
+    P.st = nullptr;
+    P.n = ctx->P.n;
+    P.p = ctx->P.p;
+    P.zscale = 0.0;
+    P.n_obs_min = ctx->n_obs_min_eff;
+    P.nzjobs = 1;
+    const int lds_m = std::min(m_max, 80);
+    const size_t lds = (size_t)lds_m * lds_m * sizeof(double);
+    if (ctx->P.max_k <= 3)
+        hipLaunchKernelGGL((fzs_subsets_seg_kernel<3, 0, true>), dim3((unsigned)nseg), dim3(256), lds, pb.launch_stream, P, d_segs, d_acc, d_out,
+                           ctx->P.max_k, ctx->P.alpha, (long long)ctx->P.max_tests, (const FwNzJob *)ctx->d_nzrecs.ptr,
+                           (const double *)ctx->d_arena.ptr, lds_m);
+    else
+        hipLaunchKernelGGL((fzs_subsets_seg_kernel<FW_MAX_K, 0, true>), dim3((unsigned)nseg), dim3(256), lds, pb.launch_stream, P, d_segs, d_acc,
+                           d_out, ctx->P.max_k, ctx->P.alpha, (long long)ctx->P.max_tests, (const FwNzJob *)ctx->d_nzrecs.ptr,
+                           (const double *)ctx->d_arena.ptr, lds_m);
     FW_HIP(ctx, hipGetLastError());
     FW_HIP(ctx, hipEventRecord(pb.ev1, pb.launch_stream));
     return FW_OK;

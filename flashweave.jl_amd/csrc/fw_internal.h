@@ -224,14 +224,15 @@ int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *d_
 int fwi_fzs_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff, const int32_t *zflat,
                        fw_test_result *out);
 int fwi_fzs_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb,
-                     const FwNzJob *recs_host, int64_t njobs, size_t arena_doubles);  // recs: one per launched job (FwSeg::pad indexes them); rec.nR != 0: matrix to be computed
+                     const FwNzJob *recs_host, int64_t njobs, size_t arena_doubles);
+int fwi_fzs_segments_nz(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb, int m_max);  // fz_nz, recursive_pcor = 0  // recs: one per launched job (FwSeg::pad indexes them); rec.nR != 0: matrix to be computed
 
 // ---- HE-S / fz_nz (fw_fz.hip) ----
 int fwi_fznz_upload(fw_ctx *ctx, const float *data);
 int fwi_fznz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &pj, std::vector<double> &stat,
                     std::vector<double> &pval, int64_t *m_reliable, FwL0Dev *dev);
 int fwi_fznz_submatrices(fw_ctx *ctx, int64_t njobs, const FwNzJob *recs_host, size_t arena_floats, const int32_t *d_acc,
-                         hipStream_t stream);
+                         hipStream_t stream, bool f64 = false);
 int fwi_fznz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb);
 int fwi_fznz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff,
                         const int32_t *zflat, fw_test_result *out);

@@ -65,7 +65,8 @@ typedef struct fw_params {
     int64_t n_obs_min; /* default -1 = automatic (src/learning.jl:51-64, fires for every test kind) */
     int64_t max_tests; /* default 10_000_000 per (T, candidate) pair (src/learning.jl:205) */
     double alpha;      /* default 0.01 */
-    int32_t recursive_pcor; /* FW_FZ only.  1 (default): conditional tests are recursive partial correlations on the resident
+    int32_t recursive_pcor; /* FW_FZ and FW_FZ_NZ (r04: for FW_FZ_NZ the correlations of a job's ROW VIEW, hiton.jl:85, in Float64,
+                             * conditioned as StatsBase.partialcor does, with the view's own sample size).  1 (default): conditional tests are recursive partial correlations on the resident
                              * Pearson matrix (pcor_rec, src/statfuns.jl:23-75).  0: no correlation matrix is used for them --
                              * every test streams its k + 2 sample columns from HBM and computes the partial correlation from
                              * the data (pcor -> StatsBase.partialcor, src/statfuns.jl:19-21; the FzTestCond with an empty

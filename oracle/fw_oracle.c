@@ -1179,6 +1179,26 @@ static int64_t fz_nz_cor_subset(const fwo_ctx *c, int X, int Y, const int *vars,
     return nR;
 }
 
+/* fz_nz with recursive_pcor = false (tests.jl:253 on the row view of hiton.jl:85: FzTestCond with an empty cor_mat): the conditional
+ * tests are StatsBase.partialcor of the view's columns.  stream != 0 switches a FWO_FZ_NZ context to that form. */
+void fwo_fz_nz_set_stream(fwo_ctx *c, int stream) { c->fz_stream = stream; }
+
+/* the rows R (X != 0 and Y != 0) of the columns `vars` as an nR x m column-major Float64 matrix (caller frees) */
+static double *fz_nz_view(const fwo_ctx *c, int X, int Y, const int *vars, int m, int64_t *nR_out)
+{
+    int64_t nR = 0;
+    for (int i = 0; i < c->n; ++i)
+        if (FD(c, i, X) != 0.0 && FD(c, i, Y) != 0.0) ++nR;
+    double *v = (double *)malloc(sizeof(double) * (size_t)((nR > 0 ? nR : 1) * m));
+    for (int a = 0; a < m; ++a) {
+        int64_t q = 0;
+        for (int i = 0; i < c->n; ++i)
+            if (FD(c, i, X) != 0.0 && FD(c, i, Y) != 0.0) v[(int64_t)a * nR + q++] = FD(c, i, vars[a]);
+    }
+    *nR_out = nR;
+    return v;
+}
+
 /* conditional fz_nz test of one explicit subset (tests.jl:250-265 on the row view of hiton.jl:85) */
 static void fz_nz_test_cond(const fwo_ctx *c, int X, int Y, const int *Zs, int k, int64_t n_obs_min, fwo_result *out)
 {
@@ -1202,6 +1222,15 @@ static void fz_nz_test_cond(const fwo_ctx *c, int X, int Y, const int *Zs, int k
     tmp.p = m;
     tmp.n = tmp.n_obs = (int)nR;
     tmp.cor32 = local;
+    if (c->fz_stream) { /* no cor_mat: pcor on the view's columns */
+        int64_t nv;
+        double *view = fz_nz_view(c, X, Y, vars, m, &nv);
+        tmp.fdata = view;
+        const double ps = fwo_pcor(&tmp, 0, 1, loc, k);
+        free(view);
+        set_result(out, ps, fwo_fz_pval(ps, nR, 0), 0, 1);
+        return;
+    }
     const double p_stat = pcor_rec(&tmp, 0, 1, loc, k).v;
     set_result(out, p_stat, fwo_fz_pval(p_stat, nR, 0), 0, 1);
 }
@@ -1293,9 +1322,17 @@ int fwo_test_subsets(fwo_ctx *c, int X, int Y, const int *Z_total, int nZ, int m
             tmp.p = m;
             tmp.n = tmp.n_obs = (int)nR;
             tmp.cor32 = local;
+            double *view = NULL;
+            if (c->fz_stream) { /* no cor_mat (recursive_pcor = false): every test is pcor on the view's columns, tests.jl:253 */
+                int64_t nv;
+                view = fz_nz_view(c, X, Y, vars, m, &nv);
+                tmp.fdata = view;
+                tmp.fz_stream = 1;
+            }
             int zl[16];
             status = fwo_test_subsets(&tmp, 0, 1, locZ, nZ, max_k, alpha, hps, n_obs_min, max_tests, out, zl, nZs_out,
                                       num_tests_out, frac_out);
+            free(view);
             for (int j = 0; j < *nZs_out; ++j) Zs_out[j] = Z_total[zl[j] - 2];
             free(local);
         }

@@ -73,6 +73,7 @@ def lib():
         L.fwo_pcor.restype = C.c_double
         L.fwo_pcor.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
         L.fwo_fz_set_data.argtypes = [vp, vp, C.c_int]
+        L.fwo_fz_nz_set_stream.argtypes = [vp, C.c_int]
         L.fwo_benjamini_hochberg.argtypes = [vp, C.c_int64, C.c_double, C.c_int64]
         L.fwo_level0.restype = vp
         L.fwo_level0.argtypes = [vp, C.c_double, C.c_int, C.c_int64, C.c_int, C.c_int]
@@ -215,6 +216,10 @@ class Oracle:
         d = np.asfortranarray(np.asarray(data, dtype=np.float64))
         self._keep.append(d)
         self.L.fwo_fz_set_data(self.h, _ptr(d), int(stream))
+
+    def set_fz_nz_stream(self, stream=True):
+        """fz_nz: conditional tests through pcor on the row view (recursive_pcor = false: FzTestCond without cor_mat, tests.jl:253)."""
+        self.L.fwo_fz_nz_set_stream(self.h, int(stream))
 
     def pcor(self, X, Y, Zs):
         z = np.asarray(Zs, dtype=np.int32)

@@ -113,3 +113,88 @@ def test_golden_networks_fz_nz(max_k):
     for e in exp:
         assert abs(got[e] - exp[e]) <= 2e-5
     eng.close()
+
+
+# ---- fz_nz without a correlation matrix (recursive_pcor = False) ---------------------------------------------------------------
+# The reference's FzTestCond with an empty cor_mat on the row views of hiton.jl:85 (tests.jl:253 -> statfuns.jl:19-21): every
+# conditional test is StatsBase.partialcor of the view's columns.  Device: Float64 view correlations per job (fznz_submat_kernel) +
+# the conditioning kernels of fw_fzs.hip with the job's own sample size.  Summation orders differ from the oracle's: 1e-10.
+RTOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def ctx_s():
+    data = _synth(250, 400, 37)
+    n, p = data.shape
+    eng = fw.Engine("fz_nz", n, p, max_k=3, recursive_pcor=False)
+    eng.set_data(data)
+    orc = O.Oracle("fz_nz", data=data.astype(np.float64))
+    orc.set_fz_nz_stream(True)
+    return dict(data=data, n=n, p=p, eng=eng, orc=orc)
+
+
+def _near(a, b):
+    return _same(a, b) or rel(a, b) < RTOL or abs(a - b) < 1e-14
+
+
+def test_no_matrix_single_tests(ctx_s):
+    eng, orc, p = ctx_s["eng"], ctx_s["orc"], ctx_s["p"]
+    rng = np.random.default_rng(12)
+    X, Y, Zs = [], [], []
+    for _ in range(1200):
+        k = int(rng.integers(0, 4))
+        v = rng.choice(p, size=k + 2, replace=False)
+        X.append(int(v[0])); Y.append(int(v[1])); Zs.append(tuple(int(t) for t in v[2:]))
+    got = eng.test_batch(X, Y, Zs)
+    npow = ndiff = 0
+    rec = fw.Engine("fz_nz", ctx_s["n"], p, max_k=3)  # the recursive form on the same data: a different statistic for k >= 2
+    rec.set_data(ctx_s["data"])
+    got_rec = rec.test_batch(X, Y, Zs)
+    rec.close()
+    for x, y, z, g, gr in zip(X, Y, Zs, got, got_rec):
+        s, pv, df, pw = orc.test(x, y, z, n_obs_min=20)
+        assert g.suff_power == pw and g.df == 0 and _near(g.stat, s), (x, y, z, g, (s, pv, pw))
+        assert _near(g.pval, pv) or abs(g.pval - pv) < 1e-12, (x, y, z, g, pv)
+        npow += pw
+        ndiff += pw and len(z) >= 2 and g.stat != gr.stat
+    assert npow > 100 and ndiff > 20
+
+
+def test_no_matrix_test_subsets(ctx_s):
+    eng, orc, p = ctx_s["eng"], ctx_s["orc"], ctx_s["p"]
+    nb = orc.level0(alpha=0.01, n_obs_min=20)
+    rng = np.random.default_rng(15)
+    T, C, A = [], [], []
+    for _ in range(120):
+        a = int(rng.integers(1, 14))
+        v = rng.choice(p, size=a + 2, replace=False)
+        T.append(int(v[0])); C.append(int(v[1])); A.append([int(t) for t in v[2:]])
+    for t in range(p):
+        nbr = [int(u) for u in nb["idx"][nb["off"][t]:nb["off"][t + 1]]]
+        if len(nbr) >= 4:
+            T.append(t); C.append(nbr[0]); A.append(nbr[1:12])
+    got = eng.test_subsets_batch(T, C, A)
+    kinds = set()
+    for t, c, a, g in zip(T, C, A, got):
+        e = orc.test_subsets(t, c, a, max_k=3, alpha=0.01, n_obs_min=20)
+        assert g["status"] == e["status"] and g["num_tests"] == e["num_tests"], (t, c, a, g, e)
+        if e["status"] == 0:
+            continue
+        assert g["Zs"] == e["Zs"] and _near(g["stat"], e["stat"]) and g["suff_power"] == e["suff_power"], (g, e)
+        assert _near(g["pval"], e["pval"]) or abs(g["pval"] - e["pval"]) < 1e-12
+        kinds.add((e["status"], e["num_tests"] == 0))
+    assert (1, True) in kinds and (1, False) in kinds
+
+
+@pytest.mark.parametrize("ff,R", [(False, 0), (True, 16)])
+def test_no_matrix_network_matches_oracle(ctx_s, ff, R):
+    data, n, p, orc = ctx_s["data"], ctx_s["n"], ctx_s["p"], ctx_s["orc"]
+    eng = fw.Engine("fz_nz", n, p, max_k=3, recursive_pcor=False)
+    eng.set_data(data)
+    got = eng.lgl(feed_forward=ff, round_size=R)
+    exp = orc.learn(max_k=3, feed_forward=ff, round_size=max(R, 1) if ff else 1)
+    assert set(got["edges"]) == set(exp["edges"]) and len(exp["edges"]) > 0
+    for e, w in exp["edges"].items():
+        assert _near(got["edges"][e], w), (e, got["edges"][e], w)
+    assert eng.counters()["cond_tests_ref"] == exp["n_cond_tests"]
+    eng.close()
