@@ -726,7 +726,7 @@ __global__ __launch_bounds__(512) void mi_level0_mfma_kernel(MiDev P, int p, int
                                                             unsigned long long *prof /* FW_L0_VERBOSE: shader cycles per phase, else null */)
 {
     // staging words [side][plane][var][L0M_WC + 1] (36 KB; the pad word makes the operand reads of 32 consecutive variables conflict-free)
-    __shared__ unsigned long long s_raw[2 * 2 * L0M_T * (L0M_WC + 1)];
+    __shared__ unsigned long long s_raw[2 * 2 * 2 * L0M_T * (L0M_WC + 1)];  // two stage buffers
     __shared__ double s_gthr[8];
     __shared__ int4 s_meta[2 * L0M_T];
     __shared__ MiCand s_q[L0M_QCAP];
@@ -735,6 +735,8 @@ __global__ __launch_bounds__(512) void mi_level0_mfma_kernel(MiDev P, int p, int
     __shared__ unsigned long long s_qbase;
     __shared__ uint4 s_surv[L0M_SCAP];  // {local X | local Y << 8, A | B << 16, C | D << 16, -}: one eighth per wavefront
     unsigned long long(*sXY)[2][L0M_T][L0M_WC + 1] = (unsigned long long(*)[2][L0M_T][L0M_WC + 1])s_raw;  // [side]
+    unsigned long long(*const sXY0)[2][L0M_T][L0M_WC + 1] = sXY;
+    (void)sXY0;
     // XCD-aware tile order: consecutive workgroups go round-robin to the eight XCDs, each with its own 4 MB L2.  The tile list is cut
     // into SUPER-TILES of L0M_S x L0M_S tiles (16 x 128 variables x 2 planes x n / 8 bytes = 2.6 MB at n = 5 000: L2-resident) and the
     // workgroups of one XCD (blockIdx & 7) work through the tiles of one super-tile after the other, so a column of bit planes crosses
@@ -818,36 +820,48 @@ __global__ __launch_bounds__(512) void mi_level0_mfma_kernel(MiDev P, int p, int
             _Pragma("unroll") for (int py_ = 0; py_ < 2; ++py_)                            \
                 acc[a_][px_][py_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(f_[a_][px_], f_[2][py_], acc[a_][px_][py_], 4, 4, 0, 127, 0, 127); \
     }
+    // Two stage buffers: stage s + 1 is written to the other buffer after stage s has been multiplied (its words arrived in registers
+    // meanwhile), so a stage costs ONE barrier and no wavefront waits between a barrier and its LDS writes.
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int e = q * 512 + tid;
+        sXY[e >> 11][(e >> 3) & 1][(e & 2047) >> 4][e & 7] = rr[q];
+    }
+    __syncthreads();
     for (int w0 = 0; w0 < P.W; w0 += L0M_WC) {
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int e = q * 512 + tid;
-            sXY[e >> 11][(e >> 3) & 1][(e & 2047) >> 4][e & 7] = rr[q];
-        }
-        __syncthreads();
-        if (w0 + L0M_WC < P.W) fetch(w0 + L0M_WC);
-        if (dbg & 4) continue;
-        unsigned wa[3][2], wb[3][2];  // [X block 0, X block 1, Y block][plane]: this lane's 32 samples of its operand rows
-        l0m_v8i f0[3][2], f1[3][2];
-        L0M_WORDS(wa, 0);
-        L0M_EXPAND4(f0, wa);
-#pragma unroll 1
-        for (int w = 0; w < L0M_WC; w += 2) {  // two words per trip: the operand buffers alternate without register copies
-            L0M_WORDS(wb, w + 1);
-            const int wn = w + 2 < L0M_WC ? w + 2 : w + 1;  // the last trip expands a word again instead of branching
-            L0M_WORDS(wa, wn);
-            L0M_EXPAND4(f1, wb);
-            L0M_MFMA8F(f0);
+        const bool more = w0 + L0M_WC < P.W;
+        if (more) fetch(w0 + L0M_WC);
+        if (!(dbg & 4)) {
+            unsigned wa[3][2], wb[3][2];  // [X block 0, X block 1, Y block][plane]: this lane's 32 samples of its operand rows
+            l0m_v8i f0[3][2], f1[3][2];
+            L0M_WORDS(wa, 0);
             L0M_EXPAND4(f0, wa);
-            L0M_MFMA8F(f1);
-            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll 1
+            for (int w = 0; w < L0M_WC; w += 2) {  // two words per trip: the operand buffers alternate without register copies
+                L0M_WORDS(wb, w + 1);
+                const int wn = w + 2 < L0M_WC ? w + 2 : w + 1;  // the last trip expands a word again instead of branching
+                L0M_WORDS(wa, wn);
+                L0M_EXPAND4(f1, wb);
+                L0M_MFMA8F(f0);
+                L0M_EXPAND4(f0, wa);
+                L0M_MFMA8F(f1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                for (int q = 0; q < 16; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                }
             }
         }
+        sXY = sXY == sXY0 ? sXY0 + 2 : sXY0;  // (a buffer is [2 sides])
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = q * 512 + tid;
+                sXY[e >> 11][(e >> 3) & 1][(e & 2047) >> 4][e & 7] = rr[q];
+            }
+        }
+        __syncthreads();
     }
 #undef L0M_EXPAND4
 #undef L0M_MFMA8F

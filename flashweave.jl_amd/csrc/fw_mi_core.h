@@ -201,6 +201,27 @@ static __device__ __forceinline__ void mi_load_words(MiWords<KM> &w, const unsig
     w.vm = !ok ? 0u : (left >= 32 ? 0xffffffffu : ((1u << left) - 1u));
 }
 
+// byte form of the loader (n <= 512: lane l holds rows 8 l .. 8 l + 7 of every plane -- 64 lanes share the rows of a small table instead
+// of 16 lanes holding a 32-row word each; the fields of MiWords then carry 8 bits)
+template <int L, int KM>
+static __device__ __forceinline__ void mi_load_bytes(MiWords<KM> &w, const unsigned *pn, const unsigned *ph, const unsigned *xn,
+                                                     const unsigned *xh, const unsigned *yn, const unsigned *yh, size_t W2,
+                                                     const MiZs &zs, int k, int lane, int n)
+{
+    const bool ok = 8 * lane < n;
+    w.xn = ok ? ((const unsigned char *)xn)[lane] : 0u;
+    w.yn = ok ? ((const unsigned char *)yn)[lane] : 0u;
+    w.xh = (L == 3 && ok && xh) ? ((const unsigned char *)xh)[lane] : 0u;
+    w.yh = (L == 3 && ok && yh) ? ((const unsigned char *)yh)[lane] : 0u;
+#pragma unroll
+    for (int j = 0; j < KM; ++j) {
+        w.zn[j] = (j < k && ok) ? ((const unsigned char *)(pn + (size_t)zs.v[j] * W2))[lane] : 0u;
+        w.zh[j] = (L == 3 && j < k && ok && ph) ? ((const unsigned char *)(ph + (size_t)zs.v[j] * W2))[lane] : 0u;
+    }
+    const int left = n - 8 * lane;
+    w.vm = !ok ? 0u : (left >= 8 ? 0xffu : ((1u << left) - 1u));
+}
+
 // adds the rows of one word to the cell counters of batch b (strata b * SB .. b * SB + SB - 1)
 template <int L, int NXY, int KM>
 static __device__ __forceinline__ void mi_count_words(const MiWords<KM> &w, unsigned (&acc)[L * L][NXY * NXY + 1], int b, int k, int SB,
@@ -392,13 +413,24 @@ static __device__ __forceinline__ MiRes mi_test_core(const MiDev &P, const int X
     constexpr int NIT = PRE ? 3 : 1;
     constexpr int KM = PRE ? 3 : MI_MAX_K;  // the register-resident form serves k <= 3 (the host picks PRE only for max_k <= 3)
     MiWords<KM> wd[NIT];
-    if (PRE) {
+    // small tables (n <= 512, k >= 2): the row form on BYTES -- every lane walks at most eight rows whatever k, where the popcount
+    // form keeps 16 lanes busy with 9 .. 27 strata x cells each (cfg2: n = 500)
+    const bool byteform = P.n <= 512 && !tot_sep && k >= P.rowk && k >= 2;
+    if (PRE && !byteform) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) mi_load_words<L, KM>(wd[it], pn, ph, xn, xh, yn, yh, W2, zs, k, it * 64 + lane, nd, P.n);
     }
     // row form or popcount form?  Both fill the same table; an estimate of their instruction counts decides (wave-uniform).
     bool rowform = false;
-    if (!tot_sep && any_flag && k >= P.rowk) {  // (sub-tables of the nz-adjusted kinds: few rows; a dense sub-table walks 32 bits per word)
+    if (byteform) {
+        rowform = true;
+        const int nw = (S * NCT16 * (int)sizeof(TabT)) >> 2;
+        for (int q = lane; q < nw; q += 64) tab32[q] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        mi_load_bytes<L, KM>(wd[0], pn, ph, xn, xh, yn, yh, W2, zs, k, lane, P.n);
+        mi_bin_rows<L, NXY, KM, WIDE>(wd[0], tab32, k, flagX, flagY);
+    } else if (!tot_sep && any_flag && k >= P.rowk) {  // (sub-tables of the nz-adjusted kinds: few rows; a dense sub-table walks 32 bits per word)
         const int nslot = (nd + 63) >> 6;
         int steps;
         if (PRE) {
@@ -414,7 +446,7 @@ static __device__ __forceinline__ MiRes mi_test_core(const MiDev &P, const int X
         const int cost_pop = nbatch * (nslot * (SB * NC * 2 + 20) + SB * ((NC + 1) / 2) * 7);
         rowform = cost_rows < cost_pop;
     }
-    if (rowform) {
+    if (rowform && !byteform) {
         const int nw = (S * NCT16 * (int)sizeof(TabT)) >> 2;
         for (int q = lane; q < nw; q += 64) tab32[q] = 0u;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
