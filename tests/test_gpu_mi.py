@@ -166,6 +166,31 @@ def test_level0_matrix_core_form_equals_oracle(kind, monkeypatch):
     assert res["2m"] == res["0m"] == p * (p - 1) // 2
 
 
+def test_level0_matrix_core_form_many_samples(monkeypatch):
+    """Counts above 2^15 (the epilogue packs two 16-bit counts per word, the MX-fp4 accumulators hold them as Float32) and a sample
+    count that is no multiple of the 64-sample words or the 8-word stages: 40 037 samples, dense dependent three-valued columns."""
+    rng = np.random.default_rng(77)
+    n, p = 40037, 150
+    base = rng.integers(0, 3, size=(n, 6))
+    data = np.empty((n, p), dtype=np.int32)
+    for j in range(p):
+        flip = rng.random(n) < 0.55
+        data[:, j] = np.where(flip, rng.choice(3, size=n, p=[0.25, 0.4, 0.35]), base[:, j % 6])
+    res = {}
+    for knob in ("2", "0"):
+        monkeypatch.setenv("FW_L0_MFMA", knob)
+        eng = fw.Engine("mi_nz", n, p, max_k=3)
+        eng.set_data(data)
+        res[knob] = eng.pw_univar_neighbors()
+        nom = eng.n_obs_min
+        eng.close()
+    for f in ("off", "idx", "stat", "pval"):
+        assert np.array_equal(res["2"][f], res["0"][f]), f
+    exp = O.Oracle("mi_nz", data, sparse=True, max_k=3).level0(alpha=0.01, hps=5, n_obs_min=nom)
+    assert (res["2"]["off"] == exp["off"]).all() and (res["2"]["idx"] == exp["idx"]).all() and len(exp["idx"]) > 1000
+    assert np.allclose(res["2"]["stat"], exp["stat"], rtol=STOL, atol=0) and np.allclose(res["2"]["pval"], exp["pval"], rtol=PTOL, atol=0)
+
+
 @pytest.mark.parametrize("ff,R", [(False, 0), (True, 1), (True, 16)])
 def test_network_matches_oracle(ctx, ff, R):
     kind, data, n, p, orc = ctx["kind"], ctx["data"], ctx["n"], ctx["p"], ctx["orc"]
