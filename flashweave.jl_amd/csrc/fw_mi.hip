@@ -667,16 +667,19 @@ __global__ __launch_bounds__(256) void mi_level0_kernel(MiDev P, int p, int T, c
 // kernel 1, matrix-core form (r04; three-valued data, n <= 65 535).  The four counts of a pair are four entries of the Gram matrix
 // of the 2p bit planes over the n samples: A = <nzX, nzY>, B = <hiX, nzY>, C = <nzX, hiY>, D = <hiX, hiY> -- a binary GEMM that
 // the popcount form above runs at the integer-VALU peak (16 instructions per pair and 64-sample word: ~40 ms at cfg4 whatever the
-// tiling).  v_mfma_i32_32x32x32_i8 does 32 768 multiply-adds per ~32 cycles and SIMD, four times the popcount rate, and an int32
-// accumulator holds a count exactly.  Workgroup tile 128 x 128 variables, four wavefronts with 64 x 64 variables each = 2 x 2
-// blocks of 32 x 32 variables x 4 plane pairs = 16 accumulator tiles (256 registers: one wavefront per SIMD, the unified 512-
-// register file).  The bit planes are staged in LDS as 64-sample words (4 KB per word and tile side, double-buffered through
-// registers like the popcount form); every lane reads the 32-bit half-word of its operand row (lane & 31: the row, lane >> 5: which
-// half) and expands 16 bits to the 16 bytes of an operand register quadruple with v_bfe / v_mul_u32_u24 / v_and (bit i of a nibble
-// times 0x204081 lands on bit 8 i).  Any assignment of samples to the K index of the instruction is right as long as both operands
-// use the same one -- the sum over samples does not depend on their order -- so no layout table is involved beyond "row = lane & 31,
-// K group = lane >> 5" for both operands and the documented C layout (col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)).
-// The epilogue is the screen of the popcount form (mi_pair_screen) on counters parked in LDS, conflict-free ([entry][thread]).
+// tiling).  Final form: the MX-fp4 instruction v_mfma_scale_f32_32x32x64_f8f6f4 (L0M_FP4 = 1: bits as the E2M1 values 0 / 1, block
+// scale 2^0, counts exact in the Float32 accumulators; 65 536 multiply-adds per ~32 cycles and SIMD); L0M_FP4 = 0 builds the int8
+// form (v_mfma_i32_32x32x32_i8) that was measured first.  Workgroup tile 128 x 128 variables, 512 threads = eight wavefronts, TWO
+// PER SIMD (a lone wavefront issues one instruction per ~5.5 cycles whatever it executes: expansion and epilogue were issue-bound in
+// the 256-thread form); wavefront (wx, wy) owns 64 X x 32 Y variables = 2 blocks of 32 x 32 variables x 4 plane pairs = 8 accumulator
+// tiles (128 registers).  The bit planes are staged in LDS as 64-sample words, eight words per stage, two stage buffers (one barrier
+// per stage; the next stage's words travel through registers while the current one is multiplied); every lane reads the 32-bit
+// half-word of its operand row (lane & 31: the row, lane >> 5: which half) and expands its bits to operand registers -- fp4: register
+// q = bit q of every nibble, (w >> (q - 1)) & 0x22222222 (seven instructions for 32 samples); int8: register q of K step ks = bit
+// 4 ks + q of every byte.  ANY assignment of samples to the K index of the instruction is right as long as both operands use the same
+// one -- the sum over samples does not depend on their order -- so no layout table is involved beyond "row = lane & 31, K group =
+// lane >> 5" for both operands and the documented C layout (col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5));
+// profiles/tools/mfma_fp4_probe.cpp checks exactly that against host popcounts.  The epilogue is described at its place below.
 typedef int l0m_v4i __attribute__((ext_vector_type(4)));
 typedef int l0m_v16i __attribute__((ext_vector_type(16)));
 #define L0M_T 128
@@ -684,7 +687,7 @@ typedef int l0m_v16i __attribute__((ext_vector_type(16)));
 static_assert(L0M_T == 128 && L0M_WC == 8, "the staging map of mi_level0_mfma_kernel is written for 128-variable tiles and 8-word stages");
 #define L0M_S 8       // tiles per side of a super-tile (the unit of the XCD-aware order and of the sharded forms)
 #define L0M_QCAP 1024 // per-workgroup candidate queue
-#define L0M_SCAP 2048 // pairs per tile that pass the integer / Float32 verdicts and take the table look-ups (more: screened in place)
+#define L0M_SCAP 2048 // pairs per tile that pass the integer / Float32 verdicts of the first pass (an eighth per wavefront; more: to the exact kernel unscreened)
 
 // Four operand registers (16 bytes of 0 / 1) from this lane's 32 samples, K step ks (0 / 1): register q holds bit 4 ks + q of
 // each of the four bytes of the word -- (w >> (4 ks + q)) & 0x01010101, two instructions.  Which sample lands on which K index
