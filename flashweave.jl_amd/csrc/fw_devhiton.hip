@@ -2358,7 +2358,18 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         { const char *e = fw_knob("FW_MI_WIN0_TAIL"); P.mi_win0_tail = e ? (unsigned int)std::max(1, atoi(e)) : 1024u; }
     }
     const bool fz = c->P.kind == FW_FZ;
-    P.w0_small = fz ? 256ull : 16ull;
+    // first window of an interleaving-phase job with fewer than 64 accepted variables.  r04 sweep at cfg3 (two chains, look-ahead 4 / 2,
+    // growth 4; ms per pass / launches): 64: 198.7 / 9 790, 128: 194.8, 256 (r01-r03): 189.1 / 8 090, 512: 186.3, 1 024: 183.9, 2 048: 184.7,
+    // 4 096: 182.5 / 7 194, 8 192: 184.3, 16 384: 187.6 -- the executed tests move by less than 1 % over that range (a job that stops does
+    // so within its first wavefront steps whatever the window), the launches by 25 %.  max_k > 3 keeps 256 (not measured at full cfg5 size).
+    // Second sweep (first window 4 096): first window of jobs with 64 accepted variables or more 8 192: 191.2, 16 384 (r01-r03): 183.8,
+    // 24 576: 182.4, 32 768: 178.1 - 179.9, 49 152: 182.4, 65 536: 191.4; with 32 768 the small window 2 048: 177.3, 4 096: 178.1, 8 192: 181.7.
+    P.w0_small = fz ? (c->P.max_k <= 3 ? 2048ull : 256ull) : 16ull;
+    if (fz && c->P.max_k <= 3 && !fw_knob("FW_W0_BIG")) P.w0_big = 32768ull;
+    if (fz) {
+        const char *e = fw_knob("FW_W0_SMALL");  // first window (ranks) of a job with fewer than 64 accepted variables (r04 sweep: DESIGN section 4)
+        if (e && atoll(e) > 0) P.w0_small = (unsigned long long)atoll(e);
+    }
     if (!fz) P.w0_big = 16ull;
     P.seg_q = fz ? 256u : 4u;
     P.seg_min = fz ? 256u : 8u;
