@@ -2343,7 +2343,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
             const char *e = fw_knob("FW_DH_SPEC1");
             P.spec1_depth = c->P.kind == FW_FZ ? std::min(std::max(e ? atoi(e) : 2, 0), DH_MAX_SPEC) : 0;
         }
-        P.mi_seq = (unsigned int)envu("FW_MI_SEQ", 16ull);
+        P.mi_seq = (unsigned int)envu("FW_MI_SEQ", 48ull);  // r04 sweep on the final kernels (cfg4, ms with / without feed-forward, two runs each): 8: 149 / 106, 16 (r02-r03): 111.0 / 72.5, 24: 118 / 71.8, 32: 102.4 / 70.9, 48: 102.4 / 70.5, 64: 102.2 / 70.8, 128: 112.9 / 72.6, never a board: 111.5 / 79.1; cfg2 neutral
         P.mi_win0 = (unsigned int)envu("FW_MI_WIN0", 128ull);
         P.mi_chunk_div = (unsigned int)envu("FW_MI_CHUNK_DIV", 256ull);
         P.mi_chunk_min = (unsigned int)envu("FW_MI_CHUNK_MIN", 8ull);

@@ -2,10 +2,10 @@
 # r04: sweeps of the persistent discrete kernel's knobs at cfg4 on the final kernels: one line per setting (ms with / without feed-forward)
 export FW_KNOBS=1
 run() { local name=$1; shift
-  env "$@" timeout 300 python bench.py --config cfg4 --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; l=json.loads(sys.stdin.read()); print(\"$name\", round(l[\"ms_per_step\"],2), round(l[\"other_schedule\"][\"ms_per_step\"],2), l[\"edges\"], \"%.4g\"%l[\"tests_per_step\"][\"conditional_evaluated\"])"
+  env "$@" timeout 300 python bench.py --config cfg4 --steps 8 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; l=json.loads(sys.stdin.read()); print(\"$name\", round(l[\"ms_per_step\"],2), round(l[\"other_schedule\"][\"ms_per_step\"],2), l[\"edges\"], \"%.4g\"%l[\"tests_per_step\"][\"conditional_evaluated\"])"
 }
 run default FW_X=0
-for v in 8 32; do run "seq=$v" FW_MI_SEQ=$v; done
+for v in 16 96; do run "seq=$v" FW_MI_SEQ=$v; done
 for v in 32 512; do run "win0=$v" FW_MI_WIN0=$v; done
 for v in 24 96; do run "heavy=$v" FW_MI_HEAVY=$v; done
 for v in 2 8; do run "seq_tail=$v" FW_MI_SEQ_TAIL=$v; done
