@@ -195,6 +195,31 @@ def test_fz_nz_tests_expected(clr_nz64):
         assert (df, pw) == (edf, epw) and abs(s - es) < 1e-4 and rel(p, ep) < 1e-3
 
 
+def test_fz_nz_without_a_matrix(clr_nz64):
+    """fz_nz with recursive_pcor = false (fwo_fz_nz_set_stream: pcor -> StatsBase.partialcor on the row view, tests.jl:253 with an empty
+    cor_mat).  Anchors: (i) the reference's own conditional fz_nz rows of tests_expected.tsv -- computed there with pcor_rec, which
+    differs from pcor only by its 5-digit rounding: 1e-4, as the reference's statfuns test states for the pair; (ii) the partial
+    correlation from the inverse covariance of the view's columns (numpy), 1e-10; (iii) the view's own row count in the p-value."""
+    o = O.Oracle("fz_nz", data=clr_nz64)
+    o.set_fz_nz_stream(True)
+    rows = (clr_nz64[:, 30] != 0) & (clr_nz64[:, 20] != 0)
+    sub = clr_nz64[rows]
+    for key, Zs in (("condZ1", (6,)), ("condZ3", (6, 13, 17))):
+        s, p, df, pw = o.test(30, 20, Zs, n_obs_min=0)
+        es, ep, edf, epw = EXP["exp_%s_fz_nz" % key][0]
+        assert (df, pw) == (edf, epw) and abs(s - es) < 1e-4 and rel(p, ep) < 2e-3
+        cols = [30, 20] + list(Zs)
+        prec = np.linalg.inv(np.cov(sub[:, cols], rowvar=False))
+        r_np = -prec[0, 1] / np.sqrt(prec[0, 0] * prec[1, 1])
+        assert abs(s - r_np) < 1e-10
+        assert rel(p, O.fz_pval(s, int(rows.sum()), 0)) < 1e-12
+    # a whole job: same stopping behaviour as single tests in the reference's order (size 3 first, lexicographic)
+    e = o.test_subsets(30, 20, [6, 13, 17, 2], max_k=3, alpha=0.01, n_obs_min=0)
+    s3, p3, _, _ = o.test(30, 20, (6, 13, 17), n_obs_min=0)
+    if not (p3 < 0.01):
+        assert e["status"] == 1 and e["num_tests"] == 1 and abs(e["stat"] - s3) < 1e-15
+
+
 @pytest.mark.parametrize("max_k", [0, 3])
 def test_fz_nz_golden_networks(clr_nz64, max_k):
     exp = read_edgelist("%s/learning_expected/exp_fz_nz_maxk%d.edgelist" % (GOLDEN, max_k))
