@@ -410,15 +410,15 @@ __device__ __forceinline__ bool dh_commit(DhTgt &x, const DhArrays &A, int lane,
 // (one atomic) and runs its whole HITON-PC: dh_advance / dh_commit are the state machine of the rounds (hiton.jl:109-149,
 // :53-78, :249-256), test_subsets (tests.jl:281-346) runs sequentially in the reference's own order, so a job that stops
 // after a few tests -- nearly all of them -- costs exactly those tests: no window, no speculation, no round trip.
-// A job that survives its first MI_SEQ tests is an enumeration that will probably run to the end (cfg4: one target owns
+// A job that survives its first mi_seq tests is an enumeration that will probably run to the end (cfg4: one target owns
 // a chain of 90 000 tests).  Its owner publishes the following ranks window by window on a BOARD in device memory: chunk
 // records any wavefront can claim with one atomic.  Wavefronts look at the boards before every job of their own and when
 // they run out of targets, so a big enumeration gets the whole GPU while its owner waits; the owner claims chunks of its
 // own board too, which is why nothing ever waits on a wavefront that is not running.  Chunk results are merged in rank
 // order exactly like segment records (dh_merge): first stop wins, otherwise the (p, rank) maximum with "later wins
 // ties"; a stop found by one chunk cancels the later chunks of the board (stop_min).  num_tests is the reference's count.
-#define MI_SEQ 4u           // tests of a job its owner runs alone before it opens a board
-#define MI_WIN0 32ull       // first board window (ranks); later windows grow x8
+// (the thresholds live in DhParams: mi_seq = 48 tests of a job its owner runs alone before it opens a board, mi_win0 = 128 ranks in the
+// first board window, later windows grow x8 -- set where the launch parameters are built, with the sweeps that chose them)
 #define MI_BOARD_CAP (1u << 18)
 #define MI_REC_CAP (1u << 20)
 
