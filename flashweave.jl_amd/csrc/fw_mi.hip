@@ -848,12 +848,17 @@ __global__ __launch_bounds__(512) void mi_level0_mfma_kernel(MiDev P, int p, int
                 L0M_MFMA8F(f0);
                 L0M_EXPAND4(f0, wa);
                 L0M_MFMA8F(f1);
+#ifndef L0M_SCHED
+#define L0M_SCHED 5  // VALU instructions between two matrix instructions (cycles of the matrix loop per tile: compiler order 82 300, 3: 79 100, 4: 77 200, 5: 76 300, 6: 79 500, 7: 79 400)
+#endif
+#if L0M_SCHED > 0
                 __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, L0M_SCHED, 0);
                 }
+#endif
             }
         }
         sXY = sXY == sXY0 ? sXY0 + 2 : sXY0;  // (a buffer is [2 sides])
