@@ -24,6 +24,7 @@
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: Julia never contracts a*b+c).
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1904,8 +1905,53 @@ static double maxweight(double w1, double w2)
 
 /* LGL (learning.jl:203-279) with the deterministic feed-forward schedule.  nb_in: optional precomputed
  * level-0 result (NULL -> computed here). */
-fwo_network *fwo_learn(fwo_ctx *c, const fwo_params *P_in, const fwo_nbrs *nb_in)
+/* Worker pool of fwo_learn_mt: the targets between two whitelist snapshots are independent of each other
+ * (interleaved.jl:124-183: a worker's whitelist is the graph as the master knew it when the job was queued), so
+ * one oracle context per thread runs them in any order; the master part (graph update) stays in schedule order. */
+typedef struct {
+    fwo_ctx *c;
+    const fwo_nbrs *nb;
+    const fwo_params *P;
+    const degrec *order;
+    const ivec *adj;
+    const int *snap;
+    odict *PCs;
+    int lo, hi;       /* schedule positions [lo, hi) of the block */
+    int *next;        /* shared ticket: positions are handed out from hi - 1 downwards (heaviest first) */
+    int64_t n_tests;
+    uint8_t *wl;
+} mt_job;
+
+static void *mt_worker(void *arg)
 {
+    mt_job *J = (mt_job *)arg;
+    for (;;) {
+        int k = __atomic_fetch_add(J->next, 1, __ATOMIC_RELAXED);
+        int ti = J->hi - 1 - k;
+        if (ti < J->lo) break;
+        int T = J->order[ti].idx;
+        const uint8_t *wlp = NULL;
+        if (J->P->feed_forward && J->P->max_k > 0 && J->snap[T] > 0) {
+            for (int i = 0; i < J->snap[T]; ++i) J->wl[J->adj[T].v[i]] = 1;
+            wlp = J->wl;
+        }
+        si_hiton_pc(J->c, T, J->nb, J->P, wlp, &J->PCs[T], &J->n_tests);
+        if (wlp)
+            for (int i = 0; i < J->snap[T]; ++i) J->wl[J->adj[T].v[i]] = 0;
+    }
+    return NULL;
+}
+
+fwo_network *fwo_learn_mt(fwo_ctx **cs, int nthr, const fwo_params *P_in, const fwo_nbrs *nb_in);
+
+fwo_network *fwo_learn(fwo_ctx *c, const fwo_params *P_in, const fwo_nbrs *nb_in) { return fwo_learn_mt(&c, 1, P_in, nb_in); }
+
+/* nthr > 1: cs[0..nthr) are contexts over the same read-only inputs (one per thread: a context holds scratch);
+ * needs round_size > 1 or feed_forward = 0, ignores target_stride / target_offset / max_seconds.  Same network,
+ * directed lists and test count as the sequential loop (tests/test_oracle_golden.py). */
+fwo_network *fwo_learn_mt(fwo_ctx **cs, int nthr, const fwo_params *P_in, const fwo_nbrs *nb_in)
+{
+    fwo_ctx *c = cs[0];
     fwo_params P = *P_in;
     const int p = c->p;
     P.n_obs_min = fwo_auto_n_obs_min(c, P.n_obs_min, P.hps, P.max_k);
@@ -1946,6 +1992,45 @@ fwo_network *fwo_learn(fwo_ctx *c, const fwo_params *P_in, const fwo_nbrs *nb_in
     int stride = (P.target_stride > 1 && !P.feed_forward) ? P.target_stride : 1;
     int n_done = 0;
     const int ti0 = (P.target_offset > 0 && !P.feed_forward) ? P.target_offset : 0;
+    if (nthr > 1 && (rs > 1 || !P.feed_forward)) {
+        pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthr);
+        mt_job *jobs = (mt_job *)calloc((size_t)nthr, sizeof(mt_job));
+        for (int w = 0; w < nthr; ++w) jobs[w].wl = (uint8_t *)calloc((size_t)p, 1);
+        const int blk = P.feed_forward ? rs : nt;
+        for (int lo = 0; lo < nt; lo += blk) {
+            int hi = lo + blk < nt ? lo + blk : nt, next = 0;
+            for (int v = 0; v < p; ++v) snap[v] = adj[v].n;
+            for (int w = 0; w < nthr; ++w) {
+                mt_job *J = &jobs[w];
+                J->c = cs[w]; J->nb = nb; J->P = &P; J->order = order; J->adj = adj; J->snap = snap; J->PCs = PCs;
+                J->lo = lo; J->hi = hi; J->next = &next;
+                pthread_create(&th[w], NULL, mt_worker, J);
+            }
+            for (int w = 0; w < nthr; ++w) pthread_join(th[w], NULL);
+            for (int ti = lo; ti < hi; ++ti) { /* the master's graph update, in schedule order */
+                int T = order[ti].idx;
+                ++n_done;
+                for (int i = 0; i < PCs[T].n; ++i) {
+                    int u = PCs[T].key[i], dup = 0;
+                    for (int j = 0; j < adj[T].n; ++j)
+                        if (adj[T].v[j] == u) {
+                            dup = 1;
+                            break;
+                        }
+                    if (!dup) {
+                        iv_push(&adj[T], u);
+                        iv_push(&adj[u], T);
+                    }
+                }
+            }
+        }
+        for (int w = 0; w < nthr; ++w) {
+            g->n_cond_tests += jobs[w].n_tests;
+            free(jobs[w].wl);
+        }
+        free(jobs);
+        free(th);
+    } else
     for (int ti = ti0; ti < nt; ti += stride) {
         int T = order[ti].idx;
         if (P.max_seconds > 0 && now_s() - t1 > P.max_seconds) break;

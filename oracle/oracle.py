@@ -94,6 +94,8 @@ def lib():
         L.fwo_auto_n_obs_min.argtypes = [vp, C.c_int64, C.c_int, C.c_int]
         L.fwo_learn.restype = vp
         L.fwo_learn.argtypes = [vp, C.POINTER(Params), vp]
+        L.fwo_learn_mt.restype = vp
+        L.fwo_learn_mt.argtypes = [vp, C.c_int, C.POINTER(Params), vp]
         L.fwo_network_free.argtypes = [vp]
         L.fwo_network_nedges.restype = C.c_int64
         L.fwo_network_nedges.argtypes = [vp]
@@ -147,6 +149,7 @@ class Oracle:
         self.kind = kind
         self.L = lib()
         self._keep = []
+        self._post = []  # set-up calls to replay on the per-thread contexts of learn(threads > 1)
         if kind in ("mi", "mi_nz"):
             if csc is not None:
                 self.n, self.p = shape
@@ -157,12 +160,14 @@ class Oracle:
             if sparse:
                 colptr, rowval, nzval = csc if csc is not None else dense_to_csc(mat)
                 self._keep += [colptr, rowval, nzval]
-                self.h = self.L.fwo_create_discrete_sparse(self.n, self.p, _ptr(colptr), _ptr(rowval), _ptr(nzval),
-                                                            nz, max_k)
+                self._mk = lambda: self.L.fwo_create_discrete_sparse(self.n, self.p, _ptr(colptr), _ptr(rowval),
+                                                                      _ptr(nzval), nz, max_k)
+                self.h = self._mk()
             else:
                 d = np.asfortranarray(mat.astype(np.int32))
                 self._keep.append(d)
-                self.h = self.L.fwo_create_discrete_dense(self.n, self.p, _ptr(d), nz, max_k)
+                self._mk = lambda: self.L.fwo_create_discrete_dense(self.n, self.p, _ptr(d), nz, max_k)
+                self.h = self._mk()
         elif kind == "fz":
             cm = np.asarray(cor_mat)
             self.p = cm.shape[0]
@@ -170,18 +175,21 @@ class Oracle:
             if cm.dtype == np.float32:
                 cm = np.asfortranarray(cm)
                 self._keep.append(cm)
-                self.h = self.L.fwo_create_fz(self.n, self.p, _ptr(cm), None)
+                self._mk = lambda: self.L.fwo_create_fz(self.n, self.p, _ptr(cm), None)
+                self.h = self._mk()
             else:
                 cm = np.asfortranarray(cm.astype(np.float64))
                 self._keep.append(cm)
-                self.h = self.L.fwo_create_fz(self.n, self.p, None, _ptr(cm))
+                self._mk = lambda: self.L.fwo_create_fz(self.n, self.p, None, _ptr(cm))
+                self.h = self._mk()
         elif kind == "fz_nz":
             arr = np.asarray(data)
             self.n, self.p = arr.shape
             is_f32 = 1 if arr.dtype == np.float32 else 0
             d = np.asfortranarray(arr.astype(np.float64))
             self._keep.append(d)
-            self.h = self.L.fwo_create_fz_nz(self.n, self.p, _ptr(d), is_f32)
+            self._mk = lambda: self.L.fwo_create_fz_nz(self.n, self.p, _ptr(d), is_f32)
+            self.h = self._mk()
         else:
             raise ValueError(kind)
 
@@ -215,11 +223,13 @@ class Oracle:
         """fz: attach the normalised n x p matrix; stream=True: conditional tests use pcor (no cor_mat, statfuns.jl:19-21)."""
         d = np.asfortranarray(np.asarray(data, dtype=np.float64))
         self._keep.append(d)
-        self.L.fwo_fz_set_data(self.h, _ptr(d), int(stream))
+        self._post.append(lambda h: self.L.fwo_fz_set_data(h, _ptr(d), int(stream)))
+        self._post[-1](self.h)
 
     def set_fz_nz_stream(self, stream=True):
         """fz_nz: conditional tests through pcor on the row view (recursive_pcor = false: FzTestCond without cor_mat, tests.jl:253)."""
-        self.L.fwo_fz_nz_set_stream(self.h, int(stream))
+        self._post.append(lambda h: self.L.fwo_fz_nz_set_stream(h, int(stream)))
+        self._post[-1](self.h)
 
     def pcor(self, X, Y, Zs):
         z = np.asarray(Zs, dtype=np.int32)
@@ -282,9 +292,11 @@ class Oracle:
         return dict(X=x[:k], Y=y[:k], stat=st[:k], pval=pv[:k], n_tests=int(nt.value), m=int(m.value))
 
     def learn(self, max_k=3, alpha=0.01, hps=5, n_obs_min=-1, max_tests=10_000_000, FDR=True, feed_forward=True,
-              round_size=1, max_targets=0, target_stride=1, max_seconds=0.0, target_offset=0, nbrs=None):
+              round_size=1, max_targets=0, target_stride=1, max_seconds=0.0, target_offset=0, nbrs=None, threads=1):
         """nbrs = dict(off, idx, stat, pval[, n_tests]): level-0 neighbour lists computed elsewhere (bench.py's
-        cpu_baseline at sizes where a full CPU level-0 pass does not fit the bounded sample)."""
+        cpu_baseline at sizes where a full CPU level-0 pass does not fit the bounded sample).
+        threads > 1 (needs round_size > 1 or feed_forward = False): the targets between two whitelist snapshots run on a pool
+        of threads, one context each over this context's arrays (fwo_learn_mt); same results as threads = 1."""
         P = Params(alpha, hps, n_obs_min, max_k, max_tests, int(FDR), int(feed_forward), round_size, max_targets,
                    target_stride, max_seconds, target_offset, 0.0)
         nb = None
@@ -294,9 +306,20 @@ class Oracle:
             s_ = np.ascontiguousarray(nbrs["stat"], dtype=np.float64)
             q = np.ascontiguousarray(nbrs["pval"], dtype=np.float64)
             nb = self.L.fwo_nbrs_from_csr(self.p, _ptr(o), _ptr(i), _ptr(s_), _ptr(q), int(nbrs.get("n_tests", 0)))
+        extra = []
         try:
-            g = self.L.fwo_learn(self.h, C.byref(P), nb)
+            if threads > 1:
+                extra = [self._mk() for _ in range(threads - 1)]
+                for h in extra:
+                    for f in self._post:
+                        f(h)
+                hs = (C.c_void_p * threads)(self.h, *extra)
+                g = self.L.fwo_learn_mt(hs, threads, C.byref(P), nb)
+            else:
+                g = self.L.fwo_learn(self.h, C.byref(P), nb)
         finally:
+            for h in extra:
+                self.L.fwo_destroy(h)
             if nb:
                 self.L.fwo_nbrs_free(nb)
         ne = self.L.fwo_network_nedges(g)

@@ -124,7 +124,7 @@ def test_cfg3_network_independent_of_schedule():
                 {"FW_DH_SPEC": "8", "FW_DH_SPEC0": "4", "FW_DH_SPEC_BELOW": "100000000000", "FW_DH_SPEC0_BELOW": "100000000000",
                  "FW_DH_SPEC0_JOBS": "100000", "FW_DH_TIME_EVERY": "1"},
                 {"FW_DH_CHAINS": "1"}, {"FW_DH_CHAINS": "3"},  # concurrent chains of device rounds (default 2)
-                {"FW_DH_FUSE": "0"}, {"FW_DH_FUSE": "1"}]    # step / plan / fill as three launches, plan fused, (default) all fused
+                {"FW_DH_FUSE": "0"}, {"FW_DH_FUSE": "1"}]    # step / plan / fill as three launches (default) / plan fused
     seen = set()
     for s in settings:
         out = subprocess.run([sys.executable, "-c", _HASH_SNIPPET % root], env=dict(os.environ, **s), cwd=root, check=True,
@@ -376,6 +376,86 @@ def test_cfg3_full_size_headline_schedule_device_rounds_equal_host_pool(monkeypa
     assert len(nd["edge_src"]) > 10000
     assert ch["cond_tests_ref"] == cd["cond_tests_ref"] > 10**10
     assert ch["subsets_calls"] == cd["subsets_calls"]
+
+
+def test_cfg3_full_size_heavy_tail_jobs_equal_oracle():
+    """cfg3 at FULL size: real (T, candidate, accepted) jobs of its 25 heaviest targets -- the jobs of the last feed-forward round,
+    where a third of the headline's time goes: accepted lists of 60 ... 180 variables, some with a whitelisted member pushed a
+    second time (hiton.jl:24-26: a duplicated entry), max_k = 3, i.e. the size-3 table form of the segment kernel with its
+    division-free screen, guard bands, cross-multiplied max-p tracking, `fz_l3_finish` and `fz_div_nn` -- through
+    fw_test_subsets_batch against the oracle's sequential test_subsets (tests.jl:281-346, statfuns.jl:23-75) on the same Float32
+    matrix: status, reference-order test count, conditioning set and statistic to the bit, p-value to 1e-12.  Two engines:
+    alpha = 0.01 (jobs stop where the reference stops) and alpha = 0.9999 (nearly every test is "significant": whole
+    enumerations of up to 972 000 subsets run, so the max-p bookkeeping over every rank is compared too)."""
+    eng, n, p = _cfg3_engine()
+    cm = eng.cor()
+    nb = eng.pw_univar_neighbors()
+    off, idx, pv = nb["off"], nb["idx"], nb["pval"]
+    deg = np.diff(off)
+    heavy = np.argsort(-deg, kind="stable")[:25]
+    assert deg[heavy[-1]] >= 200
+    T, C, A = [], [], []
+    lens = [60, 90, 120, 150, 180]
+    for i, t in enumerate(heavy):
+        cand = idx[off[t]:off[t + 1]][np.argsort(pv[off[t]:off[t + 1]], kind="stable")]  # hiton.jl:211-217 order
+        for j, L in enumerate((lens[i % 5], lens[(i + 2) % 5], lens[(i + 3) % 5])):
+            L = min(L, len(cand) - 1)
+            a = [int(v) for v in cand[:L]]
+            if j == 2:
+                # the feed-forward shape of a list: whitelisted neighbours first (untested), one of them pushed again later
+                a = a[L // 2:] + a[:L // 2] + [a[L // 2 + 3]]
+            T.append(int(t)); C.append(int(cand[L])); A.append(a)
+    assert len(T) >= 50
+    orc = O.Oracle("fz", cor_mat=cm, n_obs=n)
+    for alpha in (0.01, 0.9999):
+        if alpha != 0.01:
+            eng.close()
+            eng = fw.Engine("fz", n, p, max_k=3, alpha=alpha)
+            eng.set_cor_mat(cm)
+        got = eng.test_subsets_batch(T, C, A)
+        whole = 0
+        for t, cc, a, g in zip(T, C, A, got):
+            e = orc.test_subsets(t, cc, a, max_k=3, alpha=alpha, n_obs_min=20)
+            assert g["status"] == e["status"] and g["num_tests"] == e["num_tests"], (t, cc, len(a), g, e)
+            assert g["Zs"] == e["Zs"] and g["stat"] == e["stat"], (t, cc, len(a), g, e)
+            assert g["pval"] == e["pval"] or abs(g["pval"] - e["pval"]) <= 1e-12 * abs(e["pval"]), (g, e)
+            m = len(a)
+            whole += e["num_tests"] == m + m * (m - 1) // 2 + m * (m - 1) * (m - 2) // 6
+        if alpha != 0.01:
+            assert whole >= len(T) // 2  # most jobs ran through their whole enumeration
+    orc.close()
+    eng.close()
+
+
+def test_cfg3_full_size_whole_headline_schedule_equals_oracle():
+    """The WHOLE schedule bench.py reports (feed_forward = 1, R = 1024, all ten rounds incl. the last one with the 784 heaviest
+    targets and accepted lists up to ~180 entries plus whitelists: 1.2e10 reference-order tests) against the oracle, which runs
+    every round on all hardware threads (one context per thread, `fwo_learn_mt`: the targets of a round are independent given the
+    round's whitelists, interleaved.jl:124-183; ~1 400 core-seconds).  Directed lists and weights to the bit, p-values to
+    1e-12, reference-order test count, edges and edge weights to the bit.  FW_CFG3_ORACLE_TARGETS bounds the compared prefix of
+    the schedule (default: all 10 000 targets); FW_SKIP_LONG_ORACLE=1 skips the test on hosts with few cores."""
+    import os
+    if os.environ.get("FW_SKIP_LONG_ORACLE") == "1":
+        pytest.skip("FW_SKIP_LONG_ORACLE=1")
+    eng, n, p = _cfg3_engine()
+    cm = eng.cor()
+    M = int(os.environ.get("FW_CFG3_ORACLE_TARGETS", "0")) or p
+    R = 1024
+    got = eng.lgl(feed_forward=True, round_size=R, max_targets=(M if M < p else 0), edge_dict=False)
+    cn = eng.counters()
+    orc = O.Oracle("fz", cor_mat=cm, n_obs=n)
+    exp = orc.learn(max_k=3, feed_forward=True, round_size=R, max_targets=(M if M < p else 0), threads=os.cpu_count() or 1)
+    assert np.array_equal(got["pc_off"], exp["pc_off"])
+    assert np.array_equal(got["pc_idx"], exp["pc_idx"])
+    assert np.array_equal(got["pc_weight"], exp["pc_weight"], equal_nan=True)   # NaN = whitelisted without a test (hiton.jl:20-30)
+    assert np.allclose(got["pc_pval"], exp["pc_pval"], rtol=1e-12, atol=0.0, equal_nan=True)
+    assert cn["cond_tests_ref"] == exp["n_cond_tests"]
+    if M >= p:
+        assert exp["n_cond_tests"] > 10**10
+    ge = dict(zip(zip(got["edge_src"].tolist(), got["edge_dst"].tolist()), got["edge_weight"].tolist()))
+    assert ge == exp["edges"] and len(ge) > 1000
+    orc.close()
+    eng.close()
 
 
 def test_cfg5_full_size_long_list_jobs_equal_oracle():

@@ -350,3 +350,29 @@ def test_pcor_with_a_repeated_conditioning_variable():
         assert np.isnan(s) and np.isnan(p), (zs, s, p)
         s, p, _, _ = matrix_variant.test(0, 1, zs)
         assert np.isfinite(s) and np.isfinite(p), (zs, s, p)
+
+
+def test_threaded_learn_equals_sequential_learn():
+    """`fwo_learn_mt` (the oracle on a pool of threads, used by the full-size GPU tests): the targets between two whitelist
+    snapshots are independent (interleaved.jl:124-183), so the threaded run must reproduce the sequential loop exactly --
+    edges, weights, directed lists, p-values, test count; both kinds of test object, with and without feed-forward."""
+    rng = np.random.default_rng(7)
+    n, p = 200, 240
+    base = rng.standard_normal((n, 10))
+    data = (base @ rng.standard_normal((10, p)) + 1.2 * rng.standard_normal((n, p))).astype(np.float32)
+    cm = O.cor(data.astype(np.float64), "f32")
+    cases = [(O.Oracle("fz", cor_mat=cm, n_obs=n), 3)]
+    lat = rng.standard_normal((n, 6))
+    disc = ((lat @ rng.standard_normal((6, 90)) + rng.standard_normal((n, 90))) > 0.3).astype(np.int32)
+    disc *= 1 + (rng.random((n, 90)) < 0.4)
+    cases.append((O.Oracle("mi_nz", disc), 3))
+    cases.append((O.Oracle("mi", (disc > 0).astype(np.int32)), 2))
+    for orc, mk in cases:
+        for ff, rs in ((True, 32), (True, 5), (False, 1)):
+            a = orc.learn(max_k=mk, feed_forward=ff, round_size=rs)
+            b = orc.learn(max_k=mk, feed_forward=ff, round_size=rs, threads=4)
+            assert a["edges"] == b["edges"] and a["n_cond_tests"] == b["n_cond_tests"]
+            for k in ("pc_off", "pc_idx", "pc_weight", "pc_pval"):
+                assert np.array_equal(a[k], b[k], equal_nan=True), k
+        orc.close()
+    assert len(a["edges"]) >= 0
