@@ -990,6 +990,11 @@ int fwi_pool_launch(fw_ctx *c, FwPool &pool)
             j.gram_off = (int64_t)pool.gram_top;
             j.gram_epoch = pool.gram_epoch;
             r.cor_off = (long long)j.gram_off;
+            if (r.nR == 0) {  // a cached matrix that is computed again: counted like the ones the first loop scheduled
+                c->cnt.gram_jobs += 1;
+                c->cnt.gram_alg_bytes += (double)r.m * (double)c->P.n * 4.0;
+                c->cnt.gram_alg_flops += 2.0 * (double)c->P.n * 0.5 * (double)r.m * (double)(r.m - 1);
+            }
             r.nR = 1;
             pool.gram_top += (size_t)r.m * r.m;
         }

@@ -543,6 +543,9 @@ int fwi_fz_compute_cor_rows(fw_ctx *ctx, int rank, int world, int64_t *row0, int
     FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cnt.kernel_launches += 2;
     ctx->have_cor = false;  // until the caller has gathered the other ranks' rows (fw_cor_mat_ready)
+    ctx->cor_rows_rank = rank;
+    ctx->cor_rows_world = world;
+    ctx->cor_rows_per_rank = *rows_per_rank;
     return FW_OK;
 }
 

@@ -1,6 +1,11 @@
 // Internal declarations shared by the translation units of libflashweave_amd.so.
 // Nothing here is part of the ABI (include/flashweave_amd.h is).
 #pragma once
+// The library is written for gfx950 (MI355X, CDNA4) ONLY: mi_level0_mfma_kernel issues v_mfma_scale_f32_32x32x64_f8f6f4 and the kernels
+// size their static LDS for 160 KB per CU.  There is no dual path; another --offload-arch fails here instead of deep inside a kernel.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libflashweave_amd targets gfx950 only (make ARCH=gfx950)"
+#endif
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -130,6 +135,8 @@ struct fw_ctx {
     float *d_cor = nullptr;   // p x p (symmetric)
     bool cor_external = false;  // d_cor is caller-owned device memory (fw_use_cor_buffer): never freed here
     int64_t cor_capacity = 0;   // ... and holds this many floats
+    int cor_rows_rank = -1, cor_rows_world = 0;  // what the last fw_compute_cor_mat_rows computed: rank / world / rows per rank
+    int64_t cor_rows_per_rank = 0;               // (fw_cor_mat_allgather_comm checks its arguments against them)
     double *d_thr = nullptr;  // |r| significance thresholds of the segment kernel (fz_thresholds_kernel)
     double *d_fzs_stat = nullptr;  // recursive_pcor = 0: per column {mean, sum of squared deviations} in Float64 (fw_fzs.hip)
     uint64_t gram_epoch = 0;       // recursive_pcor = 0: bumped whenever the job-matrix arena loses its contents (new pool, reallocation, reset)

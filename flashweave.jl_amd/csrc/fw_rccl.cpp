@@ -86,7 +86,8 @@ struct FwComm {
     int rank = 0, world = 1;
     FwDevBuf d_hdr, d_send, d_recv;  // header (2 x int64 per rank), payload buffers (grow-only)
     std::vector<int64_t> h_hdr;
-    int64_t cap = 0;
+    int64_t cap = 0;  // capacity of the payload buffers in bytes per rank (grow-only)
+    int64_t cur = 0;  // this exchange's stride in records per rank: pow2(max over the ranks of this round's counts)
     int32_t rec = 0;
     // counters (bench.py reports them)
     int64_t calls = 0, collectives = 0, entries = 0, bytes = 0;
@@ -107,6 +108,14 @@ struct CommX {
     double t0;
 };
 
+// the callbacks return small non-zero codes to the exchange's caller; every one of them leaves a message in the context as well
+template <typename... A>
+int comm_fail(fw_ctx *c, int code, const char *fmt, A... a)
+{
+    (void)fw_fail(c, FW_ERR_DEVICE, fmt, a...);
+    return code;
+}
+
 // fw_dev_exchange::prepare on the library's own communicator: header all-gather (record count + one auxiliary integer per rank),
 // room for max(count) records per rank
 int comm_prepare(void *user, int64_t n_local, int64_t aux_local, int32_t rec_bytes, void **d_send, void **d_recv, int64_t *counts, int64_t *aux,
@@ -116,39 +125,44 @@ int comm_prepare(void *user, int64_t n_local, int64_t aux_local, int32_t rec_byt
     fw_ctx *c = X->c;
     FwComm *K = c->comm;
     RcclApi *R = rccl_api(nullptr);
-    if (!K || !K->comm || !R) return 1;
+    if (!K || !K->comm || !R) return comm_fail(c, 1, "comm_prepare: no communicator (fw_comm_init)");
     X->t0 = rc_now();
     const int W = K->world;
-    if (fw_dev_reserve(c, K->d_hdr, sizeof(int64_t) * 2 * (size_t)(W + 1))) return 2;
+    if (fw_dev_reserve(c, K->d_hdr, sizeof(int64_t) * 2 * (size_t)(W + 1))) return comm_fail(c, 2, "comm_prepare: no device memory for the header");
     int64_t *dh = (int64_t *)K->d_hdr.ptr;  // [0..2): this rank's header, [2..2 + 2 W): everybody's
     const int64_t mine[2] = {n_local, aux_local};
-    if (hipMemcpyAsync(dh, mine, sizeof(mine), hipMemcpyHostToDevice, c->stream) != hipSuccess) return 3;
+    if (hipMemcpyAsync(dh, mine, sizeof(mine), hipMemcpyHostToDevice, c->stream) != hipSuccess) return comm_fail(c, 3, "comm_prepare: header upload failed");
     int rc = R->AllGather(dh, dh + 2, 2, fwNcclInt64, K->comm, c->stream);
     if (rc) {
         fw_fail(c, FW_ERR_DEVICE, "ncclAllGather (header): %s", rccl_err(R, rc));
         return 4;
     }
     K->h_hdr.resize(2 * (size_t)W);
-    if (hipMemcpyAsync(K->h_hdr.data(), dh + 2, sizeof(int64_t) * 2 * (size_t)W, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return 5;
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return 6;
-    int64_t cap = 1, tot = 0;
+    if (hipMemcpyAsync(K->h_hdr.data(), dh + 2, sizeof(int64_t) * 2 * (size_t)W, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return comm_fail(c, 5, "comm_prepare: header download failed");
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return comm_fail(c, 6, "comm_prepare: stream error after the header all-gather");
+    int64_t mx = 1, tot = 0;
     for (int r = 0; r < W; ++r) {
         counts[r] = K->h_hdr[2 * (size_t)r];
         aux[r] = K->h_hdr[2 * (size_t)r + 1];
-        cap = std::max(cap, counts[r]);
+        if (counts[r] < 0) return comm_fail(c, 8, "comm_prepare: rank %d announced %lld records", r, (long long)counts[r]);
+        mx = std::max(mx, counts[r]);
         tot += counts[r];
     }
-    if (K->cap < cap || K->rec != rec_bytes) {
-        int64_t cap2 = 1;
-        while (cap2 < cap) cap2 <<= 1;
-        if (fw_dev_reserve(c, K->d_send, (size_t)cap2 * (size_t)rec_bytes)) return 7;
-        if (fw_dev_reserve(c, K->d_recv, (size_t)W * (size_t)cap2 * (size_t)rec_bytes)) return 7;
-        K->cap = cap2;
-        K->rec = rec_bytes;
+    // the stride of THIS exchange is the round's own maximum (rounded up to a power of two), not the buffers' capacity: the
+    // buffers only grow, and a level-0 exchange of a million pairs must not make every later round ship a million records per rank
+    int64_t cur = 1;
+    while (cur < mx) cur <<= 1;
+    const int64_t need = cur * (int64_t)rec_bytes;
+    if (K->cap < need) {
+        if (fw_dev_reserve(c, K->d_send, (size_t)need)) return comm_fail(c, 7, "comm_prepare: no device memory for %lld bytes per rank", (long long)need);
+        if (fw_dev_reserve(c, K->d_recv, (size_t)W * (size_t)need)) return comm_fail(c, 7, "comm_prepare: no device memory for %d x %lld bytes", W, (long long)need);
+        K->cap = need;
     }
+    K->cur = cur;
+    K->rec = rec_bytes;
     *d_send = K->d_send.ptr;
     *d_recv = K->d_recv.ptr;
-    *cap_records = K->cap;
+    *cap_records = cur;
     K->entries += tot;
     return 0;
 }
@@ -159,15 +173,15 @@ int comm_exchange(void *user)
     fw_ctx *c = X->c;
     FwComm *K = c->comm;
     RcclApi *R = rccl_api(nullptr);
-    if (!K || !K->comm || !R) return 1;
+    if (!K || !K->comm || !R) return comm_fail(c, 1, "comm_exchange: no communicator (fw_comm_init)");
     // the library's pack kernels / copies into the send buffer ran on the context's stream or were synchronous: stream order suffices
-    const size_t bytes = (size_t)K->cap * (size_t)K->rec;
+    const size_t bytes = (size_t)K->cur * (size_t)K->rec;
     int rc = R->AllGather(K->d_send.ptr, K->d_recv.ptr, bytes, fwNcclChar, K->comm, c->stream);
     if (rc) {
         fw_fail(c, FW_ERR_DEVICE, "ncclAllGather (payload): %s", rccl_err(R, rc));
         return 2;
     }
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return 3;  // "returns when the data is in place" (fw_dev_exchange)
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return comm_fail(c, 3, "comm_exchange: stream error after the payload all-gather");  // "returns when the data is in place" (fw_dev_exchange)
     K->calls += 1;
     K->collectives += 2;
     K->bytes += (int64_t)bytes * K->world;
@@ -278,6 +292,14 @@ int fw_cor_mat_allgather_comm(fw_ctx *c, int64_t rows_per_rank)
     if (!c->d_cor || !c->cor_external) return fw_fail(c, FW_ERR_STATE, "fw_cor_mat_allgather_comm: needs fw_use_cor_buffer + fw_compute_cor_mat_rows first");
     RcclApi *R = rccl_api(nullptr);
     FwComm *K = c->comm;
+    const int64_t p64 = c->P.p;
+    if (rows_per_rank <= 0 || p64 <= 0 || rows_per_rank > c->cor_capacity / p64 / K->world)
+        return fw_fail(c, FW_ERR_ARG, "fw_cor_mat_allgather_comm: rows_per_rank %lld does not fit %d blocks into the buffer of %lld floats (p = %lld)",
+                       (long long)rows_per_rank, K->world, (long long)c->cor_capacity, (long long)p64);
+    // the in-place all-gather needs this rank's block where fw_compute_cor_mat_rows wrote it: at rank * rows_per_rank
+    if (c->cor_rows_rank != K->rank || c->cor_rows_world != K->world || c->cor_rows_per_rank != rows_per_rank)
+        return fw_fail(c, FW_ERR_STATE, "fw_cor_mat_allgather_comm: fw_compute_cor_mat_rows ran as rank %d of %d with %lld rows per rank, the communicator is rank %d of %d and %lld rows were passed",
+                       c->cor_rows_rank, c->cor_rows_world, (long long)c->cor_rows_per_rank, K->rank, K->world, (long long)rows_per_rank);
     const size_t block = (size_t)rows_per_rank * (size_t)c->P.p;  // floats per rank
     if ((int64_t)(block * (size_t)K->world) > c->cor_capacity) return fw_fail(c, FW_ERR_ARG, "fw_cor_mat_allgather_comm: the buffer holds %lld floats, %d blocks of %zu need more", (long long)c->cor_capacity, K->world, block);
     const double t0 = rc_now();

@@ -198,3 +198,45 @@ def test_no_matrix_network_matches_oracle(ctx_s, ff, R):
         assert _near(got["edges"][e], w), (e, got["edges"][e], w)
     assert eng.counters()["cond_tests_ref"] == exp["n_cond_tests"]
     eng.close()
+
+
+def test_no_matrix_constant_column_in_a_view():
+    """A conditioning variable that is constant inside a job's row view (absent in every row where T and the candidate are both
+    present): StatsBase.partialcor meets a zero sum of squares, 0 / 0 = NaN, `fz_pval(NaN)` = NaN, and `issig` is false for a NaN
+    p-value (tests.jl:326-336) -- the enumeration STOPS at the first subset that holds the variable and the candidate is dropped.
+    (The matrix form never sees this: `cor_subset!` writes 0 for such a pair, statfuns.jl:150-152.)  Device against oracle: status,
+    num_tests, conditioning set; the statistic and the p-value are NaN on both sides; explicit tests likewise."""
+    data = _synth(120, 400, 41).copy()
+    n, p = data.shape
+    nzc = (data != 0)
+    co = nzc.T.astype(np.int32) @ nzc.astype(np.int32)
+    np.fill_diagonal(co, 0)
+    T, Cn = np.unravel_index(np.argmax(co), co.shape)
+    T, Cn = int(T), int(Cn)
+    both = nzc[:, T] & nzc[:, Cn]
+    assert both.sum() >= 40
+    others = [v for v in np.argsort(-(nzc & both[:, None]).sum(axis=0)) if v not in (T, Cn)]
+    a, b, c, z = (int(v) for v in others[:4])
+    data[both, z] = 0.0                      # z: present elsewhere, absent in every row of the (T, Cn) view
+    assert (data[:, z] != 0).sum() > 5
+    data = np.asfortranarray(data)
+    eng = fw.Engine("fz_nz", n, p, max_k=3, recursive_pcor=False)
+    eng.set_data(data)
+    orc = O.Oracle("fz_nz", data=data.astype(np.float64))
+    orc.set_fz_nz_stream(True)
+    jobs = [[z], [a, z], [z, a, b], [a, b, c, z], [a, z, b, c]]
+    got = eng.test_subsets_batch([T] * len(jobs), [Cn] * len(jobs), jobs)
+    nan_stops = 0
+    for acc, g in zip(jobs, got):
+        e = orc.test_subsets(T, Cn, acc, max_k=3, alpha=0.01, n_obs_min=20)
+        assert g["status"] == e["status"] and g["num_tests"] == e["num_tests"] and g["Zs"] == e["Zs"], (acc, g, e)
+        assert _near(g["stat"], e["stat"]) and (_near(g["pval"], e["pval"]) or abs(g["pval"] - e["pval"]) < 1e-12), (acc, g, e)
+        if np.isnan(e["stat"]):
+            assert z in e["Zs"] and np.isnan(e["pval"]) and np.isnan(g["stat"]) and np.isnan(g["pval"])
+            nan_stops += 1
+    assert nan_stops >= 3
+    s, pv, df, pw = orc.test(T, Cn, (a, z), n_obs_min=20)
+    g = eng.test_batch([T], [Cn], [(a, z)])[0]
+    assert pw and g.suff_power and np.isnan(s) and np.isnan(g.stat) and np.isnan(pv) and np.isnan(g.pval)
+    orc.close()
+    eng.close()
