@@ -43,7 +43,7 @@ struct DhTgt {
     // look-ahead jobs of the coming launch: spmode 0 = same accepted list / elimination pools, window = the job's own (jwin2 = jwin);
     // spmode 1 = interleaving "assume the current candidate is accepted": list = accepted + [candidate], own first window jwin2 of
     // an enumeration of jN2 subsets (see dh_step_kernel)
-    int32_t spmode, pad1;
+    int32_t spmode, wl_unsorted;  // wl_unsorted: the whitelist was appended to on the device (dh_wl_append_kernel): no order, no early exit
     unsigned long long jwin2, jN2;
 };
 
@@ -54,12 +54,16 @@ struct DhGlobal {
     unsigned long long cond_tests_ref, subsets_calls, evaluated;
     double alg_bytes;
     unsigned int n_act, act_sel;  // unfinished targets: act[act_sel * ntg + 0 .. n_act) (dh_compact_kernel)
-    unsigned int any_big, max_ab;   // max_ab: largest (accepted + whitelisted neighbours still to come) of any target so far: what a
-                                    // list can reach without tested acceptances.  any_big:
-                                    // the coming launch holds a segment with |accepted| > FW_TAB_A (set by dh_fill_kernel): the
-                                    // in-lane variant of the fz segment kernel leaves at once when it does not
+    unsigned int pad_b, max_ab;     // max_ab: largest (accepted + whitelisted neighbours still to come) of any target so far: what a
+                                    // list can reach without tested acceptances
     unsigned int ns_ring[64];  // segments of the last 64 planned launches (the host reads the record once per batch)
-    unsigned int step_ticket, pad_t;  // fused round: workgroups of dh_round_kernel that have finished their targets
+    // words that workgroups on different XCDs touch WHILE workgroup 0 writes the record above (dh_coop_kernel): a cache line each
+    unsigned int pad_l0[32];
+    unsigned int step_ticket;  // cooperative round: workgroups that have passed their step phase (monotonic over the run)
+    unsigned int pad_l1[31];
+    unsigned int any_big;      // the coming launch holds a segment with |accepted| > FW_TAB_A (set by the fill): the in-lane variant
+                               // of the fz segment kernel leaves at once when it does not
+    unsigned int pad_l2[31];
 };
 
 // accepted-list buffer b of a target: (spec_depth + 1) buffers of 2 * cap entries each
@@ -70,6 +74,7 @@ struct DhArrays {
     int32_t *tpc_key, *pc_key, *acc;
     double *tpc_stat, *tpc_p, *pc_stat, *pc_p;
     const int32_t *wl;        // sorted whitelists (feed-forward)
+    const unsigned int *wl_cnt;  // device-built whitelists (fwi_devhiton_mi_schedule): entries of variable v's list so far, else null
     const long long *nb_off;  // level-0 neighbour lists (for the empty-pool case, hiton.jl:57-59)
     const int32_t *nb_idx;
     const double *nb_stat, *nb_p;
@@ -106,18 +111,6 @@ struct DhParams {
     int spec1_depth;          // interleaving-phase look-ahead behind a candidate that is about to be accepted (same two conditions)
 };
 
-__device__ __forceinline__ unsigned long long dh_binom(long long m, int t)
-{
-    if (m < t) return 0ull;
-    const unsigned long long SAT = 1ull << 62;
-    double est = 1.0;
-    for (int i = 1; i <= t; ++i) est = est * (double)(m - t + i) / (double)i;
-    if (est > 4.0e18) return SAT;
-    unsigned long long v = 1ull;
-    for (int i = 1; i <= t; ++i) v = v * (unsigned long long)(m - t + i) / (unsigned long long)i;  // exact: C(m-t+i, i)
-    return v;
-}
-
 // Is v one of the target's whitelisted neighbours?  Called by the whole wavefront with a uniform v: the lanes read 64 entries of
 // the (sorted) list at a time and vote -- ONE load latency per 64 entries.  (r02: a binary search, i.e. log2(n) + 1 DEPENDENT global
 // loads per call, up to four calls per target and round: a third of dh_step_kernel's 19 us.)
@@ -128,7 +121,7 @@ __device__ __forceinline__ bool dh_in_wl(const DhTgt &x, const DhArrays &A, int3
     for (int base = 0; base < x.wl_n; base += 64) {
         const int32_t e = base + lane < x.wl_n ? w[base + lane] : -1;
         if (__ballot(e == v) != 0ull) return true;
-        if (__shfl(e, 63) > v) return false;  // sorted: nothing further on can match (an invalid last lane reads -1: the loop ends anyway)
+        if (!x.wl_unsorted && __shfl(e, 63) > v) return false;  // sorted: nothing further on can match (an invalid last lane reads -1: the loop ends anyway)
     }
     return false;
 }
@@ -1148,6 +1141,7 @@ __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, 
     MiTeamJob &J = dh_mi_tj;
     if (wave == 0 && lane == 0) {
         x = tg[t];
+        if (A.wl_cnt) x.wl_n = (int32_t)A.wl_cnt[x.T];  // device-built whitelist: what the earlier launches of the schedule appended
         x.r_first0 = (unsigned int)MI_CLK();
     }
     __syncthreads();
@@ -1401,6 +1395,7 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
         DhTgt &x = dh_mi_x[threadIdx.x >> 6];
         if (lane == 0) {
             x = tg[t];
+            if (A.wl_cnt) x.wl_n = (int32_t)A.wl_cnt[x.T];  // device-built whitelist: what the earlier launches of the schedule appended
             x.r_first0 = (unsigned int)MI_CLK();  // FW_TRACE_HOST: when the target was taken / finished (100 MHz ticks, low word)
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1639,10 +1634,10 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
 __device__ __forceinline__ void dh_step_dev(DhTgt *__restrict__ tg, int ntg, DhGlobal *__restrict__ g, const DhArrays &A,
                                             const FwSegOut *__restrict__ so, const long long *__restrict__ seg0,
                                             unsigned long long *__restrict__ win, unsigned int *__restrict__ sp,
-                                            unsigned long long *__restrict__ win2, const int32_t *__restrict__ act, const DhParams &P)
+                                            unsigned long long *__restrict__ win2, const int32_t *__restrict__ act, const DhParams &P,
+                                            const int ci /* position in the list of unfinished targets (seg0 is indexed by it) */)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ci = blockIdx.x * 4 + wave;  // position in the list of unfinished targets (seg0 is indexed by it)
+    const int lane = threadIdx.x & 63;
     const int d1 = P.spec_depth + 1;
     unsigned long long mywin = 0ull;
     if (ci < (int)g->n_act) {
@@ -1751,12 +1746,7 @@ __device__ __forceinline__ void dh_step_dev(DhTgt *__restrict__ tg, int ntg, DhG
             }
         }
         if (!x.jactive && x.phase != 2 && dh_advance(x, A, lane, d1)) {
-            unsigned long long N = 0ull;
-            for (int s = P.max_k; s >= 1; --s) {
-                N += dh_binom(x.na, s);
-                if (N > (1ull << 62)) N = 1ull << 62;
-            }
-            if (P.max_tests > 0 && (unsigned long long)P.max_tests < N) N = (unsigned long long)P.max_tests;
+            const unsigned long long N = dh_enum_size(x.na, P.max_k, P.max_tests);  // (32-bit binomials where every term fits)
             x.jN = N;
             x.jnext = 0ull;
             // Elimination phase: the candidate passed every test against (almost) this pool a moment ago, so nearly all
@@ -1863,12 +1853,7 @@ __device__ __forceinline__ void dh_step_dev(DhTgt *__restrict__ tg, int ntg, DhG
             }
             if (q > 0) {
                 if (lane == 0) A.acc[DH_ACC_OFF(x, x.cur, d1) + x.na] = cands[x.pos];
-                unsigned long long N2 = 0ull;
-                for (int s = P.max_k; s >= 1; --s) {
-                    N2 += dh_binom(x.na + 1, s);
-                    if (N2 > (1ull << 62)) N2 = 1ull << 62;
-                }
-                if (P.max_tests > 0 && (unsigned long long)P.max_tests < N2) N2 = (unsigned long long)P.max_tests;
+                const unsigned long long N2 = dh_enum_size(x.na + 1, P.max_k, P.max_tests);
                 const unsigned long long w0 = x.na + 1 >= 64 ? P.w0_big : P.w0_small;
                 x.nsp = q;
                 x.spmode = 1;
@@ -1891,7 +1876,7 @@ __global__ __launch_bounds__(256) void dh_step_kernel(DhTgt *__restrict__ tg, in
                                                       unsigned long long *__restrict__ win, unsigned int *__restrict__ sp,
                                                       unsigned long long *__restrict__ win2, const int32_t *__restrict__ act, DhParams P)
 {
-    dh_step_dev(tg, ntg, g, A, so, seg0, win, sp, win2, act, P);
+    dh_step_dev(tg, ntg, g, A, so, seg0, win, sp, win2, act, P, (int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
 }
 
 // one workgroup: totals of the coming launch, its segment length, per-target segment counts and their exclusive scan.
@@ -2073,35 +2058,168 @@ __global__ __launch_bounds__(256) void dh_fill_kernel(const DhTgt *__restrict__ 
     dh_fill_one(s, tg, ntg, g, seg0, A, segs, d1, act);
 }
 
-// The fused round (r04): step for every target, then the LAST workgroup to finish plans the coming launch and fills its segment
-// records -- one launch between two segment kernels instead of three.  r03's one-chain trace of cfg3: 21.5 + 7.5 + 5.6 us of
-// step / plan / fill and ~22 us of launch gaps per round, 1 100 dependent rounds per chain; the plan is one workgroup and the
-// fill a few thousand records, so the workgroup that takes the last ticket (one atomic per workgroup: a few hundred per round,
-// not the thousands of r01) does both in place of two more launches and their gaps.  Ordering: every workgroup makes its
-// stores (target states, windows, accepted lists) visible device-wide before it takes its ticket (release fence: the L2 of an
-// XCD is written back), the last one acquires after it (its L2 is invalidated -- as a kernel boundary would do anyway).
-// Rounds that compact the list of unfinished targets (one in sixteen) keep the three launches.
-__global__ __launch_bounds__(256) void dh_round_kernel(DhTgt *__restrict__ tg, int ntg, DhGlobal *__restrict__ g, DhArrays A,
-                                                       const FwSegOut *__restrict__ so, long long *__restrict__ seg0,
-                                                       unsigned long long *__restrict__ win, unsigned int *__restrict__ sp,
-                                                       unsigned long long *__restrict__ win2, const int32_t *__restrict__ act, DhParams P,
-                                                       DhPlanArgs PA, FwSeg *__restrict__ segs, int d1, int fill_here)
+// The cooperative round (r05): step, plan and fill in ONE launch of a small resident grid, with no single-workgroup phase.
+// r04 built "the last workgroup to finish plans and fills" and it lost (one 256-thread workgroup behind two device-wide fences plans
+// slower than a 1 024-thread launch, and fills a few thousand records in 25 us where a grid takes 6; profiles/r04_fused_round.json).
+// Here every workgroup steps its share of the unfinished targets (one wavefront per target, grid-strided), the grid meets at ONE
+// device-memory barrier (one ticket per workgroup), and then EVERY workgroup plans redundantly: the plan is an exclusive scan over a
+// few hundred per-target windows -- 20 bytes per target out of L2, a few microseconds -- and computing it 64-256 times costs less than
+// handing one workgroup's result to the others through a second barrier.  Each workgroup then fills its grid-strided share of the
+// segment records from its own LDS copy of the scan; workgroup 0 writes the launch record and seg0 for the next step.  Per round:
+// two launches (segment kernel, this one) instead of four, ~17 us less dependent latency.  The grid is fixed
+// for the whole run (G <= 256 workgroups of 256 threads: always co-resident, also next to a second chain's grid), the barrier
+// counts tickets monotonically (target = launches so far x G).  Used while the list holds at most DH_COOP_MAX targets; longer lists
+// and the compaction rounds keep the three launches.
+#define DH_COOP_MAX 2048
+#define DH_COOP_PER (DH_COOP_MAX / 256)
+__global__ __launch_bounds__(256) void dh_coop_kernel(DhTgt *__restrict__ tg, int ntg, DhGlobal *__restrict__ g, DhArrays A,
+                                                      const FwSegOut *__restrict__ so, long long *__restrict__ seg0,
+                                                      unsigned long long *__restrict__ win, unsigned int *__restrict__ sp,
+                                                      unsigned long long *__restrict__ win2, const int32_t *__restrict__ act_all, DhParams P,
+                                                      DhPlanArgs PA, FwSeg *__restrict__ segs, int d1, unsigned int ticket_target)
 {
-    __shared__ int s_last;
-    dh_step_dev(tg, ntg, g, A, so, seg0, win, sp, win2, act, P);
-    __threadfence();
+    __shared__ unsigned int s_seg0[DH_COOP_MAX + 1];
+    __shared__ unsigned long long s_tot[4];
+    __shared__ unsigned int s_live[4], s_wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int na = (int)g->n_act;  // (written by the compaction kernel only: stable during this launch)
+    const int32_t *act = act_all + (size_t)g->act_sel * ntg;
+    // ---- step ----
+    for (int ci = (int)blockIdx.x * 4 + wave; ci < na; ci += (int)gridDim.x * 4)
+        dh_step_dev(tg, ntg, g, A, so, seg0, win, sp, win2, act_all, P, ci);
+    if (blockIdx.x == 0 && tid == 0) atomicExch(&g->any_big, 0u);  // (the fill behind the barrier raises it)
+    // ---- barrier: every target's state, window and pools are in memory before anybody plans ----
+    // One wavefront per workgroup pays for the cache maintenance: the L2 write-back of a release and the invalidation of an acquire act
+    // on the whole cache, not on the issuing wavefront's lines, so once the workgroup's stores have left the CU (vmcnt(0) in front of
+    // the workgroup barrier) thread 0's fences cover them, and its invalidation covers the CU's L1 for the four wavefronts (first
+    // version: every wavefront fenced on both sides -- 2 048 cache-wide operations per round, 18 us slower than three launches).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&g->step_ticket, 1u) == gridDim.x - 1u;
+    if (tid == 0) {
+        __threadfence();
+        atomicAdd(&g->step_ticket, 1u);
+        while (__hip_atomic_load(&g->step_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ticket_target) __builtin_amdgcn_s_sleep(1);
+        __threadfence();
+    }
     __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    if (threadIdx.x == 0) g->step_ticket = 0u;
-    dh_plan_dev<256>(ntg, g, win, sp, win2, act, seg0, PA);
-    if (!fill_here) return;  // (FW_DH_FUSE=1: the fill keeps its own launch -- a few thousand records are one pass of a grid)
-    __threadfence();
+    // ---- plan (every workgroup, same integers) ----
+    const int per = (na + 255) / 256;  // <= DH_COOP_PER
+    const int b = tid * per, e = (b + per) < na ? (b + per) : na;
+    unsigned long long wr[DH_COOP_PER], w2r[DH_COOP_PER];
+    unsigned int mr[DH_COOP_PER];
+    unsigned long long tot = 0ull;
+    unsigned int live = 0u;
+#pragma unroll
+    for (int q = 0; q < DH_COOP_PER; ++q) {
+        const bool in = b + q < e;
+        const int tq = in ? act[b + q] : 0;
+        wr[q] = in ? __hip_atomic_load(&win[tq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        mr[q] = in ? __hip_atomic_load(&sp[tq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        w2r[q] = (in && mr[q] > 0u) ? __hip_atomic_load(&win2[tq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    }
+#pragma unroll
+    for (int q = 0; q < DH_COOP_PER; ++q) {
+        tot += wr[q] + w2r[q] * mr[q];
+        live += wr[q] != 0ull ? 1u + mr[q] : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        tot += __shfl_xor(tot, o);
+        live += __shfl_xor(live, o);
+    }
+    if (lane == 0) {
+        s_tot[wave] = tot;
+        s_live[wave] = live;
+    }
     __syncthreads();
-    const unsigned int ns = g->ns;
-    for (unsigned int s = threadIdx.x; s < ns; s += 256u) dh_fill_one(s, tg, ntg, g, seg0, A, segs, d1, act);
+    const unsigned long long total = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+    const unsigned int n_live = s_live[0] + s_live[1] + s_live[2] + s_live[3];
+    const unsigned int tgt = total < PA.seg_a ? (PA.seg_target + 2u) / 3u : (total < PA.seg_b ? (2u * PA.seg_target + 2u) / 3u : PA.seg_target);
+    unsigned long long seglen = (total / tgt + PA.seg_q - 1ull) / PA.seg_q * PA.seg_q;
+    seglen = seglen < PA.seg_min ? PA.seg_min : seglen;
+    const double inv = 1.0 / (double)seglen;
+    unsigned int local = 0u, nr[DH_COOP_PER];
+#pragma unroll
+    for (int q = 0; q < DH_COOP_PER; ++q) {
+        nr[q] = dh_ceil_div(wr[q], seglen, inv) + dh_ceil_div(w2r[q], seglen, inv) * mr[q];
+        local += nr[q];
+    }
+    unsigned int incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    unsigned int wbase = 0u, ns = 0u;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) wbase += s_wsum[w];
+        ns += s_wsum[w];
+    }
+    unsigned int run = wbase + incl - local;
+#pragma unroll
+    for (int q = 0; q < DH_COOP_PER; ++q)
+        if (b + q < e) {
+            s_seg0[b + q] = run;
+            run += nr[q];
+        }
+    if (tid == 0) s_seg0[na] = ns;
+    __syncthreads();
+    if (blockIdx.x == 0) {  // the launch record and the scan the next step reads
+        for (int i = tid; i <= na; i += 256) seg0[i] = (long long)s_seg0[i];
+        if (tid == 0) {
+            g->ns = ns;
+            g->seglen = (unsigned int)seglen;
+            g->launched_ranks = total;
+            g->n_live_prev = n_live;
+            if (n_live == 0u) g->done = 1u;
+            const unsigned int r = g->rounds;
+            g->ns_ring[r & 63u] = ns;
+            g->rounds = r + 1u;
+            if (PA.log && r < PA.log_cap) PA.log[r] = make_ulonglong2(total, ((unsigned long long)n_live << 32) | ns);  // FW_DH_LOG
+        }
+    }
+    // ---- fill: segment record s of the coming launch, grid-strided (dh_fill_one on the workgroup's own scan) ----
+    bool big = false;
+    for (unsigned int s = blockIdx.x * 256u + (unsigned int)tid; s < ns; s += gridDim.x * 256u) {
+        int lo = 0, hi = na;  // first list position with seg0 > s; the job owning slot s is the one before it
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_seg0[mid] <= s)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        const DhTgt &x = tg[act[lo - 1]];
+        unsigned long long k = (unsigned long long)(s - s_seg0[lo - 1]);
+        const int32_t *cands = x.phase == 0 ? A.cand0 + x.cand_off : A.tpc_key + x.co;
+        unsigned int slot = 0;
+        if (x.nsp > 0) {
+            const unsigned int all = s_seg0[lo] - s_seg0[lo - 1];
+            const unsigned int n0 = x.spmode == 1 ? dh_ceil_div(x.jwin, seglen, inv) : all / (1u + (unsigned int)x.nsp);
+            if ((unsigned int)k >= n0) {
+                const unsigned int pr = (all - n0) / (unsigned int)x.nsp;
+                slot = 1u + ((unsigned int)k - n0) / pr;
+                k -= (unsigned long long)n0 + (unsigned long long)(slot - 1u) * pr;
+            }
+        }
+        const bool acc_mode = slot > 0u && x.spmode == 1;
+        FwSeg sg;
+        sg.X = x.T;
+        sg.Y = cands[x.pos + (int)slot];
+        sg.acc_off = DH_ACC_OFF(x, x.phase == 1 ? (x.cur + (int)slot) % d1 : x.cur, d1);
+        sg.acc_len = x.na + (acc_mode ? 1 : 0);
+        big = big || sg.acc_len > FW_TAB_A;
+        sg.pad = 0;
+        const unsigned long long lo_r = acc_mode ? 0ull : x.jnext;
+        sg.start = lo_r + k * seglen;
+        const unsigned long long hi_r = lo_r + (slot > 0u ? x.jwin2 : x.jwin);
+        sg.end = sg.start + seglen < hi_r ? sg.start + seglen : hi_r;
+        segs[s] = sg;
+    }
+    if (big) atomicOr(&g->any_big, 1u);
 }
 
 // One workgroup, once per batch of rounds (between dh_step_kernel and dh_plan_kernel): drops the finished targets from
@@ -2150,7 +2268,184 @@ __global__ __launch_bounds__(1024) void dh_compact_kernel(const DhTgt *__restric
     }
 }
 
+// ---- the whole feed-forward schedule of the discrete kinds on the device (fwi_devhiton_mi_schedule) ------------------------------
+// per-target state of EVERY target of the schedule, built on the device from the level-0 CSR: a target's arrays (candidates in
+// hiton.jl:211-217 order, TPC / PC, accepted list, whitelist) all sit at its level-0 offset nb_off[T] with its degree as capacity
+__global__ __launch_bounds__(256) void dh_mi_init_kernel(DhTgt *__restrict__ tg, int nt, const int32_t *__restrict__ sched,
+                                                         const long long *__restrict__ nb_off, const int32_t *__restrict__ levels)
+{
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (i >= nt) return;
+    DhTgt x;
+    __builtin_memset(&x, 0, sizeof(x));
+    const int T = sched[i];
+    const long long o = nb_off[T];
+    const int deg = (int)(nb_off[T + 1] - o);
+    x.T = T;
+    x.nc = x.cap = deg;
+    x.phase = (deg == 0 || levels[T] < 2) ? 2 : 0;  // hiton.jl:182-184 (a constant variable), :336-338 (no candidate)
+    x.co = x.cand_off = x.wl_off = x.nb_off = o;
+    x.nb_n = deg;
+    x.wl_unsorted = 1;
+    tg[i] = x;
+}
+
+// after a round: the running graph of interleaved.jl:136-140, kept only where a later round will read it -- target T with u in PC(T)
+// is a whitelisted neighbour of u (hiton.jl:20-30) when u's own round comes later; T's own list is never read again.  One entry per
+// (T, u): no duplicates.  The level-0 lists are symmetric and PC(T) is a subset of T's candidates, so u's list holds at most deg(u).
+__global__ __launch_bounds__(256) void dh_wl_append_kernel(const DhTgt *__restrict__ tg, int ntg, const int32_t *__restrict__ pc_key,
+                                                           const int32_t *__restrict__ round_of, int round, int32_t *__restrict__ wl,
+                                                           const long long *__restrict__ nb_off, unsigned int *__restrict__ wl_cnt)
+{
+    const int t = (int)(blockIdx.x * 4u + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    if (t >= ntg) return;
+    const int T = tg[t].T, npc = tg[t].npc;
+    const long long co = tg[t].co;
+    for (int i = lane; i < npc; i += 64) {
+        const int32_t u = pc_key[co + i];
+        if (round_of[u] > round) wl[nb_off[u] + (long long)atomicAdd(&wl_cnt[u], 1u)] = T;
+    }
+}
+
 }  // namespace
+
+// window / look-ahead / board policy of a run (the sweeps that chose the defaults are quoted where each value is set)
+static DhParams dh_make_params(fw_ctx *c, int ntg, int spec_depth, int spec0_depth)
+{
+    DhParams P{};
+    P.alpha = c->P.alpha;
+    P.max_k = c->P.max_k;
+    P.max_tests = c->P.max_tests;
+    {
+        const char *e = fw_knob("FW_SMALL_LAUNCH");
+        P.small_launch = e ? (unsigned long long)atoll(e) : (1ull << 22);
+        const char *w = fw_knob("FW_W0_BIG");
+        P.w0_big = w ? (unsigned long long)atoll(w) : 16384ull;
+    }
+    {
+        const char *e = fw_knob("FW_ELIM_FULL");
+        P.elim_full = e ? atoi(e) : 1;
+    }
+    {
+        auto envu = [](const char *n, unsigned long long d) { const char *e = getenv(n); return e && atoll(e) > 0 ? (unsigned long long)atoll(e) : d; };
+        P.growth_small = envu("FW_DH_GROWTH_SMALL", 256ull);
+        P.growth = envu("FW_DH_GROWTH", 4ull);  // cfg3 sweeps: r01 4 -> 322 ms, 8 -> 321.5, 16 -> 331, 32 -> 350; r02 (three chains) 2 -> 219.6, 4 -> 218.3, 8 -> 219.7, 16 -> 241 (the host pool uses 16: its rounds cost 3x more)
+        P.growth_busy = envu("FW_DH_GROWTH_BUSY", 4ull);
+        P.busy_jobs = (unsigned int)envu("FW_DH_BUSY_JOBS", 2048ull);
+        P.spec_depth = spec_depth;
+        P.spec_below = envu("FW_DH_SPEC_BELOW", (c->P.max_k <= 3 && ntg >= 256) ? 30000000ull : 12000000ull);  // chains of few targets (a rank of 4 / 8: 98 / 49 per chain) are latency-bound and pay for it: slowest of 8 ranks 83.9 -> 91.0 ms with 30 M;  // max_k 4-5: whole enumerations of the look-ahead pools are too dear in big launches (cfg5, first 40 000 targets: 0.97 -> 1.95 s with 30 M)  // (r03, after the job-count gate of the interleaving look-ahead moved: 12 M -> 199.8 ms, 20 M 193.6, 30 M 193.4, 50 M 194.7, none 193.6; cfg3 without feed-forward 172.1 -> 168.4)
+        P.spec0_depth = spec0_depth;
+        P.spec0_below = envu("FW_DH_SPEC0_BELOW", 12000000ull);
+        { const char *e = fw_knob("FW_DH_SPEC0_LIGHT"); P.spec0_depth_light = spec0_depth > 0 ? std::min(std::max(e ? atoi(e) : spec0_depth, spec0_depth), DH_MAX_SPEC) : 0; }
+        P.spec0_light_below = envu("FW_DH_SPEC0_LIGHT_BELOW", 400000ull);
+        P.spec0_jobs = (unsigned int)envu("FW_DH_SPEC0_JOBS", 4096ull);  // (r03: 512 kept it off in the light feed-forward rounds of 1 024 targets: cfg3 204.8 -> 198.6 ms, 9 222 -> 7 966 launches)
+        {   // look-ahead behind a candidate that is about to be accepted (dh_step_kernel, spmode 1)
+            const char *e = fw_knob("FW_DH_SPEC1");
+            P.spec1_depth = c->P.kind == FW_FZ ? std::min(std::max(e ? atoi(e) : 2, 0), DH_MAX_SPEC) : 0;
+        }
+        P.mi_seq = (unsigned int)envu("FW_MI_SEQ", 48ull);  // r04 sweep on the final kernels (cfg4, ms with / without feed-forward, two runs each): 8: 149 / 106, 16 (r02-r03): 111.0 / 72.5, 24: 118 / 71.8, 32: 102.4 / 70.9, 48: 102.4 / 70.5, 64: 102.2 / 70.8, 128: 112.9 / 72.6, never a board: 111.5 / 79.1; cfg2 neutral
+        P.mi_win0 = (unsigned int)envu("FW_MI_WIN0", 128ull);
+        P.mi_chunk_div = (unsigned int)envu("FW_MI_CHUNK_DIV", 256ull);
+        P.mi_chunk_min = (unsigned int)envu("FW_MI_CHUNK_MIN", 8ull);
+        P.mi_chunk_max = (unsigned int)envu("FW_MI_CHUNK_MAX", 64ull);
+        { const char *e = fw_knob("FW_MI_HELP_JOBS"); P.mi_help_jobs = e ? (unsigned int)atoi(e) : 1u; }
+        { const char *e = fw_knob("FW_MI_ELIM_MIN"); P.mi_elim_min = e ? (unsigned int)atoi(e) : 64u; }
+        { const char *e = fw_knob("FW_MI_HEAVY"); P.mi_heavy = e ? (unsigned int)atoi(e) : 48u; }
+        { const char *e = fw_knob("FW_MI_SEQ_HEAVY"); P.mi_seq_heavy = e ? (unsigned int)atoi(e) : P.mi_seq; }
+        { const char *e = fw_knob("FW_MI_SEQ_TAIL"); P.mi_seq_tail = e ? (unsigned int)atoi(e) : 4u; }
+        { const char *e = fw_knob("FW_MI_AHEAD"); P.mi_ahead = e ? (unsigned int)atoi(e) : 1u; }
+        { const char *e = fw_knob("FW_MI_CHUNK_TAIL"); P.mi_chunk_tail = e ? (unsigned int)std::max(1, atoi(e)) : P.mi_chunk_min; }
+        { const char *e = fw_knob("FW_MI_WIN0_TAIL"); P.mi_win0_tail = e ? (unsigned int)std::max(1, atoi(e)) : 1024u; }
+    }
+    const bool fz = c->P.kind == FW_FZ;
+    // first window of an interleaving-phase job with fewer than 64 accepted variables.  r04 sweep at cfg3 (two chains, look-ahead 4 / 2,
+    // growth 4; ms per pass / launches): 64: 198.7 / 9 790, 128: 194.8, 256 (r01-r03): 189.1 / 8 090, 512: 186.3, 1 024: 183.9, 2 048: 184.7,
+    // 4 096: 182.5 / 7 194, 8 192: 184.3, 16 384: 187.6 -- the executed tests move by less than 1 % over that range (a job that stops does
+    // so within its first wavefront steps whatever the window), the launches by 25 %.  max_k > 3 keeps 256 (not measured at full cfg5 size).
+    // Second sweep (first window 4 096): first window of jobs with 64 accepted variables or more 8 192: 191.2, 16 384 (r01-r03): 183.8,
+    // 24 576: 182.4, 32 768: 178.1 - 179.9, 49 152: 182.4, 65 536: 191.4; with 32 768 the small window 2 048: 177.3, 4 096: 178.1, 8 192: 181.7.
+    P.w0_small = fz ? (c->P.max_k <= 3 ? 2048ull : 256ull) : 16ull;
+    if (fz && c->P.max_k <= 3 && !fw_knob("FW_W0_BIG")) P.w0_big = 32768ull;
+    if (fz) {
+        const char *e = fw_knob("FW_W0_SMALL");  // first window (ranks) of a job with fewer than 64 accepted variables (r04 sweep: DESIGN section 4)
+        if (e && atoll(e) > 0) P.w0_small = (unsigned long long)atoll(e);
+    }
+    if (!fz) P.w0_big = 16ull;
+    P.seg_q = fz ? 256u : 4u;
+    P.seg_min = fz ? 256u : 8u;
+    P.disc_bytes_per_col = fz ? 0.0 : (double)c->P.n * (c->P.kind == FW_MI ? 1.0 : 2.0) / 8.0;
+    return P;
+}
+
+static unsigned dh_team_min() { static const unsigned v = [] { const char *e = fw_knob("FW_MI_TEAM_MIN"); return e ? (unsigned)atoi(e) : 96u; }(); return v; }
+static unsigned dh_team_max() { static const unsigned v = [] { const char *e = fw_knob("FW_MI_TEAM_MAX"); return e ? (unsigned)atoi(e) : 192u; }(); return v; }  // (64 / 256: cfg2 10.5 ms, cfg4 161.7; 128 / 128: 9.4, 162.7; 96 / 192: 9.3, 159.6)
+
+// launches the persistent discrete kernel over targets tg[0 .. ntg) taken in the order d_order (heaviest first; the first `team` of
+// them by a workgroup each); returns the grid.  The queue and the boards must be zero (the caller's memsets on the same stream).
+static unsigned dh_mi_launch(fw_ctx *c, hipStream_t st, DhTgt *d_tg, int ntg, const int32_t *d_order, const DhArrays &A, DhParams P, unsigned team,
+                             bool trace_host, MiQueue *d_mq, MiBoard *d_boards, FwSegOut *d_mres, int32_t *d_bacc)
+{
+    MiDev M = fwi_mi_dev(c);
+    M.view = M.dense && M.nzmode && c->mi_view;  // HITON-PC under the dense rules tests on row views (hiton.jl:41-50)
+    // as many workgroups as stay resident (one per CU: the test routine needs ~260 VGPRs, one wavefront per SIMD; cfg4:
+    // 62 ms with one, 71 ms with two requested): the wavefronts fetch targets themselves
+    static const unsigned wg_per_cu = [] { const char *e = fw_knob("FW_MI_WG_PER_CU"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 1u; }();
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->P.device);
+    const unsigned grid = std::min((unsigned)((ntg + 3) / 4), wg_per_cu * (unsigned)n_cu);
+    static const unsigned team_steps = [] { const char *e = fw_knob("FW_MI_TEAM_STEPS"); return e ? (unsigned)atoi(e) : 2u; }();
+    static const unsigned team_tail = [] { const char *e = fw_knob("FW_MI_TEAM_TAIL"); return e ? (unsigned)atoi(e) : 0u; }();
+    P.mi_team = team;
+    P.mi_team_steps = team_steps;
+    P.mi_team_tail = team_tail;
+#ifdef FW_MI_TICKS
+    P.mi_trace = 1u;
+#else
+    P.mi_trace = trace_host ? 1u : 0u;
+#endif
+#define DH_MI_LAUNCH(LL, NN, PP, RR)                                                                                                  \
+    hipLaunchKernelGGL((dh_mi_target_kernel<LL, NN, PP, RR>), dim3(grid), dim3(256), 0, st, d_tg, ntg, d_order, A, M, P, \
+                       d_mq, d_boards, d_mres, d_bacc)
+    const bool pre = c->P.n <= MI_PRE_N && c->P.max_k <= MI_PRE_K;
+    // four subsets per wavefront step (mi_test_core4): n <= 5120, max_k <= 3, 2 x 2 cells per stratum.  FW_MI_ROW4=0: one per step
+    static const bool row4_env = [] { const char *e = fw_knob("FW_MI_ROW4"); return !(e && atoi(e) == 0); }();
+    // ... used up to 2048 samples (four words per lane): cfg2 (n = 500) 15.2 -> 12.5 ms.  At cfg4's n = 5000 a step of four
+    // tests takes as long as four one-test steps (34 us: ten words per lane, 390 registers with the spills parked in AGPRs),
+    // and since most jobs stop at their first test the three speculative ones are pure cost: measured 56.2 vs 56.8 ms on one
+    // GPU, 35.3 vs 39.2 ms for one rank of eight -- FW_MI_ROW4=2 forces it on up to MI4_N for such experiments
+    static const bool row4_force = [] { const char *e = fw_knob("FW_MI_ROW4"); return e && atoi(e) == 2; }();
+    const bool r4 = row4_env && pre && c->P.n <= (row4_force ? MI4_N : 2048) && (c->L == 2 || c->mi_nxy == 2);
+    const bool wide = c->P.n > 65535;  // cell counts beyond 16 bits: one count per register, 32-bit tables (mi_test_core<.., WIDE>)
+    if (c->L == 2) {
+        if (wide) DH_MI_LAUNCH(2, 2, 2, false); else if (r4) DH_MI_LAUNCH(2, 2, 1, true); else if (pre) DH_MI_LAUNCH(2, 2, 1, false); else DH_MI_LAUNCH(2, 2, 0, false);
+    } else if (c->mi_nxy == 2) {
+        if (wide) DH_MI_LAUNCH(3, 2, 2, false); else if (r4) DH_MI_LAUNCH(3, 2, 1, true); else if (pre) DH_MI_LAUNCH(3, 2, 1, false); else DH_MI_LAUNCH(3, 2, 0, false);
+    } else {
+        if (wide) DH_MI_LAUNCH(3, 3, 2, false); else if (pre) DH_MI_LAUNCH(3, 3, 1, false); else DH_MI_LAUNCH(3, 3, 0, false);
+    }
+#undef DH_MI_LAUNCH
+    return grid;
+}
+
+static void dh_mi_trace(const MiQueue &hq, unsigned grid)
+{
+    const double nw = 4.0 * (double)grid, ms = 1e-5;
+    if (hq.tick[1])
+        fprintf(stderr, "[fw] test routine: %llu calls, %llu tests (mean set size %.2f); per test %.2f us before the core (unranking, list), %.2f us in the core, %.2f us in the accounting (Q)\n",
+                hq.tick[0], hq.tick[1], (double)hq.tick[5] / (double)hq.tick[1], 1e-2 * hq.tick[2] / (double)hq.tick[1],
+                1e-2 * hq.tick[3] / (double)hq.tick[1], 1e-2 * hq.tick[4] / (double)hq.tick[1]);
+    if (hq.tick[1])
+        fprintf(stderr, "[fw] state machine, ms per wavefront: dh_advance %.3f, job set-up %.3f, commit + counters %.3f, publish %.3f, idle wait for own board %.3f, merge %.3f; "
+                        "test routine: before the core %.3f, core %.3f, accounting %.3f\n",
+                ms * hq.tick[6] / nw, ms * hq.tick[7] / nw, ms * hq.tick[8] / nw, ms * hq.tick[9] / nw, ms * hq.tick[10] / nw, ms * hq.tick[11] / nw,
+                ms * hq.tick[2] / nw, ms * hq.tick[3] / nw, ms * hq.tick[4] / nw);
+    if (hq.tm_steps)
+        fprintf(stderr, "[fw] team rounds: %llu wavefront-rounds, %llu tests in them; per wavefront-round %.2f us in the test routine, %.2f us at the barrier\n",
+                hq.tm_steps, hq.tm_tests, 1e-2 * hq.tm_run / (double)hq.tm_steps, 1e-2 * hq.tm_wait / (double)hq.tm_steps);
+    fprintf(stderr, "[fw] boards %u records %u; per wavefront (%u wavefronts): until out of targets %.2f ms = own first tests %.2f + board phases %.2f + helping before jobs %.2f + state machine %.2f; tail %.2f ms\n",
+            hq.n_boards, hq.res_top, 4u * grid, ms * hq.t_total / nw, ms * hq.t_body / nw, ms * hq.t_ctl / nw, ms * hq.t_sleep / nw,
+            ms * ((double)hq.t_total - (double)hq.t_body - (double)hq.t_ctl - (double)hq.t_sleep) / nw, ms * hq.n_seg / nw);
+}
 
 // One round of targets on the device.  in: T ids, interleaving candidates and (sorted) whitelists per target;
 // out: PC (keys, statistics, p-values) per target in insertion order.
@@ -2312,68 +2607,8 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         A.nb_stat = s1;
         A.nb_p = s2;
     }
-    DhParams P{};
-    P.alpha = c->P.alpha;
-    P.max_k = c->P.max_k;
-    P.max_tests = c->P.max_tests;
-    {
-        const char *e = fw_knob("FW_SMALL_LAUNCH");
-        P.small_launch = e ? (unsigned long long)atoll(e) : (1ull << 22);
-        const char *w = fw_knob("FW_W0_BIG");
-        P.w0_big = w ? (unsigned long long)atoll(w) : 16384ull;
-    }
-    {
-        const char *e = fw_knob("FW_ELIM_FULL");
-        P.elim_full = e ? atoi(e) : 1;
-    }
-    {
-        auto envu = [](const char *n, unsigned long long d) { const char *e = getenv(n); return e && atoll(e) > 0 ? (unsigned long long)atoll(e) : d; };
-        P.growth_small = envu("FW_DH_GROWTH_SMALL", 256ull);
-        P.growth = envu("FW_DH_GROWTH", 4ull);  // cfg3 sweeps: r01 4 -> 322 ms, 8 -> 321.5, 16 -> 331, 32 -> 350; r02 (three chains) 2 -> 219.6, 4 -> 218.3, 8 -> 219.7, 16 -> 241 (the host pool uses 16: its rounds cost 3x more)
-        P.growth_busy = envu("FW_DH_GROWTH_BUSY", 4ull);
-        P.busy_jobs = (unsigned int)envu("FW_DH_BUSY_JOBS", 2048ull);
-        P.spec_depth = spec_depth;
-        P.spec_below = envu("FW_DH_SPEC_BELOW", (c->P.max_k <= 3 && ntg >= 256) ? 30000000ull : 12000000ull);  // chains of few targets (a rank of 4 / 8: 98 / 49 per chain) are latency-bound and pay for it: slowest of 8 ranks 83.9 -> 91.0 ms with 30 M;  // max_k 4-5: whole enumerations of the look-ahead pools are too dear in big launches (cfg5, first 40 000 targets: 0.97 -> 1.95 s with 30 M)  // (r03, after the job-count gate of the interleaving look-ahead moved: 12 M -> 199.8 ms, 20 M 193.6, 30 M 193.4, 50 M 194.7, none 193.6; cfg3 without feed-forward 172.1 -> 168.4)
-        P.spec0_depth = spec0_depth;
-        P.spec0_below = envu("FW_DH_SPEC0_BELOW", 12000000ull);
-        { const char *e = fw_knob("FW_DH_SPEC0_LIGHT"); P.spec0_depth_light = spec0_depth > 0 ? std::min(std::max(e ? atoi(e) : spec0_depth, spec0_depth), DH_MAX_SPEC) : 0; }
-        P.spec0_light_below = envu("FW_DH_SPEC0_LIGHT_BELOW", 400000ull);
-        P.spec0_jobs = (unsigned int)envu("FW_DH_SPEC0_JOBS", 4096ull);  // (r03: 512 kept it off in the light feed-forward rounds of 1 024 targets: cfg3 204.8 -> 198.6 ms, 9 222 -> 7 966 launches)
-        {   // look-ahead behind a candidate that is about to be accepted (dh_step_kernel, spmode 1)
-            const char *e = fw_knob("FW_DH_SPEC1");
-            P.spec1_depth = c->P.kind == FW_FZ ? std::min(std::max(e ? atoi(e) : 2, 0), DH_MAX_SPEC) : 0;
-        }
-        P.mi_seq = (unsigned int)envu("FW_MI_SEQ", 48ull);  // r04 sweep on the final kernels (cfg4, ms with / without feed-forward, two runs each): 8: 149 / 106, 16 (r02-r03): 111.0 / 72.5, 24: 118 / 71.8, 32: 102.4 / 70.9, 48: 102.4 / 70.5, 64: 102.2 / 70.8, 128: 112.9 / 72.6, never a board: 111.5 / 79.1; cfg2 neutral
-        P.mi_win0 = (unsigned int)envu("FW_MI_WIN0", 128ull);
-        P.mi_chunk_div = (unsigned int)envu("FW_MI_CHUNK_DIV", 256ull);
-        P.mi_chunk_min = (unsigned int)envu("FW_MI_CHUNK_MIN", 8ull);
-        P.mi_chunk_max = (unsigned int)envu("FW_MI_CHUNK_MAX", 64ull);
-        { const char *e = fw_knob("FW_MI_HELP_JOBS"); P.mi_help_jobs = e ? (unsigned int)atoi(e) : 1u; }
-        { const char *e = fw_knob("FW_MI_ELIM_MIN"); P.mi_elim_min = e ? (unsigned int)atoi(e) : 64u; }
-        { const char *e = fw_knob("FW_MI_HEAVY"); P.mi_heavy = e ? (unsigned int)atoi(e) : 48u; }
-        { const char *e = fw_knob("FW_MI_SEQ_HEAVY"); P.mi_seq_heavy = e ? (unsigned int)atoi(e) : P.mi_seq; }
-        { const char *e = fw_knob("FW_MI_SEQ_TAIL"); P.mi_seq_tail = e ? (unsigned int)atoi(e) : 4u; }
-        { const char *e = fw_knob("FW_MI_AHEAD"); P.mi_ahead = e ? (unsigned int)atoi(e) : 1u; }
-        { const char *e = fw_knob("FW_MI_CHUNK_TAIL"); P.mi_chunk_tail = e ? (unsigned int)std::max(1, atoi(e)) : P.mi_chunk_min; }
-        { const char *e = fw_knob("FW_MI_WIN0_TAIL"); P.mi_win0_tail = e ? (unsigned int)std::max(1, atoi(e)) : 1024u; }
-    }
     const bool fz = c->P.kind == FW_FZ;
-    // first window of an interleaving-phase job with fewer than 64 accepted variables.  r04 sweep at cfg3 (two chains, look-ahead 4 / 2,
-    // growth 4; ms per pass / launches): 64: 198.7 / 9 790, 128: 194.8, 256 (r01-r03): 189.1 / 8 090, 512: 186.3, 1 024: 183.9, 2 048: 184.7,
-    // 4 096: 182.5 / 7 194, 8 192: 184.3, 16 384: 187.6 -- the executed tests move by less than 1 % over that range (a job that stops does
-    // so within its first wavefront steps whatever the window), the launches by 25 %.  max_k > 3 keeps 256 (not measured at full cfg5 size).
-    // Second sweep (first window 4 096): first window of jobs with 64 accepted variables or more 8 192: 191.2, 16 384 (r01-r03): 183.8,
-    // 24 576: 182.4, 32 768: 178.1 - 179.9, 49 152: 182.4, 65 536: 191.4; with 32 768 the small window 2 048: 177.3, 4 096: 178.1, 8 192: 181.7.
-    P.w0_small = fz ? (c->P.max_k <= 3 ? 2048ull : 256ull) : 16ull;
-    if (fz && c->P.max_k <= 3 && !fw_knob("FW_W0_BIG")) P.w0_big = 32768ull;
-    if (fz) {
-        const char *e = fw_knob("FW_W0_SMALL");  // first window (ranks) of a job with fewer than 64 accepted variables (r04 sweep: DESIGN section 4)
-        if (e && atoll(e) > 0) P.w0_small = (unsigned long long)atoll(e);
-    }
-    if (!fz) P.w0_big = 16ull;
-    P.seg_q = fz ? 256u : 4u;
-    P.seg_min = fz ? 256u : 8u;
-    P.disc_bytes_per_col = fz ? 0.0 : (double)c->P.n * (c->P.kind == FW_MI ? 1.0 : 2.0) / 8.0;
+    DhParams P = dh_make_params(c, ntg, spec_depth, spec0_depth);
     // The in-lane kernel (accepted lists beyond FW_TAB_A) is only launched when such a list can exist in the coming batch:
     // without whitelists an accepted list grows by at most one entry per round, so max_a (longest list so far, read
     // back once per batch) + BATCH bounds it; with whitelists a round can append several entries -> static bound.
@@ -2436,21 +2671,19 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     PA.log = d_log;
     PA.seg_a = seg_a;
     PA.seg_b = seg_b;
-    // FW_DH_FUSE: 0 (default) = step, plan and fill as three launches, 1 = the last workgroup of the step kernel plans, 2 = ... and
-    // fills (dh_round_kernel); rounds that compact the list keep the three launches.  Built and measured in r04, NOT kept as the
-    // default: cfg3 headline 189.9 / 188.4 / 203.0 ms and one-chain pass 237.4 / 245.5 / 270.7 ms with 0 / 1 / 2
-    // (profiles/r04_fused_round.json) -- one 256-thread workgroup behind two device-wide fences plans slower than a 1 024-thread
-    // launch (+7 us per round against the ~5 us gap it saves), and filling a few thousand records from ONE workgroup costs ~25 us
-    // where a grid does it in 6.  What would pay is a round without any single-workgroup phase.
-    static const int fuse_env = [] { const char *e = fw_knob("FW_DH_FUSE"); return e ? atoi(e) : 0; }();
+    // FW_DH_FUSE: 1 (default) = the cooperative round (dh_coop_kernel: step | device barrier | redundant plan + fill, one launch),
+    // 0 = step, plan and fill as three launches (r01-r04).  The coop form serves lists of at most DH_COOP_MAX unfinished targets;
+    // longer lists and the rounds that compact the list keep the three launches.
+    static const int fuse_env = [] { const char *e = fw_knob("FW_DH_FUSE"); return e ? atoi(e) : 1; }();
     const int fuse = c->P.kind == FW_FZ ? fuse_env : 0;
+    static const unsigned coop_cap = [] { const char *e = fw_knob("FW_DH_COOP_GRID"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 128u; }();
+    unsigned coop_tickets = 0u;  // tickets the barrier word holds after the launches so far (grids differ from launch to launch)
     auto planfill = [&](bool compact) {
-        if (fuse > 0 && !compact) {
-            hipLaunchKernelGGL(dh_round_kernel, dim3((n_act_bound + 3u) / 4u), dim3(256), 0, st, d_tg, ntg, d_g, A, (const FwSegOut *)d_so, d_seg0,
-                               d_win, d_sp, d_win2, (const int32_t *)d_act, P, PA, d_segs, d1, fuse >= 2 ? 1 : 0);
-            if (fuse < 2)
-                hipLaunchKernelGGL(dh_fill_kernel, dim3(g_fill), dim3(256), 0, st, (const DhTgt *)d_tg, ntg, d_g, (const long long *)d_seg0, A,
-                                   d_segs, d1, (const int32_t *)d_act);
+        if (fuse > 0 && !compact && n_act_bound <= (unsigned)DH_COOP_MAX) {
+            const unsigned coop_grid = std::min(coop_cap, std::max(8u, (n_act_bound + 3u) / 4u));
+            coop_tickets += coop_grid;
+            hipLaunchKernelGGL(dh_coop_kernel, dim3(coop_grid), dim3(256), 0, st, d_tg, ntg, d_g, A, (const FwSegOut *)d_so, d_seg0, d_win, d_sp,
+                               d_win2, (const int32_t *)d_act, P, PA, d_segs, d1, coop_tickets);
             return;
         }
         hipLaunchKernelGGL(dh_step_kernel, dim3((n_act_bound + 3u) / 4u), dim3(256), 0, st, d_tg, ntg, d_g, A,
@@ -2473,24 +2706,10 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         std::stable_sort(order.begin(), order.end(), [&](int32_t u, int32_t v) { return tg[u].nc > tg[v].nc; });  // heaviest first
         FW_HIP(c, hipMemcpyAsync(d_act, order.data(), sizeof(int32_t) * (size_t)ntg, hipMemcpyHostToDevice, st));
         {
-        MiDev M = fwi_mi_dev(c);
-        M.view = M.dense && M.nzmode && c->mi_view;  // HITON-PC under the dense rules tests on row views (hiton.jl:41-50)
-        // as many workgroups as stay resident (one per CU: the test routine needs ~260 VGPRs, one wavefront per SIMD; cfg4:
-        // 62 ms with one, 71 ms with two requested): the wavefronts fetch targets themselves
-        static const unsigned wg_per_cu = [] { const char *e = fw_knob("FW_MI_WG_PER_CU"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 1u; }();
-        int n_cu = 256;
-        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->P.device);
-        const unsigned grid = std::min((unsigned)((ntg + 3) / 4), wg_per_cu * (unsigned)n_cu);
+        unsigned team = 0u;
         {   // targets with at least FW_MI_TEAM_MIN candidates (at most FW_MI_TEAM_MAX of them): a workgroup each
-            static const unsigned team_min = [] { const char *e = fw_knob("FW_MI_TEAM_MIN"); return e ? (unsigned)atoi(e) : 96u; }();
-            static const unsigned team_max = [] { const char *e = fw_knob("FW_MI_TEAM_MAX"); return e ? (unsigned)atoi(e) : 192u; }();  // (64 / 256: cfg2 10.5 ms, cfg4 161.7; 128 / 128: 9.4, 162.7; 96 / 192: 9.3, 159.6)
-            static const unsigned team_steps = [] { const char *e = fw_knob("FW_MI_TEAM_STEPS"); return e ? (unsigned)atoi(e) : 2u; }();
-            unsigned team = 0u;
+            const unsigned team_min = dh_team_min(), team_max = dh_team_max();
             while (team_min > 0u && team < team_max && (int)team < ntg && (unsigned)tg[order[team]].nc >= team_min) ++team;
-            P.mi_team = team;
-            P.mi_team_steps = team_steps;
-            static const unsigned team_tail = [] { const char *e = fw_knob("FW_MI_TEAM_TAIL"); return e ? (unsigned)atoi(e) : 0u; }();
-            P.mi_team_tail = team_tail;
             if (trace_host) {
                 int c32 = 0, c64 = 0, c128 = 0, c192 = 0;
                 for (int t = 0; t < ntg; ++t) c32 += tg[t].nc >= 32, c64 += tg[t].nc >= 64, c128 += tg[t].nc >= 128, c192 += tg[t].nc >= 192;
@@ -2499,59 +2718,17 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
                         tg[order[0]].nc, ntg > 63 ? tg[order[63]].nc : -1, ntg > 255 ? tg[order[255]].nc : -1);
             }
         }
-#ifdef FW_MI_TICKS
-        P.mi_trace = 1u;
-#else
-        P.mi_trace = trace_host ? 1u : 0u;
-#endif
         FW_HIP(c, hipMemsetAsync(d_mq, 0, sizeof(MiQueue), st));
         FW_HIP(c, hipMemsetAsync(d_boards, 0, sizeof(MiBoard) * MI_BOARD_CAP, st));  // ready flags, claimed / finished counts
         FW_HIP(c, hipEventRecord(ev[0][0], st));
-#define DH_MI_LAUNCH(LL, NN, PP, RR)                                                                                                  \
-    hipLaunchKernelGGL((dh_mi_target_kernel<LL, NN, PP, RR>), dim3(grid), dim3(256), 0, st, d_tg, ntg, (const int32_t *)d_act, A, M, P, \
-                       d_mq, d_boards, d_mres, d_bacc)
-        const bool pre = c->P.n <= MI_PRE_N && c->P.max_k <= MI_PRE_K;
-        // four subsets per wavefront step (mi_test_core4): n <= 5120, max_k <= 3, 2 x 2 cells per stratum.  FW_MI_ROW4=0: one per step
-        static const bool row4_env = [] { const char *e = fw_knob("FW_MI_ROW4"); return !(e && atoi(e) == 0); }();
-        // ... used up to 2048 samples (four words per lane): cfg2 (n = 500) 15.2 -> 12.5 ms.  At cfg4's n = 5000 a step of four
-        // tests takes as long as four one-test steps (34 us: ten words per lane, 390 registers with the spills parked in AGPRs),
-        // and since most jobs stop at their first test the three speculative ones are pure cost: measured 56.2 vs 56.8 ms on one
-        // GPU, 35.3 vs 39.2 ms for one rank of eight -- FW_MI_ROW4=2 forces it on up to MI4_N for such experiments
-        static const bool row4_force = [] { const char *e = fw_knob("FW_MI_ROW4"); return e && atoi(e) == 2; }();
-        const bool r4 = row4_env && pre && c->P.n <= (row4_force ? MI4_N : 2048) && (c->L == 2 || c->mi_nxy == 2);
-        const bool wide = c->P.n > 65535;  // cell counts beyond 16 bits: one count per register, 32-bit tables (mi_test_core<.., WIDE>)
-        if (c->L == 2) {
-            if (wide) DH_MI_LAUNCH(2, 2, 2, false); else if (r4) DH_MI_LAUNCH(2, 2, 1, true); else if (pre) DH_MI_LAUNCH(2, 2, 1, false); else DH_MI_LAUNCH(2, 2, 0, false);
-        } else if (c->mi_nxy == 2) {
-            if (wide) DH_MI_LAUNCH(3, 2, 2, false); else if (r4) DH_MI_LAUNCH(3, 2, 1, true); else if (pre) DH_MI_LAUNCH(3, 2, 1, false); else DH_MI_LAUNCH(3, 2, 0, false);
-        } else {
-            if (wide) DH_MI_LAUNCH(3, 3, 2, false); else if (pre) DH_MI_LAUNCH(3, 3, 1, false); else DH_MI_LAUNCH(3, 3, 0, false);
-        }
-#undef DH_MI_LAUNCH
+        const unsigned grid = dh_mi_launch(c, st, d_tg, ntg, (const int32_t *)d_act, A, P, team, trace_host, d_mq, d_boards, d_mres, d_bacc);
         FW_HIP(c, hipGetLastError());
         FW_HIP(c, hipEventRecord(ev[0][1], st));
         FW_HIP(c, hipStreamSynchronize(st));
         MiQueue hq{};
         FW_HIP(c, hipMemcpy(&hq, d_mq, sizeof(hq), hipMemcpyDeviceToHost));
         if (hq.pad[0]) return fw_fail(c, FW_ERR_DEVICE, "discrete HITON kernel: watchdog %u (boards %u, targets done %u of %d)", hq.pad[0], hq.n_boards, hq.targets_done, ntg);
-        if (trace_host) {
-            const double nw = 4.0 * (double)grid, ms = 1e-5;
-            if (hq.tick[1])
-                fprintf(stderr, "[fw] test routine: %llu calls, %llu tests (mean set size %.2f); per test %.2f us before the core (unranking, list), %.2f us in the core, %.2f us in the accounting (Q)\n",
-                        hq.tick[0], hq.tick[1], (double)hq.tick[5] / (double)hq.tick[1], 1e-2 * hq.tick[2] / (double)hq.tick[1],
-                        1e-2 * hq.tick[3] / (double)hq.tick[1], 1e-2 * hq.tick[4] / (double)hq.tick[1]);
-            if (hq.tick[1])
-                fprintf(stderr, "[fw] state machine, ms per wavefront: dh_advance %.3f, job set-up %.3f, commit + counters %.3f, publish %.3f, idle wait for own board %.3f, merge %.3f; "
-                                "test routine: before the core %.3f, core %.3f, accounting %.3f\n",
-                        ms * hq.tick[6] / nw, ms * hq.tick[7] / nw, ms * hq.tick[8] / nw, ms * hq.tick[9] / nw, ms * hq.tick[10] / nw, ms * hq.tick[11] / nw,
-                        ms * hq.tick[2] / nw, ms * hq.tick[3] / nw, ms * hq.tick[4] / nw);
-            if (hq.tm_steps)
-                fprintf(stderr, "[fw] team rounds: %llu wavefront-rounds, %llu tests in them; per wavefront-round %.2f us in the test routine, %.2f us at the barrier\n",
-                        hq.tm_steps, hq.tm_tests, 1e-2 * hq.tm_run / (double)hq.tm_steps, 1e-2 * hq.tm_wait / (double)hq.tm_steps);
-            fprintf(stderr, "[fw] boards %u records %u; per wavefront (%u wavefronts): until out of targets %.2f ms = own first tests %.2f + board phases %.2f + helping before jobs %.2f + state machine %.2f; tail %.2f ms\n",
-                    hq.n_boards, hq.res_top, 4u * grid, ms * hq.t_total / nw, ms * hq.t_body / nw, ms * hq.t_ctl / nw, ms * hq.t_sleep / nw,
-                    ms * ((double)hq.t_total - (double)hq.t_body - (double)hq.t_ctl - (double)hq.t_sleep) / nw, ms * hq.n_seg / nw);
-        }
+        if (trace_host) dh_mi_trace(hq, grid);
         float ms = 0.0f;
         FW_HIP(c, hipEventElapsedTime(&ms, ev[0][0], ev[0][1]));
         timed_s = 1e-3 * (double)ms;
@@ -2735,5 +2912,167 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         c->cnt.cond_tests_evaluated += (int64_t)x.c_eval;
         c->cnt.alg_bytes_subsets += x.c_alg;
     }
+    return FW_OK;
+}
+
+// The WHOLE feed-forward schedule of the discrete kinds on the device (r05; one GPU, no exchange between the rounds).  r02-r04 ran one
+// persistent launch per round with the host in between: download the round's PC lists, update the running graph, build the next round's
+// targets and whitelists, upload -- cfg4: ~1.4 ms per round besides the kernel (ten rounds) plus 5 ms before the first one, for nine
+// launches of 1-3 ms each.  Here the state of every target of the schedule is built on the device from the level-0 CSR
+// (dh_mi_init_kernel), the whitelists grow on the device between two launches (dh_wl_append_kernel: interleaved.jl:136-140 kept where a
+// later round reads it), and the launches of all rounds are enqueued back to back; the host reads the results once.  Semantics per
+// round are those of fwi_devhiton_run (same kernel, same per-round order and team size).  sched[0 .. nt): the targets in schedule order
+// (learning.jl:97-98); rounds of R targets.  Appends (target, neighbour, statistic, p) in schedule order, PC insertion order inside a target.
+int fwi_devhiton_mi_schedule(fw_ctx *c, const int32_t *sched, int nt, int R, bool feed_forward, std::vector<int32_t> &all_t,
+                             std::vector<int32_t> &all_u, std::vector<double> &all_s, std::vector<double> &all_p)
+{
+    if (nt == 0) return FW_OK;
+    if (!c->d_cand || !c->d_nb_idx) return fw_fail(c, FW_ERR_STATE, "device schedule: the level-0 lists are not on the device");
+    static const bool trace_host = fw_knob("FW_TRACE_HOST") != nullptr;
+    auto wall = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double th0 = wall();
+    hipStream_t st = c->pb[0].stream;
+    const int p = c->P.p;
+    const size_t nnz = (size_t)c->nb_off[p];
+    if (R <= 0 || R > nt) R = nt;
+    const int nrounds = (nt + R - 1) / R;
+    // ---- host: per-round order (heaviest first, stable), team sizes, round of every variable ----
+    std::vector<int32_t> order((size_t)nt), round_of((size_t)p, 0x7fffffff);
+    std::vector<unsigned> team((size_t)nrounds, 0u);
+    std::vector<int32_t> deg((size_t)nt);
+    for (int i = 0; i < nt; ++i) {
+        deg[i] = (int32_t)(c->nb_off[sched[i] + 1] - c->nb_off[sched[i]]);
+        round_of[sched[i]] = i / R;
+    }
+    for (int r = 0; r < nrounds; ++r) {
+        const int r0 = r * R, r1 = std::min(nt, r0 + R);
+        for (int i = r0; i < r1; ++i) order[i] = i - r0;
+        std::stable_sort(order.begin() + r0, order.begin() + r1, [&](int32_t u, int32_t v) { return deg[r0 + u] > deg[r0 + v]; });
+        unsigned tm = 0u;
+        const unsigned team_min = dh_team_min(), team_max = dh_team_max();
+        while (team_min > 0u && tm < team_max && (int)tm < r1 - r0 && (unsigned)deg[r0 + order[r0 + tm]] >= team_min) ++tm;
+        team[r] = tm;
+    }
+    // ---- device arena ----
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t need = pad(sizeof(DhTgt) * (size_t)nt) + 2 * pad(4 * (size_t)nt) + pad(4 * (size_t)p) * 2 + pad(4 * nnz + 4) * 3 + pad(4 * 2 * nnz + 4) +
+                  pad(8 * nnz + 8) * 4 + pad(sizeof(MiQueue) * (size_t)nrounds) + pad(sizeof(MiBoard) * MI_BOARD_CAP) +
+                  pad(sizeof(FwSegOut) * (size_t)MI_REC_CAP) + pad(sizeof(int32_t) * (size_t)MI_BACC_CAP);
+    int rc;
+    if ((rc = fw_dev_reserve(c, c->d_dh[0], need))) return rc;
+    char *B = (char *)c->d_dh[0].ptr;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        char *q = B + off;
+        off += pad(bytes);
+        return q;
+    };
+    DhTgt *d_tg = (DhTgt *)carve(sizeof(DhTgt) * (size_t)nt);
+    int32_t *d_sched = (int32_t *)carve(4 * (size_t)nt);
+    int32_t *d_order = (int32_t *)carve(4 * (size_t)nt);
+    int32_t *d_round_of = (int32_t *)carve(4 * (size_t)p);
+    unsigned int *d_wl_cnt = (unsigned int *)carve(4 * (size_t)p);
+    DhArrays A{};
+    A.cand0 = c->d_cand;
+    A.tpc_key = (int32_t *)carve(4 * nnz + 4);
+    A.pc_key = (int32_t *)carve(4 * nnz + 4);
+    int32_t *d_wl = (int32_t *)carve(4 * nnz + 4);
+    A.wl = d_wl;
+    A.wl_cnt = feed_forward ? d_wl_cnt : nullptr;
+    A.acc = (int32_t *)carve(4 * 2 * nnz + 4);
+    A.tpc_stat = (double *)carve(8 * nnz + 8);
+    A.tpc_p = (double *)carve(8 * nnz + 8);
+    A.pc_stat = (double *)carve(8 * nnz + 8);
+    A.pc_p = (double *)carve(8 * nnz + 8);
+    A.nb_off = c->d_nb_off;
+    A.nb_idx = c->d_nb_idx;
+    A.nb_stat = c->d_nb_stat;
+    A.nb_p = c->d_nb_p;
+    MiQueue *d_mq = (MiQueue *)carve(sizeof(MiQueue) * (size_t)nrounds);
+    MiBoard *d_boards = (MiBoard *)carve(sizeof(MiBoard) * MI_BOARD_CAP);
+    FwSegOut *d_mres = (FwSegOut *)carve(sizeof(FwSegOut) * (size_t)MI_REC_CAP);
+    int32_t *d_bacc = (int32_t *)carve(sizeof(int32_t) * (size_t)MI_BACC_CAP);
+    FW_HIP(c, hipMemcpyAsync(d_sched, sched, 4 * (size_t)nt, hipMemcpyHostToDevice, st));
+    FW_HIP(c, hipMemcpyAsync(d_order, order.data(), 4 * (size_t)nt, hipMemcpyHostToDevice, st));
+    FW_HIP(c, hipMemcpyAsync(d_round_of, round_of.data(), 4 * (size_t)p, hipMemcpyHostToDevice, st));
+    FW_HIP(c, hipMemsetAsync(d_wl_cnt, 0, 4 * (size_t)p, st));
+    FW_HIP(c, hipMemsetAsync(d_mq, 0, sizeof(MiQueue) * (size_t)nrounds, st));
+    hipLaunchKernelGGL(dh_mi_init_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, d_tg, nt, (const int32_t *)d_sched, c->d_nb_off,
+                       (const int32_t *)c->d_levels);
+    const DhParams P = dh_make_params(c, R, 0, 0);
+    struct Ev2 {
+        hipStream_t st;
+        hipEvent_t e[2] = {nullptr, nullptr};
+        bool ok;
+        explicit Ev2(hipStream_t s) : st(s) { ok = hipEventCreate(&e[0]) == hipSuccess && hipEventCreate(&e[1]) == hipSuccess; }
+        ~Ev2()
+        {
+            (void)hipStreamSynchronize(st);
+            for (hipEvent_t &q : e)
+                if (q) (void)hipEventDestroy(q);
+        }
+    } ev(st);
+    if (!ev.ok) return fw_fail(c, FW_ERR_DEVICE, "device schedule: hipEventCreate failed");
+    const double th1 = wall();
+    FW_HIP(c, hipEventRecord(ev.e[0], st));
+    std::vector<unsigned> grids((size_t)nrounds, 0u);
+    for (int r = 0; r < nrounds; ++r) {
+        const int r0 = r * R, ntg = std::min(nt, r0 + R) - r0;
+        FW_HIP(c, hipMemsetAsync(d_boards, 0, sizeof(MiBoard) * MI_BOARD_CAP, st));  // ready flags, claimed / finished counts
+        grids[r] = dh_mi_launch(c, st, d_tg + r0, ntg, (const int32_t *)(d_order + r0), A, P, team[r], trace_host, d_mq + r, d_boards, d_mres, d_bacc);
+        if (feed_forward && r + 1 < nrounds)
+            hipLaunchKernelGGL(dh_wl_append_kernel, dim3((unsigned)((ntg + 3) / 4)), dim3(256), 0, st, (const DhTgt *)(d_tg + r0), ntg,
+                               (const int32_t *)A.pc_key, (const int32_t *)d_round_of, r, d_wl, c->d_nb_off, d_wl_cnt);
+    }
+    FW_HIP(c, hipGetLastError());
+    FW_HIP(c, hipEventRecord(ev.e[1], st));
+    // ---- results: one download ----
+    std::vector<DhTgt> tg((size_t)nt);
+    std::vector<MiQueue> hq((size_t)nrounds);
+    std::vector<int32_t> pk(nnz ? nnz : 1);
+    std::vector<double> ps(nnz ? nnz : 1), pp(nnz ? nnz : 1);
+    FW_HIP(c, hipMemcpyAsync(hq.data(), d_mq, sizeof(MiQueue) * (size_t)nrounds, hipMemcpyDeviceToHost, st));
+    FW_HIP(c, hipMemcpyAsync(tg.data(), d_tg, sizeof(DhTgt) * (size_t)nt, hipMemcpyDeviceToHost, st));
+    if (nnz) {
+        FW_HIP(c, hipMemcpyAsync(pk.data(), A.pc_key, 4 * nnz, hipMemcpyDeviceToHost, st));
+        FW_HIP(c, hipMemcpyAsync(ps.data(), A.pc_stat, 8 * nnz, hipMemcpyDeviceToHost, st));
+        FW_HIP(c, hipMemcpyAsync(pp.data(), A.pc_p, 8 * nnz, hipMemcpyDeviceToHost, st));
+    }
+    FW_HIP(c, hipStreamSynchronize(st));
+    const double th2 = wall();
+    for (int r = 0; r < nrounds; ++r) {
+        if (hq[r].pad[0])
+            return fw_fail(c, FW_ERR_DEVICE, "discrete HITON kernel, round %d: watchdog %u (boards %u, targets done %u)", r, hq[r].pad[0], hq[r].n_boards, hq[r].targets_done);
+        if (trace_host) dh_mi_trace(hq[r], grids[r]);
+    }
+    float ms = 0.0f;
+    FW_HIP(c, hipEventElapsedTime(&ms, ev.e[0], ev.e[1]));
+    size_t nres = 0;
+    for (const DhTgt &x : tg) {
+        if (x.phase != 2) return fw_fail(c, FW_ERR_DEVICE, "device schedule: target %d did not finish (phase %d)", x.T, x.phase);
+        nres += (size_t)x.npc;
+    }
+    all_t.reserve(all_t.size() + nres);
+    all_u.reserve(all_u.size() + nres);
+    all_s.reserve(all_s.size() + nres);
+    all_p.reserve(all_p.size() + nres);
+    for (const DhTgt &x : tg) {
+        for (int i = 0; i < x.npc; ++i) {
+            all_t.push_back(x.T);
+            all_u.push_back(pk[(size_t)x.co + i]);
+            all_s.push_back(ps[(size_t)x.co + i]);
+            all_p.push_back(pp[(size_t)x.co + i]);
+        }
+        c->cnt.cond_tests_ref += (int64_t)x.c_ref;
+        c->cnt.subsets_calls += (int64_t)x.c_calls;
+        c->cnt.cond_tests_evaluated += (int64_t)x.c_eval;
+        c->cnt.alg_bytes_subsets += x.c_alg;
+    }
+    c->cnt.t_dev_subsets_s += 1e-3 * (double)ms;
+    c->cnt.subsets_launches += nrounds;
+    c->cnt.kernel_launches += 2 * nrounds + 1;
+    if (trace_host)
+        fprintf(stderr, "[fw] device schedule: %d targets in %d rounds, set-up %.2f ms, launches + download %.2f ms (kernels %.2f ms), results %.2f ms\n", nt, nrounds,
+                1e3 * (th1 - th0), 1e3 * (th2 - th1), (double)ms, 1e3 * (wall() - th2));
     return FW_OK;
 }

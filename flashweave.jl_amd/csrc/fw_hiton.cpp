@@ -189,6 +189,20 @@ int devx_allgather(void *user, int64_t n, const int32_t *tgt, const int32_t *nbr
 }
 }  // namespace
 
+// fwi_devhiton_mi_schedule serves: FW_MI / FW_MI_NZ on bit planes, one rank, no exchange callback, level-0 lists and candidate order on
+// the device, rounds the persistent kernel is worth launching for (the reference's single_il rounds of one target stay on the host pool).
+// FW_MI_SCHED=0 keeps the per-round loop (A/B runs, tests/test_gpu_mi.py compares the two).
+static bool mi_schedule_on_device(const fw_ctx *c, const fw_learn_opts &opt, bool has_exchange, int nt)
+{
+    if (!(c->P.kind == FW_MI || c->P.kind == FW_MI_NZ) || c->mi_generic || has_exchange || opt.world_size > 1) return false;
+    if (!c->d_cand || !c->d_nb_idx || !c->d_nb_off) return false;
+    const char *hh = fw_knob("FW_HOST_HITON"), *mr = fw_knob("FW_MI_ROUNDS"), *sc = fw_knob("FW_MI_SCHED"), *mt = fw_knob("FW_DEV_MIN_TARGETS");
+    if ((hh && atoi(hh) == 1) || (mr && atoi(mr) != 0) || (sc && atoi(sc) == 0)) return false;
+    const int R = (opt.round_size <= 0 || opt.round_size > nt) ? nt : opt.round_size;
+    const int min_targets = mt ? atoi(mt) : 256;
+    return R >= min_targets;
+}
+
 extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allgather_fn allgather, void *user, int64_t *n_edges_out);
 
 extern "C" int fw_learn_network_dev(fw_ctx *c, const fw_learn_opts *opts_in, const fw_dev_exchange *x, int64_t *n_edges_out)
@@ -261,6 +275,11 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                 all_p.push_back(c->nb_p[o + q]);
             }
         }
+    } else if (mi_schedule_on_device(c, opt, allgather != nullptr, nt)) {
+        // discrete kinds, one GPU, rounds of a few hundred targets or more: the whole schedule stays on the device (whitelists built
+        // between the launches, one download at the end) -- same kernel, order and team sizes per round as the loop below
+        const int R = (opt.round_size <= 0) ? nt : opt.round_size;
+        if (int rc = fwi_devhiton_mi_schedule(c, order.data(), nt, R, opt.feed_forward != 0, all_t, all_u, all_s, all_p)) return rc;
     } else {
         const int R = (opt.round_size <= 0) ? nt : opt.round_size;
         for (int r0 = 0, r1 = 0; r0 < nt; r0 = r1) {

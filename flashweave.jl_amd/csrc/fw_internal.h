@@ -322,6 +322,9 @@ struct FwDhFlat {  // (one allocation per run instead of three per target: 150 0
     std::vector<double> stat, pval;
 };
 int fwi_devhiton_run(fw_ctx *ctx, const std::vector<FwDhTarget> &in, std::vector<FwDhResult> &out, FwDhFlat &flat, int chain = 0);
+// the whole feed-forward schedule of the discrete kinds on the device: whitelists built between the launches, one download (r05)
+int fwi_devhiton_mi_schedule(fw_ctx *ctx, const int32_t *sched, int nt, int R, bool feed_forward, std::vector<int32_t> &all_t,
+                             std::vector<int32_t> &all_u, std::vector<double> &all_s, std::vector<double> &all_p);
 int fwi_mi_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, const unsigned *d_ns,
                         hipStream_t stream);
 int fwi_fz_thresholds(fw_ctx *ctx, hipStream_t stream, double *zscale);  // ensures ctx->d_thr (fz_thresholds_kernel)

@@ -353,6 +353,35 @@ def test_device_rounds_equal_host_driver_and_oracle(ctx, ff, R, monkeypatch):
     assert cd["cond_tests_ref"] == exp["n_cond_tests"]
 
 
+@pytest.mark.parametrize("R", [64, 100, 257])
+def test_whole_schedule_on_the_device_equals_the_per_round_loop_and_oracle(ctx, R, monkeypatch):
+    """r05: the discrete kinds' whole feed-forward schedule on the device (fwi_devhiton_mi_schedule: per-target state built from the
+    level-0 CSR, whitelists appended between the launches by dh_wl_append_kernel, one download) against the per-round loop with the
+    host in between (FW_MI_SCHED=0: whitelists from the host's running graph, interleaved.jl:124-183) and the oracle: directed lists,
+    weights, p-values, reference-order test count; the whitelists must really be in play (NaN weights = joined without a test)."""
+    kind, data, n, p, orc = ctx["kind"], ctx["data"], ctx["n"], ctx["p"], ctx["orc"]
+    monkeypatch.setenv("FW_DEV_MIN_TARGETS", "64")
+    res = {}
+    for sched in ("0", "1"):
+        monkeypatch.setenv("FW_MI_SCHED", sched)
+        eng = fw.Engine(kind, n, p, max_k=3)
+        eng.set_data(data)
+        res[sched] = (eng.lgl(feed_forward=True, round_size=R, edge_dict=False), eng.counters())
+        eng.close()
+    (n0, c0), (n1, c1) = res["0"], res["1"]
+    for key in ("edge_src", "edge_dst", "pc_off", "pc_idx"):
+        assert np.array_equal(n0[key], n1[key]), key
+    for key in ("edge_weight", "pc_weight", "pc_pval"):
+        assert np.array_equal(n0[key], n1[key], equal_nan=True), key   # same kernel, same order per round: to the bit
+    assert c0["cond_tests_ref"] == c1["cond_tests_ref"] and c0["subsets_calls"] == c1["subsets_calls"]
+    exp = orc.learn(max_k=3, feed_forward=True, round_size=R)
+    assert np.array_equal(n1["pc_off"], exp["pc_off"]) and np.array_equal(n1["pc_idx"], exp["pc_idx"])
+    assert np.allclose(n1["pc_weight"], exp["pc_weight"], rtol=1e-11, atol=1e-15, equal_nan=True)
+    assert c1["cond_tests_ref"] == exp["n_cond_tests"]
+    if R < p // 2:
+        assert int(np.isnan(exp["pc_weight"]).sum()) > 0
+
+
 @pytest.mark.parametrize("seq,win0,cmin", [(1, 2, 1), (2, 8, 2), (4, 64, 8)])
 def test_persistent_kernel_boards_equal_oracle(ctx, seq, win0, cmin, monkeypatch):
     """dh_mi_target_kernel with the board machinery forced on for nearly every job (the owner runs `seq` tests alone, then
