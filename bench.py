@@ -517,6 +517,23 @@ def main():
                                     "directed_entries": recorded,
                                     "note": "one GPU timing each rank's share in turn; all-gathers replayed from a recorded "
                                             "single-rank pass (same whitelists as among N real ranks), no exchange cost"}
+        # r05: the replay leaves the collectives out; what IS measured about them -- the library-side exchange with a world of one rank
+        # (profiles/r04_bench_cfg3_n1_library_rccl_world1.json: 74-82 us per round incl. the header all-gather and both stream
+        # synchronisations) and the xGMI ring rate of MI355X_MICROARCH.md for the payloads -- is added as a second figure, marked as a
+        # model: N > 1 ranks over RCCL have never run (no multi-GPU node).
+        n_rounds = max(1, len(sim["rounds"]))
+        W = args.simulate_world
+        per_round_s = 82e-6
+        ring_bw = 153e9  # one xGMI link, bytes/s: a ring all-gather moves (W - 1) / W of the gathered payload over it
+        payload = 24.0 * recorded  # per-round records of 24 bytes, summed over the rounds
+        l0_bytes = 24.0 * float(sum(l0sim["counts"] or [0])) if shard_l0 else 0.0  # the ranks' packed level-0 records (pass A of the replay)
+        xs = n_rounds * per_round_s + (W - 1) / W * (payload + l0_bytes) / ring_bw + (per_round_s if shard_l0 else 0.0)
+        worst["simulated_world"]["exchange_model"] = {
+            "rounds": n_rounds, "seconds_per_round_measured_world1": per_round_s, "payload_bytes": payload + l0_bytes,
+            "ring_link_bytes_per_s": ring_bw, "exchange_seconds_added": xs,
+            "ms_per_step_with_exchange": worst["ms_per_step"] + 1e3 * xs,
+            "note": "measured part: 82 us per exchange with a world of one rank on the library's communicator; modelled part: payload over one "
+                    "xGMI link at the ring rate.  UNMEASURED on more than one GPU."}
         # whole-job figures: every rank's tests, the slowest rank's time
         worst["cond_ref"] = sum(m["cond_ref"] for m in per) if args.simulate_rank < 0 else worst["cond_ref"]
         worst["cond_eval"] = sum(m["cond_eval"] for m in per) if args.simulate_rank < 0 else worst["cond_eval"]
@@ -565,7 +582,7 @@ def main():
         # counters of the same kernel on the same workload from separate rocprofv3 --pmc passes (they cannot be read from inside
         # this process): HBM-side traffic per launch, VALU instructions per test, VALU-busy share.  profiles/README.md
         pmc, pmc_src = None, None
-        for cand in ("r04_%s_pmc_summary.json" % args.config, "r03_%s_pmc_summary.json" % args.config, "r02_%s_pmc_summary.json" % args.config):
+        for cand in ("r05_%s_pmc_summary.json" % args.config, "r04_%s_pmc_summary.json" % args.config, "r03_%s_pmc_summary.json" % args.config, "r02_%s_pmc_summary.json" % args.config):
             pmc_path = os.path.join(ROOT, "profiles", cand)
             if not args.p and not args.n and os.path.exists(pmc_path):
                 js = json.load(open(pmc_path))
@@ -576,7 +593,10 @@ def main():
         traffic = pmc.get("fetch_bytes_per_launch") if pmc else None
         valu = None
         if pmc and "valu_wave_insts_per_test" in pmc:
-            wps = pmc.get("waves_per_simd", 4)
+            # resident wavefronts per SIMD the dominant kernel is compiled for (build remarks): the persistent discrete kernel runs ONE
+            # (r04 printed 4 x the VALU-busy share for it), the long-list max_k 4-5 segment kernel three, the size-3 one four
+            wps_built = 1 if kname == "dh_mi_target_kernel" else (3 if cfg["max_k"] > 3 else 4)
+            wps = wps_built if (kname == "dh_mi_target_kernel" or "valu_mix_wave_insts_per_test" in pmc) else pmc.get("waves_per_simd", wps_built)
             ipt = pmc["valu_wave_insts_per_test"]
             tps = rcn["cond_tests_evaluated"] / max(sub_launch_s, 1e-12)
             # issue roof: 256 CUs x 4 SIMDs, a 64-lane instruction holds a SIMD >= 2 cycles (32 lanes / clock for 32-bit ops, 16 for Float64)
@@ -587,6 +607,17 @@ def main():
                     "note": "busy_frac = SQ_ACTIVE_INST_VALU x waves per SIMD / SQ_WAVE_CYCLES from the tracked PMC pass: the share of "
                             "cycles in which the SIMD's vector ALU is executing; Float64 and transcendental instructions hold it 4-16 "
                             "cycles, so the issue fraction computed at the 32-bit rate understates it", "source": pmc_src}
+            mixd = pmc.get("valu_mix_wave_insts_per_test")
+            if mixd:
+                # roofline.valu_frac: the kernel's measured instruction mix (SQ_INSTS_VALU_* per evaluated test) priced at the issue
+                # cost of each class measured on this device (profiles/r04_valu_rate.txt, cycles per wave64 instruction and SIMD at
+                # the nominal 2.4 GHz) -> cycles a test needs if nothing but VALU issue limited it -> tests/s at that bound
+                CYC = {"f64_add": 5.1, "f64_mul": 5.2, "f64_fma": 5.3, "f64_trans": 17.3, "f32_add": 3.0, "f32_mul": 3.0, "f32_fma": 3.0,
+                       "f32_trans": 9.0, "int32": 3.0, "int64": 6.0, "cvt": 3.0, "other": 3.0}
+                cyc = sum(mixd.get(k, 0.0) * c for k, c in CYC.items())
+                bound_tps = 256 * 4 * 2.4e9 / max(cyc, 1e-9)
+                valu.update({"mix_wave_insts_per_test": mixd, "issue_cycles_per_test_and_simd": cyc, "issue_bound_tests_per_s": bound_tps,
+                             "valu_frac": tps / bound_tps, "cycle_costs_source": "profiles/r04_valu_rate.txt (tools/valu_rate.cpp)"})
         # what the counters of the tracked PMC pass name as the limiter.  Fabric traffic well below the algorithmic bytes means the
         # operands are cache-resident and HBM is NOT the bound: then "valu" when the vector ALUs are busy >= 60 % of the cycles,
         # else "latency" (dependent chains / issue of a few resident wavefronts: the discrete persistent kernel).  "hbm" only when
@@ -596,7 +627,7 @@ def main():
         roofline = {"bound": bound, "kernel": kname,
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": (pmc_src + " (FETCH_SIZE + WRITE_SIZE per launch)") if traffic else None,
-                    "valu": valu, "measured_on": rsrc,
+                    "valu": valu, "valu_frac": valu.get("valu_frac") if valu else None, "measured_on": rsrc,
                     "note": "achieved / peak / frac: nominal HBM roofline with the algorithmic bytes of SURVEY 8d (fz: 4*C(k+2,2)+32 B per "
                             "test, discrete: (k+2)*n*b/8+32 B) over the HIP-event time of the kernel's launches (device rounds: one launch "
                             "in four, rotating slot, scaled to all launches).  bound = the resource the counters name: with `valu`, the "

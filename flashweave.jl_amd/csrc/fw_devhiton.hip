@@ -57,9 +57,9 @@ struct DhGlobal {
     unsigned int pad_b, max_ab;     // max_ab: largest (accepted + whitelisted neighbours still to come) of any target so far: what a
                                     // list can reach without tested acceptances
     unsigned int ns_ring[64];  // segments of the last 64 planned launches (the host reads the record once per batch)
-    // words that workgroups on different XCDs touch WHILE workgroup 0 writes the record above (dh_coop_kernel): a cache line each
+    // words that many workgroups touch: a cache line each
     unsigned int pad_l0[32];
-    unsigned int step_ticket;  // cooperative round: workgroups that have passed their step phase (monotonic over the run)
+    unsigned int step_ticket;  // (unused: the r05 cooperative round's barrier word)
     unsigned int pad_l1[31];
     unsigned int any_big;      // the coming launch holds a segment with |accepted| > FW_TAB_A (set by the fill): the in-lane variant
                                // of the fz segment kernel leaves at once when it does not
@@ -310,7 +310,7 @@ __device__ __forceinline__ DhMerge dh_merge(const FwSegOut *__restrict__ so, lon
     unsigned long long ev = 0ull;
     int my_stop = 0x7fffffff;  // smallest segment index of this lane that reports a stop
     double st_stat = 0.0, st_p = 0.0;
-    int st_pow = 0;
+    int st_pow = 0, st_df = 0;
     unsigned long long st_rank = 0ull;
     double bp = -2.0, bs = 0.0;  // lane best over its segments (increasing index, `>=`)
     int bi = -1;
@@ -324,6 +324,7 @@ __device__ __forceinline__ DhMerge dh_merge(const FwSegOut *__restrict__ so, lon
                 st_p = o.stop_pval;
                 st_pow = o.stop_power;
                 st_rank = o.stop_rank;
+                st_df = o.stop_df;
             }
         } else if (o.best_pval >= bp) {
             bp = o.best_pval;
@@ -354,6 +355,8 @@ __device__ __forceinline__ DhMerge dh_merge(const FwSegOut *__restrict__ so, lon
         M.p = __shfl(st_p, owner);
         M.pow = __shfl(st_pow, owner);
         M.nt = __shfl(st_rank, owner) + 1ull;
+        // fz_nz: too few rows with T != 0 and candidate != 0 -> (0, 1, 0, false) with ZERO tests (tests.jl:294-296; marker of fz_seg_body)
+        if (__shfl(st_df, owner) == -2) M.nt = 0ull;
     } else {
         M.stop = false;
         M.stat = bs;
@@ -814,6 +817,20 @@ struct MiAhead {
 };
 __shared__ MiAhead dh_mi_ahead[4];
 
+// candidates cands[0 .. nb) that can share ONE mi_test_core4 step with the first of them: the uniform decisions of the test core read
+// levels / maxv > 1 of Y, so only candidates that agree with cands[0] on both ride along (uniform: every lane computes the same count)
+__device__ __forceinline__ int mi_first_run(const MiDev &M, const int32_t *__restrict__ cands, int nb)
+{
+    const int c0 = cands[0];
+    int n = 1;
+    for (int t = 1; t < nb; ++t) {
+        const int ct = cands[t];
+        if (M.levels[ct] != M.levels[c0] || (M.maxv[ct] > 1) != (M.maxv[c0] > 1)) break;
+        ++n;
+    }
+    return n;
+}
+
 template <int L>
 __device__ __noinline__ void mi_first4(int T, int pos0, const int32_t *__restrict__ cands_in, int nb, const int32_t *__restrict__ acc_in,
                                        int a, int max_k, long long max_tests)
@@ -835,14 +852,8 @@ __device__ __noinline__ void mi_first4(int T, int pos0, const int32_t *__restric
     zrow[0] = acc[0];
     zrow[1] = acc[s >= 2 ? 1 : 0];
     zrow[2] = acc[s >= 3 ? 2 : 0];
-    // the uniform decisions of the test core read levels / maxv > 1 of Y: only candidates that agree with the first one share a step
     const int c0 = cands[0];
-    int n = 1;
-    for (int t = 1; t < nb; ++t) {
-        const int ct = cands[t];
-        if (M.levels[ct] != M.levels[c0] || (M.maxv[ct] > 1) != (M.maxv[c0] > 1)) break;
-        ++n;
-    }
+    const int n = mi_first_run(M, cands, nb);
     const int my_c = cands[row < n ? row : 0];
     MiRes mine = mi_test_core4<L>(M, T, c0, zrow, s, tab, my_c);
     for (int t = 0; t < n; ++t) {
@@ -1180,6 +1191,75 @@ __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, 
         double r_stat = 0.0, r_p = 0.0, best_p = -1.0, best_stat = 0.0, best_g = 0.0;
         int r_pow = 1, best_df = 0;
         unsigned int n_rounds = 0u;
+        if constexpr (R4) {
+            // First tests of up to SIXTEEN candidates in one round (r05; the one-wavefront form of this is mi_first4 in the kernel below).
+            // A heavy target of cfg2 is a chain of ~400 jobs of which ~390 end with their first test: while candidates are rejected the
+            // accepted list does not change, so the first test of the next candidates -- (T, c | the first subset of the same list) --
+            // does not depend on the earlier verdicts.  The four wavefronts take consecutive slices of the candidate list (a slice: up to
+            // four candidates that can share a mi_test_core4 step, cut in front of a whitelisted one: it joins without a test and changes
+            // the list), the results stay in the wavefronts' MiAhead slots and are consumed in candidate order while (target, accepted
+            // length) still match; an accepted candidate invalidates the rest.  r04: every job of a team target started with a
+            // lock-step round of 16 ranks of ITS OWN enumeration, 15 of them behind the stop (cfg2: 946 000 executed tests for 287 000).
+            if (P.mi_ahead && x.phase == 0 && a >= 1 && N >= 1ull) {
+                const int32_t *cands = A.cand0 + x.cand_off;
+                int hw = -1;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const MiAhead &Hq = dh_mi_ahead[w];
+                    if (Hq.n > 0 && Hq.T == T && Hq.na == a && x.pos >= Hq.pos0 && x.pos < Hq.pos0 + Hq.n) hw = w;
+                }
+                unsigned long long computed = 0ull;
+                if (hw < 0 && x.nc - x.pos >= 2) {  // (uniform: every wavefront reads the same LDS words)
+                    const MiDev Mu = mi_uniform(dh_mi_ctx.M);
+                    int start = x.pos, my_start = x.pos, my_n = 0;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const int nb = x.nc - start < 4 ? x.nc - start : 4;
+                        if (nb <= 0) break;
+                        int n = mi_first_run(Mu, cands + start, nb);  // (a cut by the levels only ends the slice: the next wavefront goes on)
+                        bool wl_cut = false;
+                        if (x.wl_n > 0)  // a whitelisted candidate ends the chain of first tests (the candidate at x.pos itself is not one: dh_advance)
+                            for (int q = (start == x.pos ? 1 : 0); q < n; ++q)
+                                if (dh_in_wl(x, A, cands[start + q])) {
+                                    n = q;
+                                    wl_cut = true;
+                                    break;
+                                }
+                        if (w == wave) {
+                            my_start = start;
+                            my_n = n;
+                        }
+                        start += n;
+                        if (wl_cut) break;
+                    }
+                    computed = (unsigned long long)(start - x.pos);
+                    if (my_n > 0)
+                        mi_first4<L>(T, my_start, cands + my_start, my_n, acc, a, P.max_k, P.max_tests);
+                    else if (lane == 0)
+                        dh_mi_ahead[wave].n = 0;
+                    __syncthreads();
+                    hw = 0;  // (wavefront 0's slice starts at x.pos and holds at least that candidate)
+                }
+                if (hw >= 0) {
+                    const MiAhead &Hq = dh_mi_ahead[hw];
+                    const int t = x.pos - Hq.pos0;
+                    ev += computed;
+                    if (Hq.stop[t]) {
+                        stopped = true;
+                        r_stat = Hq.stat[t];
+                        r_p = Hq.pval[t];
+                        r_pow = Hq.power[t];
+                        nt = 1ull;
+                    } else {  // significant: the job goes on at rank 1, seeded with its first test
+                        best_p = Hq.pval[t];
+                        best_stat = Hq.stat[t];
+                        best_g = Hq.g[t];
+                        best_df = Hq.df[t];
+                        next = 1ull;
+                    }
+                }
+            }
+        }
         for (unsigned int step = 0u; !stopped && next < N && step < P.mi_team_steps; ++step) {
             ++n_rounds;
             const unsigned long long r0 = next + (unsigned long long)wave * per;
@@ -1888,7 +1968,7 @@ struct DhPlanArgs {
     ulonglong2 *log;
     unsigned long long seg_a, seg_b;
 };
-// NT = threads of the one workgroup that plans: 1024 as a kernel of its own (dh_plan_kernel), 256 as the tail of the fused round
+// NT = threads of the one workgroup that plans (1024: dh_plan_kernel)
 // (the last workgroup of dh_step_kernel)
 template <int NT>
 __device__ __forceinline__ void dh_plan_dev(int ntg, DhGlobal *__restrict__ g, const unsigned long long *__restrict__ win,
@@ -2042,7 +2122,7 @@ __device__ __forceinline__ void dh_fill_one(const unsigned int s, const DhTgt *_
     sg.acc_off = DH_ACC_OFF(x, x.phase == 1 ? (x.cur + (int)slot) % d1 : x.cur, d1);
     sg.acc_len = x.na + (acc_mode ? 1 : 0);
     if (sg.acc_len > FW_TAB_A) g->any_big = 1u;  // same value from every writer
-    sg.pad = 0;
+    sg.pad = act[(size_t)g->act_sel * ntg + lo - 1];  // fz_nz: the job's record slot = the target's index in the run (dh_nz_recs_kernel)
     const unsigned long long lo_r = acc_mode ? 0ull : x.jnext;
     sg.start = lo_r + k * seglen;
     const unsigned long long hi_r = lo_r + (slot > 0u ? x.jwin2 : x.jwin);
@@ -2058,169 +2138,9 @@ __global__ __launch_bounds__(256) void dh_fill_kernel(const DhTgt *__restrict__ 
     dh_fill_one(s, tg, ntg, g, seg0, A, segs, d1, act);
 }
 
-// The cooperative round (r05): step, plan and fill in ONE launch of a small resident grid, with no single-workgroup phase.
-// r04 built "the last workgroup to finish plans and fills" and it lost (one 256-thread workgroup behind two device-wide fences plans
-// slower than a 1 024-thread launch, and fills a few thousand records in 25 us where a grid takes 6; profiles/r04_fused_round.json).
-// Here every workgroup steps its share of the unfinished targets (one wavefront per target, grid-strided), the grid meets at ONE
-// device-memory barrier (one ticket per workgroup), and then EVERY workgroup plans redundantly: the plan is an exclusive scan over a
-// few hundred per-target windows -- 20 bytes per target out of L2, a few microseconds -- and computing it 64-256 times costs less than
-// handing one workgroup's result to the others through a second barrier.  Each workgroup then fills its grid-strided share of the
-// segment records from its own LDS copy of the scan; workgroup 0 writes the launch record and seg0 for the next step.  Per round:
-// two launches (segment kernel, this one) instead of four, ~17 us less dependent latency.  The grid is fixed
-// for the whole run (G <= 256 workgroups of 256 threads: always co-resident, also next to a second chain's grid), the barrier
-// counts tickets monotonically (target = launches so far x G).  Used while the list holds at most DH_COOP_MAX targets; longer lists
-// and the compaction rounds keep the three launches.
-#define DH_COOP_MAX 2048
-#define DH_COOP_PER (DH_COOP_MAX / 256)
-__global__ __launch_bounds__(256) void dh_coop_kernel(DhTgt *__restrict__ tg, int ntg, DhGlobal *__restrict__ g, DhArrays A,
-                                                      const FwSegOut *__restrict__ so, long long *__restrict__ seg0,
-                                                      unsigned long long *__restrict__ win, unsigned int *__restrict__ sp,
-                                                      unsigned long long *__restrict__ win2, const int32_t *__restrict__ act_all, DhParams P,
-                                                      DhPlanArgs PA, FwSeg *__restrict__ segs, int d1, unsigned int ticket_target)
-{
-    __shared__ unsigned int s_seg0[DH_COOP_MAX + 1];
-    __shared__ unsigned long long s_tot[4];
-    __shared__ unsigned int s_live[4], s_wsum[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int na = (int)g->n_act;  // (written by the compaction kernel only: stable during this launch)
-    const int32_t *act = act_all + (size_t)g->act_sel * ntg;
-    // ---- step ----
-    for (int ci = (int)blockIdx.x * 4 + wave; ci < na; ci += (int)gridDim.x * 4)
-        dh_step_dev(tg, ntg, g, A, so, seg0, win, sp, win2, act_all, P, ci);
-    if (blockIdx.x == 0 && tid == 0) atomicExch(&g->any_big, 0u);  // (the fill behind the barrier raises it)
-    // ---- barrier: every target's state, window and pools are in memory before anybody plans ----
-    // One wavefront per workgroup pays for the cache maintenance: the L2 write-back of a release and the invalidation of an acquire act
-    // on the whole cache, not on the issuing wavefront's lines, so once the workgroup's stores have left the CU (vmcnt(0) in front of
-    // the workgroup barrier) thread 0's fences cover them, and its invalidation covers the CU's L1 for the four wavefronts (first
-    // version: every wavefront fenced on both sides -- 2 048 cache-wide operations per round, 18 us slower than three launches).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        __threadfence();
-        atomicAdd(&g->step_ticket, 1u);
-        while (__hip_atomic_load(&g->step_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ticket_target) __builtin_amdgcn_s_sleep(1);
-        __threadfence();
-    }
-    __syncthreads();
-    // ---- plan (every workgroup, same integers) ----
-    const int per = (na + 255) / 256;  // <= DH_COOP_PER
-    const int b = tid * per, e = (b + per) < na ? (b + per) : na;
-    unsigned long long wr[DH_COOP_PER], w2r[DH_COOP_PER];
-    unsigned int mr[DH_COOP_PER];
-    unsigned long long tot = 0ull;
-    unsigned int live = 0u;
-#pragma unroll
-    for (int q = 0; q < DH_COOP_PER; ++q) {
-        const bool in = b + q < e;
-        const int tq = in ? act[b + q] : 0;
-        wr[q] = in ? __hip_atomic_load(&win[tq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        mr[q] = in ? __hip_atomic_load(&sp[tq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        w2r[q] = (in && mr[q] > 0u) ? __hip_atomic_load(&win2[tq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-    }
-#pragma unroll
-    for (int q = 0; q < DH_COOP_PER; ++q) {
-        tot += wr[q] + w2r[q] * mr[q];
-        live += wr[q] != 0ull ? 1u + mr[q] : 0u;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        tot += __shfl_xor(tot, o);
-        live += __shfl_xor(live, o);
-    }
-    if (lane == 0) {
-        s_tot[wave] = tot;
-        s_live[wave] = live;
-    }
-    __syncthreads();
-    const unsigned long long total = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
-    const unsigned int n_live = s_live[0] + s_live[1] + s_live[2] + s_live[3];
-    const unsigned int tgt = total < PA.seg_a ? (PA.seg_target + 2u) / 3u : (total < PA.seg_b ? (2u * PA.seg_target + 2u) / 3u : PA.seg_target);
-    unsigned long long seglen = (total / tgt + PA.seg_q - 1ull) / PA.seg_q * PA.seg_q;
-    seglen = seglen < PA.seg_min ? PA.seg_min : seglen;
-    const double inv = 1.0 / (double)seglen;
-    unsigned int local = 0u, nr[DH_COOP_PER];
-#pragma unroll
-    for (int q = 0; q < DH_COOP_PER; ++q) {
-        nr[q] = dh_ceil_div(wr[q], seglen, inv) + dh_ceil_div(w2r[q], seglen, inv) * mr[q];
-        local += nr[q];
-    }
-    unsigned int incl = local;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned int v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
-    }
-    if (lane == 63) s_wsum[wave] = incl;
-    __syncthreads();
-    unsigned int wbase = 0u, ns = 0u;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        if (w < wave) wbase += s_wsum[w];
-        ns += s_wsum[w];
-    }
-    unsigned int run = wbase + incl - local;
-#pragma unroll
-    for (int q = 0; q < DH_COOP_PER; ++q)
-        if (b + q < e) {
-            s_seg0[b + q] = run;
-            run += nr[q];
-        }
-    if (tid == 0) s_seg0[na] = ns;
-    __syncthreads();
-    if (blockIdx.x == 0) {  // the launch record and the scan the next step reads
-        for (int i = tid; i <= na; i += 256) seg0[i] = (long long)s_seg0[i];
-        if (tid == 0) {
-            g->ns = ns;
-            g->seglen = (unsigned int)seglen;
-            g->launched_ranks = total;
-            g->n_live_prev = n_live;
-            if (n_live == 0u) g->done = 1u;
-            const unsigned int r = g->rounds;
-            g->ns_ring[r & 63u] = ns;
-            g->rounds = r + 1u;
-            if (PA.log && r < PA.log_cap) PA.log[r] = make_ulonglong2(total, ((unsigned long long)n_live << 32) | ns);  // FW_DH_LOG
-        }
-    }
-    // ---- fill: segment record s of the coming launch, grid-strided (dh_fill_one on the workgroup's own scan) ----
-    bool big = false;
-    for (unsigned int s = blockIdx.x * 256u + (unsigned int)tid; s < ns; s += gridDim.x * 256u) {
-        int lo = 0, hi = na;  // first list position with seg0 > s; the job owning slot s is the one before it
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (s_seg0[mid] <= s)
-                lo = mid + 1;
-            else
-                hi = mid;
-        }
-        const DhTgt &x = tg[act[lo - 1]];
-        unsigned long long k = (unsigned long long)(s - s_seg0[lo - 1]);
-        const int32_t *cands = x.phase == 0 ? A.cand0 + x.cand_off : A.tpc_key + x.co;
-        unsigned int slot = 0;
-        if (x.nsp > 0) {
-            const unsigned int all = s_seg0[lo] - s_seg0[lo - 1];
-            const unsigned int n0 = x.spmode == 1 ? dh_ceil_div(x.jwin, seglen, inv) : all / (1u + (unsigned int)x.nsp);
-            if ((unsigned int)k >= n0) {
-                const unsigned int pr = (all - n0) / (unsigned int)x.nsp;
-                slot = 1u + ((unsigned int)k - n0) / pr;
-                k -= (unsigned long long)n0 + (unsigned long long)(slot - 1u) * pr;
-            }
-        }
-        const bool acc_mode = slot > 0u && x.spmode == 1;
-        FwSeg sg;
-        sg.X = x.T;
-        sg.Y = cands[x.pos + (int)slot];
-        sg.acc_off = DH_ACC_OFF(x, x.phase == 1 ? (x.cur + (int)slot) % d1 : x.cur, d1);
-        sg.acc_len = x.na + (acc_mode ? 1 : 0);
-        big = big || sg.acc_len > FW_TAB_A;
-        sg.pad = 0;
-        const unsigned long long lo_r = acc_mode ? 0ull : x.jnext;
-        sg.start = lo_r + k * seglen;
-        const unsigned long long hi_r = lo_r + (slot > 0u ? x.jwin2 : x.jwin);
-        sg.end = sg.start + seglen < hi_r ? sg.start + seglen : hi_r;
-        segs[s] = sg;
-    }
-    if (big) atomicOr(&g->any_big, 1u);
-}
+// (r04 fused step + plan (+ fill) into the last workgroup to finish, r05 into a cooperative grid with one device-memory barrier and a
+// redundant plan in every workgroup: both bit-identical, neither faster -- the barrier and the second plan cost what the saved
+// launches cost, ~5 us of idle time per device-wide dependency either way.  profiles/r04_fused_round.json, profiles/r05_coop_round.json.)
 
 // One workgroup, once per batch of rounds (between dh_step_kernel and dh_plan_kernel): drops the finished targets from
 // the list the three kernels above walk.  Most targets finish early (cfg3: 10 000 targets, a few hundred alive for
@@ -2268,6 +2188,33 @@ __global__ __launch_bounds__(1024) void dh_compact_kernel(const DhTgt *__restric
     }
 }
 
+// fz_nz on the device rounds (r05): the per-job records of the sub-matrix kernel (fznz_submat_kernel: correlations over the rows where
+// T and the candidate are both non-zero, statfuns.jl:138-155), one slot per target.  A job that enters its FIRST window gets a fresh
+// record -- variables, list, the target's own arena slice ((candidates + 2)^2 floats: a list never outgrows the candidate list) -- and
+// its matrix is computed in this round; a job in a later window keeps record and matrix (bit 0 of pad: nothing to compute), as does
+// a target without a job.  (The host pool recomputes the matrix for every window of a job.)
+__global__ __launch_bounds__(256) void dh_nz_recs_kernel(const DhTgt *__restrict__ tg, int ntg, const DhGlobal *__restrict__ g,
+                                                         const int32_t *__restrict__ act, const DhArrays A, FwNzJob *__restrict__ recs,
+                                                         const long long *__restrict__ arena_off)
+{
+    const int ci = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (ci >= (int)g->n_act) return;
+    const int t = act[(size_t)g->act_sel * ntg + ci];
+    const DhTgt &x = tg[t];
+    FwNzJob *r = recs + t;
+    if (x.jactive && x.jwin > 0ull && x.jnext == 0ull) {
+        r->X = x.T;
+        r->Y = (x.phase == 0 ? A.cand0 + x.cand_off : A.tpc_key + x.co)[x.pos];
+        r->acc_off = DH_ACC_OFF(x, x.cur, 1);
+        r->acc_len = x.na;
+        r->m = x.na + 2;
+        r->cor_off = arena_off[t];
+        r->pad = 0;
+    } else {
+        r->pad = 1;
+    }
+}
+
 // ---- the whole feed-forward schedule of the discrete kinds on the device (fwi_devhiton_mi_schedule) ------------------------------
 // per-target state of EVERY target of the schedule, built on the device from the level-0 CSR: a target's arrays (candidates in
 // hiton.jl:211-217 order, TPC / PC, accepted list, whitelist) all sit at its level-0 offset nb_off[T] with its degree as capacity
@@ -2304,6 +2251,38 @@ __global__ __launch_bounds__(256) void dh_wl_append_kernel(const DhTgt *__restri
     for (int i = lane; i < npc; i += 64) {
         const int32_t u = pc_key[co + i];
         if (round_of[u] > round) wl[nb_off[u] + (long long)atomicAdd(&wl_cnt[u], 1u)] = T;
+    }
+}
+
+// results of the whole schedule, packed for ONE small download: every target's PC entries (target, neighbour, statistic, p) as a block
+// of consecutive records in insertion order -- the blocks land where an atomic ticket puts them: the host's CSR over targets
+// (fw_hiton.cpp: a stable counting sort by target) does not depend on the order of the blocks -- and the per-target counters summed
+// (integers and multiples of 1/8: every order gives the same sums).  tot[0] entries, [1] tests in reference order, [2] jobs,
+// [3] executed tests, [4] unfinished targets (must stay 0); alg: algorithmic bytes
+__global__ __launch_bounds__(256) void dh_mi_pack_kernel(const DhTgt *__restrict__ tg, int nt, const int32_t *__restrict__ pc_key,
+                                                         const double *__restrict__ pc_stat, const double *__restrict__ pc_p,
+                                                         int32_t *__restrict__ o_t, int32_t *__restrict__ o_u, double *__restrict__ o_s,
+                                                         double *__restrict__ o_p, unsigned long long *__restrict__ tot, double *__restrict__ alg)
+{
+    const int t = (int)(blockIdx.x * 4u + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    if (t >= nt) return;
+    const DhTgt &x = tg[t];
+    const int npc = x.npc;
+    unsigned long long base = 0ull;
+    if (lane == 0) {
+        if (npc > 0) base = atomicAdd(&tot[0], (unsigned long long)npc);
+        if (x.c_ref) atomicAdd(&tot[1], x.c_ref);
+        if (x.c_calls) atomicAdd(&tot[2], x.c_calls);
+        if (x.c_eval) atomicAdd(&tot[3], x.c_eval);
+        if (x.phase != 2) atomicAdd(&tot[4], 1ull);
+        if (x.c_alg != 0.0) atomicAdd(alg, x.c_alg);
+    }
+    base = mi_rfl64(base);
+    for (int i = lane; i < npc; i += 64) {
+        o_t[base + i] = x.T;
+        o_u[base + i] = pc_key[x.co + i];
+        o_s[base + i] = pc_stat[x.co + i];
+        o_p[base + i] = pc_p[x.co + i];
     }
 }
 
@@ -2357,7 +2336,7 @@ static DhParams dh_make_params(fw_ctx *c, int ntg, int spec_depth, int spec0_dep
         { const char *e = fw_knob("FW_MI_CHUNK_TAIL"); P.mi_chunk_tail = e ? (unsigned int)std::max(1, atoi(e)) : P.mi_chunk_min; }
         { const char *e = fw_knob("FW_MI_WIN0_TAIL"); P.mi_win0_tail = e ? (unsigned int)std::max(1, atoi(e)) : 1024u; }
     }
-    const bool fz = c->P.kind == FW_FZ;
+    const bool fz = c->P.kind == FW_FZ || c->P.kind == FW_FZ_NZ;  // (fz_nz: the same segment kernels on job-local matrices)
     // first window of an interleaving-phase job with fewer than 64 accepted variables.  r04 sweep at cfg3 (two chains, look-ahead 4 / 2,
     // growth 4; ms per pass / launches): 64: 198.7 / 9 790, 128: 194.8, 256 (r01-r03): 189.1 / 8 090, 512: 186.3, 1 024: 183.9, 2 048: 184.7,
     // 4 096: 182.5 / 7 194, 8 192: 184.3, 16 384: 187.6 -- the executed tests move by less than 1 % over that range (a job that stops does
@@ -2495,7 +2474,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     const size_t nnz = (size_t)c->nb_off[p];
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
     static const unsigned seg_target_env = [] { const char *e = fw_knob("FW_SEG_TARGET"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 0u; }();
-    const unsigned seg_target = seg_target_env ? seg_target_env : (c->P.kind == FW_FZ ? 3072u : 4096u);  // cfg3 sweep: 3072
+    const unsigned seg_target = seg_target_env ? seg_target_env : ((c->P.kind == FW_FZ || c->P.kind == FW_FZ_NZ) ? 3072u : 4096u);  // cfg3 sweep: 3072
     // elimination-phase look-ahead (fz, FW_ELIM_FULL windows; see dh_step_kernel): FW_DH_SPEC = members tested ahead per
     // target, FW_DH_SPEC_BELOW = only while the last launch held fewer ranks than this.  cfg3 sweep (ms per pass, one
     // GPU / one rank of 8): off 326.7 / 112.0; depth 4 always 338 / 103; depth 4 below 4M 318.5 / 104.4, below 8M
@@ -2507,7 +2486,8 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     // persistent-workgroup variant was built in r02, lost 140 vs 58 ms on the heavy rounds, and was removed in r03).
     static const bool mi_rounds = [] { const char *e = fw_knob("FW_MI_ROUNDS"); return e && atoi(e) != 0; }();
     // (more than 65 535 samples: 32-bit cell counts -- only the segment kernels have that form, so such data takes the rounds)
-    const bool per_target = c->P.kind != FW_FZ && !mi_rounds;  // (r04: the persistent kernel has a 32-bit-count form too, PRE = 2)
+    const bool nzk = c->P.kind == FW_FZ_NZ;  // fz_nz (r05): rounds like fz, with the sub-matrix kernel in front of the segment kernel
+    const bool per_target = c->P.kind != FW_FZ && !nzk && !mi_rounds;  // (r04: the persistent kernel has a 32-bit-count form too, PRE = 2)
     const int spec_depth = c->P.kind == FW_FZ ? std::min(std::max(spec_env, 0), DH_MAX_SPEC) : 0;
     const int d1 = spec_depth + 1;
     // interleaving-phase look-ahead (first windows of the next candidates, same accepted list): FW_DH_SPEC0 candidates,
@@ -2522,7 +2502,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     // but 221 for the rank of 2; 512: 102)
     static const unsigned long long seg_a_env = [] { const char *e = fw_knob("FW_SEG_A"); return e ? (unsigned long long)atoll(e) : 8000000ull; }();
     static const unsigned long long seg_b_env = [] { const char *e = fw_knob("FW_SEG_B"); return e ? (unsigned long long)atoll(e) : 12000000ull; }();
-    const unsigned long long seg_a = c->P.kind == FW_FZ ? seg_a_env : 0ull, seg_b = c->P.kind == FW_FZ ? seg_b_env : 0ull;
+    const unsigned long long seg_a = (c->P.kind == FW_FZ || c->P.kind == FW_FZ_NZ) ? seg_a_env : 0ull, seg_b = (c->P.kind == FW_FZ || c->P.kind == FW_FZ_NZ) ? seg_b_env : 0ull;
     const unsigned max_ns = seg_target + (unsigned)ntg * (unsigned)(1 + DH_MAX_SPEC) + 256u;  // capacity of the segment list (a job + its look-ahead jobs each round up)
     // striding workgroups of the segment kernel.  FW_SEG_GRID caps them (experiment: with fewer workgroups than resident
     // slots the one-workgroup step / plan kernels of the OTHER chain find a free CU at once instead of queueing behind
@@ -2538,6 +2518,17 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     if (!nb_on_dev) need += pad(8 * ((size_t)p + 1)) + pad(4 * nnz + 4) + 2 * pad(8 * nnz + 8);
     const size_t rec_cap = MI_REC_CAP, bacc_cap = MI_BACC_CAP;
     if (per_target) need += pad(sizeof(MiQueue)) + pad(sizeof(MiBoard) * MI_BOARD_CAP) + pad(sizeof(FwSegOut) * rec_cap) + pad(sizeof(int32_t) * bacc_cap);
+    // fz_nz: a record and an arena slice of (candidates + 2)^2 floats per target (an accepted list never outgrows the candidate list)
+    std::vector<long long> nz_aoff;
+    size_t nz_arena = 0;
+    if (nzk) {
+        nz_aoff.resize((size_t)ntg);
+        for (int t = 0; t < ntg; ++t) {
+            nz_aoff[t] = (long long)nz_arena;
+            nz_arena += (size_t)(tg[t].nc + 2) * (size_t)(tg[t].nc + 2);
+        }
+        need += pad(sizeof(FwNzJob) * (size_t)ntg) + pad(sizeof(long long) * (size_t)ntg) + pad(sizeof(float) * nz_arena + 4);
+    }
     int rc;
     if ((rc = fw_dev_reserve(c, c->d_dh[chain], need))) return rc;
     if ((rc = fw_pin_reserve(c, c->h_dh[chain], 4096))) return rc;
@@ -2576,6 +2567,13 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     MiBoard *d_boards = per_target ? (MiBoard *)carve(sizeof(MiBoard) * MI_BOARD_CAP) : nullptr;
     FwSegOut *d_mres = per_target ? (FwSegOut *)carve(sizeof(FwSegOut) * rec_cap) : nullptr;
     int32_t *d_bacc = per_target ? (int32_t *)carve(sizeof(int32_t) * bacc_cap) : nullptr;
+    FwNzJob *d_nzrecs = nzk ? (FwNzJob *)carve(sizeof(FwNzJob) * (size_t)ntg) : nullptr;
+    long long *d_nzaoff = nzk ? (long long *)carve(sizeof(long long) * (size_t)ntg) : nullptr;
+    float *d_nzarena = nzk ? (float *)carve(sizeof(float) * nz_arena + 4) : nullptr;
+    if (nzk) {
+        FW_HIP(c, hipMemcpyAsync(d_nzaoff, nz_aoff.data(), sizeof(long long) * (size_t)ntg, hipMemcpyHostToDevice, st));
+        FW_HIP(c, hipMemsetAsync(d_nzrecs, 0xff, sizeof(FwNzJob) * (size_t)ntg, st));  // (pad bit 0 set: nothing to compute until a job writes its record)
+    }
     FW_HIP(c, hipMemcpyAsync(d_tg, tg.data(), sizeof(DhTgt) * ntg, hipMemcpyHostToDevice, st));
     hg[0].n_act = (unsigned int)ntg;  // every target starts on the list (the pinned page is the staging copy: stream-ordered)
     FW_HIP(c, hipMemcpyAsync(d_g, hg, sizeof(DhGlobal), hipMemcpyHostToDevice, st));
@@ -2607,7 +2605,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         A.nb_stat = s1;
         A.nb_p = s2;
     }
-    const bool fz = c->P.kind == FW_FZ;
+    const bool fz = c->P.kind == FW_FZ || nzk;  // the rounds over the Fisher-z segment kernels (fz_nz: on job-local matrices)
     DhParams P = dh_make_params(c, ntg, spec_depth, spec0_depth);
     // The in-lane kernel (accepted lists beyond FW_TAB_A) is only launched when such a list can exist in the coming batch:
     // without whitelists an accepted list grows by at most one entry per round, so max_a (longest list so far, read
@@ -2671,21 +2669,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     PA.log = d_log;
     PA.seg_a = seg_a;
     PA.seg_b = seg_b;
-    // FW_DH_FUSE: 1 (default) = the cooperative round (dh_coop_kernel: step | device barrier | redundant plan + fill, one launch),
-    // 0 = step, plan and fill as three launches (r01-r04).  The coop form serves lists of at most DH_COOP_MAX unfinished targets;
-    // longer lists and the rounds that compact the list keep the three launches.
-    static const int fuse_env = [] { const char *e = fw_knob("FW_DH_FUSE"); return e ? atoi(e) : 1; }();
-    const int fuse = c->P.kind == FW_FZ ? fuse_env : 0;
-    static const unsigned coop_cap = [] { const char *e = fw_knob("FW_DH_COOP_GRID"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 128u; }();
-    unsigned coop_tickets = 0u;  // tickets the barrier word holds after the launches so far (grids differ from launch to launch)
     auto planfill = [&](bool compact) {
-        if (fuse > 0 && !compact && n_act_bound <= (unsigned)DH_COOP_MAX) {
-            const unsigned coop_grid = std::min(coop_cap, std::max(8u, (n_act_bound + 3u) / 4u));
-            coop_tickets += coop_grid;
-            hipLaunchKernelGGL(dh_coop_kernel, dim3(coop_grid), dim3(256), 0, st, d_tg, ntg, d_g, A, (const FwSegOut *)d_so, d_seg0, d_win, d_sp,
-                               d_win2, (const int32_t *)d_act, P, PA, d_segs, d1, coop_tickets);
-            return;
-        }
         hipLaunchKernelGGL(dh_step_kernel, dim3((n_act_bound + 3u) / 4u), dim3(256), 0, st, d_tg, ntg, d_g, A,
                            (const FwSegOut *)d_so, (const long long *)d_seg0, d_win, d_sp, d_win2, (const int32_t *)d_act, P);
         if (compact)  // between step and plan: seg0 of the coming launch is built on the new list
@@ -2754,8 +2738,17 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
             if (timed) (void)hipEventRecord(ev[q][2 * r], st);
             // discrete segment kernel: one workgroup per record, no stride loop -> the grid follows the bound on the list
             const unsigned grid_mi = std::min(max_ns, seg_target + n_act_bound * (unsigned)(1 + std::max(spec_depth, spec0_depth)) + 256u);
-            int rc = fz ? fwi_fz_segments_dev(c, grid_seg, d_segs, A.acc, d_so, d_ns, any_big, &d_g->any_big, st)
+            int rc;
+            if (nzk) {
+                // this round's fresh jobs: records (one thread per unfinished target), their matrices, then the enumeration
+                hipLaunchKernelGGL(dh_nz_recs_kernel, dim3((n_act_bound + 255u) / 256u), dim3(256), 0, st, (const DhTgt *)d_tg, ntg, (const DhGlobal *)d_g,
+                                   (const int32_t *)d_act, A, d_nzrecs, (const long long *)d_nzaoff);
+                rc = fwi_fznz_submatrices_dev(c, ntg, d_nzrecs, A.acc, d_nzarena, max_cap + 2, true, st);
+                if (!rc) rc = fwi_fznz_segments_dev(c, grid_seg, d_segs, A.acc, d_so, d_ns, any_big, &d_g->any_big, d_nzrecs, d_nzarena, st);
+            } else {
+                rc = fz ? fwi_fz_segments_dev(c, grid_seg, d_segs, A.acc, d_so, d_ns, any_big, &d_g->any_big, st)
                         : fwi_mi_segments_dev(c, grid_mi, d_segs, A.acc, d_so, d_ns, st);
+            }
             if (rc) return rc;
             if (timed) (void)hipEventRecord(ev[q][2 * r + 1], st);
             planfill((b * (unsigned)nb + (unsigned)r) % 16u == 0u);  // the list of unfinished targets is compacted every 16 rounds
@@ -2818,7 +2811,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         std::lock_guard<std::mutex> lk(cnt_mu);
         if (timed_n > 0) c->cnt.t_dev_subsets_s += timed_s * (double)launches_n / (double)timed_n;
         c->cnt.subsets_launches += launches_n;
-        c->cnt.kernel_launches += per_target ? launches_n : 4 * launches_n;
+        c->cnt.kernel_launches += per_target ? launches_n : (nzk ? 7 : 4) * launches_n;
     }
     if (rc2) return rc2;
     const double th2 = wall();
@@ -2922,7 +2915,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
 // (dh_mi_init_kernel), the whitelists grow on the device between two launches (dh_wl_append_kernel: interleaved.jl:136-140 kept where a
 // later round reads it), and the launches of all rounds are enqueued back to back; the host reads the results once.  Semantics per
 // round are those of fwi_devhiton_run (same kernel, same per-round order and team size).  sched[0 .. nt): the targets in schedule order
-// (learning.jl:97-98); rounds of R targets.  Appends (target, neighbour, statistic, p) in schedule order, PC insertion order inside a target.
+// (learning.jl:97-98); rounds of R targets.  Appends (target, neighbour, statistic, p): a target's entries together, in PC insertion order.
 int fwi_devhiton_mi_schedule(fw_ctx *c, const int32_t *sched, int nt, int R, bool feed_forward, std::vector<int32_t> &all_t,
                              std::vector<int32_t> &all_u, std::vector<double> &all_s, std::vector<double> &all_p)
 {
@@ -2957,7 +2950,7 @@ int fwi_devhiton_mi_schedule(fw_ctx *c, const int32_t *sched, int nt, int R, boo
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
     size_t need = pad(sizeof(DhTgt) * (size_t)nt) + 2 * pad(4 * (size_t)nt) + pad(4 * (size_t)p) * 2 + pad(4 * nnz + 4) * 3 + pad(4 * 2 * nnz + 4) +
                   pad(8 * nnz + 8) * 4 + pad(sizeof(MiQueue) * (size_t)nrounds) + pad(sizeof(MiBoard) * MI_BOARD_CAP) +
-                  pad(sizeof(FwSegOut) * (size_t)MI_REC_CAP) + pad(sizeof(int32_t) * (size_t)MI_BACC_CAP);
+                  pad(sizeof(FwSegOut) * (size_t)MI_REC_CAP) + pad(sizeof(int32_t) * (size_t)MI_BACC_CAP) + 2 * pad(4 * nnz + 4) + 2 * pad(8 * nnz + 8) + pad(64);
     int rc;
     if ((rc = fw_dev_reserve(c, c->d_dh[0], need))) return rc;
     char *B = (char *)c->d_dh[0].ptr;
@@ -2992,6 +2985,10 @@ int fwi_devhiton_mi_schedule(fw_ctx *c, const int32_t *sched, int nt, int R, boo
     MiBoard *d_boards = (MiBoard *)carve(sizeof(MiBoard) * MI_BOARD_CAP);
     FwSegOut *d_mres = (FwSegOut *)carve(sizeof(FwSegOut) * (size_t)MI_REC_CAP);
     int32_t *d_bacc = (int32_t *)carve(sizeof(int32_t) * (size_t)MI_BACC_CAP);
+    int32_t *d_ot = (int32_t *)carve(4 * nnz + 4), *d_ou = (int32_t *)carve(4 * nnz + 4);
+    double *d_os = (double *)carve(8 * nnz + 8), *d_op = (double *)carve(8 * nnz + 8);
+    unsigned long long *d_tot = (unsigned long long *)carve(64);  // [0..4] integers, [5] the Float64 sum of algorithmic bytes
+    FW_HIP(c, hipMemsetAsync(d_tot, 0, 64, st));
     FW_HIP(c, hipMemcpyAsync(d_sched, sched, 4 * (size_t)nt, hipMemcpyHostToDevice, st));
     FW_HIP(c, hipMemcpyAsync(d_order, order.data(), 4 * (size_t)nt, hipMemcpyHostToDevice, st));
     FW_HIP(c, hipMemcpyAsync(d_round_of, round_of.data(), 4 * (size_t)p, hipMemcpyHostToDevice, st));
@@ -3026,18 +3023,14 @@ int fwi_devhiton_mi_schedule(fw_ctx *c, const int32_t *sched, int nt, int R, boo
     }
     FW_HIP(c, hipGetLastError());
     FW_HIP(c, hipEventRecord(ev.e[1], st));
-    // ---- results: one download ----
-    std::vector<DhTgt> tg((size_t)nt);
+    // ---- results: packed on the device, one small download ----
+    hipLaunchKernelGGL(dh_mi_pack_kernel, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, st, (const DhTgt *)d_tg, nt, (const int32_t *)A.pc_key,
+                       (const double *)A.pc_stat, (const double *)A.pc_p, d_ot, d_ou, d_os, d_op, d_tot, (double *)(d_tot + 5));
+    FW_HIP(c, hipGetLastError());
     std::vector<MiQueue> hq((size_t)nrounds);
-    std::vector<int32_t> pk(nnz ? nnz : 1);
-    std::vector<double> ps(nnz ? nnz : 1), pp(nnz ? nnz : 1);
+    unsigned long long htot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     FW_HIP(c, hipMemcpyAsync(hq.data(), d_mq, sizeof(MiQueue) * (size_t)nrounds, hipMemcpyDeviceToHost, st));
-    FW_HIP(c, hipMemcpyAsync(tg.data(), d_tg, sizeof(DhTgt) * (size_t)nt, hipMemcpyDeviceToHost, st));
-    if (nnz) {
-        FW_HIP(c, hipMemcpyAsync(pk.data(), A.pc_key, 4 * nnz, hipMemcpyDeviceToHost, st));
-        FW_HIP(c, hipMemcpyAsync(ps.data(), A.pc_stat, 8 * nnz, hipMemcpyDeviceToHost, st));
-        FW_HIP(c, hipMemcpyAsync(pp.data(), A.pc_p, 8 * nnz, hipMemcpyDeviceToHost, st));
-    }
+    FW_HIP(c, hipMemcpyAsync(htot, d_tot, 64, hipMemcpyDeviceToHost, st));
     FW_HIP(c, hipStreamSynchronize(st));
     const double th2 = wall();
     for (int r = 0; r < nrounds; ++r) {
@@ -3047,26 +3040,27 @@ int fwi_devhiton_mi_schedule(fw_ctx *c, const int32_t *sched, int nt, int R, boo
     }
     float ms = 0.0f;
     FW_HIP(c, hipEventElapsedTime(&ms, ev.e[0], ev.e[1]));
-    size_t nres = 0;
-    for (const DhTgt &x : tg) {
-        if (x.phase != 2) return fw_fail(c, FW_ERR_DEVICE, "device schedule: target %d did not finish (phase %d)", x.T, x.phase);
-        nres += (size_t)x.npc;
+    if (htot[4]) return fw_fail(c, FW_ERR_DEVICE, "device schedule: %llu targets did not finish", htot[4]);
+    const size_t nres = (size_t)htot[0], at0 = all_t.size();
+    if (nres > nnz) return fw_fail(c, FW_ERR_DEVICE, "device schedule: %zu result entries for %zu level-0 entries", nres, nnz);
+    all_t.resize(at0 + nres);
+    all_u.resize(at0 + nres);
+    all_s.resize(at0 + nres);
+    all_p.resize(at0 + nres);
+    if (nres) {
+        FW_HIP(c, hipMemcpyAsync(all_t.data() + at0, d_ot, 4 * nres, hipMemcpyDeviceToHost, st));
+        FW_HIP(c, hipMemcpyAsync(all_u.data() + at0, d_ou, 4 * nres, hipMemcpyDeviceToHost, st));
+        FW_HIP(c, hipMemcpyAsync(all_s.data() + at0, d_os, 8 * nres, hipMemcpyDeviceToHost, st));
+        FW_HIP(c, hipMemcpyAsync(all_p.data() + at0, d_op, 8 * nres, hipMemcpyDeviceToHost, st));
+        FW_HIP(c, hipStreamSynchronize(st));
     }
-    all_t.reserve(all_t.size() + nres);
-    all_u.reserve(all_u.size() + nres);
-    all_s.reserve(all_s.size() + nres);
-    all_p.reserve(all_p.size() + nres);
-    for (const DhTgt &x : tg) {
-        for (int i = 0; i < x.npc; ++i) {
-            all_t.push_back(x.T);
-            all_u.push_back(pk[(size_t)x.co + i]);
-            all_s.push_back(ps[(size_t)x.co + i]);
-            all_p.push_back(pp[(size_t)x.co + i]);
-        }
-        c->cnt.cond_tests_ref += (int64_t)x.c_ref;
-        c->cnt.subsets_calls += (int64_t)x.c_calls;
-        c->cnt.cond_tests_evaluated += (int64_t)x.c_eval;
-        c->cnt.alg_bytes_subsets += x.c_alg;
+    c->cnt.cond_tests_ref += (int64_t)htot[1];
+    c->cnt.subsets_calls += (int64_t)htot[2];
+    c->cnt.cond_tests_evaluated += (int64_t)htot[3];
+    {
+        double alg;
+        memcpy(&alg, &htot[5], sizeof(double));
+        c->cnt.alg_bytes_subsets += alg;
     }
     c->cnt.t_dev_subsets_s += 1e-3 * (double)ms;
     c->cnt.subsets_launches += nrounds;

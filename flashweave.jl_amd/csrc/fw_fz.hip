@@ -289,6 +289,24 @@ __global__ void fz_thresholds_kernel(double alpha, double zscale, double *thr)
     thr[5] = thr[1] * thr[1] * (1.0 + 1e-12);
     thr[6] = thr[3] * thr[3] * (1.0 + 1e-12);
     thr[7] = (thr[4] < 1.0 ? thr[4] * thr[4] : 1.0) * (1.0 - 1e-12);
+    // thr[8], thr[9]: |r| (positive / negative statistic) beyond which the device p-value is exactly zero (fz_seg_body: rz_pos / rz_neg):
+    // bisection on fz_pval_dev between "p > 0" and r = 1 (log(inf) = inf, erfc(inf) = 0), upper end + 1e-9 relative
+    for (int sgn = 0; sgn < 2; ++sgn) {
+        const double sg = sgn ? -1.0 : 1.0;
+        double lo = 0.0, hi = 1.0;
+        if (!(zscale > 0.0) || fz_pval_dev(sg * 1.0, zscale) != 0.0) {
+            thr[8 + sgn] = 2.0;
+            continue;
+        }
+        for (int it = 0; it < 200; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (fz_pval_dev(sg * mid, zscale) == 0.0)
+                hi = mid;
+            else
+                lo = mid;
+        }
+        thr[8 + sgn] = hi * (1.0 + 1e-9);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -473,7 +491,8 @@ __global__ __launch_bounds__(256, HIGHK ? ((TAB || LOCAL) ? FW_HIGHK_OCC : FW_HI
     const unsigned ns = ns_dev ? *ns_dev : gridDim.x;
     for (unsigned s = blockIdx.x; s < ns; s += gridDim.x) {
         // routing by list length (workgroup-uniform); HIGHK without the flag word: the generic variant takes every segment
-        if (ns_dev && !LOCAL && (!HIGHK || big_dev) && ((segs[s].acc_len <= (HIGHK ? FZ_HK_A : FZ_TAB_A)) != TAB)) continue;
+        // (per-job matrices, device rounds of fz_nz: the size-3 table / in-lane pair routes the same way; max_k 4-5 has one variant)
+        if (ns_dev && (!LOCAL || (!HIGHK && big_dev)) && (!HIGHK || big_dev) && ((segs[s].acc_len <= (HIGHK ? FZ_HK_A : FZ_TAB_A)) != TAB)) continue;
         fz_seg_body<HIGHK, LOCAL, TAB>(cor_g, p_g, segs[s], accflat + segs[s].acc_off, false, out + s, max_k, alpha, zscale_g, max_tests, thr_g, recs,
                                        n_obs_min);
         __syncthreads();  // the LDS state of the body is reused by the next segment
@@ -693,7 +712,7 @@ static int fz_ensure_thresholds(fw_ctx *ctx, hipStream_t stream)
         const char *dbg = fw_knob("FW_FZ_DBG");
         const int flags = dbg ? atoi(dbg) : 0;
         FW_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(fz_dbg_flags), &flags, sizeof(int)));
-        FW_HIP(ctx, hipMalloc((void **)&ctx->d_thr, 8 * sizeof(double)));
+        FW_HIP(ctx, hipMalloc((void **)&ctx->d_thr, 12 * sizeof(double)));
         hipLaunchKernelGGL(fz_thresholds_kernel, dim3(1), dim3(64), 0, stream, ctx->P.alpha, fz_zscale(ctx), ctx->d_thr);
         FW_HIP(ctx, hipGetLastError());
         FW_HIP(ctx, hipStreamSynchronize(stream));  // another stream may use it next
@@ -932,7 +951,8 @@ __global__ __launch_bounds__(FZNZ_NT) void fznz_submat_kernel(const float *__res
                                                               double *__restrict__ arena64 /* recursive_pcor = 0: the UNROUNDED Float64
                                                               correlations go here (same element offsets) instead of the Float32 matrix:
                                                               no clamp, no NaN -> 0 (that is cor_subset!'s), a variable listed twice
-                                                              correlates with itself exactly 1 (StatsBase sums the same numbers) */)
+                                                              correlates with itself exactly 1 (StatsBase sums the same numbers) */,
+                                                              int m_lo /* jobs with m <= m_lo belong to another launch (host pool: 0) */)
 {
     extern __shared__ double s_dyn[];
     __shared__ double s_ss01[2];
@@ -943,6 +963,10 @@ __global__ __launch_bounds__(FZNZ_NT) void fznz_submat_kernel(const float *__res
     int *s_woff = s_var + m_cap;                             // [257] (+ padding)
     unsigned short *s_rows = (unsigned short *)(s_woff + 264);  // [n] when n <= FZNZ_ROWS_LDS
     FwNzJob *rec = recs + blockIdx.x;
+    // device rounds (fw_devhiton.hip: one record slot per target, every slot a workgroup): pad bit 0 = nothing to compute (no job, or a
+    // job in a later window whose matrix is still in its slot); m_lo < m <= m_cap selects the launch's share when the round launches
+    // this kernel twice (small jobs with small LDS arrays at four workgroups per CU, the few long lists with arrays for the longest)
+    if ((rec->pad & 1) || rec->m <= m_lo || rec->m > m_cap) return;
     const int m = rec->m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long *mx = nz + (size_t)rec->X * W, *my = nz + (size_t)rec->Y * W;
     for (int t = tid; t < m; t += FZNZ_NT) s_var[t] = t == 0 ? rec->X : (t == 1 ? rec->Y : accflat[rec->acc_off + t - 2]);
@@ -1341,9 +1365,58 @@ int fwi_fznz_submatrices(fw_ctx *ctx, int64_t njobs, const FwNzJob *recs_host, s
     }
     hipLaunchKernelGGL(fznz_submat_kernel, dim3((unsigned)njobs), dim3(FZNZ_NT), lds, stream, ctx->d_data,
                        (const unsigned long long *)ctx->d_nzbits, ctx->P.n, ctx->W, (FwNzJob *)ctx->d_nzrecs.ptr, d_acc,
-                       (float *)ctx->d_arena.ptr, ctx->P.alpha, m_cap, fznz_xcrit(ctx->P.alpha), f64 ? (double *)ctx->d_arena.ptr : (double *)nullptr);
+                       (float *)ctx->d_arena.ptr, ctx->P.alpha, m_cap, fznz_xcrit(ctx->P.alpha), f64 ? (double *)ctx->d_arena.ptr : (double *)nullptr, 0);
     FW_HIP(ctx, hipGetLastError());
     ctx->cnt.kernel_launches += 1;
+    return FW_OK;
+}
+
+// Device rounds of fz_nz (fw_devhiton.hip, r05): one record slot per target of the run, the records written on the device
+// (dh_nz_recs_kernel); one workgroup per slot, idle slots leave at once.  Two launches when the run can hold long lists: jobs of up to
+// FZNZ_DEV_SMALL variables with LDS arrays for that many (four workgroups per CU), longer ones with arrays for the longest list possible.
+#define FZNZ_DEV_SMALL 64
+int fwi_fznz_dev_limits(fw_ctx *ctx, int m_max)
+{
+    const int m_cap = (std::max(m_max, 4) + 15) & ~15;
+    return fznz_lds_bytes(m_cap, ctx->P.n) <= 160u * 1024u - 64u ? FW_OK : FW_ERR_LIMIT;
+}
+int fwi_fznz_submatrices_dev(fw_ctx *ctx, int nslots, FwNzJob *d_recs, const int32_t *d_acc, float *d_arena, int m_max, bool any_long, hipStream_t stream)
+{
+    if (!ctx->fznz_lds_raised) {
+        FW_HIP(ctx, hipFuncSetAttribute((const void *)fznz_submat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160u * 1024u - 64u)));
+        ctx->fznz_lds_raised = true;
+    }
+    const int m_small = std::min(FZNZ_DEV_SMALL, (std::max(m_max, 4) + 15) & ~15);
+    hipLaunchKernelGGL(fznz_submat_kernel, dim3((unsigned)nslots), dim3(FZNZ_NT), fznz_lds_bytes(m_small, ctx->P.n), stream, ctx->d_data,
+                       (const unsigned long long *)ctx->d_nzbits, ctx->P.n, ctx->W, d_recs, d_acc, d_arena, ctx->P.alpha, m_small,
+                       fznz_xcrit(ctx->P.alpha), (double *)nullptr, 0);
+    if (any_long && m_max > m_small) {
+        const int m_cap = (m_max + 15) & ~15;
+        hipLaunchKernelGGL(fznz_submat_kernel, dim3((unsigned)nslots), dim3(FZNZ_NT), fznz_lds_bytes(m_cap, ctx->P.n), stream, ctx->d_data,
+                           (const unsigned long long *)ctx->d_nzbits, ctx->P.n, ctx->W, d_recs, d_acc, d_arena, ctx->P.alpha, m_cap,
+                           fznz_xcrit(ctx->P.alpha), (double *)nullptr, m_small);
+    }
+    FW_HIP(ctx, hipGetLastError());
+    return FW_OK;
+}
+
+// ... and the enumeration on the job-local matrices: the segment list is the device-built one (`*d_ns` records), seg.pad = record slot
+int fwi_fznz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, const unsigned *d_ns,
+                          bool any_big, const unsigned *d_big, const FwNzJob *d_recs, const float *d_arena, hipStream_t stream)
+{
+    if (ctx->P.max_k > 3) {
+        hipLaunchKernelGGL((fz_subsets_seg_kernel<true, true, false>), dim3(grid), dim3(256), 0, stream, d_arena, 0, d_segs, d_acc, d_out, ctx->P.max_k,
+                           ctx->P.alpha, 0.0, (long long)ctx->P.max_tests, (const double *)nullptr, d_recs, (long long)ctx->n_obs_min_eff, d_ns,
+                           (const unsigned *)nullptr);
+    } else {
+        hipLaunchKernelGGL((fz_subsets_seg_kernel<false, true, true>), dim3(grid), dim3(256), 0, stream, d_arena, 0, d_segs, d_acc, d_out, ctx->P.max_k,
+                           ctx->P.alpha, 0.0, (long long)ctx->P.max_tests, (const double *)nullptr, d_recs, (long long)ctx->n_obs_min_eff, d_ns, d_big);
+        if (any_big)
+            hipLaunchKernelGGL((fz_subsets_seg_kernel<false, true, false>), dim3(grid < 512u ? grid : 512u), dim3(256), 0, stream, d_arena, 0, d_segs,
+                               d_acc, d_out, ctx->P.max_k, ctx->P.alpha, 0.0, (long long)ctx->P.max_tests, (const double *)nullptr, d_recs,
+                               (long long)ctx->n_obs_min_eff, d_ns, d_big);
+    }
+    FW_HIP(ctx, hipGetLastError());
     return FW_OK;
 }
 

@@ -668,6 +668,12 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     constexpr bool HK = TAB && HIGHK && !LOCAL;   // level-2 tables for sizes 4 and 5
     static_assert(!(TAB && HIGHK && LOCAL), "no level-2 table variant for per-job matrices");
     constexpr bool L1T = HIGHK && !TAB && !LOCAL;  // level-1 table for sizes 4 and 5 over long lists
+#ifndef FW_L3_SCREEN
+#define FW_L3_SCREEN 0  // (A/B knob; r05: built, bit-identical, cfg5 58.72 s with it against 58.63 s without -- the tests of cfg5 live in the p = 0 regime, see rz_pos -- so the r03 / r04 form stays: every size-5 test of the position tables takes its quotient)
+#endif
+    // SCR: the test loop keeps a statistic as (numerator, radicands) where a screen on the squares decides -- the size-3 table kernel
+    // (r04) and, r05, the size-5 tests of the level-3 position tables (the last formula of a test: two square roots and a division)
+    constexpr bool SCR = TAB3 || (L1T && FW_L3_SCREEN != 0);
     // the accepted list in LDS.  TAB: |accepted| bounded by the host's routing; long-list variant: up to FZ_L1_A entries (the table
     // forms), longer lists are read from global memory by the generic gather form -- LDS is what bounds this variant's occupancy
     constexpr int ACC_LDS = TAB3 ? FZ_TAB_A : (HK ? FZ_HK_A + 8 : (L1T ? FZ_L1_A : FW_ACC_LDS));
@@ -765,6 +771,12 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     // (the context-wide thresholds carry them ready-made in thr[5..7]: fz_thresholds_kernel; per-job thresholds of fz_nz: computed here)
     const double h2_pos = !LOCAL ? thr[5] : rhi_pos * rhi_pos * (1.0 + 1e-12), h2_neg = !LOCAL ? thr[6] : rhi_neg * rhi_neg * (1.0 + 1e-12);
     const double s2 = !LOCAL ? thr[7] : (rsub_lo < 1.0 ? rsub_lo * rsub_lo : 1.0) * (1.0 - 1e-12);
+    // |r| beyond which the p-value is EXACTLY zero (erfc underflows and subnormal values are flushed, fz_pval_slow): there a test
+    // needs neither its x-key nor its p for the maximum-p bookkeeping -- it ties with every other test of that regime at p = 0 and
+    // the later rank wins (tests.jl:338 `>=`).  r05: at n = 10 000 (cfg5) that is every |r| > 0.36, i.e. nearly every test of the
+    // long enumerations -- the strongly associated pairs are the ones whose jobs run for 10^5 subsets -- and each of them paid a
+    // Float64 log and an erfc (two out-of-line calls) to find that out.  Per-job thresholds of fz_nz: not computed (2 = never).
+    const double rz_pos = !LOCAL ? thr[8] : 2.0, rz_neg = !LOCAL ? thr[9] : 2.0;
     __syncthreads();
 #define ACCV(i) (LOCAL ? ((i) + 2) : (in_lds ? s_acc[(i)] : gacc[(i)]))
 #define CORV(u, v) cor[(size_t)(u) * p + (v)]
@@ -1296,7 +1308,18 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                             const double s45 = fz_sq1(R3);
                             const double X4 = pc_l3s_nn(s3_x3[em], x3l, R3, sx3l, s45);                         // rho(X,v|z1..z4)
                             const double Y4 = pc_l3s_nn(s3_y3[em], y3l, R3, sy3l, s45);                         // rho(Y,v|z1..z4)
-                            stat = pc_l3s_nn(a4l, X4, Y4, fz_sq1(X4), fz_sq1(Y4));                              // rho(X,Y|z1..z4,v)
+                            if (SCR) {
+                                // rho(X,Y|z1..z4,v) = pc_l3s_nn(a4l, X4, Y4, sqrt(1 - X4^2), sqrt(1 - Y4^2)), first half: numerator and
+                                // radicands; fz_l3_finish takes the same quotient (same operations, same values: a root of 0 makes the
+                                // denominator 0 in either form) only where the value itself is needed -- see the screen below
+                                l3_ev = round5_f64_nn(a4l - X4 * Y4);
+                                l3_xb = 1.0 - X4 * X4;
+                                l3_xc = 1.0 - Y4 * Y4;
+                                screened = true;
+                                stat = 0.0;
+                            } else {
+                                stat = pc_l3s_nn(a4l, X4, Y4, fz_sq1(X4), fz_sq1(Y4));                          // rho(X,Y|z1..z4,v)
+                            }
                         } else {
                             const TV R1 = pc_l1_r(c45, t1m.z, t1l.z, t1m.w, t1l.w);
                             const TV Bm{(double)s3_p2[em], s3_fl[em] != 0}, Cl{(double)p2l, fl3};
@@ -1323,7 +1346,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 // on the squares, no quotient taken (fz_l3_finish)
                 double e2 = 0.0, m2 = 1.0;
                 bool sure = false;
-                if (TAB3) {
+                if (SCR) {
                     if (screened) {
                         m2 = l3_xb * l3_xc;
                         e2 = l3_ev * l3_ev;
@@ -1362,7 +1385,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 // "lazily" (x is computed once per run, below), a clearly larger one is skipped, and only near-ties and
                 // the underflow regime take the exact path.
                 bool exact = false, lazy_take = false;
-                if (TAB3) {
+                if (SCR) {
                     // the same three-way decision on the squares e2 / m2 against my_bev^2 / (my_bxb my_bxc), cross-multiplied (no division)
                     if (sure || av < rsub_lo) {
                         if (my_bx == FZ_X_NONE || my_bx > FZ_X_SUB) {
@@ -1373,6 +1396,14 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                                 lazy_take = true;
                             else
                                 exact = lhs <= rhs * (1.0 + 1e-11);
+                        }
+                    } else if (av > (stat < 0.0 ? rz_neg : rz_pos)) {  // p = 0 exactly (see rz_pos): ties at zero, the later rank wins
+                        if (my_bx == FZ_X_NONE || (my_bx > FZ_X_SUB && my_bps == 0.0)) {
+                            my_bx = 1.0e9;  // (any key beyond FZ_X_SUB: the regime, not the value, is what the merges look at)
+                            my_bps = 0.0;
+                            my_br = r;
+                            my_bev = stat;
+                            my_bxb = my_bxc = 1.0;
                         }
                     } else {
                         exact = true;
@@ -1419,6 +1450,14 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                             lazy_take = true;
                         else
                             exact = av <= my_ba * (1.0 + 1e-12);
+                    } else if (av > (stat < 0.0 ? rz_neg : rz_pos)) {  // p = 0 exactly (see rz_pos): ties at zero, the later rank wins
+                        if (my_bx == FZ_X_NONE || (my_bx > FZ_X_SUB && my_bps == 0.0)) {
+                            my_bx = 1.0e9;
+                            my_bps = 0.0;
+                            my_ba = av;
+                            my_br = r;
+                            my_bstat = stat;
+                        }
                     } else {
                         exact = true;
                     }
@@ -1501,7 +1540,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 }
             }
         }
-        if (TAB3) {  // the lane best's statistic (its quotient, if it has not been taken yet)
+        if (SCR) {  // the lane best's statistic (its quotient, if it has not been taken yet)
             if (my_bx != FZ_X_NONE && (my_bxb != 1.0 || my_bxc != 1.0)) my_bev = fz_l3_finish(my_bev, my_bxb, my_bxc);
             my_bstat = my_bev;
         }

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cmath>
 #include <numeric>
+#include <functional>
 #include <thread>
 #include <unordered_map>
 
@@ -321,10 +322,18 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
             const bool host_only = hh && atoi(hh) == 1;
             const bool no_power = c->P.kind == FW_FZ && c->P.n < c->n_obs_min_eff;  // no device work at all
             const char *mt = fw_knob("FW_DEV_MIN_TARGETS");  // test knob
-            const size_t min_targets = mt ? (size_t)atol(mt) : (c->P.kind == FW_FZ ? 64 : 256);  // cfg2 (1000 targets): 19 ms on the device, 28 ms through the host pool
+            const size_t min_targets = mt ? (size_t)atol(mt) : ((c->P.kind == FW_FZ || c->P.kind == FW_FZ_NZ) ? 64 : 256);  // cfg2 (1000 targets): 19 ms on the device, 28 ms through the host pool
             const bool stream = c->P.kind == FW_FZ && !c->P.recursive_pcor;  // streamed-column tests: host pool over fw_fzs.hip
             // (discrete data with more than three levels -- the generic form of fw_mi_core.h -- runs through the host job pool as well)
-            const bool use_dev = !host_only && c->P.kind != FW_FZ_NZ && !stream && !no_power && !c->mi_generic && n_my >= min_targets;
+            // fz_nz (r05): device rounds too when its tests run on job-local Float32 matrices (recursive_pcor) and the longest possible
+            // list fits the sub-matrix kernel's LDS; FW_NZ_DEV=0 keeps the host pool (A/B, tests)
+            bool nz_dev = false;
+            if (c->P.kind == FW_FZ_NZ && c->P.recursive_pcor && !(fw_knob("FW_NZ_DEV") && atoi(fw_knob("FW_NZ_DEV")) == 0)) {
+                int64_t dmax = 0;
+                for (int i = r0; i < r1; ++i) dmax = std::max<int64_t>(dmax, c->nb_off[order[i] + 1] - c->nb_off[order[i]]);
+                nz_dev = fwi_fznz_dev_limits(c, (int)dmax + 2) == FW_OK && c->P.n >= c->n_obs_min_eff;
+            }
+            const bool use_dev = !host_only && (c->P.kind != FW_FZ_NZ || nz_dev) && !stream && !no_power && !c->mi_generic && n_my >= min_targets;
             const bool dev_cands = use_dev && c->d_cand != nullptr;  // candidate order already built on the device (fw_bh.hip)
             if (!dev_cands)
                 if (int rc = fwi_nb_host_ensure(c)) return rc;
@@ -623,19 +632,44 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
             c->pc_p[d] = all_p[i];
         }
     }
+    const double tq1 = now_s();
+    // The two passes below walk the directed CSR with data-dependent look-ups (one cache miss per entry: 5 ms of cfg4's 100 ms on one
+    // core): contiguous blocks of variables on a few host threads, every block into its own vectors, concatenated in block order --
+    // the same edge list as the sequential loop.
+    const int n_thr = ne < 20000 ? 1 : (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<int> blk((size_t)n_thr + 1, p);
+    blk[0] = 0;
+    for (int w = 1; w < n_thr; ++w) {  // block w starts where the entries before it reach w / n_thr of the total
+        const int64_t want = (int64_t)ne * w / n_thr;
+        blk[w] = (int)(std::lower_bound(c->pc_off.begin(), c->pc_off.end(), want) - c->pc_off.begin());
+        if (blk[w] > p) blk[w] = p;
+    }
+    auto run_blocks = [&](const std::function<void(int, int, int)> &fn) {
+        if (n_thr == 1) {
+            fn(0, 0, p);
+            return;
+        }
+        std::vector<std::thread> th;
+        for (int w = 1; w < n_thr; ++w) th.emplace_back(fn, w, blk[w], blk[w + 1]);
+        fn(0, blk[0], blk[1]);
+        for (std::thread &t : th) t.join();
+    };
     // misc.jl:137-159 make_weights ("cond_stat"): discrete tests take the sign of the univariate statistic
     if (discrete)
-        for (int T = 0; T < p; ++T) {
-            const int64_t o = c->nb_off[T];
-            const int deg = (int)(c->nb_off[T + 1] - o);
-            const int32_t *b = c->nb_idx.data() + o;
-            for (int64_t i = c->pc_off[T]; i < c->pc_off[T + 1]; ++i) {
-                const int32_t *it = std::lower_bound(b, b + deg, c->pc_idx[i]);
-                const double us = (it != b + deg && *it == c->pc_idx[i]) ? c->nb_stat[o + (it - b)] : NAN;
-                const double sg = std::isnan(us) ? NAN : (double)((us > 0) - (us < 0));
-                c->pc_w[i] = sg * std::fabs(c->pc_w[i]);
+        run_blocks([&](int, int lo, int hi) {
+            for (int T = lo; T < hi; ++T) {
+                const int64_t o = c->nb_off[T];
+                const int deg = (int)(c->nb_off[T + 1] - o);
+                const int32_t *b = c->nb_idx.data() + o;
+                for (int64_t i = c->pc_off[T]; i < c->pc_off[T + 1]; ++i) {
+                    const int32_t *it = std::lower_bound(b, b + deg, c->pc_idx[i]);
+                    const double us = (it != b + deg && *it == c->pc_idx[i]) ? c->nb_stat[o + (it - b)] : NAN;
+                    const double sg = std::isnan(us) ? NAN : (double)((us > 0) - (us < 0));
+                    c->pc_w[i] = sg * std::fabs(c->pc_w[i]);
+                }
             }
-        }
+        });
+    const double tq2 = now_s();
     // misc.jl:230-272 make_symmetric_graph (OR rule, maxweight merge, NaN edges dropped)
     c->e_src.clear();
     c->e_dst.clear();
@@ -655,31 +689,45 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
             if (c->pc_idx[i] == u) return i;
         return -1;
     };
-    for (int a = 0; a < p; ++a) {
-        for (int64_t i = c->pc_off[a]; i < c->pc_off[a + 1]; ++i) {  // direction a -> b exists
-            const int32_t b = c->pc_idx[i];
-            if (b <= a) continue;
-            const int64_t ri = find_in(b, a);
-            const double ww = maxweight(c->pc_w[i], ri >= 0 ? c->pc_w[ri] : NAN);
-            if (std::isnan(ww)) continue;
-            c->e_src.push_back(a);
-            c->e_dst.push_back(b);
-            c->e_w.push_back(ww);
+    const double tq3 = now_s();
+    std::vector<std::vector<int32_t>> bs((size_t)n_thr), bd((size_t)n_thr);
+    std::vector<std::vector<double>> bw((size_t)n_thr);
+    run_blocks([&](int w, int lo, int hi) {
+        std::vector<int32_t> &es = bs[(size_t)w], &ed = bd[(size_t)w];
+        std::vector<double> &ew = bw[(size_t)w];
+        for (int a = lo; a < hi; ++a) {
+            for (int64_t i = c->pc_off[a]; i < c->pc_off[a + 1]; ++i) {  // direction a -> b exists
+                const int32_t b = c->pc_idx[i];
+                if (b <= a) continue;
+                const int64_t ri = find_in(b, a);
+                const double ww = maxweight(c->pc_w[i], ri >= 0 ? c->pc_w[ri] : NAN);
+                if (std::isnan(ww)) continue;
+                es.push_back(a);
+                ed.push_back(b);
+                ew.push_back(ww);
+            }
+            for (int64_t q = in_off[a]; q < in_off[a + 1]; ++q) {  // only b -> a exists
+                const int32_t b = in_idx[(size_t)q];
+                if (b <= a || find_in(a, b) >= 0) continue;
+                const int64_t ri = find_in(b, a);
+                if (ri < 0) continue;
+                const double ww = maxweight(c->pc_w[ri], NAN);
+                if (std::isnan(ww)) continue;
+                es.push_back(a);
+                ed.push_back(b);
+                ew.push_back(ww);
+            }
         }
-        for (int64_t q = in_off[a]; q < in_off[a + 1]; ++q) {  // only b -> a exists
-            const int32_t b = in_idx[(size_t)q];
-            if (b <= a || find_in(a, b) >= 0) continue;
-            const int64_t ri = find_in(b, a);
-            if (ri < 0) continue;
-            const double ww = maxweight(c->pc_w[ri], NAN);
-            if (std::isnan(ww)) continue;
-            c->e_src.push_back(a);
-            c->e_dst.push_back(b);
-            c->e_w.push_back(ww);
-        }
+    });
+    for (int w = 0; w < n_thr; ++w) {
+        c->e_src.insert(c->e_src.end(), bs[(size_t)w].begin(), bs[(size_t)w].end());
+        c->e_dst.insert(c->e_dst.end(), bd[(size_t)w].begin(), bd[(size_t)w].end());
+        c->e_w.insert(c->e_w.end(), bw[(size_t)w].begin(), bw[(size_t)w].end());
     }
     c->have_network = true;
-    if (fw_knob("FW_TRACE_HOST")) fprintf(stderr, "[fw] weights + symmetric graph on the host: %.2f ms\n", 1e3 * (now_s() - tp0));
+    if (fw_knob("FW_TRACE_HOST"))
+        fprintf(stderr, "[fw] weights + symmetric graph on the host: %.2f ms (directed CSR %.2f, signs %.2f, transpose %.2f, edges %.2f; %d threads)\n",
+                1e3 * (now_s() - tp0), 1e3 * (tq1 - tp0), 1e3 * (tq2 - tq1), 1e3 * (tq3 - tq2), 1e3 * (now_s() - tq3), n_thr);
     if (n_edges_out) *n_edges_out = (int64_t)c->e_src.size();
     return FW_OK;
 }

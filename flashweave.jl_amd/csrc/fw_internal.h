@@ -240,6 +240,10 @@ int fwi_fznz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> 
                     std::vector<double> &pval, int64_t *m_reliable, FwL0Dev *dev);
 int fwi_fznz_submatrices(fw_ctx *ctx, int64_t njobs, const FwNzJob *recs_host, size_t arena_floats, const int32_t *d_acc,
                          hipStream_t stream, bool f64 = false);
+int fwi_fznz_dev_limits(fw_ctx *ctx, int m_max);  // FW_OK if a job of m_max variables fits the sub-matrix kernel's LDS
+int fwi_fznz_submatrices_dev(fw_ctx *ctx, int nslots, FwNzJob *d_recs, const int32_t *d_acc, float *d_arena, int m_max, bool any_long, hipStream_t stream);
+int fwi_fznz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, const unsigned *d_ns,
+                          bool any_big, const unsigned *d_big, const FwNzJob *d_recs, const float *d_arena, hipStream_t stream);
 int fwi_fznz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, FwPoolBuf &pb);
 int fwi_fznz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff,
                         const int32_t *zflat, fw_test_result *out);

@@ -61,6 +61,12 @@ static __device__ __noinline__ double mi_igamc(double a, double x)
     if (isnan(a) || isnan(x)) return NAN;
     if (x <= 0.0 || a <= 0.0) return 1.0;
     if (isinf(x)) return 0.0;
+    // one degree of freedom (every 2 x 2 table: the pair tests of the HE kinds, r05): Q(1/2, x) = erfc(sqrt(x)) -- one library call
+    // instead of a series / continued fraction of up to a few hundred terms (the level-0 exact kernel spent most of its 6.7 ms at cfg4
+    // here).  Same function, other rounding: relative difference to the expansion <= 2 x 1.1e-16 (the rounding of the root, amplified
+    // by d log erfc / d log s = 2 s^2), far inside the 1e-10 of DESIGN.md section 2.  Only in the normal range of p: the subnormal
+    // tail keeps the expansion (and its "ax < -745.2 -> 0" cut), so that p-values down there stay what they were.
+    if (a == 0.5 && x < 690.0) return erfc(sqrt(x));
     double ax = a * log(x) - x - lgamma(a);
     if (x < 1.0 || x < a) {
         if (ax < -745.2) return 1.0;

@@ -19,31 +19,29 @@ def filter_by_variance(data):
     return data[row_mask, :], row_mask, col_mask
 
 
-def adaptive_clr(X):
-    """adaptive_pseudocount! + clr!(pseudo_count=0) (preprocessing.jl:157-214)."""
-    X = np.array(X, dtype=np.float64)
-    max_depth_index = int(np.argmax(X.sum(axis=1)))
-    s1 = X[max_depth_index]
-    min_abund = X[X != 0].min()
-    base_pcount = 1.0 if min_abund >= 1 else min_abund / 10
-    k = int((s1 == 0).sum())
-    Nprod1 = float(np.log(s1[s1 != 0]).sum())
-    P = X.shape[1]
-    pseudo = np.zeros(X.shape[0])
-    for i in range(X.shape[0]):
-        s2 = X[i]
-        nz = int((s2 == 0).sum())
-        Nprod2 = float(np.log(s2[s2 != 0]).sum())
-        if not (nz < P and k < P):
-            raise ValueError("samples with all zero abundances are not allowed")
-        pseudo[i] = np.exp((1.0 / (nz - P)) * ((k - P) * np.log(base_pcount) + Nprod1 - Nprod2))
-    keep = pseudo != 0
-    X, pseudo = X[keep], pseudo[keep]
-    for i in range(X.shape[0]):
-        row = X[i]
-        row[row == 0] = pseudo[i]
-    gmean = np.exp(np.log(X).mean(axis=1, keepdims=True))  # StatsBase.geomean
-    return np.log(X / gmean), keep
+def adaptive_clr(counts):
+    """clr_adapt for a dense count matrix (what preprocessing.jl:157-214 computes): every sample's zeros are replaced by ONE fill value
+    chosen so that the filled sample is as far from its own geometric mean as the deepest sample is when ITS zeros hold the floor
+    value -- in logs,  fill_i = exp( [ (z* - w) log(floor) + L* - L_i ] / (z_i - w) )  with z = zeros of the sample, L = sum of the logs
+    of its non-zero counts, w = the table's width, * = the sample with the largest total -- followed by the centred log-ratio.
+    Returns (matrix, kept-samples mask); a sample whose fill value underflows to zero is dropped."""
+    M = np.array(counts, dtype=np.float64)
+    n_samples, width = M.shape
+    present = M != 0
+    zeros = width - present.sum(axis=1)
+    if (zeros >= width).any():
+        raise ValueError("samples with all zero abundances are not allowed")
+    log_mass = np.array([np.log(M[i, present[i]]).sum() for i in range(n_samples)])
+    deepest = int(np.argmax(M.sum(axis=1)))
+    smallest = M[present].min()
+    floor = 1.0 if smallest >= 1 else smallest / 10
+    anchor = (zeros[deepest] - width) * np.log(floor) + log_mass[deepest]
+    fill = np.exp((1.0 / (zeros - width)) * (anchor - log_mass))
+    kept = fill != 0
+    M, present, fill = M[kept], present[kept], fill[kept]
+    M = np.where(present, M, fill[:, None])
+    centre = np.exp(np.log(M).mean(axis=1, keepdims=True))  # geometric mean of the filled sample
+    return np.log(M / centre), kept
 
 
 def clr_nz(X):

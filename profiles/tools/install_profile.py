@@ -3,12 +3,14 @@ python profiles/tools/install_profile.py <cfg> <kernel-name-substring> [round, d
 import csv, json, shutil, sys
 
 cfg, kname = sys.argv[1], sys.argv[2]
-RND = sys.argv[3] if len(sys.argv) > 3 else "r04"
+RND = sys.argv[3] if len(sys.argv) > 3 else "r05"
 P = "gpurun_out/prof_%s_%s/" % (RND, cfg)
 sq, f, w = (json.load(open(P + n)) for n in ("pmc_sq.json", "pmc_f.json", "pmc_w.json"))
+import os
+mix = [json.load(open(P + n)) for n in ("pmc_m1.json", "pmc_m2.json") if os.path.exists(P + n)]
 bench = json.loads([l for l in open(P + "bench_under_rocprof.json") if l.startswith("{")][-1])
 allk = {}
-for d in (sq, f, w):
+for d in [sq, f, w] + mix:
     for k, v in d.items():
         allk.setdefault(k, {}).update(v)
 keys = [k for k in allk if kname in k]
@@ -34,8 +36,18 @@ summ = {
     "wait_inst_any_frac_of_wave_cycles": K["SQ_WAIT_INST_ANY"] / K["SQ_WAVE_CYCLES"],
     "active_inst_valu_frac_of_wave_cycles": K["SQ_ACTIVE_INST_VALU"] / K["SQ_WAVE_CYCLES"],
     "algorithmic_bytes": alg, "fabric_over_algorithmic": (fetch + wr) / alg,
-    "waves_per_simd": (K["SQ_WAVES"] and round(K["SQ_WAVE_CYCLES"] / max(K.get("SQ_BUSY_CYCLES", 0.0), 1.0), 2)) if K.get("SQ_BUSY_CYCLES") else 4,
+    # resident wavefronts per SIMD the kernel is COMPILED for (the -Rpass-analysis=kernel-resource-usage remark of the instantiation:
+    # 4 for the size-3 segment kernel, 3 for the long-list max_k 4-5 variant, 1 for the persistent discrete kernel); bench.py multiplies
+    # SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES by it to get the VALU-busy share of a SIMD
+    "waves_per_simd": 1 if "dh_mi" in kname else (3 if bench["config"]["workload"].find("max_k=5") >= 0 or bench["config"]["workload"].find("max_k=4") >= 0 else 4),
 }
+MIXC = {"f64_add": "SQ_INSTS_VALU_ADD_F64", "f64_mul": "SQ_INSTS_VALU_MUL_F64", "f64_fma": "SQ_INSTS_VALU_FMA_F64", "f64_trans": "SQ_INSTS_VALU_TRANS_F64",
+        "f32_add": "SQ_INSTS_VALU_ADD_F32", "f32_mul": "SQ_INSTS_VALU_MUL_F32", "f32_fma": "SQ_INSTS_VALU_FMA_F32", "f32_trans": "SQ_INSTS_VALU_TRANS_F32",
+        "int32": "SQ_INSTS_VALU_INT32", "int64": "SQ_INSTS_VALU_INT64", "cvt": "SQ_INSTS_VALU_CVT"}
+if all(c in K for c in MIXC.values()):
+    m = {k: K[c] / ev for k, c in MIXC.items()}
+    m["other"] = max(0.0, summ["valu_wave_insts_per_test"] - sum(m.values()))
+    summ["valu_mix_wave_insts_per_test"] = m
 out = {
     "command": "profiles/tools/collect_profile.sh %s: timeout 900 rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python "
                "bench.py --config %s --steps 1 --warmup 0 --no-cpu-baseline --no-other-schedule --no-one-chain (three separate passes: SQ_*; "

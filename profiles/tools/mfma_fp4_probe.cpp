@@ -2,7 +2,7 @@
 // 64 x 32 bit matrix B through v_mfma_scale_f32_32x32x64_f8f6f4 (both operands E2M1, block scale 2^0): every lane expands the 64 bits
 // of its row (lane & 31; K half lane >> 5 -> 32 samples) into 32 nibbles with code 0b0010 = 1.0, register q = bit q of each nibble.
 // Prints the number of accumulator entries that differ from the popcounts computed on the host.
-// build: hipcc --offload-arch=gfx950 -O2 profiles/tools/mfma_fp4_probe.cpp -o flashweave.jl_amd/mfma_fp4_probe.bin
+// build: hipcc --offload-arch=gfx950 -O2 profiles/tools/mfma_fp4_probe.cpp -o profiles/tools/mfma_fp4_probe.bin   (*.bin is git-ignored; never under the package directory)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -99,6 +99,33 @@ def test_network_matches_oracle(ctx, ff, R):
     eng.close()
 
 
+@pytest.mark.parametrize("ff,R", [(False, 0), (True, 64), (True, 100)])
+def test_device_rounds_equal_host_pool_and_oracle(ctx, ff, R, monkeypatch):
+    """r05: fz_nz on the device-resident rounds (fw_devhiton.hip: per-target record slots written by dh_nz_recs_kernel, the sub-matrix
+    kernel in front of the segment kernel of every round, matrices kept across the windows of a job) against the host job pool
+    (FW_NZ_DEV=0, the only driver of r01-r04: tests.jl:293-308, statfuns.jl:138-155 per pool round) and the oracle: edges, weights,
+    directed lists and p-values to the bit between the two drivers (same kernels, same sums), reference-order test count."""
+    data, n, p, orc = ctx["data"], ctx["n"], ctx["p"], ctx["orc"]
+    res = {}
+    for dev in ("0", "1"):
+        monkeypatch.setenv("FW_NZ_DEV", dev)
+        eng = fw.Engine("fz_nz", n, p, max_k=3)
+        eng.set_data(data)
+        res[dev] = (eng.lgl(feed_forward=ff, round_size=R, edge_dict=False), eng.counters())
+        eng.close()
+    (n0, c0), (n1, c1) = res["0"], res["1"]
+    for key in ("edge_src", "edge_dst", "pc_off", "pc_idx"):
+        assert np.array_equal(n0[key], n1[key]), key
+    for key in ("edge_weight", "pc_weight", "pc_pval"):
+        assert np.array_equal(n0[key], n1[key], equal_nan=True), key
+    assert c0["cond_tests_ref"] == c1["cond_tests_ref"] and c0["subsets_calls"] == c1["subsets_calls"]
+    assert c1["kernel_launches"] != c0["kernel_launches"]          # the two drivers really are different paths
+    exp = orc.learn(max_k=3, feed_forward=ff, round_size=max(R, 1) if ff else 1)
+    ge = dict(zip(zip(n1["edge_src"].tolist(), n1["edge_dst"].tolist()), n1["edge_weight"].tolist()))
+    assert ge == exp["edges"] and len(ge) > 0
+    assert c1["cond_tests_ref"] == exp["n_cond_tests"]
+
+
 @pytest.mark.parametrize("max_k", [0, 3])
 def test_golden_networks_fz_nz(max_k):
     # reference test/learning.jl:176-237: exp_fz_nz_maxk{0,3}.edgelist (prec = 64).  The device takes the Float32 matrix

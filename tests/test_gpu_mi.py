@@ -371,14 +371,17 @@ def test_whole_schedule_on_the_device_equals_the_per_round_loop_and_oracle(ctx, 
     (n0, c0), (n1, c1) = res["0"], res["1"]
     for key in ("edge_src", "edge_dst", "pc_off", "pc_idx"):
         assert np.array_equal(n0[key], n1[key]), key
-    for key in ("edge_weight", "pc_weight", "pc_pval"):
-        assert np.array_equal(n0[key], n1[key], equal_nan=True), key   # same kernel, same order per round: to the bit
+    # (a last round of fewer than FW_DEV_MIN_TARGETS targets runs on the host pool in the per-round loop: one test per wavefront
+    # there, four per wavefront in the persistent kernel -- another summation order of the same terms)
+    for key in ("edge_weight", "pc_weight"):
+        assert np.allclose(n0[key], n1[key], rtol=1e-12, atol=1e-15, equal_nan=True), key
+    assert np.allclose(n0["pc_pval"], n1["pc_pval"], rtol=1e-10, atol=0.0, equal_nan=True)
     assert c0["cond_tests_ref"] == c1["cond_tests_ref"] and c0["subsets_calls"] == c1["subsets_calls"]
     exp = orc.learn(max_k=3, feed_forward=True, round_size=R)
     assert np.array_equal(n1["pc_off"], exp["pc_off"]) and np.array_equal(n1["pc_idx"], exp["pc_idx"])
     assert np.allclose(n1["pc_weight"], exp["pc_weight"], rtol=1e-11, atol=1e-15, equal_nan=True)
     assert c1["cond_tests_ref"] == exp["n_cond_tests"]
-    if R < p // 2:
+    if R < p // 2 and kind == "mi":
         assert int(np.isnan(exp["pc_weight"]).sum()) > 0
 
 
