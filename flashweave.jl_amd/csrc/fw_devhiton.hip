@@ -2518,14 +2518,17 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     if (!nb_on_dev) need += pad(8 * ((size_t)p + 1)) + pad(4 * nnz + 4) + 2 * pad(8 * nnz + 8);
     const size_t rec_cap = MI_REC_CAP, bacc_cap = MI_BACC_CAP;
     if (per_target) need += pad(sizeof(MiQueue)) + pad(sizeof(MiBoard) * MI_BOARD_CAP) + pad(sizeof(FwSegOut) * rec_cap) + pad(sizeof(int32_t) * bacc_cap);
-    // fz_nz: a record and an arena slice of (candidates + 2)^2 floats per target (an accepted list never outgrows the candidate list)
+    // fz_nz: a record and an arena slice of (longest list + 2)^2 floats per target.  Without whitelists an accepted list never outgrows
+    // the candidate list; with whitelists (feed-forward) a whitelisted member of the elimination pool is pushed a second time
+    // (hiton.jl:24-26), so a list can reach twice the candidates -- the capacity of the accepted buffers (DH_ACC_OFF: 2 x cap)
     std::vector<long long> nz_aoff;
     size_t nz_arena = 0;
     if (nzk) {
         nz_aoff.resize((size_t)ntg);
         for (int t = 0; t < ntg; ++t) {
             nz_aoff[t] = (long long)nz_arena;
-            nz_arena += (size_t)(tg[t].nc + 2) * (size_t)(tg[t].nc + 2);
+            const size_t mt = (size_t)(wl.empty() ? 1 : 2) * (size_t)tg[t].nc + 2;
+            nz_arena += mt * mt;
         }
         need += pad(sizeof(FwNzJob) * (size_t)ntg) + pad(sizeof(long long) * (size_t)ntg) + pad(sizeof(float) * nz_arena + 4);
     }
@@ -2743,7 +2746,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
                 // this round's fresh jobs: records (one thread per unfinished target), their matrices, then the enumeration
                 hipLaunchKernelGGL(dh_nz_recs_kernel, dim3((n_act_bound + 255u) / 256u), dim3(256), 0, st, (const DhTgt *)d_tg, ntg, (const DhGlobal *)d_g,
                                    (const int32_t *)d_act, A, d_nzrecs, (const long long *)d_nzaoff);
-                rc = fwi_fznz_submatrices_dev(c, ntg, d_nzrecs, A.acc, d_nzarena, max_cap + 2, true, st);
+                rc = fwi_fznz_submatrices_dev(c, ntg, d_nzrecs, A.acc, d_nzarena, (any_wl ? 2 * max_cap : max_cap) + 2, true, st);
                 if (!rc) rc = fwi_fznz_segments_dev(c, grid_seg, d_segs, A.acc, d_so, d_ns, any_big, &d_g->any_big, d_nzrecs, d_nzarena, st);
             } else {
                 rc = fz ? fwi_fz_segments_dev(c, grid_seg, d_segs, A.acc, d_so, d_ns, any_big, &d_g->any_big, st)

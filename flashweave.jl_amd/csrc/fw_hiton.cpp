@@ -331,7 +331,9 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
             if (c->P.kind == FW_FZ_NZ && c->P.recursive_pcor && !(fw_knob("FW_NZ_DEV") && atoi(fw_knob("FW_NZ_DEV")) == 0)) {
                 int64_t dmax = 0;
                 for (int i = r0; i < r1; ++i) dmax = std::max<int64_t>(dmax, c->nb_off[order[i] + 1] - c->nb_off[order[i]]);
-                nz_dev = fwi_fznz_dev_limits(c, (int)dmax + 2) == FW_OK && c->P.n >= c->n_obs_min_eff;
+                // (feed-forward: a whitelisted member of the elimination pool is pushed a second time, hiton.jl:24-26 -- a list can reach
+                // twice the candidates)
+                nz_dev = fwi_fznz_dev_limits(c, (int)(opt.feed_forward ? 2 * dmax : dmax) + 2) == FW_OK && c->P.n >= c->n_obs_min_eff;
             }
             const bool use_dev = !host_only && (c->P.kind != FW_FZ_NZ || nz_dev) && !stream && !no_power && !c->mi_generic && n_my >= min_targets;
             const bool dev_cands = use_dev && c->d_cand != nullptr;  // candidate order already built on the device (fw_bh.hip)
