@@ -664,54 +664,80 @@ __global__ __launch_bounds__(256) void mi_level0_kernel(MiDev P, int p, int T, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// kernel 1, matrix-core form (r04; three-valued data, n <= 65 535).  The four counts of a pair are four entries of the Gram matrix
+// kernel 1, matrix-core form (r04 / r05; three-valued data, n <= 65 535).  The four counts of a pair are four entries of the Gram matrix
 // of the 2p bit planes over the n samples: A = <nzX, nzY>, B = <hiX, nzY>, C = <nzX, hiY>, D = <hiX, hiY> -- a binary GEMM that
 // the popcount form above runs at the integer-VALU peak (16 instructions per pair and 64-sample word: ~40 ms at cfg4 whatever the
-// tiling).  Final form: the MX-fp4 instruction v_mfma_scale_f32_32x32x64_f8f6f4 (L0M_FP4 = 1: bits as the E2M1 values 0 / 1, block
-// scale 2^0, counts exact in the Float32 accumulators; 65 536 multiply-adds per ~32 cycles and SIMD); L0M_FP4 = 0 builds the int8
-// form (v_mfma_i32_32x32x32_i8) that was measured first.  Workgroup tile 128 x 128 variables, 512 threads = eight wavefronts, TWO
-// PER SIMD (a lone wavefront issues one instruction per ~5.5 cycles whatever it executes: expansion and epilogue were issue-bound in
-// the 256-thread form); wavefront (wx, wy) owns 64 X x 32 Y variables = 2 blocks of 32 x 32 variables x 4 plane pairs = 8 accumulator
-// tiles (128 registers).  The bit planes are staged in LDS as 64-sample words, eight words per stage, two stage buffers (one barrier
-// per stage; the next stage's words travel through registers while the current one is multiplied); every lane reads the 32-bit
-// half-word of its operand row (lane & 31: the row, lane >> 5: which half) and expands its bits to operand registers -- fp4: register
-// q = bit q of every nibble, (w >> (q - 1)) & 0x22222222 (seven instructions for 32 samples); int8: register q of K step ks = bit
-// 4 ks + q of every byte.  ANY assignment of samples to the K index of the instruction is right as long as both operands use the same
-// one -- the sum over samples does not depend on their order -- so no layout table is involved beyond "row = lane & 31, K group =
-// lane >> 5" for both operands and the documented C layout (col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5));
-// profiles/tools/mfma_fp4_probe.cpp checks exactly that against host popcounts.  The epilogue is described at its place below.
-typedef int l0m_v4i __attribute__((ext_vector_type(4)));
-typedef int l0m_v16i __attribute__((ext_vector_type(16)));
+// tiling).  Here: the MX-fp4 instruction v_mfma_scale_f32_32x32x64_f8f6f4 (a set bit is a power-of-two E2M1 value, block scale 2^0, every
+// product of two set bits is exactly 1, counts exact in the Float32 accumulators; 65 536 multiply-adds per 32 cycles and SIMD).
+// (The int8 form v_mfma_i32_32x32x32_i8 was measured first in r04 -- 19.8 against 14.8 ms -- and is gone.)  Workgroup tile 128 x 128
+// variables, 512 threads = eight wavefronts, TWO PER SIMD (a lone wavefront issues one instruction per ~5.5 cycles whatever it
+// executes); wavefront (wx, wy) owns 64 X x 32 Y variables = 2 blocks of 32 x 32 variables x 4 plane pairs = 8 accumulator tiles (128
+// registers).  ANY assignment of samples to the K index of the instruction is right as long as both operands use the same one -- the
+// sum over samples does not depend on their order -- so no layout table is involved beyond "row = lane & 31, K group = lane >> 5" for
+// both operands and the documented C layout (col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5));
+// profiles/tools/mfma_fp4_probe.cpp checks exactly that against host popcounts.
+//
+// r05, from two measurements (profiles/r05_level0_matrix_loop.json): (i) profiles/tools/mfma_overlap_gen.py -- the SIMD issues up to
+// five vector instructions under every matrix instruction for free with two wavefronts resident, the sixth costs, a lone wavefront keeps
+// the pipe busy only up to ~3; (ii) ablation builds of this kernel -- the operand reads from LDS cost nothing, staging cost 2.1 of the
+// loop's 10.2 ms: the compiler had put the "value or zero" selects of the staging loads right behind the loads, so every wavefront sat
+// out the full memory latency at the head of every stage, behind a dependent load of the plane pointer (a per-lane choice between two
+// kernel arguments becomes a load from the argument segment).  Now:
+//  * staging map with the plane fixed per load (q & 1) and one 32-bit lane offset for all loads of a tile (scalar base + offset);
+//    interior tiles load unconditionally, the last tile row / column selects at the LDS write, a whole stage after the load;
+//  * pre-permuted operands (L0M_PERM): the thread that stages a 64-sample word rewrites it ONCE per workgroup so that a lane's four
+//    operand registers are three ANDs and a copy instead of seven instructions in each of the wavefronts that share the row (3 x
+//    duplicated: 42 -> 18 vector instructions per wavefront and word).  X side: register q = the samples at bit q of every nibble, as
+//    the E2M1 values 0.5 / 1 / 2 (bits 0, 1, 2 in place) and, for bit 3, 2 (moved to bit 2, second word); Y side: the same samples as
+//    2 / 1 / 0.5 / 0.5 -- every product of two set bits is 1;
+//  * the barrier of a stage sits in front of the LAST two words' matrix instructions, so the first operands of the next stage are read
+//    and expanded under 16 matrix instructions instead of in a bubble behind the barrier.
+typedef int l0m_v8i __attribute__((ext_vector_type(8)));
+typedef float l0m_v16f __attribute__((ext_vector_type(16)));
 #define L0M_T 128
 #define L0M_WC 8      // 64-sample words per stage
 static_assert(L0M_T == 128 && L0M_WC == 8, "the staging map of mi_level0_mfma_kernel is written for 128-variable tiles and 8-word stages");
 #define L0M_S 8       // tiles per side of a super-tile (the unit of the XCD-aware order and of the sharded forms)
 #define L0M_QCAP 1024 // per-workgroup candidate queue
 #define L0M_SCAP 2048 // pairs per tile that pass the integer / Float32 verdicts of the first pass (an eighth per wavefront; more: to the exact kernel unscreened)
+#ifndef L0M_PERM
+#define L0M_PERM 1    // 0: raw words in LDS, seven-instruction expansion in every wavefront (the r04 form; A/B)
+#endif
+#define L0M_RS (L0M_PERM ? 34 : 18)        // 32-bit words per staged row (side, plane, variable): 8 x {4 | 2} + 2 pad (conflict-free operand reads)
+#define L0M_BUF (2 * 2 * L0M_T * L0M_RS)   // 32-bit words per stage buffer
+static_assert(2 * L0M_BUF * 4 >= (int)(L0M_QCAP * 24 + L0M_SCAP * 16), "the epilogue's queues live in the stage buffers");
 
-// Four operand registers (16 bytes of 0 / 1) from this lane's 32 samples, K step ks (0 / 1): register q holds bit 4 ks + q of
-// each of the four bytes of the word -- (w >> (4 ks + q)) & 0x01010101, two instructions.  Which sample lands on which K index
-// is immaterial as long as both operands use the same map (the sum over samples does not depend on their order); over the two K
-// steps and four registers every bit of the word is used exactly once.
-__device__ __forceinline__ l0m_v4i l0m_expand16(unsigned w, int ks)
+#if L0M_PERM
+typedef uint2 l0m_word;  // {main, bit-3 word} of this lane's 32 samples
+// X side: bits 0..2 of every nibble stay where they are (E2M1 0.5 / 1 / 2), bit 3 moves to bit 2 of the second word (2)
+__device__ __forceinline__ void l0m_perm_x(unsigned h, unsigned &m, unsigned &b)
 {
-    l0m_v4i r;
-    r[0] = (int)((w >> (4 * ks)) & 0x01010101u);
-    r[1] = (int)((w >> (4 * ks + 1)) & 0x01010101u);
-    r[2] = (int)((w >> (4 * ks + 2)) & 0x01010101u);
-    r[3] = (int)((w >> (4 * ks + 3)) & 0x01010101u);
+    m = h;
+    b = (h >> 1) & 0x44444444u;
+}
+// Y side: the sample at bit 0 becomes 2, at bit 1 stays 1, at bit 2 becomes 0.5; bit 3 -> 0.5 in the second word
+__device__ __forceinline__ void l0m_perm_y(unsigned h, unsigned &m, unsigned &b)
+{
+    m = ((h & 0x11111111u) << 2) | (h & 0x22222222u) | ((h >> 2) & 0x11111111u);
+    b = (h >> 3) & 0x11111111u;
+}
+template <bool YSIDE>
+__device__ __forceinline__ l0m_v8i l0m_expand_fp4(l0m_word w)
+{
+    l0m_v8i r;
+    r[0] = (int)(w.x & (YSIDE ? 0x44444444u : 0x11111111u));
+    r[1] = (int)(w.x & 0x22222222u);
+    r[2] = (int)(w.x & (YSIDE ? 0x11111111u : 0x44444444u));
+    r[3] = (int)w.y;
+    r[4] = r[5] = r[6] = r[7] = 0;
     return r;
 }
-
-#ifndef L0M_FP4
-#define L0M_FP4 1  // 1: MX-fp4 matrix instruction (v_mfma_scale_f32_32x32x64_f8f6f4, 64 samples per instruction); 0: int8 (32x32x32)
-#endif
-typedef int l0m_v8i __attribute__((ext_vector_type(8)));
-typedef float l0m_v16f __attribute__((ext_vector_type(16)));
+#else
+typedef unsigned l0m_word;
 // MX-fp4 operand of this lane's 32 samples: 32 E2M1 nibbles in four registers, register q = bit q of each nibble of the word, as the
-// code 0b0010 = 1.0 (block scale 2^0): 0 and 1 are exact E2M1 values, a product is 0 or 1, the Float32 accumulator holds a count
-// (<= 65 535 here) exactly.  Seven instructions for 32 samples (int8: fifteen), and the instruction does twice the multiply-adds.
-__device__ __forceinline__ l0m_v8i l0m_expand_fp4(unsigned w)
+// code 0b0010 = 1.0 (block scale 2^0).  Seven instructions for 32 samples.
+template <bool YSIDE>
+__device__ __forceinline__ l0m_v8i l0m_expand_fp4(l0m_word w)
 {
     l0m_v8i r;
     r[0] = (int)((w << 1) & 0x22222222u);
@@ -721,6 +747,7 @@ __device__ __forceinline__ l0m_v8i l0m_expand_fp4(unsigned w)
     r[4] = r[5] = r[6] = r[7] = 0;
     return r;
 }
+#endif
 
 __global__ __launch_bounds__(512) void mi_level0_mfma_kernel(MiDev P, int p, int T, const int32_t *__restrict__ cnt_nz,
                                                             const int32_t *__restrict__ cnt_hi, const double *gthr,
@@ -728,18 +755,16 @@ __global__ __launch_bounds__(512) void mi_level0_mfma_kernel(MiDev P, int p, int
                                                             int dbg, int slot_off, int slot_end /* this launch's share of the tile list, see below */,
                                                             unsigned long long *prof /* FW_L0_VERBOSE: shader cycles per phase, else null */)
 {
-    // staging words [side][plane][var][L0M_WC + 1] (36 KB; the pad word makes the operand reads of 32 consecutive variables conflict-free)
-    __shared__ unsigned long long s_raw[2 * 2 * 2 * L0M_T * (L0M_WC + 1)];  // two stage buffers
+    // two stage buffers [side][plane][variable][L0M_RS]; the epilogue's queues reuse them (nothing reads a stage after the loop)
+    __shared__ __attribute__((aligned(16))) unsigned s_raw[2 * L0M_BUF];
     __shared__ double s_gthr[8];
     __shared__ int4 s_meta[2 * L0M_T];
-    __shared__ MiCand s_q[L0M_QCAP];
     __shared__ int s_qn, s_nsw[8], s_nun[8];
     __shared__ unsigned char s_std[2 * L0M_T];
     __shared__ unsigned long long s_qbase;
-    __shared__ uint4 s_surv[L0M_SCAP];  // {local X | local Y << 8, A | B << 16, C | D << 16, -}: one eighth per wavefront
-    unsigned long long(*sXY)[2][L0M_T][L0M_WC + 1] = (unsigned long long(*)[2][L0M_T][L0M_WC + 1])s_raw;  // [side]
-    unsigned long long(*const sXY0)[2][L0M_T][L0M_WC + 1] = sXY;
-    (void)sXY0;
+    MiCand *const s_q = (MiCand *)s_raw;                            // [L0M_QCAP]
+    uint4 *const s_surv = (uint4 *)(s_raw + (L0M_QCAP * 24) / 4);  // [L0M_SCAP] {local X | local Y << 8, A | B << 16, C | D << 16, -}: one eighth per wavefront
+    static_assert(sizeof(MiCand) == 24, "queue offsets");
     // XCD-aware tile order: consecutive workgroups go round-robin to the eight XCDs, each with its own 4 MB L2.  The tile list is cut
     // into SUPER-TILES of L0M_S x L0M_S tiles (16 x 128 variables x 2 planes x n / 8 bytes = 2.6 MB at n = 5 000: L2-resident) and the
     // workgroups of one XCD (blockIdx & 7) work through the tiles of one super-tile after the other, so a column of bit planes crosses
@@ -770,52 +795,76 @@ __global__ __launch_bounds__(512) void mi_level0_mfma_kernel(MiDev P, int p, int
         s_meta[tid] = m;
         s_std[tid] = (g < p && P.nzmode && P.L == 3 && m.w > 1 && m.z == 3) ? 1 : 0;  // nz-adjusted, three levels: see the epilogue
     }
-#if L0M_FP4
     l0m_v16f acc[2][2][2];  // [X block][X plane][Y plane]: counts as Float32 (exact)
-#else
-    l0m_v16i acc[2][2][2];  // [X block][X plane][Y plane]
-#endif
 #pragma unroll
     for (int q = 0; q < 8; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q >> 2][(q >> 1) & 1][q & 1][r] = 0;
-    // staging: a stage is 2 sides x 128 variables x 2 planes x L0M_WC words = 4 096 words, 8 per thread; element e = q * 512 + tid
-    // is (side e >> 11, variable (e & 2047) >> 4, plane (e >> 3) & 1, word e & 7): eight consecutive lanes read the 64 contiguous bytes
-    // of one (variable, plane) -- a wavefront's load touches 8 runs instead of 64 scattered words.  Addresses are clamped and the value
-    // zeroed by a select, so the loads are unconditional.
+    // staging: a stage is 2 sides x 2 planes x 128 variables x L0M_WC words = 4 096 words, 8 per thread: load q of thread t is (side
+    // q >> 2, plane q & 1, variable 64 ((q >> 1) & 1) + (t >> 3), word t & 7) -- eight consecutive lanes read the 64 contiguous bytes of
+    // one (variable, plane); the plane pointer and the row base are the same for the whole wavefront (scalar base) and the lane's offset
+    // (t >> 3) W + (t & 7) the same for all loads of the kernel.  No clamps and no selects behind the loads: the planes are allocated
+    // with their rows padded to whole tiles and eight words of slack, all zero (fwi_mi_upload), so a tile of the last tile row / column
+    // reads zeros; the words beyond W of the last stage belong to the next row and are zeroed WHEN THE STAGE IS WRITTEN TO LDS, a stage
+    // after the load.
+    const int srow = tid >> 3, sw = tid & 7;
+    const unsigned loff8 = (unsigned)(srow * P.W + sw) * 8u;  // (bytes, 32 bits: scalar base + lane offset addressing)
     unsigned long long rr[8];
-    auto fetch = [&](int w0) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int e = q * 512 + tid, side = e >> 11;
-            const int var = (e & 2047) >> 4, pl = (e >> 3) & 1, w = e & 7;
-            const int g = (side ? bj : bi) * L0M_T + var;
-            const bool ok = g < p && w0 + w < P.W && !(dbg & 2);
-            const unsigned long long *src = pl ? P.hi : P.nz;
-            const unsigned long long v = src[(size_t)(g < p ? g : p - 1) * P.W + (w0 + w < P.W ? w0 + w : P.W - 1)];
-            rr[q] = ok ? v : 0ull;
-        }
+    auto fetch1 = [&](int q, int w0) {
+        // (the base through readfirstlane: a scalar the loop optimiser cannot fold into eight per-lane 64-bit induction pointers)
+        const unsigned long long ba = (unsigned long long)(((q & 1) ? P.hi : P.nz) + ((size_t)(((q >> 2) ? bj : bi) * L0M_T + ((q >> 1) & 1) * 64) * P.W + w0));
+        // (a GLOBAL-address-space pointer: a flat load counts on the LDS counter as well, and every wait for operand words would wait for it)
+        typedef const char __attribute__((address_space(1))) *l0m_gptr;
+        const l0m_gptr b = (l0m_gptr)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ba >> 32)) << 32) |
+                                      (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)ba));
+        rr[q] = *(const unsigned long long __attribute__((address_space(1))) *)(b + loff8);
     };
-    fetch(0);
+    // rr[q] (a word of the stage that starts at word w0) -> stage buffer `bufsel`
+    unsigned *const sdst = s_raw + srow * L0M_RS + sw * (L0M_PERM ? 4 : 2);
+    auto store1 = [&](int q, int bufsel, int w0) {
+        unsigned long long v = rr[q];
+        v = (w0 + sw < P.W && !(dbg & 2)) ? v : 0ull;  // (the last stage's words beyond W belong to the next row)
+        unsigned *dst = sdst + bufsel * L0M_BUF + (((q >> 2) * 2 + (q & 1)) * L0M_T + ((q >> 1) & 1) * 64) * L0M_RS;
+#if L0M_PERM
+        unsigned m0, b0, m1, b1;
+        if (q >> 2) {
+            l0m_perm_y((unsigned)v, m0, b0);
+            l0m_perm_y((unsigned)(v >> 32), m1, b1);
+        } else {
+            l0m_perm_x((unsigned)v, m0, b0);
+            l0m_perm_x((unsigned)(v >> 32), m1, b1);
+        }
+        *(uint2 *)dst = make_uint2(m0, b0);        // half 0: samples 0..31 of the word
+        *(uint2 *)(dst + 2) = make_uint2(m1, b1);  // half 1
+#else
+        *(uint2 *)dst = make_uint2((unsigned)v, (unsigned)(v >> 32));
+#endif
+    };
     const int rowX = wx * 64 + (lane & 31), rowY = wy * 32 + (lane & 31), half = lane >> 5;
-    // The expansion of the NEXT K step (45 VALU instructions) is issued between the 8 matrix instructions of the current one
-    // (sched_group_barrier: one MFMA, then six VALU).  Two wavefronts share a SIMD: a lone wavefront issues one instruction per ~5.5
-    // cycles whatever it executes (the 256-thread form of this kernel: 1 290 cycles per 64-sample word for 235 instructions, with the
-    // matrix pipe busy 1 024 of them).
-#if L0M_FP4
-#define L0M_WORDS(dst, w)                                                                  \
+    // this lane's operand rows inside a stage buffer: X block 0, X block 1, Y block (plane 0; plane 1 is L0M_T rows further)
+    const int offX0 = rowX * L0M_RS, offX1 = (rowX + 32) * L0M_RS, offY = (2 * L0M_T + rowY) * L0M_RS;
+#if L0M_PERM
+#define L0M_LD(buf_, off_, w_) (*(const uint2 *)((buf_) + (off_) + (w_) * 4 + half * 2))
+#else
+#define L0M_LD(buf_, off_, w_) ((buf_)[(off_) + (w_) * 2 + half])
+#endif
+#define L0M_WORDS(dst, buf_, w_)                                                           \
     {                                                                                      \
         _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_)                                \
         {                                                                                  \
-            dst[0][pl_] = ((const unsigned *)&sXY[0][pl_][rowX][w])[half];                 \
-            dst[1][pl_] = ((const unsigned *)&sXY[0][pl_][rowX + 32][w])[half];            \
-            dst[2][pl_] = ((const unsigned *)&sXY[1][pl_][rowY][w])[half];                 \
+            dst[0][pl_] = L0M_LD(buf_, offX0 + pl_ * L0M_T * L0M_RS, w_);                  \
+            dst[1][pl_] = L0M_LD(buf_, offX1 + pl_ * L0M_T * L0M_RS, w_);                  \
+            dst[2][pl_] = L0M_LD(buf_, offY + pl_ * L0M_T * L0M_RS, w_);                   \
         }                                                                                  \
     }
 #define L0M_EXPAND4(f_, src)                                                               \
     {                                                                                      \
-        _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_) \
-            f_[q_][pl_] = l0m_expand_fp4(src[q_][pl_]);                                    \
+        _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_)                                \
+        {                                                                                  \
+            f_[0][pl_] = l0m_expand_fp4<false>(src[0][pl_]);                               \
+            f_[1][pl_] = l0m_expand_fp4<false>(src[1][pl_]);                               \
+            f_[2][pl_] = l0m_expand_fp4<true>(src[2][pl_]);                                \
+        }                                                                                  \
     }
 #define L0M_MFMA8F(f_)                                                                     \
     {                                                                                      \
@@ -823,112 +872,89 @@ __global__ __launch_bounds__(512) void mi_level0_mfma_kernel(MiDev P, int p, int
             _Pragma("unroll") for (int py_ = 0; py_ < 2; ++py_)                            \
                 acc[a_][px_][py_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(f_[a_][px_], f_[2][py_], acc[a_][px_][py_], 4, 4, 0, 127, 0, 127); \
     }
-    // Two stage buffers: stage s + 1 is written to the other buffer after stage s has been multiplied (its words arrived in registers
-    // meanwhile), so a stage costs ONE barrier and no wavefront waits between a barrier and its LDS writes.
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int e = q * 512 + tid;
-        sXY[e >> 11][(e >> 3) & 1][(e & 2047) >> 4][e & 7] = rr[q];
-    }
-    __syncthreads();
-    for (int w0 = 0; w0 < P.W; w0 += L0M_WC) {
-        const bool more = w0 + L0M_WC < P.W;
-        if (more) fetch(w0 + L0M_WC);
-        if (!(dbg & 4)) {
-            unsigned wa[3][2], wb[3][2];  // [X block 0, X block 1, Y block][plane]: this lane's 32 samples of its operand rows
-            l0m_v8i f0[3][2], f1[3][2];
-            L0M_WORDS(wa, 0);
-            L0M_EXPAND4(f0, wa);
-#pragma unroll 1
-            for (int w = 0; w < L0M_WC; w += 2) {  // two words per trip: the operand buffers alternate without register copies
-                L0M_WORDS(wb, w + 1);
-                const int wn = w + 2 < L0M_WC ? w + 2 : w + 1;  // the last trip expands a word again instead of branching
-                L0M_WORDS(wa, wn);
-                L0M_EXPAND4(f1, wb);
-                L0M_MFMA8F(f0);
-                L0M_EXPAND4(f0, wa);
-                L0M_MFMA8F(f1);
 #ifndef L0M_SCHED
-#define L0M_SCHED 5  // VALU instructions between two matrix instructions (cycles of the matrix loop per tile: compiler order 82 300, 3: 79 100, 4: 77 200, 5: 76 300, 6: 79 500, 7: 79 400)
+#define L0M_SCHED (L0M_PERM ? 3 : 5)  // vector instructions between two matrix instructions (r04 form, cycles of the matrix loop per tile: compiler order 82 300, 3: 79 100, 4: 77 200, 5: 76 300, 6: 79 500)
 #endif
+// One word: request the operand words of the word after next, multiply the current operands (8 matrix instructions), expand the
+// requested words under the later ones (the first three matrix instructions cover the LDS latency) -- one set of raw words live.
+// One word: request the operand words of the word after next, multiply the current operands (8 matrix instructions), expand the
+// requested words under the later ones (the first three matrix instructions cover the LDS latency and carry one staging piece: one
+// of the thread's eight staged words permuted and written to the other buffer, its successor requested) -- one set of raw words live.
 #if L0M_SCHED > 0
-                __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, L0M_SCHED, 0);
-                }
-#endif
-            }
-        }
-        sXY = sXY == sXY0 ? sXY0 + 2 : sXY0;  // (a buffer is [2 sides])
-        if (more) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int e = q * 512 + tid;
-                sXY[e >> 11][(e >> 3) & 1][(e & 2047) >> 4][e & 7] = rr[q];
-            }
-        }
-        __syncthreads();
-    }
-#undef L0M_EXPAND4
-#undef L0M_MFMA8F
-#else
-#define L0M_WORDS(dst, w)                                                                  \
+#define L0M_SCHED8()                                                                       \
     {                                                                                      \
-        _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_)                                \
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                 \
+        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                                 \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                 \
+        _Pragma("unroll") for (int q_ = 0; q_ < 5; ++q_)                                   \
         {                                                                                  \
-            dst[0][pl_] = ((const unsigned *)&sXY[0][pl_][rowX][w])[half];                 \
-            dst[1][pl_] = ((const unsigned *)&sXY[0][pl_][rowX + 32][w])[half];            \
-            dst[2][pl_] = ((const unsigned *)&sXY[1][pl_][rowY][w])[half];                 \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             \
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                             \
         }                                                                                  \
     }
-#define L0M_EXPAND(f_, src, sh)                                                            \
-    {                                                                                      \
-        _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_) \
-            f_[q_][pl_] = l0m_expand16(src[q_][pl_], sh);                                  \
-    }
-#define L0M_MFMA8(f_)                                                                      \
-    {                                                                                      \
-        _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_) _Pragma("unroll") for (int px_ = 0; px_ < 2; ++px_) \
-            _Pragma("unroll") for (int py_ = 0; py_ < 2; ++py_)                            \
-                acc[a_][px_][py_] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f_[a_][px_], f_[2][py_], acc[a_][px_][py_], 0, 0, 0); \
-    }
-    for (int w0 = 0; w0 < P.W; w0 += L0M_WC) {
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int e = q * 512 + tid;
-            sXY[e >> 11][(e >> 3) & 1][(e & 2047) >> 4][e & 7] = rr[q];
-        }
-        __syncthreads();
-        if (w0 + L0M_WC < P.W) fetch(w0 + L0M_WC);
-        if (dbg & 4) continue;
-        unsigned cur[3][2], nxt[3][2];  // [X block 0, X block 1, Y block][plane]: this lane's 32 samples of its operand rows
-        l0m_v4i f0[3][2], f1[3][2];
-        L0M_WORDS(cur, 0);
-        L0M_EXPAND(f0, cur, 0);
-#pragma unroll 1
-        for (int w = 0; w < L0M_WC; ++w) {
-            const int wn = w + 1 < L0M_WC ? w + 1 : w;  // the last step expands a word again instead of branching
-            L0M_WORDS(nxt, wn);
-            L0M_EXPAND(f1, cur, 1);
-            L0M_MFMA8(f0);
-            L0M_EXPAND(f0, nxt, 0);
-            L0M_MFMA8(f1);
-#pragma unroll
-            for (int q = 0; q < 6; ++q) cur[q >> 1][q & 1] = nxt[q >> 1][q & 1];
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-            }
-        }
-    }
-#undef L0M_EXPAND
-#undef L0M_MFMA8
+#else
+#define L0M_SCHED8()
 #endif
+#define L0M_HALF(fcur_, fnext_, buf_, widx_, piece_)                                       \
+    {                                                                                      \
+        L0M_WORDS(wt, buf_, widx_);                                                        \
+        L0M_MFMA8F(fcur_);                                                                 \
+        piece_;                                                                            \
+        L0M_EXPAND4(fnext_, wt);                                                           \
+        L0M_SCHED8();                                                                      \
+    }
+    // Two stage buffers.  Behind the barrier of stage s - 1 nobody reads the other buffer any more, so stage s + 1 is written to it
+    // PIECE BY PIECE during stage s -- one of the thread's eight staged words per matrix word: permute, write, request the word of
+    // stage s + 2 into the same registers (a whole stage of latency) -- instead of in one lump in front of the barrier, where all
+    // eight wavefronts would do nothing but staging at the same time.  The barrier of stage s sits in front of the matrix instructions
+    // of its LAST word; the read of the next stage's first word runs under those 8 matrix instructions.  The stage body is straight-line
+    // code (behind the last stage the pieces write a buffer nobody reads and request the last stage again): with branches around the
+    // pieces the compiler sank all 64 matrix instructions of a stage behind them.
+#pragma unroll
+    for (int q = 0; q < 8; ++q) fetch1(q, 0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) store1(q, 0, 0);
+    __syncthreads();
+    const int w0_last = (P.W - 1) / L0M_WC * L0M_WC;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) fetch1(q, L0M_WC < P.W ? L0M_WC : 0);
+    {
+        l0m_word wt[3][2];  // [X block 0, X block 1, Y block][plane]: this lane's 32 samples of its operand rows
+        l0m_v8i f0[3][2], f1[3][2];
+        int bufsel = 0;
+        const unsigned *cur = s_raw;
+        L0M_WORDS(wt, cur, 0);
+        L0M_EXPAND4(f0, wt);
+#pragma unroll 1
+        for (int w0 = 0; w0 < P.W; w0 += L0M_WC) {
+            const unsigned *const nxt = s_raw + (bufsel ^ 1) * L0M_BUF;
+            const int w0n = w0 + L0M_WC, w0nn = w0 + 2 * L0M_WC <= w0_last ? w0 + 2 * L0M_WC : w0_last;
+#define L0M_PIECE(q_) { store1(q_, bufsel ^ 1, w0n); fetch1(q_, w0nn); }
+            L0M_HALF(f0, f1, cur, 1, L0M_PIECE(0));
+            L0M_HALF(f1, f0, cur, 2, L0M_PIECE(1));
+            L0M_HALF(f0, f1, cur, 3, L0M_PIECE(2));
+            L0M_HALF(f1, f0, cur, 4, L0M_PIECE(3));
+            L0M_HALF(f0, f1, cur, 5, L0M_PIECE(4));
+            L0M_HALF(f1, f0, cur, 6, L0M_PIECE(5));
+            L0M_HALF(f0, f1, cur, 7, { L0M_PIECE(6); L0M_PIECE(7); });  // word 6 multiplied, word 7 expanded
+#undef L0M_PIECE
+            __syncthreads();
+            L0M_HALF(f1, f0, nxt, 0, {});  // word 7 multiplied, word 0 of the next stage expanded (behind the last stage: unused)
+            cur = nxt;
+            bufsel ^= 1;
+        }
+    }
+#undef L0M_HALF
+#undef L0M_SCHED8
+#undef L0M_EXPAND4
+#undef L0M_MFMA8F
+#undef L0M_LD
 #undef L0M_WORDS
     __syncthreads();
     const unsigned long long pt1 = prof ? __builtin_readcyclecounter() : 0ull;
@@ -1347,10 +1373,14 @@ int fwi_mi_upload(fw_ctx *ctx, const int64_t *colptr, const int32_t *rowval, con
             (void)hipFree(*q);
             *q = nullptr;
         }
-    FW_HIP(ctx, hipMalloc((void **)&ctx->d_nzbits, pb));
+    // (rows padded to whole level-0 tiles plus one stage of slack words, zero: mi_level0_mfma_kernel stages without clamps)
+    const size_t pb_alloc = sizeof(uint64_t) * ((size_t)((p + L0M_T - 1) / L0M_T * L0M_T) * W + L0M_WC);
+    FW_HIP(ctx, hipMalloc((void **)&ctx->d_nzbits, pb_alloc));
+    FW_HIP(ctx, hipMemset(ctx->d_nzbits, 0, pb_alloc));
     FW_HIP(ctx, hipMemcpy(ctx->d_nzbits, nzb.data(), pb, hipMemcpyHostToDevice));
     if (ctx->L > 2) {
-        FW_HIP(ctx, hipMalloc((void **)&ctx->d_hibits, pb));
+        FW_HIP(ctx, hipMalloc((void **)&ctx->d_hibits, pb_alloc));
+        FW_HIP(ctx, hipMemset(ctx->d_hibits, 0, pb_alloc));
         FW_HIP(ctx, hipMemcpy(ctx->d_hibits, hib.data(), pb, hipMemcpyHostToDevice));
     }
     FW_HIP(ctx, hipMalloc((void **)&ctx->d_levels, sizeof(int32_t) * p));

@@ -56,18 +56,23 @@ def word(buf, nv, dep, lds, valu_first=False):
     return out
 
 
-def kernel(name, nv, dep, lds, mfma=True):
+def kernel(name, nv, dep, lds, mfma=True, rnd=False):
     body = word(0, nv, dep, lds) + word(1, nv, dep, lds)
     if not mfma:
         body = [l for l in body if not l.startswith("v_mfma")]
-    init = ["s_mov_b32 %s, 0x22222222" % M, "v_mov_b32 %s, 0x7f7f7f7f" % SCALE, "v_lshlrev_b32 v191, 2, %1"]
+    init = ["s_mov_b32 s29, 0x85ebca6b", "s_mov_b32 %s, 0x22222222" % M, "v_mov_b32 %s, 0x7f7f7f7f" % SCALE, "v_lshlrev_b32 v191, 2, %1"]
     init += ["v_mov_b32 v%d, 0" % r for r in range(0, 128)]
-    init += ["v_mov_b32 v%d, %%1" % r for r in range(128, 190)]
+    if rnd:  # dense pseudo-random bits in the raw words and the operand registers (what real bit planes look like to the matrix pipe)
+        init += ["v_mul_lo_u32 v%d, %%1, s29" % r for r in range(128, 190)]
+        init += ["v_xor_b32 v%d, 0x%08x, v%d" % (r, (0x9e3779b9 * (r + 1)) & 0xffffffff, r) for r in range(128, 190)]
+        init += ["v_and_b32 v%d, s30, v%d" % (r, r) for r in range(128, 176)]  # operand registers: valid E2M1 codes 0 / 1.0 only
+    else:
+        init += ["v_mov_b32 v%d, %%1" % r for r in range(128, 190)]
     init += ["v_mov_b32 v%d, 0" % r for r in range(192, 208)]
     loop = ["s_mov_b32 s31, %2", "1:"] + body + ["s_sub_u32 s31, s31, 1", "s_cmp_lg_u32 s31, 0", "s_cbranch_scc1 1b", "s_nop 15", "s_nop 15"]
     fin = ["v_add_f32 v0, v0, v16", "v_add_f32 v0, v0, v32", "v_add_f32 v0, v0, v48", "v_add_f32 v0, v0, v64", "v_add_f32 v0, v0, v80",
            "v_add_f32 v0, v0, v96", "v_add_f32 v0, v0, v112", "v_add_u32 v0, v0, v192", "v_add_u32 v0, v0, v200", "v_mov_b32 %0, v0"]
-    clob = ", ".join('"v%d"' % r for r in range(0, 208)) + ', "s30", "s31", "scc", "memory"'
+    clob = ", ".join('"v%d"' % r for r in range(0, 208)) + ', "s29", "s30", "s31", "scc", "memory"'
     asm = "\\n\"\n        \"".join(init + loop + fin)
     n_valu = sum(1 for l in body if l.startswith(("v_and", "v_lsh")))
     n_mfma = sum(1 for l in body if l.startswith("v_mfma"))
@@ -75,7 +80,7 @@ def kernel(name, nv, dep, lds, mfma=True):
 __global__ __launch_bounds__(512) void %s(float *out, int iters, unsigned long long *cyc)
 {
     __shared__ unsigned s_w[2048];
-    for (int i = threadIdx.x; i < 2048; i += blockDim.x) s_w[i] = 0x9e3779b9u * (i + 1);
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) s_w[i] = %s;
     __syncthreads();
     float r;
     const unsigned lane = threadIdx.x & 63u;
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(512) void %s(float *out, int iters, unsigned long l
     if (r == 12345.5f) out[0] = r;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
-""" % (name, asm, clob)
+""" % (name, "0x9e3779b9u * (i + 1)" if rnd else "0u", asm, clob)
 
 
 VARIANTS = [  # name, VALU per matrix instruction, dependent?, ds_reads?, matrix instructions present?
@@ -105,13 +110,19 @@ VARIANTS = [  # name, VALU per matrix instruction, dependent?, ds_reads?, matrix
     ("k_v3_dep_lds", 3, 1, 1, True),
     ("k_valu_only_v5", 5, 1, 0, False),
     ("k_valu_only_v3", 3, 1, 0, False),
+    ("k_mfma_only_rnd", 0, 0, 0, True, True),
+    ("k_v5_dep_rnd", 5, 1, 0, True, True),
+    ("k_v3_dep_rnd", 3, 1, 0, True, True),
+    ("k_v5_dep_lds_rnd", 5, 1, 1, True, True),
+    ("k_v3_dep_lds_rnd", 3, 1, 1, True, True),
 ]
 
 print("// GENERATED by profiles/tools/mfma_overlap_gen.py -- do not edit.  Profiling tool, not product.")
 print("#include <hip/hip_runtime.h>\n#include <cstdio>\n#include <vector>\n#include <algorithm>")
 meta = []
-for name, nv, dep, lds, mf in VARIANTS:
-    nval, nmf, src = kernel(name, nv, dep, lds, mf)
+for v in VARIANTS:
+    name, nv, dep, lds, mf = v[:5]
+    nval, nmf, src = kernel(name, nv, dep, lds, mf, len(v) > 5 and v[5])
     meta.append((name, nval, nmf))
     print(src)
 print("""
