@@ -250,10 +250,9 @@ struct MiL0Counters {
 #define L0_WC 8
 #define L0_QCAP 512  // per-workgroup candidate queue of the level-0 screen
 
-__device__ __forceinline__ void mi_pair_epilogue(const MiDev &P, int X, int Y, int A, int B, int C, int D, const int32_t *cnt_nz,
-                                                 const int32_t *cnt_hi, double alpha, const double *gthr, MiL0Counters *cnt,
-                                                 unsigned long long cap, int32_t *out_i, int32_t *out_j, double *out_s,
-                                                 double *out_p)
+// -> bit 0: significant (p < alpha), bit 1: unreliable; statistic and p-value of a significant pair in stat_out / pval_out
+__device__ __forceinline__ int mi_pair_epilogue(const MiDev &P, int X, int Y, int A, int B, int C, int D, const int32_t *cnt_nz,
+                                                const int32_t *cnt_hi, double alpha, const double *gthr, double &stat_out, double &pval_out)
 {
     const int L = P.L;
     const int nzX = cnt_nz[X], nzY = cnt_nz[Y], hiX = cnt_hi[X], hiY = cnt_hi[Y];
@@ -331,30 +330,9 @@ __device__ __forceinline__ void mi_pair_epilogue(const MiDev &P, int X, int Y, i
                 pval = 1.0;  // any value >= alpha: never looked at again
         }
     }
-    // Unreliable pairs are counted by the screening kernel -- except those it hands over UNSCREENED (mi_level0_mfma_kernel when a
-    // survivor list is full): a screened candidate is reliable by construction, so whatever is unreliable here has not been counted.
-    const int lane = threadIdx.x & 63;
-    {
-        const unsigned long long um = __ballot(unreliable);
-        if (um != 0ull && lane == __ffsll((long long)um) - 1) atomicAdd(&cnt->n_unreliable, (unsigned long long)__popcll(um));
-    }
-    const bool keep = !unreliable && pval < alpha;
-    const unsigned long long km = __ballot(keep);  // one atomic per wavefront
-    unsigned long long base = 0;
-    if (km != 0ull) {
-        const int leader = __ffsll((long long)km) - 1;
-        if (lane == leader) base = atomicAdd(&cnt->n_sig, (unsigned long long)__popcll(km));
-        base = __shfl(base, leader);
-    }
-    if (keep) {
-        const unsigned long long slot = base + (unsigned long long)__popcll(km & ((1ull << lane) - 1ull));
-        if (slot < cap) {
-            out_i[slot] = X;
-            out_j[slot] = Y;
-            out_s[slot] = stat;
-            out_p[slot] = pval;
-        }
-    }
+    stat_out = stat;
+    pval_out = pval;
+    return ((!unreliable && pval < alpha) ? 1 : 0) | (unreliable ? 2 : 0);
 }
 
 // ---- level-0 screening (kernel 1) -----------------------------------------------------------------------
@@ -507,7 +485,8 @@ __device__ __forceinline__ int mi_pair_screen(const MiDev &P, const int4 mX, con
     return 0;
 }
 
-// kernel 2: exact Float64 statistic + p-value for the screened candidates, one thread each
+// kernel 2: exact Float64 statistic + p-value for the screened candidates, one thread each (L0X_IT x 256 candidates per workgroup)
+#define L0X_IT 4
 __global__ __launch_bounds__(256) void mi_level0_exact_kernel(MiDev P, const MiCand *__restrict__ cands, unsigned long long ncand,
                                                               const int32_t *__restrict__ cnt_nz, const int32_t *__restrict__ cnt_hi,
                                                               double alpha, const double *gthr, MiL0Counters *cnt,
@@ -700,12 +679,13 @@ static_assert(L0M_T == 128 && L0M_WC == 8, "the staging map of mi_level0_mfma_ke
 #define L0M_S 8       // tiles per side of a super-tile (the unit of the XCD-aware order and of the sharded forms)
 #define L0M_QCAP 1024 // per-workgroup candidate queue
 #define L0M_SCAP 2048 // pairs per tile that pass the integer / Float32 verdicts of the first pass (an eighth per wavefront; more: to the exact kernel unscreened)
+#define L0M_CAPL 10   // survivors per lane in the packed first pass (a lane's list; beyond: the wavefront takes the general form)
 #ifndef L0M_PERM
 #define L0M_PERM 1    // 0: raw words in LDS, seven-instruction expansion in every wavefront (the r04 form; A/B)
 #endif
 #define L0M_RS (L0M_PERM ? 34 : 18)        // 32-bit words per staged row (side, plane, variable): 8 x {4 | 2} + 2 pad (conflict-free operand reads)
 #define L0M_BUF (2 * 2 * L0M_T * L0M_RS)   // 32-bit words per stage buffer
-static_assert(2 * L0M_BUF * 4 >= (int)(L0M_QCAP * 24 + L0M_SCAP * 16), "the epilogue's queues live in the stage buffers");
+static_assert(2 * L0M_BUF * 4 >= (int)(L0M_QCAP * 24 + L0M_SCAP * 16 + L0M_CAPL * 512 * 16), "the epilogue's queues and lane lists live in the stage buffers");
 
 #if L0M_PERM
 typedef uint2 l0m_word;  // {main, bit-3 word} of this lane's 32 samples
@@ -1035,10 +1015,77 @@ __global__ __launch_bounds__(512) void mi_level0_mfma_kernel(MiDev P, int p, int
             }
         }
     };
-    if (fast_tile)
-        pass1(std::true_type{});
-    else
-        pass1(std::false_type{});
+    // FAST tiles, r05: the same verdicts on PAIRS of accumulator registers with packed Float32 instructions (v_pk_mul / v_pk_fma /
+    // v_pk_add: the counts ARE Float32 values, no conversions), and survivors appended to a list per LANE (no ballot, no lane rank, no
+    // wave-uniform bookkeeping per accumulator register: one compare-and-add for the unreliable count, an exec-masked 16-byte LDS
+    // write for a survivor -- the accumulator register's index rides in the five low mantissa bits of the count A, which are zero for
+    // an integer below 2^19); the lanes' lists are compacted into the wavefront's segment of s_surv afterwards.  The bound is the
+    // r04 one with the cross term of det^2 = (|x| k1 + k2 bc)^2 split by 2 |x| bc <= x^2 + bc^2 (no absolute value, which the packed
+    // instructions lack): 2 A det^2 <= A (K1 x^2 + K2 bc^2).  A lane with more than L0M_CAPL survivors (a hub column) sends its whole
+    // wavefront through the general form above.
+    bool packed_done = false;
+    if (fast_tile) {
+        typedef float l0m_f2 __attribute__((ext_vector_type(2)));
+        float4 *const s_lane = (float4 *)(s_raw + (L0M_QCAP * 24 + L0M_SCAP * 16) / 4);  // [L0M_CAPL][512]
+        const float fthrA = pre_ok ? (float)(thrA < (1 << 24) ? thrA : (1 << 24)) : 3.0e38f;
+        const l0m_f2 K1 = {2.000003f, 2.000003f}, K2 = {1.3e-7f, 1.3e-7f}, KT = {kthr, kthr};
+        int lcnt = 0, unrel = 0;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r2 = 0; r2 < 8; ++r2) {
+                const l0m_f2 A = {acc[a][0][0][2 * r2], acc[a][0][0][2 * r2 + 1]}, B = {acc[a][1][0][2 * r2], acc[a][1][0][2 * r2 + 1]};
+                const l0m_f2 C = {acc[a][0][1][2 * r2], acc[a][0][1][2 * r2 + 1]}, D = {acc[a][1][1][2 * r2], acc[a][1][1][2 * r2 + 1]};
+                const l0m_f2 bc = B * C;
+                const l0m_f2 x = __builtin_elementwise_fma(A, D, -bc);
+                const l0m_f2 lhs = A * __builtin_elementwise_fma(x * x, K1, (bc * bc) * K2);
+                const l0m_f2 rhs = ((A - B) * B) * ((A - C) * C);
+                const l0m_f2 kr = rhs * KT;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const bool rel = A[e] >= fthrA;
+                    const bool surv = rel && rhs[e] > 0.0f && !(lhs[e] < kr[e]);
+                    unrel += rel ? 0 : 1;
+                    if (surv) {
+                        if (lcnt < L0M_CAPL)
+                            s_lane[lcnt * 512 + tid] = make_float4(__uint_as_float(__float_as_uint(A[e]) | (unsigned)(a * 16 + 2 * r2 + e)), B[e], C[e], D[e]);
+                        ++lcnt;
+                    }
+                }
+            }
+        if (__builtin_amdgcn_ballot_w64(lcnt > L0M_CAPL) == 0ull) {
+            packed_done = true;
+            n_unrel += unrel;
+            int incl = lcnt;  // inclusive scan of the lanes' counts
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            my_ns = __builtin_amdgcn_readlane(incl, 63);
+            const int off = incl - lcnt;
+            for (int k = 0; k < lcnt; ++k) {
+                const float4 en = s_lane[k * 512 + tid];
+                const unsigned ab = __float_as_uint(en.x), tag = ab & 31u;
+                const int cA = (int)__uint_as_float(ab & ~31u), cB = (int)en.y, cC = (int)en.z, cD = (int)en.w;
+                const int r = (int)(tag & 15u), lX = wx * 64 + 32 * (int)(tag >> 4) + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (off + k < L0M_SCAP / 8) {
+                    s_surv[seg0 + off + k] = make_uint4((unsigned)lX | ((unsigned)lY << 8), (unsigned)cA | ((unsigned)cB << 16), (unsigned)cC | ((unsigned)cD << 16), 0u);
+                } else {  // segment full (rare): unscreened to the exact kernel
+                    MiCand cd;
+                    cd.X = bi * L0M_T + lX, cd.Y = Y, cd.A = cA, cd.B = cB, cd.C = cC, cd.D = cD;
+                    const int qs = atomicAdd(&s_qn, 1);
+                    if (qs < L0M_QCAP) {
+                        s_q[qs] = cd;
+                    } else {
+                        const unsigned long long gs = atomicAdd(&cnt->n_sig, 1ull);
+                        if (gs < cap_c) cands[gs] = cd;
+                    }
+                }
+            }
+        }
+    }
+    if (!packed_done) pass1(std::false_type{});
     if (lane == 0) n_unrel += n_unrel_w;
     if (lane == 0) s_nsw[wave] = my_ns < L0M_SCAP / 8 ? my_ns : L0M_SCAP / 8;
     const unsigned long long pt2 = prof ? __builtin_readcyclecounter() : 0ull;
@@ -1089,16 +1136,71 @@ __global__ __launch_bounds__(512) void mi_level0_mfma_kernel(MiDev P, int p, int
     }
 }
 
+// Kernel 2.  A workgroup takes L0X_IT x 256 consecutive candidates, gathers the significant ones in LDS and appends them to the output
+// with ONE atomic (r04 / early r05: one same-address atomic per wavefront -- 220 000 of them at cfg4 queued up behind each other in
+// the L2 and were most of the kernel's 5.3 ms).  Unreliable pairs are counted by the screening kernel -- except those it hands over
+// UNSCREENED (mi_level0_mfma_kernel when a survivor list is full): a screened candidate is reliable by construction, so whatever is
+// unreliable here has not been counted.  The order of the output does not matter (BH sorts, the neighbour lists are keyed).
+struct MiL0Rec {
+    int32_t X, Y;
+    double stat, pval;
+};
 __global__ __launch_bounds__(256) void mi_level0_exact_kernel(MiDev P, const MiCand *__restrict__ cands, unsigned long long ncand,
                                                               const int32_t *__restrict__ cnt_nz, const int32_t *__restrict__ cnt_hi,
                                                               double alpha, const double *gthr, MiL0Counters *cnt,
                                                               unsigned long long cap, int32_t *out_i, int32_t *out_j,
                                                               double *out_s, double *out_p)
 {
-    const unsigned long long t = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= ncand) return;
-    const MiCand c = cands[t];
-    mi_pair_epilogue(P, c.X, c.Y, c.A, c.B, c.C, c.D, cnt_nz, cnt_hi, alpha, gthr, cnt, cap, out_i, out_j, out_s, out_p);
+    __shared__ MiL0Rec s_rec[L0X_IT * 256];
+    __shared__ unsigned int s_n, s_unrel;
+    __shared__ unsigned long long s_base;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) s_n = 0u, s_unrel = 0u;
+    __syncthreads();
+    const unsigned long long t0 = (unsigned long long)blockIdx.x * (L0X_IT * 256);
+    unsigned int my_unrel = 0u;
+#pragma unroll 1
+    for (int it = 0; it < L0X_IT; ++it) {
+        const unsigned long long t = t0 + (unsigned long long)it * 256 + tid;
+        int verdict = 0;
+        MiL0Rec r;
+        r.X = r.Y = 0;
+        r.stat = 0.0, r.pval = 1.0;
+        if (t < ncand) {
+            const MiCand c = cands[t];
+            r.X = c.X, r.Y = c.Y;
+            verdict = mi_pair_epilogue(P, c.X, c.Y, c.A, c.B, c.C, c.D, cnt_nz, cnt_hi, alpha, gthr, r.stat, r.pval);
+        }
+        my_unrel += (unsigned)(verdict >> 1);
+        const unsigned long long km = __ballot(verdict & 1);  // one LDS atomic per wavefront
+        if (km != 0ull) {
+            unsigned int base = 0u;
+            const int leader = __ffsll((long long)km) - 1;
+            if (lane == leader) base = atomicAdd(&s_n, (unsigned int)__popcll(km));
+            base = __shfl(base, leader);
+            if (verdict & 1) s_rec[base + (unsigned int)__popcll(km & ((1ull << lane) - 1ull))] = r;
+        }
+    }
+    my_unrel = (unsigned)wave_sum_i((int)my_unrel);
+    if (lane == 0 && my_unrel) atomicAdd(&s_unrel, my_unrel);
+    __syncthreads();
+    const unsigned int n = s_n;
+    if (tid == 0) {
+        if (n) s_base = atomicAdd(&cnt->n_sig, (unsigned long long)n);
+        if (s_unrel) atomicAdd(&cnt->n_unreliable, (unsigned long long)s_unrel);
+    }
+    __syncthreads();
+    const unsigned long long base = s_base;
+    for (unsigned int k = tid; k < n; k += 256) {
+        const unsigned long long slot = base + k;
+        if (slot < cap) {
+            const MiL0Rec r = s_rec[k];
+            out_i[slot] = r.X;
+            out_j[slot] = r.Y;
+            out_s[slot] = r.stat;
+            out_p[slot] = r.pval;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1593,7 +1695,7 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
     if ((rc = fw_dev_reserve(ctx, ctx->d_tmp2, ncand * 2 * sizeof(double)))) return rc;
     int32_t *oi = (int32_t *)ctx->d_tmp1.ptr, *oj = oi + ncand;
     double *os = (double *)ctx->d_tmp2.ptr, *op = os + ncand;
-    hipLaunchKernelGGL(mi_level0_exact_kernel, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, ctx->stream, P,
+    hipLaunchKernelGGL(mi_level0_exact_kernel, dim3((unsigned)((ncand + L0X_IT * 256 - 1) / (L0X_IT * 256))), dim3(256), 0, ctx->stream, P,
                        (const MiCand *)ctx->d_jobs.ptr, ncand, ctx->d_firstnz, ctx->d_firstnz + p, ctx->P.alpha, d_gthr, d_cnt2,
                        ncand, oi, oj, os, op);
     FW_HIP(ctx, hipGetLastError());
