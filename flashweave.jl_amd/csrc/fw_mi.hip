@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256) void mi_level0_kernel(MiDev P, int p, int T, c
 // kernel arguments becomes a load from the argument segment).  Now:
 //  * staging map with the plane fixed per load (q & 1) and one 32-bit lane offset for all loads of a tile (scalar base + offset);
 //    interior tiles load unconditionally, the last tile row / column selects at the LDS write, a whole stage after the load;
-//  * pre-permuted operands (L0M_PERM): the thread that stages a 64-sample word rewrites it ONCE per workgroup so that a lane's four
+//  * pre-permuted operands: the thread that stages a 64-sample word rewrites it ONCE per workgroup so that a lane's four
 //    operand registers are three ANDs and a copy instead of seven instructions in each of the wavefronts that share the row (3 x
 //    duplicated: 42 -> 18 vector instructions per wavefront and word).  X side: register q = the samples at bit q of every nibble, as
 //    the E2M1 values 0.5 / 1 / 2 (bits 0, 1, 2 in place) and, for bit 3, 2 (moved to bit 2, second word); Y side: the same samples as
@@ -709,14 +709,10 @@ static_assert(L0M_T == 128 && L0M_WC == 8, "the staging map of mi_level0_mfma_ke
 #define L0M_QCAP 1024 // per-workgroup candidate queue
 #define L0M_SCAP 2048 // pairs per tile that pass the integer / Float32 verdicts of the first pass (an eighth per wavefront; more: to the exact kernel unscreened)
 #define L0M_CAPL 10   // survivors per lane in the packed first pass (a lane's list; beyond: the wavefront takes the general form)
-#ifndef L0M_PERM
-#define L0M_PERM 1    // 0: raw words in LDS, seven-instruction expansion in every wavefront (the r04 form; A/B)
-#endif
-#define L0M_RS (L0M_PERM ? 34 : 18)        // 32-bit words per staged row (side, plane, variable): 8 x {4 | 2} + 2 pad (conflict-free operand reads)
+#define L0M_RS 34                          // 32-bit words per staged row (side, plane, variable): 8 words x {main, bit-3 word} x 2 halves + 2 pad (conflict-free operand reads)
 #define L0M_BUF (2 * 2 * L0M_T * L0M_RS)   // 32-bit words per stage buffer
 static_assert(2 * L0M_BUF * 4 >= (int)(L0M_QCAP * 24 + L0M_SCAP * 16 + L0M_CAPL * 512 * 16), "the epilogue's queues and lane lists live in the stage buffers");
 
-#if L0M_PERM
 typedef uint2 l0m_word;  // {main, bit-3 word} of this lane's 32 samples
 // X side: bits 0..2 of every nibble stay where they are (E2M1 0.5 / 1 / 2), bit 3 moves to bit 2 of the second word (2)
 __device__ __forceinline__ void l0m_perm_x(unsigned h, unsigned &m, unsigned &b)
@@ -741,22 +737,6 @@ __device__ __forceinline__ l0m_v8i l0m_expand_fp4(l0m_word w)
     r[4] = r[5] = r[6] = r[7] = 0;
     return r;
 }
-#else
-typedef unsigned l0m_word;
-// MX-fp4 operand of this lane's 32 samples: 32 E2M1 nibbles in four registers, register q = bit q of each nibble of the word, as the
-// code 0b0010 = 1.0 (block scale 2^0).  Seven instructions for 32 samples.
-template <bool YSIDE>
-__device__ __forceinline__ l0m_v8i l0m_expand_fp4(l0m_word w)
-{
-    l0m_v8i r;
-    r[0] = (int)((w << 1) & 0x22222222u);
-    r[1] = (int)(w & 0x22222222u);
-    r[2] = (int)((w >> 1) & 0x22222222u);
-    r[3] = (int)((w >> 2) & 0x22222222u);
-    r[4] = r[5] = r[6] = r[7] = 0;
-    return r;
-}
-#endif
 
 __global__ __launch_bounds__(512) void mi_level0_mfma_kernel(MiDev P, int p, int T, const int32_t *__restrict__ cnt_nz,
                                                             const int32_t *__restrict__ cnt_hi, const double *gthr,
@@ -829,12 +809,13 @@ __global__ __launch_bounds__(512) void mi_level0_mfma_kernel(MiDev P, int p, int
         rr[q] = *(const unsigned long long __attribute__((address_space(1))) *)(b + loff8);
     };
     // rr[q] (a word of the stage that starts at word w0) -> stage buffer `bufsel`
-    unsigned *const sdst = s_raw + srow * L0M_RS + sw * (L0M_PERM ? 4 : 2);
+    unsigned *const sdst = s_raw + srow * L0M_RS + sw * 4;
     auto store1 = [&](int q, int bufsel, int w0) {
         unsigned long long v = rr[q];
-        v = (w0 + sw < P.W && !(dbg & 2)) ? v : 0ull;  // (the last stage's words beyond W belong to the next row)
+        // (the last stage's words beyond W belong to the next row: zeroed on the Y side only -- a product with a zero is zero)
+        // (FW_L0_DBG = 2, "no loads": zeros on the Y side make every count zero)
+        if (q >> 2) v = (w0 + sw < P.W && !(dbg & 2)) ? v : 0ull;
         unsigned *dst = sdst + bufsel * L0M_BUF + (((q >> 2) * 2 + (q & 1)) * L0M_T + ((q >> 1) & 1) * 64) * L0M_RS;
-#if L0M_PERM
         unsigned m0, b0, m1, b1;
         if (q >> 2) {
             l0m_perm_y((unsigned)v, m0, b0);
@@ -845,18 +826,11 @@ __global__ __launch_bounds__(512) void mi_level0_mfma_kernel(MiDev P, int p, int
         }
         *(uint2 *)dst = make_uint2(m0, b0);        // half 0: samples 0..31 of the word
         *(uint2 *)(dst + 2) = make_uint2(m1, b1);  // half 1
-#else
-        *(uint2 *)dst = make_uint2((unsigned)v, (unsigned)(v >> 32));
-#endif
     };
     const int rowX = wx * 64 + (lane & 31), rowY = wy * 32 + (lane & 31), half = lane >> 5;
     // this lane's operand rows inside a stage buffer: X block 0, X block 1, Y block (plane 0; plane 1 is L0M_T rows further)
     const int offX0 = rowX * L0M_RS, offX1 = (rowX + 32) * L0M_RS, offY = (2 * L0M_T + rowY) * L0M_RS;
-#if L0M_PERM
 #define L0M_LD(buf_, off_, w_) (*(const uint2 *)((buf_) + (off_) + (w_) * 4 + half * 2))
-#else
-#define L0M_LD(buf_, off_, w_) ((buf_)[(off_) + (w_) * 2 + half])
-#endif
 #define L0M_WORDS(dst, buf_, w_)                                                           \
     {                                                                                      \
         _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_)                                \
@@ -881,50 +855,43 @@ __global__ __launch_bounds__(512) void mi_level0_mfma_kernel(MiDev P, int p, int
             _Pragma("unroll") for (int py_ = 0; py_ < 2; ++py_)                            \
                 acc[a_][px_][py_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(f_[a_][px_], f_[2][py_], acc[a_][px_][py_], 4, 4, 0, 127, 0, 127); \
     }
+// One word (L0M_HALF): request the operand words of the word after next, multiply the current operands (8 matrix instructions) and,
+// under them, expand the words requested one word EARLIER (two sets of raw words: no wait for LDS inside a word) and do the word's
+// staging piece -- one of the thread's eight staged words permuted and written to the other buffer, its successor requested.
 #ifndef L0M_SCHED
-#define L0M_SCHED (L0M_PERM ? 3 : 5)  // vector instructions between two matrix instructions (r04 form, cycles of the matrix loop per tile: compiler order 82 300, 3: 79 100, 4: 77 200, 5: 76 300, 6: 79 500)
+#define L0M_SCHED 5  // vector instructions under one matrix instruction (the probe's free budget with two wavefronts per SIMD)
 #endif
-// One word: request the operand words of the word after next, multiply the current operands (8 matrix instructions), expand the
-// requested words under the later ones (the first three matrix instructions cover the LDS latency) -- one set of raw words live.
-// One word: request the operand words of the word after next, multiply the current operands (8 matrix instructions), expand the
-// requested words under the later ones (the first three matrix instructions cover the LDS latency and carry one staging piece: one
-// of the thread's eight staged words permuted and written to the other buffer, its successor requested) -- one set of raw words live.
 #if L0M_SCHED > 0
 #define L0M_SCHED8()                                                                       \
     {                                                                                      \
         __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                 \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
-        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                 \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
-        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                 \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
-        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                 \
-        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                                 \
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                 \
-        _Pragma("unroll") for (int q_ = 0; q_ < 5; ++q_)                                   \
+        _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                                   \
         {                                                                                  \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             \
-            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                             \
+            __builtin_amdgcn_sched_group_barrier(0x002, L0M_SCHED, 0);                     \
+            if (q_ == 3) __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);                \
+            if (q_ == 4) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                \
         }                                                                                  \
     }
 #else
 #define L0M_SCHED8()
 #endif
-#define L0M_HALF(fcur_, fnext_, buf_, widx_, piece_)                                       \
+#define L0M_HALF(fcur_, fnext_, wexp_, wload_, buf_, widx_, piece_)                        \
     {                                                                                      \
-        L0M_WORDS(wt, buf_, widx_);                                                        \
+        L0M_WORDS(wload_, buf_, widx_);                                                    \
         L0M_MFMA8F(fcur_);                                                                 \
         piece_;                                                                            \
-        L0M_EXPAND4(fnext_, wt);                                                           \
+        L0M_EXPAND4(fnext_, wexp_);                                                        \
         L0M_SCHED8();                                                                      \
     }
     // Two stage buffers.  Behind the barrier of stage s - 1 nobody reads the other buffer any more, so stage s + 1 is written to it
-    // PIECE BY PIECE during stage s -- one of the thread's eight staged words per matrix word: permute, write, request the word of
-    // stage s + 2 into the same registers (a whole stage of latency) -- instead of in one lump in front of the barrier, where all
-    // eight wavefronts would do nothing but staging at the same time.  The barrier of stage s sits in front of the matrix instructions
-    // of its LAST word; the read of the next stage's first word runs under those 8 matrix instructions.  The stage body is straight-line
-    // code (behind the last stage the pieces write a buffer nobody reads and request the last stage again): with branches around the
-    // pieces the compiler sank all 64 matrix instructions of a stage behind them.
+    // PIECE BY PIECE during the first six words of stage s -- permute, write, request the word of stage s + 2 into the same
+    // registers (a whole stage of latency) -- instead of in one lump in front of the barrier, where all eight wavefronts would do
+    // nothing but staging at the same time.  The barrier of stage s sits in front of its LAST TWO words: their matrix instructions
+    // cover the requests for the first two words of stage s + 1 (word j requests word j + 2, and the last request of stage s into its own
+    // buffer -- word 7 -- is made by word 5, in front of the barrier).  The stage body is straight-line code (behind the last stage the
+    // pieces write a buffer nobody reads and request the last stage again): with branches around the pieces the compiler sank all 64
+    // matrix instructions of a stage behind them.
 #pragma unroll
     for (int q = 0; q < 8; ++q) fetch1(q, 0);
 #pragma unroll
@@ -934,27 +901,28 @@ __global__ __launch_bounds__(512) void mi_level0_mfma_kernel(MiDev P, int p, int
 #pragma unroll
     for (int q = 0; q < 8; ++q) fetch1(q, L0M_WC < P.W ? L0M_WC : 0);
     {
-        l0m_word wt[3][2];  // [X block 0, X block 1, Y block][plane]: this lane's 32 samples of its operand rows
+        l0m_word wA[3][2], wB[3][2];  // [X block 0, X block 1, Y block][plane]: this lane's 32 samples of its operand rows, two words in flight
         l0m_v8i f0[3][2], f1[3][2];
         int bufsel = 0;
         const unsigned *cur = s_raw;
-        L0M_WORDS(wt, cur, 0);
-        L0M_EXPAND4(f0, wt);
+        L0M_WORDS(wA, cur, 0);
+        L0M_WORDS(wB, cur, 1);
+        L0M_EXPAND4(f0, wA);
 #pragma unroll 1
         for (int w0 = 0; w0 < P.W; w0 += L0M_WC) {
             const unsigned *const nxt = s_raw + (bufsel ^ 1) * L0M_BUF;
             const int w0n = w0 + L0M_WC, w0nn = w0 + 2 * L0M_WC <= w0_last ? w0 + 2 * L0M_WC : w0_last;
 #define L0M_PIECE(q_) { store1(q_, bufsel ^ 1, w0n); fetch1(q_, w0nn); }
-            L0M_HALF(f0, f1, cur, 1, L0M_PIECE(0));
-            L0M_HALF(f1, f0, cur, 2, L0M_PIECE(1));
-            L0M_HALF(f0, f1, cur, 3, L0M_PIECE(2));
-            L0M_HALF(f1, f0, cur, 4, L0M_PIECE(3));
-            L0M_HALF(f0, f1, cur, 5, L0M_PIECE(4));
-            L0M_HALF(f1, f0, cur, 6, L0M_PIECE(5));
-            L0M_HALF(f0, f1, cur, 7, { L0M_PIECE(6); L0M_PIECE(7); });  // word 6 multiplied, word 7 expanded
+            L0M_HALF(f0, f1, wB, wA, cur, 2, L0M_PIECE(0));                     // word 0 multiplied, word 1 expanded, word 2 requested
+            L0M_HALF(f1, f0, wA, wB, cur, 3, { L0M_PIECE(1); L0M_PIECE(2); });
+            L0M_HALF(f0, f1, wB, wA, cur, 4, L0M_PIECE(3));
+            L0M_HALF(f1, f0, wA, wB, cur, 5, { L0M_PIECE(4); L0M_PIECE(5); });
+            L0M_HALF(f0, f1, wB, wA, cur, 6, L0M_PIECE(6));
+            L0M_HALF(f1, f0, wA, wB, cur, 7, L0M_PIECE(7));
 #undef L0M_PIECE
             __syncthreads();
-            L0M_HALF(f1, f0, nxt, 0, {});  // word 7 multiplied, word 0 of the next stage expanded (behind the last stage: unused)
+            L0M_HALF(f0, f1, wB, wA, nxt, 0, {});  // word 6 multiplied, word 7 expanded, word 0 of the next stage requested
+            L0M_HALF(f1, f0, wA, wB, nxt, 1, {});  // word 7 multiplied, word 0 of the next stage expanded, its word 1 requested
             cur = nxt;
             bufsel ^= 1;
         }
