@@ -481,7 +481,8 @@ __global__ __launch_bounds__(256, HIGHK ? ((TAB || LOCAL) ? FW_HIGHK_OCC : FW_HI
                                                              const double *__restrict__ thr_g,
                                                              const FwNzJob *__restrict__ recs, long long n_obs_min,
                                                              const unsigned *__restrict__ ns_dev,
-                                                             const unsigned *__restrict__ big_dev)
+                                                             const unsigned *__restrict__ big_dev,
+                                                             unsigned long long *gstop /* device rounds of fz: one word per job of the launch (index: FwSeg::pad), see fz_seg_body; else null */)
 {
     // device rounds launch the in-lane variant next to the table variant whenever a long accepted list is POSSIBLE (with
     // whitelists that is nearly always); the fill kernel knows whether one EXISTS in this launch -- without one, leave
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(256, HIGHK ? ((TAB || LOCAL) ? FW_HIGHK_OCC : FW_HI
         // (per-job matrices, device rounds of fz_nz: the size-3 table / in-lane pair routes the same way; max_k 4-5 has one variant)
         if (ns_dev && (!LOCAL || (!HIGHK && big_dev)) && (!HIGHK || big_dev) && ((segs[s].acc_len <= (HIGHK ? FZ_HK_A : FZ_TAB_A)) != TAB)) continue;
         fz_seg_body<HIGHK, LOCAL, TAB>(cor_g, p_g, segs[s], accflat + segs[s].acc_off, false, out + s, max_k, alpha, zscale_g, max_tests, thr_g, recs,
-                                       n_obs_min);
+                                       n_obs_min, (!LOCAL && gstop) ? gstop + segs[s].pad : (unsigned long long *)nullptr);
         __syncthreads();  // the LDS state of the body is reused by the next segment
     }
 }
@@ -728,7 +729,7 @@ int fwi_fz_thresholds(fw_ctx *ctx, hipStream_t stream, double *zscale)
 }
 
 int fwi_fz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, const unsigned *d_ns,
-                        bool any_big, const unsigned *d_big, hipStream_t stream)
+                        bool any_big, const unsigned *d_big, unsigned long long *d_gstop, hipStream_t stream)
 {
     int rc = fz_ensure_thresholds(ctx, stream);
     if (rc) return rc;
@@ -739,18 +740,18 @@ int fwi_fz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const i
         if (!no_hk)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false, true>), dim3(grid), dim3(256), 0, stream, ctx->d_cor, ctx->P.p, d_segs,
                                d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr,
-                               (const FwNzJob *)nullptr, 0ll, d_ns, d_big);
+                               (const FwNzJob *)nullptr, 0ll, d_ns, d_big, d_gstop);
         hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false, false>), dim3(grid), dim3(256), 0, stream, ctx->d_cor,
                            ctx->P.p, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests,
-                           ctx->d_thr, (const FwNzJob *)nullptr, 0ll, d_ns, no_hk ? (const unsigned *)nullptr : d_big);
+                           ctx->d_thr, (const FwNzJob *)nullptr, 0ll, d_ns, no_hk ? (const unsigned *)nullptr : d_big, d_gstop);
     } else {
         hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false, true>), dim3(grid), dim3(256), 0, stream, ctx->d_cor, ctx->P.p, d_segs,
                            d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr,
-                           (const FwNzJob *)nullptr, 0ll, d_ns, d_big);
+                           (const FwNzJob *)nullptr, 0ll, d_ns, d_big, d_gstop);
         if (any_big)  // some accepted set may exceed FZ_TAB_A
             hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false, false>), dim3(grid_big), dim3(256), 0, stream, ctx->d_cor, ctx->P.p,
                                d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests,
-                               ctx->d_thr, (const FwNzJob *)nullptr, 0ll, d_ns, d_big);
+                               ctx->d_thr, (const FwNzJob *)nullptr, 0ll, d_ns, d_big, d_gstop);
     }
     FW_HIP(ctx, hipGetLastError());
     return FW_OK;
@@ -770,23 +771,23 @@ int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *d_
         if (nseg_tab > 0)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false, true>), dim3((unsigned)nseg_tab), dim3(256), 0, pb.launch_stream,
                                ctx->d_cor, ctx->P.p, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx),
-                               (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll, (const unsigned *)nullptr, (const unsigned *)nullptr);
+                               (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll, (const unsigned *)nullptr, (const unsigned *)nullptr, (unsigned long long *)nullptr);
         if (nseg > nseg_tab)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false, false>), dim3((unsigned)(nseg - nseg_tab)), dim3(256), 0,
                                pb.launch_stream, ctx->d_cor, ctx->P.p, d_segs + nseg_tab, d_acc, d_out + nseg_tab, ctx->P.max_k,
                                ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr,
-                               0ll, (const unsigned *)nullptr, (const unsigned *)nullptr);
+                               0ll, (const unsigned *)nullptr, (const unsigned *)nullptr, (unsigned long long *)nullptr);
     } else {
         // segments [0, nseg_tab) belong to jobs with |accepted| <= FZ_TAB_A: table kernel; the rest: in-lane caching
         if (nseg_tab > 0)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false, true>), dim3((unsigned)nseg_tab), dim3(256), 0, pb.launch_stream,
                                ctx->d_cor, ctx->P.p, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx),
-                               (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll, (const unsigned *)nullptr, (const unsigned *)nullptr);
+                               (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll, (const unsigned *)nullptr, (const unsigned *)nullptr, (unsigned long long *)nullptr);
         if (nseg > nseg_tab)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false, false>), dim3((unsigned)(nseg - nseg_tab)), dim3(256), 0,
                                pb.launch_stream, ctx->d_cor, ctx->P.p, d_segs + nseg_tab, d_acc, d_out + nseg_tab, ctx->P.max_k,
                                ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr,
-                               0ll, (const unsigned *)nullptr, (const unsigned *)nullptr);
+                               0ll, (const unsigned *)nullptr, (const unsigned *)nullptr, (unsigned long long *)nullptr);
     }
     FW_HIP(ctx, hipGetLastError());
     FW_HIP(ctx, hipEventRecord(pb.ev1, pb.launch_stream));
@@ -1407,14 +1408,14 @@ int fwi_fznz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const
     if (ctx->P.max_k > 3) {
         hipLaunchKernelGGL((fz_subsets_seg_kernel<true, true, false>), dim3(grid), dim3(256), 0, stream, d_arena, 0, d_segs, d_acc, d_out, ctx->P.max_k,
                            ctx->P.alpha, 0.0, (long long)ctx->P.max_tests, (const double *)nullptr, d_recs, (long long)ctx->n_obs_min_eff, d_ns,
-                           (const unsigned *)nullptr);
+                           (const unsigned *)nullptr, (unsigned long long *)nullptr);
     } else {
         hipLaunchKernelGGL((fz_subsets_seg_kernel<false, true, true>), dim3(grid), dim3(256), 0, stream, d_arena, 0, d_segs, d_acc, d_out, ctx->P.max_k,
-                           ctx->P.alpha, 0.0, (long long)ctx->P.max_tests, (const double *)nullptr, d_recs, (long long)ctx->n_obs_min_eff, d_ns, d_big);
+                           ctx->P.alpha, 0.0, (long long)ctx->P.max_tests, (const double *)nullptr, d_recs, (long long)ctx->n_obs_min_eff, d_ns, d_big, (unsigned long long *)nullptr);
         if (any_big)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<false, true, false>), dim3(grid < 512u ? grid : 512u), dim3(256), 0, stream, d_arena, 0, d_segs,
                                d_acc, d_out, ctx->P.max_k, ctx->P.alpha, 0.0, (long long)ctx->P.max_tests, (const double *)nullptr, d_recs,
-                               (long long)ctx->n_obs_min_eff, d_ns, d_big);
+                               (long long)ctx->n_obs_min_eff, d_ns, d_big, (unsigned long long *)nullptr);
     }
     FW_HIP(ctx, hipGetLastError());
     return FW_OK;
@@ -1429,18 +1430,18 @@ int fwi_fznz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *
         hipLaunchKernelGGL((fz_subsets_seg_kernel<true, true, false>), dim3((unsigned)nseg), dim3(256), 0, pb.launch_stream,
                            (const float *)ctx->d_arena.ptr, 0, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, 0.0,
                            (long long)ctx->P.max_tests, (const double *)nullptr, (const FwNzJob *)ctx->d_nzrecs.ptr,
-                           (long long)ctx->n_obs_min_eff, (const unsigned *)nullptr, (const unsigned *)nullptr);
+                           (long long)ctx->n_obs_min_eff, (const unsigned *)nullptr, (const unsigned *)nullptr, (unsigned long long *)nullptr);
     else {
         if (nseg_tab > 0)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<false, true, true>), dim3((unsigned)nseg_tab), dim3(256), 0, pb.launch_stream,
                                (const float *)ctx->d_arena.ptr, 0, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, 0.0,
                                (long long)ctx->P.max_tests, (const double *)nullptr, (const FwNzJob *)ctx->d_nzrecs.ptr,
-                               (long long)ctx->n_obs_min_eff, (const unsigned *)nullptr, (const unsigned *)nullptr);
+                               (long long)ctx->n_obs_min_eff, (const unsigned *)nullptr, (const unsigned *)nullptr, (unsigned long long *)nullptr);
         if (nseg > nseg_tab)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<false, true, false>), dim3((unsigned)(nseg - nseg_tab)), dim3(256), 0,
                                pb.launch_stream, (const float *)ctx->d_arena.ptr, 0, d_segs + nseg_tab, d_acc, d_out + nseg_tab,
                                ctx->P.max_k, ctx->P.alpha, 0.0, (long long)ctx->P.max_tests, (const double *)nullptr,
-                               (const FwNzJob *)ctx->d_nzrecs.ptr, (long long)ctx->n_obs_min_eff, (const unsigned *)nullptr, (const unsigned *)nullptr);
+                               (const FwNzJob *)ctx->d_nzrecs.ptr, (long long)ctx->n_obs_min_eff, (const unsigned *)nullptr, (const unsigned *)nullptr, (unsigned long long *)nullptr);
     }
     FW_HIP(ctx, hipGetLastError());
     FW_HIP(ctx, hipEventRecord(pb.ev1, pb.launch_stream));

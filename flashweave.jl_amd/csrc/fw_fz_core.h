@@ -662,7 +662,9 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                                             FwSegOut *out_rec, int max_k,
                                             double alpha, double zscale_g, long long max_tests,
                                             const double *__restrict__ thr_g, const FwNzJob *__restrict__ recs,
-                                            long long n_obs_min)
+                                            long long n_obs_min,
+                                            unsigned long long *gstop /* device rounds (r05): the job's word in device memory -- smallest stopping
+                                                                         rank any workgroup of this launch has found in the job so far; null elsewhere */)
 {
     constexpr bool TAB3 = TAB && !HIGHK;          // size-3 table (max_k <= 3)
     constexpr bool HK = TAB && HIGHK && !LOCAL;   // level-2 tables for sizes 4 and 5
@@ -700,6 +702,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     __shared__ unsigned long long s_hk_end;
     __shared__ int s_hk_n, s_hk_lin0, s_hk_nan, s_hk_skip0, s_hk_prev;
     __shared__ unsigned int s_cstop;  // smallest stopping rank of the current chunk so far (relative to the chunk), 0xffffffff = none
+    __shared__ unsigned long long s_gs0;  // the job's stop word as the segment found it
     __shared__ unsigned long long s_stop[4];
     __shared__ double s_bx[4], s_bps[4];
     __shared__ unsigned long long s_br[4];
@@ -756,6 +759,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
         s_best_rank = 0;
         s_cstop = 0xffffffffu;
         if (HK) s_hk_prev = -1;
+        s_gs0 = gstop ? __hip_atomic_load(gstop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : FW_RANK_NONE;
     }
     unsigned long long cnt[FW_MAX_K + 1];
 #pragma unroll
@@ -778,6 +782,30 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     // Float64 log and an erfc (two out-of-line calls) to find that out.  Per-job thresholds of fz_nz: not computed (2 = never).
     const double rz_pos = !LOCAL ? thr[8] : 2.0, rz_neg = !LOCAL ? thr[9] : 2.0;
     __syncthreads();
+    // Another workgroup of this launch has already found the job's stop at an EARLIER rank than anything this segment holds: the merge
+    // takes the first stop (dh_merge: segments behind it are speculative), so nothing here can matter -- an empty record, no tests.
+    // (r05.  The same word ends running segments early: a stopping lane publishes its rank with an atomic minimum, lane 0 of every
+    // wavefront looks at the word every eighth test and pulls s_cstop to 0,
+    // which the lanes' own check in front of every test picks up.  Results, reference-order test counts and the committed job sequence
+    // do not change; `evaluated` does.)
+    if (gstop && s_gs0 < seg.start) {
+        if (tid == 0) {
+            FwSegOut o;
+            o.stop_rank = FW_RANK_NONE;
+            o.stop_stat = 0.0;
+            o.stop_pval = 1.0;
+            o.best_rank = 0;
+            o.best_stat = 0.0;
+            o.best_pval = -3.0;  // "no test": dh_merge ignores it (every real p is >= 0)
+            o.stop_df = 0;
+            o.stop_power = 0;
+            o.best_df = 0;
+            o.pad = 0;
+            o.evaluated = 0;
+            *out_rec = o;
+        }
+        return;
+    }
 #define ACCV(i) (LOCAL ? ((i) + 2) : (in_lds ? s_acc[(i)] : gacc[(i)]))
 #define CORV(u, v) cor[(size_t)(u) * p + (v)]
 // CORT(u, v): the entry a lane gathers where u is the index that moves from lane to lane.  r04 measured the transposed read
@@ -1372,8 +1400,13 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                         stop_stat = stat;
                         stop_p = fz_pval_slow(stat, zscale);
                         (void)__hip_atomic_fetch_min(&s_cstop, (unsigned int)(r - cbase), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (gstop) (void)__hip_atomic_fetch_min(gstop, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
                     }
+                }
+                if (gstop && lane == 0 && (my_done & 7u) == 0u) {  // (see the prologue; the wavefront waits for the word while the SIMD's other three run)
+                    if (__hip_atomic_load(gstop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cbase)
+                        (void)__hip_atomic_fetch_min(&s_cstop, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 // a lane of this workgroup has stopped at an earlier rank of the chunk: nothing behind it matters any more
                 // (the merge takes the first stop) -- r01/r02 profile: lanes running on behind the stop were the 18 % of
