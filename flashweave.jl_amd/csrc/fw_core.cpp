@@ -95,6 +95,9 @@ int fw_ctx_create(const fw_params *P, fw_ctx **out)
     if (P->n <= 0 || P->p <= 1) return fw_fail(nullptr, FW_ERR_ARG, "fw_ctx_create: need n > 0 and p > 1 (n=%d, p=%d)", P->n, P->p);
     if (P->max_k < 0 || P->max_k > FW_MAX_K)
         return fw_fail(nullptr, FW_ERR_LIMIT, "fw_ctx_create: max_k=%d outside [0, %d]", P->max_k, FW_MAX_K);
+    if (P->max_k > FW_MAX_K_FAST && (P->kind == FW_FZ || P->kind == FW_FZ_NZ) && !P->recursive_pcor)
+        return fw_fail(nullptr, FW_ERR_LIMIT, "fw_ctx_create: max_k=%d with recursive_pcor = 0 (conditioning on job-local Gram matrices serves max_k <= %d)",
+                       P->max_k, FW_MAX_K_FAST);
     if (!(P->alpha > 0.0 && P->alpha < 1.0)) return fw_fail(nullptr, FW_ERR_ARG, "fw_ctx_create: alpha must be in (0,1)");
     if (P->hps < 0) return fw_fail(nullptr, FW_ERR_ARG, "fw_ctx_create: hps must be >= 0");
     if (P->dense_rules && (P->kind == FW_FZ || P->kind == FW_FZ_NZ))
@@ -708,7 +711,7 @@ static uint64_t binom_sat(int64_t m, int t)
     const uint64_t SAT = 1ull << 62;
     long double r = 1.0L;
     for (int i = 1; i <= t; ++i) r = r * (long double)(m - t + i) / (long double)i;
-    if (r > 3.6e18L) return SAT;  // the intermediate v * (m - t + i) is up to t * C(m, t): stay below 2^64 / 5
+    if (r > (t > 5 ? 2.0e18L : 3.6e18L)) return SAT;  // the intermediate v * (m - t + i) is up to t * C(m, t): stay below 2^64 / 5 (t = 6, 7: the device's fz_binom_sat7 bound)
     uint64_t v = 1;
     for (int i = 1; i <= t; ++i) v = v * (uint64_t)(m - t + i) / (uint64_t)i;  // exact: product of i consecutive ints / i!
     return v;
@@ -812,7 +815,7 @@ static void finish_job(const fw_ctx *c, FwPoolJob &j, bool want_zs)
     j.done = true;
     j.out.n_zs = 0;
     if (!want_zs || j.no_zs) return;  // the HITON driver never looks at the conditioning set of the returned result
-    int s = 0, pos[FW_MAX_K] = {0, 0, 0, 0, 0};
+    int s = 0, pos[FW_MAX_K] = {0};
     unrank_host(j.best_rank, (int)j.acc.size(), c->P.max_k, &s, pos);  // conditioning set of the returned result
     j.out.n_zs = s;
     for (int q = 0; q < FW_MAX_K; ++q) j.out.zs[q] = q < s ? j.acc[pos[q]] : 0;

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "fw_internal.h"
+#define MI_MAX_K FW_MAX_K_FAST  // (conditioning sets of 6 and 7 variables: host job pool over the segment kernels of fw_mi.hip)
 #include "fw_mi_core.h"
 #include "fw_fz_core.h"
 #include "fw_unrank.h"

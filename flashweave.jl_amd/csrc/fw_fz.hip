@@ -436,6 +436,18 @@ __global__ __launch_bounds__(256) void fz_level0_exact_kernel(const int32_t *__r
 // ------------------------------------------------------------------------------------------------
 // 5. batch of single tests (tests.jl:108-160 / 250-265), one lane per test
 // ------------------------------------------------------------------------------------------------
+// conditioning sets of 6 and 7 variables (r05; tests.jl:311-343 has no cap): the same bottom-up form, instantiated for K = 6, 7 -- only in
+// the general-form kernels below (a 9 x 9 Float64 work matrix per lane: nothing for the table kernels' register budgets)
+__device__ __forceinline__ double fz_pcor_any7(const float *__restrict__ cor, int p, int X, int Y, const int *z, int k)
+{
+    switch (k) {
+        case 6: return fz_pcor_dp<6>(cor, p, X, Y, z);
+        case 7: return fz_pcor_dp<7>(cor, p, X, Y, z);
+        default: return fz_pcor_any(cor, p, X, Y, z, k);
+    }
+}
+
+template <bool K7>
 __global__ __launch_bounds__(256) void fz_test_batch_kernel(const float *__restrict__ cor, int p, long long m,
                                                             const int32_t *__restrict__ X, const int32_t *__restrict__ Y,
                                                             const long long *__restrict__ zoff,
@@ -445,9 +457,10 @@ __global__ __launch_bounds__(256) void fz_test_batch_kernel(const float *__restr
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= m) return;
     const int k = (int)(zoff[t + 1] - zoff[t]);
-    int z[FW_MAX_K];
-    for (int q = 0; q < FW_MAX_K; ++q) z[q] = (q < k) ? zflat[zoff[t] + q] : 0;
-    const double r = fz_pcor_any(cor, p, X[t], Y[t], z, k);
+    constexpr int KM = K7 ? FW_MAX_K : FW_MAX_K_FAST;
+    int z[KM];
+    for (int q = 0; q < KM; ++q) z[q] = (q < k) ? zflat[zoff[t] + q] : 0;
+    const double r = K7 ? fz_pcor_any7(cor, p, X[t], Y[t], z, k) : fz_pcor_any(cor, p, X[t], Y[t], z, k);
     fw_test_result o;
     o.stat = r;
     o.pval = fz_pval_dev(r, zscale);
@@ -498,6 +511,172 @@ __global__ __launch_bounds__(256, HIGHK ? ((TAB || LOCAL) ? FW_HIGHK_OCC : FW_HI
                                        n_obs_min, (!LOCAL && gstop) ? gstop + segs[s].pad : (unsigned long long *)nullptr);
         __syncthreads();  // the LDS state of the body is reused by the next segment
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 6b. test_subsets with max_k = 6, 7 (r05): the GENERAL FORM.  One workgroup per segment, every thread a run of consecutive ranks
+//     (unranked once by a linear scan with saturating binomials, then stepped lexicographically), every test the plain bottom-up
+//     pcor_rec (fz_pcor_any7) and its exact p-value -- no tables, no thresholds, no lazy maximum: first stop = smallest stopping rank,
+//     otherwise the `>=` maximum of the p-values with the later rank winning ties (tests.jl:326-341), reduced through LDS.  Same record
+//     as the table kernels write, merged by the same host code.  A slow path by design: max_k beyond 5 is rare (the reference's
+//     default is 3) and the host job pool drives it.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long fz_binom_sat7(int m, int t)  // C(m, t), t <= 7, saturating at 2^62
+{
+    if (t < 0 || m < t) return 0ull;
+    double est = 1.0;
+    for (int i = 1; i <= t; ++i) est = est * (double)(m - t + i) / (double)i;
+    if (est > 2.0e18) return 1ull << 62;  // (the exact product below holds t * C(m, t) at most)
+    unsigned long long v = 1ull;
+    for (int i = 1; i <= t; ++i) v = v * (unsigned long long)(m - t + i) / (unsigned long long)i;
+    return v;
+}
+
+template <bool LOCAL>
+__global__ __launch_bounds__(256) void fz_subsets_slow_kernel(const float *__restrict__ cor_g, int p_g, const FwSeg *__restrict__ segs,
+                                                              const int32_t *__restrict__ accflat, FwSegOut *__restrict__ out, int max_k,
+                                                              double alpha, double zscale_g, long long max_tests,
+                                                              const FwNzJob *__restrict__ recs, long long n_obs_min)
+{
+    __shared__ unsigned long long s_stop[256], s_br[256];
+    __shared__ double s_bp[256];
+    __shared__ unsigned int s_done[256];
+    const FwSeg seg = segs[blockIdx.x];
+    FwSegOut *out_rec = out + blockIdx.x;
+    const int tid = threadIdx.x, a = seg.acc_len;
+    const int32_t *gacc = accflat + seg.acc_off;
+    const float *cor = cor_g;
+    int p = p_g;
+    double zscale = zscale_g;
+    if (LOCAL) {
+        const FwNzJob *rec = recs + seg.pad;
+        cor = cor_g + rec->cor_off;
+        p = rec->m;
+        zscale = rec->zscale;
+        if ((long long)rec->nR < n_obs_min) {  // tests.jl:294-296: (0, 1, 0, false) with zero tests (the marker of fz_seg_body)
+            if (tid == 0) {
+                FwSegOut o;
+                o.stop_rank = 0;
+                o.stop_stat = 0.0;
+                o.stop_pval = 1.0;
+                o.best_rank = 0;
+                o.best_stat = 0.0;
+                o.best_pval = -1.0;
+                o.stop_df = -2;
+                o.stop_power = 0;
+                o.best_df = 0;
+                o.pad = 0;
+                o.evaluated = 0;
+                *out_rec = o;
+            }
+            return;
+        }
+    }
+    const int X = LOCAL ? 0 : seg.X, Y = LOCAL ? 1 : seg.Y;
+    unsigned long long cnt[FW_MAX_K + 1];
+    for (int s = FW_MAX_K; s >= 1; --s) cnt[s] = (s <= max_k) ? fz_binom_sat7(a, s) : 0ull;
+    const unsigned long long len = seg.end - seg.start, R = (len + 255ull) / 256ull;
+    const unsigned long long r0 = seg.start + (unsigned long long)tid * R;
+    unsigned long long r1 = r0 + R;
+    if (r1 > seg.end) r1 = seg.end;
+    unsigned long long my_stop = FW_RANK_NONE, my_br = 0ull;
+    double stop_stat = 0.0, stop_p = 0.0, my_bp = -1.0, my_bstat = 0.0;
+    unsigned int my_done = 0u;
+    if (r0 < seg.end) {
+        unsigned long long rem = r0;
+        int s = max_k;
+        while (s > 1 && rem >= cnt[s]) {
+            rem -= cnt[s];
+            --s;
+        }
+        int pos[FW_MAX_K];
+        for (int q = 0; q < FW_MAX_K; ++q) pos[q] = 0;
+        {   // position d = the first c whose block of C(a - 1 - c, s - d - 1) subsets holds the rank (the scan of unrank_host)
+            int prev = -1;
+            for (int d = 0; d < s; ++d) {
+                int c = prev + 1;
+                for (;;) {
+                    const unsigned long long with_c = fz_binom_sat7(a - 1 - c, s - d - 1);
+                    if (rem < with_c) break;
+                    rem -= with_c;
+                    ++c;
+                }
+                pos[d] = c;
+                prev = c;
+            }
+        }
+        for (unsigned long long r = r0; r < r1; ++r) {
+            int zs[FW_MAX_K];
+            for (int q = 0; q < FW_MAX_K; ++q) zs[q] = (q < s) ? (LOCAL ? pos[q] + 2 : gacc[pos[q]]) : 0;
+            const double stat = fz_pcor_any7(cor, p, X, Y, zs, s);
+            const double pv = fz_pval_slow(stat, zscale);
+            ++my_done;
+            if (!(pv < alpha) || (max_tests > 0 && r + 1ull >= (unsigned long long)max_tests)) {
+                my_stop = r;
+                stop_stat = stat;
+                stop_p = pv;
+                break;
+            }
+            if (pv >= my_bp) {  // tests.jl:338 `>=`: the later rank wins ties
+                my_bp = pv;
+                my_bstat = stat;
+                my_br = r;
+            }
+            int i = s - 1;
+            while (i >= 0 && pos[i] == a - s + i) --i;
+            if (i < 0) {
+                --s;
+                for (int q = 0; q < FW_MAX_K; ++q) pos[q] = q;
+                if (s < 1) break;
+            } else {
+                ++pos[i];
+                for (int j = i + 1; j < s; ++j) pos[j] = pos[j - 1] + 1;
+            }
+        }
+    }
+    s_stop[tid] = my_stop;
+    s_bp[tid] = my_bp;
+    s_br[tid] = my_br;
+    s_done[tid] = my_done;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            if (s_stop[tid + o] < s_stop[tid]) s_stop[tid] = s_stop[tid + o];
+            if (s_bp[tid + o] > s_bp[tid] || (s_bp[tid + o] == s_bp[tid] && s_br[tid + o] > s_br[tid])) {
+                s_bp[tid] = s_bp[tid + o];
+                s_br[tid] = s_br[tid + o];
+            }
+            s_done[tid] += s_done[tid + o];
+        }
+        __syncthreads();
+    }
+    const unsigned long long first = s_stop[0];
+    FwSegOut o;
+    o.stop_df = 0;
+    o.best_df = 0;
+    o.pad = 0;
+    o.evaluated = s_done[0];
+    if (first != FW_RANK_NONE) {
+        if (my_stop != first) return;
+        o.stop_rank = first;
+        o.stop_stat = stop_stat;
+        o.stop_pval = stop_p;
+        o.best_rank = 0;
+        o.best_stat = 0.0;
+        o.best_pval = -1.0;
+        o.stop_power = 1;
+        *out_rec = o;
+        return;
+    }
+    if (s_bp[0] < 0.0 ? tid != 0 : !(my_bp == s_bp[0] && my_br == s_br[0] && my_done > 0u)) return;  // the owner of the maximum writes (no test at all: thread 0)
+    o.stop_rank = FW_RANK_NONE;
+    o.stop_stat = 0.0;
+    o.stop_pval = 0.0;
+    o.best_rank = s_bp[0] < 0.0 ? 0ull : my_br;
+    o.best_stat = s_bp[0] < 0.0 ? 0.0 : my_bstat;
+    o.best_pval = s_bp[0] < 0.0 ? -1.0 : my_bp;
+    o.stop_power = 1;
+    *out_rec = o;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -689,9 +868,16 @@ int fwi_fz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y
     FW_HIP(ctx, hipMemcpyAsync(dY, Y, (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     if (nz > 0)
         FW_HIP(ctx, hipMemcpyAsync(ctx->d_acc.ptr, zflat, (size_t)nz * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(fz_test_batch_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_cor,
-                       ctx->P.p, (long long)m, dX, dY, dz, (const int32_t *)ctx->d_acc.ptr, fz_zscale(ctx),
-                       (fw_test_result *)ctx->d_out.ptr);
+    int kmax = 0;
+    for (int64_t t = 0; t < m; ++t) kmax = std::max<int>(kmax, (int)(zoff[t + 1] - zoff[t]));
+    if (kmax > FW_MAX_K_FAST)
+        hipLaunchKernelGGL(fz_test_batch_kernel<true>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_cor,
+                           ctx->P.p, (long long)m, dX, dY, dz, (const int32_t *)ctx->d_acc.ptr, fz_zscale(ctx),
+                           (fw_test_result *)ctx->d_out.ptr);
+    else
+        hipLaunchKernelGGL(fz_test_batch_kernel<false>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_cor,
+                           ctx->P.p, (long long)m, dX, dY, dz, (const int32_t *)ctx->d_acc.ptr, fz_zscale(ctx),
+                           (fw_test_result *)ctx->d_out.ptr);
     FW_HIP(ctx, hipGetLastError());
     FW_HIP(ctx, hipMemcpyAsync(out, ctx->d_out.ptr, (size_t)m * sizeof(fw_test_result), hipMemcpyDeviceToHost, ctx->stream));
     FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -766,7 +952,10 @@ int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *d_
         int rc = fz_ensure_thresholds(ctx, pb.launch_stream);
         if (rc) return rc;
     }
-    if (ctx->P.max_k > 3) {
+    if (ctx->P.max_k > FW_MAX_K_FAST) {  // conditioning sets of 6 and 7 variables: the general form for every segment
+        hipLaunchKernelGGL(fz_subsets_slow_kernel<false>, dim3((unsigned)nseg), dim3(256), 0, pb.launch_stream, ctx->d_cor, ctx->P.p, d_segs, d_acc,
+                           d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, (const FwNzJob *)nullptr, 0ll);
+    } else if (ctx->P.max_k > 3) {
         // segments [0, nseg_tab) belong to jobs with |accepted| <= FZ_HK_A: level-2 table kernel; the rest: generic form
         if (nseg_tab > 0)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false, true>), dim3((unsigned)nseg_tab), dim3(256), 0, pb.launch_stream,
@@ -1238,7 +1427,7 @@ __global__ __launch_bounds__(64) void fznz_single_kernel(const FwNzJob *__restri
     } else {
         int z[FW_MAX_K];
         for (int q = 0; q < FW_MAX_K; ++q) z[q] = 2 + q;
-        const double r = arena64 ? fznz_partialcor64(arena64 + rec.cor_off, rec.m) : fz_pcor_any(arena + rec.cor_off, rec.m, 0, 1, z, rec.acc_len);
+        const double r = arena64 ? fznz_partialcor64(arena64 + rec.cor_off, rec.m) : fz_pcor_any7(arena + rec.cor_off, rec.m, 0, 1, z, rec.acc_len);
         o.stat = r;
         o.pval = fz_pval_dev(r, rec.zscale);
         o.df = 0;
@@ -1426,7 +1615,11 @@ int fwi_fznz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *
 {
     if (nseg == 0) return FW_OK;
     FW_HIP(ctx, hipEventRecord(pb.ev0, pb.launch_stream));
-    if (ctx->P.max_k > 3)
+    if (ctx->P.max_k > FW_MAX_K_FAST)  // conditioning sets of 6 and 7 variables: the general form on the job-local matrices
+        hipLaunchKernelGGL(fz_subsets_slow_kernel<true>, dim3((unsigned)nseg), dim3(256), 0, pb.launch_stream, (const float *)ctx->d_arena.ptr, 0, d_segs,
+                           d_acc, d_out, ctx->P.max_k, ctx->P.alpha, 0.0, (long long)ctx->P.max_tests, (const FwNzJob *)ctx->d_nzrecs.ptr,
+                           (long long)ctx->n_obs_min_eff);
+    else if (ctx->P.max_k > 3)
         hipLaunchKernelGGL((fz_subsets_seg_kernel<true, true, false>), dim3((unsigned)nseg), dim3(256), 0, pb.launch_stream,
                            (const float *)ctx->d_arena.ptr, 0, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, 0.0,
                            (long long)ctx->P.max_tests, (const double *)nullptr, (const FwNzJob *)ctx->d_nzrecs.ptr,

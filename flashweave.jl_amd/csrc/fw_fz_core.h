@@ -761,9 +761,9 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
         if (HK) s_hk_prev = -1;
         s_gs0 = gstop ? __hip_atomic_load(gstop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : FW_RANK_NONE;
     }
-    unsigned long long cnt[FW_MAX_K + 1];
+    unsigned long long cnt[FW_MAX_K_FAST + 1];
 #pragma unroll
-    for (int s = FW_MAX_K; s >= 1; --s)  // (size-3 table variant: |accepted| <= 512, sizes <= 3 -- 32-bit binomials, no 64-bit division in every workgroup's prologue)
+    for (int s = FW_MAX_K_FAST; s >= 1; --s)  // (size-3 table variant: |accepted| <= 512, sizes <= 3 -- 32-bit binomials, no 64-bit division in every workgroup's prologue)
         cnt[s] = (s <= max_k) ? (TAB3 ? (unsigned long long)fw_binom32(a, s) : binom_u64(a, s)) : 0ull;
     // significance thresholds on |r| (see fz_thresholds_kernel): outside [lo, hi] the verdict of p < alpha is certain
     const double rlo_pos = thr[0], rhi_pos = thr[1], rlo_neg = thr[2], rhi_neg = thr[3];
@@ -844,7 +844,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
             }
             if (s0 >= 4) {
                 if (tid == 0) {
-                    int q[FW_MAX_K];
+                    int q[FW_MAX_K_FAST];
                     fw_unrank_comb32((uint32_t)rem0, a, s0, q);  // a <= FZ_HK_A: everything fits 32 bits
                     int i = q[0], j = q[1];
                     // rank (inside the size-s0 enumeration) behind the last subset of sub-block (i, j)
@@ -971,7 +971,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 if (l1_ok && !(fz_dbg_flags & 2)) {
                     const int i = i0;
                     if (tid == 0) {
-                        int q[FW_MAX_K];
+                        int q[FW_MAX_K_FAST];
                         unrank_comb(rem0, a, s0, q);
                         int j = q[1], k = q[2];
                         const int l0 = q[3];
@@ -1116,7 +1116,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 unsigned long long last3 = cend;
                 last3 = (last3 < c3 ? last3 : c3) - 1ull;
                 if (tid == 0 || tid == 64) {
-                    int q[FW_MAX_K];
+                    int q[FW_MAX_K_FAST];
                     fw_unrank_comb32((uint32_t)(tid == 0 ? cbase : last3), a, 3, q);  // a <= FZ_TAB_A: 32-bit form
                     s_blk[tid == 0 ? 0 : 1] = q[0];
                 }
@@ -1172,9 +1172,9 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 rem -= cnt[s];
                 --s;
             }
-            int pos[FW_MAX_K];
+            int pos[FW_MAX_K_FAST];
 #pragma unroll
-            for (int q = 0; q < FW_MAX_K; ++q) pos[q] = 0;
+            for (int q = 0; q < FW_MAX_K_FAST; ++q) pos[q] = 0;
             if (TAB || (L1T && a <= FW_UNRANK32_A5))  // |accepted| <= FZ_TAB_A with max_k <= 3, or <= 128 with max_k <= 5: the 32-bit unranking (fw_unrank.h)
                 fw_unrank_comb32((uint32_t)rem, a, s, pos);
             else
@@ -1363,9 +1363,9 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                     stat = s == 5 ? fz_l1t_stat<5>(cor, p, s_l1, s_l1f, s_acc, pos, s_l1a, s_l1af != 0, l1_clean)
                                   : fz_l1t_stat<4>(cor, p, s_l1, s_l1f, s_acc, pos, s_l1a, s_l1af != 0, l1_clean);
                 } else if (HIGHK && !HK) {
-                    int zs[FW_MAX_K];
+                    int zs[FW_MAX_K_FAST];
 #pragma unroll
-                    for (int q = 0; q < FW_MAX_K; ++q) zs[q] = (q < s) ? ACCV(pos[q]) : 0;
+                    for (int q = 0; q < FW_MAX_K_FAST; ++q) zs[q] = (q < s) ? ACCV(pos[q]) : 0;
                     stat = fz_pcor_any(cor, p, X, Y, zs, s);
                 } else {
                     stat = 0.0;
@@ -1563,7 +1563,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 if (i < 0) {
                     --s;
 #pragma unroll
-                    for (int q = 0; q < FW_MAX_K; ++q) pos[q] = q;
+                    for (int q = 0; q < FW_MAX_K_FAST; ++q) pos[q] = q;
                     chg = 0;
                     if (s < 1) break;  // end of the enumeration (r1 never exceeds it)
                 } else {

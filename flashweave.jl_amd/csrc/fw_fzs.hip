@@ -24,7 +24,7 @@
 #include "fw_internal.h"
 #include "fw_unrank.h"
 
-#define FZS_MAXM (FW_MAX_K + 2)
+#define FZS_MAXM (FW_MAX_K_FAST + 2)
 
 namespace {
 
@@ -780,9 +780,9 @@ int fwi_fzs_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *
     hipLaunchKernelGGL((fzs_test_batch_kernel<KK, TT>), grid, dim3(256), 0, ctx->stream, P, (long long)m, dX, dY, dz,        \
                        (const int32_t *)ctx->d_acc.ptr, (fw_test_result *)ctx->d_out.ptr)
     if (fzs_hold_xy(ctx)) {
-        if (kmax <= 3) FZS_BATCH(3, 8); else FZS_BATCH(FW_MAX_K, 8);
+        if (kmax <= 3) FZS_BATCH(3, 8); else FZS_BATCH(FW_MAX_K_FAST, 8);
     } else {
-        if (kmax <= 3) FZS_BATCH(3, 0); else FZS_BATCH(FW_MAX_K, 0);
+        if (kmax <= 3) FZS_BATCH(3, 0); else FZS_BATCH(FW_MAX_K_FAST, 0);
     }
 #undef FZS_BATCH
     FW_HIP(ctx, hipGetLastError());
@@ -824,11 +824,11 @@ int fwi_fzs_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32
                        d_out, ctx->P.max_k, ctx->P.alpha, (long long)ctx->P.max_tests, (const FwNzJob *)ctx->d_nzrecs.ptr,         \
                        (const double *)ctx->d_arena.ptr, lds_m)
     if (gram) {
-        if (ctx->P.max_k <= 3) FZS_SEG(3, 0, true); else FZS_SEG(FW_MAX_K, 0, true);
+        if (ctx->P.max_k <= 3) FZS_SEG(3, 0, true); else FZS_SEG(FW_MAX_K_FAST, 0, true);
     } else if (fzs_hold_xy(ctx)) {
-        if (ctx->P.max_k <= 3) FZS_SEG(3, 8, false); else FZS_SEG(FW_MAX_K, 8, false);
+        if (ctx->P.max_k <= 3) FZS_SEG(3, 8, false); else FZS_SEG(FW_MAX_K_FAST, 8, false);
     } else {
-        if (ctx->P.max_k <= 3) FZS_SEG(3, 0, false); else FZS_SEG(FW_MAX_K, 0, false);
+        if (ctx->P.max_k <= 3) FZS_SEG(3, 0, false); else FZS_SEG(FW_MAX_K_FAST, 0, false);
     }
 #undef FZS_SEG
     FW_HIP(ctx, hipGetLastError());
@@ -859,7 +859,7 @@ int fwi_fzs_segments_nz(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const in
                            ctx->P.max_k, ctx->P.alpha, (long long)ctx->P.max_tests, (const FwNzJob *)ctx->d_nzrecs.ptr,
                            (const double *)ctx->d_arena.ptr, lds_m);
     else
-        hipLaunchKernelGGL((fzs_subsets_seg_kernel<FW_MAX_K, 0, true>), dim3((unsigned)nseg), dim3(256), lds, pb.launch_stream, P, d_segs, d_acc,
+        hipLaunchKernelGGL((fzs_subsets_seg_kernel<FW_MAX_K_FAST, 0, true>), dim3((unsigned)nseg), dim3(256), lds, pb.launch_stream, P, d_segs, d_acc,
                            d_out, ctx->P.max_k, ctx->P.alpha, (long long)ctx->P.max_tests, (const FwNzJob *)ctx->d_nzrecs.ptr,
                            (const double *)ctx->d_arena.ptr, lds_m);
     FW_HIP(ctx, hipGetLastError());

@@ -195,13 +195,15 @@ int devx_allgather(void *user, int64_t n, const int32_t *tgt, const int32_t *nbr
 // FW_MI_SCHED=0 keeps the per-round loop (A/B runs, tests/test_gpu_mi.py compares the two).
 static bool mi_schedule_on_device(const fw_ctx *c, const fw_learn_opts &opt, bool has_exchange, int nt)
 {
-    if (!(c->P.kind == FW_MI || c->P.kind == FW_MI_NZ) || c->mi_generic || has_exchange || opt.world_size > 1) return false;
+    if (!(c->P.kind == FW_MI || c->P.kind == FW_MI_NZ) || c->mi_generic || has_exchange || opt.world_size > 1 || c->P.max_k > FW_MAX_K_FAST) return false;
     if (!c->d_cand || !c->d_nb_idx || !c->d_nb_off) return false;
     const char *hh = fw_knob("FW_HOST_HITON"), *mr = fw_knob("FW_MI_ROUNDS"), *sc = fw_knob("FW_MI_SCHED"), *mt = fw_knob("FW_DEV_MIN_TARGETS");
     if ((hh && atoi(hh) == 1) || (mr && atoi(mr) != 0) || (sc && atoi(sc) == 0)) return false;
     const int R = (opt.round_size <= 0 || opt.round_size > nt) ? nt : opt.round_size;
     const int min_targets = mt ? atoi(mt) : 256;
-    return R >= min_targets;
+    // (R = 1 is the reference's single_il master, whose first round holds TWO targets -- interleaved.jl:62,76-86: the per-round loop
+    // below knows that rule, the device schedule cuts rounds of exactly R; r05 fuzz, 3 of 4 500 networks with the threshold forced to 1)
+    return R >= min_targets && R >= 2;
 }
 
 extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allgather_fn allgather, void *user, int64_t *n_edges_out);
@@ -335,7 +337,9 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
                 // twice the candidates)
                 nz_dev = fwi_fznz_dev_limits(c, (int)(opt.feed_forward ? 2 * dmax : dmax) + 2) == FW_OK && c->P.n >= c->n_obs_min_eff;
             }
-            const bool use_dev = !host_only && (c->P.kind != FW_FZ_NZ || nz_dev) && !stream && !no_power && !c->mi_generic && n_my >= min_targets;
+            // (conditioning sets of 6 and 7 variables: general-form kernels, host job pool)
+            const bool use_dev = !host_only && (c->P.kind != FW_FZ_NZ || nz_dev) && !stream && !no_power && !c->mi_generic && n_my >= min_targets &&
+                                 c->P.max_k <= FW_MAX_K_FAST;
             const bool dev_cands = use_dev && c->d_cand != nullptr;  // candidate order already built on the device (fw_bh.hip)
             if (!dev_cands)
                 if (int rc = fwi_nb_host_ensure(c)) return rc;

@@ -37,6 +37,10 @@ struct FwJob {
 };
 
 // Device-side result of one job (mirrors fw_subsets_result without frac)
+// Conditioning sets of 6 and 7 variables (ABI 6: FW_MAX_K = 7; tests.jl:311-343 has no cap) take general-form kernels through the host job
+// pool; every table kernel, the device rounds and the persistent discrete kernel size their arrays for FW_MAX_K_FAST.
+#define FW_MAX_K_FAST 5
+
 struct FwJobOut {
     double stat;
     double pval;
@@ -240,6 +244,7 @@ int fwi_fznz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> 
                     std::vector<double> &pval, int64_t *m_reliable, FwL0Dev *dev);
 int fwi_fznz_submatrices(fw_ctx *ctx, int64_t njobs, const FwNzJob *recs_host, size_t arena_floats, const int32_t *d_acc,
                          hipStream_t stream, bool f64 = false);
+int fwi_mi_big_limits(fw_ctx *ctx, int k);  // FW_OK if discrete tests with k (6, 7) conditioning variables fit the large LDS table
 int fwi_fznz_dev_limits(fw_ctx *ctx, int m_max);  // FW_OK if a job of m_max variables fits the sub-matrix kernel's LDS
 int fwi_fznz_submatrices_dev(fw_ctx *ctx, int nslots, FwNzJob *d_recs, const int32_t *d_acc, float *d_arena, int m_max, bool any_long, hipStream_t stream);
 int fwi_fznz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, const unsigned *d_ns,

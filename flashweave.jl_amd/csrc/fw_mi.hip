@@ -34,18 +34,22 @@ static __device__ __forceinline__ MiRes mi_test_any(const MiDev &P, int X, int Y
         return mi_test_core<L, NXY, PRE, WIDE>(P, X, Y, zs, k, tab);
 }
 #define MI_TAB_U16(L, WIDE) ((L) == 0 ? 2 * MIG_TAB32 : ((WIDE) ? 2 * MI_TAB16 : MI_TAB16))
+// conditioning sets of 6 and 7 variables (r05, BIG = true): 3^7 strata x 6 entries (2 x 2 sub-table + total) -- 26 KB per wavefront;
+// a 3 x 3 sub-table fits up to 3^6 strata (fwi_mi_big_limits)
+#define MI_TAB16_BIG 13312
+#define MI_TAB_SEL(L, WIDE, BIG) ((BIG) ? MI_TAB16_BIG : MI_TAB_U16(L, WIDE))
 
 // ------------------------------------------------------------------------------------------------
 // batch of single tests: one wave per test
 // ------------------------------------------------------------------------------------------------
-template <int L, int NXY, bool PRE, bool WIDE>
+template <int L, int NXY, bool PRE, bool WIDE, bool BIG = false>
 __global__ __launch_bounds__(256) void mi_test_batch_kernel(MiDev P, long long m, const int32_t *__restrict__ X,
                                                             const int32_t *__restrict__ Y,
                                                             const long long *__restrict__ zoff,
                                                             const int32_t *__restrict__ zflat,
                                                             fw_test_result *__restrict__ out)
 {
-    __shared__ unsigned short s_tab[4][MI_TAB_U16(L, WIDE)];
+    __shared__ unsigned short s_tab[4][MI_TAB_SEL(L, WIDE, BIG)];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long t = (long long)blockIdx.x * 4 + wave;
     if (t >= m) return;
@@ -73,12 +77,12 @@ __global__ __launch_bounds__(256) void mi_test_batch_kernel(MiDev P, long long m
 // ------------------------------------------------------------------------------------------------
 #define MI_RUN 4
 
-template <int L, int NXY, bool PRE, bool WIDE>
+template <int L, int NXY, bool PRE, bool WIDE, bool BIG = false>
 __device__ __forceinline__ void mi_seg_body(const MiDev &P, const FwSeg *__restrict__ segs, const int32_t *__restrict__ accflat,
                                             FwSegOut *__restrict__ out, int max_k, double alpha, long long max_tests,
                                             const unsigned sidx /* segment this workgroup evaluates */, int need_p)
 {
-    __shared__ unsigned short s_tab[4][MI_TAB_U16(L, WIDE)];
+    __shared__ unsigned short s_tab[4][MI_TAB_SEL(L, WIDE, BIG)];
     __shared__ unsigned long long s_stop[4], s_br[4];
     __shared__ double s_sstat[4], s_sp[4], s_bp[4], s_bstat[4];
     __shared__ int s_sdf[4], s_spow[4], s_bdf[4];
@@ -89,7 +93,7 @@ __device__ __forceinline__ void mi_seg_body(const MiDev &P, const FwSeg *__restr
     const int32_t *gacc = accflat + seg.acc_off;
     unsigned long long cnt[MI_MAX_K + 1];
 #pragma unroll
-    for (int s = MI_MAX_K; s >= 1; --s) cnt[s] = (s <= max_k) ? fw_binom_u64(a, s) : 0ull;
+    for (int s = MI_MAX_K; s >= 1; --s) cnt[s] = (s <= max_k) ? (BIG ? fw_binom_any(a, s) : fw_binom_u64(a, s)) : 0ull;
     const unsigned long long NONE = FW_RANK_NONE;
     // running best of the segment (kept redundantly by every thread: values come from LDS broadcasts)
     double best_p = -1.0, best_stat = 0.0;
@@ -115,7 +119,10 @@ __device__ __forceinline__ void mi_seg_body(const MiDev &P, const FwSeg *__restr
             int pos[MI_MAX_K];
 #pragma unroll
             for (int q = 0; q < MI_MAX_K; ++q) pos[q] = 0;
-            fw_unrank_comb(rem, a, s, pos);
+            if (BIG)
+                fw_unrank_scan(rem, a, s, pos);
+            else
+                fw_unrank_comb(rem, a, s, pos);
             MiBest mb;
             mb.p = -3.0;
             mb.stat = mb.g = 0.0;
@@ -223,7 +230,7 @@ __device__ __forceinline__ void mi_seg_body(const MiDev &P, const FwSeg *__restr
 
 // Host-driven rounds: one workgroup per segment (ns_dev == nullptr); device-driven rounds (fw_devhiton.hip): a fixed
 // grid covers the device-built segment list whose live length is *ns_dev.
-template <int L, int NXY, bool PRE, bool WIDE>
+template <int L, int NXY, bool PRE, bool WIDE, bool BIG = false>
 __global__ __launch_bounds__(256) void mi_subsets_seg_kernel(MiDev P, const FwSeg *__restrict__ segs,
                                                              const int32_t *__restrict__ accflat,
                                                              FwSegOut *__restrict__ out, int max_k, double alpha,
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(256) void mi_subsets_seg_kernel(MiDev P, const FwSe
     // no grid-stride loop here: with the body inside a loop the compiler hoists its invariants and needs 254 VGPRs
     // (occupancy 1 instead of 3); the device-driven grid covers the whole segment list and surplus workgroups leave
     if (ns_dev && blockIdx.x >= *ns_dev) return;
-    mi_seg_body<L, NXY, PRE, WIDE>(P, segs, accflat, out, max_k, alpha, max_tests, blockIdx.x, need_p);
+    mi_seg_body<L, NXY, PRE, WIDE, BIG>(P, segs, accflat, out, max_k, alpha, max_tests, blockIdx.x, need_p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1472,6 +1479,8 @@ int fwi_mi_upload(fw_ctx *ctx, const int64_t *colptr, const int32_t *rowval, con
     if (generic) return mig_upload(ctx, colptr, rowval, nzval);
     ctx->L = maxv_all + 1;  // types.jl:89,110
     if (ctx->L < 2) ctx->L = 2;
+    ctx->mi_nxy = (ctx->L == 3 && ctx->P.kind == FW_MI) ? 3 : 2;
+    if (int rcb = fwi_mi_big_limits(ctx, ctx->P.max_k)) return rcb;
     // 9-cell tables only where X / Y can take three values inside the sub-table: "mi" on data that holds the value 2
     // (nz-adjusted tests drop the zero level of such a variable, presence / absence data has two values anyway)
     ctx->mi_nxy = (ctx->L == 3 && ctx->P.kind == FW_MI) ? 3 : 2;
@@ -1757,6 +1766,21 @@ int fwi_mi_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const i
     return FW_OK;
 }
 
+// conditioning sets of 6 and 7 variables (r05): L^k strata x (sub-table cells + total, whole words) 16-bit entries must fit MI_TAB16_BIG,
+// and the large table has no 32-bit-count form
+int fwi_mi_big_limits(fw_ctx *ctx, int k)
+{
+    if (k <= FW_MAX_K_FAST || ctx->mi_generic) return FW_OK;
+    if (ctx->P.n > 65535) return fw_fail(ctx, FW_ERR_LIMIT, "discrete tests with %d conditioning variables need n <= 65535 (got %d)", k, ctx->P.n);
+    long long strata = 1;
+    for (int j = 0; j < k; ++j) strata *= ctx->L;
+    const int nct16 = (ctx->mi_nxy * ctx->mi_nxy + 1 + 1) & ~1;
+    if (strata * nct16 > MI_TAB16_BIG)
+        return fw_fail(ctx, FW_ERR_LIMIT, "discrete tests with %d conditioning variables on %d-level data with a %d x %d sub-table need %lld table entries (limit %d)", k,
+                       ctx->L, ctx->mi_nxy, ctx->mi_nxy, strata * nct16, MI_TAB16_BIG);
+    return FW_OK;
+}
+
 int fwi_mi_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y, const int64_t *zoff,
                       const int32_t *zflat, fw_test_result *out)
 {
@@ -1790,7 +1814,14 @@ int fwi_mi_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y
                        (long long)m, dX, dY, dz, (const int32_t *)ctx->d_acc.ptr, (fw_test_result *)ctx->d_out.ptr)
     const bool pre = ctx->P.n <= MI_PRE_N && kmax <= MI_PRE_K;  // the batch's own largest conditioning set decides here
     const bool wide = ctx->P.n > 65535;
-    if (ctx->mi_generic) {
+    if (kmax > FW_MAX_K_FAST && !ctx->mi_generic) {  // conditioning sets of 6 and 7 variables: the large table
+        if (int rcb = fwi_mi_big_limits(ctx, kmax)) return rcb;
+#define MI_TB_LAUNCH_BIG(LL, NN)                                                                                                             \
+    hipLaunchKernelGGL((mi_test_batch_kernel<LL, NN, false, false, true>), dim3((unsigned)((m + 3) / 4)), dim3(256), 0, ctx->stream, Pd, \
+                       (long long)m, dX, dY, dz, (const int32_t *)ctx->d_acc.ptr, (fw_test_result *)ctx->d_out.ptr)
+        if (ctx->L == 2) MI_TB_LAUNCH_BIG(2, 2); else if (ctx->mi_nxy == 2) MI_TB_LAUNCH_BIG(3, 2); else MI_TB_LAUNCH_BIG(3, 3);
+#undef MI_TB_LAUNCH_BIG
+    } else if (ctx->mi_generic) {
         MI_TB_LAUNCH(0, 2, false, false);
     } else if (ctx->L == 2) {
         if (wide) MI_TB_LAUNCH(2, 2, false, true); else if (pre) MI_TB_LAUNCH(2, 2, true, false); else MI_TB_LAUNCH(2, 2, false, false);
@@ -1826,7 +1857,13 @@ int fwi_mi_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_
                        d_acc, d_out, ctx->P.max_k, ctx->P.alpha, (long long)ctx->P.max_tests, (const unsigned *)nullptr, 1)
     const bool pre = ctx->P.n <= MI_PRE_N && ctx->P.max_k <= MI_PRE_K;
     const bool wide = ctx->P.n > 65535;  // 32-bit cell counts and tables (fw_mi_core.h)
-    if (ctx->mi_generic) {
+    if (ctx->P.max_k > FW_MAX_K_FAST && !ctx->mi_generic) {  // conditioning sets of 6 and 7 variables: the large table (fwi_mi_big_limits holds)
+#define MI_SEG_LAUNCH_BIG(LL, NN)                                                                                                           \
+    hipLaunchKernelGGL((mi_subsets_seg_kernel<LL, NN, false, false, true>), dim3((unsigned)nseg), dim3(256), 0, pb.launch_stream, mi_dev_subsets(ctx), \
+                       d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, (long long)ctx->P.max_tests, (const unsigned *)nullptr, 1)
+        if (ctx->L == 2) MI_SEG_LAUNCH_BIG(2, 2); else if (ctx->mi_nxy == 2) MI_SEG_LAUNCH_BIG(3, 2); else MI_SEG_LAUNCH_BIG(3, 3);
+#undef MI_SEG_LAUNCH_BIG
+    } else if (ctx->mi_generic) {
         MI_SEG_LAUNCH(0, 2, false, false);
     } else if (ctx->L == 2) {
         if (wide) MI_SEG_LAUNCH(2, 2, false, true); else if (pre) MI_SEG_LAUNCH(2, 2, true, false); else MI_SEG_LAUNCH(2, 2, false, false);

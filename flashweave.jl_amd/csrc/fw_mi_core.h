@@ -18,7 +18,9 @@
 #pragma once
 #include "fw_internal.h"
 
-#define MI_MAX_K FW_MAX_K
+#ifndef MI_MAX_K
+#define MI_MAX_K FW_MAX_K  // (fw_devhiton.hip: FW_MAX_K_FAST -- the persistent kernel serves max_k <= 5)
+#endif
 #define MI_PRE_N 6144  // samples up to which a lane holds every word of a column in registers (3 x 64 x 32 rows)
 #define MI_PRE_K 3     // ... and the largest conditioning set that form serves
 #define MI_TAB16 2432  // u16 entries of one wave's LDS table: 3^5 strata x 10 (9 cells + stratum total)

@@ -36,6 +36,34 @@ FW_HD unsigned long long fw_binom_u64(long long m, int t)
     }
 }
 
+// general forms for conditioning sets of 6 and 7 variables (r05; slow paths only): C(m, t) by the running product, saturating at 2^62
+// (the intermediate holds t * C(m, t)), and the unranking by a linear scan over the positions
+FW_HD unsigned long long fw_binom_any(long long m, int t)
+{
+    if (t < 0 || m < t) return 0ull;
+    double est = 1.0;
+    for (int i = 1; i <= t; ++i) est = est * (double)(m - t + i) / (double)i;
+    if (est > 2.0e18) return 1ull << 62;
+    unsigned long long v = 1ull;
+    for (int i = 1; i <= t; ++i) v = v * (unsigned long long)(m - t + i) / (unsigned long long)i;
+    return v;
+}
+FW_HD void fw_unrank_scan(unsigned long long rem, int a, int s, int *pos)
+{
+    int prev = -1;
+    for (int d = 0; d < s; ++d) {
+        int c = prev + 1;
+        for (;;) {
+            const unsigned long long with_c = fw_binom_any(a - 1 - c, s - d - 1);
+            if (rem < with_c) break;
+            rem -= with_c;
+            ++c;
+        }
+        pos[d] = c;
+        prev = c;
+    }
+}
+
 // reference form: binary search per position (3 x log2(a) binomials; kept for the host-side check)
 FW_HD void fw_unrank_bsearch(unsigned long long rem, int a, int s, int *pos)
 {

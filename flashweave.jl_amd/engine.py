@@ -7,7 +7,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 FW_MI, FW_MI_NZ, FW_FZ, FW_FZ_NZ = 0, 1, 2, 3
-FW_MAX_K = 5
+FW_MAX_K = 7
 _KINDS = {"mi": FW_MI, "mi_nz": FW_MI_NZ, "fz": FW_FZ, "fz_nz": FW_FZ_NZ}
 
 TestResult = namedtuple("TestResult", "stat pval df suff_power")  # src/types.jl:140-145

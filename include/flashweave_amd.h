@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 5 /* 2: fw_params.recursive_pcor, fw_level0_sharded; 3: device-resident exchange (fw_dev_exchange), sharded cor; 4: fw_params.no_cor_mat; 5: fw_selftest, fw_counters.gram_*, fw_comm_* (library-side RCCL) */
+#define FW_ABI_VERSION 6 /* 2: fw_params.recursive_pcor, fw_level0_sharded; 3: device-resident exchange (fw_dev_exchange), sharded cor; 4: fw_params.no_cor_mat; 5: fw_selftest, fw_counters.gram_*, fw_comm_* (library-side RCCL); 6: FW_MAX_K 5 -> 7 (fw_subsets_result.zs grows) */
 
 /* test kinds: src/types.jl:61-72 (test_name "mi" / "mi_nz" / "fz") */
 #define FW_MI 0
@@ -42,7 +42,8 @@ extern "C" {
 #define FW_ERR_LIMIT (-5)   /* a documented capacity limit was exceeded (max_k, table size) */
 #define FW_ERR_NOMEM (-6)
 
-#define FW_MAX_K 5 /* largest conditioning-set size the kernels support */
+#define FW_MAX_K 7 /* largest conditioning-set size (tests.jl:311-343 has no cap): up to 5 on the table / persistent kernels, 6 and 7 (ABI 6) on
+                      general-form kernels through the host job pool; not with recursive_pcor = 0 */
 
 typedef struct fw_ctx fw_ctx;
 

@@ -30,7 +30,7 @@ def test_header_symbols_exported(lib):
 
 def test_abi_version_and_defaults(lib):
     from flashweave_jl_amd.engine import _Params
-    assert lib.fw_abi_version() == 5  # 3: fw_dev_exchange, fw_level0_sharded_dev, fw_use_cor_buffer / fw_compute_cor_mat_rows / fw_cor_mat_ready; 4: fw_params.no_cor_mat
+    assert lib.fw_abi_version() == 6  # 6: FW_MAX_K 7; 3: fw_dev_exchange, fw_level0_sharded_dev, fw_use_cor_buffer / fw_compute_cor_mat_rows / fw_cor_mat_ready; 4: fw_params.no_cor_mat
     P = _Params()
     lib.fw_params_default(ctypes.byref(P), fw.FW_FZ, 100, 10)
     # learn_network defaults, reference src/learning.jl:466-473
