@@ -177,6 +177,7 @@ int fw_ctx_destroy(fw_ctx *c)
     free_dev(c->d_bh);
     free_dev(c->d_l0m_i);
     free_dev(c->d_l0m_d);
+    for (FwDevBuf &b : c->d_mig_tab) free_dev(b);
     for (int q = 0; q < FW_DH_MAX_CHAINS; ++q) {
         free_dev(c->d_dh[q]);
         free_pin(c->h_dh[q]);

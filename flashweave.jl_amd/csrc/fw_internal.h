@@ -162,6 +162,10 @@ struct fw_ctx {
     int32_t *d_levels = nullptr, *d_maxvals = nullptr;
     unsigned char *d_vals = nullptr;  // generic discrete form (a value above 2): one byte per (variable, sample), [p][n]; null otherwise
     bool mi_generic = false;
+    // generic form, tables beyond the LDS of a wavefront (r05: more than 8 levels, or 4-8 levels at a max_k the LDS table does not hold):
+    // one table per wavefront of a launch in device memory, launches cut so that the tables of one fit mig_gtab_bytes_max
+    long long mig_gtab_words = 0;  // words of one table (0: the table lives in LDS)
+    FwDevBuf d_mig_tab[3];  // [the engine's own stream, pool 0, pool 1]: two pools can be in flight
     bool fznz_lds_raised = false;  // fznz_submat_kernel's dynamic-LDS limit was raised on this context's device (a property of (function, device): one flag per context, set under the context's own launches)
     float *d_xlnx = nullptr;       // [x ln x | ln x] for x = 0..n (Float32 tables of the discrete level-0 screen)
     int32_t *d_firstnz = nullptr;  // per column: index of the first non-zero sample (n if none)

@@ -29,7 +29,7 @@ template <int L, int NXY, bool PRE, bool WIDE>
 static __device__ __forceinline__ MiRes mi_test_any(const MiDev &P, int X, int Y, const MiZs &zs, int k, unsigned short *tab)
 {
     if constexpr (L == 0)
-        return mi_test_core_gen(P, X, Y, zs, k, (unsigned *)tab);
+        return mi_test_core_gen(P, X, Y, zs, k, P.gtab ? P.gtab + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * P.gtab_words : (unsigned *)tab);
     else
         return mi_test_core<L, NXY, PRE, WIDE>(P, X, Y, zs, k, tab);
 }
@@ -1251,6 +1251,8 @@ static MiDev mi_dev(const fw_ctx *ctx)
     P.prof = nullptr;
     P.view = 0;
     P.vals = ctx->mi_generic ? ctx->d_vals : nullptr;
+    P.gtab = nullptr;
+    P.gtab_words = 0ull;
     static const int rowk = fw_knob("FW_MI_ROWK") ? atoi(fw_knob("FW_MI_ROWK")) : 2;  // 99: popcount form only (A/B)
     P.rowk = rowk;
     return P;
@@ -1262,6 +1264,23 @@ static MiDev mi_dev(const fw_ctx *ctx)
 // same batch / segment kernels as the bit-plane forms (template value L = 0), HITON-PC through the host job pool, level 0 through
 // mig_level0_kernel (one wavefront per pair).  Limits: values <= 7, L^max_k (L^2 + 1) <= MIG_TAB32 words of LDS per wavefront.
 static double host_igamc(double a, double x);
+#define MIG_GTAB_MAX (64ll << 20)          // words of one device-memory table
+#define MIG_GTAB_BYTES (1ll << 30)         // device memory the tables of ONE launch may take: launches are cut to fit
+// workgroups (of four wavefronts, one table each) a launch of the generic form may hold: all of them with LDS tables, else what fits
+static int64_t mig_launch_wgs(fw_ctx *ctx, int64_t want)
+{
+    if (!ctx->mi_generic || ctx->mig_gtab_words == 0) return want;
+    const int64_t fit = MIG_GTAB_BYTES / (4 * 4 * ctx->mig_gtab_words);
+    return std::max<int64_t>(1, std::min<int64_t>(want, fit));
+}
+static int mig_dev_tables(fw_ctx *ctx, MiDev &P, int64_t wgs, int which /* 0: the engine's stream, 1 / 2: pool 0 / 1 */)
+{
+    if (!ctx->mi_generic || ctx->mig_gtab_words == 0) return FW_OK;
+    if (int rc = fw_dev_reserve(ctx, ctx->d_mig_tab[which], (size_t)wgs * 4 * (size_t)ctx->mig_gtab_words * sizeof(unsigned))) return rc;
+    P.gtab = (unsigned *)ctx->d_mig_tab[which].ptr;
+    P.gtab_words = (unsigned long long)ctx->mig_gtab_words;
+    return FW_OK;
+}
 static int mig_upload(fw_ctx *ctx, const int64_t *colptr, const int32_t *rowval, const int32_t *nzval)
 {
     const int n = ctx->P.n, p = ctx->P.p;
@@ -1287,9 +1306,12 @@ static int mig_upload(fw_ctx *ctx, const int64_t *colptr, const int32_t *rowval,
     ctx->W = (n + 63) / 64;
     long long strata = 1;
     for (int j = 0; j < ctx->P.max_k; ++j) strata *= ctx->L;
-    if (strata * ((long long)ctx->L * ctx->L + 1) > MIG_TAB32)
-        return fw_fail(ctx, FW_ERR_LIMIT, "discrete data with %d levels and max_k = %d needs %lld table words per test (limit %d): lower max_k or merge levels", ctx->L,
-                       ctx->P.max_k, strata * ((long long)ctx->L * ctx->L + 1), MIG_TAB32);
+    // tables beyond the LDS of a wavefront live in device memory (r05); beyond MIG_GTAB_MAX words (256 MB) per table: the limit
+    const long long tab_words = strata * ((long long)ctx->L * ctx->L + 1);
+    if (ctx->L > MIG_MAX_L || tab_words > MIG_GTAB_MAX)
+        return fw_fail(ctx, FW_ERR_LIMIT, "discrete data with %d levels and max_k = %d needs %lld table words per test (limits: %d levels, %lld words): lower max_k or merge levels",
+                       ctx->L, ctx->P.max_k, tab_words, MIG_MAX_L, (long long)MIG_GTAB_MAX);
+    ctx->mig_gtab_words = tab_words > MIG_TAB32 ? ((tab_words + 63) & ~63ll) : 0;
     void **ptrs[] = {(void **)&ctx->d_nzbits, (void **)&ctx->d_hibits, (void **)&ctx->d_levels, (void **)&ctx->d_maxvals, (void **)&ctx->d_firstnz, (void **)&ctx->d_vals,
                      (void **)&ctx->d_gthr};
     for (void **q : ptrs)
@@ -1822,7 +1844,14 @@ int fwi_mi_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y
         if (ctx->L == 2) MI_TB_LAUNCH_BIG(2, 2); else if (ctx->mi_nxy == 2) MI_TB_LAUNCH_BIG(3, 2); else MI_TB_LAUNCH_BIG(3, 3);
 #undef MI_TB_LAUNCH_BIG
     } else if (ctx->mi_generic) {
-        MI_TB_LAUNCH(0, 2, false, false);
+        // (tables in device memory: launches of as many workgroups as fit the table budget, one after the other on the stream)
+        const int64_t wgs_all = (m + 3) / 4, wgs_max = mig_launch_wgs(ctx, wgs_all);
+        if ((rc = mig_dev_tables(ctx, Pd, wgs_max, 0))) return rc;
+        for (int64_t w0 = 0; w0 < wgs_all; w0 += wgs_max) {
+            const int64_t t0 = 4 * w0, mc = std::min<int64_t>(m - t0, 4 * wgs_max);
+            hipLaunchKernelGGL((mi_test_batch_kernel<0, 2, false, false>), dim3((unsigned)((mc + 3) / 4)), dim3(256), 0, ctx->stream, Pd, (long long)mc, dX + t0,
+                               dY + t0, dz + t0, (const int32_t *)ctx->d_acc.ptr, (fw_test_result *)ctx->d_out.ptr + t0);
+        }
     } else if (ctx->L == 2) {
         if (wide) MI_TB_LAUNCH(2, 2, false, true); else if (pre) MI_TB_LAUNCH(2, 2, true, false); else MI_TB_LAUNCH(2, 2, false, false);
     } else if (ctx->mi_nxy == 2) {
@@ -1864,7 +1893,12 @@ int fwi_mi_segments(fw_ctx *ctx, int64_t nseg, const FwSeg *d_segs, const int32_
         if (ctx->L == 2) MI_SEG_LAUNCH_BIG(2, 2); else if (ctx->mi_nxy == 2) MI_SEG_LAUNCH_BIG(3, 2); else MI_SEG_LAUNCH_BIG(3, 3);
 #undef MI_SEG_LAUNCH_BIG
     } else if (ctx->mi_generic) {
-        MI_SEG_LAUNCH(0, 2, false, false);
+        MiDev Pg = mi_dev_subsets(ctx);
+        const int64_t wgs_max = mig_launch_wgs(ctx, nseg);
+        if (int rcg = mig_dev_tables(ctx, Pg, wgs_max, &pb == &ctx->pb[1] ? 2 : 1)) return rcg;
+        for (int64_t s0 = 0; s0 < nseg; s0 += wgs_max)
+            hipLaunchKernelGGL((mi_subsets_seg_kernel<0, 2, false, false>), dim3((unsigned)std::min<int64_t>(wgs_max, nseg - s0)), dim3(256), 0, pb.launch_stream, Pg,
+                               d_segs + s0, d_acc, d_out + s0, ctx->P.max_k, ctx->P.alpha, (long long)ctx->P.max_tests, (const unsigned *)nullptr, 1);
     } else if (ctx->L == 2) {
         if (wide) MI_SEG_LAUNCH(2, 2, false, true); else if (pre) MI_SEG_LAUNCH(2, 2, true, false); else MI_SEG_LAUNCH(2, 2, false, false);
     } else if (ctx->mi_nxy == 2) {

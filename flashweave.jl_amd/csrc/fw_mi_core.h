@@ -41,6 +41,8 @@ struct MiDev {
     unsigned long long *prof;  // profiling only (FW_MI_PROF=1, fw_test_batch): shader-clock cycles per phase, summed over tests
     const unsigned char *vals;  // generic form (data with a value above 2, r04): one byte per (variable, sample), [p][n]; else null
     int rowk;  // smallest conditioning-set size for which the ROW form of the counting phase is considered (mi_bin_rows; 99: never)
+    unsigned *gtab;               // generic form with tables beyond LDS (r05): one table of gtab_words words per wavefront of the launch in
+    unsigned long long gtab_words;  // device memory (wavefront w of workgroup b: table 4 b + w); null / 0: the table lives in LDS
 };
 
 struct MiRes {
@@ -663,7 +665,7 @@ static __device__ __forceinline__ MiRes mi_test_core(const MiDev &P, const int X
 // mi_test_core, written with run-time loop bounds (sub-table = levels sx.. of X, sy.. of Y).  A slow path by design (meta-variable
 // scale problems): ~n / 64 LDS atomics per lane and test instead of a handful of popcounts.  tab: MIG_TAB32 32-bit words.
 // ------------------------------------------------------------------------------------------------
-#define MIG_MAX_L 8
+#define MIG_MAX_L 62  // values 0 .. 61: the pair table L^2 + 1 of level 0 fits MIG_TAB32 words (r01-r04: 8)
 #define MIG_TAB32 3840  // words of one wavefront's table: L^k strata x (L^2 cells + the stratum total) must fit (host check)
 static __device__ __forceinline__ MiRes mi_test_core_gen(const MiDev &P, const int X_in, const int Y_in, const MiZs &zs_in, const int k_in,
                                                          unsigned *tab)
@@ -708,8 +710,13 @@ static __device__ __forceinline__ MiRes mi_test_core_gen(const MiDev &P, const i
     const bool tot_sep = P.dense && any_flag;
     const bool viewX = P.dense && P.view && P.nzmode && P.levels[X] > 2, viewY = P.dense && P.view && P.nzmode && P.levels[Y] > 2;
     // ---- counting ----
+    // (table in device memory, r05: the counting atomics are performed in the L2, the reads below must not come from this CU's vector
+    // cache -- agent-scope fences instead of wavefront-scope ones)
     for (int i = lane; i < S * NCT; i += 64) tab[i] = 0u;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (P.gtab)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    else
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const size_t n = (size_t)P.n;
     const unsigned char *cx = P.vals + (size_t)X * n, *cy = P.vals + (size_t)Y * n;
@@ -727,7 +734,10 @@ static __device__ __forceinline__ MiRes mi_test_core_gen(const MiDev &P, const i
         if (in_sub) atomicAdd(&tab[key * NCT + x + L * y], 1u);
         if (tot_sep && in_tab) atomicAdd(&tab[key * NCT + LL], 1u);
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (P.gtab)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    else
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // ---- lanes <-> strata: occupancy, n_obs ----
     int n_nonempty = 0, zmax = -1, key0_seen = 0;

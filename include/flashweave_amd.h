@@ -154,15 +154,15 @@ int fw_abi_version(void);
 int fw_set_data_dense_f32(fw_ctx *ctx, const float *data);
 
 /* FW_MI / FW_MI_NZ: SparseMatrixCSC{Int32,Int64} as produced by normalize_data (make_sparse = true).
- * colptr has p+1 entries; rowval is 0-based and sorted within each column; values are 1..7, stored
+ * colptr has p+1 entries; rowval is 0-based and sorted within each column; values are 1..61, stored
  * zeros are not allowed.  Values 1..2 everywhere (presence / absence, the two bins of binned_nz_clr): two bit planes per variable, the
  * fast kernels.  A value above 2 anywhere (meta variables with make_onehot = false, src/preprocessing.jl:42-117): the GENERIC form -- one
- * byte per value, tables of L x L x L^k cells as src/types.jl:98-117 sizes them, L = maximum + 1 <= 8 and L^max_k (L^2 + 1) <= 3840 (else
- * FW_ERR_LIMIT); same entry points and results, HITON-PC through the host job pool.
+ * byte per value, tables of L x L x L^k cells as src/types.jl:98-117 sizes them, L = maximum + 1 <= 62; a test's table of L^max_k (L^2 + 1) words sits in LDS up to 3840
+ * words and in device memory up to 64 M words (r05), else FW_ERR_LIMIT; same entry points and results, HITON-PC through the host job pool.
  * Also computes levels / max_vals (src/misc.jl:64-97). */
 int fw_set_data_csc_i32(fw_ctx *ctx, const int64_t *colptr, const int32_t *rowval, const int32_t *nzval);
 
-/* FW_MI / FW_MI_NZ, dense input (Matrix{Int32}, n x p column-major, values 0..7, see above); converted on the host to
+/* FW_MI / FW_MI_NZ, dense input (Matrix{Int32}, n x p column-major, values 0..61, see above); converted on the host to
  * the same packed device layout, i.e. evaluated with the SPARSE-path semantics (levels_z rules). */
 int fw_set_data_dense_i32(fw_ctx *ctx, const int32_t *data);
 

@@ -235,7 +235,7 @@ def test_csc_input_equals_dense_input(ctx):
 
 def test_rejects_unsupported_values():
     bad = np.zeros((50, 4), dtype=np.int32)
-    bad[:, 1] = 8  # 0..7 are served (values above 2: the generic form); 8 and negative values are not
+    bad[:, 1] = 62  # 0..61 are served (values above 2: the generic form; r01-r04: 0..7); 62 and negative values are not
     eng = fw.Engine("mi_nz", 50, 4)
     with pytest.raises(fw.FlashWeaveError) as ei:
         eng.set_data(bad)
@@ -586,16 +586,18 @@ def _multi_level_data(n, p, levels, seed, zero_frac=0.3):
     return np.ascontiguousarray(data)
 
 
-@pytest.mark.parametrize("kind", ["mi", "mi_nz"])
-@pytest.mark.parametrize("levels", [4, 5])
-def test_more_than_three_levels(kind, levels):
+@pytest.mark.parametrize("kind,levels,max_k_", [("mi", 4, 3), ("mi_nz", 4, 3), ("mi", 5, 2), ("mi_nz", 5, 2),
+                                                # r05: tables beyond a wavefront's LDS slot live in device memory -- six levels at max_k = 3
+                                                # (7 992 words), twelve levels (more than the eight of r04) at max_k = 2 (20 880 words)
+                                                ("mi", 6, 3), ("mi_nz", 12, 2), ("mi", 12, 1)])
+def test_more_than_three_levels(kind, levels, max_k_):
     """Discrete variables with more than three levels (r04: the generic form -- one byte per value, 32-bit LDS tables of L x L x L^k
     cells; the reference sizes its tables for any L, types.jl:98-117, misc.jl:64-97, reachable with make_onehot = false meta data,
     preprocessing.jl:42-117).  Levels / max_vals, single tests of every conditioning-set size, test_subsets jobs, level 0 and the
     network against the oracle (whose table code is the reference's for any L): integers exact, MI 1e-12, p 1e-10."""
-    n, p = 700, 40
+    n, p = (700, 40) if levels <= 5 else (3000, 30)          # (more levels: more samples, or no test has power)
     data = _multi_level_data(n, p, levels, 100 + levels)
-    max_k = 3 if levels == 4 else 2                          # the table of a test must fit a wavefront's LDS slot: L^k (L^2 + 1) <= 3840
+    max_k = max_k_                                           # L^k (L^2 + 1) <= 3840 words: the table sits in LDS; else in device memory
     eng = fw.Engine(kind, n, p, max_k=max_k)
     eng.set_data(data)
     orc = O.Oracle(kind, data, sparse=True, max_k=max_k)
@@ -643,14 +645,21 @@ def test_more_than_three_levels(kind, levels):
 
 
 def test_more_than_three_levels_table_limit():
-    # L^max_k (L^2 + 1) words must fit the wavefront's LDS slot: six levels with max_k = 3 do not -> FW_ERR_LIMIT, loudly
-    data = _multi_level_data(200, 10, 6, 3)
-    eng = fw.Engine("mi", 200, 10, max_k=3)
+    # L^max_k (L^2 + 1) words per test: up to 3 840 in LDS, up to 64 M (256 MB) in device memory (r05), beyond that FW_ERR_LIMIT, loudly;
+    # values up to 61
+    data = _multi_level_data(300, 10, 40, 3)
+    eng = fw.Engine("mi", 300, 10, max_k=3)                  # 64 000 strata x 1 601 words
     with pytest.raises(fw.FlashWeaveError) as ei:
         eng.set_data(data)
     assert ei.value.code == -5  # FW_ERR_LIMIT
     eng.close()
-    eng = fw.Engine("mi", 200, 10, max_k=2)
-    eng.set_data(data)                                       # 36 strata x 37 words: fits
-    assert eng.levels()[1].max() == 5
+    eng = fw.Engine("mi", 300, 10, max_k=1)
+    eng.set_data(data)                                       # 40 strata x 1 601 words: device-memory tables
+    assert eng.levels()[1].max() == 39
+    eng.close()
+    data[0, 3] = 62
+    eng = fw.Engine("mi", 300, 10, max_k=0)
+    with pytest.raises(fw.FlashWeaveError) as ei:
+        eng.set_data(data)
+    assert ei.value.code == -5
     eng.close()
