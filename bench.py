@@ -642,6 +642,15 @@ def main():
                     "alg_bytes_per_launch": rcn["alg_bytes_subsets"] / n_sub_launches,
                     "avg_launch_us": 1e6 * sub_launch_s / n_sub_launches, "launches": n_sub_launches,
                     "evaluated_tests_per_s_in_kernel": rcn["cond_tests_evaluated"] / max(sub_launch_s, 1e-12)}
+        if cn.get("t_l0_mfma_s", 0.0) > 0.0:
+            # level 0 of the discrete kinds on the matrix cores (mi_level0_mfma_kernel, v_mfma_scale_f32_32x32x64_f8f6f4): a binary Gram
+            # product priced against the dense fp4 peak (MI355X_MICROARCH.md: ~10 PFLOP/s; 256 CUs x 4 SIMDs x 2 x 65 536 / 32 cycles at 2.4 GHz)
+            roofline["level0"] = {"kernel": "mi_level0_mfma_kernel", "bound": "mfma", "unit": "TFLOP/s", "peak": 10000.0,
+                                  "achieved": cn["l0_mfma_flops"] / cn["t_l0_mfma_s"] / 1e12,
+                                  "frac": cn["l0_mfma_flops"] / cn["t_l0_mfma_s"] / 1e16,
+                                  "kernel_seconds_per_step": cn["t_l0_mfma_s"] / steps,
+                                  "note": "HIP events around the kernel's launch on the engine's stream; flops = 2 x tiles x 256 x 256 x 64 W "
+                                          "(the samples padded to whole 64-bit words); profiles/r05_level0_matrix_loop.json"}
         if args.stream_columns:
             # variant S (recursive_pcor = 0).  B_fzS = what a test that shares nothing streams.  The kernels share: the correlations of a
             # job are computed once per job from its columns (fzs_gram_kernel) and the tests condition sub-matrices of

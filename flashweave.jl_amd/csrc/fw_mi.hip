@@ -1693,12 +1693,14 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
         FW_HIP(ctx, hipMemcpyAsync(d_gthr, gthr, sizeof(gthr), hipMemcpyHostToDevice, ctx->stream));
         if (nblk == 0)
             ;  // more ranks than tiles: nothing to screen here
-        else if (l0_mfma)
+        else if (l0_mfma) {
+            FW_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
             hipLaunchKernelGGL(mi_level0_mfma_kernel,
                                dim3((unsigned)(8 * (((slot_end - 1) / (L0M_S * L0M_S) - slot_off / (L0M_S * L0M_S) + 1 + 7) / 8) * L0M_S * L0M_S)), dim3(512), 0,
                                ctx->stream, P, p, T, ctx->d_firstnz, ctx->d_firstnz + p, d_gthr, (MiL0Counters *)ctx->d_tmp0.ptr, cap_c,
                                (MiCand *)ctx->d_jobs.ptr, l0_dbg, slot_off, slot_end, l0_prof ? d_prof : nullptr);
-        else if (ctx->d_hibits)
+            FW_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        } else if (ctx->d_hibits)
             hipLaunchKernelGGL(mi_level0_kernel<true>, dim3(nblk), dim3(256), 0, ctx->stream, P, p, T, ctx->d_firstnz,
                                ctx->d_firstnz + p, d_gthr, (MiL0Counters *)ctx->d_tmp0.ptr, cap_c, (MiCand *)ctx->d_jobs.ptr, ctx->d_xlnx, ctx->d_xlnx + (ctx->P.n + 1), l0_dbg, b_off);
         else
@@ -1708,6 +1710,11 @@ int fwi_mi_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> &p
         FW_HIP(ctx, hipMemcpyAsync(&h1, ctx->d_tmp0.ptr, sizeof(h1), hipMemcpyDeviceToHost, ctx->stream));
         FW_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->cnt.kernel_launches += 1;
+        if (l0_mfma && nblk > 0) {  // the Gram product's rate: this launch's tiles x (2 x 128 plane rows)^2 x 64 W multiply-adds
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->cnt.t_l0_mfma_s += 1e-3 * (double)ms;
+            ctx->cnt.l0_mfma_flops += 2.0 * (double)nblk * 256.0 * 256.0 * 64.0 * (double)ctx->W;
+        }
         if (l0_prof) {
             unsigned long long hp[8];
             FW_HIP(ctx, hipMemcpy(hp, d_prof, sizeof(hp), hipMemcpyDeviceToHost));

@@ -43,7 +43,8 @@ class _Counters(C.Structure):
                 ("subsets_calls", C.c_int64), ("kernel_launches", C.c_int64), ("subsets_launches", C.c_int64), ("t_level0_s", C.c_double), ("t_level0_host_s", C.c_double),
                 ("t_cond_s", C.c_double), ("t_dev_subsets_s", C.c_double), ("t_host_advance_s", C.c_double),
                 ("t_host_build_s", C.c_double), ("t_host_launch_s", C.c_double), ("t_host_wait_s", C.c_double), ("t_host_merge_s", C.c_double),
-                ("alg_bytes_subsets", C.c_double), ("gram_jobs", C.c_int64), ("gram_alg_bytes", C.c_double), ("gram_alg_flops", C.c_double)]
+                ("alg_bytes_subsets", C.c_double), ("gram_jobs", C.c_int64), ("gram_alg_bytes", C.c_double), ("gram_alg_flops", C.c_double),
+                ("l0_mfma_flops", C.c_double), ("t_l0_mfma_s", C.c_double)]
 
 
 class _LearnOpts(C.Structure):

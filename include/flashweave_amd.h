@@ -132,6 +132,10 @@ typedef struct fw_counters {
     int64_t gram_jobs;           /* job matrices computed */
     double gram_alg_bytes;       /* sum over them of (a + 2) * n * 4 */
     double gram_alg_flops;       /* sum over them of 2 * n * C(a + 2, 2) */
+    /* ABI 6 -- level 0 of the discrete kinds on the matrix cores (mi_level0_mfma_kernel): the binary Gram product, priced against the
+     * dense fp4 peak */
+    double l0_mfma_flops;        /* 2 x multiply-adds issued: tiles x 256 x 256 plane rows x 64 W samples (padded words included) */
+    double t_l0_mfma_s;          /* HIP-event seconds of the kernel's launches */
 } fw_counters;
 
 /* ---- lifecycle -------------------------------------------------------------------------------- */
