@@ -2092,7 +2092,7 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
 // segment record s of the coming launch (one thread)
 __device__ __forceinline__ void dh_fill_one(const unsigned int s, const DhTgt *__restrict__ tg, int ntg, DhGlobal *__restrict__ g,
                                             const long long *__restrict__ seg0, const DhArrays &A, FwSeg *__restrict__ segs, int d1,
-                                            const int32_t *__restrict__ act, unsigned long long *__restrict__ gstop)
+                                            const int32_t *__restrict__ act)
 {
     int lo = 0, hi = (int)g->n_act;  // first list position with seg0 > s; the job owning slot s is the one before it
     while (lo < hi) {
@@ -2124,10 +2124,6 @@ __device__ __forceinline__ void dh_fill_one(const unsigned int s, const DhTgt *_
     sg.acc_len = x.na + (acc_mode ? 1 : 0);
     if (sg.acc_len > FW_TAB_A) g->any_big = 1u;  // same value from every writer
     sg.pad = act[(size_t)g->act_sel * ntg + lo - 1];  // fz_nz: the job's record slot = the target's index in the run (dh_nz_recs_kernel)
-    if (gstop) {  // fz: the job's stop word of this launch (fz_seg_body) = the word of its first segment; that segment's record resets it
-        sg.pad = (int32_t)(s - (unsigned int)k);
-        if (k == 0ull) gstop[s] = FW_RANK_NONE;
-    }
     const unsigned long long lo_r = acc_mode ? 0ull : x.jnext;
     sg.start = lo_r + k * seglen;
     const unsigned long long hi_r = lo_r + (slot > 0u ? x.jwin2 : x.jwin);
@@ -2136,12 +2132,11 @@ __device__ __forceinline__ void dh_fill_one(const unsigned int s, const DhTgt *_
 }
 __global__ __launch_bounds__(256) void dh_fill_kernel(const DhTgt *__restrict__ tg, int ntg, DhGlobal *__restrict__ g,
                                                       const long long *__restrict__ seg0, const DhArrays A,
-                                                      FwSeg *__restrict__ segs, int d1, const int32_t *__restrict__ act,
-                                                      unsigned long long *__restrict__ gstop)
+                                                      FwSeg *__restrict__ segs, int d1, const int32_t *__restrict__ act)
 {
     const unsigned int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= g->ns) return;
-    dh_fill_one(s, tg, ntg, g, seg0, A, segs, d1, act, gstop);
+    dh_fill_one(s, tg, ntg, g, seg0, A, segs, d1, act);
 }
 
 // (r04 fused step + plan (+ fill) into the last workgroup to finish, r05 into a cooperative grid with one device-memory barrier and a
@@ -2520,7 +2515,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     constexpr unsigned LOG_CAP = 1u << 16;
     size_t need = (log_path ? pad(sizeof(ulonglong2) * LOG_CAP) : 0) + pad(sizeof(int32_t) * 2 * (size_t)ntg) + pad(sizeof(unsigned int) * ((size_t)ntg + 1)) + pad(sizeof(DhTgt) * ntg) + pad(sizeof(DhGlobal)) + 3 * pad(sizeof(long long) * ((size_t)ntg + 1));
     need += pad(4 * tot + 4) * 3 + pad(4 * 2 * tot * (size_t)d1 + 4) + pad(8 * tot + 8) * 4 + pad(4 * wl.size() + 4);
-    need += pad(sizeof(FwSeg) * max_ns) + pad(sizeof(FwSegOut) * max_ns) + pad(sizeof(unsigned long long) * max_ns);
+    need += pad(sizeof(FwSeg) * max_ns) + pad(sizeof(FwSegOut) * max_ns);
     if (!nb_on_dev) need += pad(8 * ((size_t)p + 1)) + pad(4 * nnz + 4) + 2 * pad(8 * nnz + 8);
     const size_t rec_cap = MI_REC_CAP, bacc_cap = MI_BACC_CAP;
     if (per_target) need += pad(sizeof(MiQueue)) + pad(sizeof(MiBoard) * MI_BOARD_CAP) + pad(sizeof(FwSegOut) * rec_cap) + pad(sizeof(int32_t) * bacc_cap);
@@ -2571,11 +2566,6 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     A.wl = d_wl;
     FwSeg *d_segs = (FwSeg *)carve(sizeof(FwSeg) * max_ns);
     FwSegOut *d_so = (FwSegOut *)carve(sizeof(FwSegOut) * max_ns);
-    // fz: the jobs' stop words of a launch (fz_seg_body: a stop found by one workgroup ends the later segments of the job early);
-    // FW_DH_GSTOP=0: off (A/B)
-    static const bool gstop_on = [] { const char *e = fw_knob("FW_DH_GSTOP"); return !(e && atoi(e) == 0); }();
-    unsigned long long *d_gstop_all = (unsigned long long *)carve(sizeof(unsigned long long) * max_ns);
-    unsigned long long *const d_gstop = (c->P.kind == FW_FZ && gstop_on) ? d_gstop_all : nullptr;
     ulonglong2 *d_log = log_path ? (ulonglong2 *)carve(sizeof(ulonglong2) * LOG_CAP) : nullptr;
     MiQueue *d_mq = per_target ? (MiQueue *)carve(sizeof(MiQueue)) : nullptr;
     MiBoard *d_boards = per_target ? (MiBoard *)carve(sizeof(MiBoard) * MI_BOARD_CAP) : nullptr;
@@ -2691,7 +2681,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         hipLaunchKernelGGL(dh_plan_kernel, dim3(1), dim3(1024), 0, st, ntg, d_g, (const unsigned long long *)d_win,
                            (const unsigned int *)d_sp, (const unsigned long long *)d_win2, (const int32_t *)d_act, d_seg0, PA);
         hipLaunchKernelGGL(dh_fill_kernel, dim3(g_fill), dim3(256), 0, st, (const DhTgt *)d_tg, ntg, d_g,
-                           (const long long *)d_seg0, A, d_segs, d1, (const int32_t *)d_act, d_gstop);
+                           (const long long *)d_seg0, A, d_segs, d1, (const int32_t *)d_act);
     };
     const double th1 = wall();
     int rc2 = FW_OK;
@@ -2760,7 +2750,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
                 rc = fwi_fznz_submatrices_dev(c, ntg, d_nzrecs, A.acc, d_nzarena, (any_wl ? 2 * max_cap : max_cap) + 2, true, st);
                 if (!rc) rc = fwi_fznz_segments_dev(c, grid_seg, d_segs, A.acc, d_so, d_ns, any_big, &d_g->any_big, d_nzrecs, d_nzarena, st);
             } else {
-                rc = fz ? fwi_fz_segments_dev(c, grid_seg, d_segs, A.acc, d_so, d_ns, any_big, &d_g->any_big, d_gstop, st)
+                rc = fz ? fwi_fz_segments_dev(c, grid_seg, d_segs, A.acc, d_so, d_ns, any_big, &d_g->any_big, st)
                         : fwi_mi_segments_dev(c, grid_mi, d_segs, A.acc, d_so, d_ns, st);
             }
             if (rc) return rc;

@@ -289,24 +289,6 @@ __global__ void fz_thresholds_kernel(double alpha, double zscale, double *thr)
     thr[5] = thr[1] * thr[1] * (1.0 + 1e-12);
     thr[6] = thr[3] * thr[3] * (1.0 + 1e-12);
     thr[7] = (thr[4] < 1.0 ? thr[4] * thr[4] : 1.0) * (1.0 - 1e-12);
-    // thr[8], thr[9]: |r| (positive / negative statistic) beyond which the device p-value is exactly zero (fz_seg_body: rz_pos / rz_neg):
-    // bisection on fz_pval_dev between "p > 0" and r = 1 (log(inf) = inf, erfc(inf) = 0), upper end + 1e-9 relative
-    for (int sgn = 0; sgn < 2; ++sgn) {
-        const double sg = sgn ? -1.0 : 1.0;
-        double lo = 0.0, hi = 1.0;
-        if (!(zscale > 0.0) || fz_pval_dev(sg * 1.0, zscale) != 0.0) {
-            thr[8 + sgn] = 2.0;
-            continue;
-        }
-        for (int it = 0; it < 200; ++it) {
-            const double mid = 0.5 * (lo + hi);
-            if (fz_pval_dev(sg * mid, zscale) == 0.0)
-                hi = mid;
-            else
-                lo = mid;
-        }
-        thr[8 + sgn] = hi * (1.0 + 1e-9);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -494,8 +476,7 @@ __global__ __launch_bounds__(256, HIGHK ? ((TAB || LOCAL) ? FW_HIGHK_OCC : FW_HI
                                                              const double *__restrict__ thr_g,
                                                              const FwNzJob *__restrict__ recs, long long n_obs_min,
                                                              const unsigned *__restrict__ ns_dev,
-                                                             const unsigned *__restrict__ big_dev,
-                                                             unsigned long long *gstop /* device rounds of fz: one word per job of the launch (index: FwSeg::pad), see fz_seg_body; else null */)
+                                                             const unsigned *__restrict__ big_dev)
 {
     // device rounds launch the in-lane variant next to the table variant whenever a long accepted list is POSSIBLE (with
     // whitelists that is nearly always); the fill kernel knows whether one EXISTS in this launch -- without one, leave
@@ -508,7 +489,7 @@ __global__ __launch_bounds__(256, HIGHK ? ((TAB || LOCAL) ? FW_HIGHK_OCC : FW_HI
         // (per-job matrices, device rounds of fz_nz: the size-3 table / in-lane pair routes the same way; max_k 4-5 has one variant)
         if (ns_dev && (!LOCAL || (!HIGHK && big_dev)) && (!HIGHK || big_dev) && ((segs[s].acc_len <= (HIGHK ? FZ_HK_A : FZ_TAB_A)) != TAB)) continue;
         fz_seg_body<HIGHK, LOCAL, TAB>(cor_g, p_g, segs[s], accflat + segs[s].acc_off, false, out + s, max_k, alpha, zscale_g, max_tests, thr_g, recs,
-                                       n_obs_min, (!LOCAL && gstop) ? gstop + segs[s].pad : (unsigned long long *)nullptr);
+                                       n_obs_min);
         __syncthreads();  // the LDS state of the body is reused by the next segment
     }
 }
@@ -915,7 +896,7 @@ int fwi_fz_thresholds(fw_ctx *ctx, hipStream_t stream, double *zscale)
 }
 
 int fwi_fz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, const unsigned *d_ns,
-                        bool any_big, const unsigned *d_big, unsigned long long *d_gstop, hipStream_t stream)
+                        bool any_big, const unsigned *d_big, hipStream_t stream)
 {
     int rc = fz_ensure_thresholds(ctx, stream);
     if (rc) return rc;
@@ -926,18 +907,18 @@ int fwi_fz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const i
         if (!no_hk)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false, true>), dim3(grid), dim3(256), 0, stream, ctx->d_cor, ctx->P.p, d_segs,
                                d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr,
-                               (const FwNzJob *)nullptr, 0ll, d_ns, d_big, d_gstop);
+                               (const FwNzJob *)nullptr, 0ll, d_ns, d_big);
         hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false, false>), dim3(grid), dim3(256), 0, stream, ctx->d_cor,
                            ctx->P.p, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests,
-                           ctx->d_thr, (const FwNzJob *)nullptr, 0ll, d_ns, no_hk ? (const unsigned *)nullptr : d_big, d_gstop);
+                           ctx->d_thr, (const FwNzJob *)nullptr, 0ll, d_ns, no_hk ? (const unsigned *)nullptr : d_big);
     } else {
         hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false, true>), dim3(grid), dim3(256), 0, stream, ctx->d_cor, ctx->P.p, d_segs,
                            d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr,
-                           (const FwNzJob *)nullptr, 0ll, d_ns, d_big, d_gstop);
+                           (const FwNzJob *)nullptr, 0ll, d_ns, d_big);
         if (any_big)  // some accepted set may exceed FZ_TAB_A
             hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false, false>), dim3(grid_big), dim3(256), 0, stream, ctx->d_cor, ctx->P.p,
                                d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests,
-                               ctx->d_thr, (const FwNzJob *)nullptr, 0ll, d_ns, d_big, d_gstop);
+                               ctx->d_thr, (const FwNzJob *)nullptr, 0ll, d_ns, d_big);
     }
     FW_HIP(ctx, hipGetLastError());
     return FW_OK;
@@ -960,23 +941,23 @@ int fwi_fz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *d_
         if (nseg_tab > 0)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false, true>), dim3((unsigned)nseg_tab), dim3(256), 0, pb.launch_stream,
                                ctx->d_cor, ctx->P.p, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx),
-                               (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll, (const unsigned *)nullptr, (const unsigned *)nullptr, (unsigned long long *)nullptr);
+                               (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll, (const unsigned *)nullptr, (const unsigned *)nullptr);
         if (nseg > nseg_tab)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<true, false, false>), dim3((unsigned)(nseg - nseg_tab)), dim3(256), 0,
                                pb.launch_stream, ctx->d_cor, ctx->P.p, d_segs + nseg_tab, d_acc, d_out + nseg_tab, ctx->P.max_k,
                                ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr,
-                               0ll, (const unsigned *)nullptr, (const unsigned *)nullptr, (unsigned long long *)nullptr);
+                               0ll, (const unsigned *)nullptr, (const unsigned *)nullptr);
     } else {
         // segments [0, nseg_tab) belong to jobs with |accepted| <= FZ_TAB_A: table kernel; the rest: in-lane caching
         if (nseg_tab > 0)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false, true>), dim3((unsigned)nseg_tab), dim3(256), 0, pb.launch_stream,
                                ctx->d_cor, ctx->P.p, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, fz_zscale(ctx),
-                               (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll, (const unsigned *)nullptr, (const unsigned *)nullptr, (unsigned long long *)nullptr);
+                               (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr, 0ll, (const unsigned *)nullptr, (const unsigned *)nullptr);
         if (nseg > nseg_tab)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<false, false, false>), dim3((unsigned)(nseg - nseg_tab)), dim3(256), 0,
                                pb.launch_stream, ctx->d_cor, ctx->P.p, d_segs + nseg_tab, d_acc, d_out + nseg_tab, ctx->P.max_k,
                                ctx->P.alpha, fz_zscale(ctx), (long long)ctx->P.max_tests, ctx->d_thr, (const FwNzJob *)nullptr,
-                               0ll, (const unsigned *)nullptr, (const unsigned *)nullptr, (unsigned long long *)nullptr);
+                               0ll, (const unsigned *)nullptr, (const unsigned *)nullptr);
     }
     FW_HIP(ctx, hipGetLastError());
     FW_HIP(ctx, hipEventRecord(pb.ev1, pb.launch_stream));
@@ -1597,14 +1578,14 @@ int fwi_fznz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const
     if (ctx->P.max_k > 3) {
         hipLaunchKernelGGL((fz_subsets_seg_kernel<true, true, false>), dim3(grid), dim3(256), 0, stream, d_arena, 0, d_segs, d_acc, d_out, ctx->P.max_k,
                            ctx->P.alpha, 0.0, (long long)ctx->P.max_tests, (const double *)nullptr, d_recs, (long long)ctx->n_obs_min_eff, d_ns,
-                           (const unsigned *)nullptr, (unsigned long long *)nullptr);
+                           (const unsigned *)nullptr);
     } else {
         hipLaunchKernelGGL((fz_subsets_seg_kernel<false, true, true>), dim3(grid), dim3(256), 0, stream, d_arena, 0, d_segs, d_acc, d_out, ctx->P.max_k,
-                           ctx->P.alpha, 0.0, (long long)ctx->P.max_tests, (const double *)nullptr, d_recs, (long long)ctx->n_obs_min_eff, d_ns, d_big, (unsigned long long *)nullptr);
+                           ctx->P.alpha, 0.0, (long long)ctx->P.max_tests, (const double *)nullptr, d_recs, (long long)ctx->n_obs_min_eff, d_ns, d_big);
         if (any_big)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<false, true, false>), dim3(grid < 512u ? grid : 512u), dim3(256), 0, stream, d_arena, 0, d_segs,
                                d_acc, d_out, ctx->P.max_k, ctx->P.alpha, 0.0, (long long)ctx->P.max_tests, (const double *)nullptr, d_recs,
-                               (long long)ctx->n_obs_min_eff, d_ns, d_big, (unsigned long long *)nullptr);
+                               (long long)ctx->n_obs_min_eff, d_ns, d_big);
     }
     FW_HIP(ctx, hipGetLastError());
     return FW_OK;
@@ -1623,18 +1604,18 @@ int fwi_fznz_segments(fw_ctx *ctx, int64_t nseg, int64_t nseg_tab, const FwSeg *
         hipLaunchKernelGGL((fz_subsets_seg_kernel<true, true, false>), dim3((unsigned)nseg), dim3(256), 0, pb.launch_stream,
                            (const float *)ctx->d_arena.ptr, 0, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, 0.0,
                            (long long)ctx->P.max_tests, (const double *)nullptr, (const FwNzJob *)ctx->d_nzrecs.ptr,
-                           (long long)ctx->n_obs_min_eff, (const unsigned *)nullptr, (const unsigned *)nullptr, (unsigned long long *)nullptr);
+                           (long long)ctx->n_obs_min_eff, (const unsigned *)nullptr, (const unsigned *)nullptr);
     else {
         if (nseg_tab > 0)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<false, true, true>), dim3((unsigned)nseg_tab), dim3(256), 0, pb.launch_stream,
                                (const float *)ctx->d_arena.ptr, 0, d_segs, d_acc, d_out, ctx->P.max_k, ctx->P.alpha, 0.0,
                                (long long)ctx->P.max_tests, (const double *)nullptr, (const FwNzJob *)ctx->d_nzrecs.ptr,
-                               (long long)ctx->n_obs_min_eff, (const unsigned *)nullptr, (const unsigned *)nullptr, (unsigned long long *)nullptr);
+                               (long long)ctx->n_obs_min_eff, (const unsigned *)nullptr, (const unsigned *)nullptr);
         if (nseg > nseg_tab)
             hipLaunchKernelGGL((fz_subsets_seg_kernel<false, true, false>), dim3((unsigned)(nseg - nseg_tab)), dim3(256), 0,
                                pb.launch_stream, (const float *)ctx->d_arena.ptr, 0, d_segs + nseg_tab, d_acc, d_out + nseg_tab,
                                ctx->P.max_k, ctx->P.alpha, 0.0, (long long)ctx->P.max_tests, (const double *)nullptr,
-                               (const FwNzJob *)ctx->d_nzrecs.ptr, (long long)ctx->n_obs_min_eff, (const unsigned *)nullptr, (const unsigned *)nullptr, (unsigned long long *)nullptr);
+                               (const FwNzJob *)ctx->d_nzrecs.ptr, (long long)ctx->n_obs_min_eff, (const unsigned *)nullptr, (const unsigned *)nullptr);
     }
     FW_HIP(ctx, hipGetLastError());
     FW_HIP(ctx, hipEventRecord(pb.ev1, pb.launch_stream));

@@ -662,16 +662,14 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                                             FwSegOut *out_rec, int max_k,
                                             double alpha, double zscale_g, long long max_tests,
                                             const double *__restrict__ thr_g, const FwNzJob *__restrict__ recs,
-                                            long long n_obs_min,
-                                            unsigned long long *gstop /* device rounds (r05): the job's word in device memory -- smallest stopping
-                                                                         rank any workgroup of this launch has found in the job so far; null elsewhere */)
+                                            long long n_obs_min)
 {
     constexpr bool TAB3 = TAB && !HIGHK;          // size-3 table (max_k <= 3)
     constexpr bool HK = TAB && HIGHK && !LOCAL;   // level-2 tables for sizes 4 and 5
     static_assert(!(TAB && HIGHK && LOCAL), "no level-2 table variant for per-job matrices");
     constexpr bool L1T = HIGHK && !TAB && !LOCAL;  // level-1 table for sizes 4 and 5 over long lists
 #ifndef FW_L3_SCREEN
-#define FW_L3_SCREEN 0  // (A/B knob; r05: built, bit-identical, cfg5 58.72 s with it against 58.63 s without -- the tests of cfg5 live in the p = 0 regime, see rz_pos -- so the r03 / r04 form stays: every size-5 test of the position tables takes its quotient)
+#define FW_L3_SCREEN 0  // (A/B knob; r05: built, bit-identical, cfg5 58.72 s with it against 58.63 s without -- the tests of cfg5 live where p underflows to 0 (a p = 0 branch of the maximum-p bookkeeping was tried too: neutral there, -2 % at cfg3, removed) -- so the r03 / r04 form stays: every size-5 test of the position tables takes its quotient)
 #endif
     // SCR: the test loop keeps a statistic as (numerator, radicands) where a screen on the squares decides -- the size-3 table kernel
     // (r04) and, r05, the size-5 tests of the level-3 position tables (the last formula of a test: two square roots and a division)
@@ -702,7 +700,6 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     __shared__ unsigned long long s_hk_end;
     __shared__ int s_hk_n, s_hk_lin0, s_hk_nan, s_hk_skip0, s_hk_prev;
     __shared__ unsigned int s_cstop;  // smallest stopping rank of the current chunk so far (relative to the chunk), 0xffffffff = none
-    __shared__ unsigned long long s_gs0;  // the job's stop word as the segment found it
     __shared__ unsigned long long s_stop[4];
     __shared__ double s_bx[4], s_bps[4];
     __shared__ unsigned long long s_br[4];
@@ -759,7 +756,6 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
         s_best_rank = 0;
         s_cstop = 0xffffffffu;
         if (HK) s_hk_prev = -1;
-        s_gs0 = gstop ? __hip_atomic_load(gstop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : FW_RANK_NONE;
     }
     unsigned long long cnt[FW_MAX_K_FAST + 1];
 #pragma unroll
@@ -775,37 +771,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     // (the context-wide thresholds carry them ready-made in thr[5..7]: fz_thresholds_kernel; per-job thresholds of fz_nz: computed here)
     const double h2_pos = !LOCAL ? thr[5] : rhi_pos * rhi_pos * (1.0 + 1e-12), h2_neg = !LOCAL ? thr[6] : rhi_neg * rhi_neg * (1.0 + 1e-12);
     const double s2 = !LOCAL ? thr[7] : (rsub_lo < 1.0 ? rsub_lo * rsub_lo : 1.0) * (1.0 - 1e-12);
-    // |r| beyond which the p-value is EXACTLY zero (erfc underflows and subnormal values are flushed, fz_pval_slow): there a test
-    // needs neither its x-key nor its p for the maximum-p bookkeeping -- it ties with every other test of that regime at p = 0 and
-    // the later rank wins (tests.jl:338 `>=`).  r05: at n = 10 000 (cfg5) that is every |r| > 0.36, i.e. nearly every test of the
-    // long enumerations -- the strongly associated pairs are the ones whose jobs run for 10^5 subsets -- and each of them paid a
-    // Float64 log and an erfc (two out-of-line calls) to find that out.  Per-job thresholds of fz_nz: not computed (2 = never).
-    const double rz_pos = !LOCAL ? thr[8] : 2.0, rz_neg = !LOCAL ? thr[9] : 2.0;
     __syncthreads();
-    // Another workgroup of this launch has already found the job's stop at an EARLIER rank than anything this segment holds: the merge
-    // takes the first stop (dh_merge: segments behind it are speculative), so nothing here can matter -- an empty record, no tests.
-    // (r05.  The same word ends running segments early: a stopping lane publishes its rank with an atomic minimum, lane 0 of every
-    // wavefront looks at the word every eighth test and pulls s_cstop to 0,
-    // which the lanes' own check in front of every test picks up.  Results, reference-order test counts and the committed job sequence
-    // do not change; `evaluated` does.)
-    if (gstop && s_gs0 < seg.start) {
-        if (tid == 0) {
-            FwSegOut o;
-            o.stop_rank = FW_RANK_NONE;
-            o.stop_stat = 0.0;
-            o.stop_pval = 1.0;
-            o.best_rank = 0;
-            o.best_stat = 0.0;
-            o.best_pval = -3.0;  // "no test": dh_merge ignores it (every real p is >= 0)
-            o.stop_df = 0;
-            o.stop_power = 0;
-            o.best_df = 0;
-            o.pad = 0;
-            o.evaluated = 0;
-            *out_rec = o;
-        }
-        return;
-    }
 #define ACCV(i) (LOCAL ? ((i) + 2) : (in_lds ? s_acc[(i)] : gacc[(i)]))
 #define CORV(u, v) cor[(size_t)(u) * p + (v)]
 // CORT(u, v): the entry a lane gathers where u is the index that moves from lane to lane.  r04 measured the transposed read
@@ -1400,13 +1366,8 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                         stop_stat = stat;
                         stop_p = fz_pval_slow(stat, zscale);
                         (void)__hip_atomic_fetch_min(&s_cstop, (unsigned int)(r - cbase), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (gstop) (void)__hip_atomic_fetch_min(gstop, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
                     }
-                }
-                if (gstop && lane == 0 && (my_done & 7u) == 0u) {  // (see the prologue; the wavefront waits for the word while the SIMD's other three run)
-                    if (__hip_atomic_load(gstop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cbase)
-                        (void)__hip_atomic_fetch_min(&s_cstop, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 // a lane of this workgroup has stopped at an earlier rank of the chunk: nothing behind it matters any more
                 // (the merge takes the first stop) -- r01/r02 profile: lanes running on behind the stop were the 18 % of
@@ -1429,14 +1390,6 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                                 lazy_take = true;
                             else
                                 exact = lhs <= rhs * (1.0 + 1e-11);
-                        }
-                    } else if (av > (stat < 0.0 ? rz_neg : rz_pos)) {  // p = 0 exactly (see rz_pos): ties at zero, the later rank wins
-                        if (my_bx == FZ_X_NONE || (my_bx > FZ_X_SUB && my_bps == 0.0)) {
-                            my_bx = 1.0e9;  // (any key beyond FZ_X_SUB: the regime, not the value, is what the merges look at)
-                            my_bps = 0.0;
-                            my_br = r;
-                            my_bev = stat;
-                            my_bxb = my_bxc = 1.0;
                         }
                     } else {
                         exact = true;
@@ -1483,14 +1436,6 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                             lazy_take = true;
                         else
                             exact = av <= my_ba * (1.0 + 1e-12);
-                    } else if (av > (stat < 0.0 ? rz_neg : rz_pos)) {  // p = 0 exactly (see rz_pos): ties at zero, the later rank wins
-                        if (my_bx == FZ_X_NONE || (my_bx > FZ_X_SUB && my_bps == 0.0)) {
-                            my_bx = 1.0e9;
-                            my_bps = 0.0;
-                            my_ba = av;
-                            my_br = r;
-                            my_bstat = stat;
-                        }
                     } else {
                         exact = true;
                     }

@@ -342,7 +342,7 @@ int fwi_mi_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const i
                         hipStream_t stream);
 int fwi_fz_thresholds(fw_ctx *ctx, hipStream_t stream, double *zscale);  // ensures ctx->d_thr (fz_thresholds_kernel)
 int fwi_fz_segments_dev(fw_ctx *ctx, unsigned grid, const FwSeg *d_segs, const int32_t *d_acc, FwSegOut *d_out, const unsigned *d_ns,
-                        bool any_big, const unsigned *d_big, unsigned long long *d_gstop, hipStream_t stream);
+                        bool any_big, const unsigned *d_big, hipStream_t stream);
 
 // ---- host driver (fw_hiton.cpp) ----
 int fwi_subsets_dispatch(fw_ctx *ctx, int64_t m, const FwJob *jobs_host, const int32_t *acc_host, int64_t acc_total,

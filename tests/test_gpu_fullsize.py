@@ -123,8 +123,7 @@ def test_cfg3_network_independent_of_schedule():
     settings = [{}, {"FW_SEG_TARGET": "2048", "FW_SEG_A": "0", "FW_SEG_B": "0"}, {"FW_DH_SPEC": "0", "FW_DH_SPEC0": "0"},
                 {"FW_DH_SPEC": "8", "FW_DH_SPEC0": "4", "FW_DH_SPEC_BELOW": "100000000000", "FW_DH_SPEC0_BELOW": "100000000000",
                  "FW_DH_SPEC0_JOBS": "100000", "FW_DH_TIME_EVERY": "1"},
-                {"FW_DH_CHAINS": "1"}, {"FW_DH_CHAINS": "3"},  # concurrent chains of device rounds (default 2)
-                {"FW_DH_GSTOP": "0"}]  # r05: without the jobs' stop words (a stop found by one workgroup ends the job's later segments early)
+                {"FW_DH_CHAINS": "1"}, {"FW_DH_CHAINS": "3"}]  # concurrent chains of device rounds (default 2)
     seen = set()
     for s in settings:
         out = subprocess.run([sys.executable, "-c", _HASH_SNIPPET % root], env=dict(os.environ, **s), cwd=root, check=True,
