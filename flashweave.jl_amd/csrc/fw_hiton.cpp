@@ -193,6 +193,74 @@ int devx_allgather(void *user, int64_t n, const int32_t *tgt, const int32_t *nbr
 // fwi_devhiton_mi_schedule serves: FW_MI / FW_MI_NZ on bit planes, one rank, no exchange callback, level-0 lists and candidate order on
 // the device, rounds the persistent kernel is worth launching for (the reference's single_il rounds of one target stay on the host pool).
 // FW_MI_SCHED=0 keeps the per-round loop (A/B runs, tests/test_gpu_mi.py compares the two).
+// Host threads of the graph passes at the end of fw_learn_network, kept for the life of the context: starting fifteen threads per pass
+// cost more than the passes' work at cfg3 (2.4 of 2.8 ms for 48 040 edges; r05).  run(fn): fn(w, lo[w], hi[w]) for every block w, block 0
+// on the caller.
+#include <condition_variable>
+#include <mutex>
+struct FwHostWorkers {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    const std::function<void(int, int, int)> *fn = nullptr;
+    const int *blk = nullptr;
+    unsigned long long gen = 0;
+    int pending = 0;
+    bool quit = false;
+    explicit FwHostWorkers(int n)
+    {
+        for (int w = 1; w < n; ++w)
+            th.emplace_back([this, w] {
+                unsigned long long seen = 0;
+                for (;;) {
+                    const std::function<void(int, int, int)> *f;
+                    const int *b;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv_go.wait(lk, [&] { return quit || gen != seen; });
+                        if (quit) return;
+                        seen = gen;
+                        f = fn;
+                        b = blk;
+                    }
+                    (*f)(w, b[w], b[w + 1]);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (--pending == 0) cv_done.notify_one();
+                    }
+                }
+            });
+    }
+    void run(const std::function<void(int, int, int)> &f, const int *b)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            fn = &f;
+            blk = b;
+            pending = (int)th.size();
+            ++gen;
+        }
+        cv_go.notify_all();
+        f(0, b[0], b[1]);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    ~FwHostWorkers()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+        }
+        cv_go.notify_all();
+        for (std::thread &t : th) t.join();
+    }
+};
+void fwi_host_workers_free(fw_ctx *c)
+{
+    delete c->host_workers;
+    c->host_workers = nullptr;
+}
+
 static bool mi_schedule_on_device(const fw_ctx *c, const fw_learn_opts &opt, bool has_exchange, int nt)
 {
     if (!(c->P.kind == FW_MI || c->P.kind == FW_MI_NZ) || c->mi_generic || has_exchange || opt.world_size > 1 || c->P.max_k > FW_MAX_K_FAST) return false;
@@ -642,7 +710,11 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
     // The two passes below walk the directed CSR with data-dependent look-ups (one cache miss per entry: 5 ms of cfg4's 100 ms on one
     // core): contiguous blocks of variables on a few host threads, every block into its own vectors, concatenated in block order --
     // the same edge list as the sequential loop.
-    const int n_thr = ne < 20000 ? 1 : (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+    const int n_thr = ne < 20000 ? 1 : (int)std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency()));
+    if (n_thr > 1 && (!c->host_workers || (int)c->host_workers->th.size() + 1 != n_thr)) {
+        fwi_host_workers_free(c);
+        c->host_workers = new FwHostWorkers(n_thr);
+    }
     std::vector<int> blk((size_t)n_thr + 1, p);
     blk[0] = 0;
     for (int w = 1; w < n_thr; ++w) {  // block w starts where the entries before it reach w / n_thr of the total
@@ -655,10 +727,7 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
             fn(0, 0, p);
             return;
         }
-        std::vector<std::thread> th;
-        for (int w = 1; w < n_thr; ++w) th.emplace_back(fn, w, blk[w], blk[w + 1]);
-        fn(0, blk[0], blk[1]);
-        for (std::thread &t : th) t.join();
+        c->host_workers->run(fn, blk.data());
     };
     // misc.jl:137-159 make_weights ("cond_stat"): discrete tests take the sign of the univariate statistic
     if (discrete)
@@ -680,33 +749,44 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
     c->e_src.clear();
     c->e_dst.clear();
     c->e_w.clear();
-    // incoming lists (b -> a for every a), ascending: the transpose of the CSR by counting sort
+    // incoming lists (b -> a for every a) with their weights, ascending in b: the transpose of the CSR by counting sort.  The pass below
+    // then reads two contiguous ranges per variable; looking the reverse direction up in b's own list instead cost two or three
+    // cache lines from another core per entry (cfg4: 3.1-5.0 ms on 16 / 8 threads for 380 000 entries; r05).
     std::vector<int64_t> in_off((size_t)p + 1, 0);
     std::vector<int32_t> in_idx(ne);
+    std::vector<double> in_w(ne);
     {
         for (size_t i = 0; i < ne; ++i) in_off[(size_t)c->pc_idx[i] + 1]++;
         for (int T = 0; T < p; ++T) in_off[T + 1] += in_off[T];
         std::vector<int64_t> fill(in_off.begin(), in_off.end() - 1);
         for (int T = 0; T < p; ++T)  // sources visited in ascending order -> every incoming list comes out sorted
-            for (int64_t i = c->pc_off[T]; i < c->pc_off[T + 1]; ++i) in_idx[(size_t)fill[c->pc_idx[i]]++] = T;
+            for (int64_t i = c->pc_off[T]; i < c->pc_off[T + 1]; ++i) {
+                const int64_t d = fill[c->pc_idx[i]]++;
+                in_idx[(size_t)d] = T;
+                in_w[(size_t)d] = c->pc_w[i];
+            }
     }
-    auto find_in = [&](int T, int32_t u) -> int64_t {
-        for (int64_t i = c->pc_off[T]; i < c->pc_off[T + 1]; ++i)
-            if (c->pc_idx[i] == u) return i;
-        return -1;
-    };
     const double tq3 = now_s();
     std::vector<std::vector<int32_t>> bs((size_t)n_thr), bd((size_t)n_thr);
     std::vector<std::vector<double>> bw((size_t)n_thr);
+    std::vector<double> w_t0((size_t)n_thr, 0.0), w_t1((size_t)n_thr, 0.0);
     run_blocks([&](int w, int lo, int hi) {
-        std::vector<int32_t> &es = bs[(size_t)w], &ed = bd[(size_t)w];
-        std::vector<double> &ew = bw[(size_t)w];
+        w_t0[(size_t)w] = now_s();
+        std::vector<int32_t> es, ed;  // block-local, handed over at the end: the headers of bs[w], bs[w + 1] share cache lines and every
+        std::vector<double> ew;       // push_back writes one (150 ns per entry on 8 threads; r05)
+        const size_t room = (size_t)(c->pc_off[hi] - c->pc_off[lo]);
+        es.reserve(room);
+        ed.reserve(room);
+        ew.reserve(room);
+        std::vector<int32_t> out_of((size_t)p, -1);  // out_of[b] == a: the direction a -> b exists
         for (int a = lo; a < hi; ++a) {
+            const int32_t *ib = in_idx.data() + in_off[a], *ie = in_idx.data() + in_off[a + 1];
             for (int64_t i = c->pc_off[a]; i < c->pc_off[a + 1]; ++i) {  // direction a -> b exists
                 const int32_t b = c->pc_idx[i];
+                out_of[(size_t)b] = a;
                 if (b <= a) continue;
-                const int64_t ri = find_in(b, a);
-                const double ww = maxweight(c->pc_w[i], ri >= 0 ? c->pc_w[ri] : NAN);
+                const int32_t *it = std::lower_bound(ib, ie, b);
+                const double ww = maxweight(c->pc_w[i], (it != ie && *it == b) ? in_w[(size_t)(in_off[a] + (it - ib))] : NAN);
                 if (std::isnan(ww)) continue;
                 es.push_back(a);
                 ed.push_back(b);
@@ -714,17 +794,20 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
             }
             for (int64_t q = in_off[a]; q < in_off[a + 1]; ++q) {  // only b -> a exists
                 const int32_t b = in_idx[(size_t)q];
-                if (b <= a || find_in(a, b) >= 0) continue;
-                const int64_t ri = find_in(b, a);
-                if (ri < 0) continue;
-                const double ww = maxweight(c->pc_w[ri], NAN);
+                if (b <= a || out_of[(size_t)b] == a) continue;
+                const double ww = maxweight(in_w[(size_t)q], NAN);
                 if (std::isnan(ww)) continue;
                 es.push_back(a);
                 ed.push_back(b);
                 ew.push_back(ww);
             }
         }
+        bs[(size_t)w] = std::move(es);
+        bd[(size_t)w] = std::move(ed);
+        bw[(size_t)w] = std::move(ew);
+        w_t1[(size_t)w] = now_s();
     });
+    const double tq4 = now_s();
     for (int w = 0; w < n_thr; ++w) {
         c->e_src.insert(c->e_src.end(), bs[(size_t)w].begin(), bs[(size_t)w].end());
         c->e_dst.insert(c->e_dst.end(), bd[(size_t)w].begin(), bd[(size_t)w].end());
@@ -734,6 +817,16 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
     if (fw_knob("FW_TRACE_HOST"))
         fprintf(stderr, "[fw] weights + symmetric graph on the host: %.2f ms (directed CSR %.2f, signs %.2f, transpose %.2f, edges %.2f; %d threads)\n",
                 1e3 * (now_s() - tp0), 1e3 * (tq1 - tp0), 1e3 * (tq2 - tq1), 1e3 * (tq3 - tq2), 1e3 * (now_s() - tq3), n_thr);
+    if (fw_knob("FW_TRACE_HOST")) {
+        double d0 = 0, d1 = 0, lmax = 0;
+        for (int w = 0; w < n_thr; ++w) {
+            d0 = std::max(d0, w_t0[(size_t)w] - tq3);
+            d1 = std::max(d1, w_t1[(size_t)w] - w_t0[(size_t)w]);
+            lmax = std::max(lmax, tq4 - w_t1[(size_t)w]);
+        }
+        fprintf(stderr, "[fw]   edges pass: latest start %.3f ms after the call, longest block %.3f ms, return %.3f ms, concatenation %.3f ms (ne %zu)\n",
+                1e3 * d0, 1e3 * d1, 1e3 * (tq4 - tq3), 1e3 * (now_s() - tq4), ne);
+    }
     if (n_edges_out) *n_edges_out = (int64_t)c->e_src.size();
     return FW_OK;
 }

@@ -178,6 +178,7 @@ struct fw_ctx {
 
     // ---- network result ----
     bool have_network = false;
+    struct FwHostWorkers *host_workers = nullptr;  // host threads of the graph passes (fw_hiton.cpp), started at the first network that wants them
     std::vector<int32_t> e_src, e_dst;
     std::vector<double> e_w;
     std::vector<int64_t> pc_off;
@@ -248,6 +249,7 @@ int fwi_fznz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> 
                     std::vector<double> &pval, int64_t *m_reliable, FwL0Dev *dev);
 int fwi_fznz_submatrices(fw_ctx *ctx, int64_t njobs, const FwNzJob *recs_host, size_t arena_floats, const int32_t *d_acc,
                          hipStream_t stream, bool f64 = false);
+void fwi_host_workers_free(fw_ctx *c);
 int fwi_mi_big_limits(fw_ctx *ctx, int k);  // FW_OK if discrete tests with k (6, 7) conditioning variables fit the large LDS table
 int fwi_fznz_dev_limits(fw_ctx *ctx, int m_max);  // FW_OK if a job of m_max variables fits the sub-matrix kernel's LDS
 int fwi_fznz_submatrices_dev(fw_ctx *ctx, int nslots, FwNzJob *d_recs, const int32_t *d_acc, float *d_arena, int m_max, bool any_long, hipStream_t stream);
