@@ -1,6 +1,6 @@
 #!/bin/bash
 export FW_KNOBS=1
-# r05, final kernels (level-0 matrix-core kernel rewritten, exact kernel, fz_nz on the device rounds, the jobs' stop words, the discrete
+# r05, final kernels (level-0 matrix-core kernel rewritten, exact kernel, fz_nz on the device rounds, the discrete
 # kinds' device schedule): randomised parity sweep tests/fuzz_gpu.py against the oracle, seeds disjoint from the earlier rounds'
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r5_fuzz; mkdir -p $O
 timeout 1500 python -m tests.fuzz_gpu --first 500000 --cases 3000 > $O/networks.txt 2>&1; tail -2 $O/networks.txt

@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the per-round neighbour-set exchange (the only collective of the path)."""
+"""world_size-2 and -4 gloo tests of the per-round neighbour-set exchange (the only collective of the path)."""
 import json
 import os
 import subprocess
@@ -7,15 +7,19 @@ import sys
 from tests.util import ROOT
 
 
-def _launch(mode, extra=()):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29653")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), mode, str(r), "2", *extra],
-                              env=env) for r in range(2)]
-    return [p.wait(timeout=600) for p in procs]
+import pytest
 
 
-def test_allgather_callback_gloo_world2():
-    assert _launch("callback") == [0, 0]
+def _launch(mode, extra=(), world=2):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29653 + world))
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), mode, str(r), str(world), *extra],
+                              env=env) for r in range(world)]
+    return [p.wait(timeout=900) for p in procs]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_allgather_callback_gloo(world):
+    assert _launch("callback", world=world) == [0] * world
 
 
 def test_bench_launcher_spawns_n_ranks():

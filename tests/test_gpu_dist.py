@@ -1,4 +1,4 @@
-"""Target-sharded run with 2 ranks (both on GPU 0, gloo transport) equals the single-rank run: results do not
+"""Target-sharded run with 2 and 4 ranks (all on GPU 0, gloo transport) equals the single-rank run: results do not
 depend on the number of ranks."""
 import json
 import os
@@ -12,24 +12,27 @@ from tests.test_dist_cpu import _launch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("l0_mfma", ["1", "2"])
-def test_sharded_equals_single(l0_mfma, monkeypatch):
+@pytest.mark.parametrize("l0_mfma,world", [("1", 2), ("2", 2), ("1", 4)])
+def test_sharded_equals_single(l0_mfma, world, monkeypatch):
     # l0_mfma = "2": the discrete level 0 through the matrix-core kernel whatever the size (its tile list is dealt in super-tile
     # order: mi_level0_mfma_kernel); "1": the default choice (popcount form at this size)
     monkeypatch.setenv("FW_KNOBS", "1")
     monkeypatch.setenv("FW_L0_MFMA", l0_mfma)
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "res")
-        assert _launch("sharded", (out,)) == [0, 0]
+        assert _launch("sharded", (out,), world=world) == [0] * world
         r0 = json.load(open(out + ".0"))
-        r1 = json.load(open(out + ".1"))
+        r1 = json.load(open(out + "." + str(world - 1)))
+        for r in range(1, world - 1):  # (world 4: the ranks in between hold the same networks)
+            rm = json.load(open(out + "." + str(r)))
+            assert all(rm[k] == r0[k] for k in ("fz_ff0", "fz_ff1", "mi_ff0", "mi_ff1", "fz_l0", "mi_l0", "fz_ff1_sharded_cor"))
         for k in ("fz_ff0", "fz_ff1", "mi_ff0", "mi_ff1"):
             assert r0[k] == r1[k]                 # every rank ends with the full network
             assert len(r0[k]) > 0
             if k.startswith("fz"):
                 assert r0[k] == r0[k + "_single"]     # and it equals the single-rank network, weights included
             else:
-                # discrete: 150 targets per rank run through the host pool (one test per wavefront), the single rank's 300 through
+                # discrete: 150 (75) targets per rank run through the host pool (one test per wavefront), the single rank's 300 through
                 # the persistent kernel (four per wavefront at n <= 2048): same edges, statistics to the summation order (1e-12)
                 assert [e[:2] for e in r0[k]] == [e[:2] for e in r0[k + "_single"]]
                 assert all(abs(a[2] - b[2]) <= 1e-12 * abs(b[2]) for a, b in zip(r0[k], r0[k + "_single"]))
