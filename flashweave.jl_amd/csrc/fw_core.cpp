@@ -161,6 +161,9 @@ int fw_ctx_destroy(fw_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     fwi_comm_free(c);
     fwi_host_workers_free(c);
+#ifdef FW_FZ_FASTDBG
+    fwi_fz_fastdbg_print();
+#endif
     if (c->cor_external) c->d_cor = nullptr;  // caller-owned (fw_use_cor_buffer)
     void *ptrs[] = {c->d_data, c->d_xc, c->d_sd, c->d_cor, c->d_thr, c->d_fzs_stat, c->d_nzbits, c->d_hibits, c->d_levels, c->d_maxvals, c->d_firstnz, c->d_xlnx, c->d_gthr, c->d_vals};
     for (void *q : ptrs)

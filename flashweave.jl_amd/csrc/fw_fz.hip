@@ -874,6 +874,15 @@ int fwi_fz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y
     return FW_OK;
 }
 
+#ifdef FW_FZ_FASTDBG
+extern "C" void fwi_fz_fastdbg_print()
+{
+    unsigned long long c[8] = {0};
+    if (hipMemcpyFromSymbol(c, HIP_SYMBOL(fz_fast_cnt), sizeof(c)) == hipSuccess)
+        fprintf(stderr, "[fw] fast loop: wave-iterations %llu, lane-tests %llu; waves with a lane not clean %llu, not significant-for-sure %llu, beyond the normal range of p %llu, behind a stop %llu, tie %llu; lanes beyond the normal range %llu\n",
+                c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+}
+#endif
 static int fz_ensure_thresholds(fw_ctx *ctx, hipStream_t stream)
 {
     if (!ctx->d_thr) {

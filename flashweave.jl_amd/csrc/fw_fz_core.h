@@ -445,6 +445,9 @@ __device__ __forceinline__ double pc_l3(double a, double b, double c)
 // reuses every partial correlation that does not involve the position that changed (for max_k = 3 that is 4 of the
 // 10 formula evaluations and 6 of the 10 matrix entries).  Rank order is preserved: a lane stops at its first
 // stopping rank, the workgroup takes the minimum over lanes.
+#ifndef FW_FZ_FASTLOOP
+#define FW_FZ_FASTLOOP 1  // table kernel: the common size-3 test behind one wave-uniform branch (0: the general form only; A/B knob)
+#endif
 #ifndef FW_FZ_INTERLEAVE
 #define FW_FZ_INTERLEAVE 1  // table kernel: interleaved lane <-> rank mapping for size-3 chunks (0: runs everywhere; A/B knob)
 #endif
@@ -587,6 +590,9 @@ __device__ __forceinline__ double fz_hk_stat(const double *__restrict__ tb, int 
 // matrix entries among its own later positions (6 instead of 21 for size 5) and evaluates 6 level-1 formulas with
 // ready-made roots instead of 15 full ones; levels 2..K are fz_pcor_levels as before (same values, same order).
 #define FZ_L1_A 512  // (r03: 1024 -> 512: with the level-3 tables LDS bounds the occupancy of this variant; cfg5's longest list is 480)
+#ifdef FW_FZ_FASTDBG
+static __device__ unsigned long long fz_fast_cnt[8];
+#endif
 static __device__ int fz_dbg_flags;  // profiling knob (FW_FZ_DBG, set by fz_ensure_thresholds): bit 0 = no level-1 table
 template <int K>
 __device__ __forceinline__ double fz_l1t_stat(const float *__restrict__ cor, int p, const float4 *__restrict__ tab,
@@ -1169,6 +1175,91 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 double l3_ev = 0.0, l3_xb = 1.0, l3_xc = 1.0;
                 bool screened = false;  // TAB3 fast path: stat is still (l3_ev, l3_xb, l3_xc)
                 ++my_done;
+                if (TAB3 && FW_FZ_FASTLOOP && ilv && tab_ok) {
+                    // (workgroup-uniform: the whole chunk lies in the size-3 enumeration and has its table.)  r05: the common test in one
+                    // piece -- every entry clean, the test "significant for sure" on the squares, no stop in front of it, and the
+                    // maximum-p bookkeeping decided without a quotient (clearly larger: nothing; clearly smaller or nothing yet: taken
+                    // by selects).  When that holds for EVERY lane of the wavefront the iteration ends here behind ONE scalar branch;
+                    // otherwise nothing has been committed and the general code below runs the test again with all its cases (same
+                    // values: the same functions on the same operands).  In the general form each of those cases is a v_cmp + exec
+                    // mask + branch per test: ~170 of the ~290 vector instructions of a test (profiles/r05_cfg3_pmc_summary.json:
+                    // 2.06 of 4.50 VALU per test are moves / compares / selects).
+                    const int pi = pos[0];
+                    if (chg <= 0) boff = fz_tab_off(pi, tb_i0, a) - pi - 1;
+                    const int ej = boff + pos[1];
+                    tj = s_tab[ej];
+                    rj1 = s_tab_r1[ej];
+                    rj2 = s_tab_r2[ej];
+                    A2j = s_tab_a2[ej];
+                    const int ek = boff + pos[2];
+                    const float4 tk = s_tab[ek];
+                    const float rk1 = s_tab_r1[ek];
+                    const int fj = __float_as_int(tj.w), fk = __float_as_int(tk.w);
+                    const float c32 = CORT(fk & FZ_TAB_ZMASK, fj & FZ_TAB_ZMASK);
+                    bool f1ok;
+                    const float F1f = pc_l1_rf(c32, tk.z, tj.z, rk1, rj1, f1ok);
+                    const double F1v = (double)F1f;
+                    const double dF = fz_sqrt_unit(1.0 - F1v * F1v);
+                    const bool clean = (((fj & fk) >> 28) & 7) == 7 && f1ok;
+                    const double D2 = pc_l2_all32_d1_nn(tk.x, tj.x, F1f, (double)rj2.x, dF);
+                    const double E2 = pc_l2_all32_d1_nn(tk.y, tj.y, F1f, (double)rj2.y, dF);
+                    const double f_ev = round5_f64_nn(A2j - D2 * E2), f_xb = 1.0 - D2 * D2, f_xc = 1.0 - E2 * E2;
+                    const double f_m2 = f_xb * f_xc, f_e2 = f_ev * f_ev;
+                    const bool f_sure = f_e2 > (f_ev < 0.0 ? h2_neg : h2_pos) * f_m2 && f_e2 < s2 * f_m2 &&
+                                        !(max_tests > 0 && r + 1 >= (unsigned long long)max_tests);
+                    const bool f_nostop = !(__hip_atomic_load(&s_cstop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned int)(r - cbase));
+                    const double f_lhs = f_e2 * (my_bxb * my_bxc), f_rhs = (my_bev * my_bev) * f_m2;
+                    const bool f_take = my_bx > FZ_X_SUB || f_lhs < f_rhs * (1.0 - 1e-11);
+                    const bool f_tie = !f_take && f_lhs <= f_rhs * (1.0 + 1e-11);
+#ifdef FW_FZ_FASTDBG
+                    {
+                        const bool sig = f_e2 > (f_ev < 0.0 ? h2_neg : h2_pos) * f_m2, nrm = f_e2 < s2 * f_m2;
+                        const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+                        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (unsigned)__builtin_ctzll(act)) {
+                            atomicAdd(&fz_fast_cnt[0], 1ull);
+                            atomicAdd(&fz_fast_cnt[1], (unsigned long long)__builtin_popcountll(act));
+                        }
+                        const unsigned long long b_clean = __builtin_amdgcn_ballot_w64(!clean), b_sig = __builtin_amdgcn_ballot_w64(!sig), b_nrm = __builtin_amdgcn_ballot_w64(!nrm),
+                                                 b_stop = __builtin_amdgcn_ballot_w64(!f_nostop), b_tie = __builtin_amdgcn_ballot_w64(f_tie);
+                        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (unsigned)__builtin_ctzll(act)) {
+                            if (b_clean) atomicAdd(&fz_fast_cnt[2], 1ull);
+                            if (b_sig) atomicAdd(&fz_fast_cnt[3], 1ull);
+                            if (b_nrm) atomicAdd(&fz_fast_cnt[4], 1ull);
+                            if (b_stop) atomicAdd(&fz_fast_cnt[5], 1ull);
+                            if (b_tie) atomicAdd(&fz_fast_cnt[6], 1ull);
+                            atomicAdd(&fz_fast_cnt[7], (unsigned long long)__builtin_popcountll(b_nrm));
+                        }
+                    }
+#endif
+                    if (__all(clean && f_sure && f_nostop && !f_tie)) {
+                        if (f_take) {
+                            my_bx = FZ_X_LAZY;
+                            my_bps = 0.0;
+                            my_br = r;
+                            my_bev = f_ev;
+                            my_bxb = f_xb;
+                            my_bxc = f_xc;
+                        }
+                        if (r + 64ull >= r1) break;
+                        int i = pos[0], j = pos[1], k = pos[2] + 64;
+                        chg = 2;
+                        while (k > a - 1) {
+                            const int over = k - a;
+                            if (++j > a - 2) {
+                                ++i;
+                                j = i + 1;
+                                chg = 0;
+                            } else if (chg > 1) {
+                                chg = 1;
+                            }
+                            k = j + 1 + over;
+                        }
+                        pos[0] = i;
+                        pos[1] = j;
+                        pos[2] = k;
+                        continue;
+                    }
+                }
                 if (HK && s >= 4) {  // (every chunk of this variant that holds subsets of 4 or 5 variables has its tables)
                     if (!hk_ok || s != hk_s) __builtin_trap();  // would be a chunking bug: fail loudly
                     if (chg <= 1) {  // (z1, z2) changed: this sub-block's table

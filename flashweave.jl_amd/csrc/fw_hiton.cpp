@@ -832,6 +832,9 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
         fprintf(stderr, "[fw]   edges pass: latest start %.3f ms after the call, longest block %.3f ms, return %.3f ms, concatenation %.3f ms (ne %zu)\n",
                 1e3 * d0, 1e3 * d1, 1e3 * (tq4 - tq3), 1e3 * (now_s() - tq4), ne);
     }
+#ifdef FW_FZ_FASTDBG
+    fwi_fz_fastdbg_print();
+#endif
     if (n_edges_out) *n_edges_out = (int64_t)c->e_src.size();
     return FW_OK;
 }

@@ -250,6 +250,9 @@ int fwi_fznz_level0(fw_ctx *ctx, std::vector<int32_t> &pi, std::vector<int32_t> 
 int fwi_fznz_submatrices(fw_ctx *ctx, int64_t njobs, const FwNzJob *recs_host, size_t arena_floats, const int32_t *d_acc,
                          hipStream_t stream, bool f64 = false);
 void fwi_host_workers_free(fw_ctx *c);
+#ifdef FW_FZ_FASTDBG
+extern "C" void fwi_fz_fastdbg_print();  // fw_fz.hip: counters of the size-3 fast loop (profiling build only)
+#endif
 int fwi_mi_big_limits(fw_ctx *ctx, int k);  // FW_OK if discrete tests with k (6, 7) conditioning variables fit the large LDS table
 int fwi_fznz_dev_limits(fw_ctx *ctx, int m_max);  // FW_OK if a job of m_max variables fits the sub-matrix kernel's LDS
 int fwi_fznz_submatrices_dev(fw_ctx *ctx, int nslots, FwNzJob *d_recs, const int32_t *d_acc, float *d_arena, int m_max, bool any_long, hipStream_t stream);
