@@ -877,10 +877,13 @@ int fwi_fz_test_batch(fw_ctx *ctx, int64_t m, const int32_t *X, const int32_t *Y
 #ifdef FW_FZ_FASTDBG
 extern "C" void fwi_fz_fastdbg_print()
 {
-    unsigned long long c[8] = {0};
+    unsigned long long c[16] = {0};
     if (hipMemcpyFromSymbol(c, HIP_SYMBOL(fz_fast_cnt), sizeof(c)) == hipSuccess)
         fprintf(stderr, "[fw] fast loop: wave-iterations %llu, lane-tests %llu; waves with a lane not clean %llu, not significant-for-sure %llu, beyond the normal range of p %llu, behind a stop %llu, tie %llu; lanes beyond the normal range %llu\n",
                 c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+    if (c[8])
+        fprintf(stderr, "[fw] segments (table variant) %llu, evaluated %llu; 100 MHz ticks per segment (first wavefront): prologue %.1f, table build %.1f, lane loop %.1f, reductions %.1f, whole body %.1f\n",
+                c[8], c[14], (double)c[9] / c[8], (double)c[10] / c[8], (double)c[11] / c[8], (double)c[12] / c[8], (double)c[13] / c[8]);
 }
 #endif
 static int fz_ensure_thresholds(fw_ctx *ctx, hipStream_t stream)

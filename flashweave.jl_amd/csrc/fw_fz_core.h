@@ -591,7 +591,7 @@ __device__ __forceinline__ double fz_hk_stat(const double *__restrict__ tb, int 
 // ready-made roots instead of 15 full ones; levels 2..K are fz_pcor_levels as before (same values, same order).
 #define FZ_L1_A 512  // (r03: 1024 -> 512: with the level-3 tables LDS bounds the occupancy of this variant; cfg5's longest list is 480)
 #ifdef FW_FZ_FASTDBG
-static __device__ unsigned long long fz_fast_cnt[8];
+static __device__ unsigned long long fz_fast_cnt[16];
 #endif
 static __device__ int fz_dbg_flags;  // profiling knob (FW_FZ_DBG, set by fz_ensure_thresholds): bit 0 = no level-1 table
 template <int K>
@@ -718,6 +718,10 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     __shared__ double s_tab_a2[TAB3 ? FZ_TAB_CAP : 1]; // rho(X, Y | z1, v)
     __shared__ int s_blk[2];
 
+#ifdef FW_FZ_FASTDBG
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long dbg_t1 = 0, dbg_tab = 0, dbg_loop = 0, dbg_red = 0;
+#endif
     const int a = seg.acc_len;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool in_lds = a <= (TAB3 ? FZ_TAB_A : (HK ? FZ_HK_A : (L1T ? FZ_L1_A : FW_ACC_LDS)));
@@ -800,6 +804,10 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
 
     unsigned long long cnext = seg.start;
     for (unsigned long long cbase = seg.start; cbase < seg.end; cbase = cnext) {
+#ifdef FW_FZ_FASTDBG
+        const unsigned long long dbg_c0 = __builtin_amdgcn_s_memtime();
+        if (!dbg_t1) dbg_t1 = dbg_c0;
+#endif
         unsigned long long cend = cbase + 256ull * R;
         cend = cend < seg.end ? cend : seg.end;
         int Rc = R;
@@ -1126,6 +1134,9 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 __syncthreads();
             }
         }
+#ifdef FW_FZ_FASTDBG
+        const unsigned long long dbg_c1 = __builtin_amdgcn_s_memtime();
+#endif
         // lane-local results
         unsigned long long my_stop = NONE, my_br = 0;
         double stop_stat = 0.0, stop_p = 0.0, my_bstat = 0.0;
@@ -1184,6 +1195,8 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                     // values: the same functions on the same operands).  In the general form each of those cases is a v_cmp + exec
                     // mask + branch per test: ~170 of the ~290 vector instructions of a test (profiles/r05_cfg3_pmc_summary.json:
                     // 2.06 of 4.50 VALU per test are moves / compares / selects).
+                    // (Two tests per iteration -- this rank and the one 64 further, two independent chains -- measured slower: 175.6 against
+                    // 167.8 ms on one box, profiles/r05_cfg3_fast_loop.txt.)
                     const int pi = pos[0];
                     if (chg <= 0) boff = fz_tab_off(pi, tb_i0, a) - pi - 1;
                     const int ej = boff + pos[1];
@@ -1211,7 +1224,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                     const double f_lhs = f_e2 * (my_bxb * my_bxc), f_rhs = (my_bev * my_bev) * f_m2;
                     const bool f_take = my_bx > FZ_X_SUB || f_lhs < f_rhs * (1.0 - 1e-11);
                     const bool f_tie = !f_take && f_lhs <= f_rhs * (1.0 + 1e-11);
-#ifdef FW_FZ_FASTDBG
+#if defined(FW_FZ_FASTDBG) && FW_FZ_FASTDBG >= 2
                     {
                         const bool sig = f_e2 > (f_ev < 0.0 ? h2_neg : h2_pos) * f_m2, nrm = f_e2 < s2 * f_m2;
                         const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
@@ -1609,6 +1622,9 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 }
             }
         }
+#ifdef FW_FZ_FASTDBG
+        const unsigned long long dbg_c2 = __builtin_amdgcn_s_memtime();
+#endif
         if (SCR) {  // the lane best's statistic (its quotient, if it has not been taken yet)
             if (my_bx != FZ_X_NONE && (my_bxb != 1.0 || my_bxc != 1.0)) my_bev = fz_l3_finish(my_bev, my_bxb, my_bxc);
             my_bstat = my_bev;
@@ -1686,6 +1702,14 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
             s_best_rank = my_br;
         }
         __syncthreads();
+#ifdef FW_FZ_FASTDBG
+        {
+            const unsigned long long dbg_c3 = __builtin_amdgcn_s_memtime();
+            dbg_tab += dbg_c1 - dbg_c0;
+            dbg_loop += dbg_c2 - dbg_c1;
+            dbg_red += dbg_c3 - dbg_c2;
+        }
+#endif
     }
 #undef ACCV
 #undef CORV
@@ -1704,5 +1728,16 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
         o.pad = 0;
         o.evaluated = evaluated;
         *out_rec = o;
+#ifdef FW_FZ_FASTDBG
+        if (TAB3) {
+            atomicAdd(&fz_fast_cnt[8], 1ull);
+            atomicAdd(&fz_fast_cnt[9], dbg_t1 - dbg_t0);
+            atomicAdd(&fz_fast_cnt[10], dbg_tab);
+            atomicAdd(&fz_fast_cnt[11], dbg_loop);
+            atomicAdd(&fz_fast_cnt[12], dbg_red);
+            atomicAdd(&fz_fast_cnt[13], __builtin_amdgcn_s_memtime() - dbg_t0);
+            atomicAdd(&fz_fast_cnt[14], evaluated);
+        }
+#endif
     }
 }
