@@ -1169,6 +1169,8 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
             TV A1{0.0, false}, B1{0.0, false}, C1{0.0, false};
             double A2 = 0.0;
             int boff = 0;
+            float pf_c32 = 0.0f;  // fast loop: the matrix entry of THIS iteration's test, fetched during the previous one
+            bool pf_ok = false;
             const double *hk_tb = s_hk;
             int hk_j = 0;
             float4 tj = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1208,11 +1210,34 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                     const float4 tk = s_tab[ek];
                     const float rk1 = s_tab_r1[ek];
                     const int fj = __float_as_int(tj.w), fk = __float_as_int(tk.w);
-                    const float c32 = CORT(fk & FZ_TAB_ZMASK, fj & FZ_TAB_ZMASK);
+                    float c32 = pf_c32;  // fetched during the previous iteration (below); a lane's first iteration behind the general form: now
+                    if (!pf_ok) {
+                        c32 = CORT(fk & FZ_TAB_ZMASK, fj & FZ_TAB_ZMASK);
+                        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) HERE: behind the join the compiler would otherwise wait for everything in flight, the next entry included
+                    }
+                    // the next test of this lane (64 ranks ahead): its position, and its matrix entry on the way while this test is
+                    // evaluated -- the gather (two table words, then the entry) is otherwise the head of every test's dependent chain
+                    const bool hasN = r + 64ull < r1;
+                    int ni = pos[0], nj = pos[1], nk = pos[2] + (hasN ? 64 : 0), nchg = 2;
+                    while (nk > a - 1) {  // row (i, j) holds k = j + 1 .. a - 1: carry the overflow into the next rows
+                        const int over = nk - a;
+                        if (++nj > a - 2) {
+                            ++ni;
+                            nj = ni + 1;
+                            nchg = 0;
+                        } else if (nchg > 1) {
+                            nchg = 1;
+                        }
+                        nk = nj + 1 + over;
+                    }
+                    int nboff = boff;
+                    if (nchg <= 0) nboff = fz_tab_off(ni, tb_i0, a) - ni - 1;
+                    const int nfj = __float_as_int(s_tab[nboff + nj].w), nfk = __float_as_int(s_tab[nboff + nk].w);  // (in range also without a next test: this test's row)
                     bool f1ok;
                     const float F1f = pc_l1_rf(c32, tk.z, tj.z, rk1, rj1, f1ok);
                     const double F1v = (double)F1f;
                     const double dF = fz_sqrt_unit(1.0 - F1v * F1v);
+                    if (hasN) pf_c32 = CORT(nfk & FZ_TAB_ZMASK, nfj & FZ_TAB_ZMASK);  // straight into the loop-carried register: a copy at the end of the iteration would wait for it
                     const bool clean = (((fj & fk) >> 28) & 7) == 7 && f1ok;
                     const double D2 = pc_l2_all32_d1_nn(tk.x, tj.x, F1f, (double)rj2.x, dF);
                     const double E2 = pc_l2_all32_d1_nn(tk.y, tj.y, F1f, (double)rj2.y, dF);
@@ -1253,25 +1278,16 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                             my_bxb = f_xb;
                             my_bxc = f_xc;
                         }
-                        if (r + 64ull >= r1) break;
-                        int i = pos[0], j = pos[1], k = pos[2] + 64;
-                        chg = 2;
-                        while (k > a - 1) {
-                            const int over = k - a;
-                            if (++j > a - 2) {
-                                ++i;
-                                j = i + 1;
-                                chg = 0;
-                            } else if (chg > 1) {
-                                chg = 1;
-                            }
-                            k = j + 1 + over;
-                        }
-                        pos[0] = i;
-                        pos[1] = j;
-                        pos[2] = k;
+                        if (!hasN) break;
+                        pos[0] = ni;
+                        pos[1] = nj;
+                        pos[2] = nk;
+                        chg = nchg;
+                        boff = nboff;
+                        pf_ok = true;
                         continue;
                     }
+                    pf_ok = false;
                 }
                 if (HK && s >= 4) {  // (every chunk of this variant that holds subsets of 4 or 5 variables has its tables)
                     if (!hk_ok || s != hk_s) __builtin_trap();  // would be a chunking bug: fail loudly
