@@ -397,6 +397,20 @@ __device__ __forceinline__ double fz_div_nn(double n, double d)
     return __builtin_amdgcn_div_fixup(__builtin_fma(r, y, q), d, n);
 }
 
+// pc_l2_d2 for NaN-free children of which some may be Float64 literals (0, +-1: exact in Float32 as well, so the product b c and the
+// root d1 = sqrt(1 - b^2) are the same values in either arithmetic): only `a - b c` and its rounding are done in Float32 when all three
+// are Float32 values and in Float64 otherwise
+__device__ __forceinline__ double pc_l2_mix_d1_nn(float a, float b, float c, bool all32, double d1, double d2c)
+{
+    const float prod = b * c;
+    const double ev32 = (double)round5_f32_nn(a - prod);
+    const double ev64 = round5_f64_nn((double)a - (double)prod);
+    const double ev = all32 ? ev32 : ev64;
+    const double denom = d1 * d2c;
+    const double v = (denom == 0.0) ? 0.0 : fz_div_nn(ev, denom);
+    return fz_clamp_unit_nn(v);
+}
+
 __device__ __forceinline__ double pc_l2_all32_d1_nn(float a, float b, float c, double d1, double d2c)
 {
     const float prod = b * c;
@@ -447,6 +461,9 @@ __device__ __forceinline__ double pc_l3(double a, double b, double c)
 // stopping rank, the workgroup takes the minimum over lanes.
 #ifndef FW_FZ_FASTLOOP
 #define FW_FZ_FASTLOOP 1  // table kernel: the common size-3 test behind one wave-uniform branch (0: the general form only; A/B knob)
+#endif
+#ifndef FW_L3_ENTRY_NN
+#define FW_L3_ENTRY_NN 1  // long-list kernel: NaN-free arithmetic decided per test (its two table entries) where the chunk's tables are not clean (0: per chunk only; A/B knob)
 #endif
 #ifndef FW_FZ_INTERLEAVE
 #define FW_FZ_INTERLEAVE 1  // table kernel: interleaved lane <-> rank mapping for size-3 chunks (0: runs everywhere; A/B knob)
@@ -1056,7 +1073,6 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                             const float p2f = (float)P2w.v;
                             s3_p2[e] = p2f;
                             s3_r2[e] = sqrtf(1.0f - p2f * p2f);  // the d1 of a level-2 formula whose first conditioning value is this one
-                            s3_fl[e] = P2w.f32 ? 1 : 0;
                             s3_d2c[e] = dw;
                             s3_q3[e] = Q3;
                             s3_sq3[e] = sq;
@@ -1066,7 +1082,14 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                             s3_sy3[e] = sy;
                             const double A4 = pc_l3s(s3_ba3[d], X3, Y3, sx, sy);  // rho(X,Y|z1,z2,z3,w): the size-4 statistic
                             s3_a4[e] = A4;
-                            if (!(P2w.f32 && Q3 == Q3 && X3 == X3 && Y3 == Y3 && A4 == A4)) s3_dirty = 1;
+                            // bit 0: rho(w,z2|z1) is still a Float32 value; bit 1 (r05): this ENTRY is clean -- Float32-typed and no NaN in it.  A
+                            // size-5 test whose two entries are clean takes the NaN-free arithmetic also in a chunk that holds an unclean
+                            // entry somewhere else (cfg5: 40 % of the size-5 tests sat in such chunks and took the NaN-preserving form
+                            // with its IEEE divisions for one entry in ~900)
+                            const bool e_nonan = P2w.v == P2w.v && Q3 == Q3 && X3 == X3 && Y3 == Y3 && A4 == A4;  // bit 2: no NaN in it (Float32-typed or not)
+                            const bool e_clean = P2w.f32 && e_nonan;
+                            s3_fl[e] = (unsigned char)((P2w.f32 ? 1 : 0) | (e_clean ? 2 : 0) | (e_nonan ? 4 : 0));
+                            if (!e_clean) s3_dirty = 1;
                         }
                         __syncthreads();
                         l3_nn = s3_dirty == 0 && l1_clean;
@@ -1181,7 +1204,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
             int l3_base = 0, zl = 0;
             float4 t1l = make_float4(0.f, 0.f, 0.f, 0.f);
             float p2l = 0.f;
-            bool fl3 = false;
+            bool fl3 = false, cl3 = false, nn3 = false;
             double d2cl = 0.0, q3l = 0.0, sq3l = 0.0, x3l = 0.0, sx3l = 0.0, y3l = 0.0, sy3l = 0.0, a4l = 0.0;
             for (unsigned long long r = r0; r < r1; r += rstep) {
                 double stat;
@@ -1399,7 +1422,9 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                             t1l = s_l1[pl];
                             zl = s_acc[pl];
                             p2l = s3_p2[el];
-                            fl3 = s3_fl[el] != 0;
+                            fl3 = (s3_fl[el] & 1) != 0;
+                            cl3 = (s3_fl[el] & 2) != 0;
+                            nn3 = (s3_fl[el] & 4) != 0;
                             d2cl = s3_d2c[el];
                             q3l = s3_q3[el];
                             sq3l = s3_sq3[el];
@@ -1414,10 +1439,19 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                         const float c45 = CORT(s_acc[pm], zl);
                         bool f1ok;
                         const float R1f = pc_l1_rf(c45, t1m.z, t1l.z, t1m.w, t1l.w, f1ok);     // rho(v,z4|z1)
-                        if (__all(l3_nn && f1ok)) {
-                            // wave-uniform fast path: no NaN and no Float64 literal among the inputs -- the NaN-preserving selects of
-                            // the clamps / round5 become v_max + v_min and plain arithmetic: the same values for these inputs
-                            const double R2 = pc_l2_all32_d1_nn(R1f, s3_p2[em], p2l, (double)s3_r2[em], d2cl);  // rho(v,z4|z1,z2)
+                        const int flm = (l3_nn || !FW_L3_ENTRY_NN) ? 7 : (int)s3_fl[em];
+                        const bool t_nn = l3_nn || (FW_L3_ENTRY_NN && cl3 && (flm & 2) != 0);  // the chunk's tables clean, or this test's two entries
+                        const bool nn_all32 = __all(t_nn && f1ok);
+                        // r05: no NaN among the inputs but a Float64 literal (a clamped or zero-denominator level-1 value: 0.5 % of cfg5's
+                        // size-5 tests, one lane in every fourth wavefront): only the numerator of the level-2 formula depends on the
+                        // types (Float32 arithmetic when all three children are Float32 values: pc_l2_d2) -- a select, not the
+                        // NaN-preserving form
+                        const bool nn_mix = FW_L3_ENTRY_NN && !nn_all32 && __all(nn3 && (flm & 4) != 0 && R1f == R1f);
+                        if (nn_all32 || nn_mix) {
+                            // wave-uniform fast path: no NaN (and, nn_all32, no Float64 literal) among the inputs -- the NaN-preserving selects
+                            // of the clamps / round5 become v_max + v_min and plain arithmetic: the same values for these inputs
+                            const double R2 = nn_all32 ? pc_l2_all32_d1_nn(R1f, s3_p2[em], p2l, (double)s3_r2[em], d2cl)  // rho(v,z4|z1,z2)
+                                                       : pc_l2_mix_d1_nn(R1f, s3_p2[em], p2l, f1ok && (flm & 1) != 0 && fl3, (double)s3_r2[em], d2cl);
                             const double R3 = pc_l3s_nn(R2, s3_q3[em], q3l, s3_sq3[em], sq3l);                  // rho(v,z4|z1,z2,z3)
                             const double s45 = fz_sq1(R3);
                             const double X4 = pc_l3s_nn(s3_x3[em], x3l, R3, sx3l, s45);                         // rho(X,v|z1..z4)
@@ -1436,7 +1470,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                             }
                         } else {
                             const TV R1 = pc_l1_r(c45, t1m.z, t1l.z, t1m.w, t1l.w);
-                            const TV Bm{(double)s3_p2[em], s3_fl[em] != 0}, Cl{(double)p2l, fl3};
+                            const TV Bm{(double)s3_p2[em], (s3_fl[em] & 1) != 0}, Cl{(double)p2l, fl3};
                             const double R2 = pc_l2_d2(R1, Bm, Cl, d2cl);                      // v is the first of the pair
                             const double R3 = pc_l3s(R2, s3_q3[em], q3l, s3_sq3[em], sq3l);
                             const double s45 = fz_sq1(R3);
