@@ -116,6 +116,7 @@ def parse_args(argv=None):
     ap.add_argument("--host-seam", action="store_true",
                     help="also time the pass with FW_HOST_HITON=1: the host job pool over fw_test_subsets_batch-style "
                          "launches, the seam a Julia host would call (hiton.jl:100)")
+    ap.add_argument("--check-determinism", action="store_true", help="compare every timed pass with the first (network bytes, reference-order test count) and report on stderr; not for a measured line")
     ap.add_argument("--host-normalize", action="store_true", help="normalise the count table with the host front-end (preprocess.py) instead of the device one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -457,10 +458,25 @@ def main():
         barrier()
         t0 = time.perf_counter()
         net = None
-        for _ in range(steps):
+        det = {"first": None, "differing": 0, "ref_first": None, "prev": 0, "which": []}
+        for i_step in range(steps):
             net = step(ff, R)
+            if args.check_determinism:  # (changes the timing: not for a measured line) every pass against the first: network bytes + reference-order test count
+                key = tuple(net[k].tobytes() for k in ("edge_src", "edge_dst", "edge_weight", "pc_off", "pc_idx", "pc_weight", "pc_pval"))
+                c_now = eng.counters()["cond_tests_ref"]
+                n_ref = c_now - det["prev"]
+                det["prev"] = c_now
+                if det["first"] is None:
+                    det["first"], det["ref_first"] = key, n_ref
+                elif key != det["first"] or n_ref != det["ref_first"]:
+                    det["differing"] += 1
+                    if len(det["which"]) < 16:
+                        det["which"].append([i_step, int(len(net["edge_src"])), int(n_ref)])
         barrier()
         dt = time.perf_counter() - t0
+        if args.check_determinism:
+            print("[bench] determinism check (ff=%d): %d of %d passes differ from the first (edges %d, reference-order tests %d): %s"
+                  % (ff, det["differing"], steps, len(net["edge_src"]), det["ref_first"], det["which"]), file=sys.stderr, flush=True)
         if lib_comm:  # the library's own exchange counters (fw_comm_stats), same keys as the Python callbacks keep
             cs1 = eng.comm_stats()
             xstats.update({k: cs1[k] - cs0[k] for k in ("calls", "collectives", "entries", "seconds")})

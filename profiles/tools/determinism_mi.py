@@ -18,8 +18,10 @@ eng.set_data(data)
 R = 1024 * ((p + 10239) // 10240)
 ref = None; bad = 0; prev_ref_tests = 0
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 200):
-    eng.level0()
-    net = eng.lgl(feed_forward=ff, round_size=R if ff else 0, edge_dict=False)
+    import time
+    t0 = time.perf_counter(); eng.level0(); t1 = time.perf_counter()
+    net = eng.lgl(feed_forward=ff, round_size=R if ff else 0, edge_dict=False); t2 = time.perf_counter()
+    if it < 4 or os.environ.get('DET_VERBOSE'): print('pass', it, 'level0 %.1f ms, lgl %.1f ms' % (1e3 * (t1 - t0), 1e3 * (t2 - t1)), flush=True)
     c = eng.counters()["cond_tests_ref"]; nref = c - prev_ref_tests; prev_ref_tests = c
     key = tuple(net[k].tobytes() for k in ("edge_src", "edge_dst", "edge_weight", "pc_off", "pc_idx", "pc_weight", "pc_pval"))
     if ref is None:
