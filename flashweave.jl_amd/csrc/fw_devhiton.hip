@@ -1089,6 +1089,7 @@ __device__ __noinline__ bool mi_help(MiQueue *__restrict__ Q, MiBoard *__restric
 // `>=` maximum), and what is left of a long enumeration goes to a board as before -- with three helpers that are there at once.
 struct MiTeamJob {
     int go, cand, a, tail;
+    int hw;                   // R4: the MiAhead slot that already holds this job's first test (-1: none) -- decided by the leader alone
     long long acc_off;
     unsigned long long N;
     unsigned int board;       // board of the current window (MI_BOARD_CAP: none, the leader ran the window alone)
@@ -1171,6 +1172,20 @@ __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, 
                     J.N = dh_enum_size(x.na, P.max_k, P.max_tests);
                     J.tail = (P.mi_team_tail || (mi_ld_u32(&Q->next_target) + P.mi_team >= (unsigned int)ntg &&
                                                  ((unsigned int)ntg - mi_ld_u32(&Q->targets_done)) * 8u <= gridDim.x * 4u)) ? 1 : 0;
+                    // Which look-ahead slot (if any) holds this job's first test is decided HERE, by the leader, between the barrier that
+                    // ends the previous job and the one that starts this one: no wavefront writes a slot in that interval.  (r05 let every
+                    // wavefront scan the slots inside the job, while wavefront 0 could already be rewriting its own in mi_first4: a late
+                    // wavefront then saw the NEW slot 0, skipped the compute branch and its barrier, and ran one barrier behind the others
+                    // from there on -- one of the two races behind the pass-to-pass differences of profiles/r05_discrete_pass_to_pass.txt.)
+                    int hw = -1;
+                    if (R4 && P.mi_ahead && x.phase == 0 && x.na >= 1 && J.N >= 1ull) {
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const MiAhead &Hq = dh_mi_ahead[w];
+                            if (Hq.n > 0 && Hq.T == x.T && Hq.na == x.na && x.pos >= Hq.pos0 && x.pos < Hq.pos0 + Hq.n) hw = w;
+                        }
+                    }
+                    J.hw = hw;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1203,14 +1218,9 @@ __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, 
             // lock-step round of 16 ranks of ITS OWN enumeration, 15 of them behind the stop (cfg2: 946 000 executed tests for 287 000).
             if (P.mi_ahead && x.phase == 0 && a >= 1 && N >= 1ull) {
                 const int32_t *cands = A.cand0 + x.cand_off;
-                int hw = -1;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const MiAhead &Hq = dh_mi_ahead[w];
-                    if (Hq.n > 0 && Hq.T == T && Hq.na == a && x.pos >= Hq.pos0 && x.pos < Hq.pos0 + Hq.n) hw = w;
-                }
+                int hw = J.hw;  // (the leader's decision: see where J is written)
                 unsigned long long computed = 0ull;
-                if (hw < 0 && x.nc - x.pos >= 2) {  // (uniform: every wavefront reads the same LDS words)
+                if (hw < 0 && x.nc - x.pos >= 2) {  // (uniform: x and J do not change between the job's first barrier and the one in front of its commit)
                     const MiDev Mu = mi_uniform(dh_mi_ctx.M);
                     int start = x.pos, my_start = x.pos, my_n = 0;
 #pragma unroll
@@ -1399,6 +1409,13 @@ __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, 
             r_pow = 1;
             nt = N;
         }
+        // The job's verdict changes the target state in LDS (dh_commit: x.pos, x.na, ...) and every wavefront reads that state while it
+        // works on the job (x.pos, x.nc, x.phase, the whitelist, the look-ahead slot of x.pos): nobody may still be reading when the leader
+        // commits.  r05 had this barrier BEHIND the commit only; a job that ended with a cached first test had no barrier at all between
+        // its start and the commit, a late wavefront read the advanced x.pos, took another branch with a barrier of its own and stayed one
+        // barrier behind (wrong records in its hands, one target's PC list differing about once in a thousand passes, or a hang).
+        // Behind the commit the other wavefronts read nothing until the next job's first barrier, so this is the only one needed.
+        __syncthreads();
         if (wave == 0) {
             const unsigned long long tk3 = MI_CLK();
             if (lane == 0) {
@@ -1414,7 +1431,6 @@ __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, 
                                                             : dh_alg_bytes(a, ev, P.max_k, P.disc_bytes_per_col);
             dh_commit(x, A, lane, 1, r_stat, r_p, r_pow, P.alpha);
         }
-        __syncthreads();  // (the next job's descriptor is written behind this)
     }
     if (wave == 0 && lane == 0) {
         x.r_more0 = (unsigned int)MI_CLK();
