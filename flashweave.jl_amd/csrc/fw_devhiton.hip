@@ -501,6 +501,39 @@ __device__ __forceinline__ void mi_nap_tail()
 #pragma unroll
     for (int i = 0; i < MI_NAP_TAIL; ++i) __builtin_amdgcn_s_sleep(8);
 }
+// Watchdog of the waits of the persistent kernel: a wavefront that waits for another one (records of its board, the end of the launch)
+// gives up when the word it watches has not CHANGED for MI_WD_TICKS of the 100 MHz clock (2 s: a record is at most mi_chunk_max = 64
+// tests) -- the launch then ends with a code in MiQueue::pad[0] and the host call fails with FW_ERR_DEVICE instead of hanging the GPU.
+// The clock (a scalar memory round trip) is read every 256th look only.
+#ifndef MI_WD_TICKS
+#define MI_WD_TICKS 200000000ull
+#endif
+struct MiWatch {
+    unsigned long long t0;
+    unsigned int last, n;
+};
+__device__ __forceinline__ void mi_watch_begin(MiWatch &w, unsigned int word)
+{
+    w.t0 = 0ull;
+    w.last = word;
+    w.n = 0u;
+}
+__device__ __forceinline__ bool mi_watch_expired(MiWatch &w, unsigned int word)
+{
+    if (word != w.last) {
+        w.last = word;
+        w.t0 = 0ull;
+        w.n = 0u;
+        return false;
+    }
+    if ((++w.n & 255u) != 0u) return false;
+    const unsigned long long now = wall_clock64();
+    if (w.t0 == 0ull) {
+        w.t0 = now;
+        return false;
+    }
+    return now - w.t0 > MI_WD_TICKS;
+}
 // lane 0 performs the atomic, every lane gets the value
 __device__ __forceinline__ unsigned int mi_wave_add(unsigned int *p, unsigned int v, int lane)
 {
@@ -1373,10 +1406,13 @@ __device__ __noinline__ void dh_mi_team(DhTgt *__restrict__ tg, int ntg, int t, 
                 while (mi_board_work<L, NXY, PRE, R4>(b, res, bacc, acc, lane)) {
                 }
                 if (wave == 0) {
-                    unsigned int spins = 0u;
-                    while (mi_ld_u32(&b->done) < nch) {  // records claimed by other wavefronts: they are running
+                    MiWatch wd;
+                    unsigned int dn = mi_ld_u32(&b->done);
+                    mi_watch_begin(wd, dn);
+                    while (dn < nch) {  // records claimed by other wavefronts: they are running
                         mi_nap_wait();
-                        if (++spins > (1u << 27)) {
+                        dn = mi_ld_u32(&b->done);
+                        if (mi_watch_expired(wd, dn)) {
                             if (lane == 0) atomicExch(&Q->pad[0], 3u);
                             break;
                         }
@@ -1632,17 +1668,22 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
                     MiBoard *b = boards + bi;
                     while (mi_board_work<L, NXY, PRE, R4>(b, res, bacc, A.acc + acc_off, lane)) {
                     }
-                    unsigned int spins = 0u;
-                    while (mi_ld_u32(&b->done) < nch) {  // records claimed by other wavefronts: they are running
+                    MiWatch wd;
+                    unsigned int dn = mi_ld_u32(&b->done);
+                    mi_watch_begin(wd, dn);
+                    while (dn < nch) {  // records claimed by other wavefronts: they are running
                         if (heavy || !mi_help<L, NXY, PRE, R4>(Q, boards, res, bacc, lane)) {
                             const unsigned long long tkw0 = MI_CLK();
                             mi_nap_wait();
                             MI_TICK(10, tkw0);
-                            if (++spins > (1u << 27)) {  // ~30 s: a logic error, not a workload -- report instead of hanging the GPU
+                            if (mi_watch_expired(wd, mi_ld_u32(&b->done))) {  // 2 s without a record finishing: a logic error, not a workload -- report instead of hanging the GPU
                                 if (lane == 0) atomicExch(&Q->pad[0], 1u);
                                 break;
                             }
+                        } else {
+                            mi_watch_begin(wd, dn);  // (helped another board meanwhile: the clock starts again)
                         }
+                        dn = mi_ld_u32(&b->done);
                     }
                     const unsigned long long tkm0 = MI_CLK();
                     mg = mi_merge(res, (long long)ro, (int)nch, lane);
@@ -1695,14 +1736,23 @@ __global__ __launch_bounds__(256, DH_MI_OCC) void dh_mi_target_kernel(DhTgt *__r
     }
     // no targets left to start: work on boards until every target has finished
     const unsigned long long tk_t0 = MI_CLK();
-    unsigned int spins = 0u;
+    MiWatch wd;  // progress of the launch as seen from here: a target finished or a board was opened (both counters only grow)
+    mi_watch_begin(wd, 0u);
+    unsigned int wd_periods = 0u;
     while (mi_ld_u32(&Q->targets_done) < (unsigned int)ntg && mi_ld_u32(&Q->pad[0]) == 0u) {
         if (!mi_help<L, NXY, PRE, R4>(Q, boards, res, bacc, lane)) {
             mi_nap_tail();
-            if (++spins > (1u << 27)) {
-                if (lane == 0) atomicExch(&Q->pad[0], 2u);
-                break;
+            wd.n |= 255u;  // (a nap is ~7 us: look at the clock every time)
+            if (mi_watch_expired(wd, mi_ld_u32(&Q->targets_done) + mi_ld_u32(&Q->n_boards))) {
+                wd.t0 = 0ull;
+                if (++wd_periods >= 5u) {  // 10 s in which no target finished and no board was opened
+                    if (lane == 0) atomicExch(&Q->pad[0], 2u);
+                    break;
+                }
             }
+        } else {
+            wd_periods = 0u;
+            wd.t0 = 0ull;
         }
     }
     tk_tail = MI_CLK() - tk_t0;

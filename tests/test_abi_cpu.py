@@ -75,3 +75,51 @@ def test_graft_entry_build_passes():
     # the driver's "does it build" check: compiles (or finds up to date) the HIP library + the oracle and asserts the ABI version
     import __graft_entry__ as g
     assert g.build().endswith("libflashweave_amd.so")
+
+
+def test_struct_layouts_match_header_ctypes_and_this_table(tmp_path):
+    # sizeof / offsetof of every struct that crosses the boundary, three ways: the header compiled by gcc, the ctypes mirrors the
+    # tests and bench.py call through (engine.py), and the table INTEGRATION.md gives a maintainer who writes the Julia mirrors
+    # (r05's stub declared zs::NTuple{5,Int32} against an 80-byte fw_subsets_result: nothing checked the documented layout)
+    import subprocess
+    from flashweave_jl_amd import engine as E
+    mirrors = {"fw_params": E._Params, "fw_test_result": E._TestResult, "fw_subsets_result": E._SubsetsResult,
+               "fw_learn_opts": E._LearnOpts, "fw_counters": E._Counters, "fw_dev_exchange": E._DevExchange}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "flashweave_amd.h"', 'int main(void) {']
+    for name, cls in mirrors.items():
+        src.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (name, name))
+        for f, _ in cls._fields_:
+            src.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (name, f, name, f))
+    src.append('return 0; }')
+    cfile = tmp_path / "layout.c"
+    cfile.write_text("\n".join(src))
+    exe = str(tmp_path / "layout")
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-o", exe, str(cfile)], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    hdr = {}
+    for ln in out.splitlines():
+        s, f, v = ln.split()
+        hdr.setdefault(s, {})[f] = int(v)
+    assert hdr["fw_subsets_result"]["sizeof"] == 80 and hdr["fw_params"]["sizeof"] == 64  # ABI 6
+    # (1) ctypes mirrors == header
+    for name, cls in mirrors.items():
+        assert ctypes.sizeof(cls) == hdr[name]["sizeof"], name
+        for f, _ in cls._fields_:
+            assert getattr(cls, f).offset == hdr[name][f], (name, f)
+    # (2) the table of INTEGRATION.md == header: every struct, every field
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    rows = re.findall(r"^\| `(fw_[a-z_]+)` \| (\d+) \| (.+?) \|$", doc, flags=re.M)
+    seen = {}
+    for name, size, fields in rows:
+        d = {"sizeof": int(size)}
+        for item in fields.split(","):
+            f, off = item.split()
+            d[f] = int(off)
+        seen[name] = d
+    assert seen == hdr
+    # (3) the Julia mirrors of the stub say the same sizes, and no struct is described twice
+    for jl, name in (("FwParams", "fw_params"), ("FwTestResult", "fw_test_result"), ("FwSubsetsResult", "fw_subsets_result"),
+                     ("FwLearnOpts", "fw_learn_opts"), ("FwCounters", "fw_counters")):
+        m = re.findall(r"^struct %s\s+# mirrors %s.*?: (\d+) bytes" % (jl, name), doc, flags=re.M)
+        assert m == [str(hdr[name]["sizeof"])], (jl, m)
+    assert "NTuple{%d,Int32}" % fw.engine.FW_MAX_K in doc and "zs::NTuple{5" not in doc.split("### Struct layout")[0]
