@@ -22,6 +22,7 @@ Two schedules are measured in every run (both in the ONE JSON line rank 0 prints
   * `other_schedule`: the other one of {feed_forward = 1 in rounds of R targets, feed_forward = 0}.
 """
 import argparse
+import hashlib
 import json
 import os
 import socket
@@ -598,7 +599,7 @@ def main():
         # counters of the same kernel on the same workload from separate rocprofv3 --pmc passes (they cannot be read from inside
         # this process): HBM-side traffic per launch, VALU instructions per test, VALU-busy share.  profiles/README.md
         pmc, pmc_src = None, None
-        for cand in ("r05_%s_pmc_summary.json" % args.config, "r04_%s_pmc_summary.json" % args.config, "r03_%s_pmc_summary.json" % args.config, "r02_%s_pmc_summary.json" % args.config):
+        for cand in ("r06_%s_pmc_summary.json" % args.config, "r05_%s_pmc_summary.json" % args.config, "r04_%s_pmc_summary.json" % args.config, "r03_%s_pmc_summary.json" % args.config, "r02_%s_pmc_summary.json" % args.config):
             pmc_path = os.path.join(ROOT, "profiles", cand)
             if not args.p and not args.n and os.path.exists(pmc_path):
                 js = json.load(open(pmc_path))
@@ -640,6 +641,11 @@ def main():
         # the traffic is there, or when no PMC summary of this configuration is tracked (the nominal label of SURVEY 8d)
         low_traffic = pmc is not None and (traffic or 0) < 0.5 * rcn["alg_bytes_subsets"] / n_sub_launches
         bound = ("valu" if valu and valu["busy_frac"] >= 0.6 else "latency") if low_traffic else "hbm"
+        # r06: a kernel that reaches less than 5 % of the nominal HBM rate with its vector ALUs active less than 20 % of the time is
+        # waiting -- on dependent loads, on other wavefronts -- whatever its fabric traffic looks like next to the algorithmic bytes
+        # (cfg2 / cfg3he printed "hbm" at 0.003: their spill / record writes are of the size of their tiny algorithmic bytes)
+        if valu and achieved / HBM_PEAK_GBS < 0.05 and valu["busy_frac"] < 0.2:
+            bound = "latency"
         roofline = {"bound": bound, "kernel": kname,
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": (pmc_src + " (FETCH_SIZE + WRITE_SIZE per launch)") if traffic else None,
@@ -658,6 +664,10 @@ def main():
                     "alg_bytes_per_launch": rcn["alg_bytes_subsets"] / n_sub_launches,
                     "avg_launch_us": 1e6 * sub_launch_s / n_sub_launches, "launches": n_sub_launches,
                     "evaluated_tests_per_s_in_kernel": rcn["cond_tests_evaluated"] / max(sub_launch_s, 1e-12)}
+        if pmc and cfg["test_name"] in ("mi", "mi_nz") and pmc.get("write_bytes_raw") and pmc.get("evaluated_tests"):
+            # discrete kinds: bytes the kernel writes per byte of result it owes (a 32-byte record per evaluated test) -- spills and board
+            # / record traffic show up here long before they show up in the time (tracked PMC pass of the same command)
+            roofline["write_over_result_bytes"] = pmc["write_bytes_raw"] / (32.0 * pmc["evaluated_tests"])
         if cn.get("t_l0_mfma_s", 0.0) > 0.0:
             # level 0 of the discrete kinds on the matrix cores (mi_level0_mfma_kernel, v_mfma_scale_f32_32x32x64_f8f6f4): a binary Gram
             # product priced against the dense fp4 peak (MI355X_MICROARCH.md: ~10 PFLOP/s; 256 CUs x 4 SIMDs x 2 x 65 536 / 32 cycles at 2.4 GHz)
@@ -715,6 +725,8 @@ def main():
                           "parallelism": "targets of each round dealt by estimated work over %d GPU(s), one rank per GPU, backend %s" %
                                          (world, (dist.get_backend() if use_dist else "none"))},
                "time_to_network_s": dt / steps, "normalisation": norm_rec, "edges": int(len(net["edge_src"])), "rounds": main_m["rounds"],
+               # the learned network of the last timed pass as rank 0 holds it: edge list and weights -- equal across --gpus N (profiles/tools/scale_node.sh)
+               "network_sha256": hashlib.sha256(b"".join(np.ascontiguousarray(net[k]).tobytes() for k in ("edge_src", "edge_dst", "edge_weight"))).hexdigest(),
                "tests_per_step": {"level0": main_m["level0"], "conditional_ref_equivalent": main_m["cond_ref"],
                                   "conditional_evaluated": main_m["cond_eval"]},
                "exchange": main_m["exchange"], "simulated_world": main_m.get("simulated_world"),

@@ -471,6 +471,13 @@ __device__ __forceinline__ double pc_l3(double a, double b, double c)
 #ifndef FW_RUN_MAX
 #define FW_RUN_MAX 32  // chunk = 8192 ranks: fewer table builds / unrankings per test (16 -> 32: -9 % kernel time at cfg3)
 #endif
+#ifndef FW_FZ_CHEAPRED
+#define FW_FZ_CHEAPRED 1  // r06: the end-of-chunk reductions take their common case first (0: the r05 form; A/B knob)
+#endif
+#ifndef FW_RUN_MAX3
+#define FW_RUN_MAX3 64  // size-3 table kernel (r06): chunks of up to 16 384 ranks -- a segment of the big launches (9 000-14 000 ranks) is ONE chunk, one table build, one
+                        // round of reductions instead of two; a chunk whose z1-blocks would not fit the table (1 127 entries at worst, tab_bound.py 512 16384) is halved
+#endif
 // Table path of the size-3 enumeration (accepted sets of up to FZ_TAB_A variables, max_k <= 3).  With
 // (z1, z2, z3) = accepted[(i, j, k)], i < j < k, the recursion of statfuns.jl:44-53 needs
 //   rho(X,Y|z1,z2)   = l2(A1(i), LX(i,j), LY(i,j))          -- depends on (i, j) only
@@ -816,7 +823,8 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     const float cXY = CORV(X, Y);
     const unsigned long long NONE = FW_RANK_NONE;
     const unsigned long long len = seg.end - seg.start;
-    const int R = (int)((len + 255) / 256 < FW_RUN_MAX ? (len + 255) / 256 : FW_RUN_MAX);
+    constexpr int RMAX = (TAB && !HIGHK) ? FW_RUN_MAX3 : FW_RUN_MAX;
+    const int R = (int)((len + 255) / 256 < RMAX ? (len + 255) / 256 : RMAX);
     unsigned long long evaluated = 0;
 
     unsigned long long cnext = seg.start;
@@ -1097,6 +1105,33 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                 }
             }
         }
+        // ---- size-3 table: the z1-blocks [i0, i1] this chunk touches; a chunk whose blocks do not fit the table is halved (FW_RUN_MAX3) ----
+        bool tab_ok = false;
+        int tb_i0 = 0, tb_E = 0;
+        if (TAB3) {
+            const unsigned long long c3 = (max_k >= 3) ? cnt[3] : 0ull;
+            if (cbase < c3) {  // workgroup-uniform; a <= FZ_TAB_A by the host's routing
+                for (;;) {
+                    unsigned long long last3 = cend;
+                    last3 = (last3 < c3 ? last3 : c3) - 1ull;
+                    if (tid == 0 || tid == 64) {
+                        int q[FW_MAX_K_FAST];
+                        fw_unrank_comb32((uint32_t)(tid == 0 ? cbase : last3), a, 3, q);  // a <= FZ_TAB_A: 32-bit form
+                        s_blk[tid == 0 ? 0 : 1] = q[0];
+                    }
+                    __syncthreads();
+                    const int i0 = s_blk[0], i1 = s_blk[1];
+                    tb_E = fz_tab_off(i1 + 1, i0, a);  // <= 1021 for a <= 512 and chunks of 8192 ranks
+                    tb_i0 = i0;
+                    if (tb_E <= FZ_TAB_CAP) break;
+                    if (Rc <= FW_RUN_MAX) __builtin_trap();  // would be a routing bug on the host side: fail loudly
+                    __syncthreads();                         // (s_blk is rewritten)
+                    Rc = (Rc + 1) / 2;
+                    cend = cbase + 256ull * Rc;
+                }
+                tab_ok = true;
+            }
+        }
         cnext = cend;
         // Lane <-> rank mapping.  Runs: lane l of the workgroup takes Rc consecutive ranks (one unranking, unit steps).
         // Interleaved (table kernel, chunk entirely inside the size-3 enumeration): wavefront w owns the 64 Rc consecutive
@@ -1111,25 +1146,10 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
         const unsigned long long rstep = ilv ? 64ull : 1ull;
         const bool any = r0 < r1;
         // ---- table of the z1-blocks this chunk touches (see FZ_TAB_A) ----
-        bool tab_ok = false;
-        int tb_i0 = 0;
-        if (TAB3) {
-            const unsigned long long c3 = (max_k >= 3) ? cnt[3] : 0ull;
-            if (cbase < c3) {  // workgroup-uniform; a <= FZ_TAB_A by the host's routing
-                unsigned long long last3 = cend;
-                last3 = (last3 < c3 ? last3 : c3) - 1ull;
-                if (tid == 0 || tid == 64) {
-                    int q[FW_MAX_K_FAST];
-                    fw_unrank_comb32((uint32_t)(tid == 0 ? cbase : last3), a, 3, q);  // a <= FZ_TAB_A: 32-bit form
-                    s_blk[tid == 0 ? 0 : 1] = q[0];
-                }
-                __syncthreads();
-                const int i0 = s_blk[0], i1 = s_blk[1];
-                const int E = fz_tab_off(i1 + 1, i0, a);  // <= 1021 for a <= 512 and chunks of 8192 ranks
-                if (E > FZ_TAB_CAP) __builtin_trap();      // would be a routing bug on the host side: fail loudly
-                if (E <= FZ_TAB_CAP) {
-                    tab_ok = true;
-                    tb_i0 = i0;
+        if (TAB3 && tab_ok) {
+            {
+                {
+                    const int i0 = tb_i0, E = tb_E;
                     for (int e = tid; e < E; e += 256) {
                         int i = i0, rem = e;
                         while (rem >= a - 1 - i) {
@@ -1683,23 +1703,45 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
             my_bx = fz_xkey_slow(my_bstat, zscale);
         // first stopping rank in the workgroup
         unsigned long long ws = my_stop;
+        if (!FW_FZ_CHEAPRED || __any(my_stop != NONE)) {  // (r06: no lane stopped -- nearly every chunk of cfg3 -- costs one ballot instead of six 64-bit shuffle steps)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long t = __shfl_xor(ws, o);
-            ws = t < ws ? t : ws;
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long t = __shfl_xor(ws, o);
+                ws = t < ws ? t : ws;
+            }
         }
         // key of the lane best: (xk, ps, rank); xk = x in the normal regime, FZ_X_SUBKEY in the underflow regime
         double bx = (my_bx == FZ_X_NONE) ? FZ_X_NONE : (my_bx > FZ_X_SUB ? FZ_X_SUBKEY : my_bx);
         double bps = my_bps;
         unsigned long long br = my_br;
+        bool reduced = false;
+        if (FW_FZ_CHEAPRED) {
+            // r06: the common case -- one lane holds the smallest x-key -- as a minimum over ONE double and a ballot; equal smallest keys
+            // (ties: the exact p, then the later rank decide) and the underflow regime take the full lexicographic reduction below
+            double mn = bx;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double ox = __shfl_xor(bx, o), ops = __shfl_xor(bps, o);
-            const unsigned long long orr = __shfl_xor(br, o);
-            if (fz_key_better(ox, ops, orr, bx, bps, br)) {
-                bx = ox;
-                bps = ops;
-                br = orr;
+            for (int o = 32; o > 0; o >>= 1) mn = __builtin_fmin(mn, __shfl_xor(mn, o));
+            const unsigned long long eq = __ballot(bx == mn);
+            if (mn == FZ_X_NONE) {  // no lane has a candidate: (NONE, ., .) -- what the full reduction returns is never read (fz_key_better)
+                reduced = true;
+            } else if (mn != FZ_X_SUBKEY && __popcll(eq) == 1) {
+                const int src = __ffsll((long long)eq) - 1;
+                bx = mn;
+                bps = __shfl(bps, src);
+                br = __shfl(br, src);
+                reduced = true;
+            }
+        }
+        if (!reduced) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ox = __shfl_xor(bx, o), ops = __shfl_xor(bps, o);
+                const unsigned long long orr = __shfl_xor(br, o);
+                if (fz_key_better(ox, ops, orr, bx, bps, br)) {
+                    bx = ox;
+                    bps = ops;
+                    br = orr;
+                }
             }
         }
 #pragma unroll
