@@ -578,6 +578,11 @@ __device__ __noinline__ void mi_run_ranks(int T, int cand, const int32_t *__rest
     o.stop_df = o.stop_power = o.best_df = o.pad = 0;
     o.evaluated = 0ull;
     int s = max_k;
+    // the positions of the running subset: only ever indexed with compile-time constants (unrolled loops), so they live in scalar
+    // registers.  r05 indexed them with run-time values (the unranking loop, the step to the next subset): a private array on the
+    // stack -- five dword stores per call and two or three DEPENDENT scratch loads per test in the stepping code, and, with the
+    // callee-saved registers this out-of-line routine has to park, the 3.65 GB the kernel wrote per cfg4 pass for 86 MB of results
+    // (profiles/r06_discrete_kernel_writes.txt)
     int pos[MI_MAX_K];
 #pragma unroll
     for (int q = 0; q < MI_MAX_K; ++q) pos[q] = 0;
@@ -589,14 +594,29 @@ __device__ __noinline__ void mi_run_ranks(int T, int cand, const int32_t *__rest
             rem -= fw_binom32(a, s);
             --s;
         }
-        fw_unrank_comb32(rem, a, s, pos);
+        int prev = -1;  // fw_unrank_comb32 with static position indices (s <= 3 here)
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (d < s) {
+                const int t = s - d, n = a - 1 - prev;
+                const uint32_t tot = fw_binom32(n, t);
+                const int m = fw_inv_binom32(tot - rem, t, n);
+                rem -= tot - fw_binom32(m, t);
+                pos[d] = a - m;
+                prev = a - m;
+            }
     } else {
         unsigned long long rem = r0;
         while (s > 1 && rem >= fw_binom_u64(a, s)) {
             rem -= fw_binom_u64(a, s);
             --s;
         }
-        fw_unrank_comb(rem, a, s, pos);
+        int pm[MI_MAX_K];  // (the general form keeps its array: lists beyond 1 024 entries or max_k 4-5, never at the benchmark sizes)
+#pragma unroll
+        for (int q = 0; q < MI_MAX_K; ++q) pm[q] = 0;
+        fw_unrank_comb(rem, a, s, pm);
+#pragma unroll
+        for (int q = 0; q < MI_MAX_K; ++q) pos[q] = pm[q];
     }
     // the maximum-p record the job holds so far (seed: what earlier ranks of the job found -- LDS, every lane reads the same words).
     // A test the seed dominates (mi_account: df <= and G^2 >) skips its Q(a, x); without a seed every record pays one Q for its
@@ -660,16 +680,23 @@ __device__ __noinline__ void mi_run_ranks(int T, int cand, const int32_t *__rest
             o.best_df = mb.df;
             o.stop_stat = mb.g;  // (records without a stop: G^2 of the maximum-p test, the seed of later records)
         }
-        int i = s - 1;  // next subset of this size in lexicographic order of the positions, then the next size down
-        while (i >= 0 && pos[i] == a - s + i) --i;
+        // next subset of this size in lexicographic order of the positions, then the next size down (static indices: see above)
+        int i = -1, base = 0;  // i: the last position that can still move; base: its new value
+#pragma unroll
+        for (int q = 0; q < MI_MAX_K; ++q)
+            if (q < s && pos[q] != a - s + q) {
+                i = q;
+                base = pos[q] + 1;
+            }
         if (i < 0) {
             --s;
             if (s < 1) break;
 #pragma unroll
             for (int q = 0; q < MI_MAX_K; ++q) pos[q] = q;
         } else {
-            ++pos[i];
-            for (int j = i + 1; j < s; ++j) pos[j] = pos[j - 1] + 1;
+#pragma unroll
+            for (int q = 0; q < MI_MAX_K; ++q)
+                if (q >= i && q < s) pos[q] = base + (q - i);
         }
     }
     if ((threadIdx.x & 63) == 0) dh_mi_out[threadIdx.x >> 6] = o;  // (every lane holds the same record)
@@ -1094,12 +1121,9 @@ __device__ __forceinline__ bool mi_board_work(MiBoard *__restrict__ b, FwSegOut 
 // something was done.  (A global FIFO of records with a compare-and-swap head was tried instead of the scan: 10x slower --
 // a thousand wavefronts polling and swapping the same two words.)
 template <int L, int NXY, int PRE, bool R4>
-__device__ __noinline__ bool mi_help(MiQueue *__restrict__ Q, MiBoard *__restrict__ boards, FwSegOut *__restrict__ res,
-                                     const int32_t *__restrict__ bacc, int lane)
+__device__ __noinline__ bool mi_help_scan(MiQueue *__restrict__ Q, MiBoard *__restrict__ boards, FwSegOut *__restrict__ res,
+                                          const int32_t *__restrict__ bacc, int lane, unsigned int nb, unsigned int i)
 {
-    unsigned int nb = mi_ld_u32(&Q->n_boards);
-    if (nb > MI_BOARD_CAP) nb = MI_BOARD_CAP;
-    unsigned int i = mi_ld_u32(&Q->hint);
     for (; i < nb; ++i) {
         MiBoard *b = boards + i;
         if (mi_ld_u32(&b->ready) == 0u) return false;  // reserved, not yet filled
@@ -1110,6 +1134,21 @@ __device__ __noinline__ bool mi_help(MiQueue *__restrict__ Q, MiBoard *__restric
         }
     }
     return false;
+}
+// The look that finds nothing -- no board behind the hint: what a wavefront that has run out of targets sees thousands of times while
+// the last heavy targets finish -- stays in the caller.  r05 made the call first: the out-of-line scan keeps ~38 values in callee-saved
+// registers across its own call of the test routine and parks them on the stack in its prologue, so every empty poll wrote and read
+// back 38 x 256 bytes of scratch (profiles/r06_discrete_kernel_writes.txt).
+template <int L, int NXY, int PRE, bool R4>
+__device__ __forceinline__ bool mi_help(MiQueue *__restrict__ Q, MiBoard *__restrict__ boards, FwSegOut *__restrict__ res,
+                                        const int32_t *__restrict__ bacc, int lane)
+{
+    unsigned int nb = mi_ld_u32(&Q->n_boards);
+    if (nb > MI_BOARD_CAP) nb = MI_BOARD_CAP;
+    const unsigned int i = mi_ld_u32(&Q->hint);
+    if (i >= nb) return false;
+    if (mi_ld_u32(&boards[i].ready) == 0u) return false;  // reserved, not yet filled (the scan would return at once)
+    return mi_help_scan<L, NXY, PRE, R4>(Q, boards, res, bacc, lane, nb, i);
 }
 
 // ---- heavy targets: one WORKGROUP per target -------------------------------------------------------------------------------------

@@ -85,7 +85,6 @@ def test_cfg3_full_size():
     eng = fw.Engine("fz", n, p, max_k=3)
     eng.set_data(data)
     cm = eng.cor()
-    _cfg3_whole_schedule_oracle(cm, n)  # (background: compared in test_cfg3_full_size_whole_headline_schedule_equals_oracle)
     # Pearson matrix: exactly symmetric, unit diagonal, bounded; agrees with a Float64 reference on a random sample
     assert (cm == cm.T).all() and (np.diag(cm) == 1.0).all() and np.abs(cm).max() <= 1.0
     rng = np.random.default_rng(0)
@@ -137,6 +136,10 @@ def test_cfg3_full_size():
         nchk += len(b)
     assert nchk > 1000 and ndiff == 0
     eng.close()
+    # the whole-schedule oracle of test_cfg3_full_size_whole_headline_schedule_equals_oracle starts here, in the background, on this
+    # matrix: it runs beside the tests that follow (it was started at the top of this test first: its 256 threads, even at nice 10,
+    # tripled the time of this test's own oracle calls and Float64 matrix)
+    _cfg3_whole_schedule_oracle(cm, n)
 
 
 def test_cfg3_full_size_device_rounds_equal_host_driver(monkeypatch):
