@@ -1375,6 +1375,10 @@ __global__ __launch_bounds__(FZNZ_NT) void fznz_submat_kernel(const float *__res
         const long long sf = nR - 3;
         rec->zscale = sf > 0 ? sqrt((double)sf) / 2.0 : 0.0;
         fznz_thresholds(alpha, xcrit, rec->zscale, rec->thr);
+        // the matrix is in its slot: nothing to compute until the slot gets a fresh record.  (Device rounds: a target that finishes and is
+        // compacted off the active list in the same round never gets its "pad = 1" from dh_nz_recs_kernel; r05 recomputed the matrix of
+        // every such target in every later round of the run, from a list buffer the state machine had reused -- never read, but computed.)
+        rec->pad |= 1;
     }
 }
 

@@ -136,10 +136,6 @@ def test_cfg3_full_size():
         nchk += len(b)
     assert nchk > 1000 and ndiff == 0
     eng.close()
-    # the whole-schedule oracle of test_cfg3_full_size_whole_headline_schedule_equals_oracle starts here, in the background, on this
-    # matrix: it runs beside the tests that follow (it was started at the top of this test first: its 256 threads, even at nice 10,
-    # tripled the time of this test's own oracle calls and Float64 matrix)
-    _cfg3_whole_schedule_oracle(cm, n)
 
 
 def test_cfg3_full_size_device_rounds_equal_host_driver(monkeypatch):
@@ -153,9 +149,13 @@ def test_cfg3_full_size_device_rounds_equal_host_driver(monkeypatch):
         monkeypatch.setenv("FW_HOST_HITON", host)
         eng = fw.Engine("fz", n, p, max_k=3)
         eng.set_data(data)
-        eng.cor()
+        cm = eng.cor()
         res[host] = (eng.lgl(feed_forward=False), eng.counters())
         eng.close()
+    # the whole-schedule oracle of test_cfg3_full_size_whole_headline_schedule_equals_oracle starts here, in the background, on this
+    # matrix, and runs beside the tests that follow -- behind the two tests above, whose own CPU work (oracle calls, the Float64 matrix,
+    # the host job pool of FW_HOST_HITON=1) its 256 threads slowed three- to fourfold even at nice 10
+    _cfg3_whole_schedule_oracle(cm, n)
     (nh, ch), (nd, cd) = res["1"], res["0"]
     assert nh["edges"] == nd["edges"] and len(nd["edges"]) > 10000
     for key in ("pc_off", "pc_idx", "pc_weight", "pc_pval"):
