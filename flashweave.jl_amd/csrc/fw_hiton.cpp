@@ -206,7 +206,7 @@ struct FwHostWorkers {
     const int *blk = nullptr;
     unsigned long long gen = 0;
     int pending = 0;
-    bool quit = false;
+    bool quit = false, failed = false;
     explicit FwHostWorkers(int n)
     {
         for (int w = 1; w < n; ++w)
@@ -223,27 +223,42 @@ struct FwHostWorkers {
                         f = fn;
                         b = blk;
                     }
-                    (*f)(w, b[w], b[w + 1]);
+                    bool ok = true;
+                    try {
+                        (*f)(w, b[w], b[w + 1]);
+                    } catch (...) {  // (std::bad_alloc of a block-local vector: an exception that leaves a thread is std::terminate)
+                        ok = false;
+                    }
                     {
                         std::lock_guard<std::mutex> lk(mu);
+                        if (!ok) failed = true;
                         if (--pending == 0) cv_done.notify_one();
                     }
                 }
             });
     }
-    void run(const std::function<void(int, int, int)> &f, const int *b)
+    // false: a block threw (out of memory).  The workers hold pointers to the caller's function object and block list, so the call
+    // never leaves -- normally or by an exception of block 0 -- before every worker has finished its block (r05 unwound past them).
+    bool run(const std::function<void(int, int, int)> &f, const int *b)
     {
         {
             std::lock_guard<std::mutex> lk(mu);
             fn = &f;
             blk = b;
             pending = (int)th.size();
+            failed = false;
             ++gen;
         }
         cv_go.notify_all();
-        f(0, b[0], b[1]);
+        bool ok0 = true;
+        try {
+            f(0, b[0], b[1]);
+        } catch (...) {
+            ok0 = false;
+        }
         std::unique_lock<std::mutex> lk(mu);
         cv_done.wait(lk, [&] { return pending == 0; });
+        return ok0 && !failed;
     }
     ~FwHostWorkers()
     {
@@ -712,12 +727,18 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
         blk[w] = (int)(std::lower_bound(c->pc_off.begin(), c->pc_off.end(), want) - c->pc_off.begin());
         if (blk[w] > p) blk[w] = p;
     }
+    bool blocks_ok = true;  // a block ran out of memory: reported as FW_ERR_NOMEM behind the passes (no exception crosses the C ABI)
     auto run_blocks = [&](const std::function<void(int, int, int)> &fn) {
+        if (!blocks_ok) return;
         if (n_thr == 1) {
-            fn(0, 0, p);
+            try {
+                fn(0, 0, p);
+            } catch (...) {
+                blocks_ok = false;
+            }
             return;
         }
-        c->host_workers->run(fn, blk.data());
+        blocks_ok = c->host_workers->run(fn, blk.data());
     };
     // the scatter into the CSR: every block reads the whole arrival list and places the entries of its own targets, in arrival order
     // (one thread: 1.2 ms of random writes for cfg4's 157 000 entries)
@@ -813,6 +834,7 @@ extern "C" int fw_learn_network(fw_ctx *c, const fw_learn_opts *opts_in, fw_allg
         w_t1[(size_t)w] = now_s();
     });
     const double tq4 = now_s();
+    if (!blocks_ok) return fw_fail(c, FW_ERR_NOMEM, "weights / symmetric graph: a host block ran out of memory");
     for (int w = 0; w < n_thr; ++w) {
         c->e_src.insert(c->e_src.end(), bs[(size_t)w].begin(), bs[(size_t)w].end());
         c->e_dst.insert(c->e_dst.end(), bd[(size_t)w].begin(), bd[(size_t)w].end());

@@ -73,3 +73,22 @@ def test_discrete_network_is_deterministic_under_contention(round_size):
         assert int(net["n_cond_tests"]) == exp["n_cond_tests"]
         for e, w in exp["edges"].items():
             assert abs(got[e] - w) <= 1e-10 * max(1.0, abs(w))
+
+
+def test_discrete_network_independent_of_the_persistent_kernel_s_cuts():
+    # The queue words next_target / targets_done switch how a job's ranks are cut into prefix / window / board records (tail mode), and the
+    # team / look-ahead / four-per-step machinery decides which wavefront and which step evaluates a rank: the merge is in rank order, so
+    # none of it may show in the network.  One process per setting (the knobs are read once), 30 passes each, all the same bytes.
+    base = ["--p", "1000", "--n", "500", "--seed", "20260930", "--kind", "mi", "--feed-forward", "1", "--round-size", "256", "--passes", "30"]
+    settings = [{}, {"FW_MI_TEAM_TAIL": "1"}, {"FW_MI_AHEAD": "0"}, {"FW_MI_ROW4": "0"}, {"FW_MI_TEAM_MAX": "0"}, {"FW_MI_HELP_JOBS": "0"},
+                {"FW_MI_SEQ_TAIL": "1", "FW_MI_TEAM_TAIL": "1"}]
+    procs = [subprocess.Popen([sys.executable, WORKER] + base, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT,
+                              env=dict(os.environ, FW_KNOBS="1", **s)) for s in settings]
+    seen = {}
+    for s, pr in zip(settings, procs):
+        so, se = pr.communicate(timeout=300)
+        assert pr.returncode == 0, se[-2000:]
+        r = json.loads(so.strip().splitlines()[-1])
+        assert r["differing"] == 0 and r["passes"] == 30, (s, r)
+        seen[json.dumps(s)] = (r["sha256"], r["edges"], r["ref_tests"])
+    assert len(set(seen.values())) == 1, seen
