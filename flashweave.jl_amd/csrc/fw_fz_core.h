@@ -615,7 +615,7 @@ __device__ __forceinline__ double fz_hk_stat(const double *__restrict__ tb, int 
 // ready-made roots instead of 15 full ones; levels 2..K are fz_pcor_levels as before (same values, same order).
 #define FZ_L1_A 512  // (r03: 1024 -> 512: with the level-3 tables LDS bounds the occupancy of this variant; cfg5's longest list is 480)
 #ifdef FW_FZ_FASTDBG
-static __device__ unsigned long long fz_fast_cnt[16];
+static __device__ unsigned long long fz_fast_cnt[24];
 #endif
 static __device__ int fz_dbg_flags;  // profiling knob (FW_FZ_DBG, set by fz_ensure_thresholds): bit 0 = no level-1 table
 template <int K>
@@ -1190,6 +1190,9 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
         // fz_l3_finish(my_bev, my_bxb, my_bxc), or my_bev itself when my_bxb = my_bxc = 1 (tests whose quotient was taken)
         double my_bev = 0.0, my_bxb = 1.0, my_bxc = 1.0;
         unsigned int my_done = 0;  // tests this lane executes in this chunk (it leaves its run at its first stop)
+#if defined(FW_FZ_FASTDBG) && FW_FZ_FASTDBG >= 4
+        double dbg_wmin = 1.0e300;
+#endif
         if (any) {
             // unrank the first rank of the run
             unsigned long long rem = r0;
@@ -1310,6 +1313,26 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                             if (b_tie) atomicAdd(&fz_fast_cnt[6], 1ull);
                             atomicAdd(&fz_fast_cnt[7], (unsigned long long)__builtin_popcountll(b_nrm));
                         }
+                    }
+#endif
+#if defined(FW_FZ_FASTDBG) && FW_FZ_FASTDBG >= 4
+                    {   // potential of a cheap conservative screen (r06): iterations in which EVERY lane's |stat|^2 = e2 / m2 lies clearly above the
+                        // smallest value this wavefront has seen so far in the chunk and clearly inside (significant, normal range)
+                        const double q = f_e2 / f_m2;
+                        double wq = q;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) wq = __builtin_fmin(wq, __shfl_xor(wq, o));
+                        const double hq = f_ev < 0.0 ? h2_neg : h2_pos;
+                        const bool p4 = __all(clean && q > dbg_wmin * 1.0002 && q > hq * 1.0002 && q < s2 * 0.9998);
+                        const bool p3 = __all(clean && q > dbg_wmin * 1.002 && q > hq * 1.002 && q < s2 * 0.998);
+                        const bool p2 = __all(clean && q > dbg_wmin * 1.02 && q > hq * 1.02 && q < s2 * 0.98);
+                        if (lane == 0) {
+                            atomicAdd(&fz_fast_cnt[19], 1ull);
+                            if (p4) atomicAdd(&fz_fast_cnt[16], 1ull);
+                            if (p3) atomicAdd(&fz_fast_cnt[17], 1ull);
+                            if (p2) atomicAdd(&fz_fast_cnt[18], 1ull);
+                        }
+                        dbg_wmin = __builtin_fmin(dbg_wmin, wq);
                     }
 #endif
                     if (__all(clean && f_sure && f_nostop && !f_tie)) {

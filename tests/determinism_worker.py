@@ -78,6 +78,7 @@ def main():
             time.sleep(0.01)
     ref = None
     ref_net = None
+    ref_struct = None
     bad = []
     prev = eng.counters()["cond_tests_ref"]
     ref_tests = 0
@@ -97,6 +98,11 @@ def main():
         if ref is None:
             ref, ref_tests = key, nref
             ref_net = {k: np.array(net[k]) for k in KEYS}
+            hs = hashlib.sha256()  # the integer part alone: edge list, directed lists, test count (the statistics of two arithmetic forms differ in their last bits)
+            for k in ("edge_src", "edge_dst", "pc_off", "pc_idx"):
+                hs.update(np.ascontiguousarray(net[k]).tobytes())
+            hs.update(str(nref).encode())
+            ref_struct = hs.hexdigest()
             if a.save:
                 np.savez(a.save, n_cond_tests=nref, **ref_net)
         elif key != ref:
@@ -107,7 +113,7 @@ def main():
         if a.seconds > 0 and time.time() - t0 > a.seconds:
             break
     el = time.time() - t0
-    print(json.dumps({"passes": done, "differing": len(bad), "sha256": ref, "edges": int(len(ref_net["edge_src"])), "ref_tests": int(ref_tests),
+    print(json.dumps({"passes": done, "differing": len(bad), "sha256": ref, "sha256_integers": ref_struct, "edges": int(len(ref_net["edge_src"])), "ref_tests": int(ref_tests),
                       "kind": kind, "p": int(p), "n": int(n), "feed_forward": int(ff), "round_size": int(R), "ms_per_pass": 1e3 * el / max(done, 1),
                       "bad": bad[:20]}), flush=True)
     eng.close()
