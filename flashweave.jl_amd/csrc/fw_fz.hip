@@ -881,6 +881,9 @@ extern "C" void fwi_fz_fastdbg_print()
     if (hipMemcpyFromSymbol(c, HIP_SYMBOL(fz_fast_cnt), sizeof(c)) == hipSuccess && c[19])
         fprintf(stderr, "[fw] cheap-screen potential: of %llu fast-loop wave-iterations, every lane clearly (relative margin on |stat|^2: 2e-4 / 2e-3 / 2e-2) above the wavefront's minimum so far and inside the sure range in %llu / %llu / %llu\n",
                 c[19], c[16], c[17], c[18]);
+    if (c[23])
+        fprintf(stderr, "[fw] cheap screen (validation build: decides nothing): lanes it would skip %llu, of them VIOLATIONS (exact value not above the bound, or not sure) %llu; wave-iterations it would skip whole %llu of %llu\n",
+                c[20], c[21], c[22], c[23]);
     if (hipMemcpyFromSymbol(c, HIP_SYMBOL(fz_fast_cnt), sizeof(c)) == hipSuccess)
         fprintf(stderr, "[fw] fast loop: wave-iterations %llu, lane-tests %llu; waves with a lane not clean %llu, not significant-for-sure %llu, beyond the normal range of p %llu, behind a stop %llu, tie %llu; lanes beyond the normal range %llu\n",
                 c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);

@@ -471,6 +471,9 @@ __device__ __forceinline__ double pc_l3(double a, double b, double c)
 #ifndef FW_RUN_MAX
 #define FW_RUN_MAX 32  // chunk = 8192 ranks: fewer table builds / unrankings per test (16 -> 32: -9 % kernel time at cfg3)
 #endif
+#ifndef FW_FZ_SCREEN
+#define FW_FZ_SCREEN 1  // r06: size-3 fast loop -- a conservative Float32 screen in front of the exact test (see "cheap screen" in fz_seg_body; 0: off, A/B knob)
+#endif
 #ifndef FW_FZ_CHEAPRED
 #define FW_FZ_CHEAPRED 1  // r06: the end-of-chunk reductions take their common case first (0: the r05 form; A/B knob)
 #endif
@@ -730,6 +733,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     __shared__ unsigned long long s_hk_end;
     __shared__ int s_hk_n, s_hk_lin0, s_hk_nan, s_hk_skip0, s_hk_prev;
     __shared__ unsigned int s_cstop;  // smallest stopping rank of the current chunk so far (relative to the chunk), 0xffffffff = none
+    __shared__ unsigned int s_scrq;   // cheap screen: bits of a Float32 upper bound of the smallest |stat|^2 this SEGMENT has evaluated so far in the normal range of p (FLT_MAX: none)
     __shared__ unsigned long long s_stop[4];
     __shared__ double s_bx[4], s_bps[4];
     __shared__ unsigned long long s_br[4];
@@ -789,6 +793,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
         s_best_stat = 0.0;
         s_best_rank = 0;
         s_cstop = 0xffffffffu;
+        s_scrq = 0x7f7fffffu;
         if (HK) s_hk_prev = -1;
     }
     unsigned long long cnt[FW_MAX_K_FAST + 1];
@@ -805,6 +810,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     // (the context-wide thresholds carry them ready-made in thr[5..7]: fz_thresholds_kernel; per-job thresholds of fz_nz: computed here)
     const double h2_pos = !LOCAL ? thr[5] : rhi_pos * rhi_pos * (1.0 + 1e-12), h2_neg = !LOCAL ? thr[6] : rhi_neg * rhi_neg * (1.0 + 1e-12);
     const double s2 = !LOCAL ? thr[7] : (rsub_lo < 1.0 ? rsub_lo * rsub_lo : 1.0) * (1.0 - 1e-12);
+    const float scr_h2 = (float)(h2_pos > h2_neg ? h2_pos : h2_neg) * 1.00001f;  // cheap screen: the significance bound on |stat|^2 of either sign, rounded up
     __syncthreads();
 #define ACCV(i) (LOCAL ? ((i) + 2) : (in_lds ? s_acc[(i)] : gacc[(i)]))
 #define CORV(u, v) cor[(size_t)(u) * p + (v)]
@@ -1193,6 +1199,10 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
 #if defined(FW_FZ_FASTDBG) && FW_FZ_FASTDBG >= 4
         double dbg_wmin = 1.0e300;
 #endif
+#if defined(FW_FZ_FASTDBG) && FW_FZ_FASTDBG >= 5
+        bool dbg_sok = false;
+        float dbg_sT = 0.0f;
+#endif
         if (any) {
             // unrank the first rank of the run
             unsigned long long rem = r0;
@@ -1279,19 +1289,71 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                     int nboff = boff;
                     if (nchg <= 0) nboff = fz_tab_off(ni, tb_i0, a) - ni - 1;
                     const int nfj = __float_as_int(s_tab[nboff + nj].w), nfk = __float_as_int(s_tab[nboff + nk].w);  // (in range also without a next test: this test's row)
+                    if (hasN) pf_c32 = CORT(nfk & FZ_TAB_ZMASK, nfj & FZ_TAB_ZMASK);  // straight into the loop-carried register: a copy at the end of the iteration would wait for it
+                    const bool f_nostop = !(__hip_atomic_load(&s_cstop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned int)(r - cbase));
+                    const bool f_capped = max_tests > 0 && r + 1 >= (unsigned long long)max_tests;
+#if FW_FZ_SCREEN
+                    // ---- cheap screen (r06) ----
+                    // A test that is (a) significant for sure, (b) not the last test of a capped job, (c) not behind a stop and (d) clearly
+                    // LARGER in |stat| than a test this segment has already evaluated in the normal range of p can neither end the job nor be
+                    // (or tie) its maximum-p test: its value is never needed (profiles/r06_cfg3_cheap_screen_potential.txt: true of every lane in
+                    // 77-81 % of cfg3's fast-loop iterations, whatever the margin between 1e-4 and 1e-2).  Here that is DECIDED, conservatively,
+                    // from a Float32 evaluation without the three round5 steps, the square root and the three correctly rounded divisions of the
+                    // exact sequence, with an error bound that covers every difference between the two.  With
+                    //   F = e1 / d1,  g = 1 - F^2,  nD = LXk - LXj F,  nE = LYk - LYj F        (e1 = c32 - ck cj, d1 = rk1 rj1: level 1, statfuns.jl:36)
+                    //   Pb = rjx^2 g - nD^2,  Pc = rjy^2 g - nE^2,  Num = A2j rjx rjy g - nD nE    (rjx = sqrt(1 - LXj^2), ...: level 2 multiplied out)
+                    // the exact sequence's |stat|^2 = ev^2 / (xb xc) equals Num^2 / (Pb Pc) in real arithmetic when no clamp acts.  Differences: round5 moves
+                    // e1, nD, nE and ev by <= 5e-6 each; rcp and the Float32 operations by < 3e-7 relative each.  Propagated (|values| <= 1, |nD|, |nE| <= 2):
+                    //   |dF| <= aF = 8e-6 / d1 + 4e-6,  |dg| <= 2 aF + 2e-6,  |dnD|, |dnE| <= 1e-5 + aF,  |dPb|, |dPc|, |dNum| <= dl = 6 aF + 5e-5 = 4.8e-5 / d1 + 7.4e-5
+                    // (guards: d1 > 0.01 so that aF < 1e-3; g > 0.02 so that F is not clamped; Pb, Pc > dl so that D2, E2 are not clamped and the radicands positive).
+                    // Then |stat|^2 >= (|Num| - dl)^2 / ((Pb + dl)(Pc + dl)), compared -- without a division -- with the larger of the significance bound and the
+                    // segment's smallest |stat|^2 so far (s_scrq, an upper bound of it, published by the exact path below), times 1.0002 for the roundings of the
+                    // comparison itself.  Anything else -- and every NaN: all comparisons are written to fail on one -- takes the exact path.
+                    {
+                        const unsigned int sq_bits = __hip_atomic_load(&s_scrq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (sq_bits != 0x7f7fffffu) {  // (workgroup-uniform up to timing; wave-uniform: one LDS word)
+                            const float scr_T = fmaxf(__uint_as_float(sq_bits), scr_h2) * 1.0002f;
+                            const float e1s = c32 - tk.z * tj.z;
+                            const float d1s = rk1 * rj1;
+                            const float inv1 = __builtin_amdgcn_rcpf(d1s);
+                            const float Fs = e1s * inv1;
+                            const float dl = fmaf(4.8e-5f, inv1, 7.4e-5f);
+                            const float gs = fmaf(-Fs, Fs, 1.0f);
+                            const float nDs = fmaf(-tj.x, Fs, tk.x), nEs = fmaf(-tj.y, Fs, tk.y);
+                            const float rg = rj2.x * gs;
+                            const float Pb = fmaf(-nDs, nDs, rj2.x * rg), Pc = fmaf(-nEs, nEs, rj2.y * rj2.y * gs);
+                            const float Nm = fmaf(-nDs, nEs, (float)A2j * rg * rj2.y);
+                            const float Nlo = fabsf(Nm) - dl;
+                            const bool s_ok = (((fj & fk) >> 28) & 7) == 7 && d1s > 0.01f && gs > 0.02f && Pb > dl && Pc > dl && Nlo > 0.0f &&
+                                              Nlo * Nlo > scr_T * ((Pb + dl) * (Pc + dl)) && !f_capped && f_nostop;
+#if defined(FW_FZ_FASTDBG) && FW_FZ_FASTDBG >= 5
+                            dbg_sok = s_ok;
+                            dbg_sT = scr_T;
+#else
+                            if (__all(s_ok)) {
+                                if (!hasN) break;
+                                pos[0] = ni;
+                                pos[1] = nj;
+                                pos[2] = nk;
+                                chg = nchg;
+                                boff = nboff;
+                                pf_ok = true;
+                                continue;
+                            }
+#endif
+                        }
+                    }
+#endif
                     bool f1ok;
                     const float F1f = pc_l1_rf(c32, tk.z, tj.z, rk1, rj1, f1ok);
                     const double F1v = (double)F1f;
                     const double dF = fz_sqrt_unit(1.0 - F1v * F1v);
-                    if (hasN) pf_c32 = CORT(nfk & FZ_TAB_ZMASK, nfj & FZ_TAB_ZMASK);  // straight into the loop-carried register: a copy at the end of the iteration would wait for it
                     const bool clean = (((fj & fk) >> 28) & 7) == 7 && f1ok;
                     const double D2 = pc_l2_all32_d1_nn(tk.x, tj.x, F1f, (double)rj2.x, dF);
                     const double E2 = pc_l2_all32_d1_nn(tk.y, tj.y, F1f, (double)rj2.y, dF);
                     const double f_ev = round5_f64_nn(A2j - D2 * E2), f_xb = 1.0 - D2 * D2, f_xc = 1.0 - E2 * E2;
                     const double f_m2 = f_xb * f_xc, f_e2 = f_ev * f_ev;
-                    const bool f_sure = f_e2 > (f_ev < 0.0 ? h2_neg : h2_pos) * f_m2 && f_e2 < s2 * f_m2 &&
-                                        !(max_tests > 0 && r + 1 >= (unsigned long long)max_tests);
-                    const bool f_nostop = !(__hip_atomic_load(&s_cstop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned int)(r - cbase));
+                    const bool f_sure = f_e2 > (f_ev < 0.0 ? h2_neg : h2_pos) * f_m2 && f_e2 < s2 * f_m2 && !f_capped;
                     const double f_lhs = f_e2 * (my_bxb * my_bxc), f_rhs = (my_bev * my_bev) * f_m2;
                     const bool f_take = my_bx > FZ_X_SUB || f_lhs < f_rhs * (1.0 - 1e-11);
                     const bool f_tie = !f_take && f_lhs <= f_rhs * (1.0 + 1e-11);
@@ -1335,6 +1397,23 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                         dbg_wmin = __builtin_fmin(dbg_wmin, wq);
                     }
 #endif
+#if FW_FZ_SCREEN && defined(FW_FZ_FASTDBG) && FW_FZ_FASTDBG >= 5
+                    {   // validation build: the screen decides nothing; counted: lanes it would have skipped, and among them those whose exact value the
+                        // bookkeeping needed after all (not sure, tie, or a new lane best BELOW the bound it was screened against) -- must stay 0
+                        // (a skipped test beyond the normal range of p is fine: its p is below the bound test's, which lies in the normal range)
+                        const bool f_sig = f_e2 > (f_ev < 0.0 ? h2_neg : h2_pos) * f_m2;
+                        const bool viol = dbg_sok && (!clean || !f_sig || f_capped || (f_e2 <= (double)dbg_sT / 1.0002 * f_m2));
+                        const unsigned long long bs = __ballot(dbg_sok), bv = __ballot(viol);
+                        const bool all_ok = __all(dbg_sok);
+                        if (lane == (int)__builtin_ctzll(__ballot(true))) {
+                            atomicAdd(&fz_fast_cnt[20], (unsigned long long)__popcll(bs));
+                            atomicAdd(&fz_fast_cnt[21], (unsigned long long)__popcll(bv));
+                            if (all_ok) atomicAdd(&fz_fast_cnt[22], 1ull);
+                            atomicAdd(&fz_fast_cnt[23], 1ull);
+                        }
+                        dbg_sok = false;
+                    }
+#endif
                     if (__all(clean && f_sure && f_nostop && !f_tie)) {
                         if (f_take) {
                             my_bx = FZ_X_LAZY;
@@ -1343,6 +1422,13 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                             my_bev = f_ev;
                             my_bxb = f_xb;
                             my_bxc = f_xc;
+#if FW_FZ_SCREEN
+                            // the screen's bound: this test's |stat|^2 = ev^2 / (xb xc), rounded UP into Float32 (f_sure: xb xc > 0, normal range of p);
+                            // positive floats order like their bit patterns.  Any wavefront of the workgroup may read it a little late: an older, larger
+                            // value is a bound as well.
+                            (void)__hip_atomic_fetch_min(&s_scrq, __float_as_uint(((float)f_e2 / ((float)f_xb * (float)f_xc)) * 1.00001f), __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
                         }
                         if (!hasN) break;
                         pos[0] = ni;
