@@ -46,6 +46,7 @@ struct DhTgt {
     // an enumeration of jN2 subsets (see dh_step_kernel)
     int32_t spmode, wl_unsorted;  // wl_unsorted: the whitelist was appended to on the device (dh_wl_append_kernel): no order, no early exit
     unsigned long long jwin2, jN2;
+    long long tm_off;  // fz rounds (r06): offset (floats) of the target's local correlation matrix in DhArrays::tmat, -1: none
 };
 
 struct DhGlobal {
@@ -79,6 +80,7 @@ struct DhArrays {
     const long long *nb_off;  // level-0 neighbour lists (for the empty-pool case, hiton.jl:57-59)
     const int32_t *nb_idx;
     const double *nb_stat, *nb_p;
+    const float *tmat;  // fz rounds (r06): the targets' local correlation matrices (DhTgt::tm_off), else null
 };
 
 struct DhParams {
@@ -2194,6 +2196,36 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
     dh_plan_dev<1024>(ntg, g, win, sp, win2, act_all, seg0, PA);
 }
 
+// fz rounds (r06): the local correlation matrix of every target that has one -- M[a][b] = cor[id(a)][id(b)], id(0) = T, id(1 ..) = T's
+// level-0 neighbours in ascending id order (every variable a job of T can name: candidates, TPC / PC members and whitelisted
+// neighbours are all level-0 neighbours of T).  The size-3 test gathers one matrix entry cor[z3][z2] per test, 64 scattered 4-byte
+// words per wavefront step out of a 400 MB matrix: L2 hit 88 %, i.e. every step waited for a fabric round trip and the pass read
+// 105 GB through the fabric (profiles/r05_cfg3_pmc_summary.json) -- out of a target's own (deg + 1)^2 floats (cfg3's heaviest: 250 KB)
+// the same gathers stay in L2.  One workgroup per target, rows a, columns b over the threads.
+__global__ __launch_bounds__(256) void dh_tmat_build_kernel(const DhTgt *__restrict__ tg, int ntg, const int32_t *__restrict__ nb_idx,
+                                                            const float *__restrict__ cor, int p, float *__restrict__ tmat)
+{
+    __shared__ int32_t s_id[4096];
+    const DhTgt &x = tg[blockIdx.x];
+    if (x.tm_off < 0) return;  // (workgroup-uniform)
+    const int m = x.nb_n + 1;
+    const int32_t *ids = nb_idx + x.nb_off;
+    for (int b = threadIdx.x; b < m; b += 256) s_id[b] = b == 0 ? x.T : ids[b - 1];
+    __syncthreads();
+    float *M = tmat + x.tm_off;
+    // rows blockIdx.y, blockIdx.y + gridDim.y, ...: four rows in flight per thread (independent gathers)
+    for (int a0 = (int)blockIdx.y * 4; a0 < m; a0 += (int)gridDim.y * 4)
+        for (int b = threadIdx.x; b < m; b += 256) {
+            const size_t col = (size_t)s_id[b];
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = a0 + q < m ? cor[(size_t)s_id[a0 + q] * (size_t)p + col] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (a0 + q < m) M[(size_t)(a0 + q) * m + b] = v[q];
+        }
+}
+
 // segment record s of the coming launch (one thread)
 __device__ __forceinline__ void dh_fill_one(const unsigned int s, const DhTgt *__restrict__ tg, int ntg, DhGlobal *__restrict__ g,
                                             const long long *__restrict__ seg0, const DhArrays &A, FwSeg *__restrict__ segs, int d1,
@@ -2233,6 +2265,11 @@ __device__ __forceinline__ void dh_fill_one(const unsigned int s, const DhTgt *_
     sg.start = lo_r + k * seglen;
     const unsigned long long hi_r = lo_r + (slot > 0u ? x.jwin2 : x.jwin);
     sg.end = sg.start + seglen < hi_r ? sg.start + seglen : hi_r;
+    const bool has_tm = A.tmat != nullptr && x.tm_off >= 0;
+    sg.tm = has_tm ? (uint64_t)(A.tmat + x.tm_off) : 0ull;
+    sg.tm_ids = has_tm ? (uint64_t)(A.nb_idx + x.nb_off) : 0ull;
+    sg.tm_m = has_tm ? x.nb_n + 1 : 0;
+    sg.pad1 = 0;
     segs[s] = sg;
 }
 __global__ __launch_bounds__(256) void dh_fill_kernel(const DhTgt *__restrict__ tg, int ntg, DhGlobal *__restrict__ g,
@@ -2575,6 +2612,19 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         tg[t] = x;
     }
     const size_t tot = (size_t)co;
+    // fz rounds (r06): local correlation matrices for the targets whose jobs can be long (dh_tmat_build_kernel); FW_FZ_TMAT=0: none
+    size_t tm_floats = 0;
+    {
+        static const int tm_min = [] { const char *e = fw_knob("FW_FZ_TMAT"); return e ? atoi(e) : 16; }();  // smallest degree that gets one (0: off)
+        const bool tm_on = c->P.kind == FW_FZ && c->P.max_k <= 3 && c->d_cor != nullptr && tm_min > 0;
+        for (int t = 0; t < ntg; ++t) {
+            tg[t].tm_off = -1;
+            const size_t m = (size_t)tg[t].nb_n + 1;
+            if (!tm_on || tg[t].nb_n < tm_min || m > 4096 || tm_floats + m * m > (size_t)1 << 31) continue;  // (<= 8 GB per chain; ids of a target staged in 16 KB of LDS)
+            tg[t].tm_off = (long long)tm_floats;
+            tm_floats += m * m;
+        }
+    }
     // ---- device buffers (one arena) ----
     const bool nb_on_dev = c->d_nb_idx != nullptr;
     const size_t nnz = (size_t)c->nb_off[p];
@@ -2620,7 +2670,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     constexpr unsigned LOG_CAP = 1u << 16;
     size_t need = (log_path ? pad(sizeof(ulonglong2) * LOG_CAP) : 0) + pad(sizeof(int32_t) * 2 * (size_t)ntg) + pad(sizeof(unsigned int) * ((size_t)ntg + 1)) + pad(sizeof(DhTgt) * ntg) + pad(sizeof(DhGlobal)) + 3 * pad(sizeof(long long) * ((size_t)ntg + 1));
     need += pad(4 * tot + 4) * 3 + pad(4 * 2 * tot * (size_t)d1 + 4) + pad(8 * tot + 8) * 4 + pad(4 * wl.size() + 4);
-    need += pad(sizeof(FwSeg) * max_ns) + pad(sizeof(FwSegOut) * max_ns);
+    need += pad(sizeof(FwSeg) * max_ns) + pad(sizeof(FwSegOut) * max_ns) + pad(sizeof(float) * tm_floats + 4);
     if (!nb_on_dev) need += pad(8 * ((size_t)p + 1)) + pad(4 * nnz + 4) + 2 * pad(8 * nnz + 8);
     const size_t rec_cap = MI_REC_CAP, bacc_cap = MI_BACC_CAP;
     if (per_target) need += pad(sizeof(MiQueue)) + pad(sizeof(MiBoard) * MI_BOARD_CAP) + pad(sizeof(FwSegOut) * rec_cap) + pad(sizeof(int32_t) * bacc_cap);
@@ -2671,6 +2721,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     A.wl = d_wl;
     FwSeg *d_segs = (FwSeg *)carve(sizeof(FwSeg) * max_ns);
     FwSegOut *d_so = (FwSegOut *)carve(sizeof(FwSegOut) * max_ns);
+    float *d_tmat = tm_floats ? (float *)carve(sizeof(float) * tm_floats + 4) : nullptr;
     ulonglong2 *d_log = log_path ? (ulonglong2 *)carve(sizeof(ulonglong2) * LOG_CAP) : nullptr;
     MiQueue *d_mq = per_target ? (MiQueue *)carve(sizeof(MiQueue)) : nullptr;
     MiBoard *d_boards = per_target ? (MiBoard *)carve(sizeof(MiBoard) * MI_BOARD_CAP) : nullptr;
@@ -2713,6 +2764,12 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
         A.nb_idx = ix;
         A.nb_stat = s1;
         A.nb_p = s2;
+    }
+    A.tmat = d_tmat;
+    if (d_tmat) {
+        hipLaunchKernelGGL(dh_tmat_build_kernel, dim3((unsigned)ntg, 8u), dim3(256), 0, st, (const DhTgt *)d_tg, ntg, A.nb_idx, (const float *)c->d_cor, p, d_tmat);
+        FW_HIP(c, hipGetLastError());
+        if (trace_host) fprintf(stderr, "[fw] chain %d: local correlation matrices: %.1f MB\n", chain, 4e-6 * (double)tm_floats);
     }
     const bool fz = c->P.kind == FW_FZ || nzk;  // the rounds over the Fisher-z segment kernels (fz_nz: on job-local matrices)
     DhParams P = dh_make_params(c, ntg, spec_depth, spec0_depth);

@@ -787,6 +787,37 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
         else
             for (int i = tid; i < a; i += 256) s_acc[i] = gacc[i];
     }
+    // r06: the target's LOCAL correlation matrix (FwSeg::tm, fw_devhiton.hip: dh_tmat_build_kernel): every variable id this body uses -- X, Y,
+    // the accepted list -- is replaced by its index in [T, T's level-0 neighbours ascending], `cor` / `p` by the (tm_m x tm_m) copy: the same
+    // Float32 entries, gathered out of a few hundred KB that stay in L2 instead of the 400 MB matrix.  The sorted ids are staged in the
+    // (not yet used) table array for the binary searches.  An id that is not on the list would be a bug of the caller: fail loudly.
+    int Xl = -1, Yl = -1;
+    if (TAB3 && !LOCAL && seg.tm != 0ull) {
+        int32_t *s_ids = (int32_t *)s_tab;  // FZ_TAB_CAP float4 = 4096 ints (the host gives no matrix to a target with more neighbours)
+        const int32_t *ids = (const int32_t *)seg.tm_ids;
+        const int nid = seg.tm_m - 1;
+        for (int i = tid; i < nid; i += 256) s_ids[i] = ids[i];
+        __syncthreads();
+        auto local_of = [&](int v) -> int {
+            if (v == seg.X) return 0;
+            int lo = 0, hi = nid - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_ids[mid] < v)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            if (nid <= 0 || s_ids[lo] != v) __builtin_trap();
+            return lo + 1;
+        };
+        for (int i = tid; i < a; i += 256) s_acc[i] = local_of(s_acc[i]);
+        Xl = 0;
+        Yl = local_of(seg.Y);
+        cor = cor_g + (((long long)seg.tm - (long long)(unsigned long long)cor_g) >> 2);  // (= (const float *)seg.tm, derived from the kernel's global pointer: global_load, not flat_load)
+        p = seg.tm_m;
+        __syncthreads();  // (the table array is free again; the barrier below publishes s_acc)
+    }
     if (tid == 0) {
         s_best_x = FZ_X_NONE;
         s_best_ps = 0.0;
@@ -810,7 +841,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     // (the context-wide thresholds carry them ready-made in thr[5..7]: fz_thresholds_kernel; per-job thresholds of fz_nz: computed here)
     const double h2_pos = !LOCAL ? thr[5] : rhi_pos * rhi_pos * (1.0 + 1e-12), h2_neg = !LOCAL ? thr[6] : rhi_neg * rhi_neg * (1.0 + 1e-12);
     const double s2 = !LOCAL ? thr[7] : (rsub_lo < 1.0 ? rsub_lo * rsub_lo : 1.0) * (1.0 - 1e-12);
-    const float scr_h2 = (float)(h2_pos > h2_neg ? h2_pos : h2_neg) * 1.00001f;  // cheap screen: the significance bound on |stat|^2 of either sign, rounded up
+    const float scr_h2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)(h2_pos > h2_neg ? h2_pos : h2_neg) * 1.00001f)));  // cheap screen: the significance bound on |stat|^2 of either sign, rounded up
     __syncthreads();
 #define ACCV(i) (LOCAL ? ((i) + 2) : (in_lds ? s_acc[(i)] : gacc[(i)]))
 #define CORV(u, v) cor[(size_t)(u) * p + (v)]
@@ -819,13 +850,20 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
 // neutral at cfg3 (193.2 against 191.8 ms), 3.7 % SLOWER at cfg5 (65.3 against 63.0 s on the same box, p = 100 000: a row is 400 KB,
 // the lines of 64 scattered columns of one row conflict in the L2 sets where 64 rows at one column do not) -- kept off.
 // -DFW_CORT_TRANSPOSED builds it.
+// r06: the size-3 table kernel reads the transposed entry: with a target's LOCAL matrix (FwSeg::tm) a row is at most a few hundred floats, so the
+// 64 gathers of a wavefront step -- one z2, 64 different z3 -- fall into a dozen cache lines of ONE row instead of 64 lines of 64 rows, and the
+// step stops being bound by the rate at which the CU's texture path looks up distinct lines (FW_CORT_TAB3=0: the r05 order; on the p x p
+// matrix, where a row is 40 KB, either order touches ~64 lines)
+#ifndef FW_CORT_TAB3
+#define FW_CORT_TAB3 1
+#endif
 #ifdef FW_CORT_TRANSPOSED
 #define CORT(u, v) (LOCAL ? CORV(u, v) : CORV(v, u))
 #else
-#define CORT(u, v) CORV(u, v)
+#define CORT(u, v) ((FW_CORT_TAB3 && TAB3 && !LOCAL) ? CORV(v, u) : CORV(u, v))
 #endif
 
-    const int X = LOCAL ? 0 : seg.X, Y = LOCAL ? 1 : seg.Y;
+    const int X = LOCAL ? 0 : (Xl >= 0 ? Xl : seg.X), Y = LOCAL ? 1 : (Yl >= 0 ? Yl : seg.Y);
     const float cXY = CORV(X, Y);
     const unsigned long long NONE = FW_RANK_NONE;
     const unsigned long long len = seg.end - seg.start;

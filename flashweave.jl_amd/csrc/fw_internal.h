@@ -63,6 +63,11 @@ struct FwSeg {
     int32_t pad;
     uint64_t start;
     uint64_t end;
+    // r06, fz device rounds: the target's LOCAL correlation matrix -- (tm_m x tm_m) Float32 over [T, its level-0 neighbours in ascending id
+    // order], a copy of those entries of the p x p matrix (fw_devhiton.hip: dh_tmat_build_kernel) -- and the sorted ids; 0: none (host pool,
+    // light targets): the kernel gathers from the p x p matrix
+    uint64_t tm, tm_ids;
+    int32_t tm_m, pad1;
 };
 
 #define FW_RANK_NONE (~0ull)
