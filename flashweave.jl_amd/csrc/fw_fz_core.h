@@ -1264,6 +1264,9 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
             double A2 = 0.0;
             int boff = 0;
             float pf_c32 = 0.0f;  // fast loop: the matrix entry of THIS iteration's test, fetched during the previous one
+            const unsigned int cbase32 = (unsigned int)cbase, r1rel = (unsigned int)r1 - (unsigned int)cbase;
+            const bool chunk_capped = max_tests > 0 && cend >= (unsigned long long)max_tests;  // workgroup-uniform
+            const bool p32 = p <= 46000;                                                      // p^2 < 2^31: 32-bit element index
             bool pf_ok = false;
             const double *hk_tb = s_hk;
             int hk_j = 0;
@@ -1304,14 +1307,18 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                     const float4 tk = s_tab[ek];
                     const float rk1 = s_tab_r1[ek];
                     const int fj = __float_as_int(tj.w), fk = __float_as_int(tk.w);
+                    // (the gathers of the fast loop index the matrix with 32 bits where p^2 allows it -- always with a local matrix: one multiply-add
+                    // and a scalar base instead of a 64-bit multiply and two 64-bit adds per gather)
+#define CORT32(u, v) (p32 ? ((FW_CORT_TAB3 && !LOCAL) ? cor[(unsigned int)(v) * (unsigned int)p + (unsigned int)(u)] : cor[(unsigned int)(u) * (unsigned int)p + (unsigned int)(v)]) : CORT(u, v))
                     float c32 = pf_c32;  // fetched during the previous iteration (below); a lane's first iteration behind the general form: now
                     if (!pf_ok) {
-                        c32 = CORT(fk & FZ_TAB_ZMASK, fj & FZ_TAB_ZMASK);
+                        c32 = CORT32(fk & FZ_TAB_ZMASK, fj & FZ_TAB_ZMASK);
                         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) HERE: behind the join the compiler would otherwise wait for everything in flight, the next entry included
                     }
                     // the next test of this lane (64 ranks ahead): its position, and its matrix entry on the way while this test is
                     // evaluated -- the gather (two table words, then the entry) is otherwise the head of every test's dependent chain
-                    const bool hasN = r + 64ull < r1;
+                    const unsigned int rrel = (unsigned int)r - cbase32;  // the rank relative to the chunk (a chunk holds at most 16 384 ranks)
+                    const bool hasN = rrel + 64u < r1rel;
                     int ni = pos[0], nj = pos[1], nk = pos[2] + (hasN ? 64 : 0), nchg = 2;
                     while (nk > a - 1) {  // row (i, j) holds k = j + 1 .. a - 1: carry the overflow into the next rows
                         const int over = nk - a;
@@ -1327,9 +1334,11 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                     int nboff = boff;
                     if (nchg <= 0) nboff = fz_tab_off(ni, tb_i0, a) - ni - 1;
                     const int nfj = __float_as_int(s_tab[nboff + nj].w), nfk = __float_as_int(s_tab[nboff + nk].w);  // (in range also without a next test: this test's row)
-                    if (hasN) pf_c32 = CORT(nfk & FZ_TAB_ZMASK, nfj & FZ_TAB_ZMASK);  // straight into the loop-carried register: a copy at the end of the iteration would wait for it
-                    const bool f_nostop = !(__hip_atomic_load(&s_cstop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned int)(r - cbase));
-                    const bool f_capped = max_tests > 0 && r + 1 >= (unsigned long long)max_tests;
+                    if (hasN) pf_c32 = CORT32(nfk & FZ_TAB_ZMASK, nfj & FZ_TAB_ZMASK);  // straight into the loop-carried register: a copy at the end of the iteration would wait for it
+#undef CORT32
+                    const bool f_nostop = !(__hip_atomic_load(&s_cstop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < rrel);
+                    bool f_capped = false;
+                    if (chunk_capped) f_capped = r + 1 >= (unsigned long long)max_tests;  // (wave-uniform branch: only the chunk that holds the cap looks)
 #if FW_FZ_SCREEN
                     // ---- cheap screen (r06) ----
                     // A test that is (a) significant for sure, (b) not the last test of a capped job, (c) not behind a stop and (d) clearly

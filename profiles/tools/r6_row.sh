@@ -1,5 +1,5 @@
 #!/bin/bash
-# r06: the row loop of the size-3 table kernel against the per-lane loop (libfw_row0.so = -DFW_FZ_ROWLOOP=0), cfg3, one box; then the parity suites
+# r06: A/B of the current build against libfw_row0.so (the previous build), cfg3, one box; then the parity suites
 export FW_KNOBS=1
 O=gpurun_out/r6_row; mkdir -p $O; : > $O/ab.txt
 run() { lib=$1; shift; env "$@" FW_LIB_PATH=$PWD/flashweave.jl_amd/$lib timeout 400 python bench.py --config cfg3 --steps 6 --warmup 2 --no-cpu-baseline 2>$O/err.txt | tail -1 | python -c "import sys,json; l=json.loads(sys.stdin.read()); r=l['roofline']; print('cfg3 $lib $*', round(l['ms_per_step'],2), round((l.get('other_schedule') or {}).get('ms_per_step',0),2), l['edges'], '%.5g'%l['tests_per_step']['conditional_evaluated'], 'kernel s %.4f (%s), evaluated/s in kernel %.4g'%(r['kernel_seconds_per_step'], r['measured_on'][:9], r['evaluated_tests_per_s_in_kernel']), l['network_sha256'][:12])" | tee -a $O/ab.txt; tail -3 $O/err.txt | grep -i "error\|fail" ; }
