@@ -641,10 +641,10 @@ def main():
         # the traffic is there, or when no PMC summary of this configuration is tracked (the nominal label of SURVEY 8d)
         low_traffic = pmc is not None and (traffic or 0) < 0.5 * rcn["alg_bytes_subsets"] / n_sub_launches
         bound = ("valu" if valu and valu["busy_frac"] >= 0.6 else "latency") if low_traffic else "hbm"
-        # r06: a kernel that reaches less than 5 % of the nominal HBM rate with its vector ALUs active less than 20 % of the time is
+        # r06: a kernel that reaches less than 5 % of the nominal HBM rate with its vector ALUs busy less than 60 % of the time is
         # waiting -- on dependent loads, on other wavefronts -- whatever its fabric traffic looks like next to the algorithmic bytes
         # (cfg2 / cfg3he printed "hbm" at 0.003: their spill / record writes are of the size of their tiny algorithmic bytes)
-        if valu and achieved / HBM_PEAK_GBS < 0.05 and valu["busy_frac"] < 0.2:
+        if valu and achieved / HBM_PEAK_GBS < 0.05 and valu["busy_frac"] < 0.6:
             bound = "latency"
         roofline = {"bound": bound, "kernel": kname,
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
