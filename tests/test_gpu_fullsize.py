@@ -194,7 +194,8 @@ def test_cfg3_network_independent_of_schedule():
     settings = [{}, {"FW_SEG_TARGET": "2048", "FW_SEG_A": "0", "FW_SEG_B": "0"}, {"FW_DH_SPEC": "0", "FW_DH_SPEC0": "0"},
                 {"FW_DH_SPEC": "8", "FW_DH_SPEC0": "4", "FW_DH_SPEC_BELOW": "100000000000", "FW_DH_SPEC0_BELOW": "100000000000",
                  "FW_DH_SPEC0_JOBS": "100000", "FW_DH_TIME_EVERY": "1"},
-                {"FW_DH_CHAINS": "1"}, {"FW_DH_CHAINS": "3"}]  # concurrent chains of device rounds (default 2)
+                {"FW_DH_CHAINS": "1"}, {"FW_DH_CHAINS": "3"},  # concurrent chains of device rounds (default 2)
+                {"FW_FZ_TMAT": "0"}, {"FW_FZ_TMAT": "1"}]  # r06: no local correlation matrices / one for every target (default: from 16 neighbours on)
     seen = set()
     for s in settings:
         out = subprocess.run([sys.executable, "-c", _HASH_SNIPPET % root], env=dict(os.environ, **s), cwd=root, check=True,
