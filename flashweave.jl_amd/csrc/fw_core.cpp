@@ -186,6 +186,9 @@ int fw_ctx_destroy(fw_ctx *c)
         free_dev(c->d_dh[q]);
         free_pin(c->h_dh[q]);
         if (c->dh_stream[q]) (void)hipStreamDestroy(c->dh_stream[q]);
+        if (c->dh_hp_stream[q]) (void)hipStreamDestroy(c->dh_hp_stream[q]);
+        for (int e = 0; e < 2; ++e)
+            if (c->dh_hp_ev[q][e]) (void)hipEventDestroy(c->dh_hp_ev[q][e]);
     }
     free_pin(c->h_jobs);
     free_pin(c->h_acc);

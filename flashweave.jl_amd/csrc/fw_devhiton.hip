@@ -2835,15 +2835,38 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     PA.log = d_log;
     PA.seg_a = seg_a;
     PA.seg_b = seg_b;
+    // the small kernels of a round on the chain's high-priority stream (fw_ctx::dh_hp_stream) where the segment launches are long (max_k > 3; FW_DH_HP=0 / 1
+    // forces it off / on): two cross-stream dependencies per round cost ~10 us, a one-workgroup plan kernel queued behind the other chain's segment
+    // kernel cost 3 ms per round at cfg5 (profiles/r05_cfg5_kernel_stats.csv)
+    static const int hp_env = [] { const char *e = fw_knob("FW_DH_HP"); return e ? atoi(e) : -1; }();
+    const bool use_hp = !per_target && (hp_env >= 0 ? hp_env != 0 : c->P.max_k > 3);
+    hipStream_t hs = st;
+    if (use_hp) {
+        if (!c->dh_hp_stream[chain]) {
+            int lo = 0, hi = 0;
+            FW_HIP(c, hipDeviceGetStreamPriorityRange(&lo, &hi));  // (hi: numerically lowest = highest priority)
+            FW_HIP(c, hipStreamCreateWithPriority(&c->dh_hp_stream[chain], hipStreamNonBlocking, hi));
+            for (int e = 0; e < 2; ++e) FW_HIP(c, hipEventCreateWithFlags(&c->dh_hp_ev[chain][e], hipEventDisableTiming));
+        }
+        hs = c->dh_hp_stream[chain];
+    }
     auto planfill = [&](bool compact) {
-        hipLaunchKernelGGL(dh_step_kernel, dim3((n_act_bound + 3u) / 4u), dim3(256), 0, st, d_tg, ntg, d_g, A,
+        if (use_hp) {  // behind the segment kernel of this round ...
+            (void)hipEventRecord(c->dh_hp_ev[chain][0], st);
+            (void)hipStreamWaitEvent(hs, c->dh_hp_ev[chain][0], 0);
+        }
+        hipLaunchKernelGGL(dh_step_kernel, dim3((n_act_bound + 3u) / 4u), dim3(256), 0, hs, d_tg, ntg, d_g, A,
                            (const FwSegOut *)d_so, (const long long *)d_seg0, d_win, d_sp, d_win2, (const int32_t *)d_act, P);
         if (compact)  // between step and plan: seg0 of the coming launch is built on the new list
-            hipLaunchKernelGGL(dh_compact_kernel, dim3(1), dim3(1024), 0, st, (const DhTgt *)d_tg, ntg, d_g, d_act);
-        hipLaunchKernelGGL(dh_plan_kernel, dim3(1), dim3(1024), 0, st, ntg, d_g, (const unsigned long long *)d_win,
+            hipLaunchKernelGGL(dh_compact_kernel, dim3(1), dim3(1024), 0, hs, (const DhTgt *)d_tg, ntg, d_g, d_act);
+        hipLaunchKernelGGL(dh_plan_kernel, dim3(1), dim3(1024), 0, hs, ntg, d_g, (const unsigned long long *)d_win,
                            (const unsigned int *)d_sp, (const unsigned long long *)d_win2, (const int32_t *)d_act, d_seg0, PA);
-        hipLaunchKernelGGL(dh_fill_kernel, dim3(g_fill), dim3(256), 0, st, (const DhTgt *)d_tg, ntg, d_g,
+        hipLaunchKernelGGL(dh_fill_kernel, dim3(g_fill), dim3(256), 0, hs, (const DhTgt *)d_tg, ntg, d_g,
                            (const long long *)d_seg0, A, d_segs, d1, (const int32_t *)d_act);
+        if (use_hp) {  // ... and in front of the next one
+            (void)hipEventRecord(c->dh_hp_ev[chain][1], hs);
+            (void)hipStreamWaitEvent(st, c->dh_hp_ev[chain][1], 0);
+        }
     };
     const double th1 = wall();
     int rc2 = FW_OK;

@@ -207,6 +207,11 @@ struct fw_ctx {
     FwDevBuf d_dh[FW_DH_MAX_CHAINS];  // arenas of the device-resident HITON rounds (fw_devhiton.hip), one per concurrent chain
     FwPinned h_dh[FW_DH_MAX_CHAINS];  // their pinned flag pages
     hipStream_t dh_stream[FW_DH_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};  // streams of chains 1.. (chain 0: pb[0].stream)
+    // r06: a high-priority stream per chain for the small kernels between two segment launches (step / compact / plan / fill), with the two events
+    // that tie it to the chain's stream -- used where the segment launches are long (max_k > 3): a one-workgroup kernel then no longer queues behind
+    // the thousands of pending workgroups of the OTHER chain's segment kernel
+    hipStream_t dh_hp_stream[FW_DH_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t dh_hp_ev[FW_DH_MAX_CHAINS][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     FwPinned h_jobs, h_acc, h_out;
     FwPoolBuf pb[2];
 };
