@@ -2195,6 +2195,16 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
 {
     dh_plan_dev<1024>(ntg, g, win, sp, win2, act_all, seg0, PA);
 }
+// The same plan on ONE wavefront per SIMD (r06).  The 1 024-thread form is 4 wavefronts x 127 registers per SIMD: it starts only on a CU that is EMPTY, and while the
+// other chain's long-list segment kernel (3 x 168 registers per SIMD, thousands of workgroups pending) keeps every CU refilled that happens when that kernel has
+// nothing left to dispatch -- cfg5: 3.1 ms per call, 7 588 calls (profiles/r05_cfg5_kernel_stats.csv; stream priority does not help: r06_cfg5_plan_kernel.txt).
+// 256 threads fit beside two resident segment wavefronts as soon as one workgroup leaves.  Used where the segment launches are long (max_k > 3).
+__global__ __launch_bounds__(256) void dh_plan_small_kernel(int ntg, DhGlobal *__restrict__ g, const unsigned long long *__restrict__ win,
+                                                            const unsigned int *__restrict__ sp, const unsigned long long *__restrict__ win2,
+                                                            const int32_t *__restrict__ act_all, long long *__restrict__ seg0, DhPlanArgs PA)
+{
+    dh_plan_dev<256>(ntg, g, win, sp, win2, act_all, seg0, PA);
+}
 
 // fz rounds (r06): the local correlation matrix of every target that has one -- M[a][b] = cor[id(a)][id(b)], id(0) = T, id(1 ..) = T's
 // level-0 neighbours in ascending id order (every variable a job of T can name: candidates, TPC / PC members and whitelisted
@@ -2835,11 +2845,11 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     PA.log = d_log;
     PA.seg_a = seg_a;
     PA.seg_b = seg_b;
-    // the small kernels of a round on the chain's high-priority stream (fw_ctx::dh_hp_stream) where the segment launches are long (max_k > 3; FW_DH_HP=0 / 1
-    // forces it off / on): two cross-stream dependencies per round cost ~10 us, a one-workgroup plan kernel queued behind the other chain's segment
-    // kernel cost 3 ms per round at cfg5 (profiles/r05_cfg5_kernel_stats.csv)
+    // FW_DH_HP=1: the small kernels of a round on the chain's high-priority stream (fw_ctx::dh_hp_stream) -- an experiment kept behind its knob
     static const int hp_env = [] { const char *e = fw_knob("FW_DH_HP"); return e ? atoi(e) : -1; }();
-    const bool use_hp = !per_target && (hp_env >= 0 ? hp_env != 0 : c->P.max_k > 3);
+    const bool use_hp = !per_target && hp_env > 0;  // (measured at cfg5: no effect -- what held the plan kernel back was its size, not its queue; default off)
+    static const int ps_env = [] { const char *e = fw_knob("FW_DH_PLAN_SMALL"); return e ? atoi(e) : -1; }();
+    const bool plan_small = ps_env >= 0 ? ps_env != 0 : c->P.max_k > 3;
     hipStream_t hs = st;
     if (use_hp) {
         if (!c->dh_hp_stream[chain]) {
@@ -2859,8 +2869,12 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
                            (const FwSegOut *)d_so, (const long long *)d_seg0, d_win, d_sp, d_win2, (const int32_t *)d_act, P);
         if (compact)  // between step and plan: seg0 of the coming launch is built on the new list
             hipLaunchKernelGGL(dh_compact_kernel, dim3(1), dim3(1024), 0, hs, (const DhTgt *)d_tg, ntg, d_g, d_act);
-        hipLaunchKernelGGL(dh_plan_kernel, dim3(1), dim3(1024), 0, hs, ntg, d_g, (const unsigned long long *)d_win,
-                           (const unsigned int *)d_sp, (const unsigned long long *)d_win2, (const int32_t *)d_act, d_seg0, PA);
+        if (plan_small)
+            hipLaunchKernelGGL(dh_plan_small_kernel, dim3(1), dim3(256), 0, hs, ntg, d_g, (const unsigned long long *)d_win,
+                               (const unsigned int *)d_sp, (const unsigned long long *)d_win2, (const int32_t *)d_act, d_seg0, PA);
+        else
+            hipLaunchKernelGGL(dh_plan_kernel, dim3(1), dim3(1024), 0, hs, ntg, d_g, (const unsigned long long *)d_win,
+                               (const unsigned int *)d_sp, (const unsigned long long *)d_win2, (const int32_t *)d_act, d_seg0, PA);
         hipLaunchKernelGGL(dh_fill_kernel, dim3(g_fill), dim3(256), 0, hs, (const DhTgt *)d_tg, ntg, d_g,
                            (const long long *)d_seg0, A, d_segs, d1, (const int32_t *)d_act);
         if (use_hp) {  // ... and in front of the next one
