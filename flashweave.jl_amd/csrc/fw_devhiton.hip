@@ -2198,7 +2198,9 @@ __global__ __launch_bounds__(1024) void dh_plan_kernel(int ntg, DhGlobal *__rest
 // The same plan on ONE wavefront per SIMD (r06).  The 1 024-thread form is 4 wavefronts x 127 registers per SIMD: it starts only on a CU that is EMPTY, and while the
 // other chain's long-list segment kernel (3 x 168 registers per SIMD, thousands of workgroups pending) keeps every CU refilled that happens when that kernel has
 // nothing left to dispatch -- cfg5: 3.1 ms per call, 7 588 calls (profiles/r05_cfg5_kernel_stats.csv; stream priority does not help: r06_cfg5_plan_kernel.txt).
-// 256 threads fit beside two resident segment wavefronts as soon as one workgroup leaves.  Used where the segment launches are long (max_k > 3).
+// 256 threads fit beside two resident segment wavefronts as soon as one workgroup leaves.  cfg5 59.1 -> 57.8 s; and at cfg3, whose size-3 kernel fills the register
+// file with 4 x 128, the two chains stop holding each other's rounds up: plan 27 -> 8 us per call in the two-chain pass, headline 159.6 -> 152.2 ms
+// (profiles/r06_cfg5_plan_kernel.txt, r06_cfg3_plan_kernel.txt).  The default (FW_DH_PLAN_SMALL=0: the 1 024-thread form).
 __global__ __launch_bounds__(256) void dh_plan_small_kernel(int ntg, DhGlobal *__restrict__ g, const unsigned long long *__restrict__ win,
                                                             const unsigned int *__restrict__ sp, const unsigned long long *__restrict__ win2,
                                                             const int32_t *__restrict__ act_all, long long *__restrict__ seg0, DhPlanArgs PA)
@@ -2849,7 +2851,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     static const int hp_env = [] { const char *e = fw_knob("FW_DH_HP"); return e ? atoi(e) : -1; }();
     const bool use_hp = !per_target && hp_env > 0;  // (measured at cfg5: no effect -- what held the plan kernel back was its size, not its queue; default off)
     static const int ps_env = [] { const char *e = fw_knob("FW_DH_PLAN_SMALL"); return e ? atoi(e) : -1; }();
-    const bool plan_small = ps_env >= 0 ? ps_env != 0 : c->P.max_k > 3;
+    const bool plan_small = ps_env >= 0 ? ps_env != 0 : true;
     hipStream_t hs = st;
     if (use_hp) {
         if (!c->dh_hp_stream[chain]) {
