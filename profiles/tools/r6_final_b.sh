@@ -11,4 +11,4 @@ for f in sorted(glob.glob("gpurun_out/r6_final_b/bench_*.json")):
         print(f, "ms %.2f other %s edges %d"%(l["ms_per_step"], (l.get("other_schedule") or {}).get("ms_per_step"), l["edges"]), "frac %.3f bound %s valu_frac %s traffic %s l0 %s w/r %s cpu %s"%(r["frac"], r["bound"], r.get("valu_frac"), r.get("traffic"), (r.get("level0") or {}).get("frac"), r.get("write_over_result_bytes"), (l.get("cpu_baseline") or {}).get("value")))
     except Exception as e: print(f, "ERR", e)
 PY
-timeout 1200 python -m pytest tests/test_gpu_fullsize.py -m gpu -q --durations=8 2>&1 | tail -14
+
