@@ -2628,11 +2628,11 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     size_t tm_floats = 0;
     {
         static const int tm_min = [] { const char *e = fw_knob("FW_FZ_TMAT"); return e ? atoi(e) : 16; }();  // smallest degree that gets one (0: off)
-        const bool tm_on = c->P.kind == FW_FZ && c->P.max_k <= 3 && c->d_cor != nullptr && tm_min > 0;
+        const bool tm_on = c->P.kind == FW_FZ && c->P.max_k <= 5 && c->d_cor != nullptr && tm_min > 0;  // (max_k 6-7: the general-form kernel reads the p x p matrix)
         for (int t = 0; t < ntg; ++t) {
             tg[t].tm_off = -1;
             const size_t m = (size_t)tg[t].nb_n + 1;
-            if (!tm_on || tg[t].nb_n < tm_min || m > 4096 || tm_floats + m * m > (size_t)1 << 31) continue;  // (<= 8 GB per chain; ids of a target staged in 16 KB of LDS)
+            if (!tm_on || tg[t].nb_n < tm_min || m > 4096 || tm_floats + m * m > (size_t)1 << 32) continue;  // (<= 16 GB per chain; ids of a target staged in 16 KB of LDS)
             tg[t].tm_off = (long long)tm_floats;
             tm_floats += m * m;
         }

@@ -701,6 +701,9 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     constexpr bool HK = TAB && HIGHK && !LOCAL;   // level-2 tables for sizes 4 and 5
     static_assert(!(TAB && HIGHK && LOCAL), "no level-2 table variant for per-job matrices");
     constexpr bool L1T = HIGHK && !TAB && !LOCAL;  // level-1 table for sizes 4 and 5 over long lists
+#ifndef FW_FZ_TMAT_HIGHK
+#define FW_FZ_TMAT_HIGHK 1  // r06: the max_k 4-5 kernels take a target's local matrix too (0: the p x p matrix, A/B knob)
+#endif
 #ifndef FW_L3_SCREEN
 #define FW_L3_SCREEN 0  // (A/B knob; r05: built, bit-identical, cfg5 58.72 s with it against 58.63 s without -- the tests of cfg5 live where p underflows to 0 (a p = 0 branch of the maximum-p bookkeeping was tried too: neutral there, -2 % at cfg3, removed) -- so the r03 / r04 form stays: every size-5 test of the position tables takes its quotient)
 #endif
@@ -718,8 +721,11 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     // level-3 position tables (L1T chunks, see "level-3 position tables" below)
     __shared__ float s3_p2[L1T ? FZ_L3_CAP : 1], s3_r2[L1T ? FZ_L3_CAP : 1];  // rho(w,z2|z1) and sqrt(1 - .^2) in Float32
     __shared__ unsigned char s3_fl[L1T ? FZ_L3_CAP : 1];
-    __shared__ double s3_d2c[L1T ? FZ_L3_CAP : 1], s3_q3[L1T ? FZ_L3_CAP : 1], s3_sq3[L1T ? FZ_L3_CAP : 1], s3_x3[L1T ? FZ_L3_CAP : 1],
-        s3_sx3[L1T ? FZ_L3_CAP : 1], s3_y3[L1T ? FZ_L3_CAP : 1], s3_sy3[L1T ? FZ_L3_CAP : 1], s3_a4[L1T ? FZ_L3_CAP : 1];
+    // (one block: its 28 KB also stage the sorted ids of a target's local matrix in the prologue, before any table exists)
+    __shared__ double s3_blk[L1T ? 8 * FZ_L3_CAP : 1];
+    double *const s3_d2c = s3_blk, *const s3_q3 = s3_blk + (L1T ? FZ_L3_CAP : 0), *const s3_sq3 = s3_blk + (L1T ? 2 * FZ_L3_CAP : 0),
+                  *const s3_x3 = s3_blk + (L1T ? 3 * FZ_L3_CAP : 0), *const s3_sx3 = s3_blk + (L1T ? 4 * FZ_L3_CAP : 0), *const s3_y3 = s3_blk + (L1T ? 5 * FZ_L3_CAP : 0),
+                  *const s3_sy3 = s3_blk + (L1T ? 6 * FZ_L3_CAP : 0), *const s3_a4 = s3_blk + (L1T ? 7 * FZ_L3_CAP : 0);
     __shared__ int s3_off[L1T ? FZ_L3_DIR + 1 : 2], s3_low[L1T ? FZ_L3_DIR : 1], s3_jk[L1T ? FZ_L3_DIR : 1];
     __shared__ float s3_bp2[L1T ? FZ_L3_DIR : 1];  // block scalars of sub-block (z2, z3): rho(z3,z2|z1) ...
     __shared__ unsigned char s3_bfl[L1T ? FZ_L3_DIR : 1];
@@ -792,8 +798,11 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     // Float32 entries, gathered out of a few hundred KB that stay in L2 instead of the 400 MB matrix.  The sorted ids are staged in the
     // (not yet used) table array for the binary searches.  An id that is not on the list would be a bug of the caller: fail loudly.
     int Xl = -1, Yl = -1;
-    if (TAB3 && !LOCAL && seg.tm != 0ull) {
-        int32_t *s_ids = (int32_t *)s_tab;  // FZ_TAB_CAP float4 = 4096 ints (the host gives no matrix to a target with more neighbours)
+    bool tloc = false;  // this segment reads its target's local matrix (workgroup-uniform)
+    if (!LOCAL && seg.tm != 0ull && (TAB3 || (FW_FZ_TMAT_HIGHK && (HK || L1T) && in_lds))) {
+        // staging: FZ_TAB_CAP float4 = 4096 ints / the level-2 tables' 32 KB / the level-3 tables' 28 KB (the host gives no matrix to a target with more than 4 095 neighbours)
+        int32_t *s_ids = TAB3 ? (int32_t *)s_tab : (HK ? (int32_t *)s_hk : (int32_t *)s3_blk);
+        if (!TAB3) tloc = true;
         const int32_t *ids = (const int32_t *)seg.tm_ids;
         const int nid = seg.tm_m - 1;
         for (int i = tid; i < nid; i += 256) s_ids[i] = ids[i];
@@ -860,7 +869,8 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
 #ifdef FW_CORT_TRANSPOSED
 #define CORT(u, v) (LOCAL ? CORV(u, v) : CORV(v, u))
 #else
-#define CORT(u, v) ((FW_CORT_TAB3 && TAB3 && !LOCAL) ? CORV(v, u) : CORV(u, v))
+// r06, max_k 4-5 with a local matrix (tloc, workgroup-uniform): transposed as well -- a lane's run of tests walks ALONG a row of a few hundred floats
+#define CORT(u, v) ((FW_CORT_TAB3 && TAB3 && !LOCAL) ? CORV(v, u) : ((FW_FZ_TMAT_HIGHK && HIGHK && !LOCAL) ? cor[(size_t)(tloc ? (v) : (u)) * p + (tloc ? (u) : (v))] : CORV(u, v)))
 #endif
 
     const int X = LOCAL ? 0 : (Xl >= 0 ? Xl : seg.X), Y = LOCAL ? 1 : (Yl >= 0 ? Yl : seg.Y);
