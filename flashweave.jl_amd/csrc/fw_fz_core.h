@@ -701,6 +701,9 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     constexpr bool HK = TAB && HIGHK && !LOCAL;   // level-2 tables for sizes 4 and 5
     static_assert(!(TAB && HIGHK && LOCAL), "no level-2 table variant for per-job matrices");
     constexpr bool L1T = HIGHK && !TAB && !LOCAL;  // level-1 table for sizes 4 and 5 over long lists
+#ifndef FW_FZ_L1T_ROW32
+#define FW_FZ_L1T_ROW32 0
+#endif
 #ifndef FW_FZ_TMAT_HIGHK
 #define FW_FZ_TMAT_HIGHK 1  // r06: the max_k 4-5 kernels take a target's local matrix too (0: the p x p matrix, A/B knob)
 #endif
@@ -799,7 +802,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     // (not yet used) table array for the binary searches.  An id that is not on the list would be a bug of the caller: fail loudly.
     int Xl = -1, Yl = -1;
     bool tloc = false;  // this segment reads its target's local matrix (workgroup-uniform)
-    if (!LOCAL && seg.tm != 0ull && (TAB3 || (FW_FZ_TMAT_HIGHK && (HK || L1T) && in_lds))) {
+    if (!LOCAL && seg.tm != 0ull && (TAB3 || (FW_FZ_TMAT_HIGHK && ((HK && FW_FZ_TMAT_HIGHK != 2) || L1T) && in_lds))) {
         // staging: FZ_TAB_CAP float4 = 4096 ints / the level-2 tables' 32 KB / the level-3 tables' 28 KB (the host gives no matrix to a target with more than 4 095 neighbours)
         int32_t *s_ids = TAB3 ? (int32_t *)s_tab : (HK ? (int32_t *)s_hk : (int32_t *)s3_blk);
         if (!TAB3) tloc = true;
@@ -1286,6 +1289,9 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
             double A2j = 0.0;
             // level-3 position tables: the z4 entry of the running sub-block
             int l3_base = 0, zl = 0;
+#if FW_FZ_L1T_ROW32
+            int zl_row = 0;
+#endif
             float4 t1l = make_float4(0.f, 0.f, 0.f, 0.f);
             float p2l = 0.f;
             bool fl3 = false, cl3 = false, nn3 = false;
@@ -1607,6 +1613,9 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                             const int pl = pos[3], el = l3_base + pl;
                             t1l = s_l1[pl];
                             zl = s_acc[pl];
+#if FW_FZ_L1T_ROW32
+                            zl_row = zl * p;
+#endif
                             p2l = s3_p2[el];
                             fl3 = (s3_fl[el] & 1) != 0;
                             cl3 = (s3_fl[el] & 2) != 0;
@@ -1622,7 +1631,12 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
                         }
                         const int pm = pos[4], em = l3_base + pm;
                         const float4 t1m = s_l1[pm];
+#if FW_FZ_L1T_ROW32
+                        // (local matrix: m^2 < 2^24 -- the row base of z4 is computed where z4 changes, the test adds its column)
+                        const float c45 = tloc ? cor[(unsigned int)(zl_row + s_acc[pm])] : CORV(s_acc[pm], zl);
+#else
                         const float c45 = CORT(s_acc[pm], zl);
+#endif
                         bool f1ok;
                         const float R1f = pc_l1_rf(c45, t1m.z, t1l.z, t1m.w, t1l.w, f1ok);     // rho(v,z4|z1)
                         const int flm = (l3_nn || !FW_L3_ENTRY_NN) ? 7 : (int)s3_fl[em];
