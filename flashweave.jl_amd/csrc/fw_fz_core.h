@@ -702,7 +702,7 @@ __device__ __forceinline__ void fz_seg_body(const float *__restrict__ cor_g, int
     static_assert(!(TAB && HIGHK && LOCAL), "no level-2 table variant for per-job matrices");
     constexpr bool L1T = HIGHK && !TAB && !LOCAL;  // level-1 table for sizes 4 and 5 over long lists
 #ifndef FW_FZ_L1T_ROW32
-#define FW_FZ_L1T_ROW32 0
+#define FW_FZ_L1T_ROW32 1  // r06: the size-5 gather of a local matrix with a 32-bit row base (cfg5 54.6 -> 54.0 s)
 #endif
 #ifndef FW_FZ_TMAT_HIGHK
 #define FW_FZ_TMAT_HIGHK 1  // r06: the max_k 4-5 kernels take a target's local matrix too (0: the p x p matrix, A/B knob)
