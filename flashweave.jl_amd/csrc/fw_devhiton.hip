@@ -2643,7 +2643,7 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     const size_t nnz = (size_t)c->nb_off[p];
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
     static const unsigned seg_target_env = [] { const char *e = fw_knob("FW_SEG_TARGET"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 0u; }();
-    const unsigned seg_target = seg_target_env ? seg_target_env : ((c->P.kind == FW_FZ || c->P.kind == FW_FZ_NZ) ? 3072u : 4096u);  // cfg3 sweep: 3072
+    const unsigned seg_target = seg_target_env ? seg_target_env : ((c->P.kind == FW_FZ || c->P.kind == FW_FZ_NZ) ? (c->P.max_k > 3 ? 8192u : 3072u) : 4096u);  // cfg3 sweep: 3072; cfg5 (max_k 5, launches of 10^8 ranks and more): 8192 (r06: 53.9 -> 52.4 s)
     // elimination-phase look-ahead (fz, FW_ELIM_FULL windows; see dh_step_kernel): FW_DH_SPEC = members tested ahead per
     // target, FW_DH_SPEC_BELOW = only while the last launch held fewer ranks than this.  cfg3 sweep (ms per pass, one
     // GPU / one rank of 8): off 326.7 / 112.0; depth 4 always 338 / 103; depth 4 below 4M 318.5 / 104.4, below 8M
