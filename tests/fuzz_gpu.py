@@ -20,6 +20,7 @@ from oracle import oracle as O
 STOL = 1e-12  # discrete statistics: summation order, device log (tests/test_gpu_mi.py)
 PTOL = 1e-10  # discrete p-values: device lgamma / exp in Q(a, x) (tests/test_gpu_mi.py)
 ENV_KEYS = ("FW_HOST_HITON", "FW_DEV_MIN_TARGETS", "FW_HOST_BH")
+HIGHK = False  # set by --highk
 os.environ.setdefault("FW_KNOBS", "1")  # the library reads FW_* knobs only under FW_KNOBS=1 (csrc/fw_internal.h)
 
 
@@ -53,6 +54,16 @@ def draw(seed):
         c["n"] = int(r.integers(100, 700))
     c["env"] = dict(FW_HOST_HITON=str(int(r.integers(0, 3) == 0)), FW_DEV_MIN_TARGETS=str(int(r.choice([1, 16, 64]))),
                     FW_HOST_BH=str(int(r.integers(0, 4) == 0)))
+    if HIGHK:  # --highk: Fisher-z networks with max_k 4 / 5 (level-2 / level-3 table kernels, device rounds with local matrices); jobs capped so that the oracle finishes
+        c["kind"] = "fz"
+        c["max_k"] = int(r.choice([4, 5]))
+        c["source"] = str(r.choice(["synth", "factor", "factor"]))
+        c["p"] = int(r.integers(24, 260))
+        c["n"] = int(r.integers(60, 420))
+        c["alpha"] = float(r.choice([0.01, 0.05, 0.2, 0.5]))
+        c["max_tests"] = int(r.choice([40, 700, 700, 5000, 30000])) if c["p"] > 48 else 10_000_000
+        c["dups"] = False
+        c["env"]["FW_HOST_HITON"] = str(int(r.integers(0, 5) == 0))
     return c
 
 
@@ -246,7 +257,10 @@ def main():
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--subsets", action="store_true", help="test_subsets batches instead of whole networks")
+    ap.add_argument("--highk", action="store_true", help="whole networks with fz, max_k 4 / 5")
     a = ap.parse_args()
+    global HIGHK
+    HIGHK = a.highk
     bad = 0
     tot_edges = tot_cond = 0
     if a.subsets:
