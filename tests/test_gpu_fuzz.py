@@ -18,6 +18,17 @@ def test_random_cases_match_oracle(first):
     assert kinds == {"fz", "fz_nz", "mi", "mi_nz"}
 
 
+def test_random_max_k_4_5_networks_match_oracle(monkeypatch):
+    # whole Fisher-z networks with max_k 4 / 5: level-2 / level-3 table kernels in the device rounds, on the targets' local matrices (r06)
+    monkeypatch.setattr(fuzz_gpu, "HIGHK", True)
+    ks = set()
+    for seed in range(650000, 650012):
+        case, msg = fuzz_gpu.run_case(seed)
+        assert msg is None, (msg, case)
+        ks.add(case["max_k"])
+    assert ks == {4, 5}
+
+
 def test_random_test_subsets_batches_match_oracle():
     for seed in range(60):
         case, msg = fuzz_gpu.run_subsets_case(seed)
