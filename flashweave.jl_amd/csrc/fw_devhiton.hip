@@ -2677,7 +2677,10 @@ int fwi_devhiton_run(fw_ctx *c, const std::vector<FwDhTarget> &in, std::vector<F
     // slots the one-workgroup step / plan kernels of the OTHER chain find a free CU at once instead of queueing behind
     // this launch's pending workgroups -- cfg5 profile: dh_plan_kernel 6.3 ms per call, all of it waiting)
     static const unsigned seg_grid_env = [] { const char *e = fw_knob("FW_SEG_GRID"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 0u; }();
-    const unsigned grid_seg = seg_grid_env ? std::min(seg_target + 512u, seg_grid_env) : seg_target + 512u;
+    // r06 (cfg3, one box): 3 584 workgroups 152.6 ms / ff = 0 135.2; 2 560: 151.6 / 133.3; 2 304: 150.6 / 132.2; **2 048: 149.3 / 131.8**; 1 792: 151.7 / 135.6; 1 536: 157.6; 1 024: 164 -- two
+    // resident sets of the size-3 table kernel (256 CUs x 4 workgroups), the rest of the list by striding (profiles/r06_cfg3_segment_grid.txt).  max_k > 3 and fz_nz: not measured, as before.
+    const unsigned grid_dflt = (c->P.kind == FW_FZ && c->P.max_k <= 3) ? std::min(seg_target + 512u, 2048u) : seg_target + 512u;
+    const unsigned grid_seg = seg_grid_env ? std::min(seg_target + 512u, seg_grid_env) : grid_dflt;
     // FW_DH_LOG=<file>: one line per planned launch (ranks, live jobs, segments) -- profiling aid, see profiles/README.md
     static const char *log_path = fw_knob("FW_DH_LOG");
     constexpr unsigned LOG_CAP = 1u << 16;
