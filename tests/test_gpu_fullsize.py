@@ -195,7 +195,8 @@ def test_cfg3_network_independent_of_schedule():
                 {"FW_DH_SPEC": "8", "FW_DH_SPEC0": "4", "FW_DH_SPEC_BELOW": "100000000000", "FW_DH_SPEC0_BELOW": "100000000000",
                  "FW_DH_SPEC0_JOBS": "100000", "FW_DH_TIME_EVERY": "1"},
                 {"FW_DH_CHAINS": "1"}, {"FW_DH_CHAINS": "3"},  # concurrent chains of device rounds (default 2)
-                {"FW_FZ_TMAT": "0"}, {"FW_FZ_TMAT": "1"}]  # r06: no local correlation matrices / one for every target (default: from 16 neighbours on)
+                {"FW_FZ_TMAT": "0"}, {"FW_FZ_TMAT": "1"},  # r06: no local correlation matrices / one for every target (default: from 16 neighbours on)
+                {"FW_SEG_GRID": "3584"}]  # r06: one workgroup per segment (default: 2 048 striding workgroups)
     seen = set()
     for s in settings:
         out = subprocess.run([sys.executable, "-c", _HASH_SNIPPET % root], env=dict(os.environ, **s), cwd=root, check=True,
